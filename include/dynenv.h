@@ -1,0 +1,164 @@
+/* dynenv.h — C ABI of the MI355X-native batched DynEnv step() (libdynenv_hip.so).
+ *
+ * Drop-in boundary for the reference's hot path.  Each entry point names the reference interface it replaces
+ * (paths relative to the reference repo root):
+ *
+ *   dynenv_create        <- DynEnv/__init__.py:6-25 make_dyn_env(...) building num_envs DrivingEnvironment /
+ *                           RoboCupEnvironment objects (DrivingEnvironment.py:20-56, RoboCupEnvironment.py:23-71)
+ *   dynenv_reset         <- DynEnv/utils/subproc_vec_env.py:118-122 SubprocVecEnv.reset ->
+ *                           DynEnv/environment_base.py:205-224 EnvironmentBase.reset
+ *   dynenv_step          <- DynEnv/utils/subproc_vec_env.py:102-111 step_async/step_wait ->
+ *                           DynEnv/DrivingEnvironment.py:248-322 / DynEnv/RoboCupEnvironment.py:446-524 step
+ *   dynenv_episode_stats <- info['episode_r'|'episode_p_r'|'episode_o_r'|'episode_g'] (DrivingEnvironment.py:310-316,
+ *                           RoboCupEnvironment.py:516-521)
+ *   dynenv_seed          <- DynEnv/environment_base.py:190-193 set_random_seed
+ *   dynenv_get/set_state <- (no reference equivalent; SURVEY §5 "checkpoint/resume" + parity tests)
+ *   dynenv_destroy       <- SubprocVecEnv.close (subproc_vec_env.py:124-133)
+ *
+ * All functions return 0 on success, <0 on error (dynenv_last_error() gives the text).  Pointers named *_dev are
+ * DEVICE pointers (HBM) owned by the caller; `stream` is a hipStream_t passed as void* (NULL = default stream).
+ * No torch types cross this boundary.  A handle is single-threaded; distinct handles are independent.
+ * There is NO CPU fallback: every entry fails with DYNENV_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef DYNENV_H
+#define DYNENV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DYNENV_ABI_VERSION 1
+
+/* DynEnvType / ObservationType / NoiseType values are the reference's (cutils.py:10-51) */
+#define DYNENV_ROBO_CUP 0
+#define DYNENV_DRIVE 1
+#define DYNENV_OBS_FULL 0
+#define DYNENV_OBS_PARTIAL 1
+#define DYNENV_NOISE_RANDOM 0
+#define DYNENV_NOISE_REALISTIC 1
+
+#define DYNENV_OK 0
+#define DYNENV_ERR_ARG (-1)
+#define DYNENV_ERR_NO_DEVICE (-2)
+#define DYNENV_ERR_HIP (-3)
+#define DYNENV_ERR_UNSUPPORTED (-4)
+#define DYNENV_ERR_ACTION (-5) /* reference raises on malformed actions, DrivingEnvironment.py:262-263,365-368 */
+
+/* RoboCup class-level switches (RoboCupEnvironment.py:18-21) */
+#define DYNENV_FLAG_RANDOM_INIT 1
+#define DYNENV_FLAG_DETERMINISTIC_TURN 2
+#define DYNENV_FLAG_CAN_FALL 4
+#define DYNENV_FLAG_USE_OBS_REWARDS 8
+#define DYNENV_FLAG_ALLOW_HEAD_TURN 16
+
+#define DYNENV_MAX_CARS 10
+#define DYNENV_MAX_PEDS 20
+#define DYNENV_MAX_OBST 20
+#define DYNENV_DRIVE_LANES 8
+
+typedef struct dynenv_cfg {
+  int32_t abi_version;    /* DYNENV_ABI_VERSION */
+  int32_t env_type;       /* DYNENV_DRIVE | DYNENV_ROBO_CUP */
+  int32_t num_envs;       /* environments owned by THIS handle (this GPU's shard) */
+  int32_t n_players;      /* nPlayers: cars (Driving, <=10) or robots per team (RoboCup, <=5) */
+  int32_t obs_type;       /* DYNENV_OBS_* */
+  int32_t noise_type;     /* DYNENV_NOISE_* */
+  double noise_magnitude; /* 0..5 */
+  uint64_t seed;
+  int32_t env_id_offset;  /* global id of local env 0: RNG streams are keyed by global id => shard-count invariant */
+  int32_t flags;          /* DYNENV_FLAG_* */
+  int32_t device_id;      /* HIP device ordinal */
+  int32_t reserved;
+} dynenv_cfg_t;
+
+/* dense, padded observation layout of one (env, time step, agent) row; all float32 */
+typedef struct dynenv_layout {
+  int32_t num_envs, n_agents, n_time_steps, obs_dim;
+  int32_t action_dim;       /* 2 Driving, 4 RoboCup */
+  int32_t n_blocks;         /* number of row blocks below */
+  int32_t block_offset[8];  /* float offset inside the obs row */
+  int32_t block_rows[8];    /* row capacity */
+  int32_t block_feat[8];    /* features per row */
+  int32_t steps_per_episode;
+  int32_t reserved;
+} dynenv_layout_t;
+
+/* Driving layout block ids: mirrors ((cars, obstacles, pedestrians), (self, lanes)) of DrivingEnvironment.py:121-124 */
+#define DYNENV_DRV_BLOCK_SELF 0
+#define DYNENV_DRV_BLOCK_CARS 1
+#define DYNENV_DRV_BLOCK_OBST 2
+#define DYNENV_DRV_BLOCK_PEDS 3
+#define DYNENV_DRV_BLOCK_LANES 4
+
+/* ---- canonical per-env state blob (checkpoint / parity tests).  set_state clears the contact cache. ---- */
+typedef struct dynenv_car_state {
+  double px, py, vx, vy, angle, w;
+  double dirx, diry, prevx, prevy, goalx, goaly;
+  int32_t type, team, finished, crashed, lane_pos, fric; /* fric: 0 friction_car, 1 friction_car_crashed */
+  int32_t pad[2];
+} dynenv_car_state_t;
+
+typedef struct dynenv_ped_state {
+  double px, py, vx, vy;
+  int32_t road, side, dead, moving, speed, crossing, begin_crossing, pad;
+} dynenv_ped_state_t;
+
+typedef struct dynenv_driving_state {
+  int32_t elapsed, all_finished, n_cars, n_peds, n_obst, episode;
+  int32_t pad[2];
+  double episode_r[DYNENV_MAX_CARS], episode_pos_r[DYNENV_MAX_CARS];
+  dynenv_car_state_t cars[DYNENV_MAX_CARS];
+  dynenv_ped_state_t peds[DYNENV_MAX_PEDS];
+  double obst_x[DYNENV_MAX_OBST], obst_y[DYNENV_MAX_OBST];
+} dynenv_driving_state_t;
+
+typedef struct dynenv dynenv_t;
+
+int dynenv_abi_version(void);
+const char* dynenv_last_error(void);
+
+int dynenv_create(const dynenv_cfg_t* cfg, dynenv_t** out);
+void dynenv_destroy(dynenv_t* h);
+int dynenv_layout(const dynenv_t* h, dynenv_layout_t* out);
+int dynenv_seed(dynenv_t* h, uint64_t seed);
+
+/* (Re)build every environment's scene and write the first observation(s): obs_dev float32 [E, T, A, obs_dim]. */
+int dynenv_reset(dynenv_t* h, float* obs_dev, void* stream);
+
+/* One environment step for all E environments (10 / 50 physics substeps fused in one launch).
+ *   actions_dev  int32 [E, A, action_dim]      obs_dev float32 [E, T, A, obs_dim]
+ *   rewards_dev  float64 [E, A]                dones_dev uint8 [E]
+ * Does NOT auto-reset: the host mirror calls dynenv_reset after a terminal step (SubprocVecEnv semantics). */
+int dynenv_step(dynenv_t* h, const int32_t* actions_dev, float* obs_dev, double* rewards_dev, uint8_t* dones_dev,
+                void* stream);
+
+/* Per-env object counts of the current episode: int32 [E, 2] = (n_obstacles, n_pedestrians) (Driving). */
+int dynenv_counts(dynenv_t* h, int32_t* counts_dev, void* stream);
+
+/* Episode accumulators: ep_r, ep_pos_r, ep_obs_r float64 [E, A]; goals int32 [E, 2]. Any pointer may be NULL. */
+int dynenv_episode_stats(dynenv_t* h, double* ep_r_dev, double* ep_pos_r_dev, double* ep_obs_r_dev,
+                         int32_t* goals_dev, void* stream);
+
+/* Copy one environment's canonical state blob to / from HOST memory (synchronous; test + checkpoint path). */
+size_t dynenv_state_size(const dynenv_t* h);
+int dynenv_get_state(dynenv_t* h, int32_t env_idx, void* host_blob, size_t nbytes);
+int dynenv_set_state(dynenv_t* h, int32_t env_idx, const void* host_blob, size_t nbytes);
+
+int dynenv_sync(dynenv_t* h, void* stream);
+
+/* Time `launches` back-to-back dynenv_step launches with HIP events on `stream` (ms total); used by bench.py for
+ * the roofline's per-launch duration. */
+int dynenv_time_steps(dynenv_t* h, const int32_t* actions_dev, float* obs_dev, double* rewards_dev,
+                      uint8_t* dones_dev, void* stream, int32_t launches, float* ms_total);
+
+/* Device self-test of the deterministic math header: evaluates sincos/atan2/sqrt/div on n host-provided doubles and
+ * returns the raw results so tests can compare them bit-for-bit with the host evaluation. out: [n,5]. */
+int dynenv_math_selftest(const double* x_host, const double* y_host, int32_t n, double* out_host, int32_t device_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DYNENV_H */

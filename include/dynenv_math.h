@@ -1,0 +1,231 @@
+/* dynenv_math.h — deterministic fp64 elementary functions + Philox4x32-10.
+ *
+ * Why this exists: the DynEnv hot path compares fp64 quantities against thresholds
+ * (`abs(x) < factor` cutils.py:123, `cos(...) < -0.4` DrivingEnvironment.py:627,660,
+ * `relAngle < 0` Road.py:95-96).  glibc's and the ROCm device library's sin/cos/atan2 differ
+ * in the last ulp, which flips those flags between host and gfx950.  Every routine here is
+ * built from IEEE-754 +,-,*,/ and sqrt only (all correctly rounded on both targets when FMA
+ * contraction is off: build with -ffp-contract=off), so the HIP kernels and the CPU oracle
+ * produce bit-identical results.  Accuracy against glibc is pinned in tests/test_detmath.py
+ * (<= 2 ulp over the ranges the environments use).
+ *
+ * Polynomials/reduction constants are the classic fdlibm (Sun, freely distributable) minimax
+ * sets for __kernel_sin/__kernel_cos/atan.
+ *
+ * Usable from C99 (gcc), C++ and HIP device code.
+ */
+#ifndef DYNENV_MATH_H
+#define DYNENV_MATH_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define DM_FN __host__ __device__ __forceinline__
+#pragma clang fp contract(off)
+#else
+#define DM_FN static inline
+#if defined(__GNUC__) && !defined(__clang__)
+#pragma GCC optimize("fp-contract=off")
+#endif
+#endif
+
+#define DM_PI 3.141592653589793
+#define DM_TWO_PI 6.283185307179586
+#define DM_PI_2 1.5707963267948966
+
+DM_FN double dm_abs(double x) { return x < 0.0 ? -x : x; } /* -0.0 -> -0.0 stays harmless */
+DM_FN double dm_min(double a, double b) { return a < b ? a : b; }
+DM_FN double dm_max(double a, double b) { return a > b ? a : b; }
+DM_FN double dm_clamp(double x, double lo, double hi) { return dm_min(dm_max(x, lo), hi); }
+
+DM_FN double dm_sqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_sqrt(x); /* f64 sqrt is correctly rounded on gfx950 (checked by tests -m gpu) */
+#else
+  return __builtin_sqrt(x);
+#endif
+}
+
+/* round-half-even to integer (v_rndne_f64 on gfx950, rint/roundsd on the host: both exact) */
+DM_FN double dm_rint(double x) { return __builtin_rint(x); }
+
+DM_FN double dm_kernel_sin(double r) {
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+               S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+               S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  double z = r * r;
+  double v = z * r;
+  double p = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+  return r + v * (S1 + z * p);
+}
+
+DM_FN double dm_kernel_cos(double r) {
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+               C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+               C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  double z = r * r;
+  double p = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+  double hz = 0.5 * z;
+  double w = 1.0 - hz;
+  return w + (((1.0 - w) - hz) + z * p);
+}
+
+/* sin and cos of x, |x| < ~1e6 rad (angles in DynEnv stay within a few hundred rad). */
+DM_FN void dm_sincos(double x, double* s, double* c) {
+  const double invpio2 = 6.36619772367581382433e-01;
+  const double pio2_1 = 1.57079632673412561417e+00;  /* first 33 bits of pi/2 */
+  const double pio2_1t = 6.07710050650619224932e-11; /* pi/2 - pio2_1 */
+  const double pio2_2 = 6.07710050630396597660e-11;  /* second 33 bits */
+  const double pio2_2t = 2.02226624879595063154e-21; /* pi/2 - pio2_1 - pio2_2 */
+  double fn = dm_rint(x * invpio2);
+  double r;
+  {
+    /* two-stage Cody-Waite (fdlibm __ieee754_rem_pio2 medium case, always taking the 2nd stage) */
+    double t = x - fn * pio2_1; /* exact product for |fn| < 2^20 */
+    double w = fn * pio2_2;
+    double r1 = t - w;
+    double w2 = fn * pio2_2t - ((t - r1) - w);
+    r = r1 - w2;
+    (void)pio2_1t;
+  }
+  int64_t n = (int64_t)fn;
+  double sr = dm_kernel_sin(r);
+  double cr = dm_kernel_cos(r);
+  switch ((int)(n & 3)) {
+    case 0: *s = sr; *c = cr; break;
+    case 1: *s = cr; *c = -sr; break;
+    case 2: *s = -sr; *c = -cr; break;
+    default: *s = -cr; *c = sr; break;
+  }
+}
+
+DM_FN double dm_sin(double x) { double s, c; dm_sincos(x, &s, &c); return s; }
+DM_FN double dm_cos(double x) { double s, c; dm_sincos(x, &s, &c); return c; }
+
+DM_FN double dm_atan(double x) {
+  const double atanhi0 = 4.63647609000806093515e-01, atanhi1 = 7.85398163397448278999e-01,
+               atanhi2 = 9.82793723247329054082e-01, atanhi3 = 1.57079632679489655800e+00;
+  const double atanlo0 = 2.26987774529616870924e-17, atanlo1 = 3.06161699786838301793e-17,
+               atanlo2 = 1.39033110312309984516e-17, atanlo3 = 6.12323399573676603587e-17;
+  const double aT0 = 3.33333333333329318027e-01, aT1 = -1.99999999998764832476e-01,
+               aT2 = 1.42857142725034663711e-01, aT3 = -1.11111104054623557880e-01,
+               aT4 = 9.09088713343650656196e-02, aT5 = -7.69187620504482999495e-02,
+               aT6 = 6.66107313738753120669e-02, aT7 = -5.83357013379057348645e-02,
+               aT8 = 4.97687799461593236017e-02, aT9 = -3.65315727442169155270e-02,
+               aT10 = 1.62858201153657823623e-02;
+  int neg = x < 0.0;
+  double ax = neg ? -x : x;
+  int id;
+  double hi = 0.0, lo = 0.0;
+  if (ax >= 1.0e300) { /* huge (incl. inf) */
+    double r = atanhi3 + atanlo3;
+    return neg ? -r : r;
+  }
+  if (ax < 0.4375) {
+    id = -1;
+    if (ax < 3.7252902984619140625e-09) return x; /* |x| < 2^-28 */
+  } else if (ax < 1.1875) {
+    if (ax < 0.6875) { id = 0; ax = (2.0 * ax - 1.0) / (2.0 + ax); hi = atanhi0; lo = atanlo0; }
+    else             { id = 1; ax = (ax - 1.0) / (ax + 1.0);       hi = atanhi1; lo = atanlo1; }
+  } else {
+    if (ax < 2.4375) { id = 2; ax = (ax - 1.5) / (1.0 + 1.5 * ax); hi = atanhi2; lo = atanlo2; }
+    else             { id = 3; ax = -1.0 / ax;                     hi = atanhi3; lo = atanlo3; }
+  }
+  double z = ax * ax;
+  double w = z * z;
+  double s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+  double s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+  if (id < 0) {
+    double r = ax - ax * (s1 + s2);
+    return neg ? -r : r;
+  }
+  {
+    double r = hi - ((ax * (s1 + s2) - lo) - ax);
+    return neg ? -r : r;
+  }
+}
+
+/* math.atan2 semantics incl. signed zeros (Road.py:315 spotDir.angle relies on atan2(-0.0,-90) == -pi) */
+DM_FN int dm_signbit(double x) {
+  union { double d; uint64_t u; } q;
+  q.d = x;
+  return (int)(q.u >> 63);
+}
+
+DM_FN double dm_atan2(double y, double x) {
+  const double pi = 3.1415926535897931160e+00, pi_lo = 1.2246467991473531772e-16;
+  if (x != x || y != y) return x + y;
+  if (y == 0.0) {
+    if (dm_signbit(x)) return dm_signbit(y) ? -pi : pi; /* atan2(+-0, -anything) = +-pi */
+    return y;                                           /* atan2(+-0, +anything) = +-0 */
+  }
+  if (x == 0.0) return dm_signbit(y) ? -DM_PI_2 : DM_PI_2;
+  {
+    double z;
+    double q = y / x;
+    double aq = dm_abs(q);
+    if (aq > 1.0e300) z = DM_PI_2;
+    else if (x < 0.0 && aq < 1.0e-300) z = 0.0;
+    else z = dm_atan(aq);
+    if (!dm_signbit(x)) return dm_signbit(y) ? -z : z;
+    /* x < 0 */
+    if (!dm_signbit(y)) return pi - (z - pi_lo);
+    return (z - pi_lo) - pi;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Philox4x32-10 counter-based RNG (Salmon et al., SC'11).  Replaces the reference's serial
+ * CPython `random` (MT19937) and NumPy legacy RandomState streams: a serial
+ * stream cannot be reproduced by thousands of environments stepping in parallel, a counter
+ * keyed by (seed, global env id | episode, purpose, entity, time) can, and is invariant to how
+ * environments are sharded over GPUs.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { uint32_t v[4]; } dm_u32x4;
+
+DM_FN dm_u32x4 dm_philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
+  int r;
+  for (r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  {
+    dm_u32x4 o;
+    o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+    return o;
+  }
+}
+
+/* uniform integer in [lo, hi] (inclusive, like random.randint) from one 32-bit word */
+DM_FN int32_t dm_randint(uint32_t u, int32_t lo, int32_t hi) {
+  uint32_t n = (uint32_t)(hi - lo + 1);
+  return lo + (int32_t)(((uint64_t)u * n) >> 32);
+}
+/* uniform double in [0,1) with 32-bit resolution (exact conversion) */
+DM_FN double dm_unit(uint32_t u) { return (double)u * 2.3283064365386962890625e-10; }
+
+/* RNG purposes (counter word c1) */
+#define DM_RNG_RESET_AGENT 1u
+#define DM_RNG_RESET_PERM 2u
+#define DM_RNG_RESET_PED 3u
+#define DM_RNG_RESET_OBST 4u
+#define DM_RNG_RESET_COUNTS 5u
+#define DM_RNG_PED_MOVE 6u
+#define DM_RNG_ROBO_RESET 7u
+#define DM_RNG_ROBO_STEP 8u
+#define DM_RNG_OBS_NOISE 9u
+
+DM_FN dm_u32x4 dm_env_rng(uint64_t seed, uint32_t genv, uint32_t episode, uint32_t purpose, uint32_t entity,
+                           uint32_t t) {
+  return dm_philox((uint32_t)seed, (uint32_t)(seed >> 32) ^ (genv * 0x9E3779B1u + 0x7F4A7C15u), episode, purpose,
+                   entity, t);
+}
+
+#endif /* DYNENV_MATH_H */

@@ -1,0 +1,765 @@
+/* cp_lite.c — ORACLE (test infrastructure; see cp_lite.h header for scope and parity status).
+ * Step order and formulas follow SURVEY.md Appendix A (Chipmunk2D 7.0.x cpSpaceStep / cpArbiter / cpCollision /
+ * cpPivotJoint / cpRotaryLimitJoint as reached from pymunk `Space.step`, DrivingEnvironment.py:278,
+ * RoboCupEnvironment.py:482). */
+#include "cp_lite.h"
+
+#include <float.h>
+#include <math.h>
+#include <string.h>
+
+#include "dynenv_math.h"
+
+static inline double cpfmax(double a, double b) { return (a > b) ? a : b; }
+static inline double cpfmin(double a, double b) { return (a < b) ? a : b; }
+static inline double cpfclamp(double f, double lo, double hi) { return cpfmin(cpfmax(f, lo), hi); }
+static inline double cpfclamp01(double f) { return cpfmax(0.0, cpfmin(f, 1.0)); }
+
+/* ---------------------------------------------------------------- bodies / shapes */
+
+void cpBodyInit(cpBody* b, double m, double i, int type) {
+  memset(b, 0, sizeof(*b));
+  b->type = type;
+  if (type == CP_BODY_STATIC) {
+    b->m = INFINITY; b->i = INFINITY; b->m_inv = 0.0; b->i_inv = 0.0;
+  } else {
+    b->m = m; b->i = i; b->m_inv = 1.0 / m; b->i_inv = 1.0 / i;
+  }
+  b->rot = cpv_(1.0, 0.0);
+}
+
+void cpBodySetAngle(cpBody* b, double a) {
+  double s, c;
+  b->a = a;
+  dm_sincos(a, &s, &c);
+  b->rot = cpv_(c, s);
+}
+
+static inline cpv xform_point(const cpBody* b, cpv p) {
+  /* cpTransformPoint with a=rot.x, c=-rot.y, b=rot.y, d=rot.x, t=p (cog = 0) */
+  return cpv_(b->rot.x * p.x - b->rot.y * p.y + b->p.x, b->rot.y * p.x + b->rot.x * p.y + b->p.y);
+}
+static inline cpv xform_vect(const cpBody* b, cpv v) {
+  return cpv_(b->rot.x * v.x - b->rot.y * v.y, b->rot.y * v.x + b->rot.x * v.y);
+}
+
+static void shape_common(cpShape* s, cpBody* body, int type, int slot) {
+  memset(s, 0, sizeof(*s));
+  s->type = type; s->body = body; s->slot = slot;
+}
+
+void cpCircleInit(cpShape* s, cpBody* body, double r, int slot) {
+  shape_common(s, body, CP_SHAPE_CIRCLE, slot);
+  s->r = r; s->c = cpv_(0.0, 0.0);
+}
+
+void cpSegmentInit(cpShape* s, cpBody* body, cpv a, cpv b, double r, int slot) {
+  cpv d; double len;
+  shape_common(s, body, CP_SHAPE_SEGMENT, slot);
+  s->sa = a; s->sb = b; s->r = r;
+  /* n = cpvrperp(cpvnormalize(b - a)) ; rperp(v) = (v.y, -v.x) */
+  d = cpvsub(b, a);
+  len = dm_sqrt(cpvdot(d, d));
+  d = cpvmult(d, 1.0 / (len + DBL_MIN));
+  s->sn = cpv_(d.y, -d.x);
+}
+
+void cpBoxInit(cpShape* s, cpBody* body, double hx, double hy, int slot) {
+  /* hull order of pymunk Poly([(h,w),(-h,w),(-h,-w),(h,-w)]): CCW starting at the min-x/min-y vertex (cpConvexHull) */
+  shape_common(s, body, CP_SHAPE_POLY, slot);
+  s->count = 4; s->r = 0.0;
+  s->local[0].v0 = cpv_(-hx, -hy); s->local[0].n = cpv_(-1.0, 0.0);
+  s->local[1].v0 = cpv_(hx, -hy);  s->local[1].n = cpv_(0.0, -1.0);
+  s->local[2].v0 = cpv_(hx, hy);   s->local[2].n = cpv_(1.0, 0.0);
+  s->local[3].v0 = cpv_(-hx, hy);  s->local[3].n = cpv_(0.0, 1.0);
+}
+
+void cpShapeCacheBB(cpShape* s) {
+  const cpBody* b = s->body;
+  if (s->type == CP_SHAPE_CIRCLE) {
+    s->tc = xform_point(b, s->c);
+    s->bb_l = s->tc.x - s->r; s->bb_b = s->tc.y - s->r; s->bb_r = s->tc.x + s->r; s->bb_t = s->tc.y + s->r;
+  } else if (s->type == CP_SHAPE_SEGMENT) {
+    double l, r, bt, t;
+    s->ta = xform_point(b, s->sa); s->tb = xform_point(b, s->sb); s->tn = xform_vect(b, s->sn);
+    if (s->ta.x < s->tb.x) { l = s->ta.x; r = s->tb.x; } else { l = s->tb.x; r = s->ta.x; }
+    if (s->ta.y < s->tb.y) { bt = s->ta.y; t = s->tb.y; } else { bt = s->tb.y; t = s->ta.y; }
+    s->bb_l = l - s->r; s->bb_b = bt - s->r; s->bb_r = r + s->r; s->bb_t = t + s->r;
+  } else {
+    double l = INFINITY, r = -INFINITY, bt = INFINITY, t = -INFINITY;
+    int i;
+    for (i = 0; i < s->count; ++i) {
+      cpv v = xform_point(b, s->local[i].v0);
+      s->world[i].v0 = v;
+      s->world[i].n = xform_vect(b, s->local[i].n);
+      l = cpfmin(l, v.x); r = cpfmax(r, v.x); bt = cpfmin(bt, v.y); t = cpfmax(t, v.y);
+    }
+    s->bb_l = l - s->r; s->bb_b = bt - s->r; s->bb_r = r + s->r; s->bb_t = t + s->r;
+  }
+}
+
+double cpMomentForBox(double m, double hx, double hy) {
+  /* cpMomentForPoly over Car.points order (Car.py:21-23) */
+  cpv verts[4];
+  double sum1 = 0.0, sum2 = 0.0;
+  int i;
+  verts[0] = cpv_(hx, hy); verts[1] = cpv_(-hx, hy); verts[2] = cpv_(-hx, -hy); verts[3] = cpv_(hx, -hy);
+  for (i = 0; i < 4; ++i) {
+    cpv v1 = verts[i], v2 = verts[(i + 1) % 4];
+    double a = cpvcross(v2, v1);
+    double b = cpvdot(v1, v1) + cpvdot(v1, v2) + cpvdot(v2, v2);
+    sum1 += a * b; sum2 += a;
+  }
+  return (m * sum1) / (6.0 * sum2);
+}
+double cpMomentForCircle(double m, double r1, double r2) { return m * (0.5 * (r1 * r1 + r2 * r2) + 0.0); }
+double cpMomentForSegment(double m, cpv a, cpv b, double r) {
+  cpv offset = cpvlerp(a, b, 0.5);
+  cpv d = cpvsub(b, a);
+  double length = dm_sqrt(cpvdot(d, d)) + 2.0 * r;
+  return m * ((length * length + 4.0 * r * r) / 12.0 + cpvlengthsq(offset));
+}
+
+/* ---------------------------------------------------------------- space bookkeeping */
+
+static int default_begin(cpArbiter* a, cpSpace* s, void* d) { (void)a; (void)s; (void)d; return 1; }
+
+void cpSpaceInit(cpSpace* s) {
+  memset(s, 0, sizeof(*s));
+  s->iterations = 10;
+  s->collisionSlop = 0.1;
+  s->collisionBias = pow((double)(1.0f - 0.1f), 60.0);
+  s->collisionPersistence = 3;
+  s->damping = 1.0;
+  s->gravity = cpv_(0.0, 0.0);
+  s->default_handler.typeA = -1; s->default_handler.typeB = -1;
+  s->default_handler.begin = default_begin;
+}
+
+void cpSpaceAddBody(cpSpace* s, cpBody* b) {
+  if (b->type != CP_BODY_DYNAMIC) return;
+  if (s->n_bodies >= CP_MAX_SHAPES) { s->overflow = 1; return; }
+  s->bodies[s->n_bodies++] = b;
+}
+
+void cpSpaceAddShape(cpSpace* s, cpShape* sh) {
+  int i;
+  if (s->n_shapes >= CP_MAX_SHAPES) { s->overflow = 1; return; }
+  cpShapeCacheBB(sh);
+  i = s->n_shapes++;
+  while (i > 0 && s->shapes[i - 1]->slot > sh->slot) { s->shapes[i] = s->shapes[i - 1]; --i; }
+  s->shapes[i] = sh;
+}
+
+void cpSpaceAddConstraint(cpSpace* s, cpConstraint* c) {
+  if (c->in_space) return;
+  if (s->n_constraints >= CP_MAX_CONSTRAINTS) { s->overflow = 1; return; }
+  s->constraints[s->n_constraints++] = c;
+  c->in_space = 1;
+}
+
+void cpSpaceRemoveConstraint(cpSpace* s, cpConstraint* c) {
+  int i, j;
+  if (!c->in_space) return;
+  for (i = 0; i < s->n_constraints; ++i) {
+    if (s->constraints[i] == c) {
+      /* Chipmunk's cpArrayDeleteObj moves the LAST element into the hole */
+      j = --s->n_constraints;
+      s->constraints[i] = s->constraints[j];
+      break;
+    }
+  }
+  c->in_space = 0;
+}
+
+cpHandler* cpSpaceAddHandler(cpSpace* s, int typeA, int typeB) {
+  cpHandler* h;
+  if (s->n_handlers >= CP_MAX_HANDLERS) { s->overflow = 1; return &s->default_handler; }
+  h = &s->handlers[s->n_handlers++];
+  memset(h, 0, sizeof(*h));
+  h->typeA = typeA; h->typeB = typeB; h->begin = default_begin;
+  return h;
+}
+
+static cpHandler* lookup_handler(cpSpace* s, int ta, int tb) {
+  int i;
+  for (i = 0; i < s->n_handlers; ++i) {
+    cpHandler* h = &s->handlers[i];
+    if ((h->typeA == ta && h->typeB == tb) || (h->typeA == tb && h->typeB == ta)) return h;
+  }
+  return &s->default_handler;
+}
+
+void cpArbiterGetShapes(const cpArbiter* arb, cpShape** a, cpShape** b) {
+  if (arb->swapped) { *a = arb->b; *b = arb->a; } else { *a = arb->a; *b = arb->b; }
+}
+
+void cpBodyUpdateVelocity(cpBody* b, cpv gravity, double damping, double dt) {
+  b->v = cpvadd(cpvmult(b->v, damping), cpvmult(cpvadd(gravity, cpvmult(b->f, b->m_inv)), dt));
+  b->w = b->w * damping + b->t * b->i_inv * dt;
+  b->f = cpv_(0.0, 0.0);
+  b->t = 0.0;
+}
+
+void cpBodyApplyForceAtWorldPoint(cpBody* b, cpv force, cpv point) {
+  cpv r = cpvsub(point, b->p); /* cog = 0 */
+  b->f = cpvadd(b->f, force);
+  b->t += cpvcross(r, force);
+}
+
+/* ---------------------------------------------------------------- narrowphase */
+
+typedef struct { cpShape *a, *b; cpv n; int count; cpv p1[2], p2[2]; uint32_t hash[2]; } cpCollisionInfo;
+
+static void push_contact(cpCollisionInfo* info, cpv p1, cpv p2, uint32_t hash) {
+  info->p1[info->count] = p1; info->p2[info->count] = p2; info->hash[info->count] = hash;
+  info->count++;
+}
+
+typedef struct { cpv p; uint32_t hash; } cpEdgePoint;
+typedef struct { cpEdgePoint a, b; double r; cpv n; } cpEdge;
+
+static int poly_support_index(const cpShape* p, cpv n) {
+  double max = -INFINITY; int index = 0, i;
+  for (i = 0; i < p->count; ++i) {
+    double d = cpvdot(p->world[i].v0, n);
+    if (d > max) { max = d; index = i; }
+  }
+  return index;
+}
+
+static cpEdge support_edge_poly(const cpShape* p, cpv n) {
+  int count = p->count;
+  int i1 = poly_support_index(p, n);
+  int i0 = (i1 - 1 + count) % count;
+  int i2 = (i1 + 1) % count;
+  uint32_t h = (uint32_t)p->slot * 4u;
+  cpEdge e;
+  if (cpvdot(n, p->world[i1].n) > cpvdot(n, p->world[i2].n)) {
+    e.a.p = p->world[i0].v0; e.a.hash = h + (uint32_t)i0;
+    e.b.p = p->world[i1].v0; e.b.hash = h + (uint32_t)i1;
+    e.r = p->r; e.n = p->world[i1].n;
+  } else {
+    e.a.p = p->world[i1].v0; e.a.hash = h + (uint32_t)i1;
+    e.b.p = p->world[i2].v0; e.b.hash = h + (uint32_t)i2;
+    e.r = p->r; e.n = p->world[i2].n;
+  }
+  return e;
+}
+
+static cpEdge support_edge_segment(const cpShape* s, cpv n) {
+  uint32_t h = (uint32_t)s->slot * 4u;
+  cpEdge e;
+  if (cpvdot(s->tn, n) > 0.0) {
+    e.a.p = s->ta; e.a.hash = h + 0u; e.b.p = s->tb; e.b.hash = h + 1u; e.r = s->r; e.n = s->tn;
+  } else {
+    e.a.p = s->tb; e.a.hash = h + 1u; e.b.p = s->ta; e.b.hash = h + 0u; e.r = s->r; e.n = cpvneg(s->tn);
+  }
+  return e;
+}
+
+static inline uint32_t hash_pair(uint32_t a, uint32_t b) { return 1u + ((a << 8) | b); }
+
+/* Chipmunk cpCollision.c ContactPoints(): clip the two support edges against each other */
+static void contact_points(cpEdge e1, cpEdge e2, cpv n, cpCollisionInfo* info) {
+  double d_e1_a = cpvcross(e1.a.p, n);
+  double d_e1_b = cpvcross(e1.b.p, n);
+  double d_e2_a = cpvcross(e2.a.p, n);
+  double d_e2_b = cpvcross(e2.b.p, n);
+  double e1_denom = 1.0 / (d_e1_b - d_e1_a + DBL_MIN);
+  double e2_denom = 1.0 / (d_e2_b - d_e2_a + DBL_MIN);
+  info->n = n;
+  {
+    cpv p1 = cpvadd(cpvmult(n, e1.r), cpvlerp(e1.a.p, e1.b.p, cpfclamp01((d_e2_b - d_e1_a) * e1_denom)));
+    cpv p2 = cpvadd(cpvmult(n, -e2.r), cpvlerp(e2.a.p, e2.b.p, cpfclamp01((d_e1_a - d_e2_a) * e2_denom)));
+    double dist = cpvdot(cpvsub(p2, p1), n);
+    if (dist <= 0.0) push_contact(info, p1, p2, hash_pair(e1.a.hash, e2.b.hash));
+  }
+  {
+    cpv p1 = cpvadd(cpvmult(n, e1.r), cpvlerp(e1.a.p, e1.b.p, cpfclamp01((d_e2_a - d_e1_a) * e1_denom)));
+    cpv p2 = cpvadd(cpvmult(n, -e2.r), cpvlerp(e2.a.p, e2.b.p, cpfclamp01((d_e1_b - d_e2_a) * e2_denom)));
+    double dist = cpvdot(cpvsub(p2, p1), n);
+    if (dist <= 0.0) push_contact(info, p1, p2, hash_pair(e1.b.hash, e2.a.hash));
+  }
+}
+
+/* max over planes of `a` of (min over verts of `b` of plane distance) */
+static double sat_max_sep(const cpShape* a, const cpShape* b, int* best) {
+  double maxsep = -INFINITY; int i, j;
+  *best = 0;
+  for (i = 0; i < a->count; ++i) {
+    cpv n = a->world[i].n;
+    double d0 = cpvdot(n, a->world[i].v0);
+    double minv = INFINITY;
+    for (j = 0; j < b->count; ++j) {
+      double d = cpvdot(n, b->world[j].v0) - d0;
+      if (d < minv) minv = d;
+    }
+    if (minv > maxsep) { maxsep = minv; *best = i; }
+  }
+  return maxsep;
+}
+
+static void poly_to_poly(cpShape* p1, cpShape* p2, cpCollisionInfo* info) {
+  int ia, ib;
+  double sa = sat_max_sep(p1, p2, &ia);
+  double sb;
+  cpv n;
+  if (sa > 0.0) return;
+  sb = sat_max_sep(p2, p1, &ib);
+  if (sb > 0.0) return;
+  if (sa >= sb) n = p1->world[ia].n; else n = cpvneg(p2->world[ib].n);
+  contact_points(support_edge_poly(p1, n), support_edge_poly(p2, cpvneg(n)), n, info);
+}
+
+static void circle_to_circle(cpShape* c1, cpShape* c2, cpCollisionInfo* info) {
+  double mindist = c1->r + c2->r;
+  cpv delta = cpvsub(c2->tc, c1->tc);
+  double distsq = cpvlengthsq(delta);
+  if (distsq < mindist * mindist) {
+    double dist = dm_sqrt(distsq);
+    cpv n = info->n = (dist != 0.0 ? cpvmult(delta, 1.0 / dist) : cpv_(1.0, 0.0));
+    push_contact(info, cpvadd(c1->tc, cpvmult(n, c1->r)), cpvadd(c2->tc, cpvmult(n, -c2->r)), 0);
+  }
+}
+
+static void circle_to_segment(cpShape* circle, cpShape* seg, cpCollisionInfo* info) {
+  cpv seg_a = seg->ta, seg_b = seg->tb, center = circle->tc;
+  cpv seg_delta = cpvsub(seg_b, seg_a);
+  double closest_t = cpfclamp01(cpvdot(seg_delta, cpvsub(center, seg_a)) / cpvlengthsq(seg_delta));
+  cpv closest = cpvadd(seg_a, cpvmult(seg_delta, closest_t));
+  double mindist = circle->r + seg->r;
+  cpv delta = cpvsub(closest, center);
+  double distsq = cpvlengthsq(delta);
+  if (distsq < mindist * mindist) {
+    double dist = dm_sqrt(distsq);
+    cpv n = info->n = (dist != 0.0 ? cpvmult(delta, 1.0 / dist) : seg->tn);
+    /* a_tangent = b_tangent = 0 (pymunk default) so the endcap rejection never fires */
+    push_contact(info, cpvadd(center, cpvmult(n, circle->r)), cpvadd(closest, cpvmult(n, -seg->r)), 0);
+  }
+}
+
+/* circle vs convex poly (radius 0): closest point on the boundary (outside) or minimum-penetration face (inside) */
+static void circle_to_poly(cpShape* circle, cpShape* poly, cpCollisionInfo* info) {
+  cpv c = circle->tc;
+  double maxsep = -INFINITY; int best = 0, i;
+  for (i = 0; i < poly->count; ++i) {
+    double d = cpvdot(poly->world[i].n, cpvsub(c, poly->world[i].v0));
+    if (d > maxsep) { maxsep = d; best = i; }
+  }
+  if (maxsep > circle->r) return; /* cheap reject: farther than r from one face plane */
+  if (maxsep <= 0.0) {
+    /* centre inside: n points from the circle into the poly = -face normal, d = maxsep (<0) */
+    cpv fn = poly->world[best].n;
+    cpv n = info->n = cpvneg(fn);
+    cpv pb = cpvsub(c, cpvmult(fn, maxsep));
+    push_contact(info, cpvadd(c, cpvmult(n, circle->r)), pb, 0);
+  } else {
+    /* centre outside: closest point over the 4 edges (edge i runs v[i-1] -> v[i]) */
+    double bestd = INFINITY; cpv bestp = c;
+    for (i = 0; i < poly->count; ++i) {
+      cpv a = poly->world[(i + poly->count - 1) % poly->count].v0, b = poly->world[i].v0;
+      cpv d = cpvsub(b, a);
+      double t = cpfclamp01(cpvdot(d, cpvsub(c, a)) / cpvlengthsq(d));
+      cpv q = cpvadd(a, cpvmult(d, t));
+      double dsq = cpvlengthsq(cpvsub(q, c));
+      if (dsq < bestd) { bestd = dsq; bestp = q; }
+    }
+    if (bestd <= circle->r * circle->r) { /* points.d - mindist <= 0 */
+      double dist = dm_sqrt(bestd);
+      cpv delta = cpvsub(bestp, c);
+      cpv n = info->n = (dist != 0.0 ? cpvmult(delta, 1.0 / dist) : cpvneg(poly->world[best].n));
+      push_contact(info, cpvadd(c, cpvmult(n, circle->r)), bestp, 0);
+    }
+  }
+}
+
+/* closest points between two segment cores (replaces GJK for capsule-capsule) */
+static void closest_seg_seg(cpv p1, cpv q1, cpv p2, cpv q2, cpv* c1, cpv* c2) {
+  cpv d1 = cpvsub(q1, p1), d2 = cpvsub(q2, p2), r = cpvsub(p1, p2);
+  double a = cpvdot(d1, d1), e = cpvdot(d2, d2), f = cpvdot(d2, r);
+  double c = cpvdot(d1, r), b = cpvdot(d1, d2);
+  double denom = a * e - b * b;
+  double s, t;
+  if (denom != 0.0) s = cpfclamp01((b * f - c * e) / denom); else s = 0.0;
+  t = (b * s + f) / e;
+  if (t < 0.0) { t = 0.0; s = cpfclamp01(-c / a); }
+  else if (t > 1.0) { t = 1.0; s = cpfclamp01((b - c) / a); }
+  *c1 = cpvadd(p1, cpvmult(d1, s));
+  *c2 = cpvadd(p2, cpvmult(d2, t));
+}
+
+static void segment_to_segment(cpShape* s1, cpShape* s2, cpCollisionInfo* info) {
+  cpv a, b, delta, n;
+  double dsq, d, mind = s1->r + s2->r;
+  closest_seg_seg(s1->ta, s1->tb, s2->ta, s2->tb, &a, &b);
+  delta = cpvsub(b, a);
+  dsq = cpvlengthsq(delta);
+  if (dsq > mind * mind) return;
+  d = dm_sqrt(dsq);
+  n = (d != 0.0 ? cpvmult(delta, 1.0 / d) : s1->tn);
+  contact_points(support_edge_segment(s1, n), support_edge_segment(s2, cpvneg(n)), n, info);
+}
+
+static void collide(cpShape* a, cpShape* b, cpCollisionInfo* info) {
+  info->a = a; info->b = b; info->count = 0; info->n = cpv_(0.0, 0.0);
+  if (a->type > b->type) { info->a = b; info->b = a; }
+  a = info->a; b = info->b;
+  if (a->type == CP_SHAPE_CIRCLE && b->type == CP_SHAPE_CIRCLE) circle_to_circle(a, b, info);
+  else if (a->type == CP_SHAPE_CIRCLE && b->type == CP_SHAPE_SEGMENT) circle_to_segment(a, b, info);
+  else if (a->type == CP_SHAPE_CIRCLE && b->type == CP_SHAPE_POLY) circle_to_poly(a, b, info);
+  else if (a->type == CP_SHAPE_SEGMENT && b->type == CP_SHAPE_SEGMENT) segment_to_segment(a, b, info);
+  else if (a->type == CP_SHAPE_POLY && b->type == CP_SHAPE_POLY) poly_to_poly(a, b, info);
+  /* segment-poly never occurs in DynEnv */
+}
+
+/* ---------------------------------------------------------------- arbiters */
+
+static cpArbiter* arbiter_find_or_create(cpSpace* s, cpShape* a, cpShape* b) {
+  int i, free_i = -1;
+  for (i = 0; i < CP_MAX_ARBITERS; ++i) {
+    cpArbiter* arb = &s->pool[i];
+    if (!arb->used) { if (free_i < 0) free_i = i; continue; }
+    if ((arb->a == a && arb->b == b) || (arb->a == b && arb->b == a)) return arb;
+  }
+  if (free_i < 0) { s->overflow = 1; return 0; }
+  {
+    cpArbiter* arb = &s->pool[free_i];
+    memset(arb, 0, sizeof(*arb));
+    arb->used = 1; arb->a = a; arb->b = b; arb->body_a = a->body; arb->body_b = b->body;
+    arb->state = CP_ARB_FIRST; arb->stamp = 0;
+    return arb;
+  }
+}
+
+static void arbiter_update(cpArbiter* arb, cpCollisionInfo* info, cpSpace* s) {
+  cpShape *a = info->a, *b = info->b;
+  cpContact fresh[2];
+  int i, j;
+  arb->a = a; arb->body_a = a->body; arb->b = b; arb->body_b = b->body;
+  for (i = 0; i < info->count; ++i) {
+    cpContact* con = &fresh[i];
+    memset(con, 0, sizeof(*con));
+    con->r1 = cpvsub(info->p1[i], a->body->p);
+    con->r2 = cpvsub(info->p2[i], b->body->p);
+    con->hash = info->hash[i];
+    con->jnAcc = con->jtAcc = 0.0;
+    for (j = 0; j < arb->count; ++j) {
+      cpContact* old = &arb->contacts[j];
+      if (con->hash == old->hash) { con->jnAcc = old->jnAcc; con->jtAcc = old->jtAcc; }
+    }
+  }
+  for (i = 0; i < info->count; ++i) arb->contacts[i] = fresh[i];
+  arb->count = info->count;
+  arb->n = info->n;
+  arb->e = a->e * b->e;
+  arb->u = a->u * b->u;
+  arb->handler = lookup_handler(s, a->collision_type, b->collision_type);
+  arb->swapped = (a->collision_type != arb->handler->typeA && arb->handler->typeA != -1);
+  if (arb->state == CP_ARB_CACHED) arb->state = CP_ARB_FIRST;
+}
+
+static void collide_shapes(cpSpace* s, cpShape* a, cpShape* b) {
+  cpCollisionInfo info;
+  cpArbiter* arb;
+  /* QueryReject */
+  if (!(a->bb_l <= b->bb_r && b->bb_l <= a->bb_r && a->bb_b <= b->bb_t && b->bb_b <= a->bb_t)) return;
+  if (a->body == b->body) return;
+  collide(a, b, &info);
+  if (info.count == 0) return;
+  arb = arbiter_find_or_create(s, info.a, info.b);
+  if (!arb) return;
+  arbiter_update(arb, &info, s);
+  if (arb->state == CP_ARB_FIRST && !arb->handler->begin(arb, s, arb->handler->data)) arb->state = CP_ARB_IGNORE;
+  if (arb->state != CP_ARB_IGNORE && !(a->body->m == INFINITY && b->body->m == INFINITY)) {
+    s->active[s->n_active++] = arb;
+  }
+  arb->stamp = s->stamp;
+}
+
+static inline double k_scalar_body(const cpBody* b, cpv r, cpv n) {
+  double rcn = cpvcross(r, n);
+  return b->m_inv + b->i_inv * rcn * rcn;
+}
+static inline cpv relative_velocity(const cpBody* a, const cpBody* b, cpv r1, cpv r2) {
+  cpv v1_sum = cpvadd(a->v, cpvmult(cpvperp(r1), a->w));
+  cpv v2_sum = cpvadd(b->v, cpvmult(cpvperp(r2), b->w));
+  return cpvsub(v2_sum, v1_sum);
+}
+static inline void apply_impulse(cpBody* b, cpv j, cpv r) {
+  b->v = cpvadd(b->v, cpvmult(j, b->m_inv));
+  b->w += b->i_inv * cpvcross(r, j);
+}
+static inline void apply_impulses(cpBody* a, cpBody* b, cpv r1, cpv r2, cpv j) {
+  apply_impulse(a, cpvneg(j), r1);
+  apply_impulse(b, j, r2);
+}
+static inline void apply_bias_impulse(cpBody* b, cpv j, cpv r) {
+  b->v_bias = cpvadd(b->v_bias, cpvmult(j, b->m_inv));
+  b->w_bias += b->i_inv * cpvcross(r, j);
+}
+
+static void arbiter_prestep(cpArbiter* arb, double dt, double slop, double bias) {
+  cpBody *a = arb->body_a, *b = arb->body_b;
+  cpv n = arb->n;
+  cpv body_delta = cpvsub(b->p, a->p);
+  int i;
+  for (i = 0; i < arb->count; ++i) {
+    cpContact* con = &arb->contacts[i];
+    double dist;
+    con->nMass = 1.0 / (k_scalar_body(a, con->r1, n) + k_scalar_body(b, con->r2, n));
+    con->tMass = 1.0 / (k_scalar_body(a, con->r1, cpvperp(n)) + k_scalar_body(b, con->r2, cpvperp(n)));
+    dist = cpvdot(cpvadd(cpvsub(con->r2, con->r1), body_delta), n);
+    con->bias = -bias * cpfmin(0.0, dist + slop) / dt;
+    con->jBias = 0.0;
+    con->bounce = cpvdot(relative_velocity(a, b, con->r1, con->r2), n) * arb->e;
+  }
+}
+
+static void arbiter_apply_cached(cpArbiter* arb, double dt_coef) {
+  int i;
+  if (arb->state == CP_ARB_FIRST) return;
+  for (i = 0; i < arb->count; ++i) {
+    cpContact* con = &arb->contacts[i];
+    cpv j = cpvrotate(arb->n, cpv_(con->jnAcc, con->jtAcc));
+    apply_impulses(arb->body_a, arb->body_b, con->r1, con->r2, cpvmult(j, dt_coef));
+  }
+}
+
+static void arbiter_apply_impulse(cpArbiter* arb) {
+  cpBody *a = arb->body_a, *b = arb->body_b;
+  cpv n = arb->n;
+  double friction = arb->u;
+  int i;
+  for (i = 0; i < arb->count; ++i) {
+    cpContact* con = &arb->contacts[i];
+    double nMass = con->nMass;
+    cpv r1 = con->r1, r2 = con->r2;
+    cpv vb1 = cpvadd(a->v_bias, cpvmult(cpvperp(r1), a->w_bias));
+    cpv vb2 = cpvadd(b->v_bias, cpvmult(cpvperp(r2), b->w_bias));
+    cpv vr = relative_velocity(a, b, r1, r2); /* surface_vr = 0 */
+    double vbn = cpvdot(cpvsub(vb2, vb1), n);
+    double vrn = cpvdot(vr, n);
+    double vrt = cpvdot(vr, cpvperp(n));
+    double jbn = (con->bias - vbn) * nMass;
+    double jbnOld = con->jBias;
+    double jn, jnOld, jtMax, jt, jtOld;
+    con->jBias = cpfmax(jbnOld + jbn, 0.0);
+    jn = -(con->bounce + vrn) * nMass;
+    jnOld = con->jnAcc;
+    con->jnAcc = cpfmax(jnOld + jn, 0.0);
+    jtMax = friction * con->jnAcc;
+    jt = -vrt * con->tMass;
+    jtOld = con->jtAcc;
+    con->jtAcc = cpfclamp(jtOld + jt, -jtMax, jtMax);
+    {
+      cpv jb = cpvmult(n, con->jBias - jbnOld);
+      apply_bias_impulse(a, cpvneg(jb), r1);
+      apply_bias_impulse(b, jb, r2);
+    }
+    apply_impulses(a, b, r1, r2, cpvrotate(n, cpv_(con->jnAcc - jnOld, con->jtAcc - jtOld)));
+  }
+}
+
+/* ---------------------------------------------------------------- constraints */
+
+static const double CP_DEFAULT_ERROR_BIAS_BASE = (double)(1.0f - 0.1f);
+
+void cpPivotJointInit(cpConstraint* c, cpBody* a, cpBody* b, cpv pivot) {
+  memset(c, 0, sizeof(*c));
+  c->type = CP_JOINT_PIVOT; c->a = a; c->b = b;
+  c->errorBias = pow(CP_DEFAULT_ERROR_BIAS_BASE, 60.0);
+  /* cpBodyWorldToLocal = inverse rigid transform */
+  {
+    cpv da = cpvsub(pivot, a->p), db = cpvsub(pivot, b->p);
+    c->anchorA = cpv_(a->rot.x * da.x + a->rot.y * da.y, -a->rot.y * da.x + a->rot.x * da.y);
+    c->anchorB = cpv_(b->rot.x * db.x + b->rot.y * db.y, -b->rot.y * db.x + b->rot.x * db.y);
+  }
+}
+
+void cpRotaryLimitJointInit(cpConstraint* c, cpBody* a, cpBody* b, double mn, double mx) {
+  memset(c, 0, sizeof(*c));
+  c->type = CP_JOINT_ROTARY_LIMIT; c->a = a; c->b = b; c->min = mn; c->max = mx;
+  c->errorBias = pow(CP_DEFAULT_ERROR_BIAS_BASE, 60.0);
+}
+
+static void constraint_prestep(cpConstraint* c, double dt) {
+  cpBody *a = c->a, *b = c->b;
+  double coef = 1.0 - pow(c->errorBias, dt);
+  if (c->type == CP_JOINT_PIVOT) {
+    double m_sum, k11, k12, k21, k22, det, det_inv;
+    cpv delta;
+    c->r1 = xform_vect(a, c->anchorA);
+    c->r2 = xform_vect(b, c->anchorB);
+    m_sum = a->m_inv + b->m_inv;
+    k11 = m_sum; k12 = 0.0; k21 = 0.0; k22 = m_sum;
+    {
+      double r1xsq = c->r1.x * c->r1.x * a->i_inv, r1ysq = c->r1.y * c->r1.y * a->i_inv;
+      double r1nxy = -c->r1.x * c->r1.y * a->i_inv;
+      k11 += r1ysq; k12 += r1nxy; k21 += r1nxy; k22 += r1xsq;
+    }
+    {
+      double r2xsq = c->r2.x * c->r2.x * b->i_inv, r2ysq = c->r2.y * c->r2.y * b->i_inv;
+      double r2nxy = -c->r2.x * c->r2.y * b->i_inv;
+      k11 += r2ysq; k12 += r2nxy; k21 += r2nxy; k22 += r2xsq;
+    }
+    det = k11 * k22 - k12 * k21;
+    det_inv = 1.0 / det;
+    c->k[0] = k22 * det_inv; c->k[1] = -k12 * det_inv; c->k[2] = -k21 * det_inv; c->k[3] = k11 * det_inv;
+    delta = cpvsub(cpvadd(b->p, c->r2), cpvadd(a->p, c->r1));
+    c->bias2 = cpvmult(delta, -coef / dt); /* maxBias = INFINITY: no clamp */
+  } else {
+    double dist = b->a - a->a, pdist = 0.0;
+    if (dist > c->max) pdist = c->max - dist; else if (dist < c->min) pdist = c->min - dist;
+    c->iSum = 1.0 / (a->i_inv + b->i_inv);
+    c->bias = -coef * pdist / dt;
+    if (c->bias == 0.0) c->jAcc = 0.0;
+  }
+}
+
+static void constraint_apply_cached(cpConstraint* c, double dt_coef) {
+  if (c->type == CP_JOINT_PIVOT) {
+    apply_impulses(c->a, c->b, c->r1, c->r2, cpvmult(c->jAcc2, dt_coef));
+  } else {
+    double j = c->jAcc * dt_coef;
+    c->a->w -= j * c->a->i_inv;
+    c->b->w += j * c->b->i_inv;
+  }
+}
+
+static void constraint_apply_impulse(cpConstraint* c, double dt) {
+  cpBody *a = c->a, *b = c->b;
+  (void)dt;
+  if (c->type == CP_JOINT_PIVOT) {
+    cpv vr = relative_velocity(a, b, c->r1, c->r2);
+    cpv d = cpvsub(c->bias2, vr);
+    cpv j = cpv_(d.x * c->k[0] + d.y * c->k[1], d.x * c->k[2] + d.y * c->k[3]);
+    cpv jOld = c->jAcc2;
+    c->jAcc2 = cpvadd(c->jAcc2, j); /* maxForce = INFINITY: no clamp */
+    j = cpvsub(c->jAcc2, jOld);
+    apply_impulses(a, b, c->r1, c->r2, j);
+  } else {
+    double wr, j, jOld;
+    if (c->bias == 0.0) return;
+    wr = b->w - a->w;
+    j = -(c->bias + wr) * c->iSum;
+    jOld = c->jAcc;
+    if (c->bias < 0.0) c->jAcc = cpfmax(jOld + j, 0.0); else c->jAcc = cpfmin(jOld + j, 0.0);
+    j = c->jAcc - jOld;
+    a->w -= j * a->i_inv;
+    b->w += j * b->i_inv;
+  }
+}
+
+/* ---------------------------------------------------------------- step */
+
+static int pair_key(const cpArbiter* arb) {
+  int sa = arb->a->slot, sb = arb->b->slot;
+  return sa < sb ? sa * 64 + sb : sb * 64 + sa;
+}
+
+void cpSpaceStep(cpSpace* s, double dt) {
+  int i, j, it;
+  double prev_dt;
+  if (dt == 0.0) return;
+  s->stamp++;
+  prev_dt = s->curr_dt;
+  s->curr_dt = dt;
+  for (i = 0; i < s->n_active; ++i) s->active[i]->state = CP_ARB_NORMAL;
+  s->n_active = 0;
+
+  /* integrate positions (cpBodyUpdatePosition) */
+  for (i = 0; i < s->n_bodies; ++i) {
+    cpBody* b = s->bodies[i];
+    b->p = cpvadd(b->p, cpvmult(cpvadd(b->v, b->v_bias), dt));
+    cpBodySetAngle(b, b->a + (b->w + b->w_bias) * dt);
+    b->v_bias = cpv_(0.0, 0.0);
+    b->w_bias = 0.0;
+  }
+  /* refresh world geometry of dynamic shapes, then collide all pairs in canonical slot order */
+  for (i = 0; i < s->n_shapes; ++i)
+    if (s->shapes[i]->body->type == CP_BODY_DYNAMIC) cpShapeCacheBB(s->shapes[i]);
+  for (i = 0; i < s->n_shapes; ++i) {
+    for (j = i + 1; j < s->n_shapes; ++j) {
+      cpShape *a = s->shapes[i], *b = s->shapes[j];
+      if (a->body->type != CP_BODY_DYNAMIC && b->body->type != CP_BODY_DYNAMIC) continue;
+      collide_shapes(s, a, b);
+    }
+  }
+  /* cpSpaceArbiterSetFilter in canonical pair order: separate callbacks + expiry */
+  {
+    int order[CP_MAX_ARBITERS], n = 0, k;
+    for (i = 0; i < CP_MAX_ARBITERS; ++i)
+      if (s->pool[i].used) {
+        int key = pair_key(&s->pool[i]);
+        k = n++;
+        while (k > 0 && pair_key(&s->pool[order[k - 1]]) > key) { order[k] = order[k - 1]; --k; }
+        order[k] = i;
+      }
+    for (k = 0; k < n; ++k) {
+      cpArbiter* arb = &s->pool[order[k]];
+      int ticks = s->stamp - arb->stamp;
+      if (ticks >= 1 && arb->state != CP_ARB_CACHED) {
+        arb->state = CP_ARB_CACHED;
+        if (arb->handler && arb->handler->separate) arb->handler->separate(arb, s, arb->handler->data);
+      }
+      if (ticks >= s->collisionPersistence) arb->used = 0;
+    }
+  }
+  /* prestep */
+  {
+    double slop = s->collisionSlop;
+    double biasCoef = 1.0 - pow(s->collisionBias, dt);
+    for (i = 0; i < s->n_active; ++i) arbiter_prestep(s->active[i], dt, slop, biasCoef);
+    for (i = 0; i < s->n_constraints; ++i) constraint_prestep(s->constraints[i], dt);
+  }
+  /* integrate velocities */
+  {
+    double damping = pow(s->damping, dt);
+    for (i = 0; i < s->n_bodies; ++i) {
+      cpBody* b = s->bodies[i];
+      if (b->velocity_func) b->velocity_func(b, s->gravity, damping, dt);
+      else cpBodyUpdateVelocity(b, s->gravity, damping, dt);
+    }
+  }
+  /* warm start */
+  {
+    double dt_coef = (prev_dt == 0.0 ? 0.0 : dt / prev_dt);
+    for (i = 0; i < s->n_active; ++i) arbiter_apply_cached(s->active[i], dt_coef);
+    for (i = 0; i < s->n_constraints; ++i) constraint_apply_cached(s->constraints[i], dt_coef);
+  }
+  /* sequential impulses */
+  for (it = 0; it < s->iterations; ++it) {
+    for (j = 0; j < s->n_active; ++j) arbiter_apply_impulse(s->active[j]);
+    for (j = 0; j < s->n_constraints; ++j) constraint_apply_impulse(s->constraints[j], dt);
+  }
+  /* post-solve callbacks */
+  for (i = 0; i < s->n_active; ++i) {
+    cpArbiter* arb = s->active[i];
+    if (arb->handler->post_solve) arb->handler->post_solve(arb, s, arb->handler->data);
+  }
+}
+
+/* ---------------------------------------------------------------- queries */
+
+int cpSpacePointQuery(cpSpace* s, cpv p, double maxDist, cpShape** out, int cap) {
+  int i, n = 0;
+  for (i = 0; i < s->n_shapes; ++i) {
+    cpShape* sh = s->shapes[i];
+    double d;
+    if (sh->type == CP_SHAPE_CIRCLE) {
+      cpv delta = cpvsub(p, sh->tc);
+      d = dm_sqrt(cpvdot(delta, delta)) - sh->r;
+    } else if (sh->type == CP_SHAPE_SEGMENT) {
+      cpv seg_delta = cpvsub(sh->tb, sh->ta);
+      double t = cpfclamp01(cpvdot(seg_delta, cpvsub(p, sh->ta)) / cpvlengthsq(seg_delta));
+      cpv closest = cpvadd(sh->ta, cpvmult(seg_delta, t));
+      cpv delta = cpvsub(p, closest);
+      d = dm_sqrt(cpvdot(delta, delta)) - sh->r;
+    } else {
+      continue; /* polys are never queried in DynEnv (RoboCup has none) */
+    }
+    if (d < maxDist && n < cap) out[n++] = sh;
+  }
+  return n;
+}

@@ -1,0 +1,194 @@
+/* oracle_api.c — ORACLE (test infrastructure): host-pointer C API mirroring include/dynenv.h so that tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg can drive the CPU restatement exactly like the HIP
+ * library.  Nothing in dynenv_amd/ may load this. */
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "driving.h"
+#include "dynenv.h"
+#include "dynenv_math.h"
+
+typedef struct oracle {
+  dynenv_cfg_t cfg;
+  int n_agents, obs_dim, n_time_steps, action_dim;
+  DrivingEnv* drv;
+  int threads;
+} oracle_t;
+
+int oracle_create(const dynenv_cfg_t* cfg, oracle_t** out) {
+  oracle_t* o;
+  int i;
+  if (!cfg || !out || cfg->num_envs <= 0) return DYNENV_ERR_ARG;
+  o = (oracle_t*)calloc(1, sizeof(*o));
+  o->cfg = *cfg;
+  o->threads = 1;
+  if (cfg->env_type == DYNENV_DRIVE) {
+    if (cfg->obs_type != DYNENV_OBS_FULL) { free(o); return DYNENV_ERR_UNSUPPORTED; }
+    o->n_agents = cfg->n_players > DYNENV_MAX_CARS ? DYNENV_MAX_CARS : cfg->n_players;
+    o->obs_dim = drv_obs_dim(o->n_agents);
+    o->n_time_steps = 1;
+    o->action_dim = 2;
+    o->drv = (DrivingEnv*)calloc((size_t)cfg->num_envs, sizeof(DrivingEnv));
+    for (i = 0; i < cfg->num_envs; ++i) drv_init(&o->drv[i], cfg->n_players, cfg->seed, (uint32_t)(cfg->env_id_offset + i));
+  } else {
+    free(o);
+    return DYNENV_ERR_UNSUPPORTED;
+  }
+  *out = o;
+  return DYNENV_OK;
+}
+
+void oracle_destroy(oracle_t* o) {
+  if (!o) return;
+  free(o->drv);
+  free(o);
+}
+
+void oracle_set_threads(oracle_t* o, int n) { o->threads = n > 0 ? n : 1; }
+
+int oracle_layout(const oracle_t* o, dynenv_layout_t* L) {
+  int A = o->n_agents;
+  memset(L, 0, sizeof(*L));
+  L->num_envs = o->cfg.num_envs; L->n_agents = A; L->n_time_steps = o->n_time_steps; L->obs_dim = o->obs_dim;
+  L->action_dim = o->action_dim;
+  if (o->cfg.env_type == DYNENV_DRIVE) {
+    L->n_blocks = 5;
+    L->block_offset[0] = 0; L->block_rows[0] = 1; L->block_feat[0] = 9;
+    L->block_offset[1] = 9; L->block_rows[1] = A - 1; L->block_feat[1] = 7;
+    L->block_offset[2] = 9 + (A - 1) * 7; L->block_rows[2] = DYNENV_MAX_OBST; L->block_feat[2] = 4;
+    L->block_offset[3] = L->block_offset[2] + DYNENV_MAX_OBST * 4; L->block_rows[3] = DYNENV_MAX_PEDS; L->block_feat[3] = 2;
+    L->block_offset[4] = L->block_offset[3] + DYNENV_MAX_PEDS * 2; L->block_rows[4] = DYNENV_DRIVE_LANES; L->block_feat[4] = 5;
+    L->steps_per_episode = DRV_MAX_TIME / DRV_STEP_ITER;
+  }
+  return DYNENV_OK;
+}
+
+int oracle_reset(oracle_t* o, float* obs) {
+  int e, E = o->cfg.num_envs;
+  size_t stride = (size_t)o->n_time_steps * o->n_agents * o->obs_dim;
+#pragma omp parallel for schedule(static) num_threads(o->threads)
+  for (e = 0; e < E; ++e) {
+    drv_reset(&o->drv[e]);
+    if (obs) drv_write_full_obs(&o->drv[e], obs + e * stride);
+  }
+  return DYNENV_OK;
+}
+
+int oracle_step(oracle_t* o, const int32_t* actions, float* obs, double* rewards, uint8_t* dones) {
+  int e, E = o->cfg.num_envs, A = o->n_agents;
+  size_t stride = (size_t)o->n_time_steps * A * o->obs_dim;
+#pragma omp parallel for schedule(static) num_threads(o->threads)
+  for (e = 0; e < E; ++e) {
+    int d = drv_step(&o->drv[e], actions + (size_t)e * A * 2, obs ? obs + e * stride : 0, rewards + (size_t)e * A);
+    dones[e] = (uint8_t)d;
+  }
+  return DYNENV_OK;
+}
+
+int oracle_counts(oracle_t* o, int32_t* counts) {
+  int e;
+  for (e = 0; e < o->cfg.num_envs; ++e) { counts[2 * e] = o->drv[e].nObst; counts[2 * e + 1] = o->drv[e].nPeds; }
+  return DYNENV_OK;
+}
+
+int oracle_episode_stats(oracle_t* o, double* ep_r, double* ep_pos_r, double* ep_obs_r, int32_t* goals) {
+  int e, a, A = o->n_agents;
+  for (e = 0; e < o->cfg.num_envs; ++e) {
+    const DrivingEnv* d = &o->drv[e];
+    int fin = 0, crashed = 0;
+    for (a = 0; a < A; ++a) {
+      if (ep_r) ep_r[e * A + a] = d->episodeRewards[a];
+      if (ep_pos_r) ep_pos_r[e * A + a] = d->episodePosRewards[a];
+      if (ep_obs_r) ep_obs_r[e * A + a] = 0.0; /* DrivingEnvironment.py:314 */
+      fin += d->cars[a].finished && !d->cars[a].crashed;
+      crashed += d->cars[a].crashed;
+    }
+    if (goals) { goals[2 * e] = fin; goals[2 * e + 1] = crashed; } /* :315-316 */
+  }
+  return DYNENV_OK;
+}
+
+size_t oracle_state_size(const oracle_t* o) { (void)o; return sizeof(dynenv_driving_state_t); }
+int oracle_get_state(oracle_t* o, int32_t env, void* blob, size_t n) {
+  if (env < 0 || env >= o->cfg.num_envs || n < sizeof(dynenv_driving_state_t)) return DYNENV_ERR_ARG;
+  drv_get_state(&o->drv[env], (dynenv_driving_state_t*)blob);
+  return DYNENV_OK;
+}
+int oracle_set_state(oracle_t* o, int32_t env, const void* blob, size_t n) {
+  if (env < 0 || env >= o->cfg.num_envs || n < sizeof(dynenv_driving_state_t)) return DYNENV_ERR_ARG;
+  drv_set_state(&o->drv[env], (const dynenv_driving_state_t*)blob);
+  return DYNENV_OK;
+}
+int oracle_overflow(oracle_t* o) {
+  int e, f = 0;
+  for (e = 0; e < o->cfg.num_envs; ++e) f |= o->drv[e].space.overflow;
+  return f;
+}
+int oracle_active_contacts(oracle_t* o, int32_t env) { return o->drv[env].space.n_active; }
+
+/* ---- unit entry points for the golden tests (tests/test_oracle_golden.py) ---- */
+void oracle_math(const double* x, const double* y, int n, double* out) {
+  int i;
+  for (i = 0; i < n; ++i) {
+    double s, c;
+    dm_sincos(x[i], &s, &c);
+    out[5 * i + 0] = s; out[5 * i + 1] = c; out[5 * i + 2] = dm_atan2(y[i], x[i]);
+    out[5 * i + 3] = dm_sqrt(dm_abs(x[i])); out[5 * i + 4] = (y[i] != 0.0) ? x[i] / y[i] : 0.0;
+  }
+}
+void oracle_philox(uint32_t k0, uint32_t k1, const uint32_t* ctr, uint32_t* out) {
+  dm_u32x4 r = dm_philox(k0, k1, ctr[0], ctr[1], ctr[2], ctr[3]);
+  memcpy(out, r.v, 16);
+}
+void oracle_apply_friction(double m, double* vxyw, double friction, double rotFriction, double spin) {
+  cpBody b;
+  cpBodyInit(&b, m, 1.0, CP_BODY_DYNAMIC);
+  b.v = cpv_(vxyw[0], vxyw[1]); b.w = vxyw[2];
+  apply_friction(&b, cpv_(0.0, 0.0), 1.0, 0.01, friction, rotFriction, spin);
+  vxyw[0] = b.v.x; vxyw[1] = b.v.y; vxyw[2] = b.w;
+}
+int oracle_road_is_point_on_road(int road, double x, double y, double angle) {
+  DrivingEnv e;
+  drv_init(&e, 2, 0, 0);
+  return road_is_point_on_road(&e.roads[road], cpv_(x, y), angle);
+}
+void oracle_road_geometry(int road, double* out /* dir2 normal2 length dirAngle lanes[5][4] walk[2][4] */) {
+  DrivingEnv e; const Road* r; int i, k = 0;
+  drv_init(&e, 2, 0, 0);
+  r = &e.roads[road];
+  out[k++] = r->dir.x; out[k++] = r->dir.y; out[k++] = r->normal.x; out[k++] = r->normal.y;
+  out[k++] = r->length; out[k++] = r->dirAngle;
+  for (i = 0; i < 5; ++i) { out[k++] = r->lanes[i][0].x; out[k++] = r->lanes[i][0].y; out[k++] = r->lanes[i][1].x; out[k++] = r->lanes[i][1].y; }
+  for (i = 0; i < 2; ++i) { out[k++] = r->walk[i][0].x; out[k++] = r->walk[i][0].y; out[k++] = r->walk[i][1].x; out[k++] = r->walk[i][1].y; }
+}
+void oracle_road_get_spot(int road, int lane, int spot, double* out3) {
+  DrivingEnv e; cpv p; double a;
+  drv_init(&e, 2, 0, 0);
+  road_get_spot(&e.roads[road], lane, spot, &p, &a);
+  out3[0] = p.x; out3[1] = p.y; out3[2] = a;
+}
+void oracle_road_get_walk_spot(int road, int side, double length, double width, double* out2) {
+  DrivingEnv e; cpv p;
+  drv_init(&e, 2, 0, 0);
+  p = road_get_walk_spot(&e.roads[road], side, length, width);
+  out2[0] = p.x; out2[1] = p.y;
+}
+/* run single game-logic functions on env `env` (state injected through oracle_set_state) */
+void oracle_drv_process_action(oracle_t* o, int env, int car, const int32_t* action) { drv_process_action(&o->drv[env], car, action); }
+double oracle_drv_tick(oracle_t* o, int env, int car) {
+  DrivingEnv* e = &o->drv[env];
+  e->carRewards[car] = 0.0; e->carPosRewards[car] = 0.0;
+  drv_tick(e, car);
+  return e->carRewards[car];
+}
+double oracle_drv_pos_reward(oracle_t* o, int env, int car) { return o->drv[env].carPosRewards[car]; }
+void oracle_drv_move(oracle_t* o, int env, int ped) { drv_move(&o->drv[env], ped); }
+void oracle_drv_lane_rows(oracle_t* o, float* out40) { memcpy(out40, o->drv[0].laneRows, sizeof(o->drv[0].laneRows)); }
+double oracle_moment_for_box(double m, double hx, double hy) { return cpMomentForBox(m, hx, hy); }
+double oracle_moment_for_circle(double m, double r1, double r2) { return cpMomentForCircle(m, r1, r2); }
+double oracle_moment_for_segment(double m, double ax, double ay, double bx, double by, double r) {
+  return cpMomentForSegment(m, cpv_(ax, ay), cpv_(bx, by), r);
+}
