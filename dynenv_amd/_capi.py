@@ -1,0 +1,98 @@
+"""ctypes binding of include/dynenv.h (libdynenv_hip.so).  No fallback: a missing library or GPU raises."""
+import ctypes as C
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libdynenv_hip.so")
+
+DYNENV_ABI_VERSION = 1
+ERR_NO_DEVICE = -2
+
+
+class DynEnvError(RuntimeError):
+    pass
+
+
+class Cfg(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("env_type", C.c_int32), ("num_envs", C.c_int32),
+                ("n_players", C.c_int32), ("obs_type", C.c_int32), ("noise_type", C.c_int32),
+                ("noise_magnitude", C.c_double), ("seed", C.c_uint64), ("env_id_offset", C.c_int32),
+                ("flags", C.c_int32), ("device_id", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Layout(C.Structure):
+    _fields_ = [("num_envs", C.c_int32), ("n_agents", C.c_int32), ("n_time_steps", C.c_int32),
+                ("obs_dim", C.c_int32), ("action_dim", C.c_int32), ("n_blocks", C.c_int32),
+                ("block_offset", C.c_int32 * 8), ("block_rows", C.c_int32 * 8), ("block_feat", C.c_int32 * 8),
+                ("steps_per_episode", C.c_int32), ("reserved", C.c_int32)]
+
+
+CAR_F = ("px", "py", "vx", "vy", "angle", "w", "dirx", "diry", "prevx", "prevy", "goalx", "goaly")
+CAR_I = ("type", "team", "finished", "crashed", "lane_pos", "fric")
+PED_F = ("px", "py", "vx", "vy")
+PED_I = ("road", "side", "dead", "moving", "speed", "crossing", "begin_crossing")
+
+
+class CarState(C.Structure):
+    _fields_ = [(n, C.c_double) for n in CAR_F] + [(n, C.c_int32) for n in CAR_I] + [("pad", C.c_int32 * 2)]
+
+
+class PedState(C.Structure):
+    _fields_ = [(n, C.c_double) for n in PED_F] + [(n, C.c_int32) for n in PED_I] + [("pad", C.c_int32)]
+
+
+class DrivingState(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("elapsed", "all_finished", "n_cars", "n_peds", "n_obst", "episode")] + \
+               [("pad", C.c_int32 * 2), ("episode_r", C.c_double * 10), ("episode_pos_r", C.c_double * 10),
+                ("cars", CarState * 10), ("peds", PedState * 20), ("obst_x", C.c_double * 20),
+                ("obst_y", C.c_double * 20)]
+
+
+EXPORTS = ["dynenv_abi_version", "dynenv_last_error", "dynenv_create", "dynenv_destroy", "dynenv_layout",
+           "dynenv_seed", "dynenv_reset", "dynenv_step", "dynenv_counts", "dynenv_episode_stats",
+           "dynenv_state_size", "dynenv_get_state", "dynenv_set_state", "dynenv_sync", "dynenv_math_selftest",
+           "dynenv_error_flags"]
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raises if it has not been built (there is no Python/CPU substitute)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DynEnvError("libdynenv_hip.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(dynenv_amd has no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise DynEnvError("libdynenv_hip.so does not export " + name)
+    lib.dynenv_last_error.restype = C.c_char_p
+    lib.dynenv_state_size.restype = C.c_size_t
+    vp = C.c_void_p
+    lib.dynenv_create.argtypes = [C.POINTER(Cfg), C.POINTER(vp)]
+    lib.dynenv_destroy.argtypes = [vp]
+    lib.dynenv_destroy.restype = None
+    lib.dynenv_layout.argtypes = [vp, C.POINTER(Layout)]
+    lib.dynenv_seed.argtypes = [vp, C.c_uint64]
+    lib.dynenv_reset.argtypes = [vp, vp, vp]
+    lib.dynenv_step.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.dynenv_counts.argtypes = [vp, vp, vp]
+    lib.dynenv_episode_stats.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.dynenv_state_size.argtypes = [vp]
+    lib.dynenv_get_state.argtypes = [vp, C.c_int32, vp, C.c_size_t]
+    lib.dynenv_set_state.argtypes = [vp, C.c_int32, vp, C.c_size_t]
+    lib.dynenv_sync.argtypes = [vp, vp]
+    lib.dynenv_math_selftest.argtypes = [vp, vp, C.c_int32, vp, C.c_int32]
+    lib.dynenv_error_flags.argtypes = [vp, C.POINTER(C.c_int32)]
+    if lib.dynenv_abi_version() != DYNENV_ABI_VERSION:
+        raise DynEnvError("ABI version mismatch between dynenv_amd and libdynenv_hip.so")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().dynenv_last_error().decode("utf-8", "replace")
+        raise DynEnvError("%s failed (%d): %s" % (what, rc, msg))

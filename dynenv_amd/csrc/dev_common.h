@@ -1,0 +1,67 @@
+// dev_common.h — shared device helpers for the gfx950 kernels (wave64, one environment per wavefront).
+// No compatibility layers: this is CDNA4-only code (64-wide ballots, v_readlane, LDS tiles).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dynenv_math.h"
+
+#define DE_WAVE 64
+#define DE_DEV __device__ __forceinline__
+#define DE_HD __host__ __device__ __forceinline__
+
+struct V2 {
+  double x, y;
+};
+DE_HD V2 v2(double x, double y) { V2 r; r.x = x; r.y = y; return r; }
+DE_HD V2 vadd(V2 a, V2 b) { return v2(a.x + b.x, a.y + b.y); }
+DE_HD V2 vsub(V2 a, V2 b) { return v2(a.x - b.x, a.y - b.y); }
+DE_HD V2 vneg(V2 a) { return v2(-a.x, -a.y); }
+DE_HD V2 vmul(V2 a, double s) { return v2(a.x * s, a.y * s); }
+DE_HD double vdot(V2 a, V2 b) { return a.x * b.x + a.y * b.y; }
+DE_HD double vcross(V2 a, V2 b) { return a.x * b.y - a.y * b.x; }
+DE_HD V2 vperp(V2 a) { return v2(-a.y, a.x); }
+DE_HD V2 vrotate(V2 a, V2 b) { return v2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+DE_HD double vlensq(V2 a) { return vdot(a, a); }
+DE_HD V2 vlerp(V2 a, V2 b, double t) { return vadd(vmul(a, 1.0 - t), vmul(b, t)); }
+DE_HD double vlen(V2 v) { return dm_sqrt(v.x * v.x + v.y * v.y); }  // Vec2d.length
+DE_HD V2 vrot_angle(V2 v, double a) {                                // Vec2d.rotate(angle)
+  double s, c;
+  dm_sincos(a, &s, &c);
+  return v2(v.x * c - v.y * s, v.x * s + v.y * c);
+}
+DE_HD double fmax_cp(double a, double b) { return (a > b) ? a : b; }
+DE_HD double fmin_cp(double a, double b) { return (a < b) ? a : b; }
+DE_HD double fclamp_cp(double f, double lo, double hi) { return fmin_cp(fmax_cp(f, lo), hi); }
+DE_HD double fclamp01_cp(double f) { return fmax_cp(0.0, fmin_cp(f, 1.0)); }
+
+// ---- wave64 cross-lane helpers -------------------------------------------------------------
+DE_DEV uint64_t wave_ballot(bool p) { return __ballot(p); }
+DE_DEV int lane_id() { return (int)(threadIdx.x & 63); }
+DE_DEV uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+// broadcast from a wave-uniform lane index (v_readlane_b32 pairs for doubles)
+DE_DEV int bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src)); }
+DE_DEV double bcast_d(double v, int src) {
+  union { double d; int i[2]; } u;
+  u.d = v;
+  src = __builtin_amdgcn_readfirstlane(src);
+  u.i[0] = __builtin_amdgcn_readlane(u.i[0], src);
+  u.i[1] = __builtin_amdgcn_readlane(u.i[1], src);
+  return u.d;
+}
+DE_DEV int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+DE_DEV uint64_t uniform_u64(uint64_t v) {
+  uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+
+#define DE_DBL_MIN 2.2250738585072014e-308
+// Chipmunk space defaults reached through pymunk.Space() (environment_base.py:126-128); values pinned against
+// libm pow() by tests/test_constants.py
+#define DE_COLLISION_SLOP 0.1
+#define DE_CONTACT_BIAS_COEF 0.061259621561307376 /* 1 - pow(pow(1-0.1f,60), 0.01) */
+#define DE_PIVOT_BIAS_COEF 0.022762779044189331   /* 1 - pow(0.1, 0.01)  (Robot.py:59 error_bias=0.1) */
+#define DE_JOINT_BIAS_COEF DE_CONTACT_BIAS_COEF   /* default errorBias = pow(1-0.1f,60) */
+#define DE_DT 0.01

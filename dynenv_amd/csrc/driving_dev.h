@@ -1,0 +1,78 @@
+// driving_dev.h — device-side data layout of the batched Driving environment (HBM SoA + LDS tile).
+//
+// Mapping: ONE WAVEFRONT (64 lanes) PER ENVIRONMENT.  Lane l doubles as
+//   * the owner of dynamic body l          (cars 0..9, pedestrians 10..29)        -> body state lives in VGPRs
+//   * the detector of collision pairs {l, 64+l, ..., 448+l} of the 485 canonical pairs (8 rounds)
+//   * the owner of contact-cache slot l    (l < DRV_NS persistent arbiters)        -> impulses live in VGPRs
+// HBM layout is field-major with the 32 body slots of one env contiguous (`field[e][32]`), so a wave's load of one
+// field is a single 256-byte coalesced segment.
+#pragma once
+#include "dev_common.h"
+
+#define DRV_MAXA 10
+#define DRV_MAXP 20
+#define DRV_MAXO 20
+#define DRV_NB 32          /* dynamic body slots per env (30 used) */
+#define DRV_NS 32          /* persistent arbiter (contact cache) slots per env */
+#define DRV_NPAIR_ROUNDS 8 /* ceil(485 / 64) */
+#define DRV_SLOT_PED 10
+#define DRV_SLOT_OBST 30
+#define DRV_SLOT_BLD 50
+#define DRV_W 1700.0
+#define DRV_H 1000.0
+#define DRV_MAX_TIME 6000
+#define DRV_TIME_DIFF 10
+#define DRV_LANE_ROWS 8
+
+// body f64 fields
+enum { BF_PX = 0, BF_PY, BF_VX, BF_VY, BF_ANG, BF_W, BF_VBX, BF_VBY, BF_WB, BF_COUNT };
+// car f64 fields
+enum { CF_DIRX = 0, CF_DIRY, CF_PREVX, CF_PREVY, CF_GOALX, CF_GOALY, CF_COUNT };
+// env int fields
+enum { EI_ELAPSED = 0, EI_ALLFIN, EI_NPED, EI_NOBST, EI_EPISODE, EI_OCC, EI_ERR, EI_PAD, EI_COUNT };
+// arbiter states (Chipmunk cpArbiterState)
+enum { ARB_FIRST = 0, ARB_NORMAL = 1, ARB_IGNORE = 2, ARB_CACHED = 3 };
+// LanePosition (cutils.py:143-148)
+enum { LP_AtGoal = 0, LP_InRightLane = 1, LP_InOpposingLane = 2, LP_OverRoad = 3, LP_OffRoad = 4 };
+
+// car flag word:  type[0:2) team[2:4) finished[4] crashed[5] fric[6] lanepos[8:11)
+// ped flag word:  road[0] side[1] dead[2] crossing[3] begin[4] speed[8:12)
+#define CARF_TYPE(f) ((f)&3)
+#define CARF_TEAM(f) (((f) >> 2) & 3)
+#define CARF_PACK(type, team, fin, crashed, fric, lp) \
+  ((type) | ((team) << 2) | ((fin) << 4) | ((crashed) << 5) | ((fric) << 6) | ((lp) << 8))
+#define PEDF_PACK(road, side, dead, crossing, begin, speed) \
+  ((road) | ((side) << 1) | ((dead) << 2) | ((crossing) << 3) | ((begin) << 4) | ((speed) << 8))
+
+struct DrvRoad {
+  int nLanes;
+  double width, length, dirAngle, followDist;
+  V2 p0, p1, dir, normal;
+  V2 walk[2][2];
+};
+
+struct DrvConst {
+  DrvRoad roads[2];
+  float laneRows[DRV_LANE_ROWS * 5];
+  double carMass[4], carInertia[4], carHx[4], carHy[4], carPower[4];
+  double pedMass, pedInertia;
+  double turnCos[2], turnSin[2]; /* cos/sin(-/+ 2*pi/180) */
+  uint16_t pairs[DRV_NPAIR_ROUNDS * 64]; /* (i<<8)|j in canonical order, 0xFFFF = none */
+};
+
+struct DrvState {
+  int E, A, obs_dim, pad0;
+  uint64_t seed;
+  int env_id_offset, pad1;
+  double* body;   /* [BF_COUNT][E][32] */
+  double* carx;   /* [CF_COUNT][E][16] */
+  int* flags;     /* [E][32] */
+  int* aux;       /* [E][32]  ped `moving` (ms) */
+  double* obst;   /* [2][E][20] */
+  int* envi;      /* [E][EI_COUNT] */
+  double* epr;    /* [2][E][16] episode_r, episode_pos_r */
+  int* s_pair;    /* [E][NS]  pair id (i<<8|j) */
+  int* s_meta;    /* [E][NS]  state | count<<8 | age<<16 */
+  uint32_t* s_hash; /* [2][E][NS] */
+  double* s_imp;  /* [4][E][NS] jn0 jt0 jn1 jt1 */
+};

@@ -1,0 +1,1166 @@
+// driving_kernels.hip — hand-written gfx950 kernels for the batched DynEnv Driving step.
+//
+// Replaces, for E environments at once, the body of DrivingEnvironment.step (reference DrivingEnvironment.py:248-322):
+// 10 physics substeps {processAction, tick, pedestrian move | pymunk Space.step | bookkeeping} + Full observation
+// + per-agent rewards, all fused in ONE launch.  One wavefront per environment; see driving_dev.h for the lane roles
+// and DESIGN.md for the roofline discussion.  fp64 throughout (the reference computes in Python float / C double);
+// FMA contraction is OFF so results are bit-identical to the CPU oracle.
+#include "driving_dev.h"
+
+__constant__ DrvConst C;
+
+#ifndef DRV_WAVES_PER_SIMD
+#define DRV_WAVES_PER_SIMD 4 /* 4096 envs / (256 CUs * 4 SIMDs) */
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// LDS tile of one environment
+// ------------------------------------------------------------------------------------------------
+struct __align__(16) DrvLds {
+  double px[DRV_NB], py[DRV_NB], vx[DRV_NB], vy[DRV_NB], w[DRV_NB], vbx[DRV_NB], vby[DRV_NB], wb[DRV_NB];
+  double minv[DRV_NB], iinv[DRV_NB], rc[DRV_NB], rs[DRV_NB];
+  double hx[16], hy[16];
+  double aabb[DRV_MAXA][4];
+  double ox[DRV_MAXO], oy[DRV_MAXO];
+  // mailbox: narrowphase result of the pair that maps to slot s (written by the detecting lane, read by lane s)
+  double mb_p1x[DRV_NS][2], mb_p1y[DRV_NS][2], mb_p2x[DRV_NS][2], mb_p2y[DRV_NS][2], mb_nx[DRV_NS], mb_ny[DRV_NS];
+  int mb_hash[DRV_NS][2], mb_count[DRV_NS], mb_flag[DRV_NS]; /* flag: 1 touched, 2 newly allocated */
+  int slotPair[DRV_NS];
+  // observation staging (f32)
+  float carRow[DRV_MAXA][8];
+  float goal[DRV_MAXA][2];
+  float shared[DRV_MAXO * 4 + DRV_MAXP * 2 + DRV_LANE_ROWS * 5];
+};
+
+// ------------------------------------------------------------------------------------------------
+// game logic (mirrors oracle/driving.c, which cites the reference lines)
+// ------------------------------------------------------------------------------------------------
+DE_DEV int road_is_point_on_road(const DrvRoad& r, V2 point, double angle) {  // Road.py:74-97
+  V2 pt = vsub(point, r.p0);
+  double dist = vcross(r.dir, pt);
+  if (dm_abs(dist) >= (double)r.nLanes * r.width + 5.0) return LP_OffRoad;
+  int pos = LP_OverRoad;
+  double dirDist = vdot(r.dir, pt);
+  if (dirDist >= -10.0 && dirDist <= r.length + 10.0) {
+    double relAngle = dm_cos(r.dirAngle - angle) * dist;
+    pos = relAngle < 0.0 ? LP_InRightLane : LP_InOpposingLane;
+  }
+  return pos;
+}
+
+DE_DEV bool drv_is_off_road(V2 point) {  // DrivingEnvironment.py:509-520
+  int position = LP_OffRoad;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    int rp = road_is_point_on_road(C.roads[r], point, 0.0);
+    if (rp < position) position = rp;
+  }
+  return position >= LP_OverRoad;
+}
+DE_DEV bool drv_is_out(V2 p) { return p.x <= 0.0 || p.y <= 0.0 || p.x >= DRV_W || p.y >= DRV_H; }
+
+// cutils.py:102-140 apply_friction (Body.update_velocity with g=0, damping=1, f=t=0 folded to `+ 0.0`)
+DE_DEV void apply_friction(double& vx, double& vy, double& w, double m, double friction, double rotFriction,
+                           double spin) {
+  vx = vx * 1.0 + (0.0 + 0.0) * DE_DT;
+  vy = vy * 1.0 + (0.0 + 0.0) * DE_DT;
+  w = w * 1.0 + 0.0;
+  double factor = friction * m;
+  double rotFactor = rotFriction * m;
+  double x = vx, y = vy;
+  double length = 1.0 / (dm_abs(x) + dm_abs(y) + 1e-5);
+  double theta = w;
+  double a0 = x * factor * length;
+  double a1 = y * factor * length;
+  a0 += a1 * spin * theta;
+  a1 -= a0 * spin * theta;
+  if (dm_abs(x) < factor) x = 0.0; else x -= a0;
+  if (dm_abs(y) < factor) y = 0.0; else y -= a1;
+  if (dm_abs(theta) < rotFactor) theta = 0.0; else theta -= (theta > 0.0 ? rotFactor : -rotFactor);
+  vx = x; vy = y; w = theta;
+}
+
+// ------------------------------------------------------------------------------------------------
+// narrowphase (mirrors oracle/cp_lite.c)
+// ------------------------------------------------------------------------------------------------
+struct BoxW {
+  V2 v[4], n[4];
+};
+DE_DEV void box_world(BoxW& b, V2 p, double rc, double rs, double hx, double hy) {
+  const double lx[4] = {-hx, hx, hx, -hx}, ly[4] = {-hy, -hy, hy, hy};
+  const double nx[4] = {-1.0, 0.0, 1.0, 0.0}, ny[4] = {0.0, -1.0, 0.0, 1.0};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    b.v[i] = v2(rc * lx[i] - rs * ly[i] + p.x, rs * lx[i] + rc * ly[i] + p.y);
+    b.n[i] = v2(rc * nx[i] - rs * ny[i], rs * nx[i] + rc * ny[i]);
+  }
+}
+
+struct Contacts {
+  int count;
+  V2 n, p1[2], p2[2];
+  int hash[2];
+};
+
+struct EdgeW {
+  V2 ap, bp, n;
+  int ah, bh;
+};
+
+DE_DEV int poly_support_index(const BoxW& p, V2 n) {
+  double mx = -INFINITY;
+  int index = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    double d = vdot(p.v[i], n);
+    if (d > mx) { mx = d; index = i; }
+  }
+  return index;
+}
+
+// select element `i` of a 4-vector without dynamic register indexing (no scratch)
+DE_DEV V2 sel4(const V2* a, int i) {
+  V2 r = a[0];
+  r = (i == 1) ? a[1] : r;
+  r = (i == 2) ? a[2] : r;
+  r = (i == 3) ? a[3] : r;
+  return r;
+}
+
+DE_DEV EdgeW support_edge_poly(const BoxW& p, int slot, V2 n) {
+  int i1 = poly_support_index(p, n);
+  int i0 = (i1 + 3) & 3;
+  int i2 = (i1 + 1) & 3;
+  int h = slot * 4;
+  V2 n1 = sel4(p.n, i1), n2 = sel4(p.n, i2);
+  EdgeW e;
+  if (vdot(n, n1) > vdot(n, n2)) {
+    e.ap = sel4(p.v, i0); e.ah = h + i0; e.bp = sel4(p.v, i1); e.bh = h + i1; e.n = n1;
+  } else {
+    e.ap = sel4(p.v, i1); e.ah = h + i1; e.bp = sel4(p.v, i2); e.bh = h + i2; e.n = n2;
+  }
+  return e;
+}
+
+DE_DEV int hash_pair(int a, int b) { return 1 + ((a << 8) | b); }
+
+DE_DEV void contact_points(const EdgeW& e1, const EdgeW& e2, V2 n, Contacts& out) {  // radius 0 edges
+  double d_e1_a = vcross(e1.ap, n), d_e1_b = vcross(e1.bp, n);
+  double d_e2_a = vcross(e2.ap, n), d_e2_b = vcross(e2.bp, n);
+  double e1_denom = 1.0 / (d_e1_b - d_e1_a + DE_DBL_MIN);
+  double e2_denom = 1.0 / (d_e2_b - d_e2_a + DE_DBL_MIN);
+  out.n = n;
+  out.count = 0;
+  {
+    V2 p1 = vadd(vmul(n, 0.0), vlerp(e1.ap, e1.bp, fclamp01_cp((d_e2_b - d_e1_a) * e1_denom)));
+    V2 p2 = vadd(vmul(n, -0.0), vlerp(e2.ap, e2.bp, fclamp01_cp((d_e1_a - d_e2_a) * e2_denom)));
+    double dist = vdot(vsub(p2, p1), n);
+    if (dist <= 0.0) { out.p1[0] = p1; out.p2[0] = p2; out.hash[0] = hash_pair(e1.ah, e2.bh); out.count = 1; }
+  }
+  {
+    V2 p1 = vadd(vmul(n, 0.0), vlerp(e1.ap, e1.bp, fclamp01_cp((d_e2_a - d_e1_a) * e1_denom)));
+    V2 p2 = vadd(vmul(n, -0.0), vlerp(e2.ap, e2.bp, fclamp01_cp((d_e1_b - d_e2_a) * e2_denom)));
+    double dist = vdot(vsub(p2, p1), n);
+    if (dist <= 0.0) {
+      int h = hash_pair(e1.bh, e2.ah);
+      if (out.count == 0) { out.p1[0] = p1; out.p2[0] = p2; out.hash[0] = h; }
+      else { out.p1[1] = p1; out.p2[1] = p2; out.hash[1] = h; }
+      out.count += 1;
+    }
+  }
+}
+
+DE_DEV double sat_max_sep(const BoxW& a, const BoxW& b, int& best) {
+  double maxsep = -INFINITY;
+  best = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    V2 n = a.n[i];
+    double d0 = vdot(n, a.v[i]);
+    double minv = INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double d = vdot(n, b.v[j]) - d0;
+      if (d < minv) minv = d;
+    }
+    if (minv > maxsep) { maxsep = minv; best = i; }
+  }
+  return maxsep;
+}
+
+DE_DEV void poly_to_poly(const BoxW& p1, int slot1, const BoxW& p2, int slot2, Contacts& out) {
+  out.count = 0;
+  int ia, ib;
+  double sa = sat_max_sep(p1, p2, ia);
+  if (sa > 0.0) return;
+  double sb = sat_max_sep(p2, p1, ib);
+  if (sb > 0.0) return;
+  V2 n;
+  if (sa >= sb) n = sel4(p1.n, ia); else n = vneg(sel4(p2.n, ib));
+  contact_points(support_edge_poly(p1, slot1, n), support_edge_poly(p2, slot2, vneg(n)), n, out);
+}
+
+DE_DEV void circle_to_poly(V2 c, double r, const BoxW& poly, Contacts& out) {
+  out.count = 0;
+  double maxsep = -INFINITY;
+  int best = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    double d = vdot(poly.n[i], vsub(c, poly.v[i]));
+    if (d > maxsep) { maxsep = d; best = i; }
+  }
+  if (maxsep > r) return;
+  if (maxsep <= 0.0) {
+    V2 fn = sel4(poly.n, best);
+    V2 n = vneg(fn);
+    V2 pb = vsub(c, vmul(fn, maxsep));
+    out.n = n; out.p1[0] = vadd(c, vmul(n, r)); out.p2[0] = pb; out.hash[0] = 0; out.count = 1;
+  } else {
+    double bestd = INFINITY;
+    V2 bestp = c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      V2 a = poly.v[(i + 3) & 3], b = poly.v[i];
+      V2 d = vsub(b, a);
+      double t = fclamp01_cp(vdot(d, vsub(c, a)) / vlensq(d));
+      V2 q = vadd(a, vmul(d, t));
+      double dsq = vlensq(vsub(q, c));
+      if (dsq < bestd) { bestd = dsq; bestp = q; }
+    }
+    if (bestd <= r * r) {
+      double dist = dm_sqrt(bestd);
+      V2 delta = vsub(bestp, c);
+      V2 n = (dist != 0.0) ? vmul(delta, 1.0 / dist) : vneg(sel4(poly.n, best));
+      out.n = n; out.p1[0] = vadd(c, vmul(n, r)); out.p2[0] = bestp; out.hash[0] = 0; out.count = 1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// body table access (index < 30: dynamic body in LDS; >= 30: static box, zero velocity / inverse mass)
+// ------------------------------------------------------------------------------------------------
+struct BodyV {
+  V2 p, v, vb;
+  double w, wb, minv, iinv;
+};
+DE_DEV V2 static_pos(const DrvLds& L, int idx) {
+  if (idx >= DRV_SLOT_BLD) {
+    int k = idx - DRV_SLOT_BLD; /* DrivingEnvironment.py:101-106 */
+    return v2((k & 2) ? 1385.0 : 365.0, (k & 1) ? 800.0 : 200.0);
+  }
+  return v2(L.ox[idx - DRV_SLOT_OBST], L.oy[idx - DRV_SLOT_OBST]);
+}
+DE_DEV void body_load(const DrvLds& L, int idx, BodyV& b) {
+  if (idx < DRV_SLOT_OBST) {
+    b.p = v2(L.px[idx], L.py[idx]); b.v = v2(L.vx[idx], L.vy[idx]); b.w = L.w[idx];
+    b.vb = v2(L.vbx[idx], L.vby[idx]); b.wb = L.wb[idx]; b.minv = L.minv[idx]; b.iinv = L.iinv[idx];
+  } else {
+    b.p = static_pos(L, idx); b.v = v2(0.0, 0.0); b.w = 0.0; b.vb = v2(0.0, 0.0); b.wb = 0.0; b.minv = 0.0; b.iinv = 0.0;
+  }
+}
+DE_DEV void body_store_vel(DrvLds& L, int idx, const BodyV& b) {
+  if (idx < DRV_SLOT_OBST) {
+    L.vx[idx] = b.v.x; L.vy[idx] = b.v.y; L.w[idx] = b.w; L.vbx[idx] = b.vb.x; L.vby[idx] = b.vb.y; L.wb[idx] = b.wb;
+  }
+}
+DE_DEV double k_scalar_body(const BodyV& b, V2 r, V2 n) {
+  double rcn = vcross(r, n);
+  return b.minv + b.iinv * rcn * rcn;
+}
+DE_DEV V2 relative_velocity(const BodyV& a, const BodyV& b, V2 r1, V2 r2) {
+  V2 v1 = vadd(a.v, vmul(vperp(r1), a.w));
+  V2 v2s = vadd(b.v, vmul(vperp(r2), b.w));
+  return vsub(v2s, v1);
+}
+DE_DEV void apply_impulse(BodyV& b, V2 j, V2 r) {
+  b.v = vadd(b.v, vmul(j, b.minv));
+  b.w += b.iinv * vcross(r, j);
+}
+DE_DEV void apply_bias_impulse(BodyV& b, V2 j, V2 r) {
+  b.vb = vadd(b.vb, vmul(j, b.minv));
+  b.wb += b.iinv * vcross(r, j);
+}
+
+// ------------------------------------------------------------------------------------------------
+// observation writer: Full obs of DrivingEnvironment.getFullState/get_full_obs (:686-747, :121-124)
+// dense padded row per agent: [self 9 | other cars (A-1)x7 | obstacles 20x4 | pedestrians 20x2 | lanes 8x5]
+// ------------------------------------------------------------------------------------------------
+#define STD_NORM_X (0.5 / (DRV_W + 100.0))
+#define STD_NORM_Y (0.5 / (DRV_H + 100.0))
+#define STD_NORM_W (1.0 / 15.0)
+#define STD_NORM_H (1.0 / 25.0)
+DE_DEV double normalize_obs(double pt, double nf, double mean) { return ((pt * nf) - mean) * 2.0 * 1.0; }  // cutils.py:318-323
+
+DE_DEV void write_full_obs(DrvLds& L, int lane, int A, int nPed, int nObst, int obs_dim, float* __restrict__ out,
+                           bool isCar, bool isPed, double px, double py, double ang, int type, int finished,
+                           double goalx, double goaly) {
+  if (isCar) {
+    double s, c;
+    dm_sincos(ang, &s, &c);
+    L.carRow[lane][0] = (float)normalize_obs(px, STD_NORM_X, 0.0);
+    L.carRow[lane][1] = (float)normalize_obs(py, STD_NORM_Y, 0.0);
+    L.carRow[lane][2] = (float)c;
+    L.carRow[lane][3] = (float)s;
+    L.carRow[lane][4] = (float)normalize_obs(C.carHy[type], STD_NORM_W, 0.5);  // c.width
+    L.carRow[lane][5] = (float)normalize_obs(C.carHx[type], STD_NORM_H, 0.5);  // c.height
+    L.carRow[lane][6] = (float)finished;
+    L.goal[lane][0] = (float)normalize_obs(goalx, STD_NORM_X, 0.0);
+    L.goal[lane][1] = (float)normalize_obs(goaly, STD_NORM_Y, 0.0);
+  }
+  if (lane >= DRV_SLOT_PED && lane < DRV_SLOT_PED + DRV_MAXP) {
+    int k = lane - DRV_SLOT_PED;
+    L.shared[DRV_MAXO * 4 + 2 * k + 0] = isPed ? (float)normalize_obs(px, STD_NORM_X, 0.0) : 0.0f;
+    L.shared[DRV_MAXO * 4 + 2 * k + 1] = isPed ? (float)normalize_obs(py, STD_NORM_Y, 0.0) : 0.0f;
+  }
+  if (lane < DRV_MAXO) {
+    bool on = lane < nObst;
+    L.shared[4 * lane + 0] = on ? (float)normalize_obs(L.ox[lane], STD_NORM_X, 0.0) : 0.0f;
+    L.shared[4 * lane + 1] = on ? (float)normalize_obs(L.oy[lane], STD_NORM_Y, 0.0) : 0.0f;
+    L.shared[4 * lane + 2] = on ? (float)normalize_obs(10.0, STD_NORM_W, 0.5) : 0.0f;
+    L.shared[4 * lane + 3] = on ? (float)normalize_obs(10.0, STD_NORM_H, 0.5) : 0.0f;
+  }
+  if (lane < DRV_LANE_ROWS * 5) L.shared[DRV_MAXO * 4 + DRV_MAXP * 2 + lane] = C.laneRows[lane];
+  __syncthreads();
+  const int carsEnd = 9 + (A - 1) * 7;
+  if (((carsEnd | obs_dim) & 3) == 0) {
+    // vector path (A in {2,6,10}): one float4 per lane per agent row; the 160-float shared tail is agent-independent
+    const int nvec = obs_dim >> 2;
+    for (int q = lane; q < nvec; q += DE_WAVE) {
+      int f = q << 2;
+      if (f >= carsEnd) {
+        float4 v = *reinterpret_cast<const float4*>(&L.shared[f - carsEnd]);
+        for (int a = 0; a < A; ++a) *reinterpret_cast<float4*>(out + (size_t)a * obs_dim + f) = v;
+      } else {
+        for (int a = 0; a < A; ++a) {
+          float4 v;
+          float t[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            int ff = f + k;
+            float x;
+            if (ff < 6) x = L.carRow[a][ff];
+            else if (ff < 8) x = L.goal[a][ff - 6];
+            else if (ff == 8) x = L.carRow[a][6];
+            else {
+              int c = (ff - 9) / 7, kk = (ff - 9) - c * 7;
+              c += (c >= a);
+              x = L.carRow[c][kk];
+            }
+            t[k] = x;
+          }
+          v.x = t[0]; v.y = t[1]; v.z = t[2]; v.w = t[3];
+          *reinterpret_cast<float4*>(out + (size_t)a * obs_dim + f) = v;
+        }
+      }
+    }
+  } else {
+    for (int idx = lane; idx < A * obs_dim; idx += DE_WAVE) {
+      int a = idx / obs_dim, ff = idx - a * obs_dim;
+      float x;
+      if (ff < 6) x = L.carRow[a][ff];
+      else if (ff < 8) x = L.goal[a][ff - 6];
+      else if (ff == 8) x = L.carRow[a][6];
+      else if (ff < carsEnd) {
+        int c = (ff - 9) / 7, kk = (ff - 9) - c * 7;
+        c += (c >= a);
+        x = L.carRow[c][kk];
+      } else x = L.shared[ff - carsEnd];
+      out[idx] = x;
+    }
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-lane register state + HBM load/store
+// ------------------------------------------------------------------------------------------------
+struct LaneState {
+  // body
+  double px, py, vx, vy, ang, w, vbx, vby, wb;
+  // car
+  double dirx, diry, prevx, prevy, goalx, goaly;
+  int type, team, finished, crashed, fric, lanepos;
+  // ped
+  int road, side, dead, crossing, beginc, speed, moving;
+  // arbiter slot (lane < DRV_NS)
+  int a_pair, a_state, a_count, a_age, a_hash0, a_hash1;
+  double a_jn0, a_jt0, a_jn1, a_jt1;
+};
+
+DE_DEV void load_lane(const DrvState& S, int e, int lane, bool isCar, bool isPed, uint64_t occ, LaneState& s) {
+  const size_t E = (size_t)S.E;
+  s.px = s.py = s.vx = s.vy = s.ang = s.w = s.vbx = s.vby = s.wb = 0.0;
+  s.dirx = s.diry = s.prevx = s.prevy = s.goalx = s.goaly = 0.0;
+  s.type = s.team = s.finished = s.crashed = s.fric = 0; s.lanepos = LP_OffRoad;
+  s.road = s.side = s.dead = s.crossing = s.beginc = s.speed = s.moving = 0;
+  if (isCar || isPed) {
+    const double* b = S.body + (size_t)e * DRV_NB + lane;
+    s.px = b[BF_PX * E * DRV_NB]; s.py = b[BF_PY * E * DRV_NB]; s.vx = b[BF_VX * E * DRV_NB]; s.vy = b[BF_VY * E * DRV_NB];
+    s.ang = b[BF_ANG * E * DRV_NB]; s.w = b[BF_W * E * DRV_NB];
+    s.vbx = b[BF_VBX * E * DRV_NB]; s.vby = b[BF_VBY * E * DRV_NB]; s.wb = b[BF_WB * E * DRV_NB];
+    int f = S.flags[(size_t)e * DRV_NB + lane];
+    if (isCar) {
+      const double* c = S.carx + (size_t)e * 16 + lane;
+      s.dirx = c[CF_DIRX * E * 16]; s.diry = c[CF_DIRY * E * 16]; s.prevx = c[CF_PREVX * E * 16];
+      s.prevy = c[CF_PREVY * E * 16]; s.goalx = c[CF_GOALX * E * 16]; s.goaly = c[CF_GOALY * E * 16];
+      s.type = f & 3; s.team = (f >> 2) & 3; s.finished = (f >> 4) & 1; s.crashed = (f >> 5) & 1;
+      s.fric = (f >> 6) & 1; s.lanepos = (f >> 8) & 7;
+    } else {
+      s.road = f & 1; s.side = (f >> 1) & 1; s.dead = (f >> 2) & 1; s.crossing = (f >> 3) & 1;
+      s.beginc = (f >> 4) & 1; s.speed = (f >> 8) & 15;
+      s.moving = S.aux[(size_t)e * DRV_NB + lane];
+    }
+  }
+  s.a_pair = 0xFFFF; s.a_state = ARB_FIRST; s.a_count = 0; s.a_age = 0; s.a_hash0 = s.a_hash1 = 0;
+  s.a_jn0 = s.a_jt0 = s.a_jn1 = s.a_jt1 = 0.0;
+  if (lane < DRV_NS && ((occ >> lane) & 1ull)) {
+    size_t o = (size_t)e * DRV_NS + lane;
+    s.a_pair = S.s_pair[o];
+    int m = S.s_meta[o];
+    s.a_state = m & 0xFF; s.a_count = (m >> 8) & 0xFF; s.a_age = (m >> 16) & 0xFF;
+    s.a_hash0 = (int)S.s_hash[o]; s.a_hash1 = (int)S.s_hash[E * DRV_NS + o];
+    s.a_jn0 = S.s_imp[o]; s.a_jt0 = S.s_imp[E * DRV_NS + o];
+    s.a_jn1 = S.s_imp[2 * E * DRV_NS + o]; s.a_jt1 = S.s_imp[3 * E * DRV_NS + o];
+  }
+}
+
+DE_DEV void store_lane(const DrvState& S, int e, int lane, bool isCar, bool isPed, uint64_t occ, const LaneState& s) {
+  const size_t E = (size_t)S.E;
+  if (isCar || isPed) {
+    double* b = S.body + (size_t)e * DRV_NB + lane;
+    b[BF_PX * E * DRV_NB] = s.px; b[BF_PY * E * DRV_NB] = s.py; b[BF_VX * E * DRV_NB] = s.vx; b[BF_VY * E * DRV_NB] = s.vy;
+    b[BF_ANG * E * DRV_NB] = s.ang; b[BF_W * E * DRV_NB] = s.w;
+    b[BF_VBX * E * DRV_NB] = s.vbx; b[BF_VBY * E * DRV_NB] = s.vby; b[BF_WB * E * DRV_NB] = s.wb;
+    if (isCar) {
+      double* c = S.carx + (size_t)e * 16 + lane;
+      c[CF_DIRX * E * 16] = s.dirx; c[CF_DIRY * E * 16] = s.diry; c[CF_PREVX * E * 16] = s.prevx;
+      c[CF_PREVY * E * 16] = s.prevy; c[CF_GOALX * E * 16] = s.goalx; c[CF_GOALY * E * 16] = s.goaly;
+      S.flags[(size_t)e * DRV_NB + lane] = CARF_PACK(s.type, s.team, s.finished, s.crashed, s.fric, s.lanepos);
+    } else {
+      S.flags[(size_t)e * DRV_NB + lane] = PEDF_PACK(s.road, s.side, s.dead, s.crossing, s.beginc, s.speed);
+      S.aux[(size_t)e * DRV_NB + lane] = s.moving;
+    }
+  }
+  if (lane < DRV_NS && ((occ >> lane) & 1ull)) {
+    size_t o = (size_t)e * DRV_NS + lane;
+    S.s_pair[o] = s.a_pair;
+    S.s_meta[o] = s.a_state | (s.a_count << 8) | (s.a_age << 16);
+    S.s_hash[o] = (uint32_t)s.a_hash0; S.s_hash[E * DRV_NS + o] = (uint32_t)s.a_hash1;
+    S.s_imp[o] = s.a_jn0; S.s_imp[E * DRV_NS + o] = s.a_jt0;
+    S.s_imp[2 * E * DRV_NS + o] = s.a_jn1; S.s_imp[3 * E * DRV_NS + o] = s.a_jt1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// collision `begin` callbacks, executed wave-uniformly in canonical pair order
+// (DrivingEnvironment.py:587-683: carCrash / pedHit / carHit).  Returns false => arbiter ignored until separation.
+// ------------------------------------------------------------------------------------------------
+DE_DEV void car_crash_flags(LaneState& s) { s.finished = 1; s.crashed = 1; s.fric = 1; }  // Car.py:111-117
+
+DE_DEV bool cb_begin(int i, int j, int lane, LaneState& s, double& rew) {
+  // i = car lane, j = partner slot (car / ped lane, or static >= 30); all arguments wave-uniform
+  double v1x = bcast_d(s.vx, i), v1y = bcast_d(s.vy, i);
+  if (j < DRV_SLOT_PED) {  // carCrash :591-637
+    double v2x = bcast_d(s.vx, j), v2y = bcast_d(s.vy, j);
+    int crashed1 = bcast_i(s.crashed, i), crashed2 = bcast_i(s.crashed, j);
+    int pos1 = bcast_i(s.lanepos, i), pos2 = bcast_i(s.lanepos, j);
+    double v1len = vlen(v2(v1x, v1y)), v2len = vlen(v2(v2x, v2y));
+    double v1l = v1len / 5.0, v2l = v2len / 5.0;
+    double d1 = 0.0, d2 = 0.0;  // applied as successive subtractions to keep the reference's rounding order
+    double r1 = bcast_d(rew, i), r2 = bcast_d(rew, j);
+    if (!crashed1) r1 -= v1l;
+    if (!crashed2) r2 -= v2l;
+    if (pos1 != LP_InRightLane && !crashed1) r1 -= v1l;
+    if (pos2 != LP_InRightLane && !crashed2) r2 -= v2l;
+    if (pos1 == LP_InRightLane && pos2 == LP_InRightLane) {
+      V2 dp = v2(bcast_d(s.px, i) - bcast_d(s.px, j), bcast_d(s.py, i) - bcast_d(s.py, j));
+      double adp = dm_atan2(dp.y, dp.x);
+      if (v1len > 1.0 && dm_cos(adp - dm_atan2(v1y, v1x)) < -0.4 && !crashed1) r1 -= v1l;
+      if (v2len > 1.0 && dm_cos(adp - dm_atan2(v2y, v2x)) > 0.4 && !crashed2) r2 -= v2l;
+    }
+    (void)d1; (void)d2;
+    if (lane == i) { rew = r1; car_crash_flags(s); }
+    if (lane == j) { rew = r2; car_crash_flags(s); }
+    return true;
+  } else if (j < DRV_SLOT_OBST) {  // pedHit :640-667
+    double v1l = vlen(v2(v1x, v1y));
+    if (v1l > 1.0) {
+      V2 dp = v2(bcast_d(s.px, i) - bcast_d(s.px, j), bcast_d(s.py, i) - bcast_d(s.py, j));
+      int finished = bcast_i(s.finished, i);
+      if (lane == j) { s.moving = 0; s.vx = 0.0; s.vy = 0.0; s.dead = 1; }  // Pedestrian.die
+      if (dm_cos(dm_atan2(dp.y, dp.x) - dm_atan2(v1y, v1x)) < -0.4 && !finished) {
+        if (lane == i) { car_crash_flags(s); rew -= v1l / 5.0; }
+      }
+      return true;
+    }
+    return false;
+  } else {  // carHit :670-683
+    if (lane == i) {
+      if (!s.finished) rew -= vlen(v2(s.vx, s.vy)) / 5.0;
+      car_crash_flags(s);
+    }
+    return true;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// THE step kernel: grid = E blocks of one wavefront
+// ------------------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(64, DRV_WAVES_PER_SIMD)
+drv_step_kernel(DrvState S, const int* __restrict__ actions, float* __restrict__ obs, double* __restrict__ rewards,
+                uint8_t* __restrict__ dones) {
+  __shared__ DrvLds L;
+  const int e = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int A = S.A;
+  int* envi = S.envi + (size_t)e * EI_COUNT;
+  int elapsed = uniform_i(envi[EI_ELAPSED]);
+  int allFinished = uniform_i(envi[EI_ALLFIN]);
+  const int nPed = uniform_i(envi[EI_NPED]);
+  const int nObst = uniform_i(envi[EI_NOBST]);
+  const uint32_t episode = (uint32_t)uniform_i(envi[EI_EPISODE]);
+  uint64_t occ = (uint64_t)(uint32_t)uniform_i(envi[EI_OCC]);
+  int err = 0;
+  const uint32_t genv = (uint32_t)(S.env_id_offset + e);
+
+  const bool isCar = lane < A;
+  const bool isPed = lane >= DRV_SLOT_PED && lane < DRV_SLOT_PED + nPed;
+  const bool isBody = isCar || isPed;
+  LaneState s;
+  load_lane(S, e, lane, isCar, isPed, occ, s);
+
+  // constants of my body
+  double m = 1.0, minv = 0.0, iinv = 0.0, hx = 0.0, hy = 0.0;
+  if (isCar) { m = C.carMass[s.type]; minv = 1.0 / m; iinv = 1.0 / C.carInertia[s.type]; hx = C.carHx[s.type]; hy = C.carHy[s.type]; }
+  if (isPed) { m = C.pedMass; minv = 1.0 / m; iinv = 1.0 / C.pedInertia; }
+  if (lane < DRV_NB) { L.minv[lane] = minv; L.iinv[lane] = iinv; }
+  if (lane < 16) { L.hx[lane] = hx; L.hy[lane] = hy; }
+  if (lane < DRV_MAXO) {
+    L.ox[lane] = lane < nObst ? S.obst[(size_t)e * DRV_MAXO + lane] : 0.0;
+    L.oy[lane] = lane < nObst ? S.obst[(size_t)S.E * DRV_MAXO + (size_t)e * DRV_MAXO + lane] : 0.0;
+  }
+  if (lane < DRV_NS) L.slotPair[lane] = s.a_pair;
+
+  // my 8 candidate pairs (canonical order index = round*64 + lane), packed 4 x u16 per 64-bit register so that the
+  // round loop can select one without dynamically indexed registers (no scratch)
+  uint64_t pairLo = 0ull, pairHi = 0ull;
+#pragma unroll
+  for (int t = 0; t < DRV_NPAIR_ROUNDS; ++t) {
+    int pr = C.pairs[t * 64 + lane];
+    int i = pr >> 8, j = pr & 0xFF;
+    bool ok = (pr != 0xFFFF) && i < A;
+    if (ok) {
+      if (j < DRV_SLOT_PED) ok = j < A;
+      else if (j < DRV_SLOT_OBST) ok = (j - DRV_SLOT_PED) < nPed;
+      else if (j < DRV_SLOT_BLD) ok = (j - DRV_SLOT_OBST) < nObst;
+    }
+    uint64_t v = (uint64_t)(ok ? pr : 0xFFFF);
+    if (t < 4) pairLo |= v << (16 * t); else pairHi |= v << (16 * (t - 4));
+  }
+#define MY_PAIR(t) ((int)((((t) < 4 ? pairLo : pairHi) >> (16 * ((t)&3))) & 0xFFFFull))
+
+  int act0 = 1, act1 = 1;
+  if (isCar) { act0 = actions[((size_t)e * A + lane) * 2 + 0]; act1 = actions[((size_t)e * A + lane) * 2 + 1]; }
+  double rew = 0.0, posrew = 0.0, teamReward = 0.0;  // :252-254
+  __syncthreads();
+
+  for (int it = 0; it < 10; ++it) {
+    // ---------------- game logic on own body (cars: processAction + tick; pedestrians: move) -----------------
+    if (isCar) {
+      if (it == 0) {  // processAction :357-373 -> Car.accelerate (Car.py:55-94), Car.turn (Car.py:97-108)
+        int acc = act0 - 1, steer = (act1 - 1) * 2;
+        if (!s.finished) {
+          double power = (double)acc;
+          double moveDir = s.vx * s.dirx + s.vy * s.diry;
+          bool skip = false;
+          if (acc < 0) power = (double)acc * 0.75;
+          if (acc == 0) power = (moveDir == 0.0) ? 0.0 : (moveDir > 0.0 ? -2.0 : 2.0);
+          else if (acc < 0 && moveDir > 0.0) skip = true;
+          else if (acc > 0 && moveDir < 0.0) skip = true;
+          if (!skip) {
+            double sn, cs;
+            dm_sincos(s.ang, &sn, &cs);
+            double vxa = C.carPower[s.type] * power * cs, vya = C.carPower[s.type] * power * sn;
+            s.vx = s.vx + vxa; s.vy = s.vy + vya;
+            if (acc == 0 && (s.vx * s.dirx + s.vy * s.diry) * moveDir < 0.0) { s.vx = 0.0; s.vy = 0.0; }
+          }
+        }
+        if (steer != 0 && !s.finished) {
+          double rot = (double)steer * (DM_PI / 180.0);
+          s.ang = s.ang + rot;
+          double sn, cs;
+          dm_sincos(rot, &sn, &cs);
+          double dx = s.dirx * cs - s.diry * sn, dy = s.dirx * sn + s.diry * cs;
+          s.dirx = dx; s.diry = dy;
+          double nvx = s.vx * cs - s.vy * sn, nvy = s.vx * sn + s.vy * cs;
+          s.vx = nvx; s.vy = nvy;
+        }
+      }
+      // tick :376-426
+      V2 pos = v2(s.px, s.py);
+      int lp = LP_OffRoad;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        int rp = road_is_point_on_road(C.roads[r], pos, s.ang);
+        if (rp < lp) lp = rp;
+      }
+      V2 goal = v2(s.goalx, s.goaly);
+      double dnow = vlen(vsub(pos, goal));
+      double diff = vlen(vsub(v2(s.prevx, s.prevy), goal)) - dnow;
+      if (!s.finished) { rew += diff / 50.0; posrew += dm_max(0.0, diff / 50.0); }
+      s.prevx = s.px; s.prevy = s.py;
+      if (lp >= LP_OverRoad) {
+        if (!s.finished) {
+          if (lp == LP_OverRoad && dnow < 100.0) {
+            lp = LP_AtGoal; s.finished = 1;
+            rew += (double)(DRV_MAX_TIME - elapsed) / 100.0;
+            posrew += (double)(DRV_MAX_TIME - elapsed) / 100.0;
+            s.fric = 1;
+          } else {
+            car_crash_flags(s);
+            rew -= vlen(v2(s.vx, s.vy)) / 5.0;
+          }
+        }
+      } else if (lp == LP_InOpposingLane) {
+        if (!s.finished) rew -= vlen(v2(s.vx, s.vy)) / 10000.0;
+      }
+      s.lanepos = lp;
+      if (s.prevx >= DRV_W + 50.0 || s.prevx <= -50.0 || s.prevy >= DRV_H + 50.0 || s.prevy <= -50.0) { s.vx = 0.0; s.vy = 0.0; }
+    } else if (isPed && !s.dead) {  // move :429-506
+      V2 pos = v2(s.px, s.py);
+      bool isOffRoad = drv_is_off_road(pos);
+      bool isOut = drv_is_out(pos);
+      if (s.moving > 0) {
+        s.moving = (s.moving - DRV_TIME_DIFF > 0) ? s.moving - DRV_TIME_DIFF : 0;
+        if (s.crossing) {
+          if (!s.beginc && isOffRoad) { s.moving = 0; s.crossing = 0; s.vx = 0.0; s.vy = 0.0; }
+          else if (s.beginc && !isOffRoad) { s.beginc = 0; }
+        }
+        if (isOut) { s.moving = 0; s.vx = 0.0; s.vy = 0.0; }
+      } else {
+        if (!s.crossing) {
+          dm_u32x4 u = dm_env_rng(S.seed, genv, episode, DM_RNG_PED_MOVE, (uint32_t)(lane - DRV_SLOT_PED), (uint32_t)elapsed);
+          V2 rdir = C.roads[s.road].dir, rnrm = C.roads[s.road].normal;
+          V2 dir = rdir;
+          s.moving = dm_randint(u.v[0], 5000, 30000);
+          int speed = dm_randint(u.v[1], -2, 2);
+          if (!isOffRoad) {
+            s.crossing = 1; s.beginc = 0;
+            if (speed == 0) speed = 2;
+          } else if (isOut) {
+            dir = drv_is_out(vadd(pos, rdir)) ? vneg(rdir) : rdir;
+          } else if (dm_unit(u.v[2]) < 0.05) {
+            s.crossing = 1; s.beginc = 1;
+            dir = s.side ? rnrm : vneg(rnrm);
+            s.side = s.side ? 0 : 1;
+            speed = dm_randint(u.v[3], 1, 2);
+          }
+          V2 nv = vmul(vmul(dir, (double)s.speed), (double)speed);
+          s.vx = nv.x; s.vy = nv.y;
+        } else if (isOffRoad) {
+          s.crossing = 0; s.beginc = 0;
+        }
+      }
+    }
+
+    // ---------------- Space.step(0.01): integrate positions (cpBodyUpdatePosition) ---------------------------
+    double rc = 1.0, rs = 0.0;
+    if (isBody) {
+      s.px = s.px + (s.vx + s.vbx) * DE_DT;
+      s.py = s.py + (s.vy + s.vby) * DE_DT;
+      s.ang = s.ang + (s.w + s.wb) * DE_DT;
+      s.vbx = 0.0; s.vby = 0.0; s.wb = 0.0;
+      if (isCar) dm_sincos(s.ang, &rs, &rc);
+    }
+    if (lane < DRV_NB) { L.px[lane] = s.px; L.py[lane] = s.py; L.rc[lane] = rc; L.rs[lane] = rs; }
+    if (isCar) {
+      BoxW bw;
+      box_world(bw, v2(s.px, s.py), rc, rs, hx, hy);
+      double l = INFINITY, r = -INFINITY, b = INFINITY, t = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        l = fmin_cp(l, bw.v[k].x); r = fmax_cp(r, bw.v[k].x); b = fmin_cp(b, bw.v[k].y); t = fmax_cp(t, bw.v[k].y);
+      }
+      L.aabb[lane][0] = l - 0.0; L.aabb[lane][1] = b - 0.0; L.aabb[lane][2] = r + 0.0; L.aabb[lane][3] = t + 0.0;
+    }
+    __syncthreads();
+
+    // ---------------- broadphase: exact AABB overlap on my 8 pairs ------------------------------------------
+    int cand = 0;
+#pragma unroll
+    for (int t = 0; t < DRV_NPAIR_ROUNDS; ++t) {
+      int pr = MY_PAIR(t);
+      if (pr != 0xFFFF) {
+        int i = pr >> 8, j = pr & 0xFF;
+        double al = L.aabb[i][0], ab = L.aabb[i][1], ar = L.aabb[i][2], at = L.aabb[i][3];
+        double bl, bb, br, bt;
+        if (j < DRV_SLOT_PED) { bl = L.aabb[j][0]; bb = L.aabb[j][1]; br = L.aabb[j][2]; bt = L.aabb[j][3]; }
+        else if (j < DRV_SLOT_OBST) { double cx = L.px[j], cy = L.py[j]; bl = cx - 5.0; bb = cy - 5.0; br = cx + 5.0; bt = cy + 5.0; }
+        else {
+          V2 c = static_pos(L, j);
+          double ex = j >= DRV_SLOT_BLD ? 400.0 : 10.0, ey = j >= DRV_SLOT_BLD ? 225.0 : 10.0;
+          // static box AABB = min/max of (c +- e) exactly as cached by cpShapeCacheBB with rot = (1,0)
+          bl = -ex + c.x; br = ex + c.x; bb = -ey + c.y; bt = ey + c.y;
+        }
+        if (al <= br && bl <= ar && ab <= bt && bb <= at) cand |= (1 << t);
+      }
+    }
+    const uint64_t anyCand = wave_ballot(cand != 0);
+
+    if (anyCand == 0ull && occ == 0ull) {
+      // ---------- fast path: nothing touches and the contact cache is empty: velocity update only ------------
+      if (isCar) {
+        if (s.fric) apply_friction(s.vx, s.vy, s.w, m, 5e-4, 2e-5, 0.0); else apply_friction(s.vx, s.vy, s.w, m, 5e-5, 1e-5, 0.0);
+      } else if (isPed) {
+        if (s.dead) apply_friction(s.vx, s.vy, s.w, m, 5e-2, 2e-4, 0.0);
+        else { s.vx = s.vx * 1.0 + (0.0 + 0.0) * DE_DT; s.vy = s.vy * 1.0 + (0.0 + 0.0) * DE_DT; s.w = s.w * 1.0 + 0.0; }
+      }
+    } else {
+      // ---------- slow path: narrowphase -> arbiter cache -> callbacks -> prestep -> friction -> solver -------
+      if (lane < DRV_NS) L.mb_flag[lane] = 0;
+      __syncthreads();
+#pragma unroll 1
+      for (int t = 0; t < DRV_NPAIR_ROUNDS; ++t) {
+        const bool isCand = (cand >> t) & 1;
+        if (wave_ballot(isCand) == 0ull) continue;
+        Contacts ct;
+        ct.count = 0;
+        int pr = MY_PAIR(t);
+        if (isCand) {
+          int i = pr >> 8, j = pr & 0xFF;
+          BoxW b1;
+          box_world(b1, v2(L.px[i], L.py[i]), L.rc[i], L.rs[i], L.hx[i], L.hy[i]);
+          if (j < DRV_SLOT_PED) {
+            BoxW b2;
+            box_world(b2, v2(L.px[j], L.py[j]), L.rc[j], L.rs[j], L.hx[j], L.hy[j]);
+            poly_to_poly(b1, i, b2, j, ct);
+          } else if (j < DRV_SLOT_OBST) {
+            circle_to_poly(v2(L.px[j], L.py[j]), 5.0, b1, ct);
+          } else {
+            BoxW b2;
+            double ex = j >= DRV_SLOT_BLD ? 400.0 : 10.0, ey = j >= DRV_SLOT_BLD ? 225.0 : 10.0;
+            box_world(b2, static_pos(L, j), 1.0, 0.0, ex, ey);
+            poly_to_poly(b1, i, b2, j, ct);
+          }
+        }
+        const bool touch = isCand && ct.count > 0;
+        const uint64_t tmask = wave_ballot(touch);
+        if (tmask == 0ull) continue;
+        // find my slot among the occupied ones
+        int slot = -1;
+        if (touch) {
+          for (uint64_t mm = occ; mm; mm &= mm - 1) {
+            int sidx = __builtin_ctzll(mm);
+            if (L.slotPair[sidx] == pr) slot = sidx;
+          }
+        }
+        const bool needNew = touch && slot < 0;
+        const uint64_t newMask = wave_ballot(needNew);
+        if (newMask) {
+          int rank = __popcll(newMask & lanemask_lt());
+          uint64_t fm = (~occ) & ((DRV_NS >= 64) ? ~0ull : ((1ull << DRV_NS) - 1ull));
+          if (needNew) {
+            for (int r = 0; r < rank; ++r) fm &= fm - 1;
+            if (fm) { slot = __builtin_ctzll(fm); L.slotPair[slot] = pr; }
+            else err |= 1;  // contact cache overflow: pair dropped (reported through EI_ERR)
+          }
+          int cnt = __popcll(newMask);
+          uint64_t fm2 = (~occ) & ((DRV_NS >= 64) ? ~0ull : ((1ull << DRV_NS) - 1ull));
+          for (int r = 0; r < cnt && fm2; ++r) { occ |= (fm2 & (~fm2 + 1)); fm2 &= fm2 - 1; }
+        }
+        if (touch && slot >= 0) {
+          L.mb_flag[slot] = needNew ? 3 : 1;
+          L.mb_count[slot] = ct.count;
+          L.mb_nx[slot] = ct.n.x; L.mb_ny[slot] = ct.n.y;
+          L.mb_p1x[slot][0] = ct.p1[0].x; L.mb_p1y[slot][0] = ct.p1[0].y; L.mb_p2x[slot][0] = ct.p2[0].x; L.mb_p2y[slot][0] = ct.p2[0].y;
+          L.mb_hash[slot][0] = ct.hash[0];
+          if (ct.count > 1) {
+            L.mb_p1x[slot][1] = ct.p1[1].x; L.mb_p1y[slot][1] = ct.p1[1].y; L.mb_p2x[slot][1] = ct.p2[1].x; L.mb_p2y[slot][1] = ct.p2[1].y;
+            L.mb_hash[slot][1] = ct.hash[1];
+          }
+        }
+        __syncthreads();
+      }
+      __syncthreads();
+
+      // ---- slot lanes: cpArbiterUpdate for touched slots; ageing / expiry for the rest ----------------------
+      const bool slotOcc = lane < DRV_NS && ((occ >> lane) & 1ull);
+      bool touched = false;
+      int bodyA = 0, bodyB = 0;
+      V2 n = v2(0.0, 0.0), r1[2], r2[2];
+      r1[0] = r1[1] = r2[0] = r2[1] = v2(0.0, 0.0);
+      if (slotOcc) {
+        int flag = L.mb_flag[lane];
+        touched = flag != 0;
+        if (flag & 2) { s.a_pair = L.slotPair[lane]; s.a_state = ARB_FIRST; s.a_count = 0; s.a_age = 0; s.a_hash0 = s.a_hash1 = 0; }
+        if (touched) {
+          int i = s.a_pair >> 8, j = s.a_pair & 0xFF;
+          // narrowphase order: shape type ascending => pedestrian circle first for car-ped pairs
+          if (j >= DRV_SLOT_PED && j < DRV_SLOT_OBST) { bodyA = j; bodyB = i; } else { bodyA = i; bodyB = j; }
+          V2 pa = bodyA < DRV_SLOT_OBST ? v2(L.px[bodyA], L.py[bodyA]) : static_pos(L, bodyA);
+          V2 pb = bodyB < DRV_SLOT_OBST ? v2(L.px[bodyB], L.py[bodyB]) : static_pos(L, bodyB);
+          int cnt = L.mb_count[lane];
+          int h0 = L.mb_hash[lane][0], h1 = cnt > 1 ? L.mb_hash[lane][1] : 0;
+          double jn0 = 0.0, jt0 = 0.0, jn1 = 0.0, jt1 = 0.0;
+          // carry impulses of contacts with matching hash (later match wins, as in Chipmunk's loop)
+          if (s.a_count > 0 && h0 == s.a_hash0) { jn0 = s.a_jn0; jt0 = s.a_jt0; }
+          if (s.a_count > 1 && h0 == s.a_hash1) { jn0 = s.a_jn1; jt0 = s.a_jt1; }
+          if (cnt > 1) {
+            if (s.a_count > 0 && h1 == s.a_hash0) { jn1 = s.a_jn0; jt1 = s.a_jt0; }
+            if (s.a_count > 1 && h1 == s.a_hash1) { jn1 = s.a_jn1; jt1 = s.a_jt1; }
+          }
+          r1[0] = vsub(v2(L.mb_p1x[lane][0], L.mb_p1y[lane][0]), pa);
+          r2[0] = vsub(v2(L.mb_p2x[lane][0], L.mb_p2y[lane][0]), pb);
+          if (cnt > 1) {
+            r1[1] = vsub(v2(L.mb_p1x[lane][1], L.mb_p1y[lane][1]), pa);
+            r2[1] = vsub(v2(L.mb_p2x[lane][1], L.mb_p2y[lane][1]), pb);
+          }
+          n = v2(L.mb_nx[lane], L.mb_ny[lane]);
+          s.a_count = cnt; s.a_hash0 = h0; s.a_hash1 = h1;
+          s.a_jn0 = jn0; s.a_jt0 = jt0; s.a_jn1 = jn1; s.a_jt1 = jt1;
+          if (s.a_state == ARB_CACHED) s.a_state = ARB_FIRST;
+          s.a_age = 0;
+        }
+      }
+
+      // ---- rank touched slots by canonical pair order ------------------------------------------------------
+      const uint64_t touchedMask = wave_ballot(touched);
+      const int nTouched = __popcll(touchedMask);
+      int rank = 0;
+      const int pairKey = s.a_pair;
+      for (uint64_t mm = touchedMask; mm; mm &= mm - 1) {
+        int b = __builtin_ctzll(mm);
+        int pk = bcast_i(pairKey, b);
+        rank += (pk < pairKey) ? 1 : 0;
+      }
+
+      // ---- begin callbacks in canonical order (first contact only) ------------------------------------------
+      for (int k = 0; k < nTouched; ++k) {
+        uint64_t who = wave_ballot(touched && rank == k);
+        int b = __builtin_ctzll(who);
+        int st = bcast_i(s.a_state, b);
+        if (st != ARB_FIRST) continue;
+        int pk = bcast_i(pairKey, b);
+        bool keep = cb_begin(pk >> 8, pk & 0xFF, lane, s, rew);
+        if (!keep && lane == b) s.a_state = ARB_IGNORE;
+      }
+
+      // ---- expiry of untouched slots (cpSpaceArbiterSetFilter; no `separate` handlers in Driving) -----------
+      bool freeMe = false;
+      if (slotOcc && !touched) {
+        s.a_age += 1;
+        if (s.a_state != ARB_CACHED) s.a_state = ARB_CACHED;
+        if (s.a_age >= 3) freeMe = true;
+      }
+      const uint64_t freeMask = wave_ballot(freeMe);
+
+      // ---- publish velocities (callbacks may have zeroed a pedestrian) for prestep --------------------------
+      if (lane < DRV_NB) {
+        L.vx[lane] = s.vx; L.vy[lane] = s.vy; L.w[lane] = s.w; L.vbx[lane] = s.vbx; L.vby[lane] = s.vby; L.wb[lane] = s.wb;
+      }
+      __syncthreads();
+
+      // ---- active arbiters: levels (arbiters sharing a dynamic body keep their canonical sequential order) --
+      const bool active = touched && s.a_state != ARB_IGNORE;
+      const uint64_t activeMask = wave_ballot(active);
+      int myLevel = 0, maxLevel = -1, blvl = 0;
+      for (int k = 0; k < nTouched; ++k) {
+        uint64_t who = wave_ballot(active && rank == k);
+        if (who == 0ull) continue;
+        int b = __builtin_ctzll(who);
+        int ba = bcast_i(bodyA, b), bb2 = bcast_i(bodyB, b);
+        int la = ba < DRV_SLOT_OBST ? bcast_i(blvl, ba) : 0;
+        int lb = bb2 < DRV_SLOT_OBST ? bcast_i(blvl, bb2) : 0;
+        int lv = la > lb ? la : lb;
+        if (lane == b) myLevel = lv;
+        if (lane == ba || lane == bb2) blvl = lv + 1;  // static indices (>= 30) never equal a body lane (< 30)
+        maxLevel = lv > maxLevel ? lv : maxLevel;
+      }
+
+      // ---- prestep (cpArbiterPreStep) on velocities BEFORE the friction update -------------------------------
+      double nMass[2] = {0.0, 0.0}, tMass[2] = {0.0, 0.0}, bias[2] = {0.0, 0.0}, bounce[2] = {0.0, 0.0}, jBias[2] = {0.0, 0.0};
+      double jn[2] = {s.a_jn0, s.a_jn1}, jt[2] = {s.a_jt0, s.a_jt1};
+      const double arb_e = 0.05 * 0.05, arb_u = 0.0 * 0.0;
+      if (active) {
+        BodyV a, b;
+        body_load(L, bodyA, a);
+        body_load(L, bodyB, b);
+        V2 body_delta = vsub(b.p, a.p);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          if (c < s.a_count) {
+            nMass[c] = 1.0 / (k_scalar_body(a, r1[c], n) + k_scalar_body(b, r2[c], n));
+            tMass[c] = 1.0 / (k_scalar_body(a, r1[c], vperp(n)) + k_scalar_body(b, r2[c], vperp(n)));
+            double dist = vdot(vadd(vsub(r2[c], r1[c]), body_delta), n);
+            bias[c] = -DE_CONTACT_BIAS_COEF * fmin_cp(0.0, dist + DE_COLLISION_SLOP) / DE_DT;
+            jBias[c] = 0.0;
+            bounce[c] = vdot(relative_velocity(a, b, r1[c], r2[c]), n) * arb_e;
+          }
+        }
+      }
+      __syncthreads();
+
+      // ---- velocity update (velocity_func: friction_* or default) -------------------------------------------
+      if (isCar) {
+        if (s.fric) apply_friction(s.vx, s.vy, s.w, m, 5e-4, 2e-5, 0.0); else apply_friction(s.vx, s.vy, s.w, m, 5e-5, 1e-5, 0.0);
+      } else if (isPed) {
+        if (s.dead) apply_friction(s.vx, s.vy, s.w, m, 5e-2, 2e-4, 0.0);
+        else { s.vx = s.vx * 1.0 + (0.0 + 0.0) * DE_DT; s.vy = s.vy * 1.0 + (0.0 + 0.0) * DE_DT; s.w = s.w * 1.0 + 0.0; }
+      }
+      if (activeMask) {
+        if (lane < DRV_NB) { L.vx[lane] = s.vx; L.vy[lane] = s.vy; L.w[lane] = s.w; }
+        __syncthreads();
+        // ---- warm start (cpArbiterApplyCachedImpulse; skipped on first contact), level by level ------------
+        for (int lv = 0; lv <= maxLevel; ++lv) {
+          if (active && myLevel == lv && s.a_state != ARB_FIRST) {
+            BodyV a, b;
+            body_load(L, bodyA, a);
+            body_load(L, bodyB, b);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              if (c < s.a_count) {
+                V2 j = vrotate(n, v2(jn[c], jt[c]));
+                j = vmul(j, 1.0);  // dt_coef = dt/prev_dt = 1
+                apply_impulse(a, vneg(j), r1[c]);
+                apply_impulse(b, j, r2[c]);
+              }
+            }
+            body_store_vel(L, bodyA, a);
+            body_store_vel(L, bodyB, b);
+          }
+          __syncthreads();
+        }
+        // ---- 10 sequential-impulse iterations (cpArbiterApplyImpulse) ---------------------------------------
+        for (int iter = 0; iter < 10; ++iter) {
+          for (int lv = 0; lv <= maxLevel; ++lv) {
+            if (active && myLevel == lv) {
+              BodyV a, b;
+              body_load(L, bodyA, a);
+              body_load(L, bodyB, b);
+#pragma unroll
+              for (int c = 0; c < 2; ++c) {
+                if (c < s.a_count) {
+                  V2 vb1 = vadd(a.vb, vmul(vperp(r1[c]), a.wb));
+                  V2 vb2 = vadd(b.vb, vmul(vperp(r2[c]), b.wb));
+                  V2 vr = relative_velocity(a, b, r1[c], r2[c]);
+                  double vbn = vdot(vsub(vb2, vb1), n);
+                  double vrn = vdot(vr, n);
+                  double vrt = vdot(vr, vperp(n));
+                  double jbn = (bias[c] - vbn) * nMass[c];
+                  double jbnOld = jBias[c];
+                  jBias[c] = fmax_cp(jbnOld + jbn, 0.0);
+                  double jnn = -(bounce[c] + vrn) * nMass[c];
+                  double jnOld = jn[c];
+                  jn[c] = fmax_cp(jnOld + jnn, 0.0);
+                  double jtMax = arb_u * jn[c];
+                  double jtt = -vrt * tMass[c];
+                  double jtOld = jt[c];
+                  jt[c] = fclamp_cp(jtOld + jtt, -jtMax, jtMax);
+                  V2 jb = vmul(n, jBias[c] - jbnOld);
+                  apply_bias_impulse(a, vneg(jb), r1[c]);
+                  apply_bias_impulse(b, jb, r2[c]);
+                  V2 jj = vrotate(n, v2(jn[c] - jnOld, jt[c] - jtOld));
+                  apply_impulse(a, vneg(jj), r1[c]);
+                  apply_impulse(b, jj, r2[c]);
+                }
+              }
+              body_store_vel(L, bodyA, a);
+              body_store_vel(L, bodyB, b);
+            }
+            __syncthreads();
+          }
+        }
+        if (lane < DRV_NB && isBody) {
+          s.vx = L.vx[lane]; s.vy = L.vy[lane]; s.w = L.w[lane]; s.vbx = L.vbx[lane]; s.vby = L.vby[lane]; s.wb = L.wb[lane];
+        }
+        if (active) { s.a_jn0 = jn[0]; s.a_jt0 = jt[0]; s.a_jn1 = jn[1]; s.a_jt1 = jt[1]; }
+      }
+      // arbiters that were active this step are NORMAL from the next step on (cpSpaceStep resets the state)
+      if (active && s.a_state == ARB_FIRST) s.a_state = ARB_NORMAL;
+      if (freeMe) { s.a_pair = 0xFFFF; L.slotPair[lane] = 0xFFFF; }
+      occ &= ~freeMask;
+      __syncthreads();
+    }
+
+    // ---------------- bookkeeping :280-287 ------------------------------------------------------------------
+    elapsed += 1;
+    const bool allFin = wave_ballot(isCar && !(s.finished && !s.crashed)) == 0ull;
+    if (!allFinished && allFin) {
+      allFinished = 1;
+      teamReward += (double)(DRV_MAX_TIME - elapsed) / 100.0;
+    }
+  }
+
+  // ---------------- end of env step :300-322 ----------------------------------------------------------------
+  if (isCar) {
+    rew += teamReward;
+    posrew += dm_max(0.0, teamReward);
+    double* er = S.epr + (size_t)e * 16 + lane;
+    double* ep = S.epr + (size_t)S.E * 16 + (size_t)e * 16 + lane;
+    *er = *er + rew;
+    *ep = *ep + posrew;
+    rewards[(size_t)e * A + lane] = rew;
+  }
+  if (lane == 0) {
+    dones[e] = (uint8_t)(elapsed >= DRV_MAX_TIME);
+    envi[EI_ELAPSED] = elapsed; envi[EI_ALLFIN] = allFinished; envi[EI_OCC] = (int)(uint32_t)occ;
+  }
+  const uint64_t errMask = wave_ballot(err != 0);
+  if (errMask && lane == 0) envi[EI_ERR] = envi[EI_ERR] | 1;
+  store_lane(S, e, lane, isCar, isPed, occ, s);
+  if (obs) {
+    write_full_obs(L, lane, A, nPed, nObst, S.obs_dim, obs + (size_t)e * A * S.obs_dim, isCar, isPed, s.px, s.py, s.ang,
+                   s.type, s.finished, s.goalx, s.goaly);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// observation-only kernel (used after reset / set_state)
+// ------------------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(64) drv_obs_kernel(DrvState S, float* __restrict__ obs) {
+  __shared__ DrvLds L;
+  const int e = blockIdx.x, lane = threadIdx.x, A = S.A;
+  const int* envi = S.envi + (size_t)e * EI_COUNT;
+  const int nPed = uniform_i(envi[EI_NPED]), nObst = uniform_i(envi[EI_NOBST]);
+  const bool isCar = lane < A, isPed = lane >= DRV_SLOT_PED && lane < DRV_SLOT_PED + nPed;
+  LaneState s;
+  load_lane(S, e, lane, isCar, isPed, 0ull, s);
+  if (lane < DRV_MAXO) {
+    L.ox[lane] = lane < nObst ? S.obst[(size_t)e * DRV_MAXO + lane] : 0.0;
+    L.oy[lane] = lane < nObst ? S.obst[(size_t)S.E * DRV_MAXO + (size_t)e * DRV_MAXO + lane] : 0.0;
+  }
+  __syncthreads();
+  write_full_obs(L, lane, A, nPed, nObst, S.obs_dim, obs + (size_t)e * A * S.obs_dim, isCar, isPed, s.px, s.py, s.ang, s.type,
+                 s.finished, s.goalx, s.goaly);
+}
+
+// ------------------------------------------------------------------------------------------------
+// reset kernel: scene re-randomisation, one thread per environment
+// (environment_base.py:205-211 -> DrivingEnvironment._setup_scene :58-115, :527-584).  Not on the per-step path.
+// ------------------------------------------------------------------------------------------------
+DE_DEV void road_get_spot(const DrvRoad& r, int lane, int spot, V2& pos, double& angle) {  // Road.py:100-114
+  int end = lane >= r.nLanes ? 1 : 0;
+  V2 p = end ? r.p1 : r.p0;
+  V2 spotDir = vmul(end ? vneg(r.dir) : r.dir, r.followDist);
+  V2 laneDir = vmul(end ? r.normal : vneg(r.normal), r.width);
+  double l = (double)(end ? lane - r.nLanes : lane) + 0.5;
+  pos = vadd(vadd(p, vmul(laneDir, l)), vmul(spotDir, (double)spot));
+  angle = dm_atan2(spotDir.y, spotDir.x);
+}
+DE_DEV V2 road_get_walk_spot(const DrvRoad& r, int side, double length, double width) {  // Road.py:117-123
+  V2 w0 = r.walk[side][0], w1 = r.walk[side][1];
+  V2 center = vadd(w0, vmul(vsub(w1, w0), length));
+  double f = width * r.width;
+  V2 off = vmul(vmul(r.normal, f), side ? 1.0 : -1.0);
+  return vadd(center, off);
+}
+
+extern "C" __global__ void __launch_bounds__(64) drv_reset_kernel(DrvState S) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= S.E) return;
+  const size_t E = (size_t)S.E;
+  const int A = S.A;
+  int* envi = S.envi + (size_t)e * EI_COUNT;
+  const uint32_t ep = (uint32_t)envi[EI_EPISODE];
+  const uint32_t genv = (uint32_t)(S.env_id_offset + e);
+  // zero this env's rows
+  for (int k = 0; k < DRV_NB; ++k) {
+    for (int f = 0; f < BF_COUNT; ++f) S.body[(size_t)f * E * DRV_NB + (size_t)e * DRV_NB + k] = 0.0;
+    S.flags[(size_t)e * DRV_NB + k] = 0;
+    S.aux[(size_t)e * DRV_NB + k] = 0;
+  }
+  for (int k = 0; k < 16; ++k) {
+    for (int f = 0; f < CF_COUNT; ++f) S.carx[(size_t)f * E * 16 + (size_t)e * 16 + k] = 0.0;
+    S.epr[(size_t)e * 16 + k] = 0.0;
+    S.epr[E * 16 + (size_t)e * 16 + k] = 0.0;
+  }
+  for (int k = 0; k < DRV_NS; ++k) { S.s_pair[(size_t)e * DRV_NS + k] = 0xFFFF; S.s_meta[(size_t)e * DRV_NS + k] = 0; }
+  // cars: spots = permutation(30)[:A] (partial Fisher-Yates), road/end/team/type draws
+  int spots[30];
+  for (int i = 0; i < 30; ++i) spots[i] = i;
+  for (int i = 0; i < A; ++i) {
+    dm_u32x4 u = dm_env_rng(S.seed, genv, ep, DM_RNG_RESET_PERM, (uint32_t)i, 0);
+    int j = i + dm_randint(u.v[0], 0, 29 - i);
+    int t = spots[i]; spots[i] = spots[j]; spots[j] = t;
+  }
+  for (int i = 0; i < A; ++i) {
+    dm_u32x4 u = dm_env_rng(S.seed, genv, ep, DM_RNG_RESET_AGENT, (uint32_t)i, 0);
+    int roadSel = dm_randint(u.v[0], 0, 1), endSel = dm_randint(u.v[1], 0, 1);
+    int team = dm_randint(u.v[2], 0, 2), type = dm_randint(u.v[3], 0, 3);
+    V2 goal = endSel ? C.roads[roadSel].p1 : C.roads[roadSel].p0;
+    int spotID = spots[i];
+    int roadID = spotID < 20 ? 0 : 1;
+    spotID -= roadID ? 20 : 0;
+    int laneID = spotID / 5, spot = spotID % 5;
+    V2 pos; double angle;
+    road_get_spot(C.roads[roadID], laneID, spot, pos, angle);
+    V2 dir = vrot_angle(v2(1.0, 0.0), angle);
+    size_t b = (size_t)e * DRV_NB + i;
+    S.body[BF_PX * E * DRV_NB + b] = pos.x; S.body[BF_PY * E * DRV_NB + b] = pos.y; S.body[BF_ANG * E * DRV_NB + b] = angle;
+    size_t c = (size_t)e * 16 + i;
+    S.carx[CF_DIRX * E * 16 + c] = dir.x; S.carx[CF_DIRY * E * 16 + c] = dir.y;
+    S.carx[CF_PREVX * E * 16 + c] = pos.x; S.carx[CF_PREVY * E * 16 + c] = pos.y;
+    S.carx[CF_GOALX * E * 16 + c] = goal.x; S.carx[CF_GOALY * E * 16 + c] = goal.y;
+    S.flags[b] = CARF_PACK(type, team, 0, 0, 0, LP_OffRoad);
+  }
+  dm_u32x4 uc = dm_env_rng(S.seed, genv, ep, DM_RNG_RESET_COUNTS, 0, 0);
+  int nPed = dm_randint(uc.v[0], 10, 20), nObstRaw = dm_randint(uc.v[1], 10, 20);
+  for (int i = 0; i < nPed; ++i) {
+    dm_u32x4 a = dm_env_rng(S.seed, genv, ep, DM_RNG_RESET_PED, (uint32_t)i, 0);
+    dm_u32x4 bq = dm_env_rng(S.seed, genv, ep, DM_RNG_RESET_PED, (uint32_t)i, 1);
+    int road = dm_randint(a.v[0], 0, 1), side = dm_randint(a.v[1], 0, 1);
+    double len = dm_unit(a.v[2]), wid = dm_unit(a.v[3]) / 2.0 + 0.25;
+    V2 p = road_get_walk_spot(C.roads[road], side, len, wid);
+    size_t b = (size_t)e * DRV_NB + DRV_SLOT_PED + i;
+    S.body[BF_PX * E * DRV_NB + b] = p.x; S.body[BF_PY * E * DRV_NB + b] = p.y;
+    S.flags[b] = PEDF_PACK(road, side, 0, 0, 0, dm_randint(bq.v[0], 3, 6));
+  }
+  int nObst = 0;
+  for (int i = 0; i < nObstRaw; ++i) {
+    dm_u32x4 a = dm_env_rng(S.seed, genv, ep, DM_RNG_RESET_OBST, (uint32_t)i, 0);
+    int road = dm_randint(a.v[0], 0, 1), side = dm_randint(a.v[1], 0, 1);
+    double len = dm_unit(a.v[2]), wid = dm_unit(a.v[3]) / 2.0 + 0.25;
+    V2 c = road_get_walk_spot(C.roads[road], side, len, wid);
+    if (drv_is_off_road(c)) {
+      S.obst[(size_t)e * DRV_MAXO + nObst] = c.x;
+      S.obst[E * DRV_MAXO + (size_t)e * DRV_MAXO + nObst] = c.y;
+      nObst++;
+    }
+  }
+  envi[EI_ELAPSED] = 0; envi[EI_ALLFIN] = 0; envi[EI_NPED] = nPed; envi[EI_NOBST] = nObst;
+  envi[EI_EPISODE] = (int)(ep + 1); envi[EI_OCC] = 0; envi[EI_ERR] = 0;
+}
+
+// episode_g = [#finished & !crashed, #crashed] (:315-316) + episode accumulators, gathered for the host mirror
+extern "C" __global__ void drv_stats_kernel(DrvState S, double* ep_r, double* ep_pos_r, double* ep_obs_r, int* goals) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= S.E) return;
+  int fin = 0, crashed = 0;
+  for (int a = 0; a < S.A; ++a) {
+    int f = S.flags[(size_t)e * DRV_NB + a];
+    int fi = (f >> 4) & 1, cr = (f >> 5) & 1;
+    fin += fi && !cr;
+    crashed += cr;
+    if (ep_r) ep_r[(size_t)e * S.A + a] = S.epr[(size_t)e * 16 + a];
+    if (ep_pos_r) ep_pos_r[(size_t)e * S.A + a] = S.epr[(size_t)S.E * 16 + (size_t)e * 16 + a];
+    if (ep_obs_r) ep_obs_r[(size_t)e * S.A + a] = 0.0;
+  }
+  if (goals) { goals[2 * e] = fin; goals[2 * e + 1] = crashed; }
+}
+
+extern "C" __global__ void drv_counts_kernel(DrvState S, int* counts) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= S.E) return;
+  counts[2 * e] = S.envi[(size_t)e * EI_COUNT + EI_NOBST];
+  counts[2 * e + 1] = S.envi[(size_t)e * EI_COUNT + EI_NPED];
+}
+
+// deterministic-math self test (bit-compare against the host evaluation in tests/)
+extern "C" __global__ void math_selftest_kernel(const double* x, const double* y, int n, double* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s, c;
+  dm_sincos(x[i], &s, &c);
+  out[5 * i + 0] = s; out[5 * i + 1] = c; out[5 * i + 2] = dm_atan2(y[i], x[i]);
+  out[5 * i + 3] = dm_sqrt(dm_abs(x[i])); out[5 * i + 4] = (y[i] != 0.0) ? x[i] / y[i] : 0.0;
+}

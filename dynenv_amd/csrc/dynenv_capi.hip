@@ -1,0 +1,356 @@
+// dynenv_capi.hip — the C ABI of include/dynenv.h on top of the gfx950 kernels (single translation unit).
+// Host code only does allocation, constant upload and launches.  There is NO CPU fallback: without a usable HIP
+// device every entry point fails with DYNENV_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "driving_kernels.hip"
+#include "dynenv.h"
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIP_OK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t _e = (expr);                                                                            \
+    if (_e != hipSuccess)                                                                              \
+      return fail(DYNENV_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+  } while (0)
+
+struct dynenv {
+  dynenv_cfg_t cfg;
+  int A, obs_dim, T, action_dim;
+  DrvState S;
+  std::vector<void*> allocs;
+};
+
+// ---------------------------------------------------------------------------------------------- constants
+static void road_init_host(DrvRoad& r, int nLanes, double width, V2 p0, V2 p1) {  // Road.py:11-33
+  V2 d = vsub(p1, p0);
+  r.nLanes = nLanes; r.width = width; r.p0 = p0; r.p1 = p1; r.followDist = 90.0;
+  r.length = vlen(d);
+  r.dir = v2(d.x / r.length, d.y / r.length);
+  r.normal = vrot_angle(r.dir, DM_PI / 2.0);
+  r.dirAngle = dm_atan2(r.dir.y, r.dir.x);
+  double k = (double)(nLanes + 1) * width;
+  r.walk[0][0] = vadd(p0, vmul(r.normal, k)); r.walk[0][1] = vadd(p1, vmul(r.normal, k));
+  r.walk[1][0] = vsub(p0, vmul(r.normal, k)); r.walk[1][1] = vsub(p1, vmul(r.normal, k));
+}
+
+static double moment_for_box(double m, double hx, double hy) {  // cpMomentForPoly on Car.points (Car.py:21-23)
+  V2 verts[4] = {v2(hx, hy), v2(-hx, hy), v2(-hx, -hy), v2(hx, -hy)};
+  double sum1 = 0.0, sum2 = 0.0;
+  for (int i = 0; i < 4; ++i) {
+    V2 a1 = verts[i], a2 = verts[(i + 1) % 4];
+    double a = vcross(a2, a1);
+    double b = vdot(a1, a1) + vdot(a1, a2) + vdot(a2, a2);
+    sum1 += a * b; sum2 += a;
+  }
+  return (m * sum1) / (6.0 * sum2);
+}
+
+static double norm_obs_host(double pt, double nf, double mean) { return ((pt * nf) - mean) * 2.0 * 1.0; }
+
+static void build_consts(DrvConst& c) {
+  memset(&c, 0, sizeof(c));
+  road_init_host(c.roads[0], 2, 35.0, v2(875.0, 0.0), v2(875.0, 1000.0));  // DrivingEnvironment.py:110-115
+  road_init_host(c.roads[1], 1, 35.0, v2(0.0, 500.0), v2(1750.0, 500.0));
+  // lane rows of getFullState (:689-695) incl. the negative-index quirk `Lanes[i - nLanes]`
+  int row = 0;
+  for (int r = 0; r < 2; ++r) {
+    const DrvRoad& l = c.roads[r];
+    int n = l.nLanes, cnt = 2 * n + 1;
+    for (int i = -n; i <= n; ++i) {
+      int idx = ((i - n) % cnt + cnt) % cnt;
+      double s = (double)(idx - n) * l.width;
+      V2 a = vadd(l.p0, vmul(l.normal, s)), b = vadd(l.p1, vmul(l.normal, s));
+      c.laneRows[row * 5 + 0] = (float)norm_obs_host(a.x, 0.5 / (DRV_W + 100.0), 0.0);
+      c.laneRows[row * 5 + 1] = (float)norm_obs_host(a.y, 0.5 / (DRV_H + 100.0), 0.0);
+      c.laneRows[row * 5 + 2] = (float)norm_obs_host(b.x, 0.5 / (DRV_W + 100.0), 0.0);
+      c.laneRows[row * 5 + 3] = (float)norm_obs_host(b.y, 0.5 / (DRV_H + 100.0), 0.0);
+      c.laneRows[row * 5 + 4] = (float)((i == n || i == -n) ? 1 : (i == 0 ? -1 : 0));
+      ++row;
+    }
+  }
+  const double masses[4] = {1200, 1800, 3500, 5000}, widths[4] = {5, 6, 7, 8}, lengths[4] = {10, 15, 20, 25},
+               powers[4] = {3, 4, 3, 4};  // Car.py:9-12
+  for (int t = 0; t < 4; ++t) {
+    c.carMass[t] = masses[t]; c.carHx[t] = lengths[t]; c.carHy[t] = widths[t]; c.carPower[t] = powers[t];
+    c.carInertia[t] = moment_for_box(masses[t], lengths[t], widths[t]);
+  }
+  c.pedMass = 90.0;  // Pedestrian.py:11-14
+  c.pedInertia = 90.0 * (0.5 * (0.0 * 0.0 + 5.0 * 5.0) + 0.0);
+  // canonical pair order: (car i, partner j) for i ascending, j ascending over cars>i, peds, obstacles, buildings
+  int p = 0;
+  for (int i = 0; i < DRV_MAXA; ++i) {
+    for (int j = i + 1; j < DRV_MAXA; ++j) c.pairs[p++] = (uint16_t)((i << 8) | j);
+    for (int j = DRV_SLOT_PED; j < DRV_SLOT_BLD + 4; ++j) c.pairs[p++] = (uint16_t)((i << 8) | j);
+  }
+  for (; p < DRV_NPAIR_ROUNDS * 64; ++p) c.pairs[p] = 0xFFFF;
+}
+
+// ---------------------------------------------------------------------------------------------- helpers
+template <typename T>
+static int dev_alloc(dynenv* h, T** out, size_t count) {
+  void* p = nullptr;
+  HIP_OK(hipMalloc(&p, count * sizeof(T)));
+  HIP_OK(hipMemset(p, 0, count * sizeof(T)));
+  h->allocs.push_back(p);
+  *out = (T*)p;
+  return 0;
+}
+
+extern "C" {
+
+int dynenv_abi_version(void) { return DYNENV_ABI_VERSION; }
+const char* dynenv_last_error(void) { return g_err.c_str(); }
+
+int dynenv_create(const dynenv_cfg_t* cfg, dynenv_t** out) {
+  if (!cfg || !out) return fail(DYNENV_ERR_ARG, "null argument");
+  if (cfg->abi_version != DYNENV_ABI_VERSION) return fail(DYNENV_ERR_ARG, "ABI version mismatch");
+  if (cfg->num_envs <= 0 || cfg->n_players <= 0) return fail(DYNENV_ERR_ARG, "num_envs and n_players must be > 0");
+  if (cfg->noise_magnitude < 0 || cfg->noise_magnitude > 5)
+    return fail(DYNENV_ERR_ARG, "Error: The noise magnitude must be between 0 and 5!");  // environment_base.py:162-164
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(DYNENV_ERR_NO_DEVICE, "no HIP device visible: libdynenv_hip has no CPU fallback");
+  if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(DYNENV_ERR_ARG, "device_id out of range");
+  HIP_OK(hipSetDevice(cfg->device_id));
+  if (cfg->env_type != DYNENV_DRIVE) return fail(DYNENV_ERR_UNSUPPORTED, "RoboCup not built yet");
+  if (cfg->obs_type != DYNENV_OBS_FULL) return fail(DYNENV_ERR_UNSUPPORTED, "only Full observations are built");
+  dynenv* h = new dynenv();
+  h->cfg = *cfg;
+  h->A = cfg->n_players > DRV_MAXA ? DRV_MAXA : cfg->n_players;  // environment_base.py:57
+  h->obs_dim = 9 + (h->A - 1) * 7 + DRV_MAXO * 4 + DRV_MAXP * 2 + DRV_LANE_ROWS * 5;
+  h->T = 1;
+  h->action_dim = 2;
+  DrvState& S = h->S;
+  memset(&S, 0, sizeof(S));
+  const size_t E = (size_t)cfg->num_envs;
+  S.E = (int)E; S.A = h->A; S.obs_dim = h->obs_dim; S.seed = cfg->seed; S.env_id_offset = cfg->env_id_offset;
+  int rc = 0;
+  rc |= dev_alloc(h, &S.body, (size_t)BF_COUNT * E * DRV_NB);
+  rc |= dev_alloc(h, &S.carx, (size_t)CF_COUNT * E * 16);
+  rc |= dev_alloc(h, &S.flags, E * DRV_NB);
+  rc |= dev_alloc(h, &S.aux, E * DRV_NB);
+  rc |= dev_alloc(h, &S.obst, 2 * E * DRV_MAXO);
+  rc |= dev_alloc(h, &S.envi, E * EI_COUNT);
+  rc |= dev_alloc(h, &S.epr, 2 * E * 16);
+  rc |= dev_alloc(h, &S.s_pair, E * DRV_NS);
+  rc |= dev_alloc(h, &S.s_meta, E * DRV_NS);
+  rc |= dev_alloc(h, &S.s_hash, 2 * E * DRV_NS);
+  rc |= dev_alloc(h, &S.s_imp, 4 * E * DRV_NS);
+  if (rc) { dynenv_destroy(h); return DYNENV_ERR_HIP; }
+  DrvConst c;
+  build_consts(c);
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(C), &c, sizeof(c));
+  if (e != hipSuccess) { dynenv_destroy(h); return fail(DYNENV_ERR_HIP, hipGetErrorString(e)); }
+  *out = h;
+  return DYNENV_OK;
+}
+
+void dynenv_destroy(dynenv_t* h) {
+  if (!h) return;
+  hipSetDevice(h->cfg.device_id);
+  for (void* p : h->allocs) hipFree(p);
+  delete h;
+}
+
+int dynenv_layout(const dynenv_t* h, dynenv_layout_t* L) {
+  if (!h || !L) return fail(DYNENV_ERR_ARG, "null argument");
+  memset(L, 0, sizeof(*L));
+  int A = h->A;
+  L->num_envs = h->cfg.num_envs; L->n_agents = A; L->n_time_steps = h->T; L->obs_dim = h->obs_dim;
+  L->action_dim = h->action_dim;
+  L->n_blocks = 5;
+  L->block_offset[0] = 0; L->block_rows[0] = 1; L->block_feat[0] = 9;
+  L->block_offset[1] = 9; L->block_rows[1] = A - 1; L->block_feat[1] = 7;
+  L->block_offset[2] = 9 + (A - 1) * 7; L->block_rows[2] = DRV_MAXO; L->block_feat[2] = 4;
+  L->block_offset[3] = L->block_offset[2] + DRV_MAXO * 4; L->block_rows[3] = DRV_MAXP; L->block_feat[3] = 2;
+  L->block_offset[4] = L->block_offset[3] + DRV_MAXP * 2; L->block_rows[4] = DRV_LANE_ROWS; L->block_feat[4] = 5;
+  L->steps_per_episode = DRV_MAX_TIME / 10;
+  return DYNENV_OK;
+}
+
+int dynenv_seed(dynenv_t* h, uint64_t seed) {
+  if (!h) return fail(DYNENV_ERR_ARG, "null handle");
+  h->cfg.seed = seed;
+  h->S.seed = seed;
+  return DYNENV_OK;
+}
+
+int dynenv_reset(dynenv_t* h, float* obs_dev, void* stream) {
+  if (!h) return fail(DYNENV_ERR_ARG, "null handle");
+  hipStream_t st = (hipStream_t)stream;
+  HIP_OK(hipSetDevice(h->cfg.device_id));
+  int E = h->S.E;
+  hipLaunchKernelGGL(drv_reset_kernel, dim3((E + 63) / 64), dim3(64), 0, st, h->S);
+  if (obs_dev) hipLaunchKernelGGL(drv_obs_kernel, dim3(E), dim3(64), 0, st, h->S, obs_dev);
+  HIP_OK(hipGetLastError());
+  return DYNENV_OK;
+}
+
+int dynenv_step(dynenv_t* h, const int32_t* actions_dev, float* obs_dev, double* rewards_dev, uint8_t* dones_dev,
+                void* stream) {
+  if (!h || !actions_dev || !rewards_dev || !dones_dev) return fail(DYNENV_ERR_ARG, "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(drv_step_kernel, dim3(h->S.E), dim3(64), 0, st, h->S, (const int*)actions_dev, obs_dev, rewards_dev,
+                     dones_dev);
+  HIP_OK(hipGetLastError());
+  return DYNENV_OK;
+}
+
+int dynenv_counts(dynenv_t* h, int32_t* counts_dev, void* stream) {
+  if (!h || !counts_dev) return fail(DYNENV_ERR_ARG, "null argument");
+  int E = h->S.E;
+  hipLaunchKernelGGL(drv_counts_kernel, dim3((E + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->S, (int*)counts_dev);
+  HIP_OK(hipGetLastError());
+  return DYNENV_OK;
+}
+
+int dynenv_episode_stats(dynenv_t* h, double* ep_r, double* ep_pos_r, double* ep_obs_r, int32_t* goals, void* stream) {
+  if (!h) return fail(DYNENV_ERR_ARG, "null handle");
+  int E = h->S.E;
+  hipLaunchKernelGGL(drv_stats_kernel, dim3((E + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->S, ep_r, ep_pos_r, ep_obs_r,
+                     (int*)goals);
+  HIP_OK(hipGetLastError());
+  return DYNENV_OK;
+}
+
+size_t dynenv_state_size(const dynenv_t* h) { (void)h; return sizeof(dynenv_driving_state_t); }
+
+int dynenv_sync(dynenv_t* h, void* stream) {
+  if (!h) return fail(DYNENV_ERR_ARG, "null handle");
+  HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+  return DYNENV_OK;
+}
+
+// error flags raised by the kernels (bit0: contact cache overflow), OR-ed over all envs
+int dynenv_error_flags(dynenv_t* h, int32_t* out) {
+  if (!h || !out) return fail(DYNENV_ERR_ARG, "null argument");
+  HIP_OK(hipDeviceSynchronize());
+  std::vector<int> envi((size_t)h->S.E * EI_COUNT);
+  HIP_OK(hipMemcpy(envi.data(), h->S.envi, envi.size() * sizeof(int), hipMemcpyDeviceToHost));
+  int f = 0;
+  for (int e = 0; e < h->S.E; ++e) f |= envi[(size_t)e * EI_COUNT + EI_ERR];
+  *out = f;
+  return DYNENV_OK;
+}
+
+int dynenv_get_state(dynenv_t* h, int32_t env, void* blob, size_t nbytes) {
+  if (!h || !blob) return fail(DYNENV_ERR_ARG, "null argument");
+  if (env < 0 || env >= h->S.E || nbytes < sizeof(dynenv_driving_state_t)) return fail(DYNENV_ERR_ARG, "bad env index / size");
+  HIP_OK(hipSetDevice(h->cfg.device_id));
+  HIP_OK(hipDeviceSynchronize());
+  const DrvState& S = h->S;
+  const size_t E = (size_t)S.E;
+  double body[BF_COUNT][DRV_NB], carx[CF_COUNT][16], obst[2][DRV_MAXO], epr[2][16];
+  int flags[DRV_NB], aux[DRV_NB], envi[EI_COUNT];
+  for (int f = 0; f < BF_COUNT; ++f)
+    HIP_OK(hipMemcpy(body[f], S.body + (size_t)f * E * DRV_NB + (size_t)env * DRV_NB, sizeof(double) * DRV_NB, hipMemcpyDeviceToHost));
+  for (int f = 0; f < CF_COUNT; ++f)
+    HIP_OK(hipMemcpy(carx[f], S.carx + (size_t)f * E * 16 + (size_t)env * 16, sizeof(double) * 16, hipMemcpyDeviceToHost));
+  for (int f = 0; f < 2; ++f) {
+    HIP_OK(hipMemcpy(obst[f], S.obst + (size_t)f * E * DRV_MAXO + (size_t)env * DRV_MAXO, sizeof(double) * DRV_MAXO, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(epr[f], S.epr + (size_t)f * E * 16 + (size_t)env * 16, sizeof(double) * 16, hipMemcpyDeviceToHost));
+  }
+  HIP_OK(hipMemcpy(flags, S.flags + (size_t)env * DRV_NB, sizeof(flags), hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(aux, S.aux + (size_t)env * DRV_NB, sizeof(aux), hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(envi, S.envi + (size_t)env * EI_COUNT, sizeof(envi), hipMemcpyDeviceToHost));
+  dynenv_driving_state_t* st = (dynenv_driving_state_t*)blob;
+  memset(st, 0, sizeof(*st));
+  st->elapsed = envi[EI_ELAPSED]; st->all_finished = envi[EI_ALLFIN]; st->n_cars = S.A;
+  st->n_peds = envi[EI_NPED]; st->n_obst = envi[EI_NOBST]; st->episode = envi[EI_EPISODE];
+  for (int i = 0; i < DYNENV_MAX_CARS; ++i) { st->episode_r[i] = epr[0][i]; st->episode_pos_r[i] = epr[1][i]; }
+  for (int i = 0; i < S.A; ++i) {
+    dynenv_car_state_t& c = st->cars[i];
+    c.px = body[BF_PX][i]; c.py = body[BF_PY][i]; c.vx = body[BF_VX][i]; c.vy = body[BF_VY][i];
+    c.angle = body[BF_ANG][i]; c.w = body[BF_W][i];
+    c.dirx = carx[CF_DIRX][i]; c.diry = carx[CF_DIRY][i]; c.prevx = carx[CF_PREVX][i]; c.prevy = carx[CF_PREVY][i];
+    c.goalx = carx[CF_GOALX][i]; c.goaly = carx[CF_GOALY][i];
+    int f = flags[i];
+    c.type = f & 3; c.team = (f >> 2) & 3; c.finished = (f >> 4) & 1; c.crashed = (f >> 5) & 1;
+    c.fric = (f >> 6) & 1; c.lane_pos = (f >> 8) & 7;
+  }
+  for (int i = 0; i < st->n_peds; ++i) {
+    dynenv_ped_state_t& p = st->peds[i];
+    int l = DRV_SLOT_PED + i, f = flags[l];
+    p.px = body[BF_PX][l]; p.py = body[BF_PY][l]; p.vx = body[BF_VX][l]; p.vy = body[BF_VY][l];
+    p.road = f & 1; p.side = (f >> 1) & 1; p.dead = (f >> 2) & 1; p.crossing = (f >> 3) & 1;
+    p.begin_crossing = (f >> 4) & 1; p.speed = (f >> 8) & 15; p.moving = aux[l];
+  }
+  for (int i = 0; i < st->n_obst; ++i) { st->obst_x[i] = obst[0][i]; st->obst_y[i] = obst[1][i]; }
+  return DYNENV_OK;
+}
+
+int dynenv_set_state(dynenv_t* h, int32_t env, const void* blob, size_t nbytes) {
+  if (!h || !blob) return fail(DYNENV_ERR_ARG, "null argument");
+  if (env < 0 || env >= h->S.E || nbytes < sizeof(dynenv_driving_state_t)) return fail(DYNENV_ERR_ARG, "bad env index / size");
+  const dynenv_driving_state_t* st = (const dynenv_driving_state_t*)blob;
+  if (st->n_cars != h->S.A || st->n_peds > DRV_MAXP || st->n_obst > DRV_MAXO || st->n_peds < 0 || st->n_obst < 0)
+    return fail(DYNENV_ERR_ARG, "state blob does not match this handle's layout");
+  HIP_OK(hipSetDevice(h->cfg.device_id));
+  HIP_OK(hipDeviceSynchronize());
+  const DrvState& S = h->S;
+  const size_t E = (size_t)S.E;
+  double body[BF_COUNT][DRV_NB] = {}, carx[CF_COUNT][16] = {}, obst[2][DRV_MAXO] = {}, epr[2][16] = {};
+  int flags[DRV_NB] = {}, aux[DRV_NB] = {}, envi[EI_COUNT] = {};
+  for (int i = 0; i < S.A; ++i) {
+    const dynenv_car_state_t& c = st->cars[i];
+    body[BF_PX][i] = c.px; body[BF_PY][i] = c.py; body[BF_VX][i] = c.vx; body[BF_VY][i] = c.vy;
+    body[BF_ANG][i] = c.angle; body[BF_W][i] = c.w;
+    carx[CF_DIRX][i] = c.dirx; carx[CF_DIRY][i] = c.diry; carx[CF_PREVX][i] = c.prevx; carx[CF_PREVY][i] = c.prevy;
+    carx[CF_GOALX][i] = c.goalx; carx[CF_GOALY][i] = c.goaly;
+    flags[i] = CARF_PACK(c.type & 3, c.team & 3, c.finished & 1, c.crashed & 1, c.fric & 1, c.lane_pos & 7);
+  }
+  for (int i = 0; i < st->n_peds; ++i) {
+    const dynenv_ped_state_t& p = st->peds[i];
+    int l = DRV_SLOT_PED + i;
+    body[BF_PX][l] = p.px; body[BF_PY][l] = p.py; body[BF_VX][l] = p.vx; body[BF_VY][l] = p.vy;
+    flags[l] = PEDF_PACK(p.road & 1, p.side & 1, p.dead & 1, p.crossing & 1, p.begin_crossing & 1, p.speed & 15);
+    aux[l] = p.moving;
+  }
+  for (int i = 0; i < st->n_obst; ++i) { obst[0][i] = st->obst_x[i]; obst[1][i] = st->obst_y[i]; }
+  for (int i = 0; i < DYNENV_MAX_CARS; ++i) { epr[0][i] = st->episode_r[i]; epr[1][i] = st->episode_pos_r[i]; }
+  envi[EI_ELAPSED] = st->elapsed; envi[EI_ALLFIN] = st->all_finished; envi[EI_NPED] = st->n_peds;
+  envi[EI_NOBST] = st->n_obst; envi[EI_EPISODE] = st->episode; envi[EI_OCC] = 0; envi[EI_ERR] = 0;
+  for (int f = 0; f < BF_COUNT; ++f)
+    HIP_OK(hipMemcpy(S.body + (size_t)f * E * DRV_NB + (size_t)env * DRV_NB, body[f], sizeof(double) * DRV_NB, hipMemcpyHostToDevice));
+  for (int f = 0; f < CF_COUNT; ++f)
+    HIP_OK(hipMemcpy(S.carx + (size_t)f * E * 16 + (size_t)env * 16, carx[f], sizeof(double) * 16, hipMemcpyHostToDevice));
+  for (int f = 0; f < 2; ++f) {
+    HIP_OK(hipMemcpy(S.obst + (size_t)f * E * DRV_MAXO + (size_t)env * DRV_MAXO, obst[f], sizeof(double) * DRV_MAXO, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(S.epr + (size_t)f * E * 16 + (size_t)env * 16, epr[f], sizeof(double) * 16, hipMemcpyHostToDevice));
+  }
+  HIP_OK(hipMemcpy(S.flags + (size_t)env * DRV_NB, flags, sizeof(flags), hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(S.aux + (size_t)env * DRV_NB, aux, sizeof(aux), hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(S.envi + (size_t)env * EI_COUNT, envi, sizeof(envi), hipMemcpyHostToDevice));
+  return DYNENV_OK;
+}
+
+int dynenv_math_selftest(const double* x, const double* y, int32_t n, double* out, int32_t device_id) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(DYNENV_ERR_NO_DEVICE, "no HIP device visible");
+  HIP_OK(hipSetDevice(device_id));
+  double *dx = nullptr, *dy = nullptr, *dout = nullptr;
+  HIP_OK(hipMalloc((void**)&dx, sizeof(double) * n));
+  HIP_OK(hipMalloc((void**)&dy, sizeof(double) * n));
+  HIP_OK(hipMalloc((void**)&dout, sizeof(double) * n * 5));
+  HIP_OK(hipMemcpy(dx, x, sizeof(double) * n, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(dy, y, sizeof(double) * n, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(math_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, dx, dy, n, dout);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipMemcpy(out, dout, sizeof(double) * n * 5, hipMemcpyDeviceToHost));
+  hipFree(dx); hipFree(dy); hipFree(dout);
+  return DYNENV_OK;
+}
+
+}  // extern "C"

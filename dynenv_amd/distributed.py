@@ -1,0 +1,87 @@
+"""Multi-GPU sharding: environments are independent, so each rank (one process per GPU) owns a contiguous range of
+global env ids and steps it locally; the only exchange is ONE all-gather per env step of a packed slab
+[ obs f32 | rewards f64 | dones u8 ] (RCCL over xGMI through torch.distributed backend "nccl"; "gloo" in CPU tests).
+
+RNG streams are keyed by GLOBAL env id (dynenv_cfg.env_id_offset), so per-env results are invariant to the number of
+shards.  If the consumer (policy) is itself data-parallel, pass gather=False and skip the collective entirely.
+"""
+import numpy as np
+
+
+def shard_range(total_envs, rank, world_size):
+    """Contiguous env ranges: rank g owns [g*E/G, (g+1)*E/G)."""
+    if total_envs % world_size:
+        raise ValueError("total_envs must be divisible by world_size")
+    per = total_envs // world_size
+    return rank * per, per
+
+
+class PackedSlab(object):
+    """One flat byte buffer per rank holding obs|rewards|dones so a single collective moves a whole step."""
+
+    def __init__(self, torch, device, E, T, A, D):
+        self.torch = torch
+        self.E, self.T, self.A, self.D = E, T, A, D
+        self.obs_bytes = E * T * A * D * 4
+        self.rew_off = (self.obs_bytes + 255) // 256 * 256
+        self.rew_bytes = E * A * 8
+        self.done_off = (self.rew_off + self.rew_bytes + 255) // 256 * 256
+        self.nbytes = (self.done_off + E + 255) // 256 * 256
+        self.buf = torch.zeros((self.nbytes,), dtype=torch.uint8, device=device)
+        self.obs, self.rewards, self.dones = self.views(self.buf)
+
+    def views(self, buf):
+        t = self.torch
+        obs = buf[:self.obs_bytes].view(t.float32).view(self.E, self.T, self.A, self.D)
+        rew = buf[self.rew_off:self.rew_off + self.rew_bytes].view(t.float64).view(self.E, self.A)
+        dones = buf[self.done_off:self.done_off + self.E]
+        return obs, rew, dones
+
+    def gathered_views(self, gbuf, world_size):
+        """Zero-copy [G, E_loc, ...] views into the gathered buffer."""
+        t = self.torch
+        g = gbuf.view(world_size, self.nbytes)
+        obs = g[:, :self.obs_bytes].view(t.float32).view(world_size, self.E, self.T, self.A, self.D)
+        rew = g[:, self.rew_off:self.rew_off + self.rew_bytes].view(t.float64).view(world_size, self.E, self.A)
+        dones = g[:, self.done_off:self.done_off + self.E]
+        return obs, rew, dones
+
+
+class StepGather(object):
+    """All-gather of the packed step outputs.  Works on any backend (nccl=RCCL on MI355X, gloo on CPU)."""
+
+    def __init__(self, torch, dist, slab, group=None):
+        self.torch, self.dist, self.slab, self.group = torch, dist, slab, group
+        self.world_size = dist.get_world_size(group)
+        self.gbuf = torch.zeros((self.world_size * slab.nbytes,), dtype=torch.uint8, device=slab.buf.device)
+
+    def __call__(self):
+        self.dist.all_gather_into_tensor(self.gbuf, self.slab.buf, group=self.group)
+        return self.slab.gathered_views(self.gbuf, self.world_size)
+
+
+class ShardedDynEnv(object):
+    """One process per GPU: local BatchedDynEnv over this rank's env range + optional end-of-step all-gather."""
+
+    def __init__(self, env_type, total_envs, num_players, gather=True, seed=42, **kw):
+        import torch
+        import torch.distributed as dist
+        from .vec_env import BatchedDynEnv
+        self.rank, self.world_size = dist.get_rank(), dist.get_world_size()
+        off, per = shard_range(total_envs, self.rank, self.world_size)
+        device = kw.pop("device", "cuda:%d" % torch.cuda.current_device())
+        probe = BatchedDynEnv(env_type, 1, num_players, seed=seed, device=device, **kw)
+        T, A, D = probe.n_time_steps, probe.n_agents, probe.obs_dim
+        probe.close()
+        self.slab = PackedSlab(torch, torch.device(device), per, T, A, D)
+        self.env = BatchedDynEnv(env_type, per, num_players, seed=seed, device=device, env_id_offset=off,
+                                 out_buffers=(self.slab.obs, self.slab.rewards, self.slab.dones), **kw)
+        self.gather = StepGather(torch, dist, self.slab) if gather else None
+
+    def reset(self):
+        self.env.reset_flat()
+        return self.gather() if self.gather else (self.env.obs, self.env.rewards, self.env.dones)
+
+    def step(self, local_actions):
+        self.env.step_flat(local_actions)
+        return self.gather() if self.gather else (self.env.obs, self.env.rewards, self.env.dones)

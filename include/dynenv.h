@@ -149,10 +149,9 @@ int dynenv_set_state(dynenv_t* h, int32_t env_idx, const void* host_blob, size_t
 
 int dynenv_sync(dynenv_t* h, void* stream);
 
-/* Time `launches` back-to-back dynenv_step launches with HIP events on `stream` (ms total); used by bench.py for
- * the roofline's per-launch duration. */
-int dynenv_time_steps(dynenv_t* h, const int32_t* actions_dev, float* obs_dev, double* rewards_dev,
-                      uint8_t* dones_dev, void* stream, int32_t launches, float* ms_total);
+/* OR over all environments of the kernels' error flags (bit 0: contact cache overflow, a pair was dropped).
+ * Synchronises the device. */
+int dynenv_error_flags(dynenv_t* h, int32_t* out);
 
 /* Device self-test of the deterministic math header: evaluates sincos/atan2/sqrt/div on n host-provided doubles and
  * returns the raw results so tests can compare them bit-for-bit with the host evaluation. out: [n,5]. */

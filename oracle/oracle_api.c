@@ -1,6 +1,7 @@
 /* oracle_api.c — ORACLE (test infrastructure): host-pointer C API mirroring include/dynenv.h so that tests/,
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg can drive the CPU restatement exactly like the HIP
  * library.  Nothing in dynenv_amd/ may load this. */
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -191,4 +192,69 @@ double oracle_moment_for_box(double m, double hx, double hy) { return cpMomentFo
 double oracle_moment_for_circle(double m, double r1, double r2) { return cpMomentForCircle(m, r1, r2); }
 double oracle_moment_for_segment(double m, double ax, double ay, double bx, double by, double r) {
   return cpMomentForSegment(m, cpv_(ax, ay), cpv_(bx, by), r);
+}
+
+/* ---- two-body physics sandbox for closed-form KATs (tests/test_oracle_physics.py) ----
+ * shape kind: 0 circle(radius=sx), 1 capsule (half-length sx, radius sy, along local x), 2 box (half extents sx,sy)
+ * in[b] = {kind, sx, sy, mass(<=0: static), px, py, vx, vy, angle, w, e, u}; out[b] = {px,py,vx,vy,angle,w}; returns
+ * the number of substeps in which the pair had an active arbiter. */
+int oracle_sandbox_two_body(const double* in, int steps, double* out) {
+  cpSpace sp; cpBody body[2]; cpShape shape[2];
+  int b, s, touched = 0;
+  cpSpaceInit(&sp);
+  for (b = 0; b < 2; ++b) {
+    const double* p = in + 12 * b;
+    int kind = (int)p[0];
+    double m = p[3], I;
+    if (kind == 0) I = cpMomentForCircle(m, 0.0, p[1]);
+    else if (kind == 1) I = cpMomentForSegment(m, cpv_(-p[1], 0.0), cpv_(p[1], 0.0), p[2]);
+    else I = cpMomentForBox(m, p[1], p[2]);
+    cpBodyInit(&body[b], m, I, m > 0.0 ? CP_BODY_DYNAMIC : CP_BODY_STATIC);
+    body[b].p = cpv_(p[4], p[5]); body[b].v = cpv_(p[6], p[7]); body[b].w = p[9];
+    cpBodySetAngle(&body[b], p[8]);
+    if (kind == 0) cpCircleInit(&shape[b], &body[b], p[1], b);
+    else if (kind == 1) cpSegmentInit(&shape[b], &body[b], cpv_(-p[1], 0.0), cpv_(p[1], 0.0), p[2], b);
+    else cpBoxInit(&shape[b], &body[b], p[1], p[2], b);
+    shape[b].e = p[10]; shape[b].u = p[11]; shape[b].collision_type = b;
+    cpSpaceAddBody(&sp, &body[b]);
+    cpSpaceAddShape(&sp, &shape[b]);
+  }
+  for (s = 0; s < steps; ++s) { cpSpaceStep(&sp, 0.01); touched += sp.n_active > 0; }
+  for (b = 0; b < 2; ++b) {
+    out[6 * b + 0] = body[b].p.x; out[6 * b + 1] = body[b].p.y; out[6 * b + 2] = body[b].v.x;
+    out[6 * b + 3] = body[b].v.y; out[6 * b + 4] = body[b].a; out[6 * b + 5] = body[b].w;
+  }
+  return touched;
+}
+
+/* two capsule bodies joined like Robot.py:58-60 (PivotJoint error_bias=0.1 + RotaryLimitJoint(0,0)); the left one
+ * gets velocity (vx,vy) and angular velocity w0; returns state of both after `steps` substeps. */
+void oracle_sandbox_robot_joint(double vx, double vy, double w0, int steps, double* out) {
+  cpSpace sp; cpBody body[2]; cpShape shape[2]; cpConstraint pivot, rot;
+  int b, s;
+  cpSpaceInit(&sp);
+  for (b = 0; b < 2; ++b) {
+    double y = b ? -10.0 : 10.0;
+    double I = cpMomentForSegment(4000.0, cpv_(-10.0, y), cpv_(10.0, y), 7.5);
+    cpBodyInit(&body[b], 4000.0, I, CP_BODY_DYNAMIC);
+    body[b].p = cpv_(100.0, 100.0);
+    cpSegmentInit(&shape[b], &body[b], cpv_(-10.0, y), cpv_(10.0, y), 7.5, b);
+    shape[b].e = 0.3; shape[b].u = 2.5;
+    cpSpaceAddBody(&sp, &body[b]); cpSpaceAddShape(&sp, &shape[b]);
+  }
+  cpPivotJointInit(&pivot, &body[0], &body[1], cpv_(100.0, 100.0));
+  pivot.errorBias = 0.1;
+  cpRotaryLimitJointInit(&rot, &body[0], &body[1], 0.0, 0.0);
+  cpSpaceAddConstraint(&sp, &pivot); cpSpaceAddConstraint(&sp, &rot);
+  body[0].v = cpv_(vx, vy); body[0].w = w0;
+  for (s = 0; s < steps; ++s) cpSpaceStep(&sp, 0.01);
+  for (b = 0; b < 2; ++b) {
+    out[6 * b + 0] = body[b].p.x; out[6 * b + 1] = body[b].p.y; out[6 * b + 2] = body[b].v.x;
+    out[6 * b + 3] = body[b].v.y; out[6 * b + 4] = body[b].a; out[6 * b + 5] = body[b].w;
+  }
+}
+double oracle_bias_coef(int which) {
+  cpSpace sp; cpSpaceInit(&sp);
+  if (which == 0) return 1.0 - pow(sp.collisionBias, 0.01);
+  return 1.0 - pow(0.1, 0.01);
 }

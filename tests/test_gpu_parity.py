@@ -1,0 +1,235 @@
+"""GPU parity tests proper: the HIP path (through the C ABI, via dynenv_amd) against the CPU oracle on the same seeds.
+
+Bar (BASELINE.json north_star): reward/done bit-exact, float positions/velocities <= 1e-4 relative.  Because both
+sides use the deterministic math header with FMA contraction off, we assert the stronger property: EVERYTHING is
+bit-identical (observations, rewards, dones and the full state blob).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    import dynenv_amd
+    from dynenv_amd import _capi
+    ol.build()
+    return dynenv_amd, _capi, torch
+
+
+def _assert_state_equal(sg, so, msg=""):
+    dg, do = ol.state_to_dict(sg), ol.state_to_dict(so)
+    for k in do:
+        np.testing.assert_array_equal(dg[k], do[k], err_msg="%s field %s" % (msg, k))
+
+
+def test_detmath_bitwise_device_vs_host(gpu):
+    _, _capi, _ = gpu
+    lib = _capi.load()
+    rng = np.random.default_rng(1)
+    n = 1 << 18
+    x = np.concatenate([(rng.random(n // 2) - 0.5) * 2000.0, (rng.random(n // 2) - 0.5) * 8.0])
+    y = np.concatenate([(rng.random(n // 2) - 0.5) * 2000.0, (rng.random(n // 2) - 0.5) * 1e-3])
+    x[:8] = [0.0, -0.0, np.pi / 2, -np.pi / 2, -np.pi, np.pi, 1e-10, 90.0]
+    y[:8] = [1.0, -1.0, 0.0, -0.0, -0.0, 0.0, 1e300, -0.0]
+    dev = np.zeros((n, 5))
+    host = np.zeros((n, 5))
+    rc = lib.dynenv_math_selftest(x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), n,
+                                  dev.ctypes.data_as(C.c_void_p), 0)
+    assert rc == 0, lib.dynenv_last_error()
+    ol.lib().oracle_math(x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), n, host.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(dev.view(np.uint64), host.view(np.uint64)), \
+        "sincos/atan2/sqrt/div must be bit-identical on gfx950 and the host (columns: %s)" % \
+        np.nonzero((dev.view(np.uint64) != host.view(np.uint64)).any(0))[0]
+
+
+@pytest.mark.parametrize("A,E,seed", [(10, 64, 42), (2, 8, 5), (7, 16, 9)])
+def test_reset_parity(gpu, A, E, seed):
+    dynenv_amd, _, _ = gpu
+    env = dynenv_amd.BatchedDynEnv(dynenv_amd.DynEnvType.DRIVE, E, A, seed=seed)
+    ora = ol.OracleEnv(num_envs=E, n_players=A, seed=seed)
+    og = env.reset_flat().cpu().numpy()
+    oc = ora.reset()
+    np.testing.assert_array_equal(og, oc)
+    np.testing.assert_array_equal(env.counts().cpu().numpy(), ora.counts())
+    for e in range(0, E, max(1, E // 8)):
+        _assert_state_equal(env.get_state(e), ora.get_state(e), "env %d" % e)
+    env.close()
+
+
+@pytest.mark.parametrize("A,E,seed,steps", [(10, 64, 42, 120), (2, 8, 5, 100), (10, 32, 1234, 600)])
+def test_step_parity_random_actions(gpu, A, E, seed, steps):
+    """configs[0] (nPlayers=2) and configs[1] (nPlayers=10) at oracle-sized batches; the 600-step case crosses a
+    whole episode incl. the terminal step."""
+    dynenv_amd, _, _ = gpu
+    env = dynenv_amd.BatchedDynEnv(dynenv_amd.DynEnvType.DRIVE, E, A, seed=seed)
+    ora = ol.OracleEnv(num_envs=E, n_players=A, seed=seed, threads=8)
+    env.reset_flat()
+    ora.reset()
+    rng = np.random.default_rng(seed)
+    contacts = 0
+    for s in range(steps):
+        a = rng.integers(0, 3, size=(E, A, 2)).astype(np.int32)
+        og, rg, dg = env.step_flat(a, auto_reset=False)
+        oc, rc, dc = ora.step(a)
+        contacts += sum(ora.active_contacts(e) > 0 for e in range(E))
+        np.testing.assert_array_equal(rg.cpu().numpy(), rc, err_msg="rewards step %d" % s)
+        np.testing.assert_array_equal(dg.cpu().numpy(), dc, err_msg="dones step %d" % s)
+        np.testing.assert_array_equal(og.cpu().numpy(), oc, err_msg="obs step %d" % s)
+        if s % 20 == 19 or s == steps - 1:
+            for e in range(0, E, max(1, E // 4)):
+                _assert_state_equal(env.get_state(e), ora.get_state(e), "step %d env %d" % (s, e))
+    assert env.error_flags() == 0 and ora.overflow() == 0
+    if steps >= 600:
+        assert contacts > 0, "the long run must exercise the contact solver"
+        assert dc.all()
+        sg = [x.cpu().numpy() for x in env.episode_stats()]
+        so = ora.episode_stats()
+        for g, o in zip(sg, so):
+            np.testing.assert_array_equal(g, o)
+    env.close()
+
+
+def _scenario(kind):
+    """Hand-built collision scenes (set_state on both sides): analytically meaningful contact cases."""
+    st = ol.DrivingState()
+    st.n_cars, st.n_peds, st.n_obst, st.episode = 10, 2, 2, 1
+    for i in range(10):  # park the unused cars far apart on the vertical road's right lane
+        c = st.cars[i]
+        c.px, c.py, c.angle = 892.5, 40.0 + 95.0 * i, np.pi / 2
+        c.dirx, c.diry = 6.123233995736766e-17, 1.0
+        c.prevx, c.prevy, c.goalx, c.goaly = c.px, c.py, 875.0, 1000.0
+        c.type, c.lane_pos = i % 4, 4
+    for k in range(2):
+        p = st.peds[k]
+        p.px, p.py, p.road, p.side, p.speed, p.moving = 700.0 + 30 * k, 440.0, 1, 0, 4, 100000
+    st.obst_x[0], st.obst_y[0] = 200.0, 440.0
+    st.obst_x[1], st.obst_y[1] = 1500.0, 560.0
+    a, b = st.cars[0], st.cars[1]
+    if kind == "head_on":  # two cars on the horizontal road driving into each other
+        a.px, a.py, a.angle, a.vx, a.vy = 400.0, 517.5, 0.0, 60.0, 0.0
+        a.dirx, a.diry = 1.0, 0.0
+        b.px, b.py, b.angle, b.vx, b.vy = 480.0, 517.5, -np.pi, -45.0, 0.0
+        b.dirx, b.diry = -1.0, -1.2246467991473532e-16
+    elif kind == "oblique":  # rotated box hits a moving box off-centre -> spin + 1 or 2 contact points
+        a.px, a.py, a.angle, a.vx, a.vy = 400.0, 510.0, 0.3, 50.0, 10.0
+        a.dirx, a.diry = np.cos(0.3), np.sin(0.3)
+        b.px, b.py, b.angle, b.vx, b.vy = 455.0, 530.0, 2.0, -30.0, -5.0
+        b.dirx, b.diry = np.cos(2.0), np.sin(2.0)
+    elif kind == "obstacle":  # car slides into a static obstacle box and comes to rest against it
+        a.px, a.py, a.angle, a.vx, a.vy = 160.0, 442.0, 0.0, 90.0, 0.0
+        a.dirx, a.diry = 1.0, 0.0
+    elif kind == "building":  # car leaves the road into a building wall (rests there => persistent contacts)
+        a.px, a.py, a.angle, a.vx, a.vy = 500.0, 440.0, -np.pi / 2 + 0.2, 5.0, -40.0
+        a.dirx, a.diry = np.cos(a.angle), np.sin(a.angle)
+    elif kind == "ped_fast":  # fast car kills a pedestrian (pedHit returns True: solved) and crashes
+        a.px, a.py, a.angle, a.vx, a.vy = 660.0, 482.5, 0.0, 55.0, 0.0
+        a.dirx, a.diry = 1.0, 0.0
+        st.peds[0].py = 484.0
+    elif kind == "ped_slow":  # slow car touches a pedestrian: pedHit returns False -> ignored until separation
+        a.px, a.py, a.angle, a.vx, a.vy = 683.0, 482.5, 0.0, 0.9, 0.0
+        a.dirx, a.diry = 1.0, 0.0
+        st.peds[0].py = 484.0
+        st.peds[0].vx = -1.0
+    elif kind == "pileup":  # three cars in a row + the building: chained arbiters share bodies (multi-level solve)
+        a.px, a.py, a.angle, a.vx, a.vy = 300.0, 480.0, 0.0, 70.0, -8.0
+        a.dirx, a.diry = 1.0, 0.0
+        b.px, b.py, b.angle, b.vx, b.vy = 345.0, 478.0, 0.1, 0.0, 0.0
+        b.dirx, b.diry = np.cos(0.1), np.sin(0.1)
+        c = st.cars[2]
+        c.px, c.py, c.angle, c.vx, c.vy = 388.0, 474.0, -0.4, -70.0, -3.0
+        c.dirx, c.diry = np.cos(-0.4), np.sin(-0.4)
+    for c in (st.cars[0], st.cars[1], st.cars[2]):
+        c.prevx, c.prevy = c.px, c.py
+    return st
+
+
+@pytest.mark.parametrize("kind", ["head_on", "oblique", "obstacle", "building", "ped_fast", "ped_slow", "pileup"])
+def test_collision_scenarios(gpu, kind):
+    dynenv_amd, _, _ = gpu
+    env = dynenv_amd.BatchedDynEnv(dynenv_amd.DynEnvType.DRIVE, 2, 10, seed=3)
+    ora = ol.OracleEnv(num_envs=2, n_players=10, seed=3)
+    env.reset_flat()
+    ora.reset()
+    st = _scenario(kind)
+    for e in range(2):
+        env.set_state(e, st)
+        ora.set_state(e, st)
+    acts = np.ones((2, 10, 2), np.int32)  # coast
+    touched = 0
+    for s in range(40):
+        if s == 10 and kind != "ped_slow":
+            acts[:, 0, 0] = 2  # accelerate into whatever we are resting against
+        og, rg, dg = env.step_flat(acts, auto_reset=False)
+        oc, rc, dc = ora.step(acts)
+        touched += ora.active_contacts(0)
+        np.testing.assert_array_equal(rg.cpu().numpy(), rc, err_msg="%s rewards step %d" % (kind, s))
+        np.testing.assert_array_equal(og.cpu().numpy(), oc, err_msg="%s obs step %d" % (kind, s))
+        _assert_state_equal(env.get_state(0), ora.get_state(0), "%s step %d" % (kind, s))
+    if kind != "ped_slow":
+        assert touched > 0, "scenario %s never produced an active contact" % kind
+    assert env.error_flags() == 0
+    env.close()
+
+
+def test_full_size_properties(gpu):
+    """configs[1] at BASELINE size (4096 envs): size-independent properties over a whole episode + auto-reset."""
+    dynenv_amd, _, torch = gpu
+    E, A = 4096, 10
+    env = dynenv_amd.BatchedDynEnv(dynenv_amd.DynEnvType.DRIVE, E, A, seed=42)
+    obs0 = env.reset_flat().clone()
+    st0 = [env.get_state(e) for e in (0, 1000, 4095)]
+    g = torch.Generator(device="cuda").manual_seed(0)
+    total = torch.zeros((E, A), dtype=torch.float64, device="cuda")
+    for s in range(600):
+        a = torch.randint(0, 3, (E, A, 2), generator=g, device="cuda", dtype=torch.int32)
+        obs, rew, done = env.step_flat(a, auto_reset=False)
+        total += rew
+        assert bool(done.all()) == (s == 599)
+    assert torch.isfinite(obs).all() and torch.isfinite(total).all()
+    ep_r, ep_p, _, goals = env.episode_stats()
+    # the per-step rewards telescope into the episode accumulator (DrivingEnvironment.py:300-304)
+    assert torch.allclose(ep_r, total, rtol=0, atol=1e-9)
+    assert bool((ep_p >= 0).all())
+    assert int(goals.sum(1).max()) <= A
+    assert env.error_flags() == 0
+    # spot-check three envs of the big batch against the oracle run on the same global env ids (shard invariance)
+    for st, e in zip(st0, (0, 1000, 4095)):
+        ora = ol.OracleEnv(num_envs=1, n_players=A, seed=42, env_id_offset=e)
+        ora.reset()
+        _assert_state_equal(st, ora.get_state(0), "env %d at reset" % e)
+    # lock-step auto reset returns the next episode's first observation
+    env.reset_flat()
+    assert not torch.equal(env.obs, obs0)
+    env.close()
+
+
+def test_vec_env_compat_surface(gpu):
+    """make_dyn_env drop-in: same call shape and return structure as the reference's SubprocVecEnv path."""
+    dynenv_amd, _, _ = gpu
+    from dynenv_amd import DynEnvType, NoiseType, ObservationType, make_dyn_env
+    venv, name = make_dyn_env(DynEnvType.DRIVE, 3, 2, False, ObservationType.FULL, NoiseType.REALISTIC, 0, False)
+    assert name == "Driving" and venv.num_envs == 3
+    obs = venv.reset()
+    assert obs.shape == (3, 1, 2, 3) and obs.dtype == object
+    cars, obst, peds = obs[0, 0, 0, 0]
+    selfr, lanes = obs[0, 0, 0, 1]
+    assert cars.shape == (1, 7) and selfr.shape == (1, 9) and lanes.shape == (8, 5) and obst.shape[1] == 4 and peds.shape[1] == 2
+    assert obs[0, 0, 0, 2] == (1, 1, 1)
+    acts = np.ones((3, 2, 2), np.int64)
+    obs, rew, dones, infos = venv.step(acts)
+    assert rew.shape == (3, 2) and rew.dtype == np.float64 and dones.shape == (3,) and len(infos) == 3
+    assert set(infos[0]) >= {"Full State", "Recon States"} and infos[0]["Full State"][0].shape == (2, 7)
+    with pytest.raises(Exception):
+        venv.step(np.ones((3, 2, 3), np.int64))
+    assert venv.get_attr("stepNum")[0] == 600.0
+    assert len(venv.env_method("get_agent_locs")[0]) == 2
+    assert venv.action_space.spaces[0].nvec.tolist() == [3, 3]
+    venv.close()
