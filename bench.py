@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the batched DynEnv step() on MI355X (contract: see the task prompt / DESIGN.md §Measurement).
+
+A "step" = one environment step (10 fused physics substeps + Full observation + rewards) of EVERY environment of
+this rank's shard = one launch of drv_step_kernel.  Workload = BASELINE.json configs[1]: DrivingEnvironment
+nPlayers=10, Full obs, noise 0, 4096 envs per GPU (weak scaling over GPUs, env ids sharded by rank, one RCCL
+all-gather of the packed obs|reward|done slab per step when N > 1).  Inputs (actions) are resident in HBM before
+the timed region; lock-step episode resets (every 600 steps) are inside it.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--no-cpu-baseline]
+  N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# Algorithmic HBM bytes per Driving env-step, A=10, Full obs (derivation in DESIGN.md):
+# actions 20 + state read 2550 + state write 2230 + obs 10*232*4 (+8 counts) + rewards 80 + done 1
+B_ALG_DRIVING_FULL_A10 = 20 + 2550 + 2230 + (9280 + 8) + 80 + 1
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def cpu_baseline(E, A, seed, target_seconds=12.0):
+    """The CPU restatement (oracle, kind='port') timed on this box's host cores on a bounded sample of the same
+    workload.  It is a C restatement, i.e. a much stronger baseline than the reference's Python+pymunk path, which
+    cannot run here (pymunk absent; the reference never ships to the GPU box)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as ol
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    ol.build()
+    env = ol.OracleEnv(env_type=1, num_envs=E, n_players=A, seed=seed, threads=cores)
+    env.reset()
+    rng = np.random.default_rng(0)
+    acts = [rng.integers(0, 3, size=(E, A, 2)).astype(np.int32) for _ in range(8)]
+    env.step(acts[0])  # touch memory
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        env.step(acts[n % 8])
+        n += 1
+        dt = time.perf_counter() - t0
+        if (dt >= target_seconds and n >= 5) or n >= 600:
+            break
+    value = E * n * A / dt
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": value, "unit": "agent-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d env-steps of the same %d-env Driving nPlayers=%d workload (first %d steps of an episode), "
+                      "oracle/liboracle.so with %d OpenMP threads, %.1f s" % (n, E, A, n, cores, dt),
+            "cpu_model": model}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1200)   # 2 full episodes
+    ap.add_argument("--warmup", type=int, default=600)   # 1 full episode
+    ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
+    ap.add_argument("--players", type=int, default=10)
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="skip the end-of-step all-gather (data-parallel consumer)")
+    args = ap.parse_args()
+
+    import torch
+    from dynenv_amd import BatchedDynEnv, DynEnvType
+    from dynenv_amd.distributed import PackedSlab, StepGather
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 through torch.distributed.run (one process per GPU)")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    E, A = args.envs, args.players
+    slab = gather = None
+    out_buffers = None
+    if world > 1 and not args.no_gather:
+        probe = BatchedDynEnv(DynEnvType.DRIVE, 1, A, device=device)
+        T, D = probe.n_time_steps, probe.obs_dim
+        probe.close()
+        slab = PackedSlab(torch, device, E, T, A, D)
+        out_buffers = (slab.obs, slab.rewards, slab.dones)
+        gather = StepGather(torch, dist, slab)
+    env = BatchedDynEnv(DynEnvType.DRIVE, E, A, seed=args.seed, device=device, env_id_offset=rank * E,
+                        out_buffers=out_buffers)
+    # synthetic inputs: i.i.d. uniform actions (action_space MultiDiscrete([3,3])), resident in HBM
+    g = torch.Generator(device=device).manual_seed(1234 + rank)
+    pool = [torch.randint(0, 3, (E, A, 2), generator=g, device=device, dtype=torch.int32) for _ in range(64)]
+
+    def one_step(i):
+        env.step_flat(pool[i & 63])
+        if gather is not None:
+            gather()
+
+    env.reset_flat()
+    for i in range(args.warmup):
+        one_step(i)
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(args.steps):
+        one_step(i)
+    ev1.record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    gpu_ms = ev0.elapsed_time(ev1)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    err = env.error_flags()
+
+    # roofline leg: the dominant kernel alone (no resets, no collective), HIP events on the launch stream
+    roofline = None
+    if rank == 0:
+        env.reset_flat()
+        for i in range(50):
+            env.step_flat(pool[i & 63], auto_reset=False)
+        n_launch = 400
+        torch.cuda.synchronize(device)
+        k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        k0.record()
+        for i in range(n_launch):
+            env.step_flat(pool[i & 63], auto_reset=False)
+        k1.record()
+        torch.cuda.synchronize(device)
+        launch_ms = k0.elapsed_time(k1) / n_launch
+        b_alg = B_ALG_DRIVING_FULL_A10 if A == 10 else None
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                with open(pmc) as f:
+                    traffic = json.load(f).get("drv_step_kernel_bytes_per_launch")
+            except (OSError, ValueError):
+                traffic = None
+        if b_alg is not None:
+            achieved = b_alg * E / (launch_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "drv_step_kernel",
+                        "launch_ms": launch_ms, "alg_bytes_per_env_step": b_alg, "env_steps_per_launch": E}
+
+    if rank == 0:
+        env_steps = E * world * args.steps
+        value = env_steps * A / elapsed
+        out = {
+            "metric": "agent-steps/s", "value": value, "unit": "agent-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "DrivingEnvironment nPlayers=%d Full obs, noise=0, %d envs per GPU "
+                                   "(BASELINE.json configs[1]), 10 substeps/step, lock-step resets every 600 steps"
+                                   % (A, E),
+                       "envs_per_gpu": E, "n_players": A, "obs": "full", "gather": bool(gather is not None),
+                       "parallelism": "env-shard x%d" % world},
+            "env_steps_per_s": env_steps / elapsed,
+            "gpu_ms_per_step_rank0": gpu_ms / args.steps,
+            "kernel_error_flags": err,
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(E, A, args.seed)
+        elif not args.no_cpu_baseline:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
