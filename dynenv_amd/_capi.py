@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libdynenv_hip.so")
+LIB_PATH = os.environ.get("DYNENV_HIP_LIB", os.path.join(PKG, "libdynenv_hip.so"))  # override: A/B builds only
 
 DYNENV_ABI_VERSION = 1
 ERR_NO_DEVICE = -2

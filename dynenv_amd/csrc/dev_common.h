@@ -57,6 +57,21 @@ DE_DEV uint64_t uniform_u64(uint64_t v) {
   return ((uint64_t)hi << 32) | lo;
 }
 
+// Out-of-line transcendental wrappers for device code.  sincos/atan2 are only needed when a car's angle changes or a
+// collision callback fires; inlining their polynomial constants into the substep loop makes the compiler hoist dozens
+// of 64-bit literals into registers for the whole loop (=> scratch spills on the hot path).  As small leaf functions
+// they only touch caller-saved registers.
+struct DevSC {
+  double s, c;
+};
+__device__ __noinline__ static DevSC dev_sincos(double x) {
+  DevSC r;
+  dm_sincos(x, &r.s, &r.c);
+  return r;
+}
+__device__ __noinline__ static double dev_atan2(double y, double x) { return dm_atan2(y, x); }
+DE_DEV double dev_cos(double x) { return dev_sincos(x).c; }
+
 #define DE_DBL_MIN 2.2250738585072014e-308
 // Chipmunk space defaults reached through pymunk.Space() (environment_base.py:126-128); values pinned against
 // libm pow() by tests/test_constants.py

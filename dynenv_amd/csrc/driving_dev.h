@@ -13,7 +13,7 @@
 #define DRV_MAXP 20
 #define DRV_MAXO 20
 #define DRV_NB 32          /* dynamic body slots per env (30 used) */
-#define DRV_NS 32          /* persistent arbiter (contact cache) slots per env */
+#define DRV_NS 24          /* persistent arbiter (contact cache) slots per env (LDS budget: 16 envs per CU) */
 #define DRV_NPAIR_ROUNDS 8 /* ceil(485 / 64) */
 #define DRV_SLOT_PED 10
 #define DRV_SLOT_OBST 30
@@ -47,6 +47,7 @@ enum { LP_AtGoal = 0, LP_InRightLane = 1, LP_InOpposingLane = 2, LP_OverRoad = 3
 struct DrvRoad {
   int nLanes;
   double width, length, dirAngle, followDist;
+  double cosDir0; /* dm_cos(dirAngle - 0.0): the pedestrian / obstacle road test always passes angle 0 */
   V2 p0, p1, dir, normal;
   V2 walk[2][2];
 };

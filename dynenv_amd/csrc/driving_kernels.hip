@@ -5,6 +5,10 @@
 // + per-agent rewards, all fused in ONE launch.  One wavefront per environment; see driving_dev.h for the lane roles
 // and DESIGN.md for the roofline discussion.  fp64 throughout (the reference computes in Python float / C double);
 // FMA contraction is OFF so results are bit-identical to the CPU oracle.
+//
+// Register discipline: the LDS tile is the HOME of every per-body quantity; each phase of a substep loads the few
+// values it needs, computes, and stores back.  Nothing but a handful of scalars stays live across phases, so the
+// rare contact path (narrowphase + solver) cannot push the common path into scratch.
 #include "driving_dev.h"
 
 __constant__ DrvConst C;
@@ -14,47 +18,100 @@ __constant__ DrvConst C;
 #endif
 
 // ------------------------------------------------------------------------------------------------
-// LDS tile of one environment
+// LDS tile of one environment (10 KiB budget => 16 environments per CU)
 // ------------------------------------------------------------------------------------------------
-struct __align__(16) DrvLds {
-  double px[DRV_NB], py[DRV_NB], vx[DRV_NB], vy[DRV_NB], w[DRV_NB], vbx[DRV_NB], vby[DRV_NB], wb[DRV_NB];
-  double minv[DRV_NB], iinv[DRV_NB], rc[DRV_NB], rs[DRV_NB];
-  double hx[16], hy[16];
-  double aabb[DRV_MAXA][4];
-  double ox[DRV_MAXO], oy[DRV_MAXO];
-  // mailbox: narrowphase result of the pair that maps to slot s (written by the detecting lane, read by lane s)
-  double mb_p1x[DRV_NS][2], mb_p1y[DRV_NS][2], mb_p2x[DRV_NS][2], mb_p2y[DRV_NS][2], mb_nx[DRV_NS], mb_ny[DRV_NS];
-  int mb_hash[DRV_NS][2], mb_count[DRV_NS], mb_flag[DRV_NS]; /* flag: 1 touched, 2 newly allocated */
-  int slotPair[DRV_NS];
-  // observation staging (f32)
+struct DrvMailbox {  // narrowphase result of the pair that maps to slot s (written by the detecting lane)
+  double p1x[DRV_NS][2], p1y[DRV_NS][2], p2x[DRV_NS][2], p2y[DRV_NS][2], nx[DRV_NS], ny[DRV_NS];
+  int hash[DRV_NS][2], count[DRV_NS], flag[DRV_NS]; /* flag: bit0 touched, bit1 newly allocated */
+};
+struct DrvObsStage {  // f32 staging of the observation rows (only used after the last substep)
   float carRow[DRV_MAXA][8];
   float goal[DRV_MAXA][2];
   float shared[DRV_MAXO * 4 + DRV_MAXP * 2 + DRV_LANE_ROWS * 5];
 };
+struct __align__(16) DrvLds {
+  // dynamic bodies (lane l = body l): home location of the state
+  double px[DRV_NB], py[DRV_NB], vx[DRV_NB], vy[DRV_NB], ang[DRV_NB], w[DRV_NB], vbx[DRV_NB], vby[DRV_NB], wb[DRV_NB];
+  double minv[DRV_NB], iinv[DRV_NB];
+  double rc[DRV_NB], rs[DRV_NB], rotAng[DRV_NB];  // cos/sin of rotAng (recomputed only when the angle changes)
+  // cars
+  double dirx[16], diry[16], prevx[16], prevy[16], goalx[16], goaly[16];
+  double cosRel0[16], cosRel1[16];  // dm_cos(road.dirAngle - rotAng), cached with rc/rs
+  double dprev[16];                 // |prevPos - goal|
+  double cmass[16], cpower[16], chx[16], chy[16];  // per-car constants (Car.py:9-12) copied out of constant memory
+  double aabb[DRV_MAXA][4];
+  int flags[DRV_NB], moving[DRV_NB];
+  double ox[DRV_MAXO], oy[DRV_MAXO];
+  // contact cache slots (lane s = slot s)
+  int s_pair[DRV_NS], s_meta[DRV_NS], s_hash0[DRV_NS], s_hash1[DRV_NS];
+  double s_jn0[DRV_NS], s_jt0[DRV_NS], s_jn1[DRV_NS], s_jt1[DRV_NS];
+  union {
+    DrvMailbox mb;
+    DrvObsStage ob;
+  } u;
+};
+
+// One tile per workgroup (= one wavefront = one environment).  File scope so that the out-of-line contact path
+// addresses it with ds_* instructions instead of flat pointers.
+__shared__ DrvLds g_L;
+
+#define MY_PAIR(t) ((int)((((t) < 4 ? pairLo : pairHi) >> (16 * ((t)&3))) & 0xFFFFull))
+
+// flag-word accessors (layout in driving_dev.h)
+#define CF_FIN(f) (((f) >> 4) & 1)
+#define CF_CRASHED(f) (((f) >> 5) & 1)
+#define CF_FRIC(f) (((f) >> 6) & 1)
+#define CF_LP(f) (((f) >> 8) & 7)
+#define CF_SET_LP(f, lp) (((f) & ~(7 << 8)) | ((lp) << 8))
+#define CF_CRASH_BITS ((1 << 4) | (1 << 5) | (1 << 6)) /* Car.crash(): finished, crashed, friction_car_crashed */
+#define PF_ROAD(f) ((f)&1)
+#define PF_SIDE(f) (((f) >> 1) & 1)
+#define PF_DEAD(f) (((f) >> 2) & 1)
+#define PF_CROSSING(f) (((f) >> 3) & 1)
+#define PF_BEGIN(f) (((f) >> 4) & 1)
+#define PF_SPEED(f) (((f) >> 8) & 15)
 
 // ------------------------------------------------------------------------------------------------
 // game logic (mirrors oracle/driving.c, which cites the reference lines)
 // ------------------------------------------------------------------------------------------------
-DE_DEV int road_is_point_on_road(const DrvRoad& r, V2 point, double angle) {  // Road.py:74-97
-  V2 pt = vsub(point, r.p0);
-  double dist = vcross(r.dir, pt);
-  if (dm_abs(dist) >= (double)r.nLanes * r.width + 5.0) return LP_OffRoad;
+// The two roads are fixed by the reference (DrivingEnvironment.py:110-115).  Their derived constants are spelled as
+// literals here (instead of reading DrvConst) so that the substep loop carries no loop-invariant SGPRs for them; the
+// host checks at dynenv_create() that these literals equal the values it computes with the Road.__init__ arithmetic.
+#define DRV_COS_PI_2 6.123233995736766e-17 /* dm_cos(pi/2) == math.cos(math.pi/2) */
+template <int R>
+struct RoadK;
+template <>
+struct RoadK<0> {  // Road(2, 35, [(875,0),(875,1000)])
+  static constexpr double p0x = 875.0, p0y = 0.0, dirx = 0.0, diry = 1.0, lat = 2.0 * 35.0 + 5.0, length = 1000.0;
+  static constexpr double dirAngle = 1.5707963267948966, cosDir0 = DRV_COS_PI_2, nx = -1.0, ny = DRV_COS_PI_2;
+};
+template <>
+struct RoadK<1> {  // Road(1, 35, [(0,500),(1750,500)])
+  static constexpr double p0x = 0.0, p0y = 500.0, dirx = 1.0, diry = 0.0, lat = 1.0 * 35.0 + 5.0, length = 1750.0;
+  static constexpr double dirAngle = 0.0, cosDir0 = 1.0, nx = DRV_COS_PI_2, ny = 1.0;
+};
+
+// Road.isPointOnRoad (Road.py:74-97) with cos(road.dirAngle - angle) supplied by the caller (cached)
+template <int R>
+DE_DEV int road_pos(V2 point, double cosRel) {
+  V2 pt = vsub(point, v2(RoadK<R>::p0x, RoadK<R>::p0y));
+  double dist = vcross(v2(RoadK<R>::dirx, RoadK<R>::diry), pt);
+  if (dm_abs(dist) >= RoadK<R>::lat) return LP_OffRoad;
   int pos = LP_OverRoad;
-  double dirDist = vdot(r.dir, pt);
-  if (dirDist >= -10.0 && dirDist <= r.length + 10.0) {
-    double relAngle = dm_cos(r.dirAngle - angle) * dist;
+  double dirDist = vdot(v2(RoadK<R>::dirx, RoadK<R>::diry), pt);
+  if (dirDist >= -10.0 && dirDist <= RoadK<R>::length + 10.0) {
+    double relAngle = cosRel * dist;
     pos = relAngle < 0.0 ? LP_InRightLane : LP_InOpposingLane;
   }
   return pos;
 }
 
-DE_DEV bool drv_is_off_road(V2 point) {  // DrivingEnvironment.py:509-520
+DE_DEV bool drv_is_off_road(V2 point) {  // DrivingEnvironment.py:509-520 (angle argument is always 0)
   int position = LP_OffRoad;
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    int rp = road_is_point_on_road(C.roads[r], point, 0.0);
-    if (rp < position) position = rp;
-  }
+  int rp = road_pos<0>(point, RoadK<0>::cosDir0);
+  if (rp < position) position = rp;
+  rp = road_pos<1>(point, RoadK<1>::cosDir0);
+  if (rp < position) position = rp;
   return position >= LP_OverRoad;
 }
 DE_DEV bool drv_is_out(V2 p) { return p.x <= 0.0 || p.y <= 0.0 || p.x >= DRV_W || p.y >= DRV_H; }
@@ -78,6 +135,30 @@ DE_DEV void apply_friction(double& vx, double& vy, double& w, double m, double f
   if (dm_abs(y) < factor) y = 0.0; else y -= a1;
   if (dm_abs(theta) < rotFactor) theta = 0.0; else theta -= (theta > 0.0 ? rotFactor : -rotFactor);
   vx = x; vy = y; w = theta;
+}
+
+// velocity_func of body `lane` on the LDS tile (friction_car / friction_car_crashed / friction_pedestrian_dead /
+// default cpBodyUpdateVelocity)
+DE_DEV void velocity_update(DrvLds& L, int lane, bool isCar, bool isPed) {
+  if (!(isCar || isPed)) return;
+  double vx = L.vx[lane], vy = L.vy[lane], w = L.w[lane];
+  int f = L.flags[lane];
+  if (isCar) {
+    double m = L.cmass[lane];
+    if (CF_FRIC(f)) apply_friction(vx, vy, w, m, 5e-4, 2e-5, 0.0); else apply_friction(vx, vy, w, m, 5e-5, 1e-5, 0.0);
+  } else {
+    if (PF_DEAD(f)) apply_friction(vx, vy, w, C.pedMass, 5e-2, 2e-4, 0.0);
+    else { vx = vx * 1.0 + (0.0 + 0.0) * DE_DT; vy = vy * 1.0 + (0.0 + 0.0) * DE_DT; w = w * 1.0 + 0.0; }
+  }
+  L.vx[lane] = vx; L.vy[lane] = vy; L.w[lane] = w;
+}
+
+// refresh the cached rotation of car `lane` (cpBodySetAngle -> cpvforangle) and the two road-relative cosines
+DE_DEV void car_refresh_rot(DrvLds& L, int lane, double ang) {
+  const DevSC sc = dev_sincos(ang);
+  L.rc[lane] = sc.c; L.rs[lane] = sc.s; L.rotAng[lane] = ang;
+  L.cosRel0[lane] = dev_cos(RoadK<0>::dirAngle - ang);
+  L.cosRel1[lane] = dev_cos(RoadK<1>::dirAngle - ang);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -291,64 +372,60 @@ DE_DEV void apply_bias_impulse(BodyV& b, V2 j, V2 r) {
 #define STD_NORM_H (1.0 / 25.0)
 DE_DEV double normalize_obs(double pt, double nf, double mean) { return ((pt * nf) - mean) * 2.0 * 1.0; }  // cutils.py:318-323
 
-DE_DEV void write_full_obs(DrvLds& L, int lane, int A, int nPed, int nObst, int obs_dim, float* __restrict__ out,
-                           bool isCar, bool isPed, double px, double py, double ang, int type, int finished,
-                           double goalx, double goaly) {
-  if (isCar) {
-    double s, c;
-    dm_sincos(ang, &s, &c);
-    L.carRow[lane][0] = (float)normalize_obs(px, STD_NORM_X, 0.0);
-    L.carRow[lane][1] = (float)normalize_obs(py, STD_NORM_Y, 0.0);
-    L.carRow[lane][2] = (float)c;
-    L.carRow[lane][3] = (float)s;
-    L.carRow[lane][4] = (float)normalize_obs(C.carHy[type], STD_NORM_W, 0.5);  // c.width
-    L.carRow[lane][5] = (float)normalize_obs(C.carHx[type], STD_NORM_H, 0.5);  // c.height
-    L.carRow[lane][6] = (float)finished;
-    L.goal[lane][0] = (float)normalize_obs(goalx, STD_NORM_X, 0.0);
-    L.goal[lane][1] = (float)normalize_obs(goaly, STD_NORM_Y, 0.0);
+DE_DEV float obs_self_or_car(const DrvObsStage& O, int A, int a, int ff) {
+  if (ff < 6) return O.carRow[a][ff];
+  if (ff < 8) return O.goal[a][ff - 6];
+  if (ff == 8) return O.carRow[a][6];
+  int c = (ff - 9) / 7, kk = (ff - 9) - c * 7;
+  c += (c >= a);
+  return O.carRow[c][kk];
+}
+
+// all state is read from the LDS tile; the staging area aliases the (idle) mailbox
+DE_DEV void write_full_obs(DrvLds& L, int lane, int A, int nPed, int nObst, int obs_dim, float* __restrict__ out) {
+  DrvObsStage& O = L.u.ob;
+  __syncthreads();
+  if (lane < A) {
+    int f = L.flags[lane];
+    O.carRow[lane][0] = (float)normalize_obs(L.px[lane], STD_NORM_X, 0.0);
+    O.carRow[lane][1] = (float)normalize_obs(L.py[lane], STD_NORM_Y, 0.0);
+    O.carRow[lane][2] = (float)L.rc[lane];  // rc/rs are cos/sin of the current angle (refreshed on every change)
+    O.carRow[lane][3] = (float)L.rs[lane];
+    O.carRow[lane][4] = (float)normalize_obs(L.chy[lane], STD_NORM_W, 0.5);  // c.width
+    O.carRow[lane][5] = (float)normalize_obs(L.chx[lane], STD_NORM_H, 0.5);  // c.height
+    O.carRow[lane][6] = (float)CF_FIN(f);
+    O.goal[lane][0] = (float)normalize_obs(L.goalx[lane], STD_NORM_X, 0.0);
+    O.goal[lane][1] = (float)normalize_obs(L.goaly[lane], STD_NORM_Y, 0.0);
   }
   if (lane >= DRV_SLOT_PED && lane < DRV_SLOT_PED + DRV_MAXP) {
     int k = lane - DRV_SLOT_PED;
-    L.shared[DRV_MAXO * 4 + 2 * k + 0] = isPed ? (float)normalize_obs(px, STD_NORM_X, 0.0) : 0.0f;
-    L.shared[DRV_MAXO * 4 + 2 * k + 1] = isPed ? (float)normalize_obs(py, STD_NORM_Y, 0.0) : 0.0f;
+    bool on = k < nPed;
+    O.shared[DRV_MAXO * 4 + 2 * k + 0] = on ? (float)normalize_obs(L.px[lane], STD_NORM_X, 0.0) : 0.0f;
+    O.shared[DRV_MAXO * 4 + 2 * k + 1] = on ? (float)normalize_obs(L.py[lane], STD_NORM_Y, 0.0) : 0.0f;
   }
   if (lane < DRV_MAXO) {
     bool on = lane < nObst;
-    L.shared[4 * lane + 0] = on ? (float)normalize_obs(L.ox[lane], STD_NORM_X, 0.0) : 0.0f;
-    L.shared[4 * lane + 1] = on ? (float)normalize_obs(L.oy[lane], STD_NORM_Y, 0.0) : 0.0f;
-    L.shared[4 * lane + 2] = on ? (float)normalize_obs(10.0, STD_NORM_W, 0.5) : 0.0f;
-    L.shared[4 * lane + 3] = on ? (float)normalize_obs(10.0, STD_NORM_H, 0.5) : 0.0f;
+    O.shared[4 * lane + 0] = on ? (float)normalize_obs(L.ox[lane], STD_NORM_X, 0.0) : 0.0f;
+    O.shared[4 * lane + 1] = on ? (float)normalize_obs(L.oy[lane], STD_NORM_Y, 0.0) : 0.0f;
+    O.shared[4 * lane + 2] = on ? (float)normalize_obs(10.0, STD_NORM_W, 0.5) : 0.0f;
+    O.shared[4 * lane + 3] = on ? (float)normalize_obs(10.0, STD_NORM_H, 0.5) : 0.0f;
   }
-  if (lane < DRV_LANE_ROWS * 5) L.shared[DRV_MAXO * 4 + DRV_MAXP * 2 + lane] = C.laneRows[lane];
+  if (lane < DRV_LANE_ROWS * 5) O.shared[DRV_MAXO * 4 + DRV_MAXP * 2 + lane] = C.laneRows[lane];
   __syncthreads();
   const int carsEnd = 9 + (A - 1) * 7;
   if (((carsEnd | obs_dim) & 3) == 0) {
-    // vector path (A in {2,6,10}): one float4 per lane per agent row; the 160-float shared tail is agent-independent
+    // vector path (A in {2,6,10}): one float4 per lane; the 160-float tail is identical for every agent of the env
     const int nvec = obs_dim >> 2;
     for (int q = lane; q < nvec; q += DE_WAVE) {
       int f = q << 2;
       if (f >= carsEnd) {
-        float4 v = *reinterpret_cast<const float4*>(&L.shared[f - carsEnd]);
+        float4 v = *reinterpret_cast<const float4*>(&O.shared[f - carsEnd]);
         for (int a = 0; a < A; ++a) *reinterpret_cast<float4*>(out + (size_t)a * obs_dim + f) = v;
       } else {
         for (int a = 0; a < A; ++a) {
           float4 v;
-          float t[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            int ff = f + k;
-            float x;
-            if (ff < 6) x = L.carRow[a][ff];
-            else if (ff < 8) x = L.goal[a][ff - 6];
-            else if (ff == 8) x = L.carRow[a][6];
-            else {
-              int c = (ff - 9) / 7, kk = (ff - 9) - c * 7;
-              c += (c >= a);
-              x = L.carRow[c][kk];
-            }
-            t[k] = x;
-          }
-          v.x = t[0]; v.y = t[1]; v.z = t[2]; v.w = t[3];
+          v.x = obs_self_or_car(O, A, a, f + 0); v.y = obs_self_or_car(O, A, a, f + 1);
+          v.z = obs_self_or_car(O, A, a, f + 2); v.w = obs_self_or_car(O, A, a, f + 3);
           *reinterpret_cast<float4*>(out + (size_t)a * obs_dim + f) = v;
         }
       }
@@ -356,151 +433,411 @@ DE_DEV void write_full_obs(DrvLds& L, int lane, int A, int nPed, int nObst, int 
   } else {
     for (int idx = lane; idx < A * obs_dim; idx += DE_WAVE) {
       int a = idx / obs_dim, ff = idx - a * obs_dim;
-      float x;
-      if (ff < 6) x = L.carRow[a][ff];
-      else if (ff < 8) x = L.goal[a][ff - 6];
-      else if (ff == 8) x = L.carRow[a][6];
-      else if (ff < carsEnd) {
-        int c = (ff - 9) / 7, kk = (ff - 9) - c * 7;
-        c += (c >= a);
-        x = L.carRow[c][kk];
-      } else x = L.shared[ff - carsEnd];
-      out[idx] = x;
+      out[idx] = ff < carsEnd ? obs_self_or_car(O, A, a, ff) : O.shared[ff - carsEnd];
     }
   }
   __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------
-// per-lane register state + HBM load/store
+// HBM <-> LDS (field-major rows: each field of one env is one coalesced 256-byte segment)
 // ------------------------------------------------------------------------------------------------
-struct LaneState {
-  // body
-  double px, py, vx, vy, ang, w, vbx, vby, wb;
-  // car
-  double dirx, diry, prevx, prevy, goalx, goaly;
-  int type, team, finished, crashed, fric, lanepos;
-  // ped
-  int road, side, dead, crossing, beginc, speed, moving;
-  // arbiter slot (lane < DRV_NS)
-  int a_pair, a_state, a_count, a_age, a_hash0, a_hash1;
-  double a_jn0, a_jt0, a_jn1, a_jt1;
-};
-
-DE_DEV void load_lane(const DrvState& S, int e, int lane, bool isCar, bool isPed, uint64_t occ, LaneState& s) {
+DE_DEV void load_env(const DrvState& S, DrvLds& L, int e, int lane, int A, int nPed, int nObst, uint64_t occ) {
   const size_t E = (size_t)S.E;
-  s.px = s.py = s.vx = s.vy = s.ang = s.w = s.vbx = s.vby = s.wb = 0.0;
-  s.dirx = s.diry = s.prevx = s.prevy = s.goalx = s.goaly = 0.0;
-  s.type = s.team = s.finished = s.crashed = s.fric = 0; s.lanepos = LP_OffRoad;
-  s.road = s.side = s.dead = s.crossing = s.beginc = s.speed = s.moving = 0;
-  if (isCar || isPed) {
+  if (lane < DRV_NB) {
+    const bool used = lane < A || (lane >= DRV_SLOT_PED && lane < DRV_SLOT_PED + nPed);
     const double* b = S.body + (size_t)e * DRV_NB + lane;
-    s.px = b[BF_PX * E * DRV_NB]; s.py = b[BF_PY * E * DRV_NB]; s.vx = b[BF_VX * E * DRV_NB]; s.vy = b[BF_VY * E * DRV_NB];
-    s.ang = b[BF_ANG * E * DRV_NB]; s.w = b[BF_W * E * DRV_NB];
-    s.vbx = b[BF_VBX * E * DRV_NB]; s.vby = b[BF_VBY * E * DRV_NB]; s.wb = b[BF_WB * E * DRV_NB];
-    int f = S.flags[(size_t)e * DRV_NB + lane];
-    if (isCar) {
+    L.px[lane] = used ? b[BF_PX * E * DRV_NB] : 0.0; L.py[lane] = used ? b[BF_PY * E * DRV_NB] : 0.0;
+    L.vx[lane] = used ? b[BF_VX * E * DRV_NB] : 0.0; L.vy[lane] = used ? b[BF_VY * E * DRV_NB] : 0.0;
+    double ang = used ? b[BF_ANG * E * DRV_NB] : 0.0;
+    L.ang[lane] = ang; L.w[lane] = used ? b[BF_W * E * DRV_NB] : 0.0;
+    L.vbx[lane] = used ? b[BF_VBX * E * DRV_NB] : 0.0; L.vby[lane] = used ? b[BF_VBY * E * DRV_NB] : 0.0;
+    L.wb[lane] = used ? b[BF_WB * E * DRV_NB] : 0.0;
+    int f = used ? S.flags[(size_t)e * DRV_NB + lane] : 0;
+    L.flags[lane] = f;
+    L.moving[lane] = used ? S.aux[(size_t)e * DRV_NB + lane] : 0;
+    double minv = 0.0, iinv = 0.0;
+    if (lane < A) { minv = 1.0 / C.carMass[f & 3]; iinv = 1.0 / C.carInertia[f & 3]; }
+    else if (used) { minv = 1.0 / C.pedMass; iinv = 1.0 / C.pedInertia; }
+    L.minv[lane] = minv; L.iinv[lane] = iinv;
+    L.rc[lane] = 1.0; L.rs[lane] = 0.0; L.rotAng[lane] = 0.0;
+    if (lane < A) {
       const double* c = S.carx + (size_t)e * 16 + lane;
-      s.dirx = c[CF_DIRX * E * 16]; s.diry = c[CF_DIRY * E * 16]; s.prevx = c[CF_PREVX * E * 16];
-      s.prevy = c[CF_PREVY * E * 16]; s.goalx = c[CF_GOALX * E * 16]; s.goaly = c[CF_GOALY * E * 16];
-      s.type = f & 3; s.team = (f >> 2) & 3; s.finished = (f >> 4) & 1; s.crashed = (f >> 5) & 1;
-      s.fric = (f >> 6) & 1; s.lanepos = (f >> 8) & 7;
-    } else {
-      s.road = f & 1; s.side = (f >> 1) & 1; s.dead = (f >> 2) & 1; s.crossing = (f >> 3) & 1;
-      s.beginc = (f >> 4) & 1; s.speed = (f >> 8) & 15;
-      s.moving = S.aux[(size_t)e * DRV_NB + lane];
+      double prevx = c[CF_PREVX * E * 16], prevy = c[CF_PREVY * E * 16], gx = c[CF_GOALX * E * 16], gy = c[CF_GOALY * E * 16];
+      L.dirx[lane] = c[CF_DIRX * E * 16]; L.diry[lane] = c[CF_DIRY * E * 16];
+      L.prevx[lane] = prevx; L.prevy[lane] = prevy; L.goalx[lane] = gx; L.goaly[lane] = gy;
+      L.dprev[lane] = vlen(vsub(v2(prevx, prevy), v2(gx, gy)));
+      L.cmass[lane] = C.carMass[f & 3]; L.cpower[lane] = C.carPower[f & 3];
+      L.chx[lane] = C.carHx[f & 3]; L.chy[lane] = C.carHy[f & 3];
+      car_refresh_rot(L, lane, ang);
     }
   }
-  s.a_pair = 0xFFFF; s.a_state = ARB_FIRST; s.a_count = 0; s.a_age = 0; s.a_hash0 = s.a_hash1 = 0;
-  s.a_jn0 = s.a_jt0 = s.a_jn1 = s.a_jt1 = 0.0;
-  if (lane < DRV_NS && ((occ >> lane) & 1ull)) {
+  if (lane < DRV_MAXO) {
+    L.ox[lane] = lane < nObst ? S.obst[(size_t)e * DRV_MAXO + lane] : 0.0;
+    L.oy[lane] = lane < nObst ? S.obst[E * DRV_MAXO + (size_t)e * DRV_MAXO + lane] : 0.0;
+  }
+  if (lane < DRV_NS) {
+    const bool on = (occ >> lane) & 1ull;
     size_t o = (size_t)e * DRV_NS + lane;
-    s.a_pair = S.s_pair[o];
-    int m = S.s_meta[o];
-    s.a_state = m & 0xFF; s.a_count = (m >> 8) & 0xFF; s.a_age = (m >> 16) & 0xFF;
-    s.a_hash0 = (int)S.s_hash[o]; s.a_hash1 = (int)S.s_hash[E * DRV_NS + o];
-    s.a_jn0 = S.s_imp[o]; s.a_jt0 = S.s_imp[E * DRV_NS + o];
-    s.a_jn1 = S.s_imp[2 * E * DRV_NS + o]; s.a_jt1 = S.s_imp[3 * E * DRV_NS + o];
+    L.s_pair[lane] = on ? S.s_pair[o] : 0xFFFF;
+    L.s_meta[lane] = on ? S.s_meta[o] : 0;
+    L.s_hash0[lane] = on ? (int)S.s_hash[o] : 0; L.s_hash1[lane] = on ? (int)S.s_hash[E * DRV_NS + o] : 0;
+    L.s_jn0[lane] = on ? S.s_imp[o] : 0.0; L.s_jt0[lane] = on ? S.s_imp[E * DRV_NS + o] : 0.0;
+    L.s_jn1[lane] = on ? S.s_imp[2 * E * DRV_NS + o] : 0.0; L.s_jt1[lane] = on ? S.s_imp[3 * E * DRV_NS + o] : 0.0;
   }
 }
 
-DE_DEV void store_lane(const DrvState& S, int e, int lane, bool isCar, bool isPed, uint64_t occ, const LaneState& s) {
+DE_DEV void store_env(const DrvState& S, const DrvLds& L, int e, int lane, int A, int nPed, uint64_t occ) {
   const size_t E = (size_t)S.E;
-  if (isCar || isPed) {
+  if (lane < A || (lane >= DRV_SLOT_PED && lane < DRV_SLOT_PED + nPed)) {
     double* b = S.body + (size_t)e * DRV_NB + lane;
-    b[BF_PX * E * DRV_NB] = s.px; b[BF_PY * E * DRV_NB] = s.py; b[BF_VX * E * DRV_NB] = s.vx; b[BF_VY * E * DRV_NB] = s.vy;
-    b[BF_ANG * E * DRV_NB] = s.ang; b[BF_W * E * DRV_NB] = s.w;
-    b[BF_VBX * E * DRV_NB] = s.vbx; b[BF_VBY * E * DRV_NB] = s.vby; b[BF_WB * E * DRV_NB] = s.wb;
-    if (isCar) {
+    b[BF_PX * E * DRV_NB] = L.px[lane]; b[BF_PY * E * DRV_NB] = L.py[lane]; b[BF_VX * E * DRV_NB] = L.vx[lane];
+    b[BF_VY * E * DRV_NB] = L.vy[lane]; b[BF_ANG * E * DRV_NB] = L.ang[lane]; b[BF_W * E * DRV_NB] = L.w[lane];
+    b[BF_VBX * E * DRV_NB] = L.vbx[lane]; b[BF_VBY * E * DRV_NB] = L.vby[lane]; b[BF_WB * E * DRV_NB] = L.wb[lane];
+    S.flags[(size_t)e * DRV_NB + lane] = L.flags[lane];
+    if (lane < A) {
       double* c = S.carx + (size_t)e * 16 + lane;
-      c[CF_DIRX * E * 16] = s.dirx; c[CF_DIRY * E * 16] = s.diry; c[CF_PREVX * E * 16] = s.prevx;
-      c[CF_PREVY * E * 16] = s.prevy; c[CF_GOALX * E * 16] = s.goalx; c[CF_GOALY * E * 16] = s.goaly;
-      S.flags[(size_t)e * DRV_NB + lane] = CARF_PACK(s.type, s.team, s.finished, s.crashed, s.fric, s.lanepos);
+      c[CF_DIRX * E * 16] = L.dirx[lane]; c[CF_DIRY * E * 16] = L.diry[lane];
+      c[CF_PREVX * E * 16] = L.prevx[lane]; c[CF_PREVY * E * 16] = L.prevy[lane];
     } else {
-      S.flags[(size_t)e * DRV_NB + lane] = PEDF_PACK(s.road, s.side, s.dead, s.crossing, s.beginc, s.speed);
-      S.aux[(size_t)e * DRV_NB + lane] = s.moving;
+      S.aux[(size_t)e * DRV_NB + lane] = L.moving[lane];
     }
   }
   if (lane < DRV_NS && ((occ >> lane) & 1ull)) {
     size_t o = (size_t)e * DRV_NS + lane;
-    S.s_pair[o] = s.a_pair;
-    S.s_meta[o] = s.a_state | (s.a_count << 8) | (s.a_age << 16);
-    S.s_hash[o] = (uint32_t)s.a_hash0; S.s_hash[E * DRV_NS + o] = (uint32_t)s.a_hash1;
-    S.s_imp[o] = s.a_jn0; S.s_imp[E * DRV_NS + o] = s.a_jt0;
-    S.s_imp[2 * E * DRV_NS + o] = s.a_jn1; S.s_imp[3 * E * DRV_NS + o] = s.a_jt1;
+    S.s_pair[o] = L.s_pair[lane]; S.s_meta[o] = L.s_meta[lane];
+    S.s_hash[o] = (uint32_t)L.s_hash0[lane]; S.s_hash[E * DRV_NS + o] = (uint32_t)L.s_hash1[lane];
+    S.s_imp[o] = L.s_jn0[lane]; S.s_imp[E * DRV_NS + o] = L.s_jt0[lane];
+    S.s_imp[2 * E * DRV_NS + o] = L.s_jn1[lane]; S.s_imp[3 * E * DRV_NS + o] = L.s_jt1[lane];
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// collision `begin` callbacks, executed wave-uniformly in canonical pair order
+// collision `begin` callbacks, executed wave-uniformly in canonical pair order on the LDS tile
 // (DrivingEnvironment.py:587-683: carCrash / pedHit / carHit).  Returns false => arbiter ignored until separation.
+// `rew` is the per-step reward accumulator held by the car's own lane.
 // ------------------------------------------------------------------------------------------------
-DE_DEV void car_crash_flags(LaneState& s) { s.finished = 1; s.crashed = 1; s.fric = 1; }  // Car.py:111-117
-
-DE_DEV bool cb_begin(int i, int j, int lane, LaneState& s, double& rew) {
-  // i = car lane, j = partner slot (car / ped lane, or static >= 30); all arguments wave-uniform
-  double v1x = bcast_d(s.vx, i), v1y = bcast_d(s.vy, i);
+DE_DEV bool cb_begin(DrvLds& L, int i, int j, int lane, double& rew) {
+  // i = car, j = partner slot (car / pedestrian lane, or static >= 30); all arguments are wave-uniform
+  const double v1x = L.vx[i], v1y = L.vy[i];
+  const int f1 = L.flags[i];
   if (j < DRV_SLOT_PED) {  // carCrash :591-637
-    double v2x = bcast_d(s.vx, j), v2y = bcast_d(s.vy, j);
-    int crashed1 = bcast_i(s.crashed, i), crashed2 = bcast_i(s.crashed, j);
-    int pos1 = bcast_i(s.lanepos, i), pos2 = bcast_i(s.lanepos, j);
-    double v1len = vlen(v2(v1x, v1y)), v2len = vlen(v2(v2x, v2y));
-    double v1l = v1len / 5.0, v2l = v2len / 5.0;
-    double d1 = 0.0, d2 = 0.0;  // applied as successive subtractions to keep the reference's rounding order
+    const double v2x = L.vx[j], v2y = L.vy[j];
+    const int f2 = L.flags[j];
+    const int crashed1 = CF_CRASHED(f1), crashed2 = CF_CRASHED(f2), pos1 = CF_LP(f1), pos2 = CF_LP(f2);
+    const double v1len = vlen(v2(v1x, v1y)), v2len = vlen(v2(v2x, v2y));
+    const double v1l = v1len / 5.0, v2l = v2len / 5.0;
     double r1 = bcast_d(rew, i), r2 = bcast_d(rew, j);
     if (!crashed1) r1 -= v1l;
     if (!crashed2) r2 -= v2l;
     if (pos1 != LP_InRightLane && !crashed1) r1 -= v1l;
     if (pos2 != LP_InRightLane && !crashed2) r2 -= v2l;
     if (pos1 == LP_InRightLane && pos2 == LP_InRightLane) {
-      V2 dp = v2(bcast_d(s.px, i) - bcast_d(s.px, j), bcast_d(s.py, i) - bcast_d(s.py, j));
-      double adp = dm_atan2(dp.y, dp.x);
-      if (v1len > 1.0 && dm_cos(adp - dm_atan2(v1y, v1x)) < -0.4 && !crashed1) r1 -= v1l;
-      if (v2len > 1.0 && dm_cos(adp - dm_atan2(v2y, v2x)) > 0.4 && !crashed2) r2 -= v2l;
+      V2 dp = v2(L.px[i] - L.px[j], L.py[i] - L.py[j]);
+      double adp = dev_atan2(dp.y, dp.x);
+      if (v1len > 1.0 && dev_cos(adp - dev_atan2(v1y, v1x)) < -0.4 && !crashed1) r1 -= v1l;
+      if (v2len > 1.0 && dev_cos(adp - dev_atan2(v2y, v2x)) > 0.4 && !crashed2) r2 -= v2l;
     }
-    (void)d1; (void)d2;
-    if (lane == i) { rew = r1; car_crash_flags(s); }
-    if (lane == j) { rew = r2; car_crash_flags(s); }
+    if (lane == i) { rew = r1; L.flags[i] = f1 | CF_CRASH_BITS; }
+    if (lane == j) { rew = r2; L.flags[j] = f2 | CF_CRASH_BITS; }
     return true;
   } else if (j < DRV_SLOT_OBST) {  // pedHit :640-667
-    double v1l = vlen(v2(v1x, v1y));
+    const double v1l = vlen(v2(v1x, v1y));
     if (v1l > 1.0) {
-      V2 dp = v2(bcast_d(s.px, i) - bcast_d(s.px, j), bcast_d(s.py, i) - bcast_d(s.py, j));
-      int finished = bcast_i(s.finished, i);
-      if (lane == j) { s.moving = 0; s.vx = 0.0; s.vy = 0.0; s.dead = 1; }  // Pedestrian.die
-      if (dm_cos(dm_atan2(dp.y, dp.x) - dm_atan2(v1y, v1x)) < -0.4 && !finished) {
-        if (lane == i) { car_crash_flags(s); rew -= v1l / 5.0; }
+      V2 dp = v2(L.px[i] - L.px[j], L.py[i] - L.py[j]);
+      if (lane == j) {  // Pedestrian.die (Pedestrian.py:40-47)
+        L.moving[j] = 0; L.vx[j] = 0.0; L.vy[j] = 0.0; L.flags[j] = L.flags[j] | (1 << 2);
+      }
+      if (dev_cos(dev_atan2(dp.y, dp.x) - dev_atan2(v1y, v1x)) < -0.4 && !CF_FIN(f1)) {
+        if (lane == i) { L.flags[i] = f1 | CF_CRASH_BITS; rew -= v1l / 5.0; }
       }
       return true;
     }
     return false;
   } else {  // carHit :670-683
     if (lane == i) {
-      if (!s.finished) rew -= vlen(v2(s.vx, s.vy)) / 5.0;
-      car_crash_flags(s);
+      if (!CF_FIN(f1)) rew -= vlen(v2(v1x, v1y)) / 5.0;
+      L.flags[i] = f1 | CF_CRASH_BITS;
     }
     return true;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// contact path of one substep, OUT OF LINE on purpose: narrowphase + contact cache + callbacks + solver need far
+// more registers than the common no-contact path; as a separate function its spills and saves are only paid
+// when something actually touches.  Operates on the LDS tile; returns the few scalars it changes.
+// ------------------------------------------------------------------------------------------------
+struct ContactRet {
+  uint64_t occ;
+  double rew;
+  int err;
+};
+
+__device__ __noinline__ ContactRet drv_contact_path(int lane, int cand, uint64_t pairLo, uint64_t pairHi, uint64_t occ,
+                                                    double rew, bool isCar, bool isPed) {
+  DrvLds& L = g_L;
+  int err = 0;
+  // ---------- slow path: narrowphase -> arbiter cache -> callbacks -> prestep -> friction -> solver -------
+  DrvMailbox& M = L.u.mb;
+  if (lane < DRV_NS) M.flag[lane] = 0;
+  __syncthreads();
+#pragma unroll 1
+  for (int t = 0; t < DRV_NPAIR_ROUNDS; ++t) {
+    const bool isCand = (cand >> t) & 1;
+    if (wave_ballot(isCand) == 0ull) continue;
+    Contacts ct;
+    ct.count = 0;
+    const int pr = MY_PAIR(t);
+    if (isCand) {
+      int i = pr >> 8, j = pr & 0xFF;
+      BoxW b1;
+      box_world(b1, v2(L.px[i], L.py[i]), L.rc[i], L.rs[i], L.chx[i], L.chy[i]);
+      if (j < DRV_SLOT_PED) {
+        BoxW b2;
+        box_world(b2, v2(L.px[j], L.py[j]), L.rc[j], L.rs[j], L.chx[j], L.chy[j]);
+        poly_to_poly(b1, i, b2, j, ct);
+      } else if (j < DRV_SLOT_OBST) {
+        circle_to_poly(v2(L.px[j], L.py[j]), 5.0, b1, ct);
+      } else {
+        BoxW b2;
+        double ex = j >= DRV_SLOT_BLD ? 400.0 : 10.0, ey = j >= DRV_SLOT_BLD ? 225.0 : 10.0;
+        box_world(b2, static_pos(L, j), 1.0, 0.0, ex, ey);
+        poly_to_poly(b1, i, b2, j, ct);
+      }
+    }
+    const bool touch = isCand && ct.count > 0;
+    const uint64_t tmask = wave_ballot(touch);
+    if (tmask == 0ull) continue;
+    // find my slot among the occupied ones
+    int slot = -1;
+    if (touch) {
+      for (uint64_t mm = occ; mm; mm &= mm - 1) {
+        int sidx = __builtin_ctzll(mm);
+        if (L.s_pair[sidx] == pr) slot = sidx;
+      }
+    }
+    const bool needNew = touch && slot < 0;
+    const uint64_t newMask = wave_ballot(needNew);
+    if (newMask) {
+      const uint64_t slotBits = (1ull << DRV_NS) - 1ull;
+      int rank = __popcll(newMask & lanemask_lt());
+      uint64_t fm = (~occ) & slotBits;
+      if (needNew) {
+        for (int r = 0; r < rank; ++r) fm &= fm - 1;
+        if (fm) { slot = __builtin_ctzll(fm); L.s_pair[slot] = pr; }
+        else err |= 1;  // contact cache overflow: pair dropped (reported through EI_ERR)
+      }
+      int cnt = __popcll(newMask);
+      uint64_t fm2 = (~occ) & slotBits;
+      for (int r = 0; r < cnt && fm2; ++r) { occ |= (fm2 & (~fm2 + 1)); fm2 &= fm2 - 1; }
+    }
+    if (touch && slot >= 0) {
+      M.flag[slot] = needNew ? 3 : 1;
+      M.count[slot] = ct.count;
+      M.nx[slot] = ct.n.x; M.ny[slot] = ct.n.y;
+      M.p1x[slot][0] = ct.p1[0].x; M.p1y[slot][0] = ct.p1[0].y; M.p2x[slot][0] = ct.p2[0].x; M.p2y[slot][0] = ct.p2[0].y;
+      M.hash[slot][0] = ct.hash[0];
+      if (ct.count > 1) {
+        M.p1x[slot][1] = ct.p1[1].x; M.p1y[slot][1] = ct.p1[1].y; M.p2x[slot][1] = ct.p2[1].x; M.p2y[slot][1] = ct.p2[1].y;
+        M.hash[slot][1] = ct.hash[1];
+      }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+
+  // ---- slot lanes: cpArbiterUpdate for touched slots; ageing / expiry for the rest ----------------------
+  const bool slotOcc = lane < DRV_NS && ((occ >> lane) & 1ull);
+  bool touched = false;
+  int bodyA = 0, bodyB = 0;
+  int a_pair = 0xFFFF, a_state = ARB_FIRST, a_count = 0, a_age = 0;
+  double jn[2] = {0.0, 0.0}, jt[2] = {0.0, 0.0};
+  V2 n = v2(0.0, 0.0), r1[2], r2[2];
+  r1[0] = r1[1] = r2[0] = r2[1] = v2(0.0, 0.0);
+  if (slotOcc) {
+    const int flag = M.flag[lane];
+    touched = flag != 0;
+    a_pair = L.s_pair[lane];
+    int meta = L.s_meta[lane];
+    a_state = meta & 0xFF; a_count = (meta >> 8) & 0xFF; a_age = (meta >> 16) & 0xFF;
+    if (flag & 2) { a_state = ARB_FIRST; a_count = 0; a_age = 0; }
+    if (touched) {
+      const int i = a_pair >> 8, j = a_pair & 0xFF;
+      // narrowphase order: shape type ascending => pedestrian circle first for car-ped pairs
+      if (j >= DRV_SLOT_PED && j < DRV_SLOT_OBST) { bodyA = j; bodyB = i; } else { bodyA = i; bodyB = j; }
+      const V2 pa = bodyA < DRV_SLOT_OBST ? v2(L.px[bodyA], L.py[bodyA]) : static_pos(L, bodyA);
+      const V2 pb = bodyB < DRV_SLOT_OBST ? v2(L.px[bodyB], L.py[bodyB]) : static_pos(L, bodyB);
+      const int cnt = M.count[lane];
+      const int h0 = M.hash[lane][0], h1 = cnt > 1 ? M.hash[lane][1] : 0;
+      const int oh0 = L.s_hash0[lane], oh1 = L.s_hash1[lane];
+      // carry impulses of contacts with matching hash (later match wins, as in Chipmunk's loop)
+      if (a_count > 0 && h0 == oh0) { jn[0] = L.s_jn0[lane]; jt[0] = L.s_jt0[lane]; }
+      if (a_count > 1 && h0 == oh1) { jn[0] = L.s_jn1[lane]; jt[0] = L.s_jt1[lane]; }
+      if (cnt > 1) {
+        if (a_count > 0 && h1 == oh0) { jn[1] = L.s_jn0[lane]; jt[1] = L.s_jt0[lane]; }
+        if (a_count > 1 && h1 == oh1) { jn[1] = L.s_jn1[lane]; jt[1] = L.s_jt1[lane]; }
+      }
+      r1[0] = vsub(v2(M.p1x[lane][0], M.p1y[lane][0]), pa);
+      r2[0] = vsub(v2(M.p2x[lane][0], M.p2y[lane][0]), pb);
+      if (cnt > 1) {
+        r1[1] = vsub(v2(M.p1x[lane][1], M.p1y[lane][1]), pa);
+        r2[1] = vsub(v2(M.p2x[lane][1], M.p2y[lane][1]), pb);
+      }
+      n = v2(M.nx[lane], M.ny[lane]);
+      a_count = cnt;
+      L.s_hash0[lane] = h0; L.s_hash1[lane] = h1;
+      if (a_state == ARB_CACHED) a_state = ARB_FIRST;
+      a_age = 0;
+    }
+  }
+
+  // ---- rank touched slots by canonical pair order ------------------------------------------------------
+  const uint64_t touchedMask = wave_ballot(touched);
+  const int nTouched = __popcll(touchedMask);
+  int rank = 0;
+  for (uint64_t mm = touchedMask; mm; mm &= mm - 1) {
+    int b = __builtin_ctzll(mm);
+    int pk = bcast_i(a_pair, b);
+    rank += (pk < a_pair) ? 1 : 0;
+  }
+
+  // ---- begin callbacks in canonical order (first contact only) ------------------------------------------
+  for (int k = 0; k < nTouched; ++k) {
+    uint64_t who = wave_ballot(touched && rank == k);
+    int b = __builtin_ctzll(who);
+    int st = bcast_i(a_state, b);
+    if (st != ARB_FIRST) continue;
+    int pk = bcast_i(a_pair, b);
+    bool keep = cb_begin(L, pk >> 8, pk & 0xFF, lane, rew);
+    if (!keep && lane == b) a_state = ARB_IGNORE;
+    __syncthreads();
+  }
+
+  // ---- expiry of untouched slots (cpSpaceArbiterSetFilter; no `separate` handlers in Driving) -----------
+  bool freeMe = false;
+  if (slotOcc && !touched) {
+    a_age += 1;
+    if (a_state != ARB_CACHED) a_state = ARB_CACHED;
+    if (a_age >= 3) freeMe = true;
+  }
+  const uint64_t freeMask = wave_ballot(freeMe);
+
+  // ---- active arbiters: levels (arbiters sharing a dynamic body keep their canonical sequential order) --
+  const bool active = touched && a_state != ARB_IGNORE;
+  const uint64_t activeMask = wave_ballot(active);
+  int myLevel = 0, maxLevel = -1, blvl = 0;
+  for (int k = 0; k < nTouched; ++k) {
+    uint64_t who = wave_ballot(active && rank == k);
+    if (who == 0ull) continue;
+    int b = __builtin_ctzll(who);
+    int ba = bcast_i(bodyA, b), bb2 = bcast_i(bodyB, b);
+    int la = ba < DRV_SLOT_OBST ? bcast_i(blvl, ba) : 0;
+    int lb = bb2 < DRV_SLOT_OBST ? bcast_i(blvl, bb2) : 0;
+    int lv = la > lb ? la : lb;
+    if (lane == b) myLevel = lv;
+    if (lane == ba || lane == bb2) blvl = lv + 1;  // static indices (>= 30) never equal a body lane (< 30)
+    maxLevel = lv > maxLevel ? lv : maxLevel;
+  }
+
+  // ---- prestep (cpArbiterPreStep) on velocities BEFORE the friction update -------------------------------
+  double nMass[2] = {0.0, 0.0}, tMass[2] = {0.0, 0.0}, bias[2] = {0.0, 0.0}, bounce[2] = {0.0, 0.0}, jBias[2] = {0.0, 0.0};
+  const double arb_e = 0.05 * 0.05, arb_u = 0.0 * 0.0;
+  if (active) {
+    BodyV a, b;
+    body_load(L, bodyA, a);
+    body_load(L, bodyB, b);
+    V2 body_delta = vsub(b.p, a.p);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      if (c < a_count) {
+        nMass[c] = 1.0 / (k_scalar_body(a, r1[c], n) + k_scalar_body(b, r2[c], n));
+        tMass[c] = 1.0 / (k_scalar_body(a, r1[c], vperp(n)) + k_scalar_body(b, r2[c], vperp(n)));
+        double dist = vdot(vadd(vsub(r2[c], r1[c]), body_delta), n);
+        bias[c] = -DE_CONTACT_BIAS_COEF * fmin_cp(0.0, dist + DE_COLLISION_SLOP) / DE_DT;
+        jBias[c] = 0.0;
+        bounce[c] = vdot(relative_velocity(a, b, r1[c], r2[c]), n) * arb_e;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- velocity update (velocity_func: friction_* or default) -------------------------------------------
+  velocity_update(L, lane, isCar, isPed);
+  if (activeMask) {
+    __syncthreads();
+    // ---- warm start (cpArbiterApplyCachedImpulse; skipped on first contact), level by level ------------
+    for (int lv = 0; lv <= maxLevel; ++lv) {
+      if (active && myLevel == lv && a_state != ARB_FIRST) {
+        BodyV a, b;
+        body_load(L, bodyA, a);
+        body_load(L, bodyB, b);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          if (c < a_count) {
+            V2 j = vrotate(n, v2(jn[c], jt[c]));
+            j = vmul(j, 1.0);  // dt_coef = dt/prev_dt = 1
+            apply_impulse(a, vneg(j), r1[c]);
+            apply_impulse(b, j, r2[c]);
+          }
+        }
+        body_store_vel(L, bodyA, a);
+        body_store_vel(L, bodyB, b);
+      }
+      __syncthreads();
+    }
+    // ---- 10 sequential-impulse iterations (cpArbiterApplyImpulse) ---------------------------------------
+    for (int iter = 0; iter < 10; ++iter) {
+      for (int lv = 0; lv <= maxLevel; ++lv) {
+        if (active && myLevel == lv) {
+          BodyV a, b;
+          body_load(L, bodyA, a);
+          body_load(L, bodyB, b);
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            if (c < a_count) {
+              V2 vb1 = vadd(a.vb, vmul(vperp(r1[c]), a.wb));
+              V2 vb2 = vadd(b.vb, vmul(vperp(r2[c]), b.wb));
+              V2 vr = relative_velocity(a, b, r1[c], r2[c]);
+              double vbn = vdot(vsub(vb2, vb1), n);
+              double vrn = vdot(vr, n);
+              double vrt = vdot(vr, vperp(n));
+              double jbn = (bias[c] - vbn) * nMass[c];
+              double jbnOld = jBias[c];
+              jBias[c] = fmax_cp(jbnOld + jbn, 0.0);
+              double jnn = -(bounce[c] + vrn) * nMass[c];
+              double jnOld = jn[c];
+              jn[c] = fmax_cp(jnOld + jnn, 0.0);
+              double jtMax = arb_u * jn[c];
+              double jtt = -vrt * tMass[c];
+              double jtOld = jt[c];
+              jt[c] = fclamp_cp(jtOld + jtt, -jtMax, jtMax);
+              V2 jb = vmul(n, jBias[c] - jbnOld);
+              apply_bias_impulse(a, vneg(jb), r1[c]);
+              apply_bias_impulse(b, jb, r2[c]);
+              V2 jj = vrotate(n, v2(jn[c] - jnOld, jt[c] - jtOld));
+              apply_impulse(a, vneg(jj), r1[c]);
+              apply_impulse(b, jj, r2[c]);
+            }
+          }
+          body_store_vel(L, bodyA, a);
+          body_store_vel(L, bodyB, b);
+        }
+        __syncthreads();
+      }
+    }
+  }
+  // arbiters that were active this step are NORMAL from the next step on (cpSpaceStep resets the state)
+  if (active && a_state == ARB_FIRST) a_state = ARB_NORMAL;
+  if (slotOcc) {
+    if (freeMe) L.s_pair[lane] = 0xFFFF;
+    L.s_meta[lane] = a_state | (a_count << 8) | (a_age << 16);
+    if (touched) { L.s_jn0[lane] = jn[0]; L.s_jt0[lane] = jt[0]; L.s_jn1[lane] = jn[1]; L.s_jt1[lane] = jt[1]; }
+  }
+  occ &= ~freeMask;
+  ContactRet ret;
+  ret.occ = occ; ret.rew = rew; ret.err = err;
+  return ret;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -509,7 +846,7 @@ DE_DEV bool cb_begin(int i, int j, int lane, LaneState& s, double& rew) {
 extern "C" __global__ void __launch_bounds__(64, DRV_WAVES_PER_SIMD)
 drv_step_kernel(DrvState S, const int* __restrict__ actions, float* __restrict__ obs, double* __restrict__ rewards,
                 uint8_t* __restrict__ dones) {
-  __shared__ DrvLds L;
+  DrvLds& L = g_L;
   const int e = blockIdx.x;
   const int lane = threadIdx.x;
   const int A = S.A;
@@ -526,20 +863,7 @@ drv_step_kernel(DrvState S, const int* __restrict__ actions, float* __restrict__
   const bool isCar = lane < A;
   const bool isPed = lane >= DRV_SLOT_PED && lane < DRV_SLOT_PED + nPed;
   const bool isBody = isCar || isPed;
-  LaneState s;
-  load_lane(S, e, lane, isCar, isPed, occ, s);
-
-  // constants of my body
-  double m = 1.0, minv = 0.0, iinv = 0.0, hx = 0.0, hy = 0.0;
-  if (isCar) { m = C.carMass[s.type]; minv = 1.0 / m; iinv = 1.0 / C.carInertia[s.type]; hx = C.carHx[s.type]; hy = C.carHy[s.type]; }
-  if (isPed) { m = C.pedMass; minv = 1.0 / m; iinv = 1.0 / C.pedInertia; }
-  if (lane < DRV_NB) { L.minv[lane] = minv; L.iinv[lane] = iinv; }
-  if (lane < 16) { L.hx[lane] = hx; L.hy[lane] = hy; }
-  if (lane < DRV_MAXO) {
-    L.ox[lane] = lane < nObst ? S.obst[(size_t)e * DRV_MAXO + lane] : 0.0;
-    L.oy[lane] = lane < nObst ? S.obst[(size_t)S.E * DRV_MAXO + (size_t)e * DRV_MAXO + lane] : 0.0;
-  }
-  if (lane < DRV_NS) L.slotPair[lane] = s.a_pair;
+  load_env(S, L, e, lane, A, nPed, nObst, occ);
 
   // my 8 candidate pairs (canonical order index = round*64 + lane), packed 4 x u16 per 64-bit register so that the
   // round loop can select one without dynamically indexed registers (no scratch)
@@ -557,137 +881,153 @@ drv_step_kernel(DrvState S, const int* __restrict__ actions, float* __restrict__
     uint64_t v = (uint64_t)(ok ? pr : 0xFFFF);
     if (t < 4) pairLo |= v << (16 * t); else pairHi |= v << (16 * (t - 4));
   }
-#define MY_PAIR(t) ((int)((((t) < 4 ? pairLo : pairHi) >> (16 * ((t)&3))) & 0xFFFFull))
-
   int act0 = 1, act1 = 1;
   if (isCar) { act0 = actions[((size_t)e * A + lane) * 2 + 0]; act1 = actions[((size_t)e * A + lane) * 2 + 1]; }
   double rew = 0.0, posrew = 0.0, teamReward = 0.0;  // :252-254
+  bool aabbValid = false;
   __syncthreads();
 
   for (int it = 0; it < 10; ++it) {
-    // ---------------- game logic on own body (cars: processAction + tick; pedestrians: move) -----------------
+    // ======== phase 1: game logic on own body, then cpBodyUpdatePosition ===================================
     if (isCar) {
+      int f = L.flags[lane];
+      double px = L.px[lane], py = L.py[lane], vx = L.vx[lane], vy = L.vy[lane], ang = L.ang[lane];
       if (it == 0) {  // processAction :357-373 -> Car.accelerate (Car.py:55-94), Car.turn (Car.py:97-108)
-        int acc = act0 - 1, steer = (act1 - 1) * 2;
-        if (!s.finished) {
+        const int acc = act0 - 1, steer = (act1 - 1) * 2;
+        if (!CF_FIN(f)) {
+          double dirx = L.dirx[lane], diry = L.diry[lane];
           double power = (double)acc;
-          double moveDir = s.vx * s.dirx + s.vy * s.diry;
+          double moveDir = vx * dirx + vy * diry;
           bool skip = false;
           if (acc < 0) power = (double)acc * 0.75;
           if (acc == 0) power = (moveDir == 0.0) ? 0.0 : (moveDir > 0.0 ? -2.0 : 2.0);
           else if (acc < 0 && moveDir > 0.0) skip = true;
           else if (acc > 0 && moveDir < 0.0) skip = true;
           if (!skip) {
-            double sn, cs;
-            dm_sincos(s.ang, &sn, &cs);
-            double vxa = C.carPower[s.type] * power * cs, vya = C.carPower[s.type] * power * sn;
-            s.vx = s.vx + vxa; s.vy = s.vy + vya;
-            if (acc == 0 && (s.vx * s.dirx + s.vy * s.diry) * moveDir < 0.0) { s.vx = 0.0; s.vy = 0.0; }
+            const double cs = L.rc[lane], sn = L.rs[lane];  // = dm_sincos(ang): the cache is refreshed on every change
+            vx = vx + L.cpower[lane] * power * cs;
+            vy = vy + L.cpower[lane] * power * sn;
+            if (acc == 0 && (vx * dirx + vy * diry) * moveDir < 0.0) { vx = 0.0; vy = 0.0; }
           }
-        }
-        if (steer != 0 && !s.finished) {
-          double rot = (double)steer * (DM_PI / 180.0);
-          s.ang = s.ang + rot;
-          double sn, cs;
-          dm_sincos(rot, &sn, &cs);
-          double dx = s.dirx * cs - s.diry * sn, dy = s.dirx * sn + s.diry * cs;
-          s.dirx = dx; s.diry = dy;
-          double nvx = s.vx * cs - s.vy * sn, nvy = s.vx * sn + s.vy * cs;
-          s.vx = nvx; s.vy = nvy;
+          if (steer != 0) {
+            const double rot = (double)steer * (DM_PI / 180.0);
+            ang = ang + rot;
+            const DevSC rsc = dev_sincos(rot);
+            const double sn = rsc.s, cs = rsc.c;
+            const double dx = dirx * cs - diry * sn, dy = dirx * sn + diry * cs;
+            L.dirx[lane] = dx; L.diry[lane] = dy;
+            const double nvx = vx * cs - vy * sn, nvy = vx * sn + vy * cs;
+            vx = nvx; vy = nvy;
+            car_refresh_rot(L, lane, ang);
+          }
         }
       }
       // tick :376-426
-      V2 pos = v2(s.px, s.py);
+      const V2 pos = v2(px, py);
       int lp = LP_OffRoad;
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        int rp = road_is_point_on_road(C.roads[r], pos, s.ang);
+      {
+        int rp = road_pos<0>(pos, L.cosRel0[lane]);
+        if (rp < lp) lp = rp;
+        rp = road_pos<1>(pos, L.cosRel1[lane]);
         if (rp < lp) lp = rp;
       }
-      V2 goal = v2(s.goalx, s.goaly);
-      double dnow = vlen(vsub(pos, goal));
-      double diff = vlen(vsub(v2(s.prevx, s.prevy), goal)) - dnow;
-      if (!s.finished) { rew += diff / 50.0; posrew += dm_max(0.0, diff / 50.0); }
-      s.prevx = s.px; s.prevy = s.py;
+      const double dnow = vlen(vsub(pos, v2(L.goalx[lane], L.goaly[lane])));
+      const double diff = L.dprev[lane] - dnow;
+      if (!CF_FIN(f)) { rew += diff / 50.0; posrew += dm_max(0.0, diff / 50.0); }
+      L.prevx[lane] = px; L.prevy[lane] = py; L.dprev[lane] = dnow;
       if (lp >= LP_OverRoad) {
-        if (!s.finished) {
+        if (!CF_FIN(f)) {
           if (lp == LP_OverRoad && dnow < 100.0) {
-            lp = LP_AtGoal; s.finished = 1;
+            lp = LP_AtGoal;
+            f |= (1 << 4) | (1 << 6);  // finished, friction_car_crashed
             rew += (double)(DRV_MAX_TIME - elapsed) / 100.0;
             posrew += (double)(DRV_MAX_TIME - elapsed) / 100.0;
-            s.fric = 1;
           } else {
-            car_crash_flags(s);
-            rew -= vlen(v2(s.vx, s.vy)) / 5.0;
+            f |= CF_CRASH_BITS;
+            rew -= vlen(v2(vx, vy)) / 5.0;
           }
         }
       } else if (lp == LP_InOpposingLane) {
-        if (!s.finished) rew -= vlen(v2(s.vx, s.vy)) / 10000.0;
+        if (!CF_FIN(f)) rew -= vlen(v2(vx, vy)) / 10000.0;
       }
-      s.lanepos = lp;
-      if (s.prevx >= DRV_W + 50.0 || s.prevx <= -50.0 || s.prevy >= DRV_H + 50.0 || s.prevy <= -50.0) { s.vx = 0.0; s.vy = 0.0; }
-    } else if (isPed && !s.dead) {  // move :429-506
-      V2 pos = v2(s.px, s.py);
-      bool isOffRoad = drv_is_off_road(pos);
-      bool isOut = drv_is_out(pos);
-      if (s.moving > 0) {
-        s.moving = (s.moving - DRV_TIME_DIFF > 0) ? s.moving - DRV_TIME_DIFF : 0;
-        if (s.crossing) {
-          if (!s.beginc && isOffRoad) { s.moving = 0; s.crossing = 0; s.vx = 0.0; s.vy = 0.0; }
-          else if (s.beginc && !isOffRoad) { s.beginc = 0; }
-        }
-        if (isOut) { s.moving = 0; s.vx = 0.0; s.vy = 0.0; }
-      } else {
-        if (!s.crossing) {
-          dm_u32x4 u = dm_env_rng(S.seed, genv, episode, DM_RNG_PED_MOVE, (uint32_t)(lane - DRV_SLOT_PED), (uint32_t)elapsed);
-          V2 rdir = C.roads[s.road].dir, rnrm = C.roads[s.road].normal;
-          V2 dir = rdir;
-          s.moving = dm_randint(u.v[0], 5000, 30000);
-          int speed = dm_randint(u.v[1], -2, 2);
-          if (!isOffRoad) {
-            s.crossing = 1; s.beginc = 0;
-            if (speed == 0) speed = 2;
-          } else if (isOut) {
-            dir = drv_is_out(vadd(pos, rdir)) ? vneg(rdir) : rdir;
-          } else if (dm_unit(u.v[2]) < 0.05) {
-            s.crossing = 1; s.beginc = 1;
-            dir = s.side ? rnrm : vneg(rnrm);
-            s.side = s.side ? 0 : 1;
-            speed = dm_randint(u.v[3], 1, 2);
-          }
-          V2 nv = vmul(vmul(dir, (double)s.speed), (double)speed);
-          s.vx = nv.x; s.vy = nv.y;
-        } else if (isOffRoad) {
-          s.crossing = 0; s.beginc = 0;
-        }
-      }
-    }
-
-    // ---------------- Space.step(0.01): integrate positions (cpBodyUpdatePosition) ---------------------------
-    double rc = 1.0, rs = 0.0;
-    if (isBody) {
-      s.px = s.px + (s.vx + s.vbx) * DE_DT;
-      s.py = s.py + (s.vy + s.vby) * DE_DT;
-      s.ang = s.ang + (s.w + s.wb) * DE_DT;
-      s.vbx = 0.0; s.vby = 0.0; s.wb = 0.0;
-      if (isCar) dm_sincos(s.ang, &rs, &rc);
-    }
-    if (lane < DRV_NB) { L.px[lane] = s.px; L.py[lane] = s.py; L.rc[lane] = rc; L.rs[lane] = rs; }
-    if (isCar) {
-      BoxW bw;
-      box_world(bw, v2(s.px, s.py), rc, rs, hx, hy);
-      double l = INFINITY, r = -INFINITY, b = INFINITY, t = -INFINITY;
+      f = CF_SET_LP(f, lp);
+      if (px >= DRV_W + 50.0 || px <= -50.0 || py >= DRV_H + 50.0 || py <= -50.0) { vx = 0.0; vy = 0.0; }  // prevPos == pos here
+      L.flags[lane] = f;
+      // integrate position
+      const double w = L.w[lane];
+      const double vbx = L.vbx[lane], vby = L.vby[lane], wb = L.wb[lane];
+      const double npx = px + (vx + vbx) * DE_DT, npy = py + (vy + vby) * DE_DT, nang = ang + (w + wb) * DE_DT;
+      L.vx[lane] = vx; L.vy[lane] = vy;
+      L.px[lane] = npx; L.py[lane] = npy; L.ang[lane] = nang;
+      L.vbx[lane] = 0.0; L.vby[lane] = 0.0; L.wb[lane] = 0.0;
+      if (nang != L.rotAng[lane]) car_refresh_rot(L, lane, nang);
+      if (!aabbValid || npx != px || npy != py || nang != ang) {
+        BoxW bw;
+        box_world(bw, v2(npx, npy), L.rc[lane], L.rs[lane], L.chx[lane], L.chy[lane]);
+        double l = INFINITY, r = -INFINITY, b = INFINITY, t = -INFINITY;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        l = fmin_cp(l, bw.v[k].x); r = fmax_cp(r, bw.v[k].x); b = fmin_cp(b, bw.v[k].y); t = fmax_cp(t, bw.v[k].y);
+        for (int k = 0; k < 4; ++k) {
+          l = fmin_cp(l, bw.v[k].x); r = fmax_cp(r, bw.v[k].x); b = fmin_cp(b, bw.v[k].y); t = fmax_cp(t, bw.v[k].y);
+        }
+        L.aabb[lane][0] = l - 0.0; L.aabb[lane][1] = b - 0.0; L.aabb[lane][2] = r + 0.0; L.aabb[lane][3] = t + 0.0;
       }
-      L.aabb[lane][0] = l - 0.0; L.aabb[lane][1] = b - 0.0; L.aabb[lane][2] = r + 0.0; L.aabb[lane][3] = t + 0.0;
+    } else if (isPed) {
+      int f = L.flags[lane];
+      double px = L.px[lane], py = L.py[lane], vx = L.vx[lane], vy = L.vy[lane];
+      if (!PF_DEAD(f)) {  // move :429-506
+        int moving = L.moving[lane];
+        int crossing = PF_CROSSING(f), beginc = PF_BEGIN(f), side = PF_SIDE(f);
+        const V2 pos = v2(px, py);
+        const bool isOffRoad = drv_is_off_road(pos);
+        const bool isOut = drv_is_out(pos);
+        if (moving > 0) {
+          moving = (moving - DRV_TIME_DIFF > 0) ? moving - DRV_TIME_DIFF : 0;
+          if (crossing) {
+            if (!beginc && isOffRoad) { moving = 0; crossing = 0; vx = 0.0; vy = 0.0; }
+            else if (beginc && !isOffRoad) { beginc = 0; }
+          }
+          if (isOut) { moving = 0; vx = 0.0; vy = 0.0; }
+        } else {
+          if (!crossing) {
+            dm_u32x4 u = dm_env_rng(S.seed, genv, episode, DM_RNG_PED_MOVE, (uint32_t)(lane - DRV_SLOT_PED), (uint32_t)elapsed);
+            const bool r1 = PF_ROAD(f) != 0;
+            const V2 rdir = r1 ? v2(RoadK<1>::dirx, RoadK<1>::diry) : v2(RoadK<0>::dirx, RoadK<0>::diry);
+            const V2 rnrm = r1 ? v2(RoadK<1>::nx, RoadK<1>::ny) : v2(RoadK<0>::nx, RoadK<0>::ny);
+            V2 dir = rdir;
+            moving = dm_randint(u.v[0], 5000, 30000);
+            int speed = dm_randint(u.v[1], -2, 2);
+            if (!isOffRoad) {
+              crossing = 1; beginc = 0;
+              if (speed == 0) speed = 2;
+            } else if (isOut) {
+              dir = drv_is_out(vadd(pos, rdir)) ? vneg(rdir) : rdir;
+            } else if (dm_unit(u.v[2]) < 0.05) {
+              crossing = 1; beginc = 1;
+              dir = side ? rnrm : vneg(rnrm);
+              side = side ? 0 : 1;
+              speed = dm_randint(u.v[3], 1, 2);
+            }
+            const V2 nv = vmul(vmul(dir, (double)PF_SPEED(f)), (double)speed);
+            vx = nv.x; vy = nv.y;
+          } else if (isOffRoad) {
+            crossing = 0; beginc = 0;
+          }
+        }
+        L.moving[lane] = moving;
+        L.flags[lane] = PEDF_PACK(PF_ROAD(f), side, 0, crossing, beginc, PF_SPEED(f));
+      }
+      const double vbx = L.vbx[lane], vby = L.vby[lane], wb = L.wb[lane];
+      L.vx[lane] = vx; L.vy[lane] = vy;
+      L.px[lane] = px + (vx + vbx) * DE_DT; L.py[lane] = py + (vy + vby) * DE_DT;
+      L.ang[lane] = L.ang[lane] + (L.w[lane] + wb) * DE_DT;  // unobservable for circles, kept for completeness
+      L.vbx[lane] = 0.0; L.vby[lane] = 0.0; L.wb[lane] = 0.0;
     }
+    aabbValid = true;
     __syncthreads();
 
-    // ---------------- broadphase: exact AABB overlap on my 8 pairs ------------------------------------------
+    // ======== phase 2: broadphase — exact AABB overlap on my 8 pairs =========================================
     int cand = 0;
-#pragma unroll
+#pragma unroll 2
     for (int t = 0; t < DRV_NPAIR_ROUNDS; ++t) {
       int pr = MY_PAIR(t);
       if (pr != 0xFFFF) {
@@ -709,282 +1049,19 @@ drv_step_kernel(DrvState S, const int* __restrict__ actions, float* __restrict__
 
     if (anyCand == 0ull && occ == 0ull) {
       // ---------- fast path: nothing touches and the contact cache is empty: velocity update only ------------
-      if (isCar) {
-        if (s.fric) apply_friction(s.vx, s.vy, s.w, m, 5e-4, 2e-5, 0.0); else apply_friction(s.vx, s.vy, s.w, m, 5e-5, 1e-5, 0.0);
-      } else if (isPed) {
-        if (s.dead) apply_friction(s.vx, s.vy, s.w, m, 5e-2, 2e-4, 0.0);
-        else { s.vx = s.vx * 1.0 + (0.0 + 0.0) * DE_DT; s.vy = s.vy * 1.0 + (0.0 + 0.0) * DE_DT; s.w = s.w * 1.0 + 0.0; }
-      }
+      velocity_update(L, lane, isCar, isPed);
     } else {
-      // ---------- slow path: narrowphase -> arbiter cache -> callbacks -> prestep -> friction -> solver -------
-      if (lane < DRV_NS) L.mb_flag[lane] = 0;
-      __syncthreads();
-#pragma unroll 1
-      for (int t = 0; t < DRV_NPAIR_ROUNDS; ++t) {
-        const bool isCand = (cand >> t) & 1;
-        if (wave_ballot(isCand) == 0ull) continue;
-        Contacts ct;
-        ct.count = 0;
-        int pr = MY_PAIR(t);
-        if (isCand) {
-          int i = pr >> 8, j = pr & 0xFF;
-          BoxW b1;
-          box_world(b1, v2(L.px[i], L.py[i]), L.rc[i], L.rs[i], L.hx[i], L.hy[i]);
-          if (j < DRV_SLOT_PED) {
-            BoxW b2;
-            box_world(b2, v2(L.px[j], L.py[j]), L.rc[j], L.rs[j], L.hx[j], L.hy[j]);
-            poly_to_poly(b1, i, b2, j, ct);
-          } else if (j < DRV_SLOT_OBST) {
-            circle_to_poly(v2(L.px[j], L.py[j]), 5.0, b1, ct);
-          } else {
-            BoxW b2;
-            double ex = j >= DRV_SLOT_BLD ? 400.0 : 10.0, ey = j >= DRV_SLOT_BLD ? 225.0 : 10.0;
-            box_world(b2, static_pos(L, j), 1.0, 0.0, ex, ey);
-            poly_to_poly(b1, i, b2, j, ct);
-          }
-        }
-        const bool touch = isCand && ct.count > 0;
-        const uint64_t tmask = wave_ballot(touch);
-        if (tmask == 0ull) continue;
-        // find my slot among the occupied ones
-        int slot = -1;
-        if (touch) {
-          for (uint64_t mm = occ; mm; mm &= mm - 1) {
-            int sidx = __builtin_ctzll(mm);
-            if (L.slotPair[sidx] == pr) slot = sidx;
-          }
-        }
-        const bool needNew = touch && slot < 0;
-        const uint64_t newMask = wave_ballot(needNew);
-        if (newMask) {
-          int rank = __popcll(newMask & lanemask_lt());
-          uint64_t fm = (~occ) & ((DRV_NS >= 64) ? ~0ull : ((1ull << DRV_NS) - 1ull));
-          if (needNew) {
-            for (int r = 0; r < rank; ++r) fm &= fm - 1;
-            if (fm) { slot = __builtin_ctzll(fm); L.slotPair[slot] = pr; }
-            else err |= 1;  // contact cache overflow: pair dropped (reported through EI_ERR)
-          }
-          int cnt = __popcll(newMask);
-          uint64_t fm2 = (~occ) & ((DRV_NS >= 64) ? ~0ull : ((1ull << DRV_NS) - 1ull));
-          for (int r = 0; r < cnt && fm2; ++r) { occ |= (fm2 & (~fm2 + 1)); fm2 &= fm2 - 1; }
-        }
-        if (touch && slot >= 0) {
-          L.mb_flag[slot] = needNew ? 3 : 1;
-          L.mb_count[slot] = ct.count;
-          L.mb_nx[slot] = ct.n.x; L.mb_ny[slot] = ct.n.y;
-          L.mb_p1x[slot][0] = ct.p1[0].x; L.mb_p1y[slot][0] = ct.p1[0].y; L.mb_p2x[slot][0] = ct.p2[0].x; L.mb_p2y[slot][0] = ct.p2[0].y;
-          L.mb_hash[slot][0] = ct.hash[0];
-          if (ct.count > 1) {
-            L.mb_p1x[slot][1] = ct.p1[1].x; L.mb_p1y[slot][1] = ct.p1[1].y; L.mb_p2x[slot][1] = ct.p2[1].x; L.mb_p2y[slot][1] = ct.p2[1].y;
-            L.mb_hash[slot][1] = ct.hash[1];
-          }
-        }
-        __syncthreads();
-      }
-      __syncthreads();
-
-      // ---- slot lanes: cpArbiterUpdate for touched slots; ageing / expiry for the rest ----------------------
-      const bool slotOcc = lane < DRV_NS && ((occ >> lane) & 1ull);
-      bool touched = false;
-      int bodyA = 0, bodyB = 0;
-      V2 n = v2(0.0, 0.0), r1[2], r2[2];
-      r1[0] = r1[1] = r2[0] = r2[1] = v2(0.0, 0.0);
-      if (slotOcc) {
-        int flag = L.mb_flag[lane];
-        touched = flag != 0;
-        if (flag & 2) { s.a_pair = L.slotPair[lane]; s.a_state = ARB_FIRST; s.a_count = 0; s.a_age = 0; s.a_hash0 = s.a_hash1 = 0; }
-        if (touched) {
-          int i = s.a_pair >> 8, j = s.a_pair & 0xFF;
-          // narrowphase order: shape type ascending => pedestrian circle first for car-ped pairs
-          if (j >= DRV_SLOT_PED && j < DRV_SLOT_OBST) { bodyA = j; bodyB = i; } else { bodyA = i; bodyB = j; }
-          V2 pa = bodyA < DRV_SLOT_OBST ? v2(L.px[bodyA], L.py[bodyA]) : static_pos(L, bodyA);
-          V2 pb = bodyB < DRV_SLOT_OBST ? v2(L.px[bodyB], L.py[bodyB]) : static_pos(L, bodyB);
-          int cnt = L.mb_count[lane];
-          int h0 = L.mb_hash[lane][0], h1 = cnt > 1 ? L.mb_hash[lane][1] : 0;
-          double jn0 = 0.0, jt0 = 0.0, jn1 = 0.0, jt1 = 0.0;
-          // carry impulses of contacts with matching hash (later match wins, as in Chipmunk's loop)
-          if (s.a_count > 0 && h0 == s.a_hash0) { jn0 = s.a_jn0; jt0 = s.a_jt0; }
-          if (s.a_count > 1 && h0 == s.a_hash1) { jn0 = s.a_jn1; jt0 = s.a_jt1; }
-          if (cnt > 1) {
-            if (s.a_count > 0 && h1 == s.a_hash0) { jn1 = s.a_jn0; jt1 = s.a_jt0; }
-            if (s.a_count > 1 && h1 == s.a_hash1) { jn1 = s.a_jn1; jt1 = s.a_jt1; }
-          }
-          r1[0] = vsub(v2(L.mb_p1x[lane][0], L.mb_p1y[lane][0]), pa);
-          r2[0] = vsub(v2(L.mb_p2x[lane][0], L.mb_p2y[lane][0]), pb);
-          if (cnt > 1) {
-            r1[1] = vsub(v2(L.mb_p1x[lane][1], L.mb_p1y[lane][1]), pa);
-            r2[1] = vsub(v2(L.mb_p2x[lane][1], L.mb_p2y[lane][1]), pb);
-          }
-          n = v2(L.mb_nx[lane], L.mb_ny[lane]);
-          s.a_count = cnt; s.a_hash0 = h0; s.a_hash1 = h1;
-          s.a_jn0 = jn0; s.a_jt0 = jt0; s.a_jn1 = jn1; s.a_jt1 = jt1;
-          if (s.a_state == ARB_CACHED) s.a_state = ARB_FIRST;
-          s.a_age = 0;
-        }
-      }
-
-      // ---- rank touched slots by canonical pair order ------------------------------------------------------
-      const uint64_t touchedMask = wave_ballot(touched);
-      const int nTouched = __popcll(touchedMask);
-      int rank = 0;
-      const int pairKey = s.a_pair;
-      for (uint64_t mm = touchedMask; mm; mm &= mm - 1) {
-        int b = __builtin_ctzll(mm);
-        int pk = bcast_i(pairKey, b);
-        rank += (pk < pairKey) ? 1 : 0;
-      }
-
-      // ---- begin callbacks in canonical order (first contact only) ------------------------------------------
-      for (int k = 0; k < nTouched; ++k) {
-        uint64_t who = wave_ballot(touched && rank == k);
-        int b = __builtin_ctzll(who);
-        int st = bcast_i(s.a_state, b);
-        if (st != ARB_FIRST) continue;
-        int pk = bcast_i(pairKey, b);
-        bool keep = cb_begin(pk >> 8, pk & 0xFF, lane, s, rew);
-        if (!keep && lane == b) s.a_state = ARB_IGNORE;
-      }
-
-      // ---- expiry of untouched slots (cpSpaceArbiterSetFilter; no `separate` handlers in Driving) -----------
-      bool freeMe = false;
-      if (slotOcc && !touched) {
-        s.a_age += 1;
-        if (s.a_state != ARB_CACHED) s.a_state = ARB_CACHED;
-        if (s.a_age >= 3) freeMe = true;
-      }
-      const uint64_t freeMask = wave_ballot(freeMe);
-
-      // ---- publish velocities (callbacks may have zeroed a pedestrian) for prestep --------------------------
-      if (lane < DRV_NB) {
-        L.vx[lane] = s.vx; L.vy[lane] = s.vy; L.w[lane] = s.w; L.vbx[lane] = s.vbx; L.vby[lane] = s.vby; L.wb[lane] = s.wb;
-      }
-      __syncthreads();
-
-      // ---- active arbiters: levels (arbiters sharing a dynamic body keep their canonical sequential order) --
-      const bool active = touched && s.a_state != ARB_IGNORE;
-      const uint64_t activeMask = wave_ballot(active);
-      int myLevel = 0, maxLevel = -1, blvl = 0;
-      for (int k = 0; k < nTouched; ++k) {
-        uint64_t who = wave_ballot(active && rank == k);
-        if (who == 0ull) continue;
-        int b = __builtin_ctzll(who);
-        int ba = bcast_i(bodyA, b), bb2 = bcast_i(bodyB, b);
-        int la = ba < DRV_SLOT_OBST ? bcast_i(blvl, ba) : 0;
-        int lb = bb2 < DRV_SLOT_OBST ? bcast_i(blvl, bb2) : 0;
-        int lv = la > lb ? la : lb;
-        if (lane == b) myLevel = lv;
-        if (lane == ba || lane == bb2) blvl = lv + 1;  // static indices (>= 30) never equal a body lane (< 30)
-        maxLevel = lv > maxLevel ? lv : maxLevel;
-      }
-
-      // ---- prestep (cpArbiterPreStep) on velocities BEFORE the friction update -------------------------------
-      double nMass[2] = {0.0, 0.0}, tMass[2] = {0.0, 0.0}, bias[2] = {0.0, 0.0}, bounce[2] = {0.0, 0.0}, jBias[2] = {0.0, 0.0};
-      double jn[2] = {s.a_jn0, s.a_jn1}, jt[2] = {s.a_jt0, s.a_jt1};
-      const double arb_e = 0.05 * 0.05, arb_u = 0.0 * 0.0;
-      if (active) {
-        BodyV a, b;
-        body_load(L, bodyA, a);
-        body_load(L, bodyB, b);
-        V2 body_delta = vsub(b.p, a.p);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          if (c < s.a_count) {
-            nMass[c] = 1.0 / (k_scalar_body(a, r1[c], n) + k_scalar_body(b, r2[c], n));
-            tMass[c] = 1.0 / (k_scalar_body(a, r1[c], vperp(n)) + k_scalar_body(b, r2[c], vperp(n)));
-            double dist = vdot(vadd(vsub(r2[c], r1[c]), body_delta), n);
-            bias[c] = -DE_CONTACT_BIAS_COEF * fmin_cp(0.0, dist + DE_COLLISION_SLOP) / DE_DT;
-            jBias[c] = 0.0;
-            bounce[c] = vdot(relative_velocity(a, b, r1[c], r2[c]), n) * arb_e;
-          }
-        }
-      }
-      __syncthreads();
-
-      // ---- velocity update (velocity_func: friction_* or default) -------------------------------------------
-      if (isCar) {
-        if (s.fric) apply_friction(s.vx, s.vy, s.w, m, 5e-4, 2e-5, 0.0); else apply_friction(s.vx, s.vy, s.w, m, 5e-5, 1e-5, 0.0);
-      } else if (isPed) {
-        if (s.dead) apply_friction(s.vx, s.vy, s.w, m, 5e-2, 2e-4, 0.0);
-        else { s.vx = s.vx * 1.0 + (0.0 + 0.0) * DE_DT; s.vy = s.vy * 1.0 + (0.0 + 0.0) * DE_DT; s.w = s.w * 1.0 + 0.0; }
-      }
-      if (activeMask) {
-        if (lane < DRV_NB) { L.vx[lane] = s.vx; L.vy[lane] = s.vy; L.w[lane] = s.w; }
-        __syncthreads();
-        // ---- warm start (cpArbiterApplyCachedImpulse; skipped on first contact), level by level ------------
-        for (int lv = 0; lv <= maxLevel; ++lv) {
-          if (active && myLevel == lv && s.a_state != ARB_FIRST) {
-            BodyV a, b;
-            body_load(L, bodyA, a);
-            body_load(L, bodyB, b);
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-              if (c < s.a_count) {
-                V2 j = vrotate(n, v2(jn[c], jt[c]));
-                j = vmul(j, 1.0);  // dt_coef = dt/prev_dt = 1
-                apply_impulse(a, vneg(j), r1[c]);
-                apply_impulse(b, j, r2[c]);
-              }
-            }
-            body_store_vel(L, bodyA, a);
-            body_store_vel(L, bodyB, b);
-          }
-          __syncthreads();
-        }
-        // ---- 10 sequential-impulse iterations (cpArbiterApplyImpulse) ---------------------------------------
-        for (int iter = 0; iter < 10; ++iter) {
-          for (int lv = 0; lv <= maxLevel; ++lv) {
-            if (active && myLevel == lv) {
-              BodyV a, b;
-              body_load(L, bodyA, a);
-              body_load(L, bodyB, b);
-#pragma unroll
-              for (int c = 0; c < 2; ++c) {
-                if (c < s.a_count) {
-                  V2 vb1 = vadd(a.vb, vmul(vperp(r1[c]), a.wb));
-                  V2 vb2 = vadd(b.vb, vmul(vperp(r2[c]), b.wb));
-                  V2 vr = relative_velocity(a, b, r1[c], r2[c]);
-                  double vbn = vdot(vsub(vb2, vb1), n);
-                  double vrn = vdot(vr, n);
-                  double vrt = vdot(vr, vperp(n));
-                  double jbn = (bias[c] - vbn) * nMass[c];
-                  double jbnOld = jBias[c];
-                  jBias[c] = fmax_cp(jbnOld + jbn, 0.0);
-                  double jnn = -(bounce[c] + vrn) * nMass[c];
-                  double jnOld = jn[c];
-                  jn[c] = fmax_cp(jnOld + jnn, 0.0);
-                  double jtMax = arb_u * jn[c];
-                  double jtt = -vrt * tMass[c];
-                  double jtOld = jt[c];
-                  jt[c] = fclamp_cp(jtOld + jtt, -jtMax, jtMax);
-                  V2 jb = vmul(n, jBias[c] - jbnOld);
-                  apply_bias_impulse(a, vneg(jb), r1[c]);
-                  apply_bias_impulse(b, jb, r2[c]);
-                  V2 jj = vrotate(n, v2(jn[c] - jnOld, jt[c] - jtOld));
-                  apply_impulse(a, vneg(jj), r1[c]);
-                  apply_impulse(b, jj, r2[c]);
-                }
-              }
-              body_store_vel(L, bodyA, a);
-              body_store_vel(L, bodyB, b);
-            }
-            __syncthreads();
-          }
-        }
-        if (lane < DRV_NB && isBody) {
-          s.vx = L.vx[lane]; s.vy = L.vy[lane]; s.w = L.w[lane]; s.vbx = L.vbx[lane]; s.vby = L.vby[lane]; s.wb = L.wb[lane];
-        }
-        if (active) { s.a_jn0 = jn[0]; s.a_jt0 = jt[0]; s.a_jn1 = jn[1]; s.a_jt1 = jt[1]; }
-      }
-      // arbiters that were active this step are NORMAL from the next step on (cpSpaceStep resets the state)
-      if (active && s.a_state == ARB_FIRST) s.a_state = ARB_NORMAL;
-      if (freeMe) { s.a_pair = 0xFFFF; L.slotPair[lane] = 0xFFFF; }
-      occ &= ~freeMask;
-      __syncthreads();
+      // ---------- contact path (out of line): narrowphase -> contact cache -> callbacks -> prestep -> friction -> solver
+      ContactRet cr = drv_contact_path(lane, cand, pairLo, pairHi, occ, rew, isCar, isPed);
+      occ = uniform_u64(cr.occ); rew = cr.rew; err |= cr.err;
     }
+    __syncthreads();
 
-    // ---------------- bookkeeping :280-287 ------------------------------------------------------------------
+    // ======== bookkeeping :280-287 =========================================================================
     elapsed += 1;
-    const bool allFin = wave_ballot(isCar && !(s.finished && !s.crashed)) == 0ull;
+    bool notDone = false;
+    if (isCar) { int f = L.flags[lane]; notDone = !(CF_FIN(f) && !CF_CRASHED(f)); }
+    const bool allFin = wave_ballot(notDone) == 0ull;
     if (!allFinished && allFin) {
       allFinished = 1;
       teamReward += (double)(DRV_MAX_TIME - elapsed) / 100.0;
@@ -1007,31 +1084,20 @@ drv_step_kernel(DrvState S, const int* __restrict__ actions, float* __restrict__
   }
   const uint64_t errMask = wave_ballot(err != 0);
   if (errMask && lane == 0) envi[EI_ERR] = envi[EI_ERR] | 1;
-  store_lane(S, e, lane, isCar, isPed, occ, s);
-  if (obs) {
-    write_full_obs(L, lane, A, nPed, nObst, S.obs_dim, obs + (size_t)e * A * S.obs_dim, isCar, isPed, s.px, s.py, s.ang,
-                   s.type, s.finished, s.goalx, s.goaly);
-  }
+  store_env(S, L, e, lane, A, nPed, occ);
+  if (obs) write_full_obs(L, lane, A, nPed, nObst, S.obs_dim, obs + (size_t)e * A * S.obs_dim);
 }
 
 // ------------------------------------------------------------------------------------------------
 // observation-only kernel (used after reset / set_state)
 // ------------------------------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(64) drv_obs_kernel(DrvState S, float* __restrict__ obs) {
-  __shared__ DrvLds L;
+  DrvLds& L = g_L;
   const int e = blockIdx.x, lane = threadIdx.x, A = S.A;
   const int* envi = S.envi + (size_t)e * EI_COUNT;
   const int nPed = uniform_i(envi[EI_NPED]), nObst = uniform_i(envi[EI_NOBST]);
-  const bool isCar = lane < A, isPed = lane >= DRV_SLOT_PED && lane < DRV_SLOT_PED + nPed;
-  LaneState s;
-  load_lane(S, e, lane, isCar, isPed, 0ull, s);
-  if (lane < DRV_MAXO) {
-    L.ox[lane] = lane < nObst ? S.obst[(size_t)e * DRV_MAXO + lane] : 0.0;
-    L.oy[lane] = lane < nObst ? S.obst[(size_t)S.E * DRV_MAXO + (size_t)e * DRV_MAXO + lane] : 0.0;
-  }
-  __syncthreads();
-  write_full_obs(L, lane, A, nPed, nObst, S.obs_dim, obs + (size_t)e * A * S.obs_dim, isCar, isPed, s.px, s.py, s.ang, s.type,
-                 s.finished, s.goalx, s.goaly);
+  load_env(S, L, e, lane, A, nPed, nObst, 0ull);
+  write_full_obs(L, lane, A, nPed, nObst, S.obs_dim, obs + (size_t)e * A * S.obs_dim);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -40,6 +40,7 @@ static void road_init_host(DrvRoad& r, int nLanes, double width, V2 p0, V2 p1) {
   r.dir = v2(d.x / r.length, d.y / r.length);
   r.normal = vrot_angle(r.dir, DM_PI / 2.0);
   r.dirAngle = dm_atan2(r.dir.y, r.dir.x);
+  r.cosDir0 = dm_cos(r.dirAngle - 0.0);
   double k = (double)(nLanes + 1) * width;
   r.walk[0][0] = vadd(p0, vmul(r.normal, k)); r.walk[0][1] = vadd(p1, vmul(r.normal, k));
   r.walk[1][0] = vsub(p0, vmul(r.normal, k)); r.walk[1][1] = vsub(p1, vmul(r.normal, k));
@@ -97,6 +98,15 @@ static void build_consts(DrvConst& c) {
   for (; p < DRV_NPAIR_ROUNDS * 64; ++p) c.pairs[p] = 0xFFFF;
 }
 
+// the device code spells the road constants as literals (RoadK<R>): they must equal the computed ones bit for bit
+template <int R>
+static bool road_literals_ok(const DrvRoad& r) {
+  return r.p0.x == RoadK<R>::p0x && r.p0.y == RoadK<R>::p0y && r.dir.x == RoadK<R>::dirx && r.dir.y == RoadK<R>::diry &&
+         (double)r.nLanes * r.width + 5.0 == RoadK<R>::lat && r.length == RoadK<R>::length &&
+         r.dirAngle == RoadK<R>::dirAngle && r.cosDir0 == RoadK<R>::cosDir0 && r.normal.x == RoadK<R>::nx &&
+         r.normal.y == RoadK<R>::ny;
+}
+
 // ---------------------------------------------------------------------------------------------- helpers
 template <typename T>
 static int dev_alloc(dynenv* h, T** out, size_t count) {
@@ -151,6 +161,10 @@ int dynenv_create(const dynenv_cfg_t* cfg, dynenv_t** out) {
   if (rc) { dynenv_destroy(h); return DYNENV_ERR_HIP; }
   DrvConst c;
   build_consts(c);
+  if (!road_literals_ok<0>(c.roads[0]) || !road_literals_ok<1>(c.roads[1])) {
+    dynenv_destroy(h);
+    return fail(DYNENV_ERR_HIP, "internal: RoadK literals differ from the computed road constants");
+  }
   hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(C), &c, sizeof(c));
   if (e != hipSuccess) { dynenv_destroy(h); return fail(DYNENV_ERR_HIP, hipGetErrorString(e)); }
   *out = h;
