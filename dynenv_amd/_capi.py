@@ -51,7 +51,7 @@ class DrivingState(C.Structure):
 EXPORTS = ["dynenv_abi_version", "dynenv_last_error", "dynenv_create", "dynenv_destroy", "dynenv_layout",
            "dynenv_seed", "dynenv_reset", "dynenv_step", "dynenv_counts", "dynenv_episode_stats",
            "dynenv_state_size", "dynenv_get_state", "dynenv_set_state", "dynenv_sync", "dynenv_math_selftest",
-           "dynenv_error_flags"]
+           "dynenv_error_flags", "dynenv_debug_counters"]
 
 _lib = None
 
@@ -86,6 +86,7 @@ def load():
     lib.dynenv_sync.argtypes = [vp, vp]
     lib.dynenv_math_selftest.argtypes = [vp, vp, C.c_int32, vp, C.c_int32]
     lib.dynenv_error_flags.argtypes = [vp, C.POINTER(C.c_int32)]
+    lib.dynenv_debug_counters.argtypes = [vp, C.POINTER(C.c_int64)]
     if lib.dynenv_abi_version() != DYNENV_ABI_VERSION:
         raise DynEnvError("ABI version mismatch between dynenv_amd and libdynenv_hip.so")
     _lib = lib

@@ -24,6 +24,9 @@ struct DrvMailbox {  // narrowphase result of the pair that maps to slot s (writ
   double p1x[DRV_NS][2], p1y[DRV_NS][2], p2x[DRV_NS][2], p2y[DRV_NS][2], nx[DRV_NS], ny[DRV_NS];
   int hash[DRV_NS][2], count[DRV_NS], flag[DRV_NS]; /* flag: bit0 touched, bit1 newly allocated */
 };
+struct DrvPrefilter {  // fp32 conservative AABB (centre, half extent + 1 px margin) of the 32 dynamic slots; rewritten
+  float cx[DRV_NB], cy[DRV_NB], hx[DRV_NB], hy[DRV_NB];  // every substep before the broadphase (aliases the mailbox)
+};
 struct DrvObsStage {  // f32 staging of the observation rows (only used after the last substep)
   float carRow[DRV_MAXA][8];
   float goal[DRV_MAXA][2];
@@ -45,9 +48,11 @@ struct __align__(16) DrvLds {
   // contact cache slots (lane s = slot s)
   int s_pair[DRV_NS], s_meta[DRV_NS], s_hash0[DRV_NS], s_hash1[DRV_NS];
   double s_jn0[DRV_NS], s_jt0[DRV_NS], s_jn1[DRV_NS], s_jt1[DRV_NS];
+  int still[DRV_NB];  // body had exactly zero v, w, v_bias, w_bias when positions were integrated this substep
   union {
     DrvMailbox mb;
     DrvObsStage ob;
+    DrvPrefilter pf;
   } u;
 };
 
@@ -138,18 +143,17 @@ DE_DEV void apply_friction(double& vx, double& vy, double& w, double m, double f
 }
 
 // velocity_func of body `lane` on the LDS tile (friction_car / friction_car_crashed / friction_pedestrian_dead /
-// default cpBodyUpdateVelocity)
+// default cpBodyUpdateVelocity): parameters are selected per lane so that ONE instance of the arithmetic serves all
 DE_DEV void velocity_update(DrvLds& L, int lane, bool isCar, bool isPed) {
   if (!(isCar || isPed)) return;
   double vx = L.vx[lane], vy = L.vy[lane], w = L.w[lane];
-  int f = L.flags[lane];
-  if (isCar) {
-    double m = L.cmass[lane];
-    if (CF_FRIC(f)) apply_friction(vx, vy, w, m, 5e-4, 2e-5, 0.0); else apply_friction(vx, vy, w, m, 5e-5, 1e-5, 0.0);
-  } else {
-    if (PF_DEAD(f)) apply_friction(vx, vy, w, C.pedMass, 5e-2, 2e-4, 0.0);
-    else { vx = vx * 1.0 + (0.0 + 0.0) * DE_DT; vy = vy * 1.0 + (0.0 + 0.0) * DE_DT; w = w * 1.0 + 0.0; }
-  }
+  const int f = L.flags[lane];
+  double m, fr, rfr;
+  bool dflt = false;
+  if (isCar) { m = L.cmass[lane]; fr = CF_FRIC(f) ? 5e-4 : 5e-5; rfr = CF_FRIC(f) ? 2e-5 : 1e-5; }
+  else { m = 90.0; fr = 5e-2; rfr = 2e-4; dflt = !PF_DEAD(f); }
+  if (dflt) { vx = vx * 1.0 + (0.0 + 0.0) * DE_DT; vy = vy * 1.0 + (0.0 + 0.0) * DE_DT; w = w * 1.0 + 0.0; }
+  else apply_friction(vx, vy, w, m, fr, rfr, 0.0);
   L.vx[lane] = vx; L.vy[lane] = vy; L.w[lane] = w;
 }
 
@@ -828,6 +832,7 @@ __device__ __noinline__ ContactRet drv_contact_path(int lane, int cand, uint64_t
     }
   }
   // arbiters that were active this step are NORMAL from the next step on (cpSpaceStep resets the state)
+  const bool wasNormal = a_state == ARB_NORMAL;  // i.e. not a first contact in this substep
   if (active && a_state == ARB_FIRST) a_state = ARB_NORMAL;
   if (slotOcc) {
     if (freeMe) L.s_pair[lane] = 0xFFFF;
@@ -835,8 +840,17 @@ __device__ __noinline__ ContactRet drv_contact_path(int lane, int cand, uint64_t
     if (touched) { L.s_jn0[lane] = jn[0]; L.s_jt0[lane] = jt[0]; L.s_jn1[lane] = jn[1]; L.s_jt1[lane] = jt[1]; }
   }
   occ &= ~freeMask;
+  // inert: touched, not first contact, and (ignored | zero bias and zero accumulated impulses on every contact)
+  bool inert = true;
+  if (slotOcc) {
+    inert = touched && !freeMe &&
+            (a_state == ARB_IGNORE ||
+             (a_state == ARB_NORMAL && wasNormal && bias[0] == 0.0 && bias[1] == 0.0 && jn[0] == 0.0 && jt[0] == 0.0 &&
+              jn[1] == 0.0 && jt[1] == 0.0 && jBias[0] == 0.0 && jBias[1] == 0.0));
+  }
+  const bool allInert = wave_ballot(!inert) == 0ull;
   ContactRet ret;
-  ret.occ = occ; ret.rew = rew; ret.err = err;
+  ret.occ = occ; ret.rew = rew; ret.err = err | (allInert ? 2 : 0);
   return ret;
 }
 
@@ -885,13 +899,20 @@ drv_step_kernel(DrvState S, const int* __restrict__ actions, float* __restrict__
   if (isCar) { act0 = actions[((size_t)e * A + lane) * 2 + 0]; act1 = actions[((size_t)e * A + lane) * 2 + 1]; }
   double rew = 0.0, posrew = 0.0, teamReward = 0.0;  // :252-254
   bool aabbValid = false;
+  // quiescent-shortcut state carried across launches: candidate mask of the previous substep (-1: unknown) and
+  // whether every cached arbiter was inert when the contact path last ran
+  int lastCand = S.lastcand[(size_t)e * 64 + lane];
+  bool inertAll = uniform_i(envi[EI_PAD]) != 0;
+  int nFast = 0, nQuiet = 0, nContact = 0, nSlots = 0;  // diagnostics
   __syncthreads();
 
   for (int it = 0; it < 10; ++it) {
-    // ======== phase 1: game logic on own body, then cpBodyUpdatePosition ===================================
+    // ======== phase 1a: car game logic (processAction at substep 0, tick) ===================================
+    bool turned = false;  // Car.turn rotated the body in place: geometry changed even if every velocity is zero
     if (isCar) {
       int f = L.flags[lane];
-      double px = L.px[lane], py = L.py[lane], vx = L.vx[lane], vy = L.vy[lane], ang = L.ang[lane];
+      const double px = L.px[lane], py = L.py[lane];
+      double vx = L.vx[lane], vy = L.vy[lane];
       if (it == 0) {  // processAction :357-373 -> Car.accelerate (Car.py:55-94), Car.turn (Car.py:97-108)
         const int acc = act0 - 1, steer = (act1 - 1) * 2;
         if (!CF_FIN(f)) {
@@ -911,14 +932,16 @@ drv_step_kernel(DrvState S, const int* __restrict__ actions, float* __restrict__
           }
           if (steer != 0) {
             const double rot = (double)steer * (DM_PI / 180.0);
-            ang = ang + rot;
+            const double ang = L.ang[lane] + rot;
             const DevSC rsc = dev_sincos(rot);
             const double sn = rsc.s, cs = rsc.c;
             const double dx = dirx * cs - diry * sn, dy = dirx * sn + diry * cs;
             L.dirx[lane] = dx; L.diry[lane] = dy;
             const double nvx = vx * cs - vy * sn, nvy = vx * sn + vy * cs;
             vx = nvx; vy = nvy;
+            L.ang[lane] = ang;
             car_refresh_rot(L, lane, ang);
+            turned = true;
           }
         }
       }
@@ -933,7 +956,7 @@ drv_step_kernel(DrvState S, const int* __restrict__ actions, float* __restrict__
       }
       const double dnow = vlen(vsub(pos, v2(L.goalx[lane], L.goaly[lane])));
       const double diff = L.dprev[lane] - dnow;
-      if (!CF_FIN(f)) { rew += diff / 50.0; posrew += dm_max(0.0, diff / 50.0); }
+      if (!CF_FIN(f)) { const double d50 = diff / 50.0; rew += d50; posrew += dm_max(0.0, d50); }
       L.prevx[lane] = px; L.prevy[lane] = py; L.dprev[lane] = dnow;
       if (lp >= LP_OverRoad) {
         if (!CF_FIN(f)) {
@@ -953,31 +976,15 @@ drv_step_kernel(DrvState S, const int* __restrict__ actions, float* __restrict__
       f = CF_SET_LP(f, lp);
       if (px >= DRV_W + 50.0 || px <= -50.0 || py >= DRV_H + 50.0 || py <= -50.0) { vx = 0.0; vy = 0.0; }  // prevPos == pos here
       L.flags[lane] = f;
-      // integrate position
-      const double w = L.w[lane];
-      const double vbx = L.vbx[lane], vby = L.vby[lane], wb = L.wb[lane];
-      const double npx = px + (vx + vbx) * DE_DT, npy = py + (vy + vby) * DE_DT, nang = ang + (w + wb) * DE_DT;
       L.vx[lane] = vx; L.vy[lane] = vy;
-      L.px[lane] = npx; L.py[lane] = npy; L.ang[lane] = nang;
-      L.vbx[lane] = 0.0; L.vby[lane] = 0.0; L.wb[lane] = 0.0;
-      if (nang != L.rotAng[lane]) car_refresh_rot(L, lane, nang);
-      if (!aabbValid || npx != px || npy != py || nang != ang) {
-        BoxW bw;
-        box_world(bw, v2(npx, npy), L.rc[lane], L.rs[lane], L.chx[lane], L.chy[lane]);
-        double l = INFINITY, r = -INFINITY, b = INFINITY, t = -INFINITY;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          l = fmin_cp(l, bw.v[k].x); r = fmax_cp(r, bw.v[k].x); b = fmin_cp(b, bw.v[k].y); t = fmax_cp(t, bw.v[k].y);
-        }
-        L.aabb[lane][0] = l - 0.0; L.aabb[lane][1] = b - 0.0; L.aabb[lane][2] = r + 0.0; L.aabb[lane][3] = t + 0.0;
-      }
     } else if (isPed) {
-      int f = L.flags[lane];
-      double px = L.px[lane], py = L.py[lane], vx = L.vx[lane], vy = L.vy[lane];
-      if (!PF_DEAD(f)) {  // move :429-506
+      // ======== phase 1b: pedestrian FSM (move :429-506) ====================================================
+      const int f = L.flags[lane];
+      if (!PF_DEAD(f)) {
+        double vx = L.vx[lane], vy = L.vy[lane];
         int moving = L.moving[lane];
         int crossing = PF_CROSSING(f), beginc = PF_BEGIN(f), side = PF_SIDE(f);
-        const V2 pos = v2(px, py);
+        const V2 pos = v2(L.px[lane], L.py[lane]);
         const bool isOffRoad = drv_is_off_road(pos);
         const bool isOut = drv_is_out(pos);
         if (moving > 0) {
@@ -1015,45 +1022,95 @@ drv_step_kernel(DrvState S, const int* __restrict__ actions, float* __restrict__
         }
         L.moving[lane] = moving;
         L.flags[lane] = PEDF_PACK(PF_ROAD(f), side, 0, crossing, beginc, PF_SPEED(f));
+        L.vx[lane] = vx; L.vy[lane] = vy;
       }
+    }
+
+    // ======== phase 1c: cpBodyUpdatePosition for every body (one instance of the code for cars + pedestrians) ===
+    if (isBody) {
+      const double px = L.px[lane], py = L.py[lane], ang = L.ang[lane];
+      const double vx = L.vx[lane], vy = L.vy[lane], w = L.w[lane];
       const double vbx = L.vbx[lane], vby = L.vby[lane], wb = L.wb[lane];
-      L.vx[lane] = vx; L.vy[lane] = vy;
-      L.px[lane] = px + (vx + vbx) * DE_DT; L.py[lane] = py + (vy + vby) * DE_DT;
-      L.ang[lane] = L.ang[lane] + (L.w[lane] + wb) * DE_DT;  // unobservable for circles, kept for completeness
+      const double npx = px + (vx + vbx) * DE_DT, npy = py + (vy + vby) * DE_DT, nang = ang + (w + wb) * DE_DT;
+      const bool still = !turned && vx == 0.0 && vy == 0.0 && w == 0.0 && vbx == 0.0 && vby == 0.0 && wb == 0.0;
+      L.px[lane] = npx; L.py[lane] = npy; L.ang[lane] = nang;
       L.vbx[lane] = 0.0; L.vby[lane] = 0.0; L.wb[lane] = 0.0;
+      L.still[lane] = still ? 1 : 0;
+      float fcx = (float)npx, fcy = (float)npy, fhx = 6.0f, fhy = 6.0f;  // pedestrian circle r = 5 (+1 px margin)
+      if (isCar) {
+        if (nang != L.rotAng[lane]) car_refresh_rot(L, lane, nang);
+        if (!aabbValid || !still) {
+          BoxW bw;
+          box_world(bw, v2(npx, npy), L.rc[lane], L.rs[lane], L.chx[lane], L.chy[lane]);
+          double l = INFINITY, r = -INFINITY, b = INFINITY, t = -INFINITY;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            l = fmin_cp(l, bw.v[k].x); r = fmax_cp(r, bw.v[k].x); b = fmin_cp(b, bw.v[k].y); t = fmax_cp(t, bw.v[k].y);
+          }
+          L.aabb[lane][0] = l - 0.0; L.aabb[lane][1] = b - 0.0; L.aabb[lane][2] = r + 0.0; L.aabb[lane][3] = t + 0.0;
+        }
+        const double al = L.aabb[lane][0], ab = L.aabb[lane][1], ar = L.aabb[lane][2], at = L.aabb[lane][3];
+        fcx = (float)(0.5 * (al + ar)); fcy = (float)(0.5 * (ab + at));
+        fhx = (float)(0.5 * (ar - al)) + 1.0f; fhy = (float)(0.5 * (at - ab)) + 1.0f;
+      }
+      L.u.pf.cx[lane] = fcx; L.u.pf.cy[lane] = fcy; L.u.pf.hx[lane] = fhx; L.u.pf.hy[lane] = fhy;
     }
     aabbValid = true;
     __syncthreads();
 
-    // ======== phase 2: broadphase — exact AABB overlap on my 8 pairs =========================================
+    // ======== phase 2: broadphase on my 8 pairs: fp32 conservative prefilter, then the exact AABB test ==========
     int cand = 0;
+    bool candMoving = false;
 #pragma unroll 2
     for (int t = 0; t < DRV_NPAIR_ROUNDS; ++t) {
-      int pr = MY_PAIR(t);
+      const int pr = MY_PAIR(t);
       if (pr != 0xFFFF) {
-        int i = pr >> 8, j = pr & 0xFF;
-        double al = L.aabb[i][0], ab = L.aabb[i][1], ar = L.aabb[i][2], at = L.aabb[i][3];
-        double bl, bb, br, bt;
-        if (j < DRV_SLOT_PED) { bl = L.aabb[j][0]; bb = L.aabb[j][1]; br = L.aabb[j][2]; bt = L.aabb[j][3]; }
-        else if (j < DRV_SLOT_OBST) { double cx = L.px[j], cy = L.py[j]; bl = cx - 5.0; bb = cy - 5.0; br = cx + 5.0; bt = cy + 5.0; }
+        const int i = pr >> 8, j = pr & 0xFF;
+        float bx, by, bhx, bhy;
+        if (j < DRV_SLOT_OBST) { bx = L.u.pf.cx[j]; by = L.u.pf.cy[j]; bhx = L.u.pf.hx[j]; bhy = L.u.pf.hy[j]; }
         else {
-          V2 c = static_pos(L, j);
-          double ex = j >= DRV_SLOT_BLD ? 400.0 : 10.0, ey = j >= DRV_SLOT_BLD ? 225.0 : 10.0;
-          // static box AABB = min/max of (c +- e) exactly as cached by cpShapeCacheBB with rot = (1,0)
-          bl = -ex + c.x; br = ex + c.x; bb = -ey + c.y; bt = ey + c.y;
+          const V2 c = static_pos(L, j);
+          bx = (float)c.x; by = (float)c.y;
+          bhx = j >= DRV_SLOT_BLD ? 401.0f : 11.0f; bhy = j >= DRV_SLOT_BLD ? 226.0f : 11.0f;
         }
-        if (al <= br && bl <= ar && ab <= bt && bb <= at) cand |= (1 << t);
+        const float dx = L.u.pf.cx[i] - bx, dy = L.u.pf.cy[i] - by;
+        if (__builtin_fabsf(dx) <= L.u.pf.hx[i] + bhx && __builtin_fabsf(dy) <= L.u.pf.hy[i] + bhy) {
+          const double al = L.aabb[i][0], ab = L.aabb[i][1], ar = L.aabb[i][2], at = L.aabb[i][3];
+          double bl, bb, br, bt;
+          if (j < DRV_SLOT_PED) { bl = L.aabb[j][0]; bb = L.aabb[j][1]; br = L.aabb[j][2]; bt = L.aabb[j][3]; }
+          else if (j < DRV_SLOT_OBST) { double cx = L.px[j], cy = L.py[j]; bl = cx - 5.0; bb = cy - 5.0; br = cx + 5.0; bt = cy + 5.0; }
+          else {
+            const V2 c = static_pos(L, j);
+            const double ex = j >= DRV_SLOT_BLD ? 400.0 : 10.0, ey = j >= DRV_SLOT_BLD ? 225.0 : 10.0;
+            // static box AABB = min/max of (c +- e) exactly as cached by cpShapeCacheBB with rot = (1,0)
+            bl = -ex + c.x; br = ex + c.x; bb = -ey + c.y; bt = ey + c.y;
+          }
+          if (al <= br && bl <= ar && ab <= bt && bb <= at) {
+            cand |= (1 << t);
+            if (!(L.still[i] && (j >= DRV_SLOT_OBST || L.still[j]))) candMoving = true;
+          }
+        }
       }
     }
     const uint64_t anyCand = wave_ballot(cand != 0);
+    // Quiescent contact set: same candidate pairs as in the previous substep, every body in them exactly at rest and
+    // every cached arbiter inert (zero bias, zero accumulated impulse, not first contact).  Then narrowphase, arbiter
+    // update, warm start and all 10 solver iterations are exact no-ops (DESIGN.md "quiescent shortcut") and only the
+    // velocity update remains.
+    const bool quiescent = inertAll && wave_ballot(cand != lastCand || candMoving) == 0ull;
+    lastCand = cand;
+    __syncthreads();  // the prefilter aliases the contact mailbox
 
-    if (anyCand == 0ull && occ == 0ull) {
-      // ---------- fast path: nothing touches and the contact cache is empty: velocity update only ------------
+    if (anyCand == 0ull && occ == 0ull) nFast++; else if (quiescent) nQuiet++; else nContact++;
+    nSlots += __popcll(occ);
+    if ((anyCand == 0ull && occ == 0ull) || quiescent) {
+      // ---------- fast path: nothing touches and the contact cache is empty (or quiescent): velocity update only
       velocity_update(L, lane, isCar, isPed);
     } else {
       // ---------- contact path (out of line): narrowphase -> contact cache -> callbacks -> prestep -> friction -> solver
       ContactRet cr = drv_contact_path(lane, cand, pairLo, pairHi, occ, rew, isCar, isPed);
-      occ = uniform_u64(cr.occ); rew = cr.rew; err |= cr.err;
+      occ = uniform_u64(cr.occ); rew = cr.rew; err |= cr.err & 1;
+      inertAll = uniform_i(cr.err >> 1) != 0;
     }
     __syncthreads();
 
@@ -1081,9 +1138,12 @@ drv_step_kernel(DrvState S, const int* __restrict__ actions, float* __restrict__
   if (lane == 0) {
     dones[e] = (uint8_t)(elapsed >= DRV_MAX_TIME);
     envi[EI_ELAPSED] = elapsed; envi[EI_ALLFIN] = allFinished; envi[EI_OCC] = (int)(uint32_t)occ;
+    envi[EI_PAD] = inertAll ? 1 : 0;
+    envi[EI_N_FAST] += nFast; envi[EI_N_QUIET] += nQuiet; envi[EI_N_CONTACT] += nContact; envi[EI_N_SLOTS] += nSlots;
   }
   const uint64_t errMask = wave_ballot(err != 0);
   if (errMask && lane == 0) envi[EI_ERR] = envi[EI_ERR] | 1;
+  S.lastcand[(size_t)e * 64 + lane] = lastCand;
   store_env(S, L, e, lane, A, nPed, occ);
   if (obs) write_full_obs(L, lane, A, nPed, nObst, S.obs_dim, obs + (size_t)e * A * S.obs_dim);
 }
@@ -1195,6 +1255,8 @@ extern "C" __global__ void __launch_bounds__(64) drv_reset_kernel(DrvState S) {
   }
   envi[EI_ELAPSED] = 0; envi[EI_ALLFIN] = 0; envi[EI_NPED] = nPed; envi[EI_NOBST] = nObst;
   envi[EI_EPISODE] = (int)(ep + 1); envi[EI_OCC] = 0; envi[EI_ERR] = 0;
+  envi[EI_N_FAST] = 0; envi[EI_N_QUIET] = 0; envi[EI_N_CONTACT] = 0; envi[EI_N_SLOTS] = 0; envi[EI_PAD] = 0;
+  for (int k = 0; k < 64; ++k) S.lastcand[(size_t)e * 64 + k] = -1;
 }
 
 // episode_g = [#finished & !crashed, #crashed] (:315-316) + episode accumulators, gathered for the host mirror

@@ -158,6 +158,7 @@ int dynenv_create(const dynenv_cfg_t* cfg, dynenv_t** out) {
   rc |= dev_alloc(h, &S.s_meta, E * DRV_NS);
   rc |= dev_alloc(h, &S.s_hash, 2 * E * DRV_NS);
   rc |= dev_alloc(h, &S.s_imp, 4 * E * DRV_NS);
+  rc |= dev_alloc(h, &S.lastcand, E * 64);
   if (rc) { dynenv_destroy(h); return DYNENV_ERR_HIP; }
   DrvConst c;
   build_consts(c);
@@ -259,6 +260,18 @@ int dynenv_error_flags(dynenv_t* h, int32_t* out) {
   return DYNENV_OK;
 }
 
+// diagnostics: per-path substep counts since the last reset, summed over envs: {fast, quiescent, contact, slot-sum}
+int dynenv_debug_counters(dynenv_t* h, int64_t* out4) {
+  if (!h || !out4) return fail(DYNENV_ERR_ARG, "null argument");
+  HIP_OK(hipDeviceSynchronize());
+  std::vector<int> envi((size_t)h->S.E * EI_COUNT);
+  HIP_OK(hipMemcpy(envi.data(), h->S.envi, envi.size() * sizeof(int), hipMemcpyDeviceToHost));
+  out4[0] = out4[1] = out4[2] = out4[3] = 0;
+  for (int e = 0; e < h->S.E; ++e)
+    for (int k = 0; k < 4; ++k) out4[k] += envi[(size_t)e * EI_COUNT + EI_N_FAST + k];
+  return DYNENV_OK;
+}
+
 int dynenv_get_state(dynenv_t* h, int32_t env, void* blob, size_t nbytes) {
   if (!h || !blob) return fail(DYNENV_ERR_ARG, "null argument");
   if (env < 0 || env >= h->S.E || nbytes < sizeof(dynenv_driving_state_t)) return fail(DYNENV_ERR_ARG, "bad env index / size");
@@ -347,6 +360,7 @@ int dynenv_set_state(dynenv_t* h, int32_t env, const void* blob, size_t nbytes) 
   HIP_OK(hipMemcpy(S.flags + (size_t)env * DRV_NB, flags, sizeof(flags), hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(S.aux + (size_t)env * DRV_NB, aux, sizeof(aux), hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(S.envi + (size_t)env * EI_COUNT, envi, sizeof(envi), hipMemcpyHostToDevice));
+  HIP_OK(hipMemset(S.lastcand + (size_t)env * 64, 0xFF, 64 * sizeof(int)));  // -1: quiescent shortcut state unknown
   return DYNENV_OK;
 }
 

@@ -203,6 +203,11 @@ class BatchedDynEnv(object):
         _capi.check(self._lib.dynenv_error_flags(self._h, C.byref(f)), "dynenv_error_flags")
         return f.value
 
+    def debug_counters(self):
+        out = (C.c_int64 * 4)()
+        _capi.check(self._lib.dynenv_debug_counters(self._h, out), "dynenv_debug_counters")
+        return dict(fast=out[0], quiescent=out[1], contact=out[2], slot_sum=out[3])
+
     def get_state(self, env=0):
         st = _capi.DrivingState()
         _capi.check(self._lib.dynenv_get_state(self._h, env, C.byref(st), C.sizeof(st)), "dynenv_get_state")

@@ -153,6 +153,10 @@ int dynenv_sync(dynenv_t* h, void* stream);
  * Synchronises the device. */
 int dynenv_error_flags(dynenv_t* h, int32_t* out);
 
+/* Diagnostics (Driving): substeps since the last reset taken by {no-contact fast path, quiescent shortcut, full contact
+ * path} and the sum of live contact-cache slots, summed over environments.  Synchronises the device. */
+int dynenv_debug_counters(dynenv_t* h, int64_t* out4);
+
 /* Device self-test of the deterministic math header: evaluates sincos/atan2/sqrt/div on n host-provided doubles and
  * returns the raw results so tests can compare them bit-for-bit with the host evaluation. out: [n,5]. */
 int dynenv_math_selftest(const double* x_host, const double* y_host, int32_t n, double* out_host, int32_t device_id);
