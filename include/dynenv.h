@@ -115,6 +115,26 @@ typedef struct dynenv_driving_state {
   double obst_x[DYNENV_MAX_OBST], obst_y[DYNENV_MAX_OBST];
 } dynenv_driving_state_t;
 
+/* RoboCup blob.  set_state clears the contact cache, the joints' accumulated impulses and pending fall forces. */
+#define DYNENV_MAX_ROBOTS 10
+typedef struct dynenv_robot_state {
+  double lpx, lpy, lvx, lvy, la, lw; /* left foot body */
+  double rpx, rpy, rvx, rvy, ra, rw; /* right foot body */
+  double head_angle, head_moving, prevx, prevy, initx, inity, penal_time, fall_time, move_time;
+  int32_t team, penalized, touching, touch_cntr, might_push, fallen, fall_cntr, kicking, foot, joint_removed;
+  int32_t pad[2];
+} dynenv_robot_state_t;
+
+typedef struct dynenv_robocup_state {
+  int32_t elapsed, n_robots, ball_owned, n_last_kicked;
+  int32_t last_kicked[4], goals[2], closest[2], n_def[2], defenders[2][DYNENV_MAX_ROBOTS];
+  int32_t episode, pad;
+  double ball_free_cntr, grace_period, penal_times[2];
+  double bpx, bpy, bvx, bvy, bw, bprevx, bprevy;
+  double episode_r[DYNENV_MAX_ROBOTS], episode_pos_r[DYNENV_MAX_ROBOTS];
+  dynenv_robot_state_t robots[DYNENV_MAX_ROBOTS];
+} dynenv_robocup_state_t;
+
 typedef struct dynenv dynenv_t;
 
 int dynenv_abi_version(void);

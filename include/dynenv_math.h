@@ -211,6 +211,18 @@ DM_FN int32_t dm_randint(uint32_t u, int32_t lo, int32_t hi) {
 /* uniform double in [0,1) with 32-bit resolution (exact conversion) */
 DM_FN double dm_unit(uint32_t u) { return (double)u * 2.3283064365386962890625e-10; }
 
+/* b ** n for small non-negative integer n by square-and-multiply (deterministic on host and device; the reference's
+ * `0.9999 ** touchCntr` dice thresholds, RoboCupEnvironment.py:1065,1069,1117) */
+DM_FN double dm_powi(double b, int n) {
+  double r = 1.0;
+  while (n > 0) {
+    if (n & 1) r = r * b;
+    b = b * b;
+    n >>= 1;
+  }
+  return r;
+}
+
 /* RNG purposes (counter word c1) */
 #define DM_RNG_RESET_AGENT 1u
 #define DM_RNG_RESET_PERM 2u

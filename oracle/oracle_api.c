@@ -9,6 +9,7 @@
 #endif
 
 #include "driving.h"
+#include "robocup.h"
 #include "dynenv.h"
 #include "dynenv_math.h"
 
@@ -16,6 +17,7 @@ typedef struct oracle {
   dynenv_cfg_t cfg;
   int n_agents, obs_dim, n_time_steps, action_dim;
   DrivingEnv* drv;
+  RoboCupEnv* rc;
   int threads;
 } oracle_t;
 
@@ -34,6 +36,14 @@ int oracle_create(const dynenv_cfg_t* cfg, oracle_t** out) {
     o->action_dim = 2;
     o->drv = (DrivingEnv*)calloc((size_t)cfg->num_envs, sizeof(DrivingEnv));
     for (i = 0; i < cfg->num_envs; ++i) drv_init(&o->drv[i], cfg->n_players, cfg->seed, (uint32_t)(cfg->env_id_offset + i));
+  } else if (cfg->env_type == DYNENV_ROBO_CUP) {
+    if (cfg->obs_type != DYNENV_OBS_FULL) { free(o); return DYNENV_ERR_UNSUPPORTED; }
+    o->n_agents = 2 * (cfg->n_players > RC_MAX_PLAYERS ? RC_MAX_PLAYERS : cfg->n_players);
+    o->obs_dim = rc_obs_dim(o->n_agents / 2);
+    o->n_time_steps = 5;
+    o->action_dim = 4;
+    o->rc = (RoboCupEnv*)calloc((size_t)cfg->num_envs, sizeof(RoboCupEnv));
+    for (i = 0; i < cfg->num_envs; ++i) rc_init(&o->rc[i], cfg->n_players, cfg->seed, (uint32_t)(cfg->env_id_offset + i), cfg->flags);
   } else {
     free(o);
     return DYNENV_ERR_UNSUPPORTED;
@@ -45,6 +55,7 @@ int oracle_create(const dynenv_cfg_t* cfg, oracle_t** out) {
 void oracle_destroy(oracle_t* o) {
   if (!o) return;
   free(o->drv);
+  free(o->rc);
   free(o);
 }
 
@@ -63,6 +74,12 @@ int oracle_layout(const oracle_t* o, dynenv_layout_t* L) {
     L->block_offset[3] = L->block_offset[2] + DYNENV_MAX_OBST * 4; L->block_rows[3] = DYNENV_MAX_PEDS; L->block_feat[3] = 2;
     L->block_offset[4] = L->block_offset[3] + DYNENV_MAX_PEDS * 2; L->block_rows[4] = DYNENV_DRIVE_LANES; L->block_feat[4] = 5;
     L->steps_per_episode = DRV_MAX_TIME / DRV_STEP_ITER;
+  } else {
+    L->n_blocks = 3; /* ((ball, robots), (self,)) of RoboCupEnvironment.py:440-443 */
+    L->block_offset[0] = 0; L->block_rows[0] = 1; L->block_feat[0] = 4;
+    L->block_offset[1] = 4; L->block_rows[1] = 1; L->block_feat[1] = 8;
+    L->block_offset[2] = 12; L->block_rows[2] = A - 1; L->block_feat[2] = 6;
+    L->steps_per_episode = RC_MAX_TIME / RC_STEP_ITER;
   }
   return DYNENV_OK;
 }
@@ -72,8 +89,15 @@ int oracle_reset(oracle_t* o, float* obs) {
   size_t stride = (size_t)o->n_time_steps * o->n_agents * o->obs_dim;
 #pragma omp parallel for schedule(static) num_threads(o->threads)
   for (e = 0; e < E; ++e) {
-    drv_reset(&o->drv[e]);
-    if (obs) drv_write_full_obs(&o->drv[e], obs + e * stride);
+    if (o->drv) {
+      drv_reset(&o->drv[e]);
+      if (obs) drv_write_full_obs(&o->drv[e], obs + e * stride);
+    } else {
+      int t;
+      rc_reset(&o->rc[e]);
+      /* environment_base.py:217-222: nTimeSteps identical copies of the initial observation */
+      if (obs) for (t = 0; t < o->n_time_steps; ++t) rc_write_full_obs(&o->rc[e], obs + e * stride + (size_t)t * o->n_agents * o->obs_dim);
+    }
   }
   return DYNENV_OK;
 }
@@ -83,7 +107,8 @@ int oracle_step(oracle_t* o, const int32_t* actions, float* obs, double* rewards
   size_t stride = (size_t)o->n_time_steps * A * o->obs_dim;
 #pragma omp parallel for schedule(static) num_threads(o->threads)
   for (e = 0; e < E; ++e) {
-    int d = drv_step(&o->drv[e], actions + (size_t)e * A * 2, obs ? obs + e * stride : 0, rewards + (size_t)e * A);
+    int d = o->drv ? drv_step(&o->drv[e], actions + (size_t)e * A * 2, obs ? obs + e * stride : 0, rewards + (size_t)e * A)
+                   : rc_step(&o->rc[e], actions + (size_t)e * A * 4, obs ? obs + e * stride : 0, rewards + (size_t)e * A);
     dones[e] = (uint8_t)d;
   }
   return DYNENV_OK;
@@ -91,12 +116,27 @@ int oracle_step(oracle_t* o, const int32_t* actions, float* obs, double* rewards
 
 int oracle_counts(oracle_t* o, int32_t* counts) {
   int e;
-  for (e = 0; e < o->cfg.num_envs; ++e) { counts[2 * e] = o->drv[e].nObst; counts[2 * e + 1] = o->drv[e].nPeds; }
+  for (e = 0; e < o->cfg.num_envs; ++e) {
+    counts[2 * e] = o->drv ? o->drv[e].nObst : 0;
+    counts[2 * e + 1] = o->drv ? o->drv[e].nPeds : 0;
+  }
   return DYNENV_OK;
 }
 
 int oracle_episode_stats(oracle_t* o, double* ep_r, double* ep_pos_r, double* ep_obs_r, int32_t* goals) {
   int e, a, A = o->n_agents;
+  if (o->rc) {
+    for (e = 0; e < o->cfg.num_envs; ++e) {
+      const RoboCupEnv* r = &o->rc[e];
+      for (a = 0; a < A; ++a) {
+        if (ep_r) ep_r[e * A + a] = r->episodeRewards[a];
+        if (ep_pos_r) ep_pos_r[e * A + a] = r->episodePosRewards[a];
+        if (ep_obs_r) ep_obs_r[e * A + a] = 0.0;
+      }
+      if (goals) { goals[2 * e] = r->goals[0]; goals[2 * e + 1] = r->goals[1]; }
+    }
+    return DYNENV_OK;
+  }
   for (e = 0; e < o->cfg.num_envs; ++e) {
     const DrivingEnv* d = &o->drv[e];
     int fin = 0, crashed = 0;
@@ -112,23 +152,25 @@ int oracle_episode_stats(oracle_t* o, double* ep_r, double* ep_pos_r, double* ep
   return DYNENV_OK;
 }
 
-size_t oracle_state_size(const oracle_t* o) { (void)o; return sizeof(dynenv_driving_state_t); }
+size_t oracle_state_size(const oracle_t* o) { return o->drv ? sizeof(dynenv_driving_state_t) : sizeof(dynenv_robocup_state_t); }
 int oracle_get_state(oracle_t* o, int32_t env, void* blob, size_t n) {
-  if (env < 0 || env >= o->cfg.num_envs || n < sizeof(dynenv_driving_state_t)) return DYNENV_ERR_ARG;
-  drv_get_state(&o->drv[env], (dynenv_driving_state_t*)blob);
+  if (env < 0 || env >= o->cfg.num_envs || n < oracle_state_size(o)) return DYNENV_ERR_ARG;
+  if (o->drv) drv_get_state(&o->drv[env], (dynenv_driving_state_t*)blob);
+  else rc_get_state(&o->rc[env], (dynenv_robocup_state_t*)blob);
   return DYNENV_OK;
 }
 int oracle_set_state(oracle_t* o, int32_t env, const void* blob, size_t n) {
-  if (env < 0 || env >= o->cfg.num_envs || n < sizeof(dynenv_driving_state_t)) return DYNENV_ERR_ARG;
-  drv_set_state(&o->drv[env], (const dynenv_driving_state_t*)blob);
+  if (env < 0 || env >= o->cfg.num_envs || n < oracle_state_size(o)) return DYNENV_ERR_ARG;
+  if (o->drv) drv_set_state(&o->drv[env], (const dynenv_driving_state_t*)blob);
+  else rc_set_state(&o->rc[env], (const dynenv_robocup_state_t*)blob);
   return DYNENV_OK;
 }
 int oracle_overflow(oracle_t* o) {
   int e, f = 0;
-  for (e = 0; e < o->cfg.num_envs; ++e) f |= o->drv[e].space.overflow;
+  for (e = 0; e < o->cfg.num_envs; ++e) f |= o->drv ? o->drv[e].space.overflow : o->rc[e].space.overflow;
   return f;
 }
-int oracle_active_contacts(oracle_t* o, int32_t env) { return o->drv[env].space.n_active; }
+int oracle_active_contacts(oracle_t* o, int32_t env) { return o->drv ? o->drv[env].space.n_active : o->rc[env].space.n_active; }
 
 /* ---- unit entry points for the golden tests (tests/test_oracle_golden.py) ---- */
 void oracle_math(const double* x, const double* y, int n, double* out) {
@@ -257,4 +299,45 @@ double oracle_bias_coef(int which) {
   cpSpace sp; cpSpaceInit(&sp);
   if (which == 0) return 1.0 - pow(sp.collisionBias, 0.01);
   return 1.0 - pow(0.1, 0.01);
+}
+
+/* ---- RoboCup unit entry points for the golden tests ---- */
+int rc_test_begin(RoboCupEnv* e, int slotA, int slotB);
+void rc_test_zero_rewards(RoboCupEnv* e);
+void rc_test_get_rewards(const RoboCupEnv* e, double* out22);
+void oracle_rc_process_action(oracle_t* o, int env, int robot, const int32_t* action, double* rew22) {
+  rc_test_zero_rewards(&o->rc[env]);
+  rc_process_action(&o->rc[env], &o->rc[env].robots[robot], action);
+  rc_test_get_rewards(&o->rc[env], rew22);
+}
+void oracle_rc_tick(oracle_t* o, int env, int robot, double* rew22) {
+  rc_test_zero_rewards(&o->rc[env]);
+  rc_tick(&o->rc[env], &o->rc[env].robots[robot]);
+  rc_test_get_rewards(&o->rc[env], rew22);
+}
+int oracle_rc_ball(oracle_t* o, int env, double* rew22) {
+  int f;
+  rc_test_zero_rewards(&o->rc[env]);
+  f = rc_is_ball_out_of_field(&o->rc[env]);
+  rc_test_get_rewards(&o->rc[env], rew22);
+  return f;
+}
+void oracle_rc_penalize(oracle_t* o, int env, int robot, double* rew22) {
+  rc_test_zero_rewards(&o->rc[env]);
+  rc_penalize(&o->rc[env], &o->rc[env].robots[robot]);
+  rc_test_get_rewards(&o->rc[env], rew22);
+}
+int oracle_rc_begin(oracle_t* o, int env, int slotA, int slotB, double* rew22) {
+  int r;
+  rc_test_zero_rewards(&o->rc[env]);
+  r = rc_test_begin(&o->rc[env], slotA, slotB);
+  rc_test_get_rewards(&o->rc[env], rew22);
+  return r;
+}
+int oracle_rc_joint_count(oracle_t* o, int env) { return o->rc[env].space.n_constraints; }
+void oracle_rc_obs(oracle_t* o, int env, float* out) { rc_write_full_obs(&o->rc[env], out); }
+void oracle_rc_spots(const double* rnd18, double* out20) {
+  cpv spots[2][5]; int t, i;
+  rc_spots(rnd18, spots);
+  for (t = 0; t < 2; ++t) for (i = 0; i < 5; ++i) { out20[(t * 5 + i) * 2] = spots[t][i].x; out20[(t * 5 + i) * 2 + 1] = spots[t][i].y; }
 }

@@ -122,6 +122,12 @@ class _Shape(object):
         self.color = None
 
 
+class _Joint(object):  # identity-compared placeholder for PivotJoint / RotaryLimitJoint (never solved here)
+    def __init__(self, *a, **k):
+        self.args = a
+        self.error_bias = 0
+
+
 class _Handler(object):
     begin = post_solve = separate = None
 
@@ -194,7 +200,7 @@ def install_standins():
     pgu.DrawOptions = lambda *a: None
     pm.pygame_util = pgu
     cons = types.ModuleType("pymunk.constraint")
-    cons.PivotJoint = cons.RotaryLimitJoint = lambda *a, **k: types.SimpleNamespace(error_bias=0)
+    cons.PivotJoint = cons.RotaryLimitJoint = _Joint
     pm.constraint = cons
     sys.modules.update({"pymunk": pm, "pymunk.pygame_util": pgu, "pymunk.constraint": cons})
 

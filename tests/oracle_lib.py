@@ -48,6 +48,30 @@ class DrivingState(C.Structure):
                 ("obst_y", C.c_double * 20)]
 
 
+ROBOT_F = ("lpx", "lpy", "lvx", "lvy", "la", "lw", "rpx", "rpy", "rvx", "rvy", "ra", "rw", "head_angle", "head_moving",
+           "prevx", "prevy", "initx", "inity", "penal_time", "fall_time", "move_time")
+ROBOT_I = ("team", "penalized", "touching", "touch_cntr", "might_push", "fallen", "fall_cntr", "kicking", "foot",
+           "joint_removed")
+
+
+class RobotState(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ROBOT_F] + [(n, C.c_int32) for n in ROBOT_I] + [("pad", C.c_int32 * 2)]
+
+
+class RoboCupState(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("elapsed", "n_robots", "ball_owned", "n_last_kicked")] + \
+               [("last_kicked", C.c_int32 * 4), ("goals", C.c_int32 * 2), ("closest", C.c_int32 * 2),
+                ("n_def", C.c_int32 * 2), ("defenders", (C.c_int32 * 10) * 2), ("episode", C.c_int32),
+                ("pad", C.c_int32), ("ball_free_cntr", C.c_double), ("grace_period", C.c_double),
+                ("penal_times", C.c_double * 2)] + \
+               [(n, C.c_double) for n in ("bpx", "bpy", "bvx", "bvy", "bw", "bprevx", "bprevy")] + \
+               [("episode_r", C.c_double * 10), ("episode_pos_r", C.c_double * 10), ("robots", RobotState * 10)]
+
+
+FLAG_RANDOM_INIT, FLAG_DETERMINISTIC_TURN, FLAG_CAN_FALL, FLAG_USE_OBS_REWARDS, FLAG_ALLOW_HEAD_TURN = 1, 2, 4, 8, 16
+ROBOCUP_DEFAULT_FLAGS = FLAG_CAN_FALL | FLAG_USE_OBS_REWARDS  # class switches, RoboCupEnvironment.py:18-21
+
+
 def build():
     subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
 
@@ -137,7 +161,7 @@ class OracleEnv:
         return r, p, o, g
 
     def get_state(self, env=0):
-        st = DrivingState()
+        st = DrivingState() if self.cfg.env_type == 1 else RoboCupState()
         rc = self.l.oracle_get_state(self.h, env, C.byref(st), C.sizeof(st))
         assert rc == 0
         return st
@@ -164,3 +188,16 @@ def state_to_dict(st):
                 episode_r=np.array(st.episode_r[:nc]), episode_pos_r=np.array(st.episode_pos_r[:nc]),
                 cars_f=cars_f, cars_i=cars_i, peds_f=peds_f, peds_i=peds_i,
                 obst=np.array([list(st.obst_x[:no]), list(st.obst_y[:no])]))
+
+
+def rc_state_to_dict(st):
+    n = st.n_robots
+    rf = np.array([[getattr(st.robots[i], k) for k in ROBOT_F] for i in range(n)])
+    ri = np.array([[getattr(st.robots[i], k) for k in ROBOT_I] for i in range(n)], dtype=np.int64)
+    sc = np.array([st.elapsed, n, st.ball_owned, st.n_last_kicked] + list(st.last_kicked)[:st.n_last_kicked] +
+                  list(st.goals) + list(st.closest) + list(st.n_def) + list(st.defenders[0])[:st.n_def[0]] +
+                  list(st.defenders[1])[:st.n_def[1]] + [st.episode])
+    fl = np.array([st.ball_free_cntr, st.grace_period, st.penal_times[0], st.penal_times[1], st.bpx, st.bpy, st.bvx,
+                   st.bvy, st.bw, st.bprevx, st.bprevy])
+    return dict(robots_f=rf, robots_i=ri, scalars=sc, floats=fl, episode_r=np.array(st.episode_r[:n]),
+                episode_pos_r=np.array(st.episode_pos_r[:n]))
