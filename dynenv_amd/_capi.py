@@ -48,6 +48,28 @@ class DrivingState(C.Structure):
                 ("obst_y", C.c_double * 20)]
 
 
+ROBOT_F = ("lpx", "lpy", "lvx", "lvy", "la", "lw", "rpx", "rpy", "rvx", "rvy", "ra", "rw", "head_angle", "head_moving",
+           "prevx", "prevy", "initx", "inity", "penal_time", "fall_time", "move_time")
+ROBOT_I = ("team", "penalized", "touching", "touch_cntr", "might_push", "fallen", "fall_cntr", "kicking", "foot",
+           "joint_removed")
+
+
+class RobotState(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ROBOT_F] + [(n, C.c_int32) for n in ROBOT_I] + [("pad", C.c_int32 * 2)]
+
+
+class RoboCupState(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("elapsed", "n_robots", "ball_owned", "n_last_kicked")] + \
+               [("last_kicked", C.c_int32 * 4), ("goals", C.c_int32 * 2), ("closest", C.c_int32 * 2),
+                ("n_def", C.c_int32 * 2), ("defenders", (C.c_int32 * 10) * 2), ("episode", C.c_int32),
+                ("pad", C.c_int32), ("ball_free_cntr", C.c_double), ("grace_period", C.c_double),
+                ("penal_times", C.c_double * 2)] + \
+               [(n, C.c_double) for n in ("bpx", "bpy", "bvx", "bvy", "bw", "bprevx", "bprevy")] + \
+               [("episode_r", C.c_double * 10), ("episode_pos_r", C.c_double * 10), ("robots", RobotState * 10)]
+
+
+FLAG_RANDOM_INIT, FLAG_DETERMINISTIC_TURN, FLAG_CAN_FALL, FLAG_USE_OBS_REWARDS, FLAG_ALLOW_HEAD_TURN = 1, 2, 4, 8, 16
+
 EXPORTS = ["dynenv_abi_version", "dynenv_last_error", "dynenv_create", "dynenv_destroy", "dynenv_layout",
            "dynenv_seed", "dynenv_reset", "dynenv_step", "dynenv_counts", "dynenv_episode_stats",
            "dynenv_state_size", "dynenv_get_state", "dynenv_set_state", "dynenv_sync", "dynenv_math_selftest",

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "driving_kernels.hip"
+#include "robocup_kernels.hip"
 #include "dynenv.h"
 
 static thread_local std::string g_err;
@@ -29,6 +30,8 @@ struct dynenv {
   dynenv_cfg_t cfg;
   int A, obs_dim, T, action_dim;
   DrvState S;
+  RcState R;
+  bool robocup;
   std::vector<void*> allocs;
 };
 
@@ -118,6 +121,160 @@ static int dev_alloc(dynenv* h, T** out, size_t count) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------- RoboCup host side
+static double moment_for_segment_host(double m, V2 a, V2 b, double r) {  // cpMomentForSegment
+  V2 offset = vlerp(a, b, 0.5);
+  V2 d = vsub(b, a);
+  double length = dm_sqrt(vdot(d, d)) + 2.0 * r;
+  return m * ((length * length + 4.0 * r * r) / 12.0 + vlensq(offset));
+}
+
+static int rc_create(dynenv* h) {
+  const dynenv_cfg_t& cfg = h->cfg;
+  RcState& R = h->R;
+  memset(&R, 0, sizeof(R));
+  const size_t E = (size_t)cfg.num_envs;
+  R.E = (int)E; R.n = cfg.n_players > 5 ? 5 : cfg.n_players; R.R = 2 * R.n;  // environment_base.py:57, maxPlayers = 5
+  R.obs_dim = 4 + 8 + (R.R - 1) * 6;
+  R.seed = cfg.seed; R.env_id_offset = cfg.env_id_offset; R.flags = cfg.flags;
+  h->A = R.R; h->obs_dim = R.obs_dim; h->T = 5; h->action_dim = 4;
+  int rc = 0;
+  rc |= dev_alloc(h, &R.body, (size_t)(RB_COUNT + 4) * E * RC_NB);
+  rc |= dev_alloc(h, &R.rob, (size_t)RR_COUNT * E * 16);
+  rc |= dev_alloc(h, &R.robi, (size_t)RI_COUNT * E * 16);
+  rc |= dev_alloc(h, &R.envi, E * RE_COUNT);
+  rc |= dev_alloc(h, &R.envd, E * RD_COUNT);
+  rc |= dev_alloc(h, &R.epr, 2 * E * 16);
+  rc |= dev_alloc(h, &R.s_pair, E * RC_NS);
+  rc |= dev_alloc(h, &R.s_meta, E * RC_NS);
+  rc |= dev_alloc(h, &R.s_hash, 2 * E * RC_NS);
+  rc |= dev_alloc(h, &R.s_imp, 4 * E * RC_NS);
+  if (rc) return DYNENV_ERR_HIP;
+  RcConst c;
+  memset(&c, 0, sizeof(c));
+  c.footInertia = moment_for_segment_host(4000.0, v2(-10.0, 10.0), v2(10.0, 10.0), 7.5);  // Robot.py:34
+  c.ballInertia = 10.0 * (0.5 * (0.0 * 0.0 + 10.0 * 10.0) + 0.0);                          // Ball.py:9
+  int p = 0;
+  for (int i = 0; i <= RC_BALL; ++i)
+    for (int j = i + 1; j < RC_POST + 4; ++j) c.pairs[p++] = (uint16_t)((i << 8) | j);
+  for (; p < RC_NPAIR_ROUNDS * 64; ++p) c.pairs[p] = 0xFFFF;
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(RC), &c, sizeof(c));
+  if (e != hipSuccess) return fail(DYNENV_ERR_HIP, hipGetErrorString(e));
+  return 0;
+}
+
+template <typename T>
+static int rows_d2h(T* dst, const T* src, size_t nfields, size_t E, size_t width, int env) {
+  for (size_t f = 0; f < nfields; ++f)
+    HIP_OK(hipMemcpy(dst + f * width, src + f * E * width + (size_t)env * width, sizeof(T) * width, hipMemcpyDeviceToHost));
+  return 0;
+}
+template <typename T>
+static int rows_h2d(T* dst, const T* src, size_t nfields, size_t E, size_t width, int env) {
+  for (size_t f = 0; f < nfields; ++f)
+    HIP_OK(hipMemcpy(dst + f * E * width + (size_t)env * width, src + f * width, sizeof(T) * width, hipMemcpyHostToDevice));
+  return 0;
+}
+
+static int rc_get_state_host(dynenv* h, int32_t env, void* blob, size_t nbytes) {
+  const RcState& R = h->R;
+  if (env < 0 || env >= R.E || nbytes < sizeof(dynenv_robocup_state_t)) return fail(DYNENV_ERR_ARG, "bad env index / size");
+  HIP_OK(hipSetDevice(h->cfg.device_id));
+  HIP_OK(hipDeviceSynchronize());
+  const size_t E = (size_t)R.E;
+  static thread_local double body[RB_COUNT + 4][RC_NB], rob[RR_COUNT][16], envd[RD_COUNT], epr[2][16];
+  static thread_local int robi[RI_COUNT][16], envi[RE_COUNT];
+  if (rows_d2h(&body[0][0], R.body, RB_COUNT + 4, E, RC_NB, env) || rows_d2h(&rob[0][0], R.rob, RR_COUNT, E, 16, env) ||
+      rows_d2h(&robi[0][0], R.robi, RI_COUNT, E, 16, env) || rows_d2h(&epr[0][0], R.epr, 2, E, 16, env))
+    return DYNENV_ERR_HIP;
+  HIP_OK(hipMemcpy(envi, R.envi + (size_t)env * RE_COUNT, sizeof(envi), hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(envd, R.envd + (size_t)env * RD_COUNT, sizeof(envd), hipMemcpyDeviceToHost));
+  dynenv_robocup_state_t* st = (dynenv_robocup_state_t*)blob;
+  memset(st, 0, sizeof(*st));
+  st->elapsed = envi[RE_ELAPSED]; st->n_robots = R.R; st->ball_owned = envi[RE_OWNED]; st->n_last_kicked = envi[RE_NLK];
+  for (int i = 0; i < 4; ++i) st->last_kicked[i] = i < envi[RE_NLK] ? envi[RE_LK0 + i] : 0;
+  st->goals[0] = envi[RE_GOAL0]; st->goals[1] = envi[RE_GOAL1]; st->closest[0] = envi[RE_CLOSE0]; st->closest[1] = envi[RE_CLOSE1];
+  for (int t = 0; t < 2; ++t) {  // defenders are a set on the device: reported in ascending id order
+    int n = 0;
+    for (int i = 0; i < DYNENV_MAX_ROBOTS; ++i) if (envi[RE_DEF0 + t] & (1 << i)) st->defenders[t][n++] = i;
+    st->n_def[t] = n;
+    st->penal_times[t] = envd[RD_PT0 + t];
+  }
+  st->episode = envi[RE_EPISODE];
+  st->ball_free_cntr = envd[RD_FREECNT]; st->grace_period = envd[RD_GRACE];
+  st->bpx = body[RB_PX][RC_BALL]; st->bpy = body[RB_PY][RC_BALL]; st->bvx = body[RB_VX][RC_BALL]; st->bvy = body[RB_VY][RC_BALL];
+  st->bw = body[RB_W][RC_BALL]; st->bprevx = envd[RD_BPREVX]; st->bprevy = envd[RD_BPREVY];
+  for (int i = 0; i < DYNENV_MAX_ROBOTS; ++i) { st->episode_r[i] = epr[0][i]; st->episode_pos_r[i] = epr[1][i]; }
+  for (int i = 0; i < R.R; ++i) {
+    dynenv_robot_state_t& s = st->robots[i];
+    const int l = 2 * i, r = 2 * i + 1, f = robi[RI_FLAGS][i];
+    s.lpx = body[RB_PX][l]; s.lpy = body[RB_PY][l]; s.lvx = body[RB_VX][l]; s.lvy = body[RB_VY][l]; s.la = body[RB_ANG][l]; s.lw = body[RB_W][l];
+    s.rpx = body[RB_PX][r]; s.rpy = body[RB_PY][r]; s.rvx = body[RB_VX][r]; s.rvy = body[RB_VY][r]; s.ra = body[RB_ANG][r]; s.rw = body[RB_W][r];
+    s.head_angle = rob[RR_HEAD][i]; s.head_moving = rob[RR_HEADMOV][i]; s.prevx = rob[RR_PREVX][i]; s.prevy = rob[RR_PREVY][i];
+    s.initx = rob[RR_INITX][i]; s.inity = rob[RR_INITY][i]; s.penal_time = rob[RR_PENALT][i]; s.fall_time = rob[RR_FALLT][i];
+    s.move_time = rob[RR_MOVET][i];
+    s.team = (f & RF_TEAMPOS) ? 1 : -1; s.penalized = !!(f & RF_PENAL); s.touching = !!(f & RF_TOUCH); s.might_push = !!(f & RF_PUSH);
+    s.fallen = !!(f & RF_FALLEN); s.kicking = !!(f & RF_KICK); s.foot = !!(f & RF_FOOT); s.joint_removed = !!(f & RF_JREM);
+    s.touch_cntr = robi[RI_TOUCHC][i]; s.fall_cntr = robi[RI_FALLC][i];
+  }
+  return DYNENV_OK;
+}
+
+static int rc_set_state_host(dynenv* h, int32_t env, const void* blob, size_t nbytes) {
+  const RcState& R = h->R;
+  if (env < 0 || env >= R.E || nbytes < sizeof(dynenv_robocup_state_t)) return fail(DYNENV_ERR_ARG, "bad env index / size");
+  const dynenv_robocup_state_t* st = (const dynenv_robocup_state_t*)blob;
+  if (st->n_robots != R.R) return fail(DYNENV_ERR_ARG, "state blob does not match this handle's layout");
+  HIP_OK(hipSetDevice(h->cfg.device_id));
+  HIP_OK(hipDeviceSynchronize());
+  const size_t E = (size_t)R.E;
+  static thread_local double body[RB_COUNT + 4][RC_NB], rob[RR_COUNT][16], envd[RD_COUNT], epr[2][16];
+  static thread_local int robi[RI_COUNT][16], envi[RE_COUNT];
+  memset(body, 0, sizeof(body)); memset(rob, 0, sizeof(rob)); memset(envd, 0, sizeof(envd)); memset(epr, 0, sizeof(epr));
+  memset(robi, 0, sizeof(robi)); memset(envi, 0, sizeof(envi));
+  int ncon = 0;
+  for (int i = 0; i < R.R; ++i) {
+    const dynenv_robot_state_t& s = st->robots[i];
+    const int l = 2 * i, r = 2 * i + 1;
+    body[RB_PX][l] = s.lpx; body[RB_PY][l] = s.lpy; body[RB_VX][l] = s.lvx; body[RB_VY][l] = s.lvy; body[RB_ANG][l] = s.la; body[RB_W][l] = s.lw;
+    body[RB_PX][r] = s.rpx; body[RB_PY][r] = s.rpy; body[RB_VX][r] = s.rvx; body[RB_VY][r] = s.rvy; body[RB_ANG][r] = s.ra; body[RB_W][r] = s.rw;
+    for (int k = 0; k < 2; ++k) {  // shape cache = geometry at cpSpaceAddShape time
+      const int b = 2 * i + k;
+      double sn, cs;
+      dm_sincos(body[RB_ANG][b], &sn, &cs);
+      body[RB_COUNT + 0][b] = body[RB_PX][b]; body[RB_COUNT + 1][b] = body[RB_PY][b]; body[RB_COUNT + 2][b] = cs; body[RB_COUNT + 3][b] = sn;
+    }
+    rob[RR_HEAD][i] = s.head_angle; rob[RR_HEADMOV][i] = s.head_moving; rob[RR_PREVX][i] = s.prevx; rob[RR_PREVY][i] = s.prevy;
+    rob[RR_INITX][i] = s.initx; rob[RR_INITY][i] = s.inity; rob[RR_PENALT][i] = s.penal_time; rob[RR_FALLT][i] = s.fall_time;
+    rob[RR_MOVET][i] = s.move_time;
+    int f = (s.team > 0 ? RF_TEAMPOS : 0) | (s.penalized ? RF_PENAL : 0) | (s.touching ? RF_TOUCH : 0) | (s.might_push ? RF_PUSH : 0) |
+            (s.fallen ? RF_FALLEN : 0) | (s.kicking ? RF_KICK : 0) | (s.foot ? RF_FOOT : 0) | (s.joint_removed ? RF_JREM : 0);
+    robi[RI_FLAGS][i] = f; robi[RI_TOUCHC][i] = s.touch_cntr; robi[RI_FALLC][i] = s.fall_cntr;
+    if (!s.joint_removed) envi[RE_CORDER + ncon++] = 2 * i;
+    envi[RE_CORDER + ncon++] = 2 * i + 1;
+  }
+  body[RB_PX][RC_BALL] = st->bpx; body[RB_PY][RC_BALL] = st->bpy; body[RB_VX][RC_BALL] = st->bvx; body[RB_VY][RC_BALL] = st->bvy;
+  body[RB_W][RC_BALL] = st->bw; body[RB_COUNT + 0][RC_BALL] = st->bpx; body[RB_COUNT + 1][RC_BALL] = st->bpy; body[RB_COUNT + 2][RC_BALL] = 1.0;
+  envi[RE_ELAPSED] = st->elapsed; envi[RE_OWNED] = st->ball_owned; envi[RE_NLK] = st->n_last_kicked;
+  for (int i = 0; i < 4; ++i) envi[RE_LK0 + i] = st->last_kicked[i];
+  envi[RE_GOAL0] = st->goals[0]; envi[RE_GOAL1] = st->goals[1]; envi[RE_CLOSE0] = st->closest[0]; envi[RE_CLOSE1] = st->closest[1];
+  for (int t = 0; t < 2; ++t) {
+    int m = 0;
+    for (int i = 0; i < st->n_def[t]; ++i) m |= 1 << st->defenders[t][i];
+    envi[RE_DEF0 + t] = m;
+    envd[RD_PT0 + t] = st->penal_times[t];
+  }
+  envi[RE_NCON] = ncon; envi[RE_EPISODE] = st->episode; envi[RE_OCC] = 0; envi[RE_ERR] = 0;
+  envd[RD_FREECNT] = st->ball_free_cntr; envd[RD_GRACE] = st->grace_period; envd[RD_BPREVX] = st->bprevx; envd[RD_BPREVY] = st->bprevy;
+  for (int i = 0; i < DYNENV_MAX_ROBOTS; ++i) { epr[0][i] = st->episode_r[i]; epr[1][i] = st->episode_pos_r[i]; }
+  if (rows_h2d(R.body, &body[0][0], RB_COUNT + 4, E, RC_NB, env) || rows_h2d(R.rob, &rob[0][0], RR_COUNT, E, 16, env) ||
+      rows_h2d(R.robi, &robi[0][0], RI_COUNT, E, 16, env) || rows_h2d(R.epr, &epr[0][0], 2, E, 16, env))
+    return DYNENV_ERR_HIP;
+  HIP_OK(hipMemcpy(R.envi + (size_t)env * RE_COUNT, envi, sizeof(envi), hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(R.envd + (size_t)env * RD_COUNT, envd, sizeof(envd), hipMemcpyHostToDevice));
+  return DYNENV_OK;
+}
+
 extern "C" {
 
 int dynenv_abi_version(void) { return DYNENV_ABI_VERSION; }
@@ -134,10 +291,17 @@ int dynenv_create(const dynenv_cfg_t* cfg, dynenv_t** out) {
     return fail(DYNENV_ERR_NO_DEVICE, "no HIP device visible: libdynenv_hip has no CPU fallback");
   if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(DYNENV_ERR_ARG, "device_id out of range");
   HIP_OK(hipSetDevice(cfg->device_id));
-  if (cfg->env_type != DYNENV_DRIVE) return fail(DYNENV_ERR_UNSUPPORTED, "RoboCup not built yet");
+  if (cfg->env_type != DYNENV_DRIVE && cfg->env_type != DYNENV_ROBO_CUP) return fail(DYNENV_ERR_ARG, "unknown env_type");
   if (cfg->obs_type != DYNENV_OBS_FULL) return fail(DYNENV_ERR_UNSUPPORTED, "only Full observations are built");
   dynenv* h = new dynenv();
   h->cfg = *cfg;
+  h->robocup = cfg->env_type == DYNENV_ROBO_CUP;
+  if (h->robocup) {
+    int rc = rc_create(h);
+    if (rc) { dynenv_destroy(h); return rc; }
+    *out = h;
+    return DYNENV_OK;
+  }
   h->A = cfg->n_players > DRV_MAXA ? DRV_MAXA : cfg->n_players;  // environment_base.py:57
   h->obs_dim = 9 + (h->A - 1) * 7 + DRV_MAXO * 4 + DRV_MAXP * 2 + DRV_LANE_ROWS * 5;
   h->T = 1;
@@ -185,6 +349,14 @@ int dynenv_layout(const dynenv_t* h, dynenv_layout_t* L) {
   int A = h->A;
   L->num_envs = h->cfg.num_envs; L->n_agents = A; L->n_time_steps = h->T; L->obs_dim = h->obs_dim;
   L->action_dim = h->action_dim;
+  if (h->robocup) {
+    L->n_blocks = 3;  // ((ball, robots), (self,)) of RoboCupEnvironment.py:440-443
+    L->block_offset[0] = 0; L->block_rows[0] = 1; L->block_feat[0] = 4;
+    L->block_offset[1] = 4; L->block_rows[1] = 1; L->block_feat[1] = 8;
+    L->block_offset[2] = 12; L->block_rows[2] = A - 1; L->block_feat[2] = 6;
+    L->steps_per_episode = RC_MAX_TIME / 50;
+    return DYNENV_OK;
+  }
   L->n_blocks = 5;
   L->block_offset[0] = 0; L->block_rows[0] = 1; L->block_feat[0] = 9;
   L->block_offset[1] = 9; L->block_rows[1] = A - 1; L->block_feat[1] = 7;
@@ -199,6 +371,7 @@ int dynenv_seed(dynenv_t* h, uint64_t seed) {
   if (!h) return fail(DYNENV_ERR_ARG, "null handle");
   h->cfg.seed = seed;
   h->S.seed = seed;
+  h->R.seed = seed;
   return DYNENV_OK;
 }
 
@@ -206,6 +379,13 @@ int dynenv_reset(dynenv_t* h, float* obs_dev, void* stream) {
   if (!h) return fail(DYNENV_ERR_ARG, "null handle");
   hipStream_t st = (hipStream_t)stream;
   HIP_OK(hipSetDevice(h->cfg.device_id));
+  if (h->robocup) {
+    int E = h->R.E;
+    hipLaunchKernelGGL(rc_reset_kernel, dim3((E + 63) / 64), dim3(64), 0, st, h->R);
+    if (obs_dev) hipLaunchKernelGGL(rc_obs_kernel, dim3(E), dim3(64), 0, st, h->R, obs_dev);
+    HIP_OK(hipGetLastError());
+    return DYNENV_OK;
+  }
   int E = h->S.E;
   hipLaunchKernelGGL(drv_reset_kernel, dim3((E + 63) / 64), dim3(64), 0, st, h->S);
   if (obs_dev) hipLaunchKernelGGL(drv_obs_kernel, dim3(E), dim3(64), 0, st, h->S, obs_dev);
@@ -217,6 +397,11 @@ int dynenv_step(dynenv_t* h, const int32_t* actions_dev, float* obs_dev, double*
                 void* stream) {
   if (!h || !actions_dev || !rewards_dev || !dones_dev) return fail(DYNENV_ERR_ARG, "null argument");
   hipStream_t st = (hipStream_t)stream;
+  if (h->robocup) {
+    hipLaunchKernelGGL(rc_step_kernel, dim3(h->R.E), dim3(64), 0, st, h->R, (const int*)actions_dev, obs_dev, rewards_dev, dones_dev);
+    HIP_OK(hipGetLastError());
+    return DYNENV_OK;
+  }
   hipLaunchKernelGGL(drv_step_kernel, dim3(h->S.E), dim3(64), 0, st, h->S, (const int*)actions_dev, obs_dev, rewards_dev,
                      dones_dev);
   HIP_OK(hipGetLastError());
@@ -225,6 +410,7 @@ int dynenv_step(dynenv_t* h, const int32_t* actions_dev, float* obs_dev, double*
 
 int dynenv_counts(dynenv_t* h, int32_t* counts_dev, void* stream) {
   if (!h || !counts_dev) return fail(DYNENV_ERR_ARG, "null argument");
+  if (h->robocup) { HIP_OK(hipMemsetAsync(counts_dev, 0, sizeof(int32_t) * 2 * h->R.E, (hipStream_t)stream)); return DYNENV_OK; }
   int E = h->S.E;
   hipLaunchKernelGGL(drv_counts_kernel, dim3((E + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->S, (int*)counts_dev);
   HIP_OK(hipGetLastError());
@@ -233,6 +419,12 @@ int dynenv_counts(dynenv_t* h, int32_t* counts_dev, void* stream) {
 
 int dynenv_episode_stats(dynenv_t* h, double* ep_r, double* ep_pos_r, double* ep_obs_r, int32_t* goals, void* stream) {
   if (!h) return fail(DYNENV_ERR_ARG, "null handle");
+  if (h->robocup) {
+    int E = h->R.E;
+    hipLaunchKernelGGL(rc_stats_kernel, dim3((E + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->R, ep_r, ep_pos_r, ep_obs_r, (int*)goals);
+    HIP_OK(hipGetLastError());
+    return DYNENV_OK;
+  }
   int E = h->S.E;
   hipLaunchKernelGGL(drv_stats_kernel, dim3((E + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->S, ep_r, ep_pos_r, ep_obs_r,
                      (int*)goals);
@@ -240,7 +432,7 @@ int dynenv_episode_stats(dynenv_t* h, double* ep_r, double* ep_pos_r, double* ep
   return DYNENV_OK;
 }
 
-size_t dynenv_state_size(const dynenv_t* h) { (void)h; return sizeof(dynenv_driving_state_t); }
+size_t dynenv_state_size(const dynenv_t* h) { return (h && h->robocup) ? sizeof(dynenv_robocup_state_t) : sizeof(dynenv_driving_state_t); }
 
 int dynenv_sync(dynenv_t* h, void* stream) {
   if (!h) return fail(DYNENV_ERR_ARG, "null handle");
@@ -252,6 +444,14 @@ int dynenv_sync(dynenv_t* h, void* stream) {
 int dynenv_error_flags(dynenv_t* h, int32_t* out) {
   if (!h || !out) return fail(DYNENV_ERR_ARG, "null argument");
   HIP_OK(hipDeviceSynchronize());
+  if (h->robocup) {
+    std::vector<int> ev((size_t)h->R.E * RE_COUNT);
+    HIP_OK(hipMemcpy(ev.data(), h->R.envi, ev.size() * sizeof(int), hipMemcpyDeviceToHost));
+    int fl = 0;
+    for (int e = 0; e < h->R.E; ++e) fl |= ev[(size_t)e * RE_COUNT + RE_ERR];
+    *out = fl;
+    return DYNENV_OK;
+  }
   std::vector<int> envi((size_t)h->S.E * EI_COUNT);
   HIP_OK(hipMemcpy(envi.data(), h->S.envi, envi.size() * sizeof(int), hipMemcpyDeviceToHost));
   int f = 0;
@@ -263,6 +463,7 @@ int dynenv_error_flags(dynenv_t* h, int32_t* out) {
 // diagnostics: per-path substep counts since the last reset, summed over envs: {fast, quiescent, contact, slot-sum}
 int dynenv_debug_counters(dynenv_t* h, int64_t* out4) {
   if (!h || !out4) return fail(DYNENV_ERR_ARG, "null argument");
+  if (h->robocup) { out4[0] = out4[1] = out4[2] = out4[3] = 0; return DYNENV_OK; }
   HIP_OK(hipDeviceSynchronize());
   std::vector<int> envi((size_t)h->S.E * EI_COUNT);
   HIP_OK(hipMemcpy(envi.data(), h->S.envi, envi.size() * sizeof(int), hipMemcpyDeviceToHost));
@@ -274,6 +475,7 @@ int dynenv_debug_counters(dynenv_t* h, int64_t* out4) {
 
 int dynenv_get_state(dynenv_t* h, int32_t env, void* blob, size_t nbytes) {
   if (!h || !blob) return fail(DYNENV_ERR_ARG, "null argument");
+  if (h->robocup) return rc_get_state_host(h, env, blob, nbytes);
   if (env < 0 || env >= h->S.E || nbytes < sizeof(dynenv_driving_state_t)) return fail(DYNENV_ERR_ARG, "bad env index / size");
   HIP_OK(hipSetDevice(h->cfg.device_id));
   HIP_OK(hipDeviceSynchronize());
@@ -320,6 +522,7 @@ int dynenv_get_state(dynenv_t* h, int32_t env, void* blob, size_t nbytes) {
 
 int dynenv_set_state(dynenv_t* h, int32_t env, const void* blob, size_t nbytes) {
   if (!h || !blob) return fail(DYNENV_ERR_ARG, "null argument");
+  if (h->robocup) return rc_set_state_host(h, env, blob, nbytes);
   if (env < 0 || env >= h->S.E || nbytes < sizeof(dynenv_driving_state_t)) return fail(DYNENV_ERR_ARG, "bad env index / size");
   const dynenv_driving_state_t* st = (const dynenv_driving_state_t*)blob;
   if (st->n_cars != h->S.A || st->n_peds > DRV_MAXP || st->n_obst > DRV_MAXO || st->n_peds < 0 || st->n_obst < 0)

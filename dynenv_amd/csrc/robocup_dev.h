@@ -1,0 +1,68 @@
+// robocup_dev.h — device-side layout of the batched RoboCup environment (HBM SoA + LDS tile).
+//
+// One wavefront per environment, like Driving.  Lane l doubles as
+//   * owner of dynamic body l: feet 2*id (left) / 2*id+1 (right) for robot id 0..9, ball = 20
+//   * owner of robot l (l < 10) for the joint solver: PivotJoint + RotaryLimitJoint of Robot.py:58-60
+//   * detector of collision pairs {l, 64+l, ...} of the 294 canonical pairs (5 rounds)
+//   * owner of contact-cache slot l (l < RC_NS)
+// The order-dependent game logic (processAction / tick / isBallOutOfField and the collision callbacks with their
+// fall()/penalize() side effects) runs as a scalar program on lane 0 — it is strictly sequential in the reference.
+#pragma once
+#include "dev_common.h"
+
+#define RC_MAXR 10
+#define RC_NB 32
+#define RC_NS 16
+#define RC_NPAIR_ROUNDS 5 /* ceil(294 / 64) */
+#define RC_BALL 20
+#define RC_POST 21
+#define RC_W 1040.0
+#define RC_H 740.0
+#define RC_SIDE 70.0
+#define RC_MAX_TIME 12000
+
+// body f64 fields in HBM
+enum { RB_PX = 0, RB_PY, RB_VX, RB_VY, RB_ANG, RB_W, RB_VBX, RB_VBY, RB_WB, RB_FX, RB_FY, RB_TQ, RB_COUNT };
+// robot f64 fields
+enum { RR_HEAD = 0, RR_HEADMOV, RR_PREVX, RR_PREVY, RR_INITX, RR_INITY, RR_PENALT, RR_FALLT, RR_MOVET, RR_JX, RR_JY, RR_JROT,
+       RR_COUNT };
+// robot int fields
+enum { RI_FLAGS = 0, RI_TOUCHC, RI_FALLC, RI_COUNT };
+// env ints
+enum { RE_ELAPSED = 0, RE_OWNED, RE_GOAL0, RE_GOAL1, RE_CLOSE0, RE_CLOSE1, RE_DEF0, RE_DEF1, RE_NLK, RE_LK0, RE_LK1, RE_LK2,
+       RE_LK3, RE_NCON, RE_EPISODE, RE_OCC, RE_ERR, RE_CORDER /* 20 entries */, RE_COUNT = RE_CORDER + 20 + 3 };
+// env doubles
+enum { RD_FREECNT = 0, RD_GRACE, RD_PT0, RD_PT1, RD_BPREVX, RD_BPREVY, RD_COUNT = 8 };
+
+enum { ARB_FIRST_ = 0, ARB_NORMAL_ = 1, ARB_IGNORE_ = 2, ARB_CACHED_ = 3 };  // cpArbiterState
+
+// robot flag word: team(+1 -> bit0 = 1, -1 -> 0) penalized touching mightPush fallen kicking foot jointRemoved
+#define RF_TEAMPOS 1
+#define RF_PENAL 2
+#define RF_TOUCH 4
+#define RF_PUSH 8
+#define RF_FALLEN 16
+#define RF_KICK 32
+#define RF_FOOT 64
+#define RF_JREM 128
+
+struct RcConst {
+  double footInertia, ballInertia;
+  uint16_t pairs[RC_NPAIR_ROUNDS * 64];
+};
+
+struct RcState {
+  int E, n, R, obs_dim; /* n players per team, R = 2n robots */
+  uint64_t seed;
+  int env_id_offset, flags;
+  double* body;  /* [RB_COUNT][E][32] */
+  double* rob;   /* [RR_COUNT][E][16] */
+  int* robi;     /* [RI_COUNT][E][16] */
+  int* envi;     /* [E][RE_COUNT] */
+  double* envd;  /* [E][RD_COUNT] */
+  double* epr;   /* [2][E][16] */
+  int* s_pair;   /* [E][NS] */
+  int* s_meta;
+  uint32_t* s_hash; /* [2][E][NS] */
+  double* s_imp;    /* [4][E][NS] */
+};

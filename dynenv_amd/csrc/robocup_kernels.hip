@@ -1,0 +1,1416 @@
+// robocup_kernels.hip — hand-written gfx950 kernels for the batched DynEnv RoboCup step (Full observations).
+//
+// Replaces RoboCupEnvironment.step (reference RoboCupEnvironment.py:446-524) for E environments at once: 50 physics
+// substeps {processAction, tick per robot, isBallOutOfField | pymunk Space.step with 2 joints per robot and capsule /
+// circle contacts | callbacks} and the 5 Full-observation snapshots, fused in ONE launch; one wavefront per
+// environment (lane roles in robocup_dev.h).  Mirrors oracle/robocup.c + oracle/cp_lite.c operation by operation
+// (fp64, FMA contraction off) so results are bit-identical to the CPU oracle.
+#include "robocup_dev.h"
+
+__constant__ RcConst RC;
+
+#ifndef RC_WAVES_PER_SIMD
+#define RC_WAVES_PER_SIMD 4
+#endif
+
+#define ROBOT_VELOCITY 50.0
+#define ROBOT_MASS 4000.0
+#define ROBOT_HEAD_MAX (2.0 * DM_PI / 3.0)
+#define ROBOT_TOTAL_RADIUS 17.5
+#define FOOT_RADIUS 7.5
+#define BALL_R 10.0 /* Circle(body, radius*2) with radius = 5 (Ball.py:8-16) */
+#define POST_R 10.0 /* Goalpost.py:5-13 */
+#define RC_TIME 10.0
+
+struct RcMailbox {
+  double p1x[RC_NS][2], p1y[RC_NS][2], p2x[RC_NS][2], p2y[RC_NS][2], nx[RC_NS], ny[RC_NS];
+  int hash[RC_NS][2], count[RC_NS], flag[RC_NS];
+};
+struct RcObsStage {
+  float rx[RC_MAXR], ry[RC_MAXR], rcs[RC_MAXR], rsn[RC_MAXR], hc[RC_MAXR], hs[RC_MAXR], ahc[RC_MAXR], ahs[RC_MAXR];
+  float team[RC_MAXR], down[RC_MAXR];
+  float bx, by;
+};
+struct RcPrefilter {
+  float cx[RC_NB], cy[RC_NB], hx[RC_NB], hy[RC_NB];
+};
+struct __align__(16) RcLds {
+  // bodies: feet 0..19, ball 20 (home location of the state); posts 21..24 are constants
+  double px[RC_NB], py[RC_NB], vx[RC_NB], vy[RC_NB], ang[RC_NB], w[RC_NB], vbx[RC_NB], vby[RC_NB], wb[RC_NB];
+  double fx[RC_NB], fy[RC_NB], tq[RC_NB];
+  double rc[RC_NB], rs[RC_NB], rotAng[RC_NB];
+  // shape cache as of the last position integration (what pymunk's spatial queries and the narrowphase see)
+  double cpx[RC_NB], cpy[RC_NB], crc[RC_NB], crs[RC_NB];
+  double aabb[21][4];
+  // robots
+  double head[16], headmov[16], prevx[16], prevy[16], initx[16], inity[16], penalT[16], fallT[16], moveT[16];
+  double jx[16], jy[16], jrot[16];
+  double rrew[16], rposrew[16];
+  double envd[RD_COUNT], teamRew[2];
+  int rflags[16], touchc[16], fallc[16];
+  int envi[RE_COUNT];
+  int still[RC_NB];
+  int s_pair[RC_NS], s_meta[RC_NS], s_hash0[RC_NS], s_hash1[RC_NS];
+  double s_jn0[RC_NS], s_jt0[RC_NS], s_jn1[RC_NS], s_jt1[RC_NS];
+  union {
+    RcMailbox mb;
+    RcObsStage ob;
+    RcPrefilter pf;
+  } u;
+};
+__shared__ RcLds g_R;
+
+#define RC_MY_PAIR(t) ((int)((((t) < 4 ? pairLo : pairHi) >> (16 * ((t)&3))) & 0xFFFFull))
+
+DE_DEV double rc_minv(int b) { return b == RC_BALL ? 1.0 / 10.0 : (b < RC_BALL ? 1.0 / ROBOT_MASS : 0.0); }
+DE_DEV double rc_iinv(int b) { return b == RC_BALL ? 1.0 / RC.ballInertia : (b < RC_BALL ? 1.0 / RC.footInertia : 0.0); }
+DE_DEV V2 post_pos(int idx) {  // RoboCupEnvironment.py:295-302
+  int k = idx - RC_POST;
+  return v2((k & 2) ? RC_W - RC_SIDE : RC_SIDE, (k & 1) ? RC_H / 2.0 - 80.0 : RC_H / 2.0 + 80.0);
+}
+DE_DEV V2 robot_pos(const RcLds& L, int r) {  // Robot.getPos
+  return v2((L.px[2 * r] + L.px[2 * r + 1]) / 2.0, (L.py[2 * r] + L.py[2 * r + 1]) / 2.0);
+}
+DE_DEV double robot_angle(const RcLds& L, int r) { return (L.ang[2 * r] + L.ang[2 * r + 1]) / 2.0; }
+DE_DEV int robot_team(const RcLds& L, int r) { return (L.rflags[r] & RF_TEAMPOS) ? 1 : -1; }
+
+// cutils.py:102-140 apply_friction incl. the embedded Body.update_velocity (forces from fall() are consumed here)
+DE_DEV void rc_velocity_update(RcLds& L, int b) {
+  double vx = L.vx[b], vy = L.vy[b], w = L.w[b];
+  const double minv = rc_minv(b), iinv = rc_iinv(b);
+  vx = vx * 1.0 + (0.0 + L.fx[b] * minv) * DE_DT;
+  vy = vy * 1.0 + (0.0 + L.fy[b] * minv) * DE_DT;
+  w = w * 1.0 + L.tq[b] * iinv * DE_DT;
+  L.fx[b] = 0.0; L.fy[b] = 0.0; L.tq[b] = 0.0;
+  const double m = b == RC_BALL ? 10.0 : ROBOT_MASS;
+  const double friction = b == RC_BALL ? 2.8e-2 : 1e-3, rotFriction = b == RC_BALL ? 1e-3 : 1e-2;
+  const double spin = b == RC_BALL ? 5e-2 : 0.0;
+  const double factor = friction * m, rotFactor = rotFriction * m;
+  double x = vx, y = vy;
+  const double length = 1.0 / (dm_abs(x) + dm_abs(y) + 1e-5);
+  double theta = w;
+  double a0 = x * factor * length;
+  double a1 = y * factor * length;
+  a0 += a1 * spin * theta;
+  a1 -= a0 * spin * theta;
+  if (dm_abs(x) < factor) x = 0.0; else x -= a0;
+  if (dm_abs(y) < factor) y = 0.0; else y -= a1;
+  if (dm_abs(theta) < rotFactor) theta = 0.0; else theta -= (theta > 0.0 ? rotFactor : -rotFactor);
+  L.vx[b] = x; L.vy[b] = y; L.w[b] = theta;
+}
+
+// ------------------------------------------------------------------------------------------------
+// scalar game logic (lane 0): mirrors oracle/robocup.c
+// ------------------------------------------------------------------------------------------------
+struct RcCtx {
+  uint64_t seed;
+  uint32_t genv, episode;
+  int n, R, canFall, allowHead;
+};
+
+DE_DEV dm_u32x4 rc_rng(const RcCtx& c, const RcLds& L, uint32_t entity) {
+  return dm_env_rng(c.seed, c.genv, c.episode, DM_RNG_ROBO_STEP, entity, (uint32_t)L.envi[RE_ELAPSED]);
+}
+DE_DEV bool in_last_kicked(const RcLds& L, int id) {
+  for (int i = 0; i < L.envi[RE_NLK]; ++i) if (L.envi[RE_LK0 + i] == id) return true;
+  return false;
+}
+DE_DEV void push_last_kicked(RcLds& L, int id) {
+  int n = L.envi[RE_NLK] < 4 ? L.envi[RE_NLK] : 3;
+  for (int i = n; i > 0; --i) L.envi[RE_LK0 + i] = L.envi[RE_LK0 + i - 1];
+  L.envi[RE_LK0] = id;
+  L.envi[RE_NLK] = n + 1;
+}
+// constraint array bookkeeping (cpArrayDeleteObj swaps the last element into the hole; add appends)
+DE_DEV void con_remove(RcLds& L, int cid) {
+  int n = L.envi[RE_NCON];
+  for (int i = 0; i < n; ++i) {
+    if (L.envi[RE_CORDER + i] == cid) { L.envi[RE_CORDER + i] = L.envi[RE_CORDER + n - 1]; L.envi[RE_NCON] = n - 1; return; }
+  }
+}
+DE_DEV void con_add(RcLds& L, int cid) { L.envi[RE_CORDER + L.envi[RE_NCON]] = cid; L.envi[RE_NCON] += 1; }
+
+DE_DEV void set_body_angle(RcLds& L, int b, double a) { L.ang[b] = a; }
+
+DE_DEV void free_penalty_spot(const RcCtx& c, const RcLds& L, int r, V2& spot, double& angle) {  // :792-821
+  const double y = L.py[RC_BALL];
+  const bool lower = !(y > RC_H / 2.0);
+  const int team = robot_team(L, r);
+  int sel = 0;
+  angle = (y < RC_H / 2.0) ? -DM_PI / 2.0 : DM_PI / 2.0;
+  for (int k = 0; k < 7; ++k) {
+    const double sx = team > 0 ? RC_SIDE + (double)(k + 1) * ROBOT_TOTAL_RADIUS * 3.0 : RC_W - RC_SIDE - (double)(k + 1) * ROBOT_TOTAL_RADIUS * 3.0;
+    const double sy = lower ? RC_H - RC_SIDE : RC_SIDE;
+    bool available = true;
+    for (int j = 0; j < c.R; ++j) {
+      if (j == r) continue;
+      V2 p = robot_pos(L, j);
+      if (vlen(v2(sx - p.x, sy - p.y)) < ROBOT_TOTAL_RADIUS * 3.0) { available = false; break; }
+    }
+    if (available) { sel = k; break; }
+  }
+  spot.x = team > 0 ? RC_SIDE + (double)(sel + 1) * ROBOT_TOTAL_RADIUS * 3.0 : RC_W - RC_SIDE - (double)(sel + 1) * ROBOT_TOTAL_RADIUS * 3.0;
+  spot.y = lower ? RC_H - RC_SIDE : RC_SIDE;
+}
+
+__device__ __noinline__ void rc_penalize(const RcCtx& c, int r) {  // :824-859
+  RcLds& L = g_R;
+  const int teamIdx = robot_team(L, r) > 0 ? 0 : 1;
+  int f = L.rflags[r];
+  f |= RF_PENAL;
+  L.penalT[r] = L.envd[RD_PT0 + teamIdx];
+  L.rrew[r] -= L.envd[RD_PT0 + teamIdx] / 2000.0;
+  L.envd[RD_PT0 + teamIdx] += 10000.0;
+  V2 pos; double angle;
+  free_penalty_spot(c, L, r, pos, angle);
+  for (int k = 0; k < 2; ++k) {
+    const int b = 2 * r + k;
+    L.px[b] = pos.x; L.py[b] = pos.y; set_body_angle(L, b, angle);
+    L.vx[b] = 0.0; L.vy[b] = 0.0; L.w[b] = 0.0;
+  }
+  if ((f & RF_KICK) && (f & RF_JREM)) {
+    f &= ~RF_KICK;
+    con_add(L, 2 * r);
+    f &= ~RF_JREM;
+  }
+  L.rflags[r] = f;
+}
+
+// surface distance of cached shape `s` to p (cpSpacePointQuery in cp_lite.c)
+DE_DEV double shape_point_dist(const RcLds& L, int s, V2 p) {
+  if (s == RC_BALL) { V2 d = vsub(p, v2(L.cpx[s], L.cpy[s])); return dm_sqrt(vdot(d, d)) - BALL_R; }
+  if (s > RC_BALL) { V2 d = vsub(p, post_pos(s)); return dm_sqrt(vdot(d, d)) - POST_R; }
+  const double ly = (s & 1) ? -10.0 : 10.0;
+  const double c = L.crc[s], sn = L.crs[s];
+  const V2 ta = v2(c * -10.0 - sn * ly + L.cpx[s], sn * -10.0 + c * ly + L.cpy[s]);
+  const V2 tb = v2(c * 10.0 - sn * ly + L.cpx[s], sn * 10.0 + c * ly + L.cpy[s]);
+  const V2 seg = vsub(tb, ta);
+  const double t = fclamp01_cp(vdot(seg, vsub(p, ta)) / vlensq(seg));
+  const V2 closest = vadd(ta, vmul(seg, t));
+  const V2 d = vsub(p, closest);
+  return dm_sqrt(vdot(d, d)) - FOOT_RADIUS;
+}
+
+__device__ __noinline__ void rc_fall(const RcCtx& c, int r, int punish) {  // :735-791
+  RcLds& L = g_R;
+  const V2 pos = robot_pos(L, r);
+  if (punish) L.rrew[r] -= 2.0;
+  for (int s = 0; s <= RC_BALL; ++s) {  // canonical slot order; goalposts are static (forces never integrated)
+    if (s < RC_BALL && s >= 2 * c.R) continue;
+    if (s == 2 * r || s == 2 * r + 1) continue;
+    if (!(shape_point_dist(L, s, pos) < 40.0)) continue;
+    const double m = s == RC_BALL ? 10.0 : ROBOT_MASS;
+    const double force = ROBOT_VELOCITY * ROBOT_MASS * m / 50.0;
+    V2 dp = vsub(pos, v2(L.px[s], L.py[s]));
+    const double len = vlen(dp);
+    dp = v2(-dp.x * force / len, -dp.y * force / len);
+    const V2 rr = vsub(pos, v2(L.px[s], L.py[s]));  // cpBodyApplyForceAtWorldPoint
+    L.fx[s] = L.fx[s] + dp.x; L.fy[s] = L.fy[s] + dp.y;
+    L.tq[s] += vcross(rr, dp);
+    if (s == RC_BALL) {
+      if (L.envi[RE_NLK] && !in_last_kicked(L, r)) push_last_kicked(L, r);
+      if (L.envi[RE_OWNED] != 0) { L.envd[RD_GRACE] = 0.0; L.envd[RD_FREECNT] = 0.0; L.envi[RE_OWNED] = 0; }
+    }
+  }
+  L.rflags[r] |= RF_FALLEN;
+  L.fallc[r] += 1;
+  L.fallT[r] = 4000.0;
+  if (L.fallc[r] > 2) rc_penalize(c, r);
+}
+
+DE_DEV void rc_process_action(const RcCtx& c, RcLds& L, int r, const int* action) {  // :527-581
+  const int move = action[0], turn = action[1], kick = action[2];
+  int head = action[3];
+  const dm_u32x4 u = rc_rng(c, L, (uint32_t)r);
+  if (!c.allowHead) head -= 3;
+  const int f0 = L.rflags[r];
+  const bool canMove = !(f0 & (RF_PENAL | RF_KICK | RF_FALLEN));
+  if (move > 0 && canMove) {
+    const double rr = c.canFall ? dm_unit(u.v[0]) : 0.0;
+    if (rr > 0.999) { rc_fall(c, r, 0); return; }
+    if (!(L.rflags[r] & (RF_KICK | RF_PENAL | RF_FALLEN))) {  // Robot.step :103-119
+      L.moveT[r] = 500.0;
+      const int dir = move - 1;
+      V2 vel = v2(0.0, 0.0);
+      bool has = true;
+      if (dir == 0) vel = v2(0.0, 2.0 * ROBOT_VELOCITY);
+      else if (dir == 1) vel = v2(0.0, -2.0 * ROBOT_VELOCITY);
+      else if (dir == 2) vel = v2(2.5 * ROBOT_VELOCITY, 0.0);
+      else if (dir == 3) vel = v2(-2.0 * ROBOT_VELOCITY, 0.0);
+      else has = false;
+      if (has) {
+        const DevSC sc = dev_sincos(L.ang[2 * r]);
+        L.vx[2 * r] = vel.x * sc.c - vel.y * sc.s;
+        L.vy[2 * r] = vel.x * sc.s + vel.y * sc.c;
+      }
+    }
+  }
+  if (turn > 0 && canMove) {
+    const double rr = c.canFall ? dm_unit(u.v[1]) : 0.0;
+    if (rr > 0.999) { rc_fall(c, r, 0); return; }
+    if (!(L.rflags[r] & (RF_KICK | RF_PENAL | RF_FALLEN))) {  // Robot.turn :122-125
+      L.moveT[r] = 500.0;
+      L.w[2 * r] += (turn - 1) ? 20.0 : -20.0;
+    }
+  }
+  if (head) { L.headmov[r] = (double)head * DM_PI / 720.0; L.moveT[r] = 500.0; }  // Robot.turnHead :136-138
+  if (kick > 0 && move == 0 && turn == 0 && canMove) {
+    const double rr = c.canFall ? dm_unit(u.v[2]) : 0.0;
+    if (rr > 0.99) { rc_fall(c, r, 0); return; }
+    int f = L.rflags[r];
+    if (!(f & (RF_KICK | RF_PENAL | RF_FALLEN))) {  // Robot.kick :128-133
+      const int foot = kick - 1;
+      f = foot ? (f | RF_FOOT) : (f & ~RF_FOOT);
+      L.initx[r] = L.px[2 * r + foot]; L.inity[r] = L.py[2 * r + foot];
+      f |= RF_KICK;
+      L.moveT[r] = 1000.0;
+      L.rflags[r] = f;
+    }
+  }
+}
+
+DE_DEV void rc_tick(const RcCtx& c, RcLds& L, int r) {  // :862-1007
+  const double time = RC_TIME;
+  if (L.moveT[r] > 0.0) {
+    L.moveT[r] -= time;
+    if (L.headmov[r] != 0.0) {
+      double h = L.head[r] + L.headmov[r];
+      L.head[r] = dm_max(-ROBOT_HEAD_MAX, dm_min(ROBOT_HEAD_MAX, h));
+    }
+    int f = L.rflags[r];
+    if (f & RF_KICK) {
+      const int fb = 2 * r + ((f & RF_FOOT) ? 1 : 0);
+      const double mt = L.moveT[r];
+      if (mt + time > 500.0 && mt <= 500.0) {
+        if (!(f & RF_JREM)) { con_remove(L, 2 * r); f |= RF_JREM; }
+        const DevSC sc = dev_sincos(L.ang[fb]);
+        const double vxl = ROBOT_VELOCITY * 3.0;
+        L.vx[fb] = vxl * sc.c - 0.0 * sc.s; L.vy[fb] = vxl * sc.s + 0.0 * sc.c;
+      }
+      if (mt + time > 400.0 && mt <= 400.0) {
+        const DevSC sc = dev_sincos(L.ang[fb]);
+        const double vxl = ROBOT_VELOCITY * 2.5;
+        L.vx[fb] = -(vxl * sc.c - 0.0 * sc.s); L.vy[fb] = -(vxl * sc.s + 0.0 * sc.c);
+      } else if (mt <= 300.0) {
+        L.vx[fb] = 0.0; L.vy[fb] = 0.0;
+        f &= ~RF_KICK;
+        L.px[fb] = L.initx[r]; L.py[fb] = L.inity[r];
+        if (f & RF_JREM) { con_add(L, 2 * r); f &= ~RF_JREM; }
+      }
+      L.rflags[r] = f;
+    }
+    if (L.moveT[r] <= 0.0) {
+      L.moveT[r] = 0.0; L.headmov[r] = 0.0;
+      L.vx[2 * r] = 0.0; L.vy[2 * r] = 0.0; L.w[2 * r] = 0.0;
+      L.vx[2 * r + 1] = 0.0; L.vy[2 * r + 1] = 0.0; L.w[2 * r + 1] = 0.0;
+    }
+  }
+  if (L.rflags[r] & RF_FALLEN) {
+    L.fallT[r] -= time;
+    if (L.fallT[r] < 0.0) {
+      const dm_u32x4 u = rc_rng(c, L, (uint32_t)r | (1u << 8));
+      const double rr = dm_unit(u.v[0]);
+      if (rr > 0.9 && !(L.rflags[r] & RF_PENAL) && c.canFall) { rc_fall(c, r, 0); return; }
+      L.rflags[r] &= ~RF_FALLEN;
+      L.fallc[r] = 0;
+    }
+  }
+  if (L.rflags[r] & RF_PENAL) {
+    L.penalT[r] -= time;
+    if (L.penalT[r] <= 0.0) {
+      L.penalT[r] = 0.0;
+      L.rflags[r] &= ~(RF_PENAL | RF_FALLEN);
+      L.fallc[r] = 0;
+      V2 p; double angle;
+      free_penalty_spot(c, L, r, p, angle);
+      for (int k = 0; k < 2; ++k) { L.px[2 * r + k] = p.x; L.py[2 * r + k] = p.y; set_body_angle(L, 2 * r + k, angle); }
+    }
+  } else {
+    const int teamIdx = robot_team(L, r) > 0 ? 0 : 1;
+    const V2 p = robot_pos(L, r);
+    const double robX = teamIdx ? RC_W - p.x : p.x;
+    const double penX = RC_SIDE + 60.0 + 5.0 / 2.0;
+    const int bit = 1 << r;
+    const bool isDef = (L.envi[RE_DEF0 + teamIdx] & bit) != 0;
+    if (robX < penX && p.y > (RC_H / 2.0 - 110.0) && p.y < (RC_H / 2.0 + 110.0)) {
+      if (!isDef) {
+        if (__popc(L.envi[RE_DEF0 + teamIdx]) >= 2) rc_penalize(c, r);
+        else L.envi[RE_DEF0 + teamIdx] |= bit;
+      }
+    } else if (isDef) {
+      L.envi[RE_DEF0 + teamIdx] &= ~bit;
+    }
+  }
+  const V2 pos = robot_pos(L, r);
+  if (pos.y < 0.0 || pos.x < 0.0 || pos.y > RC_H || pos.x > RC_W) rc_penalize(c, r);
+  if (pos.x != L.prevx[r] || pos.y != L.prevy[r]) {
+    if ((r == L.envi[RE_CLOSE0] || r == L.envi[RE_CLOSE1]) && !(L.rflags[r] & RF_PENAL)) {
+      const V2 ballPos = v2(L.px[RC_BALL], L.py[RC_BALL]);
+      const double diff = vlen(vsub(pos, ballPos)) - vlen(vsub(v2(L.prevx[r], L.prevy[r]), ballPos));
+      L.rrew[r] -= diff * 0.05;
+      L.rposrew[r] += dm_max(0.0, -diff * 0.05);
+    }
+    L.prevx[r] = pos.x; L.prevy[r] = pos.y;
+  }
+}
+
+DE_DEV void ball_free_kick_process(RcLds& L, int team) {  // :600-619
+  if (team == 0) {
+    if (L.envd[RD_GRACE] > 0.0) {
+      L.envd[RD_GRACE] -= RC_TIME;
+      if (L.envd[RD_GRACE] < 0.0) { L.envd[RD_GRACE] = 0.0; L.envd[RD_FREECNT] = 9999.0; }
+    } else if (L.envd[RD_FREECNT] > 0.0) {
+      L.envd[RD_FREECNT] -= RC_TIME;
+      if (L.envd[RD_FREECNT] < 0.0) { L.envd[RD_FREECNT] = 0.0; L.envi[RE_OWNED] = 0; }
+    }
+  } else {
+    L.envi[RE_OWNED] = team;
+    L.envd[RD_GRACE] = 14999.0;
+    L.envd[RD_FREECNT] = 0.0;
+  }
+}
+
+DE_DEV void rc_ball_logic(const RcCtx& c, RcLds& L) {  // isBallOutOfField :622-732
+  bool finished = false;
+  int team = 0;
+  const int n = c.n;
+  const V2 pos = v2(L.px[RC_BALL], L.py[RC_BALL]);
+  double cr0 = 0.0, cr1 = 0.0;
+  const double outMin = RC_SIDE - 5.0, outMaxX = RC_W - RC_SIDE + 5.0, outMaxY = RC_H - RC_SIDE + 5.0;
+  if (pos.y < outMin || pos.x < outMin || pos.y > outMaxY || pos.x > outMaxX) {
+    double x = RC_W / 2.0, y = RC_H / 2.0;
+    team = L.envi[RE_NLK] ? robot_team(L, L.envi[RE_LK0]) : 1;
+    if (pos.y < outMin || pos.y > outMaxY) {
+      x = team < 0 ? pos.x + 50.0 : pos.x - 50.0;
+      y = pos.y < outMin ? outMin + 5.0 : outMaxY - 5.0;
+    } else {
+      if (pos.y < RC_H / 2.0 + 80.0 && pos.y > RC_H / 2.0 - 80.0) {
+        finished = true;
+        if (pos.x < outMin) { cr0 += -25.0; cr1 += 25.0; L.envi[RE_GOAL1] += 1; }
+        else { cr0 += 25.0; cr1 += -25.0; L.envi[RE_GOAL0] += 1; }
+      } else {
+        if (pos.x < outMin) {
+          if (team < 0) x = RC_SIDE + 60.0;
+          else { x = RC_SIDE; y = pos.y < RC_H / 2.0 ? RC_SIDE : RC_H - RC_SIDE; }
+        } else {
+          if (team > 0) x = RC_W - (RC_SIDE + 60.0);
+          else { x = RC_W - RC_SIDE; y = pos.y < RC_H / 2.0 ? RC_SIDE : RC_H - RC_SIDE; }
+        }
+      }
+    }
+    L.px[RC_BALL] = x; L.py[RC_BALL] = y; L.vx[RC_BALL] = 0.0; L.vy[RC_BALL] = 0.0; L.w[RC_BALL] = 0.0;
+  }
+  ball_free_kick_process(L, -team);
+  if (!finished) {
+    const double d = (L.px[RC_BALL] - L.envd[RD_BPREVX]) / 20.0;
+    cr0 += d;
+    cr1 -= d;
+  }
+  L.envd[RD_BPREVX] = L.px[RC_BALL]; L.envd[RD_BPREVY] = L.py[RC_BALL];
+  {
+    double disc = 1.0;
+    for (int i = 0; i < L.envi[RE_NLK]; ++i) {
+      const int id = L.envi[RE_LK0 + i];
+      const double rew = (id < n ? cr0 : cr1) * disc;
+      L.rrew[id] += rew;
+      L.rposrew[id] += dm_max(0.0, rew);
+      disc *= 0.5;
+    }
+  }
+  for (int i = 0; i < c.R; ++i) {
+    const bool cond1 = (i == L.envi[RE_CLOSE0] || i == L.envi[RE_CLOSE1]);
+    const bool cond2 = vlen(vsub(robot_pos(L, i), pos)) < 150.0;
+    if (cond1 || cond2) {
+      if (!in_last_kicked(L, i)) L.rrew[i] += dm_min(0.0, (i < n ? cr0 : cr1) * 0.5);
+    }
+  }
+  L.teamRew[0] += cr0 * 0.1;
+  L.teamRew[1] += cr1 * 0.1;
+  {
+    const V2 bp = v2(L.px[RC_BALL], L.py[RC_BALL]);
+    int best0 = 0, best1 = 0;
+    double d0 = INFINITY, d1 = INFINITY;
+    for (int i = 0; i < n; ++i) {
+      V2 d = vsub(bp, robot_pos(L, i));
+      double q = d.x * d.x + d.y * d.y;
+      if (q < d0) { d0 = q; best0 = i; }
+    }
+    for (int i = 0; i < n; ++i) {
+      V2 d = vsub(bp, robot_pos(L, n + i));
+      double q = d.x * d.x + d.y * d.y;
+      if (q < d1) { d1 = q; best1 = i; }
+    }
+    L.envi[RE_CLOSE0] = best0;
+    L.envi[RE_CLOSE1] = n + best1;
+  }
+}
+
+// the sequential per-substep game logic (lane 0 only): for robot in agents: [processAction]; tick; then the ball
+__device__ __noinline__ void rc_game_logic(RcCtx c, int it, const int* __restrict__ actions) {
+  RcLds& L = g_R;
+  for (int r = 0; r < c.R; ++r) {
+    if (it == 0) {
+      int act[4] = {actions[4 * r], actions[4 * r + 1], actions[4 * r + 2], actions[4 * r + 3]};
+      rc_process_action(c, L, r, act);
+    }
+    rc_tick(c, L, r);
+  }
+  rc_ball_logic(c, L);
+}
+
+// ------------------------------------------------------------------------------------------------
+// collision callbacks (lane 0), RoboCupEnvironment.py:1010-1146
+// ------------------------------------------------------------------------------------------------
+DE_DEV bool rc_cb_begin(const RcCtx& c, RcLds& L, int i, int j) {  // pair (i < j), returns "keep"
+  if (j < RC_BALL) {  // robotPushingDet: shapes in collision order (a = lower slot)
+    const int r1 = i >> 1, r2 = j >> 1;
+    const double v1x = L.vx[i], v1y = L.vy[i], v2x = L.vx[j], v2y = L.vy[j];
+    const V2 p1 = robot_pos(L, r1), p2 = robot_pos(L, r2);
+    const V2 dp = vsub(p1, p2);
+    const double adp = dev_atan2(dp.y, dp.x);
+    const bool push1 = vlen(v2(v1x, v1y)) > 1.0 && dev_cos(adp - dev_atan2(v1y, v1x)) < -0.4;
+    const bool push2 = vlen(v2(v2x, v2y)) > 1.0 && dev_cos(adp - dev_atan2(v2y, v2x)) > 0.4;
+    L.rflags[r1] = push1 ? (L.rflags[r1] | RF_PUSH) : (L.rflags[r1] & ~RF_PUSH);
+    L.rflags[r2] = push2 ? (L.rflags[r2] | RF_PUSH) : (L.rflags[r2] & ~RF_PUSH);
+    L.rflags[r1] |= RF_TOUCH; L.rflags[r2] |= RF_TOUCH;
+    L.touchc[r1] = 0; L.touchc[r2] = 0;
+    return true;
+  }
+  if (j == RC_BALL) {  // ballCollision (foot i, ball)
+    const int r = i >> 1;
+    if (L.envi[RE_OWNED] != 0) {
+      if (robot_team(L, r) != L.envi[RE_OWNED] && !(L.rflags[r] & RF_PENAL) && c.canFall) rc_penalize(c, r);
+      else { L.envi[RE_OWNED] = 0; L.envd[RD_GRACE] = 0.0; L.envd[RD_FREECNT] = 0.0; }
+    }
+    push_last_kicked(L, r);
+    return true;
+  }
+  return true;  // foot-goalpost and ball-goalpost: default begin
+}
+
+DE_DEV void rc_cb_post_solve(const RcCtx& c, RcLds& L, int i, int j) {
+  if (!c.canFall) return;
+  const uint32_t key = (uint32_t)(i * 32 + j);
+  if (j < RC_BALL) {  // robotCollision :1039-1088
+    const int r1 = i >> 1, r2 = j >> 1;
+    if (r1 == r2) return;
+    if (!(L.rflags[r1] & (RF_FALLEN | RF_PENAL))) L.touchc[r1] += 1;
+    if (!(L.rflags[r2] & (RF_FALLEN | RF_PENAL))) L.touchc[r2] += 1;
+    const dm_u32x4 u = rc_rng(c, L, key | (2u << 16));
+    double rr = dm_unit(u.v[0]);
+    if (rr > dm_powi((L.rflags[r1] & RF_PUSH) ? 0.99995 : 0.9999, L.touchc[r1]) && !(L.rflags[r1] & RF_FALLEN)) {
+      rc_fall(c, r1, (L.rflags[r1] & RF_PUSH) ? 1 : 0);
+      L.touchc[r1] = 0;
+    }
+    rr = dm_unit(u.v[1]);
+    if (rr > dm_powi((L.rflags[r2] & RF_PUSH) ? 0.99995 : 0.9999, L.touchc[r2]) && !(L.rflags[r2] & RF_FALLEN)) {
+      rc_fall(c, r2, (L.rflags[r2] & RF_PUSH) ? 1 : 0);
+      L.touchc[r2] = 0;
+    }
+    const bool p1 = L.rflags[r1] & RF_PUSH, p2 = L.rflags[r2] & RF_PUSH;
+    const bool diffTeam = robot_team(L, r1) != robot_team(L, r2);
+    if (p1 && !p2 && (L.rflags[r2] & RF_FALLEN) && diffTeam) { rc_penalize(c, r1); L.touchc[r1] = 0; }
+    else if (p2 && !p1 && (L.rflags[r1] & RF_FALLEN) && diffTeam) { rc_penalize(c, r2); L.touchc[r2] = 0; }
+  } else if (j > RC_BALL && i < RC_BALL) {  // goalpostCollision :1106-1125
+    const int r = i >> 1;
+    if (L.rflags[r] & RF_FALLEN) { L.touchc[r] = 0; return; }
+    if (!(L.rflags[r] & RF_TOUCH)) { L.rflags[r] |= RF_TOUCH; L.touchc[r] = 0; }
+    L.touchc[r] += 1;
+    const dm_u32x4 u = rc_rng(c, L, key | (3u << 16));
+    if (dm_unit(u.v[0]) > dm_powi(0.9998, L.touchc[r])) rc_fall(c, r, 1);
+  }
+}
+
+DE_DEV void rc_cb_separate(RcLds& L, int i, int j) {  // :1091-1103 (Robot-Robot and Robot-Goalpost handlers only)
+  if (i < RC_BALL && j != RC_BALL) {
+    const int r1 = i >> 1;
+    L.rflags[r1] &= ~(RF_TOUCH | RF_PUSH); L.touchc[r1] = 0;
+    if (j < RC_BALL) { const int r2 = j >> 1; L.rflags[r2] &= ~(RF_TOUCH | RF_PUSH); L.touchc[r2] = 0; }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// narrowphase (mirrors oracle/cp_lite.c: circle_to_circle, circle_to_segment, segment_to_segment + ContactPoints)
+// ------------------------------------------------------------------------------------------------
+struct RcContacts {
+  int count;
+  V2 n, p1[2], p2[2];
+  int hash[2];
+};
+struct SegW {
+  V2 ta, tb, tn;
+};
+DE_DEV void seg_world(const RcLds& L, int s, SegW& o) {
+  const double ly = (s & 1) ? -10.0 : 10.0;
+  const double c = L.crc[s], sn = L.crs[s], x = L.cpx[s], y = L.cpy[s];
+  o.ta = v2(c * -10.0 - sn * ly + x, sn * -10.0 + c * ly + y);
+  o.tb = v2(c * 10.0 - sn * ly + x, sn * 10.0 + c * ly + y);
+  o.tn = v2(c * 0.0 - sn * -1.0, sn * 0.0 + c * -1.0);  // local normal (0,-1)
+}
+struct RcEdge {
+  V2 ap, bp, n;
+  int ah, bh;
+};
+DE_DEV RcEdge support_edge_segment(const SegW& s, int slot, V2 n) {
+  RcEdge e;
+  const int h = slot * 4;
+  if (vdot(s.tn, n) > 0.0) { e.ap = s.ta; e.ah = h + 0; e.bp = s.tb; e.bh = h + 1; e.n = s.tn; }
+  else { e.ap = s.tb; e.ah = h + 1; e.bp = s.ta; e.bh = h + 0; e.n = vneg(s.tn); }
+  return e;
+}
+DE_DEV int rc_hash_pair(int a, int b) { return 1 + ((a << 8) | b); }
+DE_DEV void rc_contact_points(const RcEdge& e1, const RcEdge& e2, double r1, double r2, V2 n, RcContacts& out) {
+  const double d_e1_a = vcross(e1.ap, n), d_e1_b = vcross(e1.bp, n);
+  const double d_e2_a = vcross(e2.ap, n), d_e2_b = vcross(e2.bp, n);
+  const double e1_denom = 1.0 / (d_e1_b - d_e1_a + DE_DBL_MIN);
+  const double e2_denom = 1.0 / (d_e2_b - d_e2_a + DE_DBL_MIN);
+  out.n = n;
+  out.count = 0;
+  {
+    V2 p1 = vadd(vmul(n, r1), vlerp(e1.ap, e1.bp, fclamp01_cp((d_e2_b - d_e1_a) * e1_denom)));
+    V2 p2 = vadd(vmul(n, -r2), vlerp(e2.ap, e2.bp, fclamp01_cp((d_e1_a - d_e2_a) * e2_denom)));
+    double dist = vdot(vsub(p2, p1), n);
+    if (dist <= 0.0) { out.p1[0] = p1; out.p2[0] = p2; out.hash[0] = rc_hash_pair(e1.ah, e2.bh); out.count = 1; }
+  }
+  {
+    V2 p1 = vadd(vmul(n, r1), vlerp(e1.ap, e1.bp, fclamp01_cp((d_e2_a - d_e1_a) * e1_denom)));
+    V2 p2 = vadd(vmul(n, -r2), vlerp(e2.ap, e2.bp, fclamp01_cp((d_e1_b - d_e2_a) * e2_denom)));
+    double dist = vdot(vsub(p2, p1), n);
+    if (dist <= 0.0) {
+      int h = rc_hash_pair(e1.bh, e2.ah);
+      if (out.count == 0) { out.p1[0] = p1; out.p2[0] = p2; out.hash[0] = h; }
+      else { out.p1[1] = p1; out.p2[1] = p2; out.hash[1] = h; }
+      out.count += 1;
+    }
+  }
+}
+DE_DEV void closest_seg_seg(V2 p1, V2 q1, V2 p2, V2 q2, V2& c1, V2& c2) {
+  const V2 d1 = vsub(q1, p1), d2 = vsub(q2, p2), r = vsub(p1, p2);
+  const double a = vdot(d1, d1), e = vdot(d2, d2), f = vdot(d2, r);
+  const double c = vdot(d1, r), b = vdot(d1, d2);
+  const double denom = a * e - b * b;
+  double s, t;
+  if (denom != 0.0) s = fclamp01_cp((b * f - c * e) / denom); else s = 0.0;
+  t = (b * s + f) / e;
+  if (t < 0.0) { t = 0.0; s = fclamp01_cp(-c / a); }
+  else if (t > 1.0) { t = 1.0; s = fclamp01_cp((b - c) / a); }
+  c1 = vadd(p1, vmul(d1, s));
+  c2 = vadd(p2, vmul(d2, t));
+}
+DE_DEV void rc_narrowphase(const RcLds& L, int i, int j, RcContacts& out) {  // pair i < j in canonical slot order
+  out.count = 0;
+  if (j < RC_BALL) {  // capsule - capsule
+    SegW s1, s2;
+    seg_world(L, i, s1);
+    seg_world(L, j, s2);
+    V2 a, b;
+    closest_seg_seg(s1.ta, s1.tb, s2.ta, s2.tb, a, b);
+    const V2 delta = vsub(b, a);
+    const double dsq = vlensq(delta), mind = FOOT_RADIUS + FOOT_RADIUS;
+    if (dsq > mind * mind) return;
+    const double d = dm_sqrt(dsq);
+    const V2 n = (d != 0.0) ? vmul(delta, 1.0 / d) : s1.tn;
+    rc_contact_points(support_edge_segment(s1, i, n), support_edge_segment(s2, j, vneg(n)), FOOT_RADIUS, FOOT_RADIUS, n, out);
+  } else if (i < RC_BALL) {  // circle (ball or goalpost) = shape a, capsule foot i = shape b
+    const V2 center = j == RC_BALL ? v2(L.cpx[RC_BALL], L.cpy[RC_BALL]) : post_pos(j);
+    const double cr = 10.0;
+    SegW s;
+    seg_world(L, i, s);
+    const V2 seg_delta = vsub(s.tb, s.ta);
+    const double closest_t = fclamp01_cp(vdot(seg_delta, vsub(center, s.ta)) / vlensq(seg_delta));
+    const V2 closest = vadd(s.ta, vmul(seg_delta, closest_t));
+    const double mindist = cr + FOOT_RADIUS;
+    const V2 delta = vsub(closest, center);
+    const double distsq = vlensq(delta);
+    if (distsq < mindist * mindist) {
+      const double dist = dm_sqrt(distsq);
+      const V2 n = (dist != 0.0) ? vmul(delta, 1.0 / dist) : s.tn;
+      out.n = n; out.p1[0] = vadd(center, vmul(n, cr)); out.p2[0] = vadd(closest, vmul(n, -FOOT_RADIUS));
+      out.hash[0] = 0; out.count = 1;
+    }
+  } else {  // ball - goalpost: circle_to_circle (a = ball)
+    const V2 c1 = v2(L.cpx[RC_BALL], L.cpy[RC_BALL]), c2 = post_pos(j);
+    const double mindist = BALL_R + POST_R;
+    const V2 delta = vsub(c2, c1);
+    const double distsq = vlensq(delta);
+    if (distsq < mindist * mindist) {
+      const double dist = dm_sqrt(distsq);
+      const V2 n = (dist != 0.0) ? vmul(delta, 1.0 / dist) : v2(1.0, 0.0);
+      out.n = n; out.p1[0] = vadd(c1, vmul(n, BALL_R)); out.p2[0] = vadd(c2, vmul(n, -POST_R));
+      out.hash[0] = 0; out.count = 1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// body table for the solver
+// ------------------------------------------------------------------------------------------------
+struct RBody {
+  V2 p, v, vb;
+  double w, wb, minv, iinv;
+};
+DE_DEV void rbody_load(const RcLds& L, int idx, RBody& b) {
+  if (idx <= RC_BALL) {
+    b.p = v2(L.px[idx], L.py[idx]); b.v = v2(L.vx[idx], L.vy[idx]); b.w = L.w[idx];
+    b.vb = v2(L.vbx[idx], L.vby[idx]); b.wb = L.wb[idx]; b.minv = rc_minv(idx); b.iinv = rc_iinv(idx);
+  } else {
+    b.p = post_pos(idx); b.v = v2(0.0, 0.0); b.w = 0.0; b.vb = v2(0.0, 0.0); b.wb = 0.0; b.minv = 0.0; b.iinv = 0.0;
+  }
+}
+DE_DEV void rbody_store_vel(RcLds& L, int idx, const RBody& b) {
+  if (idx <= RC_BALL) {
+    L.vx[idx] = b.v.x; L.vy[idx] = b.v.y; L.w[idx] = b.w; L.vbx[idx] = b.vb.x; L.vby[idx] = b.vb.y; L.wb[idx] = b.wb;
+  }
+}
+DE_DEV double rk_scalar_body(const RBody& b, V2 r, V2 n) {
+  double rcn = vcross(r, n);
+  return b.minv + b.iinv * rcn * rcn;
+}
+DE_DEV V2 rrelative_velocity(const RBody& a, const RBody& b, V2 r1, V2 r2) {
+  V2 v1 = vadd(a.v, vmul(vperp(r1), a.w));
+  V2 v2s = vadd(b.v, vmul(vperp(r2), b.w));
+  return vsub(v2s, v1);
+}
+DE_DEV void rapply_impulse(RBody& b, V2 j, V2 r) {
+  b.v = vadd(b.v, vmul(j, b.minv));
+  b.w += b.iinv * vcross(r, j);
+}
+DE_DEV void rapply_bias_impulse(RBody& b, V2 j, V2 r) {
+  b.vb = vadd(b.vb, vmul(j, b.minv));
+  b.wb += b.iinv * vcross(r, j);
+}
+// arbiter material: e = e_a * e_b, u = u_a * u_b in narrowphase order (a = circle / lower slot)
+DE_DEV void pair_material(int i, int j, double& e, double& u) {
+  if (j < RC_BALL) { e = 0.3 * 0.3; u = 2.5 * 2.5; }
+  else if (i < RC_BALL && j == RC_BALL) { e = 0.98 * 0.3; u = 3.0 * 2.5; }
+  else if (i < RC_BALL) { e = 0.95 * 0.3; u = 0.0 * 2.5; }
+  else { e = 0.98 * 0.95; u = 3.0 * 0.0; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Space.step(0.01) after the position update: contacts + joints + velocity update + solver + post-solve callbacks.
+// Out of line (large register footprint).  `cand`: my broadphase candidates; returns updated occupancy / error bit.
+// ------------------------------------------------------------------------------------------------
+struct RcStepRet {
+  uint64_t occ;
+  int err;
+};
+
+__device__ __noinline__ RcStepRet rc_physics(RcCtx c, int lane, int cand, uint64_t pairLo, uint64_t pairHi, uint64_t occ) {
+  RcLds& L = g_R;
+  RcMailbox& M = L.u.mb;
+  int err = 0;
+  const bool anyContactWork = wave_ballot(cand != 0) != 0ull || occ != 0ull;
+  // --- contact detection / cache -------------------------------------------------------------------------
+  bool touched = false, slotOcc = false, freeMe = false, active = false;
+  int bodyA = 0, bodyB = 0, a_pair = 0xFFFF, a_state = ARB_FIRST_, a_count = 0, a_age = 0, rank = 0, nTouched = 0;
+  int myLevel = 0, maxLevel = -1;
+  double jn[2] = {0.0, 0.0}, jt[2] = {0.0, 0.0};
+  double nMass[2] = {0.0, 0.0}, tMass[2] = {0.0, 0.0}, bias[2] = {0.0, 0.0}, bounce[2] = {0.0, 0.0}, jBias[2] = {0.0, 0.0};
+  double arb_e = 0.0, arb_u = 0.0;
+  V2 n = v2(0.0, 0.0), r1[2], r2[2];
+  r1[0] = r1[1] = r2[0] = r2[1] = v2(0.0, 0.0);
+  uint64_t touchedMask = 0ull, activeMask = 0ull;
+  if (anyContactWork) {
+    if (lane < RC_NS) M.flag[lane] = 0;
+    __syncthreads();
+#pragma unroll 1
+    for (int t = 0; t < RC_NPAIR_ROUNDS; ++t) {
+      const bool isCand = (cand >> t) & 1;
+      if (wave_ballot(isCand) == 0ull) continue;
+      RcContacts ct;
+      ct.count = 0;
+      const int pr = RC_MY_PAIR(t);
+      if (isCand) rc_narrowphase(L, pr >> 8, pr & 0xFF, ct);
+      const bool touch = isCand && ct.count > 0;
+      if (wave_ballot(touch) == 0ull) continue;
+      int slot = -1;
+      if (touch) {
+        for (uint64_t mm = occ; mm; mm &= mm - 1) {
+          int sidx = __builtin_ctzll(mm);
+          if (L.s_pair[sidx] == pr) slot = sidx;
+        }
+      }
+      const bool needNew = touch && slot < 0;
+      const uint64_t newMask = wave_ballot(needNew);
+      if (newMask) {
+        const uint64_t slotBits = (1ull << RC_NS) - 1ull;
+        int rk = __popcll(newMask & lanemask_lt());
+        uint64_t fm = (~occ) & slotBits;
+        if (needNew) {
+          for (int r = 0; r < rk; ++r) fm &= fm - 1;
+          if (fm) { slot = __builtin_ctzll(fm); L.s_pair[slot] = pr; }
+          else err |= 1;
+        }
+        int cnt = __popcll(newMask);
+        uint64_t fm2 = (~occ) & slotBits;
+        for (int r = 0; r < cnt && fm2; ++r) { occ |= (fm2 & (~fm2 + 1)); fm2 &= fm2 - 1; }
+      }
+      if (touch && slot >= 0) {
+        M.flag[slot] = needNew ? 3 : 1;
+        M.count[slot] = ct.count;
+        M.nx[slot] = ct.n.x; M.ny[slot] = ct.n.y;
+        M.p1x[slot][0] = ct.p1[0].x; M.p1y[slot][0] = ct.p1[0].y; M.p2x[slot][0] = ct.p2[0].x; M.p2y[slot][0] = ct.p2[0].y;
+        M.hash[slot][0] = ct.hash[0];
+        if (ct.count > 1) {
+          M.p1x[slot][1] = ct.p1[1].x; M.p1y[slot][1] = ct.p1[1].y; M.p2x[slot][1] = ct.p2[1].x; M.p2y[slot][1] = ct.p2[1].y;
+          M.hash[slot][1] = ct.hash[1];
+        }
+      }
+      __syncthreads();
+    }
+    __syncthreads();
+    // slot lanes: load the cached arbiter, match hashes (cpArbiterUpdate without the r1/r2 part, see below)
+    slotOcc = lane < RC_NS && ((occ >> lane) & 1ull);
+    int cnt = 0;
+    if (slotOcc) {
+      const int flag = M.flag[lane];
+      touched = flag != 0;
+      a_pair = L.s_pair[lane];
+      const int meta = L.s_meta[lane];
+      a_state = meta & 0xFF; a_count = (meta >> 8) & 0xFF; a_age = (meta >> 16) & 0xFF;
+      if (flag & 2) { a_state = ARB_FIRST_; a_count = 0; a_age = 0; }
+      if (touched) {
+        const int i = a_pair >> 8, j = a_pair & 0xFF;
+        if (j < RC_BALL) { bodyA = i; bodyB = j; }       // capsule-capsule: a = lower slot
+        else if (i < RC_BALL) { bodyA = j; bodyB = i; }  // circle (ball/post) is shape a, the foot shape b
+        else { bodyA = i; bodyB = j; }                   // ball - post
+        pair_material(i, j, arb_e, arb_u);
+        cnt = M.count[lane];
+        const int h0 = M.hash[lane][0], h1 = cnt > 1 ? M.hash[lane][1] : 0;
+        const int oh0 = L.s_hash0[lane], oh1 = L.s_hash1[lane];
+        if (a_count > 0 && h0 == oh0) { jn[0] = L.s_jn0[lane]; jt[0] = L.s_jt0[lane]; }
+        if (a_count > 1 && h0 == oh1) { jn[0] = L.s_jn1[lane]; jt[0] = L.s_jt1[lane]; }
+        if (cnt > 1) {
+          if (a_count > 0 && h1 == oh0) { jn[1] = L.s_jn0[lane]; jt[1] = L.s_jt0[lane]; }
+          if (a_count > 1 && h1 == oh1) { jn[1] = L.s_jn1[lane]; jt[1] = L.s_jt1[lane]; }
+        }
+        n = v2(M.nx[lane], M.ny[lane]);
+        a_count = cnt;
+        L.s_hash0[lane] = h0; L.s_hash1[lane] = h1;
+        if (a_state == ARB_CACHED_) a_state = ARB_FIRST_;
+        a_age = 0;
+      }
+    }
+    touchedMask = wave_ballot(touched);
+    nTouched = __popcll(touchedMask);
+    for (uint64_t mm = touchedMask; mm; mm &= mm - 1) {
+      int b = __builtin_ctzll(mm);
+      int pk = bcast_i(a_pair, b);
+      rank += (pk < a_pair) ? 1 : 0;
+    }
+    // canonical order: r1/r2 relative to the bodies' CURRENT positions (an earlier begin callback may have teleported
+    // a robot: ballCollision -> penalize), then the begin callback of first contacts (scalar, lane 0)
+    for (int k = 0; k < nTouched; ++k) {
+      const uint64_t who = wave_ballot(touched && rank == k);
+      const int b = __builtin_ctzll(who);
+      if (lane == b) {
+        const V2 pa = bodyA <= RC_BALL ? v2(L.px[bodyA], L.py[bodyA]) : post_pos(bodyA);
+        const V2 pb = bodyB <= RC_BALL ? v2(L.px[bodyB], L.py[bodyB]) : post_pos(bodyB);
+        r1[0] = vsub(v2(M.p1x[lane][0], M.p1y[lane][0]), pa);
+        r2[0] = vsub(v2(M.p2x[lane][0], M.p2y[lane][0]), pb);
+        if (a_count > 1) {
+          r1[1] = vsub(v2(M.p1x[lane][1], M.p1y[lane][1]), pa);
+          r2[1] = vsub(v2(M.p2x[lane][1], M.p2y[lane][1]), pb);
+        }
+      }
+      const int st = bcast_i(a_state, b);
+      if (st != ARB_FIRST_) continue;
+      const int pk = bcast_i(a_pair, b);
+      if (lane == 0) rc_cb_begin(c, L, pk >> 8, pk & 0xFF);  // every RoboCup begin handler returns True
+      __syncthreads();
+    }
+    // separate callbacks + expiry of untouched slots, canonical order over ALL occupied slots
+    if (slotOcc && !touched) {
+      a_age += 1;
+      if (a_age >= 3) freeMe = true;
+    }
+    {
+      const bool sepMe = slotOcc && !touched && a_state != ARB_CACHED_;
+      const uint64_t sepMask = wave_ballot(sepMe);
+      if (sepMask) {
+        int srank = 0;
+        for (uint64_t mm = sepMask; mm; mm &= mm - 1) {
+          int b = __builtin_ctzll(mm);
+          int pk = bcast_i(a_pair, b);
+          srank += (pk < a_pair) ? 1 : 0;
+        }
+        const int ns = __popcll(sepMask);
+        for (int k = 0; k < ns; ++k) {
+          const uint64_t who = wave_ballot(sepMe && srank == k);
+          const int b = __builtin_ctzll(who);
+          const int pk = bcast_i(a_pair, b);
+          if (lane == 0) rc_cb_separate(L, pk >> 8, pk & 0xFF);
+          __syncthreads();
+        }
+      }
+      if (sepMe) a_state = ARB_CACHED_;
+    }
+    // levels of the active arbiters
+    active = touched && a_state != ARB_IGNORE_;
+    activeMask = wave_ballot(active);
+    int blvl = 0;
+    for (int k = 0; k < nTouched; ++k) {
+      const uint64_t who = wave_ballot(active && rank == k);
+      if (who == 0ull) continue;
+      const int b = __builtin_ctzll(who);
+      const int ba = bcast_i(bodyA, b), bb2 = bcast_i(bodyB, b);
+      const int la = ba <= RC_BALL ? bcast_i(blvl, ba) : 0;
+      const int lb = bb2 <= RC_BALL ? bcast_i(blvl, bb2) : 0;
+      const int lv = la > lb ? la : lb;
+      if (lane == b) myLevel = lv;
+      if (lane == ba || lane == bb2) blvl = lv + 1;
+      maxLevel = lv > maxLevel ? lv : maxLevel;
+    }
+    // arbiter prestep
+    if (active) {
+      RBody a, b;
+      rbody_load(L, bodyA, a);
+      rbody_load(L, bodyB, b);
+      const V2 body_delta = vsub(b.p, a.p);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if (q < a_count) {
+          nMass[q] = 1.0 / (rk_scalar_body(a, r1[q], n) + rk_scalar_body(b, r2[q], n));
+          tMass[q] = 1.0 / (rk_scalar_body(a, r1[q], vperp(n)) + rk_scalar_body(b, r2[q], vperp(n)));
+          const double dist = vdot(vadd(vsub(r2[q], r1[q]), body_delta), n);
+          bias[q] = -DE_CONTACT_BIAS_COEF * fmin_cp(0.0, dist + DE_COLLISION_SLOP) / DE_DT;
+          jBias[q] = 0.0;
+          bounce[q] = vdot(rrelative_velocity(a, b, r1[q], r2[q]), n) * arb_e;
+        }
+      }
+    }
+  }
+  // --- joints: prestep (cpPivotJoint / cpRotaryLimitJoint preStep), one robot per lane ------------------------
+  const bool isRobot = lane < c.R;
+  bool hasPivot = false, pivotFirst = true;
+  double kk0 = 0.0, kk1 = 0.0, kk2 = 0.0, kk3 = 0.0, pbx = 0.0, pby = 0.0, iSum = 0.0, rbias = 0.0, jx = 0.0, jy = 0.0, jr = 0.0;
+  if (isRobot) {
+    const int la = 2 * lane, lb = 2 * lane + 1;
+    hasPivot = !(L.rflags[lane] & RF_JREM);
+    int posP = -1, posR = -1;
+    for (int i = 0; i < L.envi[RE_NCON]; ++i) {
+      const int cid = L.envi[RE_CORDER + i];
+      if (cid == 2 * lane) posP = i;
+      if (cid == 2 * lane + 1) posR = i;
+    }
+    pivotFirst = posP < posR;
+    jx = L.jx[lane]; jy = L.jy[lane]; jr = L.jrot[lane];
+    const double ma = rc_minv(la), mb = rc_minv(lb), ia = rc_iinv(la), ib = rc_iinv(lb);
+    if (hasPivot) {
+      // anchors are the body origins (PivotJoint(a, b, pos) with both bodies at pos): r1 = r2 = 0
+      const V2 pr1 = v2(0.0, 0.0), pr2 = v2(0.0, 0.0);
+      const double m_sum = ma + mb;
+      double k11 = m_sum, k12 = 0.0, k21 = 0.0, k22 = m_sum;
+      {
+        const double r1xsq = pr1.x * pr1.x * ia, r1ysq = pr1.y * pr1.y * ia, r1nxy = -pr1.x * pr1.y * ia;
+        k11 += r1ysq; k12 += r1nxy; k21 += r1nxy; k22 += r1xsq;
+      }
+      {
+        const double r2xsq = pr2.x * pr2.x * ib, r2ysq = pr2.y * pr2.y * ib, r2nxy = -pr2.x * pr2.y * ib;
+        k11 += r2ysq; k12 += r2nxy; k21 += r2nxy; k22 += r2xsq;
+      }
+      const double det = k11 * k22 - k12 * k21;
+      const double det_inv = 1.0 / det;
+      kk0 = k22 * det_inv; kk1 = -k12 * det_inv; kk2 = -k21 * det_inv; kk3 = k11 * det_inv;
+      const V2 delta = vsub(vadd(v2(L.px[lb], L.py[lb]), pr2), vadd(v2(L.px[la], L.py[la]), pr1));
+      pbx = delta.x * (-DE_PIVOT_BIAS_COEF / DE_DT); pby = delta.y * (-DE_PIVOT_BIAS_COEF / DE_DT);
+    }
+    {
+      const double dist = L.ang[lb] - L.ang[la];
+      double pdist = 0.0;
+      if (dist > 0.0) pdist = 0.0 - dist; else if (dist < 0.0) pdist = 0.0 - dist;
+      iSum = 1.0 / (ia + ib);
+      rbias = -DE_JOINT_BIAS_COEF * pdist / DE_DT;
+      if (rbias == 0.0) jr = 0.0;
+    }
+  }
+  __syncthreads();
+  // --- velocity update ------------------------------------------------------------------------------------
+  if (lane <= RC_BALL && (lane == RC_BALL || lane < 2 * c.R)) rc_velocity_update(L, lane);
+  __syncthreads();
+  // --- warm start: arbiters (level by level), then joints ---------------------------------------------------
+  for (int lv = 0; lv <= maxLevel; ++lv) {
+    if (active && myLevel == lv && a_state != ARB_FIRST_) {
+      RBody a, b;
+      rbody_load(L, bodyA, a);
+      rbody_load(L, bodyB, b);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if (q < a_count) {
+          V2 j = vrotate(n, v2(jn[q], jt[q]));
+          j = vmul(j, 1.0);
+          rapply_impulse(a, vneg(j), r1[q]);
+          rapply_impulse(b, j, r2[q]);
+        }
+      }
+      rbody_store_vel(L, bodyA, a);
+      rbody_store_vel(L, bodyB, b);
+    }
+    __syncthreads();
+  }
+  if (isRobot) {
+    const int la = 2 * lane, lb = 2 * lane + 1;
+    const double ma = rc_minv(la), mb = rc_minv(lb), ia = rc_iinv(la), ib = rc_iinv(lb);
+    for (int ord = 0; ord < 2; ++ord) {
+      const bool doPivot = (ord == 0) == pivotFirst;
+      if (doPivot) {
+        if (hasPivot) {
+          const V2 j = vmul(v2(jx, jy), 1.0);
+          L.vx[la] = L.vx[la] + (-j.x) * ma; L.vy[la] = L.vy[la] + (-j.y) * ma; L.w[la] += ia * vcross(v2(0.0, 0.0), vneg(j));
+          L.vx[lb] = L.vx[lb] + j.x * mb; L.vy[lb] = L.vy[lb] + j.y * mb; L.w[lb] += ib * vcross(v2(0.0, 0.0), j);
+        }
+      } else {
+        const double j = jr * 1.0;
+        L.w[la] -= j * ia;
+        L.w[lb] += j * ib;
+      }
+    }
+  }
+  __syncthreads();
+  // --- 10 iterations: all arbiters (canonical order via levels), then all constraints ------------------------
+  for (int iter = 0; iter < 10; ++iter) {
+    for (int lv = 0; lv <= maxLevel; ++lv) {
+      if (active && myLevel == lv) {
+        RBody a, b;
+        rbody_load(L, bodyA, a);
+        rbody_load(L, bodyB, b);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          if (q < a_count) {
+            const V2 vb1 = vadd(a.vb, vmul(vperp(r1[q]), a.wb));
+            const V2 vb2 = vadd(b.vb, vmul(vperp(r2[q]), b.wb));
+            const V2 vr = rrelative_velocity(a, b, r1[q], r2[q]);
+            const double vbn = vdot(vsub(vb2, vb1), n);
+            const double vrn = vdot(vr, n);
+            const double vrt = vdot(vr, vperp(n));
+            const double jbn = (bias[q] - vbn) * nMass[q];
+            const double jbnOld = jBias[q];
+            jBias[q] = fmax_cp(jbnOld + jbn, 0.0);
+            const double jnn = -(bounce[q] + vrn) * nMass[q];
+            const double jnOld = jn[q];
+            jn[q] = fmax_cp(jnOld + jnn, 0.0);
+            const double jtMax = arb_u * jn[q];
+            const double jtt = -vrt * tMass[q];
+            const double jtOld = jt[q];
+            jt[q] = fclamp_cp(jtOld + jtt, -jtMax, jtMax);
+            const V2 jb = vmul(n, jBias[q] - jbnOld);
+            rapply_bias_impulse(a, vneg(jb), r1[q]);
+            rapply_bias_impulse(b, jb, r2[q]);
+            const V2 jj = vrotate(n, v2(jn[q] - jnOld, jt[q] - jtOld));
+            rapply_impulse(a, vneg(jj), r1[q]);
+            rapply_impulse(b, jj, r2[q]);
+          }
+        }
+        rbody_store_vel(L, bodyA, a);
+        rbody_store_vel(L, bodyB, b);
+      }
+      __syncthreads();
+    }
+    if (isRobot) {
+      const int la = 2 * lane, lb = 2 * lane + 1;
+      const double ma = rc_minv(la), mb = rc_minv(lb), ia = rc_iinv(la), ib = rc_iinv(lb);
+      for (int ord = 0; ord < 2; ++ord) {
+        const bool doPivot = (ord == 0) == pivotFirst;
+        if (doPivot) {
+          if (hasPivot) {
+            // relative_velocity with r1 = r2 = 0
+            const V2 v1s = vadd(v2(L.vx[la], L.vy[la]), vmul(vperp(v2(0.0, 0.0)), L.w[la]));
+            const V2 v2s = vadd(v2(L.vx[lb], L.vy[lb]), vmul(vperp(v2(0.0, 0.0)), L.w[lb]));
+            const V2 vr = vsub(v2s, v1s);
+            const V2 d = vsub(v2(pbx, pby), vr);
+            V2 j = v2(d.x * kk0 + d.y * kk1, d.x * kk2 + d.y * kk3);
+            const V2 jOld = v2(jx, jy);
+            jx = jx + j.x; jy = jy + j.y;
+            j = vsub(v2(jx, jy), jOld);
+            L.vx[la] = L.vx[la] + (-j.x) * ma; L.vy[la] = L.vy[la] + (-j.y) * ma; L.w[la] += ia * vcross(v2(0.0, 0.0), vneg(j));
+            L.vx[lb] = L.vx[lb] + j.x * mb; L.vy[lb] = L.vy[lb] + j.y * mb; L.w[lb] += ib * vcross(v2(0.0, 0.0), j);
+          }
+        } else if (rbias != 0.0) {
+          const double wr = L.w[lb] - L.w[la];
+          double j = -(rbias + wr) * iSum;
+          const double jOld = jr;
+          if (rbias < 0.0) jr = fmax_cp(jOld + j, 0.0); else jr = fmin_cp(jOld + j, 0.0);
+          j = jr - jOld;
+          L.w[la] -= j * ia;
+          L.w[lb] += j * ib;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (isRobot) { L.jx[lane] = jx; L.jy[lane] = jy; L.jrot[lane] = jr; }
+  // --- post-solve callbacks of the active arbiters, canonical order (scalar, lane 0) -------------------------
+  if (anyContactWork) {
+    for (int k = 0; k < nTouched; ++k) {
+      const uint64_t who = wave_ballot(active && rank == k);
+      if (who == 0ull) continue;
+      const int b = __builtin_ctzll(who);
+      const int pk = bcast_i(a_pair, b);
+      if (lane == 0) rc_cb_post_solve(c, L, pk >> 8, pk & 0xFF);
+      __syncthreads();
+    }
+    if (active && a_state == ARB_FIRST_) a_state = ARB_NORMAL_;
+    if (slotOcc) {
+      if (freeMe) L.s_pair[lane] = 0xFFFF;
+      L.s_meta[lane] = a_state | (a_count << 8) | (a_age << 16);
+      if (touched) { L.s_jn0[lane] = jn[0]; L.s_jt0[lane] = jt[0]; L.s_jn1[lane] = jn[1]; L.s_jt1[lane] = jt[1]; }
+    }
+    occ &= ~wave_ballot(freeMe);
+  }
+  __syncthreads();
+  RcStepRet ret;
+  ret.occ = occ; ret.err = err;
+  return ret;
+}
+
+// ------------------------------------------------------------------------------------------------
+// HBM <-> LDS
+// ------------------------------------------------------------------------------------------------
+DE_DEV void rc_load_env(const RcState& S, RcLds& L, int e, int lane, uint64_t occ) {
+  const size_t E = (size_t)S.E;
+  if (lane < RC_NB) {
+    const bool used = lane == RC_BALL || lane < 2 * S.R;
+    const double* b = S.body + (size_t)e * RC_NB + lane;
+    L.px[lane] = used ? b[RB_PX * E * RC_NB] : 0.0; L.py[lane] = used ? b[RB_PY * E * RC_NB] : 0.0;
+    L.vx[lane] = used ? b[RB_VX * E * RC_NB] : 0.0; L.vy[lane] = used ? b[RB_VY * E * RC_NB] : 0.0;
+    L.ang[lane] = used ? b[RB_ANG * E * RC_NB] : 0.0; L.w[lane] = used ? b[RB_W * E * RC_NB] : 0.0;
+    L.vbx[lane] = used ? b[RB_VBX * E * RC_NB] : 0.0; L.vby[lane] = used ? b[RB_VBY * E * RC_NB] : 0.0;
+    L.wb[lane] = used ? b[RB_WB * E * RC_NB] : 0.0;
+    L.fx[lane] = used ? b[RB_FX * E * RC_NB] : 0.0; L.fy[lane] = used ? b[RB_FY * E * RC_NB] : 0.0;
+    L.tq[lane] = used ? b[RB_TQ * E * RC_NB] : 0.0;
+    // shape cache (position / rotation at the last integration) is stored in the 4 spare body fields
+    L.cpx[lane] = used ? b[(RB_COUNT + 0) * E * RC_NB] : 0.0; L.cpy[lane] = used ? b[(RB_COUNT + 1) * E * RC_NB] : 0.0;
+    L.crc[lane] = used ? b[(RB_COUNT + 2) * E * RC_NB] : 1.0; L.crs[lane] = used ? b[(RB_COUNT + 3) * E * RC_NB] : 0.0;
+    L.rc[lane] = 1.0; L.rs[lane] = 0.0; L.rotAng[lane] = 0.0;  // rot cache: rebuilt on first use (rotValid flag below)
+    L.still[lane] = 0;
+  }
+  if (lane < 16) {
+    const bool used = lane < S.R;
+    const double* r = S.rob + (size_t)e * 16 + lane;
+    L.head[lane] = used ? r[RR_HEAD * E * 16] : 0.0; L.headmov[lane] = used ? r[RR_HEADMOV * E * 16] : 0.0;
+    L.prevx[lane] = used ? r[RR_PREVX * E * 16] : 0.0; L.prevy[lane] = used ? r[RR_PREVY * E * 16] : 0.0;
+    L.initx[lane] = used ? r[RR_INITX * E * 16] : 0.0; L.inity[lane] = used ? r[RR_INITY * E * 16] : 0.0;
+    L.penalT[lane] = used ? r[RR_PENALT * E * 16] : 0.0; L.fallT[lane] = used ? r[RR_FALLT * E * 16] : 0.0;
+    L.moveT[lane] = used ? r[RR_MOVET * E * 16] : 0.0;
+    L.jx[lane] = used ? r[RR_JX * E * 16] : 0.0; L.jy[lane] = used ? r[RR_JY * E * 16] : 0.0; L.jrot[lane] = used ? r[RR_JROT * E * 16] : 0.0;
+    const int* ri = S.robi + (size_t)e * 16 + lane;
+    L.rflags[lane] = used ? ri[RI_FLAGS * E * 16] : 0; L.touchc[lane] = used ? ri[RI_TOUCHC * E * 16] : 0;
+    L.fallc[lane] = used ? ri[RI_FALLC * E * 16] : 0;
+    L.rrew[lane] = 0.0; L.rposrew[lane] = 0.0;
+  }
+  if (lane < RE_COUNT) L.envi[lane] = S.envi[(size_t)e * RE_COUNT + lane];
+  if (lane < RD_COUNT) L.envd[lane] = S.envd[(size_t)e * RD_COUNT + lane];
+  if (lane < 2) L.teamRew[lane] = 0.0;
+  if (lane < RC_NS) {
+    const bool on = (occ >> lane) & 1ull;
+    size_t o = (size_t)e * RC_NS + lane;
+    L.s_pair[lane] = on ? S.s_pair[o] : 0xFFFF;
+    L.s_meta[lane] = on ? S.s_meta[o] : 0;
+    L.s_hash0[lane] = on ? (int)S.s_hash[o] : 0; L.s_hash1[lane] = on ? (int)S.s_hash[E * RC_NS + o] : 0;
+    L.s_jn0[lane] = on ? S.s_imp[o] : 0.0; L.s_jt0[lane] = on ? S.s_imp[E * RC_NS + o] : 0.0;
+    L.s_jn1[lane] = on ? S.s_imp[2 * E * RC_NS + o] : 0.0; L.s_jt1[lane] = on ? S.s_imp[3 * E * RC_NS + o] : 0.0;
+  }
+}
+
+DE_DEV void rc_store_env(const RcState& S, const RcLds& L, int e, int lane, uint64_t occ) {
+  const size_t E = (size_t)S.E;
+  if (lane == RC_BALL || lane < 2 * S.R) {
+    double* b = S.body + (size_t)e * RC_NB + lane;
+    b[RB_PX * E * RC_NB] = L.px[lane]; b[RB_PY * E * RC_NB] = L.py[lane]; b[RB_VX * E * RC_NB] = L.vx[lane];
+    b[RB_VY * E * RC_NB] = L.vy[lane]; b[RB_ANG * E * RC_NB] = L.ang[lane]; b[RB_W * E * RC_NB] = L.w[lane];
+    b[RB_VBX * E * RC_NB] = L.vbx[lane]; b[RB_VBY * E * RC_NB] = L.vby[lane]; b[RB_WB * E * RC_NB] = L.wb[lane];
+    b[RB_FX * E * RC_NB] = L.fx[lane]; b[RB_FY * E * RC_NB] = L.fy[lane]; b[RB_TQ * E * RC_NB] = L.tq[lane];
+    b[(RB_COUNT + 0) * E * RC_NB] = L.cpx[lane]; b[(RB_COUNT + 1) * E * RC_NB] = L.cpy[lane];
+    b[(RB_COUNT + 2) * E * RC_NB] = L.crc[lane]; b[(RB_COUNT + 3) * E * RC_NB] = L.crs[lane];
+  }
+  if (lane < S.R) {
+    double* r = S.rob + (size_t)e * 16 + lane;
+    r[RR_HEAD * E * 16] = L.head[lane]; r[RR_HEADMOV * E * 16] = L.headmov[lane];
+    r[RR_PREVX * E * 16] = L.prevx[lane]; r[RR_PREVY * E * 16] = L.prevy[lane];
+    r[RR_INITX * E * 16] = L.initx[lane]; r[RR_INITY * E * 16] = L.inity[lane];
+    r[RR_PENALT * E * 16] = L.penalT[lane]; r[RR_FALLT * E * 16] = L.fallT[lane]; r[RR_MOVET * E * 16] = L.moveT[lane];
+    r[RR_JX * E * 16] = L.jx[lane]; r[RR_JY * E * 16] = L.jy[lane]; r[RR_JROT * E * 16] = L.jrot[lane];
+    int* ri = S.robi + (size_t)e * 16 + lane;
+    ri[RI_FLAGS * E * 16] = L.rflags[lane]; ri[RI_TOUCHC * E * 16] = L.touchc[lane]; ri[RI_FALLC * E * 16] = L.fallc[lane];
+  }
+  if (lane < RE_COUNT) S.envi[(size_t)e * RE_COUNT + lane] = L.envi[lane];
+  if (lane < RD_COUNT) S.envd[(size_t)e * RD_COUNT + lane] = L.envd[lane];
+  if (lane < RC_NS && ((occ >> lane) & 1ull)) {
+    size_t o = (size_t)e * RC_NS + lane;
+    S.s_pair[o] = L.s_pair[lane]; S.s_meta[o] = L.s_meta[lane];
+    S.s_hash[o] = (uint32_t)L.s_hash0[lane]; S.s_hash[E * RC_NS + o] = (uint32_t)L.s_hash1[lane];
+    S.s_imp[o] = L.s_jn0[lane]; S.s_imp[E * RC_NS + o] = L.s_jt0[lane];
+    S.s_imp[2 * E * RC_NS + o] = L.s_jn1[lane]; S.s_imp[3 * E * RC_NS + o] = L.s_jt1[lane];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Full observation of one snapshot (RoboCupEnvironment.getFullState/get_full_obs :1149-1189, :440-443)
+// row per agent: [ball 4 | self 8 | other robots (R-1) x 6]
+// ------------------------------------------------------------------------------------------------
+#define RC_STD_NORM (2.0 / RC_W)
+DE_DEV double norm_after_scale(double pt, double nf, double mean) { return (pt - mean) * nf; }  // x team applied as a sign
+
+DE_DEV void rc_write_obs(RcLds& L, int lane, int R, int obs_dim, float* __restrict__ out) {
+  RcObsStage& O = L.u.ob;
+  __syncthreads();
+  if (lane < R) {
+    const V2 p = robot_pos(L, lane);
+    const double ang = robot_angle(L, lane);
+    const int f = L.rflags[lane];
+    O.rx[lane] = (float)norm_after_scale(p.x, RC_STD_NORM, RC_W / 2.0);
+    O.ry[lane] = (float)norm_after_scale(p.y, RC_STD_NORM, RC_H / 2.0);
+    const DevSC a = dev_sincos(ang);
+    O.rcs[lane] = (float)a.c; O.rsn[lane] = (float)a.s;
+    const DevSC ah = dev_sincos(ang + L.head[lane]);
+    O.ahc[lane] = (float)ah.c; O.ahs[lane] = (float)ah.s;
+    const DevSC h = dev_sincos(L.head[lane]);
+    O.hc[lane] = (float)h.c; O.hs[lane] = (float)h.s;
+    O.team[lane] = (f & RF_TEAMPOS) ? 1.0f : -1.0f;
+    O.down[lane] = (f & (RF_FALLEN | RF_PENAL)) ? 1.0f : 0.0f;
+  }
+  if (lane == 32) {
+    O.bx = (float)norm_after_scale(L.px[RC_BALL], RC_STD_NORM, RC_W / 2.0);
+    O.by = (float)norm_after_scale(L.py[RC_BALL], RC_STD_NORM, RC_H / 2.0);
+  }
+  __syncthreads();
+  const float owned = (float)L.envi[RE_OWNED];
+  const int c0 = L.envi[RE_CLOSE0], c1 = L.envi[RE_CLOSE1];
+  for (int idx = lane; idx < R * obs_dim; idx += DE_WAVE) {
+    const int a = idx / obs_dim, ff = idx - a * obs_dim;
+    const float team = O.team[a];
+    float x;
+    if (ff == 0) x = O.bx * team;
+    else if (ff == 1) x = O.by * team;
+    else if (ff == 2) x = owned * team;
+    else if (ff == 3) x = (a == c0 || a == c1) ? 1.0f : 0.0f;
+    else if (ff == 4) x = O.rx[a] * team;
+    else if (ff == 5) x = O.ry[a] * team;
+    else if (ff == 6) x = O.ahc[a];
+    else if (ff == 7) x = O.ahs[a];
+    else if (ff == 8) x = O.hc[a];
+    else if (ff == 9) x = O.hs[a];
+    else if (ff == 10) x = team;
+    else if (ff == 11) x = O.down[a];
+    else {
+      int k = (ff - 12) / 6, q = (ff - 12) - k * 6;
+      k += (k >= a);
+      x = q == 0 ? O.rx[k] * team : q == 1 ? O.ry[k] * team : q == 2 ? O.rcs[k] : q == 3 ? O.rsn[k] : q == 4 ? O.team[k] * team : O.down[k];
+    }
+    out[idx] = x;
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// THE RoboCup step kernel
+// ------------------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(64, RC_WAVES_PER_SIMD)
+rc_step_kernel(RcState S, const int* __restrict__ actions, float* __restrict__ obs, double* __restrict__ rewards,
+               uint8_t* __restrict__ dones) {
+  RcLds& L = g_R;
+  const int e = blockIdx.x, lane = threadIdx.x, R = S.R;
+  uint64_t occ = (uint64_t)(uint32_t)uniform_i(S.envi[(size_t)e * RE_COUNT + RE_OCC]);
+  rc_load_env(S, L, e, lane, occ);
+  RcCtx c;
+  c.seed = S.seed; c.genv = (uint32_t)(S.env_id_offset + e); c.n = S.n; c.R = R;
+  c.canFall = (S.flags & 4) != 0; c.allowHead = (S.flags & 16) != 0;
+  int err = 0;
+  uint64_t pairLo = 0ull, pairHi = 0ull;
+#pragma unroll
+  for (int t = 0; t < RC_NPAIR_ROUNDS; ++t) {
+    int pr = RC.pairs[t * 64 + lane];
+    int i = pr >> 8, j = pr & 0xFF;
+    bool ok = pr != 0xFFFF;
+    if (ok && i < RC_BALL) ok = i < 2 * R;
+    if (ok && j < RC_BALL) ok = j < 2 * R;
+    uint64_t v = (uint64_t)(ok ? pr : 0xFFFF);
+    if (t < 4) pairLo |= v << (16 * t); else pairHi |= v << (16 * (t - 4));
+  }
+  __syncthreads();
+  c.episode = (uint32_t)L.envi[RE_EPISODE];
+  const bool isBody = lane == RC_BALL || lane < 2 * R;
+  const int* myActions = actions + (size_t)e * R * 4;
+  int snap = 0;
+
+  for (int it = 0; it < 50; ++it) {
+    // ---- sequential game logic (lane 0): processAction / tick per robot, then the ball (:465-475) ----------
+    if (lane == 0) rc_game_logic(c, it, myActions);
+    __syncthreads();
+    // ---- cpBodyUpdatePosition + shape cache + AABB ------------------------------------------------------
+    if (isBody) {
+      const double npx = L.px[lane] + (L.vx[lane] + L.vbx[lane]) * DE_DT;
+      const double npy = L.py[lane] + (L.vy[lane] + L.vby[lane]) * DE_DT;
+      const double nang = L.ang[lane] + (L.w[lane] + L.wb[lane]) * DE_DT;
+      L.px[lane] = npx; L.py[lane] = npy; L.ang[lane] = nang;
+      L.vbx[lane] = 0.0; L.vby[lane] = 0.0; L.wb[lane] = 0.0;
+      float fcx, fcy, fhx, fhy;
+      if (lane != RC_BALL) {
+        if (nang != L.rotAng[lane] || L.still[lane] == 0) {  // still[] doubles as "rot cache valid" (0 at kernel entry)
+          const DevSC sc = dev_sincos(nang);
+          L.rc[lane] = sc.c; L.rs[lane] = sc.s; L.rotAng[lane] = nang; L.still[lane] = 1;
+        }
+        L.cpx[lane] = npx; L.cpy[lane] = npy; L.crc[lane] = L.rc[lane]; L.crs[lane] = L.rs[lane];
+        SegW s;
+        seg_world(L, lane, s);
+        double l, r, b, t;
+        if (s.ta.x < s.tb.x) { l = s.ta.x; r = s.tb.x; } else { l = s.tb.x; r = s.ta.x; }
+        if (s.ta.y < s.tb.y) { b = s.ta.y; t = s.tb.y; } else { b = s.tb.y; t = s.ta.y; }
+        L.aabb[lane][0] = l - FOOT_RADIUS; L.aabb[lane][1] = b - FOOT_RADIUS; L.aabb[lane][2] = r + FOOT_RADIUS; L.aabb[lane][3] = t + FOOT_RADIUS;
+      } else {
+        L.cpx[lane] = npx; L.cpy[lane] = npy;
+        L.aabb[lane][0] = npx - BALL_R; L.aabb[lane][1] = npy - BALL_R; L.aabb[lane][2] = npx + BALL_R; L.aabb[lane][3] = npy + BALL_R;
+      }
+      const double al = L.aabb[lane][0], ab = L.aabb[lane][1], ar = L.aabb[lane][2], at = L.aabb[lane][3];
+      fcx = (float)(0.5 * (al + ar)); fcy = (float)(0.5 * (ab + at));
+      fhx = (float)(0.5 * (ar - al)) + 1.0f; fhy = (float)(0.5 * (at - ab)) + 1.0f;
+      L.u.pf.cx[lane] = fcx; L.u.pf.cy[lane] = fcy; L.u.pf.hx[lane] = fhx; L.u.pf.hy[lane] = fhy;
+    }
+    __syncthreads();
+    // ---- broadphase ---------------------------------------------------------------------------------------
+    int cand = 0;
+#pragma unroll 1
+    for (int t = 0; t < RC_NPAIR_ROUNDS; ++t) {
+      const int pr = RC_MY_PAIR(t);
+      if (pr != 0xFFFF) {
+        const int i = pr >> 8, j = pr & 0xFF;
+        float bx, by, bhx, bhy;
+        if (j <= RC_BALL) { bx = L.u.pf.cx[j]; by = L.u.pf.cy[j]; bhx = L.u.pf.hx[j]; bhy = L.u.pf.hy[j]; }
+        else { const V2 pc = post_pos(j); bx = (float)pc.x; by = (float)pc.y; bhx = 11.0f; bhy = 11.0f; }
+        const float dx = L.u.pf.cx[i] - bx, dy = L.u.pf.cy[i] - by;
+        if (__builtin_fabsf(dx) <= L.u.pf.hx[i] + bhx && __builtin_fabsf(dy) <= L.u.pf.hy[i] + bhy) {
+          const double al = L.aabb[i][0], ab = L.aabb[i][1], ar = L.aabb[i][2], at = L.aabb[i][3];
+          double bl, bb, br, bt;
+          if (j <= RC_BALL) { bl = L.aabb[j][0]; bb = L.aabb[j][1]; br = L.aabb[j][2]; bt = L.aabb[j][3]; }
+          else { const V2 pc = post_pos(j); bl = pc.x - POST_R; bb = pc.y - POST_R; br = pc.x + POST_R; bt = pc.y + POST_R; }
+          if (al <= br && bl <= ar && ab <= bt && bb <= at) cand |= (1 << t);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- contacts, joints, velocity update, solver, post-solve callbacks (out of line) -----------------------
+    const RcStepRet sr = rc_physics(c, lane, cand, pairLo, pairHi, occ);
+    occ = uniform_u64(sr.occ); err |= sr.err;
+    if (lane == 0) L.envi[RE_ELAPSED] += 1;
+    __syncthreads();
+    if (it % 10 == 9) {
+      if (obs) rc_write_obs(L, lane, R, S.obs_dim, obs + ((size_t)e * 5 + snap) * R * S.obs_dim);
+      ++snap;
+    }
+  }
+  // ---- end of env step :497-524 ------------------------------------------------------------------------------
+  if (lane < R) {
+    const double tr = lane < S.n ? L.teamRew[0] : L.teamRew[1];
+    double rew = L.rrew[lane] + tr;
+    rew += 0.0;
+    double prew = L.rposrew[lane] + dm_max(0.0, tr);
+    prew += 0.0;
+    double* er = S.epr + (size_t)e * 16 + lane;
+    double* ep = S.epr + (size_t)S.E * 16 + (size_t)e * 16 + lane;
+    *er = *er + rew;
+    *ep = *ep + prew;
+    rewards[(size_t)e * R + lane] = rew;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    dones[e] = (uint8_t)(L.envi[RE_ELAPSED] >= RC_MAX_TIME);
+    L.envi[RE_OCC] = (int)(uint32_t)occ;
+    if (err) L.envi[RE_ERR] |= 1;
+  }
+  __syncthreads();
+  rc_store_env(S, L, e, lane, occ);
+}
+
+extern "C" __global__ void __launch_bounds__(64) rc_obs_kernel(RcState S, float* __restrict__ obs) {
+  RcLds& L = g_R;
+  const int e = blockIdx.x, lane = threadIdx.x;
+  rc_load_env(S, L, e, lane, 0ull);
+  __syncthreads();
+  for (int t = 0; t < 5; ++t)  // environment_base.py:217-222: nTimeSteps copies of the initial observation
+    rc_write_obs(L, lane, S.R, S.obs_dim, obs + ((size_t)e * 5 + t) * S.R * S.obs_dim);
+}
+
+// ------------------------------------------------------------------------------------------------
+// reset: one thread per environment (RoboCupEnvironment.__init__ + _setup_scene, randomInit = False)
+// ------------------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(64) rc_reset_kernel(RcState S) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= S.E) return;
+  const size_t E = (size_t)S.E;
+  int* envi = S.envi + (size_t)e * RE_COUNT;
+  double* envd = S.envd + (size_t)e * RD_COUNT;
+  const uint32_t ep = (uint32_t)envi[RE_EPISODE];
+  const uint32_t genv = (uint32_t)(S.env_id_offset + e);
+  for (int k = 0; k < RC_NB; ++k)
+    for (int f = 0; f < RB_COUNT + 4; ++f) S.body[(size_t)f * E * RC_NB + (size_t)e * RC_NB + k] = (f == RB_COUNT + 2) ? 1.0 : 0.0;
+  for (int k = 0; k < 16; ++k) {
+    for (int f = 0; f < RR_COUNT; ++f) S.rob[(size_t)f * E * 16 + (size_t)e * 16 + k] = 0.0;
+    for (int f = 0; f < RI_COUNT; ++f) S.robi[(size_t)f * E * 16 + (size_t)e * 16 + k] = 0;
+    S.epr[(size_t)e * 16 + k] = 0.0; S.epr[E * 16 + (size_t)e * 16 + k] = 0.0;
+  }
+  for (int k = 0; k < RC_NS; ++k) { S.s_pair[(size_t)e * RC_NS + k] = 0xFFFF; S.s_meta[(size_t)e * RC_NS + k] = 0; }
+  double rnd[18];
+  for (int i = 0; i < 18; ++i) rnd[i] = dm_unit(dm_env_rng(S.seed, genv, ep, DM_RNG_ROBO_RESET, (uint32_t)i, 0).v[0]);
+  const double centX = RC_W / 2.0;
+  V2 spots[2][5];  // _create_robot_spots :275-293
+  spots[0][0] = v2(centX - (5.0 * 2.0 + ROBOT_TOTAL_RADIUS) - rnd[0] * 50.0, RC_H / 2.0 + (rnd[1] - 0.5) * 25.0);
+  spots[0][1] = v2(centX - (ROBOT_TOTAL_RADIUS + 5.0 * 2.0) - rnd[2] * 50.0, RC_SIDE + 600.0 / 4.0 + (rnd[3] - 0.5) * 50.0);
+  spots[0][2] = v2(centX - (ROBOT_TOTAL_RADIUS + 5.0 * 2.0) - rnd[4] * 50.0, RC_SIDE + 3.0 * 600.0 / 4.0 + (rnd[5] - 0.5) * 50.0);
+  spots[0][3] = v2(centX - (900.0 / 4.0) - (rnd[6] - 0.5) * 50.0, RC_SIDE + 600.0 / 2.0 + (rnd[7] - 0.5) * 50.0);
+  spots[0][4] = v2(RC_SIDE + 20.0, RC_H / 2.0 + (rnd[8] - 0.5) * 50.0);
+  spots[1][0] = v2(centX + (75.0 * 2.0 + ROBOT_TOTAL_RADIUS + 5.0 / 2.0) + rnd[9] * 50.0, RC_H / 2.0 + (rnd[10] - 0.5) * 50.0);
+  spots[1][1] = v2(centX + (ROBOT_TOTAL_RADIUS + 5.0 / 2.0 + 75.0) + rnd[11] * 50.0, RC_SIDE + 600.0 / 4.0 + (rnd[12] - 0.5) * 50.0);
+  spots[1][2] = v2(centX + (ROBOT_TOTAL_RADIUS + 5.0 / 2.0 + 75.0) + rnd[13] * 50.0, RC_SIDE + 3.0 * 600.0 / 4.0 + (rnd[14] - 0.5) * 50.0);
+  spots[1][3] = v2(centX + (RC_SIDE + 900.0 / 4.0) + rnd[15] * 50.0, RC_SIDE + 600.0 / 2.0 + (rnd[16] - 0.5) * 50.0);
+  spots[1][4] = v2(RC_W - (RC_SIDE + 20.0), RC_H / 2.0 + (rnd[17] - 0.5) * 50.0);
+  int perm[2][5];
+  for (int t = 0; t < 2; ++t) {
+    for (int i = 0; i < 5; ++i) perm[t][i] = i;
+    for (int i = 0; i < 4; ++i) {
+      dm_u32x4 u = dm_env_rng(S.seed, genv, ep, DM_RNG_ROBO_RESET, (uint32_t)(32 + t * 8 + i), 0);
+      int j = i + dm_randint(u.v[0], 0, 4 - i);
+      int tmp = perm[t][i]; perm[t][i] = perm[t][j]; perm[t][j] = tmp;
+    }
+  }
+  for (int id = 0; id < S.R; ++id) {
+    const int team = id < S.n ? 1 : -1;
+    const V2 pos = id < S.n ? spots[0][perm[0][id]] : spots[1][perm[1][id - S.n]];
+    const double angle = team > 0 ? 0.0 : DM_PI;
+    double sn, cs;
+    dm_sincos(angle, &sn, &cs);
+    for (int k = 0; k < 2; ++k) {
+      size_t b = (size_t)e * RC_NB + 2 * id + k;
+      S.body[RB_PX * E * RC_NB + b] = pos.x; S.body[RB_PY * E * RC_NB + b] = pos.y; S.body[RB_ANG * E * RC_NB + b] = angle;
+      S.body[(RB_COUNT + 0) * E * RC_NB + b] = pos.x; S.body[(RB_COUNT + 1) * E * RC_NB + b] = pos.y;
+      S.body[(RB_COUNT + 2) * E * RC_NB + b] = cs; S.body[(RB_COUNT + 3) * E * RC_NB + b] = sn;
+    }
+    size_t r = (size_t)e * 16 + id;
+    // prevPos = getPos() = (p + p) / 2
+    S.rob[RR_PREVX * E * 16 + r] = (pos.x + pos.x) / 2.0; S.rob[RR_PREVY * E * 16 + r] = (pos.y + pos.y) / 2.0;
+    S.robi[RI_FLAGS * E * 16 + r] = team > 0 ? RF_TEAMPOS : 0;
+  }
+  {
+    size_t b = (size_t)e * RC_NB + RC_BALL;
+    S.body[RB_PX * E * RC_NB + b] = 520.0; S.body[RB_PY * E * RC_NB + b] = 370.0;
+    S.body[(RB_COUNT + 0) * E * RC_NB + b] = 520.0; S.body[(RB_COUNT + 1) * E * RC_NB + b] = 370.0;
+  }
+  for (int k = 0; k < RE_COUNT; ++k) envi[k] = 0;
+  envi[RE_OWNED] = 1; envi[RE_EPISODE] = (int)(ep + 1);
+  envi[RE_NCON] = 2 * S.R;
+  for (int k = 0; k < 2 * S.R; ++k) envi[RE_CORDER + k] = k;  // add order: joint, rotJoint per robot (:321-323)
+  for (int k = 0; k < RD_COUNT; ++k) envd[k] = 0.0;
+  envd[RD_FREECNT] = 9999.0; envd[RD_GRACE] = 0.0; envd[RD_PT0] = 20000.0; envd[RD_PT1] = 20000.0;
+  envd[RD_BPREVX] = 520.0; envd[RD_BPREVY] = 370.0;
+}
+
+extern "C" __global__ void rc_stats_kernel(RcState S, double* ep_r, double* ep_pos_r, double* ep_obs_r, int* goals) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= S.E) return;
+  for (int a = 0; a < S.R; ++a) {
+    if (ep_r) ep_r[(size_t)e * S.R + a] = S.epr[(size_t)e * 16 + a];
+    if (ep_pos_r) ep_pos_r[(size_t)e * S.R + a] = S.epr[(size_t)S.E * 16 + (size_t)e * 16 + a];
+    if (ep_obs_r) ep_obs_r[(size_t)e * S.R + a] = 0.0;
+  }
+  if (goals) { goals[2 * e] = S.envi[(size_t)e * RE_COUNT + RE_GOAL0]; goals[2 * e + 1] = S.envi[(size_t)e * RE_COUNT + RE_GOAL1]; }
+}

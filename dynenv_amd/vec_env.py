@@ -88,6 +88,36 @@ def _driving_spaces(obs_type):
     return observation_space, action_space, reco
 
 
+def _robocup_spaces(obs_type, allow_head_turn):
+    """RoboCupEnvironment._create_observation_space / _setup_action_space / _setup_reconstruction_info
+    (RoboCupEnvironment.py:101-132,338-430), Full observation; mean = 2.0 always (quirk C1, :67)."""
+    mean = 2.0
+    pos_xy = sp.Box(-mean * 2, +mean * 2, shape=(2,))
+    team = sp.Box(-1, 1, shape=(1,))
+    self_space = sp.Dict([("position", pos_xy), ("orientation", sp.Box(-1, 1, shape=(4,))), ("team", team),
+                          ("penalized or penalized", sp.MultiBinary(1))])
+    ball_space = sp.Dict([("position", pos_xy), ("team", team), ("closest", sp.MultiBinary(1))])
+    robot_space = sp.Dict([("position", pos_xy), ("orientation", sp.Box(-1, 1, shape=(2,))), ("team", team),
+                           ("penalized or penalized", sp.MultiBinary(1))])
+    observation_space = sp.Tuple([sp.Tuple([ball_space, robot_space]), sp.Tuple([self_space, ])])
+    if allow_head_turn:
+        action_space = sp.Tuple((sp.MultiDiscrete([5, 3, 3]), sp.Box(low=-3, high=3, shape=(1,))))
+    else:
+        action_space = sp.Tuple((sp.MultiDiscrete([5, 3, 3, 7]),))
+    position_xy = sp.Box(-2, +2, shape=(2,))
+    conf = sp.MultiBinary(1)
+    ball_state = StateSpaceDescriptor(1, sp.Dict([("position", position_xy), ("team", sp.Box(-1, 1, shape=(1,))),
+                                                  ("confidence", conf)]))
+    robot_state = StateSpaceDescriptor(4, sp.Dict([("position", position_xy),
+                                                   ("orientation", sp.Box(-1.0, +1.0, shape=(2,))),
+                                                   ("team", sp.Box(-1, 1, shape=(1,))), ("active", sp.MultiBinary(1)),
+                                                   ("confidence", conf)]))
+    reco = RecoDescriptor(featureGridSize=(1, 1), fullStateSpace=[ball_state, robot_state],
+                          targetDefs=[PredictionDescriptor(numContinuous=1, contIdx=[2, ]),
+                                      PredictionDescriptor(numContinuous=3, numBinary=1, contIdx=[2, 3, 4], binaryIdx=[5, ])])
+    return observation_space, action_space, reco
+
+
 class BatchedDynEnv(object):
     """All `num_envs` environments of one GPU shard behind the reference's VecEnv surface."""
 
@@ -107,6 +137,12 @@ class BatchedDynEnv(object):
             raise NotImplementedError("continuous actions are broken in the reference Driving env (acc/steer unbound)")
         if observationType == ObservationType.IMAGE:
             raise NotImplementedError("Image observations are out of scope (SURVEY.md §2)")
+        if env_type == DynEnvType.ROBO_CUP and flags == 0:
+            # class-level switches of the reference (RoboCupEnvironment.py:18-21): canFall=True, useObsRewards=True;
+            # make_dyn_env passes allowHeadTurn=use_continuous_actions (DynEnv/__init__.py:9-11)
+            flags = _capi.FLAG_CAN_FALL | _capi.FLAG_USE_OBS_REWARDS
+            if use_continuous_actions:
+                flags |= _capi.FLAG_ALLOW_HEAD_TURN
         self.env_type = env_type
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.cfg = _capi.Cfg(_capi.DYNENV_ABI_VERSION, int(env_type), int(num_envs), int(num_players),
@@ -123,6 +159,10 @@ class BatchedDynEnv(object):
         if env_type == DynEnvType.DRIVE:
             self.observation_space, self.action_space, self.recoDescriptor = _driving_spaces(observationType)
             self.stepNum = 6000 / 10.0  # DrivingEnvironment.py:49
+        else:
+            self.observation_space, self.action_space, self.recoDescriptor = _robocup_spaces(
+                observationType, bool(flags & _capi.FLAG_ALLOW_HEAD_TURN))
+            self.stepNum = 12000 / 10.0 / 5  # RoboCupEnvironment.py:61
         E, T, A, D = self.num_envs, self.n_time_steps, self.n_agents, self.obs_dim
         if out_buffers is None:
             self.obs = torch.zeros((E, T, A, D), dtype=torch.float32, device=self.device)
@@ -165,10 +205,15 @@ class BatchedDynEnv(object):
         """One env step of every environment: ONE kernel launch on torch's current stream."""
         if self._needs_reset:
             raise _capi.DynEnvError("call reset() before step()")
+        torch = self._torch
         a = self._stage_actions(actions)
         if validate and self.env_type == DynEnvType.DRIVE:
             if bool(((a < 0) | (a > 2)).any()):  # DrivingEnvironment.py:365-368
                 raise Exception("Error: Acceleration must be between +/-3")
+        if validate and self.env_type == DynEnvType.ROBO_CUP:  # RoboCupEnvironment.py:543-550
+            hi = torch.tensor([4, 2, 2, 6], device=a.device, dtype=a.dtype)
+            if bool(((a < 0) | (a > hi)).any()):
+                raise Exception("Error: Robot movement must be categorical in the range [0-4]")
         _capi.check(self._lib.dynenv_step(self._h, C.c_void_p(a.data_ptr()), C.c_void_p(self.obs.data_ptr()),
                                           C.c_void_p(self.rewards.data_ptr()), C.c_void_p(self.dones.data_ptr()),
                                           self._stream()), "dynenv_step")
@@ -209,7 +254,7 @@ class BatchedDynEnv(object):
         return dict(fast=out[0], quiescent=out[1], contact=out[2], slot_sum=out[3])
 
     def get_state(self, env=0):
-        st = _capi.DrivingState()
+        st = _capi.DrivingState() if self.env_type == DynEnvType.DRIVE else _capi.RoboCupState()
         _capi.check(self._lib.dynenv_get_state(self._h, env, C.byref(st), C.sizeof(st)), "dynenv_get_state")
         return st
 
@@ -229,6 +274,15 @@ class BatchedDynEnv(object):
         L = self.layout
         off, rows, feat = list(L.block_offset), list(L.block_rows), list(L.block_feat)
         out = np.empty((E, T, A, 3), dtype=object)
+        if self.env_type == DynEnvType.ROBO_CUP:  # ((ball, robots), (self,), (1,1,1)) RoboCupEnvironment.py:440-443
+            for e in range(E):
+                for t in range(T):
+                    for a in range(A):
+                        r = o[e, t, a]
+                        out[e, t, a, 0] = [r[0:4].reshape(1, 4).copy(), r[12:12 + (A - 1) * 6].reshape(A - 1, 6).copy()]
+                        out[e, t, a, 1] = [r[4:12].reshape(1, 8).copy(), ]
+                        out[e, t, a, 2] = (1, 1, 1)
+            return out
         for e in range(E):
             n_obst, n_ped = int(counts[e, 0]), int(counts[e, 1])
             for t in range(T):
@@ -249,6 +303,13 @@ class BatchedDynEnv(object):
         L = self.layout
         off, rows = list(L.block_offset), list(L.block_rows)
         A = self.n_agents
+        if self.env_type == DynEnvType.ROBO_CUP:  # getFullState(agent) = [ball, self, robots] (:1164-1188)
+            recon = []
+            for a in range(A):
+                r = obs_np[e, -1, a]
+                recon.append([r[0:4].reshape(1, 4).copy(), r[4:12].reshape(1, 8).copy(),
+                              r[12:12 + (A - 1) * 6].reshape(A - 1, 6).copy()])
+            return recon[0], recon  # (the reference's agent=None variant is un-normalised; not reproduced)
         n_obst, n_ped = int(counts[e, 0]), int(counts[e, 1])
         recon = []
         for a in range(A):
@@ -290,7 +351,7 @@ class BatchedDynEnv(object):
             if done:
                 info["episode_r"] = stats[0][e].copy()
                 info["episode_p_r"] = stats[1][e].copy()
-                info["episode_o_r"] = [0, ] * self.n_agents
+                info["episode_o_r"] = stats[2][e].copy() if self.env_type == DynEnvType.ROBO_CUP else [0, ] * self.n_agents
                 info["episode_g"] = [int(stats[3][e, 0]), int(stats[3][e, 1])]
                 info["terminal_observation"] = [list(term[e, t]) for t in range(self.n_time_steps)]
             infos.append(info)
@@ -330,8 +391,11 @@ class BatchedDynEnv(object):
 
     def env_method(self, method_name, *method_args, indices=None, **method_kwargs):
         idx = self._get_indices(indices)
-        if method_name == "get_agent_locs":  # DrivingEnvironment.py:126-127: self rows [x, y, cos, sin] per agent
+        if method_name == "get_agent_locs":
             o = self.obs.cpu().numpy()
+            if self.env_type == DynEnvType.ROBO_CUP:  # RoboCupEnvironment.py:434-435: self rows [:, 0:6]
+                return [[o[e, -1, a, 4:10].reshape(1, 6).copy() for a in range(self.n_agents)] for e in idx]
+            # DrivingEnvironment.py:126-127: self rows [x, y, cos, sin] per agent
             return [[o[e, -1, a, 0:4].reshape(1, 4).copy() for a in range(self.n_agents)] for e in idx]
         if method_name == "set_random_seed":
             return self.seed(*method_args)

@@ -233,3 +233,68 @@ def test_vec_env_compat_surface(gpu):
     assert len(venv.env_method("get_agent_locs")[0]) == 2
     assert venv.action_space.spaces[0].nvec.tolist() == [3, 3]
     venv.close()
+
+
+# ------------------------------------------------------------------------------------------------ RoboCup (configs[2])
+def _assert_rc_state_equal(sg, so, msg=""):
+    dg, do = ol.rc_state_to_dict(sg), ol.rc_state_to_dict(so)
+    for k in do:
+        if k == "scalars":  # defenders are a set on the device (reported ascending); compare everything else exactly
+            continue
+        np.testing.assert_array_equal(dg[k], do[k], err_msg="%s field %s" % (msg, k))
+    assert [sg.elapsed, sg.ball_owned, sg.n_last_kicked, sg.episode] == [so.elapsed, so.ball_owned, so.n_last_kicked, so.episode], msg
+    assert list(sg.last_kicked)[:sg.n_last_kicked] == list(so.last_kicked)[:so.n_last_kicked], msg
+    assert list(sg.goals) == list(so.goals) and list(sg.closest) == list(so.closest), msg
+    for t in range(2):
+        assert sorted(list(sg.defenders[t])[:sg.n_def[t]]) == sorted(list(so.defenders[t])[:so.n_def[t]]), msg + " defenders"
+
+
+def _rc_actions(rng, E, A):
+    return np.stack([rng.integers(0, 5, (E, A)), rng.integers(0, 3, (E, A)), rng.integers(0, 3, (E, A)),
+                     rng.integers(0, 7, (E, A))], -1).astype(np.int32)
+
+
+@pytest.mark.parametrize("n,E,seed", [(5, 32, 42), (2, 8, 7), (1, 4, 3)])
+def test_robocup_reset_parity(gpu, n, E, seed):
+    dynenv_amd, _, _ = gpu
+    env = dynenv_amd.BatchedDynEnv(dynenv_amd.DynEnvType.ROBO_CUP, E, n, seed=seed)
+    ora = ol.OracleEnv(env_type=0, num_envs=E, n_players=n, seed=seed, flags=ol.ROBOCUP_DEFAULT_FLAGS)
+    og = env.reset_flat().cpu().numpy()
+    oc = ora.reset()
+    assert og.shape == oc.shape == (E, 5, 2 * n, 12 + (2 * n - 1) * 6)
+    np.testing.assert_array_equal(og, oc)
+    for e in range(0, E, max(1, E // 4)):
+        _assert_rc_state_equal(env.get_state(e), ora.get_state(e), "env %d" % e)
+    env.close()
+
+
+@pytest.mark.parametrize("n,E,seed,steps,flags", [(5, 32, 42, 60, None), (2, 8, 7, 60, None), (5, 16, 11, 240, None),
+                                                   (5, 16, 5, 60, 0)])
+def test_robocup_step_parity(gpu, n, E, seed, steps, flags):
+    """configs[2]: RoboCup nPlayers=5, Full obs, 50 substeps (canFall=True like the reference default; flags=0 turns
+    the dice off = the RNG-free configuration of SURVEY Appendix D)."""
+    dynenv_amd, _, _ = gpu
+    fl = ol.ROBOCUP_DEFAULT_FLAGS if flags is None else flags
+    env = dynenv_amd.BatchedDynEnv(dynenv_amd.DynEnvType.ROBO_CUP, E, n, seed=seed, flags=fl if fl else 8)
+    ora = ol.OracleEnv(env_type=0, num_envs=E, n_players=n, seed=seed, flags=fl if fl else 8, threads=8)
+    env.reset_flat()
+    ora.reset()
+    rng = np.random.default_rng(seed)
+    contacts = 0
+    for s in range(steps):
+        a = _rc_actions(rng, E, 2 * n)
+        og, rg, dg = env.step_flat(a, auto_reset=False)
+        oc, rc, dc = ora.step(a)
+        contacts += sum(ora.active_contacts(e) > 0 for e in range(E))
+        np.testing.assert_array_equal(rg.cpu().numpy(), rc, err_msg="rewards step %d" % s)
+        np.testing.assert_array_equal(dg.cpu().numpy(), dc, err_msg="dones step %d" % s)
+        np.testing.assert_array_equal(og.cpu().numpy(), oc, err_msg="obs step %d" % s)
+        if s % 10 == 9 or s == steps - 1:
+            for e in range(0, E, max(1, E // 4)):
+                _assert_rc_state_equal(env.get_state(e), ora.get_state(e), "step %d env %d" % (s, e))
+    assert env.error_flags() == 0 and ora.overflow() == 0
+    if steps >= 240:
+        assert dc.all() and contacts > 0
+        for g, o in zip([x.cpu().numpy() for x in env.episode_stats()], ora.episode_stats()):
+            np.testing.assert_array_equal(g, o)
+    env.close()
