@@ -22,25 +22,49 @@ sys.path.insert(0, ROOT)
 # Algorithmic HBM bytes per Driving env-step, A=10, Full obs (derivation in DESIGN.md):
 # actions 20 + state read 2550 + state write 2230 + obs 10*232*4 (+8 counts) + rewards 80 + done 1
 B_ALG_DRIVING_FULL_A10 = 20 + 2550 + 2230 + (9280 + 8) + 80 + 1
+# RoboCup Full, A=10: actions 40 + state 3650 R + 3650 W + obs 10*5*66*4 + rewards 80 + done 1
+B_ALG_ROBOCUP_FULL_A10 = 40 + 3650 + 3650 + 13200 + 80 + 1
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def cpu_baseline(E, A, seed, target_seconds=12.0):
+def host_core_share():
+    """Cores this job may use: cgroup cpu.max quota if set, else the affinity mask, capped at 16 (the per-GPU share of
+    the GPU box; an un-capped 256-thread pool on a shared host measures scheduler noise, not the code)."""
+    n = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()
+            if q != "max":
+                n = max(1, int(int(q) / int(p)))
+    except (OSError, ValueError):
+        pass
+    if n is None:
+        try:
+            n = len(os.sched_getaffinity(0))
+        except AttributeError:
+            n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(E, n_players, A, seed, robocup=False, target_seconds=12.0):
     """The CPU restatement (oracle, kind='port') timed on this box's host cores on a bounded sample of the same
     workload.  It is a C restatement, i.e. a much stronger baseline than the reference's Python+pymunk path, which
     cannot run here (pymunk absent; the reference never ships to the GPU box)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib as ol
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores = host_core_share()
     ol.build()
-    env = ol.OracleEnv(env_type=1, num_envs=E, n_players=A, seed=seed, threads=cores)
+    if robocup:
+        env = ol.OracleEnv(env_type=0, num_envs=E, n_players=n_players, seed=seed, threads=cores, flags=ol.ROBOCUP_DEFAULT_FLAGS)
+    else:
+        env = ol.OracleEnv(env_type=1, num_envs=E, n_players=n_players, seed=seed, threads=cores)
     env.reset()
     rng = np.random.default_rng(0)
-    acts = [rng.integers(0, 3, size=(E, A, 2)).astype(np.int32) for _ in range(8)]
+    if robocup:
+        acts = [np.stack([rng.integers(0, k, (E, A)) for k in (5, 3, 3, 7)], -1).astype(np.int32) for _ in range(8)]
+    else:
+        acts = [rng.integers(0, 3, size=(E, A, 2)).astype(np.int32) for _ in range(8)]
     env.step(acts[0])  # touch memory
     t0 = time.perf_counter()
     n = 0
@@ -61,8 +85,9 @@ def cpu_baseline(E, A, seed, target_seconds=12.0):
     except OSError:
         pass
     return {"value": value, "unit": "agent-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d env-steps of the same %d-env Driving nPlayers=%d workload (first %d steps of an episode), "
-                      "oracle/liboracle.so with %d OpenMP threads, %.1f s" % (n, E, A, n, cores, dt),
+            "sample": "%d steps of the same %d-env %s nPlayers=%d workload (first %d steps of an episode), "
+                      "oracle/liboracle.so with %d OpenMP threads, %.1f s"
+                      % (n, E, "RoboCup" if robocup else "Driving", n_players, n, cores, dt),
             "cpu_model": model}
 
 
@@ -72,7 +97,9 @@ def main():
     ap.add_argument("--steps", type=int, default=1200)   # 2 full episodes
     ap.add_argument("--warmup", type=int, default=600)   # 1 full episode
     ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
-    ap.add_argument("--players", type=int, default=10)
+    ap.add_argument("--players", type=int, default=None)
+    ap.add_argument("--workload", choices=["driving", "robocup"], default="driving",
+                    help="driving = BASELINE configs[1] (the headline metric); robocup = configs[2], reported on request")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the end-of-step all-gather (data-parallel consumer)")
@@ -97,21 +124,31 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    E, A = args.envs, args.players
+    robocup = args.workload == "robocup"
+    n_players = args.players if args.players is not None else (5 if robocup else 10)
+    env_type = DynEnvType.ROBO_CUP if robocup else DynEnvType.DRIVE
+    E = args.envs
+    A = 2 * n_players if robocup else n_players
+    if args.steps == 1200 and robocup:
+        args.steps, args.warmup = 480, 240  # 2 + 1 episodes of 240 steps
     slab = gather = None
     out_buffers = None
     if world > 1 and not args.no_gather:
-        probe = BatchedDynEnv(DynEnvType.DRIVE, 1, A, device=device)
+        probe = BatchedDynEnv(env_type, 1, n_players, device=device)
         T, D = probe.n_time_steps, probe.obs_dim
         probe.close()
         slab = PackedSlab(torch, device, E, T, A, D)
         out_buffers = (slab.obs, slab.rewards, slab.dones)
         gather = StepGather(torch, dist, slab)
-    env = BatchedDynEnv(DynEnvType.DRIVE, E, A, seed=args.seed, device=device, env_id_offset=rank * E,
+    env = BatchedDynEnv(env_type, E, n_players, seed=args.seed, device=device, env_id_offset=rank * E,
                         out_buffers=out_buffers)
     # synthetic inputs: i.i.d. uniform actions (action_space MultiDiscrete([3,3])), resident in HBM
     g = torch.Generator(device=device).manual_seed(1234 + rank)
-    pool = [torch.randint(0, 3, (E, A, 2), generator=g, device=device, dtype=torch.int32) for _ in range(64)]
+    if robocup:  # MultiDiscrete([5, 3, 3, 7]) RoboCupEnvironment.py:342
+        hi = torch.tensor([5, 3, 3, 7], device=device)
+        pool = [(torch.rand((E, A, 4), generator=g, device=device) * hi).to(torch.int32) for _ in range(64)]
+    else:
+        pool = [torch.randint(0, 3, (E, A, 2), generator=g, device=device, dtype=torch.int32) for _ in range(64)]
 
     def one_step(i):
         env.step_flat(pool[i & 63])
@@ -159,7 +196,7 @@ def main():
         k1.record()
         torch.cuda.synchronize(device)
         launch_ms = k0.elapsed_time(k1) / n_launch
-        b_alg = B_ALG_DRIVING_FULL_A10 if A == 10 else None
+        b_alg = (B_ALG_ROBOCUP_FULL_A10 if robocup else B_ALG_DRIVING_FULL_A10) if A == 10 else None
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
@@ -171,7 +208,7 @@ def main():
         if b_alg is not None:
             achieved = b_alg * E / (launch_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "drv_step_kernel",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "rc_step_kernel" if robocup else "drv_step_kernel",
                         "launch_ms": launch_ms, "alg_bytes_per_env_step": b_alg, "env_steps_per_launch": E}
 
     if rank == 0:
@@ -181,10 +218,12 @@ def main():
             "metric": "agent-steps/s", "value": value, "unit": "agent-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "DrivingEnvironment nPlayers=%d Full obs, noise=0, %d envs per GPU "
-                                   "(BASELINE.json configs[1]), 10 substeps/step, lock-step resets every 600 steps"
-                                   % (A, E),
-                       "envs_per_gpu": E, "n_players": A, "obs": "full", "gather": bool(gather is not None),
+            "config": {"workload": ("RoboCupEnvironment nPlayers=%d Full obs, 50 substeps/step, %d envs per GPU "
+                                    "(BASELINE.json configs[2]), lock-step resets every 240 steps" % (n_players, E))
+                       if robocup else
+                       ("DrivingEnvironment nPlayers=%d Full obs, noise=0, %d envs per GPU "
+                        "(BASELINE.json configs[1]), 10 substeps/step, lock-step resets every 600 steps" % (A, E)),
+                       "envs_per_gpu": E, "n_players": n_players, "n_agents": A, "obs": "full", "gather": bool(gather is not None),
                        "parallelism": "env-shard x%d" % world},
             "env_steps_per_s": env_steps / elapsed,
             "gpu_ms_per_step_rank0": gpu_ms / args.steps,
@@ -192,7 +231,7 @@ def main():
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(E, A, args.seed)
+            out["cpu_baseline"] = cpu_baseline(E, n_players, A, args.seed, robocup)
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
         print(json.dumps(out))

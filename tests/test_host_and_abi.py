@@ -1,0 +1,112 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol include/dynenv.h declares,
+fails loudly without a GPU (no CPU fallback), and the product package never touches the oracle."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from dynenv_amd import _capi, build
+    build.build()
+    return _capi
+
+
+def _declared_functions():
+    txt = open(os.path.join(ROOT, "include", "dynenv.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = re.findall(r"^\s*(?:const\s+)?(?:int|void|size_t|char\s*\*|const char\s*\*)\s*\*?\s*(dynenv_\w+)\s*\(", txt, flags=re.M)
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol(capi):
+    lib = capi.load()
+    names = _declared_functions()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), "libdynenv_hip.so does not export %s declared in include/dynenv.h" % n
+    assert set(names) <= set(capi.EXPORTS) | {"dynenv_abi_version", "dynenv_last_error"}
+    assert lib.dynenv_abi_version() == 1
+
+
+def test_struct_sizes_match_the_header(capi):
+    # sizes the C compiler gives the blob structs (compiled on the fly with gcc)
+    src = '#include <stdio.h>\n#include "dynenv.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(dynenv_cfg_t), ' \
+          'sizeof(dynenv_layout_t), sizeof(dynenv_car_state_t), sizeof(dynenv_ped_state_t), sizeof(dynenv_driving_state_t), ' \
+          'sizeof(dynenv_robocup_state_t));return 0;}'
+    exe = "/tmp/dynenv_sizes"
+    subprocess.run(["gcc", "-x", "c", "-", "-I" + os.path.join(ROOT, "include"), "-o", exe], input=src.encode(), check=True)
+    sizes = [int(x) for x in subprocess.run([exe], capture_output=True, check=True).stdout.split()]
+    assert sizes == [C.sizeof(capi.Cfg), C.sizeof(capi.Layout), C.sizeof(capi.CarState), C.sizeof(capi.PedState),
+                     C.sizeof(capi.DrivingState), C.sizeof(capi.RoboCupState)]
+
+
+def test_no_gpu_means_loud_failure_not_fallback(capi):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this check is for the CPU-only container")
+    lib = capi.load()
+    cfg = capi.Cfg(1, 1, 4, 10, 0, 1, 0.0, 42, 0, 0, 0, 0)
+    h = C.c_void_p()
+    rc = lib.dynenv_create(C.byref(cfg), C.byref(h))
+    assert rc == capi.ERR_NO_DEVICE and not h
+    assert b"no CPU fallback" in lib.dynenv_last_error()
+    import dynenv_amd
+    with pytest.raises(capi.DynEnvError):
+        dynenv_amd.BatchedDynEnv(dynenv_amd.DynEnvType.DRIVE, 4, 10)
+    with pytest.raises(capi.DynEnvError):
+        dynenv_amd.make_dyn_env(dynenv_amd.DynEnvType.DRIVE, 4, 10, False, dynenv_amd.ObservationType.FULL,
+                                dynenv_amd.NoiseType.REALISTIC, 0, False)
+
+
+def test_argument_validation(capi):
+    lib = capi.load()
+    h = C.c_void_p()
+    bad = capi.Cfg(99, 1, 4, 10, 0, 1, 0.0, 42, 0, 0, 0, 0)
+    assert lib.dynenv_create(C.byref(bad), C.byref(h)) == -1 and b"ABI" in lib.dynenv_last_error()
+    bad = capi.Cfg(1, 1, 0, 10, 0, 1, 0.0, 42, 0, 0, 0, 0)
+    assert lib.dynenv_create(C.byref(bad), C.byref(h)) == -1
+    bad = capi.Cfg(1, 1, 4, 10, 0, 1, 7.0, 42, 0, 0, 0, 0)  # environment_base.py:162-164
+    assert lib.dynenv_create(C.byref(bad), C.byref(h)) == -1 and b"noise magnitude" in lib.dynenv_last_error()
+
+
+def test_product_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "dynenv_amd")
+    offenders = []
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(d, f), errors="replace").read()
+                if re.search(r"oracle_lib|liboracle|/oracle/|import oracle|from oracle", txt):
+                    offenders.append(os.path.join(d, f))
+    assert not offenders, "product files reference the oracle: %s" % offenders
+
+
+def test_enums_and_spaces_mirror_the_reference():
+    from dynenv_amd import DynEnvType, NoiseType, ObservationType
+    from dynenv_amd import spaces as sp
+    from dynenv_amd.vec_env import _driving_spaces, _robocup_spaces
+    assert (int(DynEnvType.ROBO_CUP), int(DynEnvType.DRIVE)) == (0, 1)
+    assert (int(ObservationType.FULL), int(ObservationType.PARTIAL), int(ObservationType.IMAGE)) == (0, 1, 2)
+    assert DynEnvType.argparse("drive") is DynEnvType.DRIVE and str(NoiseType.REALISTIC) == "realistic"
+    obs, act, reco = _driving_spaces(ObservationType.FULL)
+    assert act.spaces[0].nvec.tolist() == [3, 3] and reco.featureGridSize == (10, 17)
+    assert list(obs.spaces[1].spaces[1].spaces) == ["points", "type"]       # Full lanes: 4 points + type
+    assert sp.flatdim(obs.spaces[0].spaces[0]) == 7 and sp.flatdim(obs.spaces[1].spaces[0]) == 9
+    obs, act, reco = _robocup_spaces(ObservationType.FULL, False)
+    assert act.spaces[0].nvec.tolist() == [5, 3, 3, 7]
+    assert sp.flatdim(obs.spaces[0].spaces[0]) == 4 and sp.flatdim(obs.spaces[0].spaces[1]) == 6
+    assert sp.flatdim(obs.spaces[1].spaces[0]) == 8
+
+
+def test_shard_ranges():
+    from dynenv_amd.distributed import shard_range
+    assert [shard_range(32768, r, 8) for r in (0, 7)] == [(0, 4096), (28672, 4096)]
+    with pytest.raises(ValueError):
+        shard_range(10, 0, 3)
