@@ -505,6 +505,17 @@ void drv_write_full_obs(const DrivingEnv* e, float* out) {
   }
 }
 
+int drv_env_obs_dim(const DrivingEnv* e) { return e->obsType == DYNENV_OBS_PARTIAL ? drv_partial_obs_dim() : drv_obs_dim(e->nPlayers); }
+
+void drv_write_obs(DrivingEnv* e, float* out) { /* :290-294 and environment_base.py:217-222 */
+  if (e->obsType == DYNENV_OBS_PARTIAL) {
+    int a, dim = drv_partial_obs_dim();
+    for (a = 0; a < e->nPlayers; ++a) e->obsOverflow |= drv_agent_vision(e, a, e->noiseType, e->noiseMagnitude, out + (size_t)a * dim);
+  } else {
+    drv_write_full_obs(e, out);
+  }
+}
+
 /* ------------------------------------------------------------------ step :248-322 */
 int drv_step(DrivingEnv* e, const int32_t* actions, float* obs, double* rewards) {
   int A = e->nPlayers, i, a, k;
@@ -524,7 +535,7 @@ int drv_step(DrivingEnv* e, const int32_t* actions, float* obs, double* rewards)
       e->allFinished = 1;
       e->teamReward += (double)(DRV_MAX_TIME - e->elapsed) / 100.0;
     }
-    if (i % 10 == 9 && obs) drv_write_full_obs(e, obs);
+    if (i % 10 == 9 && obs) drv_write_obs(e, obs);
   }
   for (a = 0; a < A; ++a) {
     e->carRewards[a] += e->teamReward;

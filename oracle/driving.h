@@ -55,6 +55,9 @@ typedef struct DrivingEnv {
   uint64_t seed;
   uint32_t genv, episode;
   float laneRows[DYNENV_DRIVE_LANES][5];
+  int obsType, noiseType; /* ObservationType / NoiseType (cutils.py:29-51) */
+  double noiseMagnitude;
+  int obsOverflow;
 } DrivingEnv;
 
 #define DRV_W 1700.0
@@ -74,6 +77,10 @@ int drv_obs_dim(int nPlayers);
 void drv_init(DrivingEnv* e, int nPlayers, uint64_t seed, uint32_t genv);
 void drv_reset(DrivingEnv* e); /* new episode: scene re-randomisation (environment_base.py:205-211) */
 void drv_write_full_obs(const DrivingEnv* e, float* out /* [A][obs_dim] */);
+int drv_partial_obs_dim(void);
+int drv_agent_vision(const DrivingEnv* e, int agentIdx, int noiseType, double magn, float* out);
+void drv_write_obs(DrivingEnv* e, float* out); /* Full or Partial according to e->obsType */
+int drv_env_obs_dim(const DrivingEnv* e);
 /* returns done flag; rewards[A] */
 int drv_step(DrivingEnv* e, const int32_t* actions /* [A][2] */, float* obs, double* rewards);
 void drv_get_state(const DrivingEnv* e, dynenv_driving_state_t* st);

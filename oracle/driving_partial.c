@@ -1,0 +1,475 @@
+/* driving_partial.c — ORACLE (test infrastructure): CPU restatement of DrivingEnvironment.getAgentVision
+ * (DynEnv/DrivingEnvironment.py:750-977) with its helpers isSeenInRadius / doesInteractPoly / getViewBlockAngle /
+ * filterOcclude / addNoiseRect / addNoiseLane (DynEnv/cutils.py:382-413,472-542,569-696) and Road.getCarLaneDistances
+ * (DynEnv/Road.py:36-71).  Quirks kept on purpose: corners are translated but never rotated (C3),
+ * `pedInter = max(list, list)` is a lexicographic list comparison (C12), Distant is unreachable (C17), REALISTIC
+ * rect noise divides a length by a squared distance (C18), RANDOM lane noise multiplies (C19).
+ *
+ * RNG: the serial random.random() stream is replaced by Philox blocks keyed
+ *   (seed, env, episode, OBS_NOISE, entity = agent | kind<<4 | index<<8 | block<<16, elapsed)
+ * with a FIXED word per draw site, so every object's noise is independent of the others (parallel on the GPU):
+ *   rect noise   kind 0 self / 1 car / 2 pedestrian / 3 obstacle: w0,w1 position, w2 false negative, w3 misclassification,
+ *                block1.w0 angle
+ *   lane noise   kind 4: w0 distance, w1 angle, w2 false negative
+ *   random FP    kind 5, index = trial: w0 gate, w1 class, w2 distance, w3 bearing; block1: w0 object angle, w1/w2 size or
+ *                lane angle/distance, w3 lane type
+ *   FP pedestrian near car  kind 6, index = position in the car list: w0 gate, w1/w2 offset
+ * The golden generator serves the reference's random.* calls from the same words (tests/golden/gen_golden_partial.py).
+ *
+ * Dense output row per agent (float32, zero padded): self[9] | cars[24 x 7] | obstacles[32 x 6] | pedestrians[40 x 2] |
+ * lanes[16 x 4] | counts[4]. */
+#include <math.h>
+#include <string.h>
+
+#include "driving.h"
+#include "dynenv_math.h"
+
+#define SIGHT_NONE 0
+#define SIGHT_PARTIAL 1
+#define SIGHT_DISTANT 2
+#define SIGHT_NORMAL 3
+#define SIGHT_MISCLASS 4
+#define INTER_NONE 0
+#define INTER_NEARBY 1
+#define INTER_OCCLUDE 2
+
+typedef struct {
+  int seen;
+  cpv pos;
+  double c, s;
+  int hasCorners;
+  cpv corners[4];
+  double w, h;
+  int finished;
+} Det;
+
+typedef struct {
+  int seen;
+  double dist, c, s, type;
+} LaneDet;
+
+static inline double vlen(cpv v) { return dm_sqrt(v.x * v.x + v.y * v.y); }
+static inline double lensq(cpv v) { return v.x * v.x + v.y * v.y; }
+static inline cpv rotated(cpv v, double a) {
+  double s, c;
+  dm_sincos(a, &s, &c);
+  return cpv_(v.x * c - v.y * s, v.x * s + v.y * c);
+}
+static inline double vangle(cpv v) { return dm_atan2(v.y, v.x); } /* cutils.angle :600-601 */
+
+static dm_u32x4 obs_rng(const DrivingEnv* e, int agent, int kind, int index, int block) {
+  uint32_t entity = (uint32_t)agent | ((uint32_t)kind << 4) | ((uint32_t)index << 8) | ((uint32_t)block << 16);
+  return dm_env_rng(e->seed, e->genv, e->episode, DM_RNG_OBS_NOISE, entity, (uint32_t)e->elapsed);
+}
+
+/* cutils.isSeenInRadius :569-596 */
+static void is_seen_in_radius(Det* d, cpv point, const cpv* corners, double angle, cpv obsPt, double obsAngle,
+                              double maxDist, double distantDist) {
+  cpv trPt = cpvsub(point, obsPt);
+  double dist = lensq(trPt);
+  int i;
+  d->hasCorners = 0;
+  if (dist <= maxDist) {
+    d->seen = SIGHT_DISTANT;
+    if (dist <= distantDist) d->seen = SIGHT_NORMAL;
+    if (corners) {
+      d->hasCorners = 1;
+      for (i = 0; i < 4; ++i) d->corners[i] = cpvadd(cpvsub(corners[i], point), trPt); /* rotations are discarded (C3) */
+    }
+    d->pos = rotated(trPt, -obsAngle);
+    {
+      double trAngle = angle - obsAngle, s, c;
+      dm_sincos(trAngle, &s, &c);
+      d->c = c; d->s = s;
+    }
+  } else {
+    d->seen = SIGHT_NONE;
+  }
+}
+
+/* cutils.doesInteractPoly :643-696 (+ getViewBlockAngle :626-640) */
+static int does_interact_poly(const Det* e1, const Det* e2, double radius) {
+  int ret = INTER_NONE, i, minIdx = 0, maxIdx = 0, cIdx = 0;
+  double angles[4], dists[4], angle2, pAngle;
+  cpv p1, p2, pm, point1, point2;
+  if (e1->seen == SIGHT_NONE || e2->seen == SIGHT_NONE) return ret;
+  point1 = e1->pos; point2 = e2->pos;
+  if (radius > 0.0 && lensq(cpvsub(point2, point1)) < radius) ret = INTER_NEARBY;
+  angle2 = vangle(point2);
+  for (i = 0; i < 4; ++i) {
+    angles[i] = vangle(e2->corners[i]) - angle2;
+    dists[i] = lensq(e2->corners[i]);
+  }
+  for (i = 0; i < 4; ++i) if (angles[i] > DM_PI) angles[i] -= DM_TWO_PI;
+  for (i = 0; i < 4; ++i) if (angles[i] < -DM_PI) angles[i] += DM_TWO_PI;
+  for (i = 1; i < 4; ++i) {
+    if (angles[i] < angles[minIdx]) minIdx = i;
+    if (angles[i] > angles[maxIdx]) maxIdx = i;
+    if (dists[i] < dists[cIdx]) cIdx = i;
+  }
+  p1 = e2->corners[minIdx]; p2 = e2->corners[maxIdx]; pm = e2->corners[cIdx];
+  pAngle = vangle(point1) - angle2;
+  if (pAngle > DM_PI) pAngle -= DM_TWO_PI; else if (pAngle < -DM_PI) pAngle += DM_TWO_PI;
+  if (pAngle > angles[minIdx] && pAngle < angles[maxIdx]) {
+    if (cIdx == minIdx || cIdx == maxIdx) {
+      if (cpvcross(cpvsub(p2, p1), cpvsub(point1, p1)) < 0.0) ret = INTER_OCCLUDE;
+    } else if (cpvcross(cpvsub(p2, pm), cpvsub(point1, pm)) < 0.0 && cpvcross(cpvsub(pm, p1), cpvsub(point1, p1)) < 0.0) {
+      ret = INTER_OCCLUDE;
+    }
+  }
+  return ret;
+}
+
+#define ANGLE_NOISE (DM_PI / 180.0) /* cutils.angleNoise :203 */
+
+/* cutils.addNoiseRect :479-542 */
+static void add_noise_rect(const DrivingEnv* e, Det* obj, int noiseType, int interaction, double magn, double rnd,
+                           double maxDist, int misClass, int agent, int kind, int index) {
+  dm_u32x4 u, u1;
+  cpv noiseVec;
+  int i;
+  if (!obj->seen) return;
+  u = obs_rng(e, agent, kind, index, 0);
+  u1 = obs_rng(e, agent, kind, index, 1);
+  noiseVec = cpv_((dm_unit(u.v[0]) - 0.5) * magn, (dm_unit(u.v[1]) - 0.5) * magn);
+  if (noiseType == DYNENV_NOISE_RANDOM) {
+    if (dm_unit(u.v[2]) < rnd) {
+      obj->seen = SIGHT_NONE;
+    } else {
+      cpv newPos = cpvadd(obj->pos, noiseVec);
+      double angleDiff = (dm_unit(u1.v[0]) - 0.5) * magn * ANGLE_NOISE;
+      double ang = dm_atan2(obj->s, obj->c) + angleDiff, s, c;
+      dm_sincos(ang, &s, &c);
+      obj->c = c; obj->s = s;
+      if (obj->hasCorners) for (i = 0; i < 4; ++i) obj->corners[i] = cpvadd(cpvsub(obj->corners[i], obj->pos), obj->pos);
+      obj->pos = newPos;
+    }
+  } else {
+    double range = 0.25 + 3.75 * vlen(obj->pos) / maxDist; /* C18 */
+    double multiplier = range;
+    cpv newPos;
+    double angleDiff, ang, s, c;
+    if (interaction == INTER_NEARBY) multiplier = range * 2.0;
+    if (obj->seen == SIGHT_DISTANT) multiplier = range * 3.0; else if (obj->seen == SIGHT_PARTIAL) multiplier = range * 4.0;
+    newPos = cpvadd(obj->pos, cpvmult(noiseVec, multiplier));
+    if (dm_unit(u.v[2]) < rnd * multiplier) { obj->seen = SIGHT_NONE; return; }
+    if (misClass && dm_unit(u.v[3]) < rnd * multiplier / 2.0) obj->seen = SIGHT_MISCLASS;
+    angleDiff = (dm_unit(u1.v[0]) - 0.5) * magn * ANGLE_NOISE * 0.25;
+    ang = dm_atan2(obj->s, obj->c) + angleDiff;
+    dm_sincos(ang, &s, &c);
+    obj->c = c; obj->s = s;
+    if (obj->hasCorners) for (i = 0; i < 4; ++i) obj->corners[i] = cpvadd(cpvsub(obj->corners[i], obj->pos), newPos);
+    obj->pos = newPos;
+  }
+}
+
+/* cutils.addNoiseLane :382-413 */
+static void add_noise_lane(const DrivingEnv* e, LaneDet* obj, int noiseType, double magn, double rnd, double maxDist,
+                           int agent, int index) {
+  dm_u32x4 u;
+  double distNoise, angleDiff, ang, s, c;
+  if (!obj->seen) return;
+  u = obs_rng(e, agent, 4, index, 0);
+  distNoise = (dm_unit(u.v[0]) - 0.5) * magn;
+  angleDiff = (dm_unit(u.v[1]) - 0.5) * magn;
+  if (noiseType == DYNENV_NOISE_RANDOM) {
+    if (dm_unit(u.v[2]) < rnd) obj->seen = SIGHT_NONE;
+    obj->dist *= distNoise; /* C19 */
+    ang = dm_atan2(obj->s, obj->c);
+    ang += ANGLE_NOISE * angleDiff;
+  } else {
+    double multiplier1 = 0.25 + 3.75 * obj->dist * obj->dist / maxDist;
+    if (dm_unit(u.v[2]) < rnd * multiplier1) obj->seen = SIGHT_NONE;
+    obj->dist += distNoise * multiplier1;
+    ang = dm_atan2(obj->s, obj->c);
+    ang += ANGLE_NOISE * multiplier1 / 5.0 * angleDiff;
+  }
+  dm_sincos(ang, &s, &c);
+  obj->c = c; obj->s = s;
+}
+
+/* Road.getCarLaneDistances :36-71; returns the number of rows written (1 NoSighting row or 2*nLanes rows) */
+static int car_lane_distances(const Road* r, cpv carPos, double carAngle, LaneDet* out) {
+  cpv pt = cpvsub(carPos, r->p0);
+  double dist = cpvcross(r->dir, pt) / r->width;
+  int n = r->nLanes, i;
+  double a, c, s, distMult = 1.0, typeMult = 1.0;
+  if (dm_abs(dist) > 10.0) { out[0].seen = SIGHT_NONE; out[0].dist = out[0].c = out[0].s = out[0].type = 0.0; return 1; }
+  a = r->dirAngle - carAngle;
+  dm_sincos(a, &s, &c);
+  if (c >= 0.0) { typeMult = -1.0; c *= -1.0; s *= -1.0; distMult = -1.0; }
+  for (i = -n; i < n; ++i) {
+    LaneDet* o = &out[i + n];
+    o->seen = SIGHT_NORMAL;
+    o->dist = ((dist + 0.5) + (double)i) * r->width * 0.1 * distMult;
+    o->c = c; o->s = s;
+    o->type = ((i + n) < n ? 1.0 : -1.0) * typeMult;
+  }
+  return 2 * n;
+}
+
+#define PCAP_CARS 24
+#define PCAP_OBST 32
+#define PCAP_PEDS 40
+#define PCAP_LANES 16
+int drv_partial_obs_dim(void) { return 9 + PCAP_CARS * 7 + PCAP_OBST * 6 + PCAP_PEDS * 2 + PCAP_LANES * 4 + 4; }
+
+static inline double normalize(double pt, double nf, double mean) { return ((pt * nf) - mean) * 2.0 * 1.0; }
+#define P_MEAN 5.0
+#define P_NORM_X (P_MEAN * 2.0 / DRV_W)
+#define P_NORM_Y (P_MEAN * 2.0 / DRV_H)
+#define P_NORM_W (1.0 / 7.5)
+#define P_NORM_H (1.0 / 15.0)
+
+/* returns 1 if a row cap overflowed (rows beyond the cap are dropped) */
+int drv_agent_vision(const DrivingEnv* e, int agentIdx, int noiseType, double magn, float* out) {
+  static const cpv BUILDINGS[4] = {{365.0, 200.0}, {365.0, 800.0}, {1385.0, 200.0}, {1385.0, 800.0}};
+  const double randBase = 0.01 * magn;                       /* environment_base.py:170 */
+  const double maxVis0 = (DRV_W * 0.4) * (DRV_W * 0.4), maxVis1 = (DRV_W * 0.6) * (DRV_W * 0.6); /* :172, (0.4, 0.6) */
+  const Car* agent = &e->cars[agentIdx];
+  const double ang = agent->body.a;
+  const cpv P = agent->body.p;
+  Det self, cars[PCAP_CARS + 16], obst[PCAP_OBST + 16], peds[PCAP_PEDS + 16], build[4];
+  int carSrc[PCAP_CARS + 16]; /* original agent index of the real car rows (noise stream id) */
+  LaneDet lanes[PCAP_LANES + 16];
+  int laneSrc[PCAP_LANES + 16];
+  int nCars = 0, nObst = 0, nPeds = 0, nLanes = 0, i, j, k, overflow = 0;
+  int pedInter[PCAP_PEDS + 16];
+  double s, c;
+  cpv corners[4];
+  /* self detection :755-756 */
+  dm_sincos(ang, &s, &c);
+  self.seen = SIGHT_NORMAL; self.pos = P; self.c = c; self.s = s; self.hasCorners = 1;
+  {
+    double h = agent->height, w = agent->width;
+    cpv pts[4];
+    pts[0] = cpv_(h, w); pts[1] = cpv_(-h, w); pts[2] = cpv_(-h, -w); pts[3] = cpv_(h, -w);
+    for (i = 0; i < 4; ++i) self.corners[i] = cpvadd(pts[i], P);
+  }
+  self.w = agent->width; self.h = agent->height; self.finished = agent->finished;
+  /* other cars :757-759 */
+  for (j = 0; j < e->nPlayers; ++j) {
+    const Car* cj = &e->cars[j];
+    Det d;
+    double h = cj->height, w = cj->width;
+    cpv pts[4];
+    if (j == agentIdx) continue;
+    pts[0] = cpv_(h, w); pts[1] = cpv_(-h, w); pts[2] = cpv_(-h, -w); pts[3] = cpv_(h, -w);
+    for (i = 0; i < 4; ++i) corners[i] = cpvadd(pts[i], cj->body.p);
+    is_seen_in_radius(&d, cj->body.p, corners, cj->body.a, P, ang, maxVis0, maxVis1);
+    d.w = cj->width; d.h = cj->height; d.finished = cj->finished;
+    if (d.seen != SIGHT_NONE) { carSrc[nCars] = j; cars[nCars++] = d; }
+  }
+  /* obstacles :760-763 */
+  {
+    int srcIdx[DYNENV_MAX_OBST];
+    for (k = 0; k < e->nObst; ++k) {
+      Det d;
+      cpv ctr = e->obst[k].body.p;
+      cpv pts[4];
+      pts[0] = cpv_(10.0, 10.0); pts[1] = cpv_(-10.0, 10.0); pts[2] = cpv_(-10.0, -10.0); pts[3] = cpv_(10.0, -10.0);
+      for (i = 0; i < 4; ++i) corners[i] = cpvadd(pts[i], ctr);
+      is_seen_in_radius(&d, ctr, corners, 0.0, P, ang, maxVis0, maxVis1);
+      d.w = 10.0; d.h = 10.0; d.finished = 0;
+      if (d.seen != SIGHT_NONE) { srcIdx[nObst] = k; obst[nObst++] = d; }
+    }
+    /* buildings :764-765 (always seen) */
+    for (k = 0; k < 4; ++k) {
+      cpv pts[4];
+      pts[0] = cpv_(400.0, 225.0); pts[1] = cpv_(-400.0, 225.0); pts[2] = cpv_(-400.0, -225.0); pts[3] = cpv_(400.0, -225.0);
+      for (i = 0; i < 4; ++i) corners[i] = cpvadd(pts[i], BUILDINGS[k]);
+      is_seen_in_radius(&build[k], BUILDINGS[k], corners, 0.0, P, ang, 20000000.0, 20000000.0);
+    }
+    /* pedestrians :766-767 */
+    {
+      int pedSrc[DYNENV_MAX_PEDS];
+      for (k = 0; k < e->nPeds; ++k) {
+        Det d;
+        is_seen_in_radius(&d, e->peds[k].body.p, 0, 0.0, P, ang, maxVis0, maxVis1);
+        d.w = d.h = 0.0; d.finished = 0;
+        if (d.seen != SIGHT_NONE) { pedSrc[nPeds] = k; peds[nPeds++] = d; }
+      }
+      /* lanes :768 + :779 */
+      {
+        LaneDet tmp[8];
+        int row = 0, r;
+        for (r = 0; r < 2; ++r) {
+          int cnt = car_lane_distances(&e->roads[r], P, ang, tmp);
+          for (i = 0; i < cnt; ++i) {
+            if (tmp[i].seen != SIGHT_NONE) { laneSrc[nLanes] = row + i; lanes[nLanes++] = tmp[i]; }
+          }
+          row += 2 * e->roads[r].nLanes;
+        }
+      }
+      /* building occlusion :782-789 */
+      {
+        int n2;
+        n2 = 0;
+        for (i = 0; i < nCars; ++i) {
+          int m = 0;
+          for (k = 0; k < 4; ++k) { int t = does_interact_poly(&cars[i], &build[k], 0.0); if (t > m) m = t; }
+          if (m != INTER_OCCLUDE) { carSrc[n2] = carSrc[i]; cars[n2++] = cars[i]; }
+        }
+        nCars = n2;
+        n2 = 0;
+        for (i = 0; i < nPeds; ++i) {
+          int m = 0;
+          for (k = 0; k < 4; ++k) { int t = does_interact_poly(&peds[i], &build[k], 0.0); if (t > m) m = t; }
+          if (m != INTER_OCCLUDE) { pedSrc[n2] = pedSrc[i]; peds[n2++] = peds[i]; }
+        }
+        nPeds = n2;
+        n2 = 0;
+        for (i = 0; i < nObst; ++i) {
+          int m = 0;
+          for (k = 0; k < 4; ++k) { int t = does_interact_poly(&obst[i], &build[k], 0.0); if (t > m) m = t; }
+          if (m != INTER_OCCLUDE) { srcIdx[n2] = srcIdx[i]; obst[n2++] = obst[i]; }
+        }
+        nObst = n2;
+      }
+      /* pedestrian interactions :792-801; pedInter = max(list, list) is LEXICOGRAPHIC (C12) */
+      {
+        int carPed[PCAP_PEDS + 16], obsPed[PCAP_PEDS + 16], useObs = 0;
+        for (i = 0; i < nPeds; ++i) {
+          int m = 0;
+          for (j = 0; j < nCars; ++j) { int t = does_interact_poly(&peds[i], &cars[j], 400.0); if (t > m) m = t; }
+          carPed[i] = nCars ? m : INTER_NONE;
+          m = 0;
+          for (j = 0; j < nObst; ++j) { int t = does_interact_poly(&peds[i], &obst[j], 400.0); if (t > m) m = t; }
+          obsPed[i] = nObst ? m : INTER_NONE;
+        }
+        for (i = 0; i < nPeds; ++i) {
+          if (obsPed[i] != carPed[i]) { useObs = obsPed[i] > carPed[i]; break; }
+        }
+        for (i = 0; i < nPeds; ++i) {
+          pedInter[i] = useObs ? obsPed[i] : carPed[i];
+          if (pedInter[i] == INTER_OCCLUDE) peds[i].seen = SIGHT_NONE; /* filterOcclude */
+        }
+      }
+      /* noise :804-813 */
+      add_noise_rect(e, &self, noiseType, INTER_NONE, magn, randBase, maxVis1, 0, agentIdx, 0, 0);
+      /* noise streams are indexed by the row's position in its (filtered) list = the order of the reference's calls */
+      for (i = 0; i < nCars; ++i) add_noise_rect(e, &cars[i], noiseType, INTER_NONE, magn, randBase, maxVis1, 1, agentIdx, 1, i);
+      for (i = 0; i < nPeds; ++i) add_noise_rect(e, &peds[i], noiseType, pedInter[i], magn, randBase, maxVis0, 0, agentIdx, 2, i);
+      for (i = 0; i < nObst; ++i) add_noise_rect(e, &obst[i], noiseType, INTER_NONE, magn, randBase, maxVis1, 1, agentIdx, 3, i);
+      for (i = 0; i < nLanes; ++i) add_noise_lane(e, &lanes[i], noiseType, magn, randBase, maxVis1, agentIdx, i);
+    }
+  }
+  /* misclassification swap :816-821 */
+  {
+    int nc0 = nCars, no0 = nObst;
+    for (i = 0; i < nc0; ++i) {
+      if (cars[i].seen == SIGHT_MISCLASS) {
+        if (nObst < PCAP_OBST + 16) { obst[nObst] = cars[i]; obst[nObst].seen = SIGHT_NORMAL; nObst++; } else overflow = 1;
+      }
+    }
+    for (i = 0; i < no0; ++i) {
+      if (obst[i].seen == SIGHT_MISCLASS) {
+        if (nCars < PCAP_CARS + 16) { cars[nCars] = obst[i]; cars[nCars].seen = SIGHT_NORMAL; cars[nCars].finished = 0; nCars++; } else overflow = 1;
+      }
+    }
+  }
+  /* random false positives :824-874 */
+  for (i = 0; i < 10; ++i) {
+    dm_u32x4 u = obs_rng(e, agentIdx, 5, i, 0), u1 = obs_rng(e, agentIdx, 5, i, 1);
+    if (dm_unit(u.v[0]) < randBase) {
+      int cls = dm_randint(u.v[1], 0, 5);
+      double d = dm_unit(u.v[2]) * maxVis1;
+      double a1 = dm_unit(u.v[3]) * 2.0 * DM_PI;
+      cpv pos = rotated(cpv_(d, 0.0), a1);
+      double angle = dm_unit(u1.v[0]) * 2.0 * DM_PI, co, si;
+      dm_sincos(angle, &si, &co);
+      if (cls <= 1) {
+        double w = dm_unit(u1.v[1]) * 5.0 + 5.0, h = dm_unit(u1.v[2]) * 10.0 + 5.0;
+        Det dt;
+        cpv pts[4];
+        pts[0] = cpv_(h, w); pts[1] = cpv_(-h, w); pts[2] = cpv_(-h, -w); pts[3] = cpv_(h, -w);
+        dt.seen = SIGHT_NORMAL; dt.pos = pos; dt.c = co; dt.s = si; dt.hasCorners = 1; dt.w = w; dt.h = h; dt.finished = 0;
+        for (k = 0; k < 4; ++k) dt.corners[k] = cpvadd(cpv_(pts[k].x * co - pts[k].y * si, pts[k].x * si + pts[k].y * co), pos);
+        if (cls == 0) { if (nCars < PCAP_CARS + 16) cars[nCars++] = dt; else overflow = 1; }
+        else { if (nObst < PCAP_OBST + 16) obst[nObst++] = dt; else overflow = 1; }
+      } else if (cls == 2) {
+        Det dt;
+        memset(&dt, 0, sizeof(dt));
+        dt.seen = SIGHT_NORMAL; dt.pos = pos;
+        if (nPeds < PCAP_PEDS + 16) peds[nPeds++] = dt; else overflow = 1;
+      } else if (cls == 3) {
+        double a = (dm_unit(u1.v[1]) - 0.5) * DM_PI * 2.0, cc, ss;
+        LaneDet l;
+        dm_sincos(a, &ss, &cc);
+        l.seen = SIGHT_NORMAL;
+        l.dist = floor(dm_unit(u1.v[2]) * DRV_W / 2.0); /* random.random() * self.W // 2 */
+        l.c = cc; l.s = ss;
+        l.type = (double)dm_randint(u1.v[3], -1, 1);
+        if (nLanes < PCAP_LANES + 16) lanes[nLanes++] = l; else overflow = 1;
+      }
+    }
+  }
+  /* FP pedestrians near cars :877-882 (REALISTIC only) */
+  if (noiseType == DYNENV_NOISE_REALISTIC) {
+    for (i = 0; i < nCars; ++i) {
+      if (cars[i].seen == SIGHT_NORMAL) {
+        dm_u32x4 u = obs_rng(e, agentIdx, 6, i, 0);
+        if (dm_unit(u.v[0]) < randBase * 10.0 && vlen(cars[i].pos) < 250.0) {
+          Det dt;
+          cpv off = cpvmult(cpv_(2.0 * dm_unit(u.v[1]) - 1.0, 2.0 * dm_unit(u.v[2]) - 1.0), 10.0);
+          memset(&dt, 0, sizeof(dt));
+          dt.seen = SIGHT_NORMAL; dt.pos = cpvadd(cars[i].pos, off);
+          if (nPeds < PCAP_PEDS + 16) peds[nPeds++] = dt; else overflow = 1;
+        }
+      }
+    }
+  }
+  /* final filter + normalisation :885-974 */
+  {
+    int dim = drv_partial_obs_dim();
+    float* p;
+    int cnt;
+    memset(out, 0, sizeof(float) * dim);
+    out[0] = (float)normalize(self.pos.x, P_NORM_X, P_MEAN); out[1] = (float)normalize(self.pos.y, P_NORM_Y, P_MEAN);
+    out[2] = (float)self.c; out[3] = (float)self.s;
+    out[4] = (float)normalize(self.w, P_NORM_W, 0.5); out[5] = (float)normalize(self.h, P_NORM_H, 0.5);
+    out[6] = (float)normalize(agent->goal.x, P_NORM_X, P_MEAN); out[7] = (float)normalize(agent->goal.y, P_NORM_Y, P_MEAN);
+    out[8] = (float)self.finished;
+    p = out + 9; cnt = 0;
+    for (i = 0; i < nCars; ++i) {
+      const Det* d = &cars[i];
+      if (d->seen == SIGHT_NONE || d->seen == SIGHT_MISCLASS) continue;
+      if (cnt >= PCAP_CARS) { overflow = 1; break; }
+      p[0] = (float)normalize(d->pos.x, P_NORM_X, 0.0); p[1] = (float)normalize(d->pos.y, P_NORM_Y, 0.0);
+      p[2] = (float)d->c; p[3] = (float)d->s;
+      p[4] = (float)normalize(d->w, P_NORM_W, 0.5); p[5] = (float)normalize(d->h, P_NORM_H, 0.5); p[6] = (float)d->finished;
+      p += 7; ++cnt;
+    }
+    out[dim - 4] = (float)cnt;
+    p = out + 9 + PCAP_CARS * 7; cnt = 0;
+    for (i = 0; i < nObst; ++i) {
+      const Det* d = &obst[i];
+      if (d->seen == SIGHT_NONE || d->seen == SIGHT_MISCLASS) continue;
+      if (cnt >= PCAP_OBST) { overflow = 1; break; }
+      p[0] = (float)normalize(d->pos.x, P_NORM_X, 0.0); p[1] = (float)normalize(d->pos.y, P_NORM_Y, 0.0);
+      p[2] = (float)d->c; p[3] = (float)d->s;
+      p[4] = (float)normalize(d->w, P_NORM_W, 0.5); p[5] = (float)normalize(d->h, P_NORM_H, 0.5);
+      p += 6; ++cnt;
+    }
+    out[dim - 3] = (float)cnt;
+    p = out + 9 + PCAP_CARS * 7 + PCAP_OBST * 6; cnt = 0;
+    for (i = 0; i < nPeds; ++i) {
+      const Det* d = &peds[i];
+      if (d->seen == SIGHT_NONE) continue;
+      if (cnt >= PCAP_PEDS) { overflow = 1; break; }
+      p[0] = (float)normalize(d->pos.x, P_NORM_X, 0.0); p[1] = (float)normalize(d->pos.y, P_NORM_Y, 0.0);
+      p += 2; ++cnt;
+    }
+    out[dim - 2] = (float)cnt;
+    p = out + 9 + PCAP_CARS * 7 + PCAP_OBST * 6 + PCAP_PEDS * 2; cnt = 0;
+    for (i = 0; i < nLanes; ++i) {
+      const LaneDet* l = &lanes[i];
+      if (l->seen == SIGHT_NONE) continue;
+      if (cnt >= PCAP_LANES) { overflow = 1; break; }
+      p[0] = (float)l->dist; p[1] = (float)l->c; p[2] = (float)l->s; p[3] = (float)l->type;
+      p += 4; ++cnt;
+    }
+    out[dim - 1] = (float)cnt;
+  }
+  return overflow;
+}

@@ -29,13 +29,16 @@ int oracle_create(const dynenv_cfg_t* cfg, oracle_t** out) {
   o->cfg = *cfg;
   o->threads = 1;
   if (cfg->env_type == DYNENV_DRIVE) {
-    if (cfg->obs_type != DYNENV_OBS_FULL) { free(o); return DYNENV_ERR_UNSUPPORTED; }
+    if (cfg->obs_type != DYNENV_OBS_FULL && cfg->obs_type != DYNENV_OBS_PARTIAL) { free(o); return DYNENV_ERR_UNSUPPORTED; }
     o->n_agents = cfg->n_players > DYNENV_MAX_CARS ? DYNENV_MAX_CARS : cfg->n_players;
-    o->obs_dim = drv_obs_dim(o->n_agents);
+    o->obs_dim = cfg->obs_type == DYNENV_OBS_PARTIAL ? drv_partial_obs_dim() : drv_obs_dim(o->n_agents);
     o->n_time_steps = 1;
     o->action_dim = 2;
     o->drv = (DrivingEnv*)calloc((size_t)cfg->num_envs, sizeof(DrivingEnv));
-    for (i = 0; i < cfg->num_envs; ++i) drv_init(&o->drv[i], cfg->n_players, cfg->seed, (uint32_t)(cfg->env_id_offset + i));
+    for (i = 0; i < cfg->num_envs; ++i) {
+      drv_init(&o->drv[i], cfg->n_players, cfg->seed, (uint32_t)(cfg->env_id_offset + i));
+      o->drv[i].obsType = cfg->obs_type; o->drv[i].noiseType = cfg->noise_type; o->drv[i].noiseMagnitude = cfg->noise_magnitude;
+    }
   } else if (cfg->env_type == DYNENV_ROBO_CUP) {
     if (cfg->obs_type != DYNENV_OBS_FULL) { free(o); return DYNENV_ERR_UNSUPPORTED; }
     o->n_agents = 2 * (cfg->n_players > RC_MAX_PLAYERS ? RC_MAX_PLAYERS : cfg->n_players);
@@ -66,7 +69,17 @@ int oracle_layout(const oracle_t* o, dynenv_layout_t* L) {
   memset(L, 0, sizeof(*L));
   L->num_envs = o->cfg.num_envs; L->n_agents = A; L->n_time_steps = o->n_time_steps; L->obs_dim = o->obs_dim;
   L->action_dim = o->action_dim;
-  if (o->cfg.env_type == DYNENV_DRIVE) {
+  if (o->cfg.env_type == DYNENV_DRIVE && o->cfg.obs_type == DYNENV_OBS_PARTIAL) {
+    /* ((cars, obstacles, pedestrians), (self, lanes)) rows of getAgentVision + 4 row counts (DrivingEnvironment.py:977) */
+    L->n_blocks = 6;
+    L->block_offset[0] = 0; L->block_rows[0] = 1; L->block_feat[0] = 9;
+    L->block_offset[1] = 9; L->block_rows[1] = 24; L->block_feat[1] = 7;
+    L->block_offset[2] = 9 + 24 * 7; L->block_rows[2] = 32; L->block_feat[2] = 6;
+    L->block_offset[3] = L->block_offset[2] + 32 * 6; L->block_rows[3] = 40; L->block_feat[3] = 2;
+    L->block_offset[4] = L->block_offset[3] + 40 * 2; L->block_rows[4] = 16; L->block_feat[4] = 4;
+    L->block_offset[5] = L->block_offset[4] + 16 * 4; L->block_rows[5] = 1; L->block_feat[5] = 4;
+    L->steps_per_episode = DRV_MAX_TIME / DRV_STEP_ITER;
+  } else if (o->cfg.env_type == DYNENV_DRIVE) {
     L->n_blocks = 5;
     L->block_offset[0] = 0; L->block_rows[0] = 1; L->block_feat[0] = 9;
     L->block_offset[1] = 9; L->block_rows[1] = A - 1; L->block_feat[1] = 7;
@@ -91,7 +104,7 @@ int oracle_reset(oracle_t* o, float* obs) {
   for (e = 0; e < E; ++e) {
     if (o->drv) {
       drv_reset(&o->drv[e]);
-      if (obs) drv_write_full_obs(&o->drv[e], obs + e * stride);
+      if (obs) drv_write_obs(&o->drv[e], obs + e * stride);
     } else {
       int t;
       rc_reset(&o->rc[e]);
@@ -169,6 +182,15 @@ int oracle_overflow(oracle_t* o) {
   int e, f = 0;
   for (e = 0; e < o->cfg.num_envs; ++e) f |= o->drv ? o->drv[e].space.overflow : o->rc[e].space.overflow;
   return f;
+}
+int oracle_obs_overflow(oracle_t* o) {
+  int e, f = 0;
+  if (o->drv) for (e = 0; e < o->cfg.num_envs; ++e) f |= o->drv[e].obsOverflow;
+  return f;
+}
+void oracle_drv_vision(oracle_t* o, int env, int agent, float* out) {
+  DrivingEnv* d = &o->drv[env];
+  d->obsOverflow |= drv_agent_vision(d, agent, d->noiseType, d->noiseMagnitude, out);
 }
 int oracle_active_contacts(oracle_t* o, int32_t env) { return o->drv ? o->drv[env].space.n_active : o->rc[env].space.n_active; }
 
