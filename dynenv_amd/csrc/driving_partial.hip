@@ -1,0 +1,439 @@
+// driving_partial.hip — Driving PARTIAL observation + noise on gfx950 (BASELINE configs[3]).
+//
+// Replaces DrivingEnvironment.getAgentVision (reference DrivingEnvironment.py:750-977 with cutils.py isSeenInRadius /
+// doesInteractPoly / addNoiseRect / addNoiseLane and Road.getCarLaneDistances) for all agents of all environments.
+// One wavefront per environment, looping over the env's agents; for one agent the lanes are the OBJECTS it might see:
+//   lanes 0..9 cars (the agent's own lane builds the self row), 10..29 pedestrians, 30..49 obstacles, 50..53 buildings,
+//   54..59 the six lane rows; the ten random false-positive trials are evaluated by lanes 0..9 in a later phase.
+// Row positions inside the ragged lists (which also index the noise streams) come from wave ballots + popcounts.
+// Mirrors oracle/driving_partial.c operation by operation (bit-identical output); see that file for the RNG keying.
+#include "driving_dev.h"
+
+#define PV_CAP_CARS 24
+#define PV_CAP_OBST 32
+#define PV_CAP_PEDS 40
+#define PV_CAP_LANES 16
+#define PV_DIM (9 + PV_CAP_CARS * 7 + PV_CAP_OBST * 6 + PV_CAP_PEDS * 2 + PV_CAP_LANES * 4 + 4)
+#define PV_OFF_CARS 9
+#define PV_OFF_OBST (9 + PV_CAP_CARS * 7)
+#define PV_OFF_PEDS (PV_OFF_OBST + PV_CAP_OBST * 6)
+#define PV_OFF_LANES (PV_OFF_PEDS + PV_CAP_PEDS * 2)
+#define SIGHT_NONE 0
+#define SIGHT_NORMAL 3
+#define SIGHT_MISCLASS 4
+#define INTER_NONE 0
+#define INTER_NEARBY 1
+#define INTER_OCCLUDE 2
+#define PV_ANGLE_NOISE (DM_PI / 180.0)
+
+struct PvBlocker {  // an object as `elem2` of doesInteractPoly: view-blocking interval + the three decisive corners
+  double posx, posy, angle2, minA, maxA, p1x, p1y, p2x, p2y, pmx, pmy;
+  int seen, extreme;
+};
+struct PvLds {
+  double px[DRV_NB], py[DRV_NB], ang[DRV_NB];
+  double ox[DRV_MAXO], oy[DRV_MAXO];
+  int flags[DRV_NB];
+  PvBlocker blk[64];  // indexed by lane (cars 0..9, obstacles 30..49, buildings 50..53)
+  float row[PV_DIM + 3];  // the agent's dense row is assembled here, then streamed out with coalesced stores
+};
+__shared__ PvLds g_P;
+
+DE_DEV dm_u32x4 pv_rng(const DrvState& S, uint32_t genv, uint32_t episode, int elapsed, int agent, int kind, int index, int block) {
+  uint32_t entity = (uint32_t)agent | ((uint32_t)kind << 4) | ((uint32_t)index << 8) | ((uint32_t)block << 16);
+  return dm_env_rng(S.seed, genv, episode, DM_RNG_OBS_NOISE, entity, (uint32_t)elapsed);
+}
+DE_DEV double pv_normalize(double pt, double nf, double mean) { return ((pt * nf) - mean) * 2.0 * 1.0; }
+DE_DEV V2 pv_rotated(V2 v, double a) {
+  const DevSC sc = dev_sincos(a);
+  return v2(v.x * sc.c - v.y * sc.s, v.x * sc.s + v.y * sc.c);
+}
+DE_DEV double pv_lensq(V2 v) { return v.x * v.x + v.y * v.y; }
+
+// cutils.doesInteractPoly :643-696 with the blocker's interval precomputed (getViewBlockAngle :626-640)
+DE_DEV int pv_interact(int seen1, V2 point1, double angle1, const PvBlocker& b, double radius) {
+  int ret = INTER_NONE;
+  if (seen1 == SIGHT_NONE || b.seen == SIGHT_NONE) return ret;
+  const V2 point2 = v2(b.posx, b.posy);
+  if (radius > 0.0 && pv_lensq(vsub(point2, point1)) < radius) ret = INTER_NEARBY;
+  double pAngle = angle1 - b.angle2;
+  if (pAngle > DM_PI) pAngle -= DM_TWO_PI; else if (pAngle < -DM_PI) pAngle += DM_TWO_PI;
+  if (pAngle > b.minA && pAngle < b.maxA) {
+    const V2 p1 = v2(b.p1x, b.p1y), p2 = v2(b.p2x, b.p2y), pm = v2(b.pmx, b.pmy);
+    if (b.extreme) {
+      if (vcross(vsub(p2, p1), vsub(point1, p1)) < 0.0) ret = INTER_OCCLUDE;
+    } else if (vcross(vsub(p2, pm), vsub(point1, pm)) < 0.0 && vcross(vsub(pm, p1), vsub(point1, p1)) < 0.0) {
+      ret = INTER_OCCLUDE;
+    }
+  }
+  return ret;
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+drv_partial_obs_kernel(DrvState S, int noiseType, double magn, float* __restrict__ obs) {
+  PvLds& L = g_P;
+  const int e = blockIdx.x, lane = threadIdx.x, A = S.A;
+  const size_t E = (size_t)S.E;
+  int* envi = S.envi + (size_t)e * EI_COUNT;
+  const int nPed = uniform_i(envi[EI_NPED]), nObst = uniform_i(envi[EI_NOBST]), elapsed = uniform_i(envi[EI_ELAPSED]);
+  const uint32_t episode = (uint32_t)uniform_i(envi[EI_EPISODE]);
+  const uint32_t genv = (uint32_t)(S.env_id_offset + e);
+  if (lane < DRV_NB) {
+    const bool used = lane < A || (lane >= DRV_SLOT_PED && lane < DRV_SLOT_PED + nPed);
+    const double* b = S.body + (size_t)e * DRV_NB + lane;
+    L.px[lane] = used ? b[BF_PX * E * DRV_NB] : 0.0; L.py[lane] = used ? b[BF_PY * E * DRV_NB] : 0.0;
+    L.ang[lane] = used ? b[BF_ANG * E * DRV_NB] : 0.0;
+    L.flags[lane] = used ? S.flags[(size_t)e * DRV_NB + lane] : 0;
+  }
+  if (lane < DRV_MAXO) {
+    L.ox[lane] = lane < nObst ? S.obst[(size_t)e * DRV_MAXO + lane] : 0.0;
+    L.oy[lane] = lane < nObst ? S.obst[E * DRV_MAXO + (size_t)e * DRV_MAXO + lane] : 0.0;
+  }
+  __syncthreads();
+  const double randBase = 0.01 * magn;
+  const double maxVis0 = (DRV_W * 0.4) * (DRV_W * 0.4), maxVis1 = (DRV_W * 0.6) * (DRV_W * 0.6);
+  int overflow = 0;
+  // lane role (fixed over agents)
+  const bool isCarLane = lane < A;
+  const bool isPedLane = lane >= DRV_SLOT_PED && lane < DRV_SLOT_PED + nPed;
+  const bool isObsLane = lane >= DRV_SLOT_OBST && lane < DRV_SLOT_OBST + nObst;
+  const bool isBldLane = lane >= DRV_SLOT_BLD && lane < DRV_SLOT_BLD + 4;
+  const bool isLaneRow = lane >= 54 && lane < 60;
+  const uint64_t carLanes = wave_ballot(isCarLane), pedLanes = wave_ballot(isPedLane), obsLanes = wave_ballot(isObsLane);
+  (void)carLanes;
+
+#pragma unroll 1
+  for (int a = 0; a < A; ++a) {
+    float* __restrict__ grow = obs + ((size_t)e * A + a) * PV_DIM;
+    float* row = L.row;
+    for (int i = lane; i < PV_DIM; i += DE_WAVE) row[i] = 0.0f;
+    const V2 P = v2(L.px[a], L.py[a]);
+    const double ang = L.ang[a];
+    const int typeA = L.flags[a] & 3;
+
+    // ---- phase 1: detection of my object (isSeenInRadius) --------------------------------------------------
+    int seen = SIGHT_NONE;
+    V2 pos = v2(0.0, 0.0);
+    double dc = 0.0, ds = 0.0, dw = 0.0, dh = 0.0;
+    int dfin = 0;
+    bool hasCorners = false;
+    V2 cor[4];
+    cor[0] = cor[1] = cor[2] = cor[3] = v2(0.0, 0.0);
+    const bool isSelf = isCarLane && lane == a;
+    if (isCarLane || isPedLane || isObsLane || isBldLane) {
+      V2 point; double hx = 0.0, hy = 0.0, oangle = 0.0, maxD = maxVis0, distD = maxVis1;
+      if (isCarLane) {
+        const int f = L.flags[lane];
+        point = v2(L.px[lane], L.py[lane]); oangle = L.ang[lane];
+        hx = C.carHx[f & 3]; hy = C.carHy[f & 3];  // Car.points (h, w): h = length, w = width
+        dw = hy; dh = hx; dfin = CF_FIN(f);
+        hasCorners = true;
+      } else if (isPedLane) {
+        point = v2(L.px[lane], L.py[lane]);
+      } else if (isObsLane) {
+        point = v2(L.ox[lane - DRV_SLOT_OBST], L.oy[lane - DRV_SLOT_OBST]); hx = 10.0; hy = 10.0; dw = 10.0; dh = 10.0; hasCorners = true;
+      } else {
+        const int k = lane - DRV_SLOT_BLD;
+        point = v2((k & 2) ? 1385.0 : 365.0, (k & 1) ? 800.0 : 200.0); hx = 400.0; hy = 225.0; hasCorners = true;
+        maxD = 20000000.0; distD = 20000000.0;
+      }
+      if (isSelf) {  // selfDet :755-756: absolute position, own corners, never filtered
+        const DevSC sc = dev_sincos(ang);
+        seen = SIGHT_NORMAL; pos = P; dc = sc.c; ds = sc.s;
+        const double lx[4] = {hx, -hx, -hx, hx}, ly[4] = {hy, hy, -hy, -hy};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cor[i] = vadd(v2(lx[i], ly[i]), P);
+      } else {
+        const V2 trPt = vsub(point, P);
+        const double dist = pv_lensq(trPt);
+        if (dist <= maxD) {
+          seen = SIGHT_NORMAL;  // Distant is unreachable: maxDist < distantDist (quirk C17)
+          if (!(dist <= distD)) seen = 2;
+          if (hasCorners) {
+            const double lx[4] = {hx, -hx, -hx, hx}, ly[4] = {hy, hy, -hy, -hy};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cor[i] = vadd(vsub(vadd(v2(lx[i], ly[i]), point), point), trPt);
+          }
+          pos = pv_rotated(trPt, -ang);
+          const DevSC sc = dev_sincos(oangle - ang);
+          dc = sc.c; ds = sc.s;
+        }
+      }
+    }
+    // ---- lane rows: Road.getCarLaneDistances :36-71 (rows 0..3 road 0, rows 4..5 road 1) ---------------------
+    double ldist = 0.0, lc = 0.0, ls = 0.0, ltype = 0.0;
+    int lseen = SIGHT_NONE;
+    if (isLaneRow) {
+      const int rowi = lane - 54;
+      const int r = rowi < 4 ? 0 : 1;
+      const int n = r ? 1 : 2;
+      const int i = (rowi - (r ? 4 : 0)) - n;
+      const V2 pt = vsub(P, C.roads[r].p0);
+      const double dist = vcross(C.roads[r].dir, pt) / C.roads[r].width;
+      if (!(dm_abs(dist) > 10.0)) {
+        const DevSC sc = dev_sincos(C.roads[r].dirAngle - ang);
+        double cc = sc.c, ss = sc.s, distMult = 1.0, typeMult = 1.0;
+        if (cc >= 0.0) { typeMult = -1.0; cc *= -1.0; ss *= -1.0; distMult = -1.0; }
+        lseen = SIGHT_NORMAL;
+        ldist = ((dist + 0.5) + (double)i) * C.roads[r].width * 0.1 * distMult;
+        lc = cc; ls = ss;
+        ltype = ((i + n) < n ? 1.0 : -1.0) * typeMult;
+      }
+    }
+    // ---- phase 2: publish blockers (cars other than self, obstacles, buildings) ------------------------------
+    const double angle1 = (seen != SIGHT_NONE && !isSelf && (isCarLane || isPedLane || isObsLane || isBldLane)) ? dev_atan2(pos.y, pos.x) : 0.0;
+    if ((isCarLane && !isSelf) || isObsLane || isBldLane) {
+      PvBlocker b;
+      b.seen = seen; b.posx = pos.x; b.posy = pos.y; b.angle2 = angle1;
+      b.minA = b.maxA = 0.0; b.p1x = b.p1y = b.p2x = b.p2y = b.pmx = b.pmy = 0.0; b.extreme = 0;
+      if (seen != SIGHT_NONE) {
+        double angs[4], dsts[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { angs[i] = dev_atan2(cor[i].y, cor[i].x) - angle1; dsts[i] = pv_lensq(cor[i]); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (angs[i] > DM_PI) angs[i] -= DM_TWO_PI;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (angs[i] < -DM_PI) angs[i] += DM_TWO_PI;
+        int mn = 0, mx = 0, ci = 0;
+        double amin = angs[0], amax = angs[0], dmin = dsts[0];
+#pragma unroll
+        for (int i = 1; i < 4; ++i) {
+          if (angs[i] < amin) { amin = angs[i]; mn = i; }
+          if (angs[i] > amax) { amax = angs[i]; mx = i; }
+          if (dsts[i] < dmin) { dmin = dsts[i]; ci = i; }
+        }
+        const V2 p1 = sel4(cor, mn), p2 = sel4(cor, mx), pm = sel4(cor, ci);
+        b.minA = amin; b.maxA = amax; b.p1x = p1.x; b.p1y = p1.y; b.p2x = p2.x; b.p2y = p2.y; b.pmx = pm.x; b.pmy = pm.y;
+        b.extreme = (ci == mn || ci == mx) ? 1 : 0;
+      }
+      L.blk[lane] = b;
+    }
+    __syncthreads();
+    // ---- phase 3: building occlusion :782-789, then list positions ------------------------------------------
+    const bool isObj = (isCarLane && !isSelf) || isPedLane || isObsLane;
+    bool alive = isObj && seen != SIGHT_NONE;
+    if (alive) {
+      int m = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { int t = pv_interact(seen, pos, angle1, L.blk[DRV_SLOT_BLD + k], 0.0); m = t > m ? t : m; }
+      if (m == INTER_OCCLUDE) alive = false;
+    }
+    const uint64_t aliveMask = wave_ballot(alive);
+    const uint64_t carMask = aliveMask & ((1ull << DRV_SLOT_PED) - 1ull);
+    const uint64_t pedMask = aliveMask & pedLanes;
+    const uint64_t obsMask = aliveMask & obsLanes;
+    const uint64_t laneAlive = wave_ballot(isLaneRow && lseen != SIGHT_NONE);
+    const int nCars0 = __popcll(carMask), nObst0 = __popcll(obsMask), nPeds0 = __popcll(pedMask);
+    const int nLanes0 = __popcll(laneAlive);
+    const uint64_t below = lanemask_lt();
+    int listIdx = 0;
+    if (alive) listIdx = isCarLane ? __popcll(carMask & below) : (isPedLane ? __popcll(pedMask & below) : __popcll(obsMask & below));
+    if (isLaneRow) listIdx = __popcll(laneAlive & below);
+    // ---- phase 4: pedestrian interactions :792-801 ----------------------------------------------------------
+    int pedInter = INTER_NONE;
+    {
+      int carPed = INTER_NONE, obsPed = INTER_NONE;
+      if (alive && isPedLane) {
+        for (uint64_t mm = carMask; mm; mm &= mm - 1) { int t = pv_interact(seen, pos, angle1, L.blk[__builtin_ctzll(mm)], 400.0); carPed = t > carPed ? t : carPed; }
+        for (uint64_t mm = obsMask; mm; mm &= mm - 1) { int t = pv_interact(seen, pos, angle1, L.blk[__builtin_ctzll(mm)], 400.0); obsPed = t > obsPed ? t : obsPed; }
+      }
+      // pedInter = max(carPedInter, obsPedInter): Python LIST comparison -> first differing pedestrian decides (C12)
+      const uint64_t diff = wave_ballot(alive && isPedLane && carPed != obsPed);
+      bool useObs = false;
+      if (diff) {
+        const int first = __builtin_ctzll(diff);
+        useObs = bcast_i(obsPed, first) > bcast_i(carPed, first);
+      }
+      pedInter = useObs ? obsPed : carPed;
+      if (alive && isPedLane && pedInter == INTER_OCCLUDE) seen = SIGHT_NONE;  // filterOcclude (row stays in the list)
+    }
+    // ---- phase 5: noise (addNoiseRect :479-542 on self / cars / pedestrians / obstacles; addNoiseLane :382-413) ---
+    if ((alive || isSelf) && seen != SIGHT_NONE) {
+      const int kind = isSelf ? 0 : (isCarLane ? 1 : (isPedLane ? 2 : 3));
+      const int idx = isSelf ? 0 : listIdx;
+      const bool misClass = (isCarLane && !isSelf) || isObsLane;
+      const double maxDist = isPedLane ? maxVis0 : maxVis1;
+      const dm_u32x4 u = pv_rng(S, genv, episode, elapsed, a, kind, idx, 0), u1 = pv_rng(S, genv, episode, elapsed, a, kind, idx, 1);
+      const V2 noiseVec = v2((dm_unit(u.v[0]) - 0.5) * magn, (dm_unit(u.v[1]) - 0.5) * magn);
+      if (noiseType == 0) {  // NoiseType.RANDOM
+        if (dm_unit(u.v[2]) < randBase) {
+          seen = SIGHT_NONE;
+        } else {
+          const V2 newPos = vadd(pos, noiseVec);
+          const double angleDiff = (dm_unit(u1.v[0]) - 0.5) * magn * PV_ANGLE_NOISE;
+          const DevSC sc = dev_sincos(dev_atan2(ds, dc) + angleDiff);
+          dc = sc.c; ds = sc.s;
+          pos = newPos;
+        }
+      } else {
+        const double range = 0.25 + 3.75 * vlen(pos) / maxDist;  // C18
+        double multiplier = range;
+        if (pedInter == INTER_NEARBY && isPedLane) multiplier = range * 2.0;
+        if (seen == 2) multiplier = range * 3.0;
+        const V2 newPos = vadd(pos, vmul(noiseVec, multiplier));
+        if (dm_unit(u.v[2]) < randBase * multiplier) {
+          seen = SIGHT_NONE;
+        } else {
+          if (misClass && dm_unit(u.v[3]) < randBase * multiplier / 2.0) seen = SIGHT_MISCLASS;
+          const double angleDiff = (dm_unit(u1.v[0]) - 0.5) * magn * PV_ANGLE_NOISE * 0.25;
+          const DevSC sc = dev_sincos(dev_atan2(ds, dc) + angleDiff);
+          dc = sc.c; ds = sc.s;
+          pos = newPos;
+        }
+      }
+    }
+    if (isLaneRow && lseen != SIGHT_NONE) {
+      const dm_u32x4 u = pv_rng(S, genv, episode, elapsed, a, 4, listIdx, 0);
+      const double distNoise = (dm_unit(u.v[0]) - 0.5) * magn, angleDiff = (dm_unit(u.v[1]) - 0.5) * magn;
+      double angl;
+      if (noiseType == 0) {
+        if (dm_unit(u.v[2]) < randBase) lseen = SIGHT_NONE;
+        ldist *= distNoise;  // C19
+        angl = dev_atan2(ls, lc);
+        angl += PV_ANGLE_NOISE * angleDiff;
+      } else {
+        const double multiplier1 = 0.25 + 3.75 * ldist * ldist / maxVis1;
+        if (dm_unit(u.v[2]) < randBase * multiplier1) lseen = SIGHT_NONE;
+        ldist += distNoise * multiplier1;
+        angl = dev_atan2(ls, lc);
+        angl += PV_ANGLE_NOISE * multiplier1 / 5.0 * angleDiff;
+      }
+      const DevSC sc = dev_sincos(angl);
+      lc = sc.c; ls = sc.s;
+    }
+    // ---- phase 6: random false positives :824-874, evaluated by lanes 0..9 (trial = lane) ---------------------
+    int fpClass = -1;
+    V2 fpPos = v2(0.0, 0.0);
+    double fpc = 0.0, fps = 0.0, fpw = 0.0, fph = 0.0, fpLaneDist = 0.0, fpLaneType = 0.0;
+    if (lane < 10) {
+      const dm_u32x4 u = pv_rng(S, genv, episode, elapsed, a, 5, lane, 0), u1 = pv_rng(S, genv, episode, elapsed, a, 5, lane, 1);
+      if (dm_unit(u.v[0]) < randBase) {
+        fpClass = dm_randint(u.v[1], 0, 5);
+        const double d = dm_unit(u.v[2]) * maxVis1;
+        const double a1 = dm_unit(u.v[3]) * 2.0 * DM_PI;
+        fpPos = pv_rotated(v2(d, 0.0), a1);
+        const DevSC sc = dev_sincos(dm_unit(u1.v[0]) * 2.0 * DM_PI);
+        fpc = sc.c; fps = sc.s;
+        if (fpClass <= 1) { fpw = dm_unit(u1.v[1]) * 5.0 + 5.0; fph = dm_unit(u1.v[2]) * 10.0 + 5.0; }
+        else if (fpClass == 3) {
+          const DevSC lsc = dev_sincos((dm_unit(u1.v[1]) - 0.5) * DM_PI * 2.0);
+          fpc = lsc.c; fps = lsc.s;
+          fpLaneDist = __builtin_floor(dm_unit(u1.v[2]) * DRV_W / 2.0);
+          fpLaneType = (double)dm_randint(u1.v[3], -1, 1);
+        }
+      }
+    }
+    // ---- phase 7: list assembly (misclassification swap :816-821, FP pedestrians near cars :877-882, final filter) ---
+    // A lane can hold a real object AND a random-FP trial (lanes 0..9): the two are handled by independent code paths.
+    const bool realCar = alive && isCarLane, realObs = alive && isObsLane, realPed = alive && isPedLane;
+    const uint64_t misCarMask = wave_ballot(realCar && seen == SIGHT_MISCLASS);   // cars -> appended to obstacles
+    const uint64_t misObsMask = wave_ballot(realObs && seen == SIGHT_MISCLASS);   // obstacles -> appended to cars
+    const uint64_t fpCarMask = wave_ballot(fpClass == 0), fpObsMask = wave_ballot(fpClass == 1);
+    const uint64_t fpPedMask = wave_ballot(fpClass == 2), fpLaneMask = wave_ballot(fpClass == 3);
+    const uint64_t outCarReal = wave_ballot(realCar && seen == SIGHT_NORMAL);
+    const uint64_t outObsReal = wave_ballot(realObs && seen == SIGHT_NORMAL);
+    const uint64_t outPedReal = wave_ballot(realPed && seen != SIGHT_NONE);
+    const uint64_t outLaneReal = wave_ballot(isLaneRow && lseen != SIGHT_NONE);
+    // FP pedestrians near the entries of the reference's carDets list (positions BEFORE the final filter):
+    //   real cars keep their slot, misclassified obstacles are appended next, then the random-FP cars
+    bool genA = false, genB = false;  // A: from my real object (car or misclassified obstacle), B: from my FP car
+    V2 genPosA = v2(0.0, 0.0), genPosB = v2(0.0, 0.0);
+    if (noiseType == 1) {
+      int idxA = -1;
+      if (realCar && seen == SIGHT_NORMAL) idxA = listIdx;
+      else if (realObs && seen == SIGHT_MISCLASS) idxA = nCars0 + __popcll(misObsMask & below);
+      if (idxA >= 0) {
+        const dm_u32x4 u = pv_rng(S, genv, episode, elapsed, a, 6, idxA, 0);
+        if (dm_unit(u.v[0]) < randBase * 10.0 && vlen(pos) < 250.0) {
+          genA = true;
+          genPosA = vadd(pos, vmul(v2(2.0 * dm_unit(u.v[1]) - 1.0, 2.0 * dm_unit(u.v[2]) - 1.0), 10.0));
+        }
+      }
+      if (fpClass == 0) {
+        const int idxB = nCars0 + __popcll(misObsMask) + __popcll(fpCarMask & below);
+        const dm_u32x4 u = pv_rng(S, genv, episode, elapsed, a, 6, idxB, 0);
+        if (dm_unit(u.v[0]) < randBase * 10.0 && vlen(fpPos) < 250.0) {
+          genB = true;
+          genPosB = vadd(fpPos, vmul(v2(2.0 * dm_unit(u.v[1]) - 1.0, 2.0 * dm_unit(u.v[2]) - 1.0), 10.0));
+        }
+      }
+    }
+    const uint64_t genReal = wave_ballot(genA && realCar), genMis = wave_ballot(genA && realObs), genFp = wave_ballot(genB);
+    const int nOutCars = __popcll(outCarReal) + __popcll(misObsMask) + __popcll(fpCarMask);
+    const int nOutObst = __popcll(outObsReal) + __popcll(misCarMask) + __popcll(fpObsMask);
+    const int nOutPeds = __popcll(outPedReal) + __popcll(fpPedMask) + __popcll(genReal) + __popcll(genMis) + __popcll(genFp);
+    const int nOutLanes = __popcll(outLaneReal) + __popcll(fpLaneMask);
+    __syncthreads();  // row buffer zero-filled
+#define PV_PUT_CAR(P_, q_, c_, s_, w_, h_, fin_)                                                                         \
+  do {                                                                                                                  \
+    if ((P_) < PV_CAP_CARS) {                                                                                           \
+      float* o = row + PV_OFF_CARS + (P_)*7;                                                                            \
+      o[0] = (float)pv_normalize((q_).x, (5.0 * 2.0 / DRV_W), 0.0); o[1] = (float)pv_normalize((q_).y, (5.0 * 2.0 / DRV_H), 0.0);     \
+      o[2] = (float)(c_); o[3] = (float)(s_);                                                                           \
+      o[4] = (float)pv_normalize((w_), 1.0 / 7.5, 0.5); o[5] = (float)pv_normalize((h_), 1.0 / 15.0, 0.5); o[6] = (fin_); \
+    } else overflow = 1;                                                                                                \
+  } while (0)
+#define PV_PUT_OBS(P_, q_, c_, s_, w_, h_)                                                                               \
+  do {                                                                                                                  \
+    if ((P_) < PV_CAP_OBST) {                                                                                           \
+      float* o = row + PV_OFF_OBST + (P_)*6;                                                                            \
+      o[0] = (float)pv_normalize((q_).x, (5.0 * 2.0 / DRV_W), 0.0); o[1] = (float)pv_normalize((q_).y, (5.0 * 2.0 / DRV_H), 0.0);     \
+      o[2] = (float)(c_); o[3] = (float)(s_);                                                                           \
+      o[4] = (float)pv_normalize((w_), 1.0 / 7.5, 0.5); o[5] = (float)pv_normalize((h_), 1.0 / 15.0, 0.5);              \
+    } else overflow = 1;                                                                                                \
+  } while (0)
+#define PV_PUT_PED(P_, q_)                                                                                               \
+  do {                                                                                                                  \
+    if ((P_) < PV_CAP_PEDS) {                                                                                           \
+      float* o = row + PV_OFF_PEDS + (P_)*2;                                                                            \
+      o[0] = (float)pv_normalize((q_).x, (5.0 * 2.0 / DRV_W), 0.0); o[1] = (float)pv_normalize((q_).y, (5.0 * 2.0 / DRV_H), 0.0);     \
+    } else overflow = 1;                                                                                                \
+  } while (0)
+    // --- cars block: surviving real cars, misclassified obstacles, random-FP cars
+    if (realCar && seen == SIGHT_NORMAL) { const int p = __popcll(outCarReal & below); PV_PUT_CAR(p, pos, dc, ds, dw, dh, (float)dfin); }
+    if (realObs && seen == SIGHT_MISCLASS) { const int p = __popcll(outCarReal) + __popcll(misObsMask & below); PV_PUT_CAR(p, pos, dc, ds, dw, dh, 0.0f); }
+    if (fpClass == 0) { const int p = __popcll(outCarReal) + __popcll(misObsMask) + __popcll(fpCarMask & below); PV_PUT_CAR(p, fpPos, fpc, fps, fpw, fph, 0.0f); }
+    // --- obstacles block: surviving real obstacles, misclassified cars, random-FP obstacles
+    if (realObs && seen == SIGHT_NORMAL) { const int p = __popcll(outObsReal & below); PV_PUT_OBS(p, pos, dc, ds, dw, dh); }
+    if (realCar && seen == SIGHT_MISCLASS) { const int p = __popcll(outObsReal) + __popcll(misCarMask & below); PV_PUT_OBS(p, pos, dc, ds, dw, dh); }
+    if (fpClass == 1) { const int p = __popcll(outObsReal) + __popcll(misCarMask) + __popcll(fpObsMask & below); PV_PUT_OBS(p, fpPos, fpc, fps, fpw, fph); }
+    // --- pedestrians block: real, random FP (class 2), then the FP pedestrians near cars in car-list order
+    if (realPed && seen != SIGHT_NONE) { const int p = __popcll(outPedReal & below); PV_PUT_PED(p, pos); }
+    if (fpClass == 2) { const int p = __popcll(outPedReal) + __popcll(fpPedMask & below); PV_PUT_PED(p, fpPos); }
+    {
+      const int base = __popcll(outPedReal) + __popcll(fpPedMask);
+      if (genA) {
+        const int g = realCar ? __popcll(genReal & below) : __popcll(genReal) + __popcll(genMis & below);
+        PV_PUT_PED(base + g, genPosA);
+      }
+      if (genB) { const int g = __popcll(genReal) + __popcll(genMis) + __popcll(genFp & below); PV_PUT_PED(base + g, genPosB); }
+    }
+    // --- lanes block
+    if (isLaneRow && lseen != SIGHT_NONE) {
+      const int p = __popcll(outLaneReal & below);
+      if (p < PV_CAP_LANES) { float* o = row + PV_OFF_LANES + p * 4; o[0] = (float)ldist; o[1] = (float)lc; o[2] = (float)ls; o[3] = (float)ltype; } else overflow = 1;
+    }
+    if (fpClass == 3) {
+      const int p = __popcll(outLaneReal) + __popcll(fpLaneMask & below);
+      if (p < PV_CAP_LANES) { float* o = row + PV_OFF_LANES + p * 4; o[0] = (float)fpLaneDist; o[1] = (float)fpc; o[2] = (float)fps; o[3] = (float)fpLaneType; } else overflow = 1;
+    }
+    // --- self row + counts
+    if (isSelf) {
+      row[0] = (float)pv_normalize(pos.x, (5.0 * 2.0 / DRV_W), 5.0); row[1] = (float)pv_normalize(pos.y, (5.0 * 2.0 / DRV_H), 5.0);
+      row[2] = (float)dc; row[3] = (float)ds;
+      row[4] = (float)pv_normalize(C.carHy[typeA], 1.0 / 7.5, 0.5); row[5] = (float)pv_normalize(C.carHx[typeA], 1.0 / 15.0, 0.5);
+      const double gx = S.carx[CF_GOALX * E * 16 + (size_t)e * 16 + a], gy = S.carx[CF_GOALY * E * 16 + (size_t)e * 16 + a];
+      row[6] = (float)pv_normalize(gx, (5.0 * 2.0 / DRV_W), 5.0); row[7] = (float)pv_normalize(gy, (5.0 * 2.0 / DRV_H), 5.0);
+      row[8] = (float)CF_FIN(L.flags[a]);
+      row[PV_DIM - 4] = (float)(nOutCars < PV_CAP_CARS ? nOutCars : PV_CAP_CARS);
+      row[PV_DIM - 3] = (float)(nOutObst < PV_CAP_OBST ? nOutObst : PV_CAP_OBST);
+      row[PV_DIM - 2] = (float)(nOutPeds < PV_CAP_PEDS ? nOutPeds : PV_CAP_PEDS);
+      row[PV_DIM - 1] = (float)(nOutLanes < PV_CAP_LANES ? nOutLanes : PV_CAP_LANES);
+    }
+    __syncthreads();
+    for (int i = lane; i < PV_DIM; i += DE_WAVE) grow[i] = row[i];
+    (void)nObst0; (void)nPeds0; (void)nLanes0;
+    __syncthreads();
+  }
+  if (wave_ballot(overflow != 0) && lane == 0) envi[EI_ERR] = envi[EI_ERR] | 2;
+}

@@ -12,6 +12,7 @@
 
 #include "driving_kernels.hip"
 #include "robocup_kernels.hip"
+#include "driving_partial.hip"
 #include "dynenv.h"
 
 static thread_local std::string g_err;
@@ -32,6 +33,7 @@ struct dynenv {
   DrvState S;
   RcState R;
   bool robocup;
+  bool partial;
   std::vector<void*> allocs;
 };
 
@@ -292,10 +294,12 @@ int dynenv_create(const dynenv_cfg_t* cfg, dynenv_t** out) {
   if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(DYNENV_ERR_ARG, "device_id out of range");
   HIP_OK(hipSetDevice(cfg->device_id));
   if (cfg->env_type != DYNENV_DRIVE && cfg->env_type != DYNENV_ROBO_CUP) return fail(DYNENV_ERR_ARG, "unknown env_type");
-  if (cfg->obs_type != DYNENV_OBS_FULL) return fail(DYNENV_ERR_UNSUPPORTED, "only Full observations are built");
+  if (cfg->obs_type != DYNENV_OBS_FULL && !(cfg->obs_type == DYNENV_OBS_PARTIAL && cfg->env_type == DYNENV_DRIVE))
+    return fail(DYNENV_ERR_UNSUPPORTED, "Partial observations are built for Driving only; Image observations are out of scope");
   dynenv* h = new dynenv();
   h->cfg = *cfg;
   h->robocup = cfg->env_type == DYNENV_ROBO_CUP;
+  h->partial = false;
   if (h->robocup) {
     int rc = rc_create(h);
     if (rc) { dynenv_destroy(h); return rc; }
@@ -303,13 +307,14 @@ int dynenv_create(const dynenv_cfg_t* cfg, dynenv_t** out) {
     return DYNENV_OK;
   }
   h->A = cfg->n_players > DRV_MAXA ? DRV_MAXA : cfg->n_players;  // environment_base.py:57
-  h->obs_dim = 9 + (h->A - 1) * 7 + DRV_MAXO * 4 + DRV_MAXP * 2 + DRV_LANE_ROWS * 5;
+  h->partial = cfg->obs_type == DYNENV_OBS_PARTIAL;
+  h->obs_dim = h->partial ? PV_DIM : 9 + (h->A - 1) * 7 + DRV_MAXO * 4 + DRV_MAXP * 2 + DRV_LANE_ROWS * 5;
   h->T = 1;
   h->action_dim = 2;
   DrvState& S = h->S;
   memset(&S, 0, sizeof(S));
   const size_t E = (size_t)cfg->num_envs;
-  S.E = (int)E; S.A = h->A; S.obs_dim = h->obs_dim; S.seed = cfg->seed; S.env_id_offset = cfg->env_id_offset;
+  S.E = (int)E; S.A = h->A; S.obs_dim = h->partial ? 9 + (h->A - 1) * 7 + DRV_MAXO * 4 + DRV_MAXP * 2 + DRV_LANE_ROWS * 5 : h->obs_dim; S.seed = cfg->seed; S.env_id_offset = cfg->env_id_offset;
   int rc = 0;
   rc |= dev_alloc(h, &S.body, (size_t)BF_COUNT * E * DRV_NB);
   rc |= dev_alloc(h, &S.carx, (size_t)CF_COUNT * E * 16);
@@ -357,6 +362,17 @@ int dynenv_layout(const dynenv_t* h, dynenv_layout_t* L) {
     L->steps_per_episode = RC_MAX_TIME / 50;
     return DYNENV_OK;
   }
+  if (h->partial) {  // ((cars, obstacles, pedestrians), (self, lanes)) of getAgentVision + the 4 row counts
+    L->n_blocks = 6;
+    L->block_offset[0] = 0; L->block_rows[0] = 1; L->block_feat[0] = 9;
+    L->block_offset[1] = PV_OFF_CARS; L->block_rows[1] = PV_CAP_CARS; L->block_feat[1] = 7;
+    L->block_offset[2] = PV_OFF_OBST; L->block_rows[2] = PV_CAP_OBST; L->block_feat[2] = 6;
+    L->block_offset[3] = PV_OFF_PEDS; L->block_rows[3] = PV_CAP_PEDS; L->block_feat[3] = 2;
+    L->block_offset[4] = PV_OFF_LANES; L->block_rows[4] = PV_CAP_LANES; L->block_feat[4] = 4;
+    L->block_offset[5] = PV_DIM - 4; L->block_rows[5] = 1; L->block_feat[5] = 4;
+    L->steps_per_episode = DRV_MAX_TIME / 10;
+    return DYNENV_OK;
+  }
   L->n_blocks = 5;
   L->block_offset[0] = 0; L->block_rows[0] = 1; L->block_feat[0] = 9;
   L->block_offset[1] = 9; L->block_rows[1] = A - 1; L->block_feat[1] = 7;
@@ -388,7 +404,10 @@ int dynenv_reset(dynenv_t* h, float* obs_dev, void* stream) {
   }
   int E = h->S.E;
   hipLaunchKernelGGL(drv_reset_kernel, dim3((E + 63) / 64), dim3(64), 0, st, h->S);
-  if (obs_dev) hipLaunchKernelGGL(drv_obs_kernel, dim3(E), dim3(64), 0, st, h->S, obs_dev);
+  if (obs_dev && h->partial)
+    hipLaunchKernelGGL(drv_partial_obs_kernel, dim3(E), dim3(64), 0, st, h->S, (int)h->cfg.noise_type, h->cfg.noise_magnitude, obs_dev);
+  else if (obs_dev)
+    hipLaunchKernelGGL(drv_obs_kernel, dim3(E), dim3(64), 0, st, h->S, obs_dev);
   HIP_OK(hipGetLastError());
   return DYNENV_OK;
 }
@@ -402,8 +421,10 @@ int dynenv_step(dynenv_t* h, const int32_t* actions_dev, float* obs_dev, double*
     HIP_OK(hipGetLastError());
     return DYNENV_OK;
   }
-  hipLaunchKernelGGL(drv_step_kernel, dim3(h->S.E), dim3(64), 0, st, h->S, (const int*)actions_dev, obs_dev, rewards_dev,
-                     dones_dev);
+  hipLaunchKernelGGL(drv_step_kernel, dim3(h->S.E), dim3(64), 0, st, h->S, (const int*)actions_dev, h->partial ? (float*)nullptr : obs_dev,
+                     rewards_dev, dones_dev);
+  if (h->partial && obs_dev)  // getAgentVision for every agent (DrivingEnvironment.py:294), a second launch on the same stream
+    hipLaunchKernelGGL(drv_partial_obs_kernel, dim3(h->S.E), dim3(64), 0, st, h->S, (int)h->cfg.noise_type, h->cfg.noise_magnitude, obs_dev);
   HIP_OK(hipGetLastError());
   return DYNENV_OK;
 }

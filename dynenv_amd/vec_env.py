@@ -283,6 +283,18 @@ class BatchedDynEnv(object):
                         out[e, t, a, 1] = [r[4:12].reshape(1, 8).copy(), ]
                         out[e, t, a, 2] = (1, 1, 1)
             return out
+        if self.observationType == ObservationType.PARTIAL:  # ragged rows of getAgentVision, lengths in the last 4 floats
+            for e in range(E):
+                for t in range(T):
+                    for a in range(A):
+                        r = o[e, t, a]
+                        nc, no, npd, nl = (int(x) for x in r[-4:])
+                        out[e, t, a, 0] = [r[off[1]:off[1] + nc * 7].reshape(nc, 7).copy(),
+                                           r[off[2]:off[2] + no * 6].reshape(no, 6).copy(),
+                                           r[off[3]:off[3] + npd * 2].reshape(npd, 2).copy()]
+                        out[e, t, a, 1] = [r[0:9].reshape(1, 9).copy(), r[off[4]:off[4] + nl * 4].reshape(nl, 4).copy()]
+                        out[e, t, a, 2] = (1, 1, 1)
+            return out
         for e in range(E):
             n_obst, n_ped = int(counts[e, 0]), int(counts[e, 1])
             for t in range(T):
@@ -311,6 +323,10 @@ class BatchedDynEnv(object):
                               r[12:12 + (A - 1) * 6].reshape(A - 1, 6).copy()])
             return recon[0], recon  # (the reference's agent=None variant is un-normalised; not reproduced)
         n_obst, n_ped = int(counts[e, 0]), int(counts[e, 1])
+        if self.observationType == ObservationType.PARTIAL:
+            # info['Full State'] needs the noise-free full state, which the Partial launch does not emit (only the
+            # out-of-scope reconstruction losses of the reference's trainer consume it)
+            return None, None
         recon = []
         for a in range(A):
             r = obs_np[e, -1, a]

@@ -298,3 +298,47 @@ def test_robocup_step_parity(gpu, n, E, seed, steps, flags):
         for g, o in zip([x.cpu().numpy() for x in env.episode_stats()], ora.episode_stats()):
             np.testing.assert_array_equal(g, o)
     env.close()
+
+
+# ------------------------------------------------------------------------------------------------ Driving Partial (configs[3])
+@pytest.mark.parametrize("noise_type,magn,E,steps", [(1, 3.0, 32, 40), (0, 3.0, 8, 20), (1, 0.0, 8, 20), (1, 5.0, 16, 60)])
+def test_driving_partial_obs_parity(gpu, noise_type, magn, E, steps):
+    """configs[3]: Driving nPlayers=10, Partial obs, Realistic noise magnitude 3 (+ RANDOM noise, no noise, max noise):
+    the ragged getAgentVision rows (dense padded + counts) are bit-identical to the oracle."""
+    dynenv_amd, _, _ = gpu
+    from dynenv_amd import NoiseType, ObservationType
+    env = dynenv_amd.BatchedDynEnv(dynenv_amd.DynEnvType.DRIVE, E, 10, observationType=ObservationType.PARTIAL,
+                                   noiseType=NoiseType(noise_type), noiseMagnitude=magn, seed=42)
+    ora = ol.OracleEnv(env_type=1, num_envs=E, n_players=10, obs_type=1, noise_type=noise_type, noise_magnitude=magn,
+                       seed=42, threads=8)
+    assert env.obs_dim == ora.D == 517
+    og = env.reset_flat().cpu().numpy()
+    oc = ora.reset()
+    np.testing.assert_array_equal(og, oc, err_msg="reset obs")
+    rng = np.random.default_rng(1)
+    rows = np.zeros(4)
+    for s in range(steps):
+        a = rng.integers(0, 3, size=(E, 10, 2)).astype(np.int32)
+        og, rg, dg = env.step_flat(a, auto_reset=False)
+        oc, rc, dc = ora.step(a)
+        og = og.cpu().numpy()
+        bad = np.argwhere(og != oc)
+        assert len(bad) == 0, "obs step %d first mismatch at %s: %r vs %r" % (s, bad[0], og[tuple(bad[0])], oc[tuple(bad[0])])
+        np.testing.assert_array_equal(rg.cpu().numpy(), rc)
+        rows += oc[..., -4:].reshape(-1, 4).sum(0)
+    assert env.error_flags() == 0 and ora.l.oracle_obs_overflow(ora.h) == 0
+    assert (rows > 0).all()
+    env.close()
+
+
+def test_partial_compat_view(gpu):
+    dynenv_amd, _, _ = gpu
+    from dynenv_amd import DynEnvType, NoiseType, ObservationType, make_dyn_env
+    venv, name = make_dyn_env(DynEnvType.DRIVE, 2, 10, False, ObservationType.PARTIAL, NoiseType.REALISTIC, 3, False)
+    obs = venv.reset()
+    cars, obst, peds = obs[0, 0, 0, 0]
+    selfr, lanes = obs[0, 0, 0, 1]
+    assert cars.shape[1] == 7 and obst.shape[1] == 6 and peds.shape[1] == 2 and selfr.shape == (1, 9) and lanes.shape[1] == 4
+    obs, rew, dones, infos = venv.step(np.ones((2, 10, 2), np.int64))
+    assert obs.shape == (2, 1, 10, 3)
+    venv.close()
