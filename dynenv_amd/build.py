@@ -7,7 +7,8 @@ ROOT = os.path.dirname(PKG)
 LIB = os.path.join(PKG, "libdynenv_hip.so")
 SRC = os.path.join(PKG, "csrc", "dynenv_capi.hip")
 DEPS = [os.path.join(PKG, "csrc", f) for f in
-        ("dynenv_capi.hip", "driving_kernels.hip", "driving_dev.h", "dev_common.h")] + \
+        ("dynenv_capi.hip", "driving_kernels.hip", "driving_partial.hip", "robocup_kernels.hip", "driving_dev.h",
+         "robocup_dev.h", "dev_common.h")] + \
        [os.path.join(ROOT, "include", f) for f in ("dynenv.h", "dynenv_math.h")]
 
 
@@ -18,20 +19,21 @@ def needs_build():
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in DEPS)
 
 
-def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950, FMA contraction off (bit-exact parity with the oracle)."""
-    if not force and not needs_build():
+def build(force=False, verbose=False, out=None, defines=()):
+    """hipcc --offload-arch=gfx950, FMA contraction off (bit-exact parity with the oracle).
+    `out` / `defines` build an instrumented variant next to the product library (e.g. -DDRV_PROFILE)."""
+    if out is None and not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
            "-std=c++17", "-Wno-unused-value", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc"),
-           "-o", LIB, SRC]
+           "-o", out or LIB, SRC] + ["-D" + d for d in defines]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    return LIB
+    return out or LIB
 
 
 if __name__ == "__main__":

@@ -32,6 +32,14 @@ struct DrvObsStage {  // f32 staging of the observation rows (only used after th
   float goal[DRV_MAXA][2];
   float shared[DRV_MAXO * 4 + DRV_MAXP * 2 + DRV_LANE_ROWS * 5];
 };
+// -DDRV_PROFILE: per-environment cycle counters for the step kernel and the stages of the contact path, dumped by
+// dynenv_debug_counters() (tools/contact_profile.py).  Compiled out of the product build.
+#ifdef DRV_PROFILE
+#define DRV_PROF(...) __VA_ARGS__
+#else
+#define DRV_PROF(...)
+#endif
+#define DRV_CLIST 128  // capacity of the per-substep candidate list (485 pairs exist; more than 128 AABB overlaps sets EI_ERR)
 struct __align__(16) DrvLds {
   // dynamic bodies (lane l = body l): home location of the state
   double px[DRV_NB], py[DRV_NB], vx[DRV_NB], vy[DRV_NB], ang[DRV_NB], w[DRV_NB], vbx[DRV_NB], vby[DRV_NB], wb[DRV_NB];
@@ -48,7 +56,8 @@ struct __align__(16) DrvLds {
   // contact cache slots (lane s = slot s)
   int s_pair[DRV_NS], s_meta[DRV_NS], s_hash0[DRV_NS], s_hash1[DRV_NS];
   double s_jn0[DRV_NS], s_jt0[DRV_NS], s_jn1[DRV_NS], s_jt1[DRV_NS];
-  int still[DRV_NB];  // body had exactly zero v, w, v_bias, w_bias when positions were integrated this substep
+  int still[DRV_NB];  // bit0: body had exactly zero v, w, v_bias, w_bias when positions were integrated; bit1: frozen
+  unsigned short clist[DRV_CLIST];  // contact path: dense list of candidate pair ids in canonical order
   union {
     DrvMailbox mb;
     DrvObsStage ob;
@@ -572,6 +581,8 @@ DE_DEV bool cb_begin(DrvLds& L, int i, int j, int lane, double& rew) {
 // more registers than the common no-contact path; as a separate function its spills and saves are only paid
 // when something actually touches.  Operates on the LDS tile; returns the few scalars it changes.
 // ------------------------------------------------------------------------------------------------
+DRV_PROF(__device__ unsigned long long g_dbgw[4096 * 4];)
+DRV_PROF(__device__ unsigned long long g_dbgp[4096 * 8];)
 struct ContactRet {
   uint64_t occ;
   double rew;
@@ -583,30 +594,45 @@ __device__ __noinline__ ContactRet drv_contact_path(int lane, int cand, uint64_t
   DrvLds& L = g_L;
   int err = 0;
   // ---------- slow path: narrowphase -> arbiter cache -> callbacks -> prestep -> friction -> solver -------
+DRV_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
   DrvMailbox& M = L.u.mb;
   if (lane < DRV_NS) M.flag[lane] = 0;
   __syncthreads();
+  // ---- compact the candidate pairs of all 8 rounds into one dense list in canonical order, so that the narrowphase
+  //      runs once over up to 64 pairs instead of once per round that holds a candidate
+  int nCand = 0;
 #pragma unroll 1
   for (int t = 0; t < DRV_NPAIR_ROUNDS; ++t) {
-    const bool isCand = (cand >> t) & 1;
-    if (wave_ballot(isCand) == 0ull) continue;
+    const bool c = (cand >> t) & 1;
+    const uint64_t m = wave_ballot(c);
+    if (m == 0ull) continue;
+    if (c) {
+      const int idx = nCand + __popcll(m & lanemask_lt());
+      if (idx < DRV_CLIST) L.clist[idx] = (unsigned short)MY_PAIR(t); else err |= 1;  // overflow is reported, not silent
+    }
+    nCand += __popcll(m);
+  }
+  if (nCand > DRV_CLIST) nCand = DRV_CLIST;
+  __syncthreads();
+#pragma unroll 1
+  for (int pass = 0; pass * 64 < nCand; ++pass) {
+    const bool isCand = pass * 64 + lane < nCand;
     Contacts ct;
     ct.count = 0;
-    const int pr = MY_PAIR(t);
+    const int pr = isCand ? (int)L.clist[pass * 64 + lane] : 0xFFFF;
     if (isCand) {
-      int i = pr >> 8, j = pr & 0xFF;
+      const int i = pr >> 8, j = pr & 0xFF;
       BoxW b1;
       box_world(b1, v2(L.px[i], L.py[i]), L.rc[i], L.rs[i], L.chx[i], L.chy[i]);
-      if (j < DRV_SLOT_PED) {
-        BoxW b2;
-        box_world(b2, v2(L.px[j], L.py[j]), L.rc[j], L.rs[j], L.chx[j], L.chy[j]);
-        poly_to_poly(b1, i, b2, j, ct);
-      } else if (j < DRV_SLOT_OBST) {
+      if (j >= DRV_SLOT_PED && j < DRV_SLOT_OBST) {
         circle_to_poly(v2(L.px[j], L.py[j]), 5.0, b1, ct);
-      } else {
+      } else {  // car or static box: one instance of the SAT + clipping code for both
+        V2 p2;
+        double c2 = 1.0, s2 = 0.0, ex, ey;
+        if (j < DRV_SLOT_PED) { p2 = v2(L.px[j], L.py[j]); c2 = L.rc[j]; s2 = L.rs[j]; ex = L.chx[j]; ey = L.chy[j]; }
+        else { p2 = static_pos(L, j); ex = j >= DRV_SLOT_BLD ? 400.0 : 10.0; ey = j >= DRV_SLOT_BLD ? 225.0 : 10.0; }
         BoxW b2;
-        double ex = j >= DRV_SLOT_BLD ? 400.0 : 10.0, ey = j >= DRV_SLOT_BLD ? 225.0 : 10.0;
-        box_world(b2, static_pos(L, j), 1.0, 0.0, ex, ey);
+        box_world(b2, p2, c2, s2, ex, ey);
         poly_to_poly(b1, i, b2, j, ct);
       }
     }
@@ -651,11 +677,13 @@ __device__ __noinline__ ContactRet drv_contact_path(int lane, int cand, uint64_t
   }
   __syncthreads();
 
+DRV_PROF(const unsigned long long T1 = __builtin_amdgcn_s_memtime();)
   // ---- slot lanes: cpArbiterUpdate for touched slots; ageing / expiry for the rest ----------------------
   const bool slotOcc = lane < DRV_NS && ((occ >> lane) & 1ull);
   bool touched = false;
   int bodyA = 0, bodyB = 0;
   int a_pair = 0xFFFF, a_state = ARB_FIRST, a_count = 0, a_age = 0;
+  bool hashSame = false;  // same contact ids in the same order as when the slot was last written
   double jn[2] = {0.0, 0.0}, jt[2] = {0.0, 0.0};
   V2 n = v2(0.0, 0.0), r1[2], r2[2];
   r1[0] = r1[1] = r2[0] = r2[1] = v2(0.0, 0.0);
@@ -689,6 +717,7 @@ __device__ __noinline__ ContactRet drv_contact_path(int lane, int cand, uint64_t
         r2[1] = vsub(v2(M.p2x[lane][1], M.p2y[lane][1]), pb);
       }
       n = v2(M.nx[lane], M.ny[lane]);
+      hashSame = a_count == cnt && h0 == oh0 && (cnt < 2 || h1 == oh1);
       a_count = cnt;
       L.s_hash0[lane] = h0; L.s_hash1[lane] = h1;
       if (a_state == ARB_CACHED) a_state = ARB_FIRST;
@@ -744,13 +773,16 @@ __device__ __noinline__ ContactRet drv_contact_path(int lane, int cand, uint64_t
     maxLevel = lv > maxLevel ? lv : maxLevel;
   }
 
+DRV_PROF(const unsigned long long T2 = __builtin_amdgcn_s_memtime();)
   // ---- prestep (cpArbiterPreStep) on velocities BEFORE the friction update -------------------------------
   double nMass[2] = {0.0, 0.0}, tMass[2] = {0.0, 0.0}, bias[2] = {0.0, 0.0}, bounce[2] = {0.0, 0.0}, jBias[2] = {0.0, 0.0};
   const double arb_e = 0.05 * 0.05, arb_u = 0.0 * 0.0;
+  bool restIn = false;  // both bodies exactly at rest when the arbiter was prestepped
   if (active) {
     BodyV a, b;
     body_load(L, bodyA, a);
     body_load(L, bodyB, b);
+    restIn = a.v.x == 0.0 && a.v.y == 0.0 && a.w == 0.0 && b.v.x == 0.0 && b.v.y == 0.0 && b.w == 0.0;
     V2 body_delta = vsub(b.p, a.p);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -766,8 +798,10 @@ __device__ __noinline__ ContactRet drv_contact_path(int lane, int cand, uint64_t
   }
   __syncthreads();
 
+DRV_PROF(const unsigned long long T3 = __builtin_amdgcn_s_memtime();)
   // ---- velocity update (velocity_func: friction_* or default) -------------------------------------------
   velocity_update(L, lane, isCar, isPed);
+DRV_PROF(unsigned long long T4 = __builtin_amdgcn_s_memtime();)
   if (activeMask) {
     __syncthreads();
     // ---- warm start (cpArbiterApplyCachedImpulse; skipped on first contact), level by level ------------
@@ -790,6 +824,7 @@ __device__ __noinline__ ContactRet drv_contact_path(int lane, int cand, uint64_t
       }
       __syncthreads();
     }
+DRV_PROF(T4 = __builtin_amdgcn_s_memtime();)
     // ---- 10 sequential-impulse iterations (cpArbiterApplyImpulse) ---------------------------------------
     for (int iter = 0; iter < 10; ++iter) {
       for (int lv = 0; lv <= maxLevel; ++lv) {
@@ -834,6 +869,23 @@ __device__ __noinline__ ContactRet drv_contact_path(int lane, int cand, uint64_t
   // arbiters that were active this step are NORMAL from the next step on (cpSpaceStep resets the state)
   const bool wasNormal = a_state == ARB_NORMAL;  // i.e. not a first contact in this substep
   if (active && a_state == ARB_FIRST) a_state = ARB_NORMAL;
+  // steady: re-running this slot on identical inputs (same frozen positions, bodies at rest) reproduces this substep
+  // bit for bit: the slot record is unchanged (same contact ids, same accumulated impulses, NORMAL before and after, or
+  // ignored) and both bodies were at rest before the prestep and after the solve.  See DESIGN.md "steady replay".
+  bool steady = true;
+  if (slotOcc) {
+    steady = touched && !freeMe && hashSame;
+    if (steady && a_state != ARB_IGNORE) {
+      steady = a_state == ARB_NORMAL && wasNormal && restIn && L.s_jn0[lane] == jn[0] && L.s_jt0[lane] == jt[0] &&
+               L.s_jn1[lane] == jn[1] && L.s_jt1[lane] == jt[1];
+      if (steady) {
+        const int i = a_pair >> 8, j = a_pair & 0xFF;
+        steady = L.vx[i] == 0.0 && L.vy[i] == 0.0 && L.w[i] == 0.0;
+        if (j < DRV_SLOT_OBST) steady = steady && L.vx[j] == 0.0 && L.vy[j] == 0.0 && L.w[j] == 0.0;
+      }
+    }
+  }
+  const bool allSteady = wave_ballot(!steady) == 0ull;
   if (slotOcc) {
     if (freeMe) L.s_pair[lane] = 0xFFFF;
     L.s_meta[lane] = a_state | (a_count << 8) | (a_age << 16);
@@ -849,8 +901,10 @@ __device__ __noinline__ ContactRet drv_contact_path(int lane, int cand, uint64_t
               jn[1] == 0.0 && jt[1] == 0.0 && jBias[0] == 0.0 && jBias[1] == 0.0));
   }
   const bool allInert = wave_ballot(!inert) == 0ull;
+DRV_PROF(const unsigned long long T5 = __builtin_amdgcn_s_memtime();)
+DRV_PROF(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* d = g_dbgp + blockIdx.x * 8; d[0] += T1 - T0; d[1] += T2 - T1; d[2] += T3 - T2; d[3] += T4 - T3; d[4] += T5 - T4; d[5] += 1ull; d[6] += (unsigned long long)(maxLevel + 1); d[7] += (unsigned long long)nTouched; })
   ContactRet ret;
-  ret.occ = occ; ret.rew = rew; ret.err = err | (allInert ? 2 : 0);
+  ret.occ = occ; ret.rew = rew; ret.err = err | (allInert ? 2 : 0) | (allSteady ? 4 : 0);
   return ret;
 }
 
@@ -860,9 +914,11 @@ __device__ __noinline__ ContactRet drv_contact_path(int lane, int cand, uint64_t
 extern "C" __global__ void __launch_bounds__(64, DRV_WAVES_PER_SIMD)
 drv_step_kernel(DrvState S, const int* __restrict__ actions, float* __restrict__ obs, double* __restrict__ rewards,
                 uint8_t* __restrict__ dones) {
+DRV_PROF(const unsigned long long KS = __builtin_amdgcn_s_memtime();)
   DrvLds& L = g_L;
   const int e = blockIdx.x;
   const int lane = threadIdx.x;
+DRV_PROF(if (lane < 8 && e < 4096) g_dbgp[e * 8 + lane] = 0ull;)
   const int A = S.A;
   int* envi = S.envi + (size_t)e * EI_COUNT;
   int elapsed = uniform_i(envi[EI_ELAPSED]);
@@ -902,8 +958,10 @@ drv_step_kernel(DrvState S, const int* __restrict__ actions, float* __restrict__
   // quiescent-shortcut state carried across launches: candidate mask of the previous substep (-1: unknown) and
   // whether every cached arbiter was inert when the contact path last ran
   int lastCand = S.lastcand[(size_t)e * 64 + lane];
-  bool inertAll = uniform_i(envi[EI_PAD]) != 0;
-  int nFast = 0, nQuiet = 0, nContact = 0, nSlots = 0;  // diagnostics
+  bool inertAll = (uniform_i(envi[EI_PAD]) & 1) != 0;
+  // steady-replay state: the contact path ran (or was replayed) in the previous substep and reported every slot steady
+  bool steadyAll = (uniform_i(envi[EI_PAD]) & 2) != 0;
+  int nFast = 0, nQuiet = 0, nContact = 0, nSlots = 0, nWhyCand = 0, nWhyMoving = 0, nWhyInert = 0, nSteady = 0;  // diagnostics
   __syncthreads();
 
   for (int it = 0; it < 10; ++it) {
@@ -1035,11 +1093,13 @@ drv_step_kernel(DrvState S, const int* __restrict__ actions, float* __restrict__
       const bool still = !turned && vx == 0.0 && vy == 0.0 && w == 0.0 && vbx == 0.0 && vby == 0.0 && wb == 0.0;
       L.px[lane] = npx; L.py[lane] = npy; L.ang[lane] = nang;
       L.vbx[lane] = 0.0; L.vby[lane] = 0.0; L.wb[lane] = 0.0;
-      L.still[lane] = still ? 1 : 0;
+      // frozen: at rest and the position update was absorbed by rounding (sub-ulp bias velocities of a resting contact)
+      const bool frozen = !turned && vx == 0.0 && vy == 0.0 && w == 0.0 && npx == px && npy == py && nang == ang;
+      L.still[lane] = (still ? 1 : 0) | (frozen ? 2 : 0);
       float fcx = (float)npx, fcy = (float)npy, fhx = 6.0f, fhy = 6.0f;  // pedestrian circle r = 5 (+1 px margin)
       if (isCar) {
         if (nang != L.rotAng[lane]) car_refresh_rot(L, lane, nang);
-        if (!aabbValid || !still) {
+        if (!aabbValid || !frozen) {  // frozen: same position and rotation => same box
           BoxW bw;
           box_world(bw, v2(npx, npy), L.rc[lane], L.rs[lane], L.chx[lane], L.chy[lane]);
           double l = INFINITY, r = -INFINITY, b = INFINITY, t = -INFINITY;
@@ -1060,7 +1120,7 @@ drv_step_kernel(DrvState S, const int* __restrict__ actions, float* __restrict__
 
     // ======== phase 2: broadphase on my 8 pairs: fp32 conservative prefilter, then the exact AABB test ==========
     int cand = 0;
-    bool candMoving = false;
+    bool candMoving = false, candThawed = false;
 #pragma unroll 2
     for (int t = 0; t < DRV_NPAIR_ROUNDS; ++t) {
       const int pr = MY_PAIR(t);
@@ -1087,7 +1147,9 @@ drv_step_kernel(DrvState S, const int* __restrict__ actions, float* __restrict__
           }
           if (al <= br && bl <= ar && ab <= bt && bb <= at) {
             cand |= (1 << t);
-            if (!(L.still[i] && (j >= DRV_SLOT_OBST || L.still[j]))) candMoving = true;
+            const int si = L.still[i], sj = j >= DRV_SLOT_OBST ? 3 : L.still[j];
+            if (!(si & sj & 1)) candMoving = true;
+            if (!(si & sj & 2)) candThawed = true;
           }
         }
       }
@@ -1097,20 +1159,38 @@ drv_step_kernel(DrvState S, const int* __restrict__ actions, float* __restrict__
     // every cached arbiter inert (zero bias, zero accumulated impulse, not first contact).  Then narrowphase, arbiter
     // update, warm start and all 10 solver iterations are exact no-ops (DESIGN.md "quiescent shortcut") and only the
     // velocity update remains.
-    const bool quiescent = inertAll && wave_ballot(cand != lastCand || candMoving) == 0ull;
+    const bool candChanged = wave_ballot(cand != lastCand) != 0ull, anyMoving = wave_ballot(candMoving) != 0ull;
+    const bool quiescent = inertAll && !candChanged && !anyMoving;
+    // Steady replay: the contact path of the previous substep reported every slot steady, the candidate set is the
+    // same and every body in it is frozen => this substep's contact path would read the same inputs and reproduce the
+    // same outputs: slots unchanged, velocities stay zero, bias velocities equal to the saved ones.
+    const bool replay = !quiescent && steadyAll && !candChanged && wave_ballot(candThawed) == 0ull;
+    if (!(anyCand == 0ull && occ == 0ull) && !quiescent && !replay) { if (candChanged) nWhyCand++; else if (anyMoving) nWhyMoving++; else nWhyInert++; }
     lastCand = cand;
     __syncthreads();  // the prefilter aliases the contact mailbox
 
-    if (anyCand == 0ull && occ == 0ull) nFast++; else if (quiescent) nQuiet++; else nContact++;
+    if (anyCand == 0ull && occ == 0ull) nFast++; else if (quiescent) nQuiet++; else if (replay) nSteady++; else nContact++;
     nSlots += __popcll(occ);
     if ((anyCand == 0ull && occ == 0ull) || quiescent) {
       // ---------- fast path: nothing touches and the contact cache is empty (or quiescent): velocity update only
       velocity_update(L, lane, isCar, isPed);
+      if (anyCand == 0ull && occ == 0ull) steadyAll = false;
+    } else if (replay) {
+      velocity_update(L, lane, isCar, isPed);
+      if (isBody) {
+        const double* vb = S.vbout + (size_t)e * 96 + lane;
+        L.vbx[lane] = vb[0]; L.vby[lane] = vb[32]; L.wb[lane] = vb[64];
+      }
     } else {
       // ---------- contact path (out of line): narrowphase -> contact cache -> callbacks -> prestep -> friction -> solver
       ContactRet cr = drv_contact_path(lane, cand, pairLo, pairHi, occ, rew, isCar, isPed);
       occ = uniform_u64(cr.occ); rew = cr.rew; err |= cr.err & 1;
-      inertAll = uniform_i(cr.err >> 1) != 0;
+      inertAll = (uniform_i(cr.err >> 1) & 1) != 0;
+      steadyAll = (uniform_i(cr.err >> 2) & 1) != 0;
+      if (steadyAll && isBody) {  // bias velocities this solve produced: what a replay has to reinstate
+        double* vb = S.vbout + (size_t)e * 96 + lane;
+        vb[0] = L.vbx[lane]; vb[32] = L.vby[lane]; vb[64] = L.wb[lane];
+      }
     }
     __syncthreads();
 
@@ -1138,7 +1218,9 @@ drv_step_kernel(DrvState S, const int* __restrict__ actions, float* __restrict__
   if (lane == 0) {
     dones[e] = (uint8_t)(elapsed >= DRV_MAX_TIME);
     envi[EI_ELAPSED] = elapsed; envi[EI_ALLFIN] = allFinished; envi[EI_OCC] = (int)(uint32_t)occ;
-    envi[EI_PAD] = inertAll ? 1 : 0;
+    envi[EI_PAD] = (inertAll ? 1 : 0) | (steadyAll ? 2 : 0);
+    envi[EI_N_STEADY] += nSteady;
+    envi[EI_N_WHY_CAND] += nWhyCand; envi[EI_N_WHY_MOVING] += nWhyMoving; envi[EI_N_WHY_INERT] += nWhyInert;
     envi[EI_N_FAST] += nFast; envi[EI_N_QUIET] += nQuiet; envi[EI_N_CONTACT] += nContact; envi[EI_N_SLOTS] += nSlots;
   }
   const uint64_t errMask = wave_ballot(err != 0);
@@ -1146,6 +1228,7 @@ drv_step_kernel(DrvState S, const int* __restrict__ actions, float* __restrict__
   S.lastcand[(size_t)e * 64 + lane] = lastCand;
   store_env(S, L, e, lane, A, nPed, occ);
   if (obs) write_full_obs(L, lane, A, nPed, nObst, S.obs_dim, obs + (size_t)e * A * S.obs_dim);
+DRV_PROF(if (lane == 0 && e < 4096) { g_dbgw[e * 4] = __builtin_amdgcn_s_memtime() - KS; g_dbgw[e * 4 + 1] = nContact; g_dbgw[e * 4 + 2] = __popcll(occ); g_dbgw[e * 4 + 3] = nSteady + nQuiet; })
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1256,6 +1339,8 @@ extern "C" __global__ void __launch_bounds__(64) drv_reset_kernel(DrvState S) {
   envi[EI_ELAPSED] = 0; envi[EI_ALLFIN] = 0; envi[EI_NPED] = nPed; envi[EI_NOBST] = nObst;
   envi[EI_EPISODE] = (int)(ep + 1); envi[EI_OCC] = 0; envi[EI_ERR] = 0;
   envi[EI_N_FAST] = 0; envi[EI_N_QUIET] = 0; envi[EI_N_CONTACT] = 0; envi[EI_N_SLOTS] = 0; envi[EI_PAD] = 0;
+  envi[EI_N_STEADY] = 0;
+  envi[EI_N_WHY_CAND] = 0; envi[EI_N_WHY_MOVING] = 0; envi[EI_N_WHY_INERT] = 0;
   for (int k = 0; k < 64; ++k) S.lastcand[(size_t)e * 64 + k] = -1;
 }
 

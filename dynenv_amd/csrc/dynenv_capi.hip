@@ -328,6 +328,7 @@ int dynenv_create(const dynenv_cfg_t* cfg, dynenv_t** out) {
   rc |= dev_alloc(h, &S.s_hash, 2 * E * DRV_NS);
   rc |= dev_alloc(h, &S.s_imp, 4 * E * DRV_NS);
   rc |= dev_alloc(h, &S.lastcand, E * 64);
+  rc |= dev_alloc(h, &S.vbout, (size_t)E * 96);
   if (rc) { dynenv_destroy(h); return DYNENV_ERR_HIP; }
   DrvConst c;
   build_consts(c);
@@ -481,16 +482,22 @@ int dynenv_error_flags(dynenv_t* h, int32_t* out) {
   return DYNENV_OK;
 }
 
-// diagnostics: per-path substep counts since the last reset, summed over envs: {fast, quiescent, contact, slot-sum}
+// diagnostics: per-path substep counts since the last reset, summed over envs: out8 = {fast, quiescent, contact,
+// slot-sum, contact-because-candidates-changed, -because-a-body-moved, -because-an-arbiter-was-not-inert,
+// steady replays, 0...}
 int dynenv_debug_counters(dynenv_t* h, int64_t* out4) {
   if (!h || !out4) return fail(DYNENV_ERR_ARG, "null argument");
-  if (h->robocup) { out4[0] = out4[1] = out4[2] = out4[3] = 0; return DYNENV_OK; }
+  if (h->robocup) { for (int k = 0; k < 12; ++k) out4[k] = 0; return DYNENV_OK; }
   HIP_OK(hipDeviceSynchronize());
   std::vector<int> envi((size_t)h->S.E * EI_COUNT);
   HIP_OK(hipMemcpy(envi.data(), h->S.envi, envi.size() * sizeof(int), hipMemcpyDeviceToHost));
-  out4[0] = out4[1] = out4[2] = out4[3] = 0;
+  for (int k = 0; k < 12; ++k) out4[k] = 0;
   for (int e = 0; e < h->S.E; ++e)
-    for (int k = 0; k < 4; ++k) out4[k] += envi[(size_t)e * EI_COUNT + EI_N_FAST + k];
+    for (int k = 0; k < 8; ++k) out4[k] += envi[(size_t)e * EI_COUNT + EI_N_FAST + k];
+#ifdef DRV_PROFILE
+  { static unsigned long long d[4096 * 4]; HIP_OK(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_dbgw), sizeof(d))); FILE* f = fopen("gpurun_out/dbgw.txt", "w"); for (int k = 0; k < 4096; ++k) fprintf(f, "%llu %llu %llu %llu\n", d[4*k], d[4*k+1], d[4*k+2], d[4*k+3]); fclose(f); }
+  { static unsigned long long d[4096 * 8]; HIP_OK(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_dbgp), sizeof(d))); FILE* f = fopen("gpurun_out/dbgp.txt", "w"); for (int k = 0; k < 4096; ++k) { for (int q = 0; q < 8; ++q) fprintf(f, "%llu ", d[8*k+q]); fprintf(f, "\n"); } fclose(f); }
+#endif
   return DYNENV_OK;
 }
 

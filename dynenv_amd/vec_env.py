@@ -249,9 +249,10 @@ class BatchedDynEnv(object):
         return f.value
 
     def debug_counters(self):
-        out = (C.c_int64 * 4)()
+        out = (C.c_int64 * 12)()
         _capi.check(self._lib.dynenv_debug_counters(self._h, out), "dynenv_debug_counters")
-        return dict(fast=out[0], quiescent=out[1], contact=out[2], slot_sum=out[3])
+        return dict(fast=out[0], quiescent=out[1], contact=out[2], slot_sum=out[3], why_cand=out[4], why_moving=out[5],
+                    why_inert=out[6], steady=out[7])
 
     def get_state(self, env=0):
         st = _capi.DrivingState() if self.env_type == DynEnvType.DRIVE else _capi.RoboCupState()

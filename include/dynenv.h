@@ -173,9 +173,11 @@ int dynenv_sync(dynenv_t* h, void* stream);
  * Synchronises the device. */
 int dynenv_error_flags(dynenv_t* h, int32_t* out);
 
-/* Diagnostics (Driving): substeps since the last reset taken by {no-contact fast path, quiescent shortcut, full contact
- * path} and the sum of live contact-cache slots, summed over environments.  Synchronises the device. */
-int dynenv_debug_counters(dynenv_t* h, int64_t* out4);
+/* Diagnostics (Driving), summed over environments since the last reset: out12 = {substeps on the no-contact fast path,
+ * on the quiescent shortcut, on the full contact path, sum of live contact-cache slots, contact-path substeps caused by
+ * a changed candidate set / a moving body / a non-inert arbiter, substeps served by a steady replay, 0, 0, 0, 0}.
+ * Synchronises the device. */
+int dynenv_debug_counters(dynenv_t* h, int64_t* out12);
 
 /* Device self-test of the deterministic math header: evaluates sincos/atan2/sqrt/div on n host-provided doubles and
  * returns the raw results so tests can compare them bit-for-bit with the host evaluation. out: [n,5]. */

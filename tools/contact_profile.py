@@ -1,0 +1,41 @@
+"""Where does the Driving step kernel spend its time?  Builds the -DDRV_PROFILE variant of the library, drives 4096
+environments to a late step of an episode (many resting contacts) and prints, per environment, the cycles of one
+launch and of the contact path's stages.  The launch lasts as long as its slowest environment, so the top of the list
+is what to optimise.  Usage (GPU box):  python tools/contact_profile.py [step]"""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PROF = os.path.join(ROOT, "dynenv_amd", "libdynenv_hip_prof.so")
+from dynenv_amd import build as _b
+if not os.path.exists(PROF) or any(os.path.getmtime(d) > os.path.getmtime(PROF) for d in _b.DEPS if os.path.exists(d)):
+    _b.build(out=PROF, defines=("DRV_PROFILE",))
+os.environ["DYNENV_HIP_LIB"] = PROF
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+os.chdir(ROOT)
+import torch, numpy as np
+from dynenv_amd import BatchedDynEnv, DynEnvType
+STEP = int(sys.argv[1]) if len(sys.argv) > 1 else 560
+env = BatchedDynEnv(DynEnvType.DRIVE, 4096, 10, seed=42)
+env.reset_flat()
+g = torch.Generator(device="cuda"); g.manual_seed(1)
+for s in range(STEP):
+    a = torch.randint(0, 3, (4096, 10, 2), dtype=torch.int32, device="cuda", generator=g)
+    env.step_flat(a)
+env.debug_counters()
+d = np.loadtxt("gpurun_out/dbgw.txt")
+c = d[:, 0]
+print("cycles: mean %.0f  p50 %.0f p90 %.0f p99 %.0f max %.0f" % (c.mean(), *np.percentile(c, [50, 90, 99]), c.max()))
+for k in range(11):
+    m = d[:, 1] == k
+    if m.any(): print("nContact=%d: n=%d mean cycles %.0f max %.0f, mean occ %.2f" % (k, m.sum(), c[m].mean(), c[m].max(), d[m, 2].mean()))
+top = np.argsort(-c)[:15]
+print(d[top])
+m = d[:, 1] == 10
+for o in range(0, 25):
+    mm = m & (d[:, 2] == o)
+    if mm.any(): print("nContact=10 occ=%d n=%d mean %.0f" % (o, mm.sum(), c[mm].mean()))
+p = np.loadtxt("gpurun_out/dbgp.txt")
+print("top envs: total | narrow slots prestep velupd solver | calls levels touched")
+for k in top[:10]: print(int(c[k]), p[k].astype(int))
+m = d[:, 1] == 10
+print("mean over nContact=10 envs:", p[m].mean(0).astype(int), "total", int(c[m].mean()))
