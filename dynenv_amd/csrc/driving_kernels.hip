@@ -24,9 +24,6 @@ struct DrvMailbox {  // narrowphase result of the pair that maps to slot s (writ
   double p1x[DRV_NS][2], p1y[DRV_NS][2], p2x[DRV_NS][2], p2y[DRV_NS][2], nx[DRV_NS], ny[DRV_NS];
   int hash[DRV_NS][2], count[DRV_NS], flag[DRV_NS]; /* flag: bit0 touched, bit1 newly allocated */
 };
-struct DrvPrefilter {  // fp32 conservative AABB (centre, half extent + 1 px margin) of the 32 dynamic slots; rewritten
-  float cx[DRV_NB], cy[DRV_NB], hx[DRV_NB], hy[DRV_NB];  // every substep before the broadphase (aliases the mailbox)
-};
 struct DrvObsStage {  // f32 staging of the observation rows (only used after the last substep)
   float carRow[DRV_MAXA][8];
   float goal[DRV_MAXA][2];
@@ -61,7 +58,6 @@ struct __align__(16) DrvLds {
   union {
     DrvMailbox mb;
     DrvObsStage ob;
-    DrvPrefilter pf;
   } u;
 };
 
@@ -69,7 +65,6 @@ struct __align__(16) DrvLds {
 // addresses it with ds_* instructions instead of flat pointers.
 __shared__ DrvLds g_L;
 
-#define MY_PAIR(t) ((int)((((t) < 4 ? pairLo : pairHi) >> (16 * ((t)&3))) & 0xFFFFull))
 
 // flag-word accessors (layout in driving_dev.h)
 #define CF_FIN(f) (((f) >> 4) & 1)
@@ -201,17 +196,6 @@ struct EdgeW {
   int ah, bh;
 };
 
-DE_DEV int poly_support_index(const BoxW& p, V2 n) {
-  double mx = -INFINITY;
-  int index = 0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    double d = vdot(p.v[i], n);
-    if (d > mx) { mx = d; index = i; }
-  }
-  return index;
-}
-
 // select element `i` of a 4-vector without dynamic register indexing (no scratch)
 DE_DEV V2 sel4(const V2* a, int i) {
   V2 r = a[0];
@@ -221,17 +205,45 @@ DE_DEV V2 sel4(const V2* a, int i) {
   return r;
 }
 
-DE_DEV EdgeW support_edge_poly(const BoxW& p, int slot, V2 n) {
+// A box by its parameters.  The narrowphase derives vertices and normals from these on demand (same arithmetic as
+// box_world) instead of holding two expanded boxes (64 doubles) in registers, which spilled to scratch.
+struct BoxP {
+  V2 p;
+  double c, s, hx, hy;
+};
+DE_DEV V2 boxp_vertex(const BoxP& b, int i) {
+  const double lx = (i == 1 || i == 2) ? b.hx : -b.hx;
+  const double ly = (i >= 2) ? b.hy : -b.hy;
+  return v2(b.c * lx - b.s * ly + b.p.x, b.s * lx + b.c * ly + b.p.y);
+}
+DE_DEV V2 boxp_normal(const BoxP& b, int i) {
+  const double nx = (i == 0) ? -1.0 : ((i == 2) ? 1.0 : 0.0);
+  const double ny = (i == 1) ? -1.0 : ((i == 3) ? 1.0 : 0.0);
+  return v2(b.c * nx - b.s * ny, b.s * nx + b.c * ny);
+}
+
+DE_DEV int poly_support_index(const BoxP& p, V2 n) {
+  double mx = -INFINITY;
+  int index = 0;
+#pragma unroll 1
+  for (int i = 0; i < 4; ++i) {
+    double d = vdot(boxp_vertex(p, i), n);
+    if (d > mx) { mx = d; index = i; }
+  }
+  return index;
+}
+
+DE_DEV EdgeW support_edge_poly(const BoxP& p, int slot, V2 n) {
   int i1 = poly_support_index(p, n);
   int i0 = (i1 + 3) & 3;
   int i2 = (i1 + 1) & 3;
   int h = slot * 4;
-  V2 n1 = sel4(p.n, i1), n2 = sel4(p.n, i2);
+  V2 n1 = boxp_normal(p, i1), n2 = boxp_normal(p, i2);
   EdgeW e;
   if (vdot(n, n1) > vdot(n, n2)) {
-    e.ap = sel4(p.v, i0); e.ah = h + i0; e.bp = sel4(p.v, i1); e.bh = h + i1; e.n = n1;
+    e.ap = boxp_vertex(p, i0); e.ah = h + i0; e.bp = boxp_vertex(p, i1); e.bh = h + i1; e.n = n1;
   } else {
-    e.ap = sel4(p.v, i1); e.ah = h + i1; e.bp = sel4(p.v, i2); e.bh = h + i2; e.n = n2;
+    e.ap = boxp_vertex(p, i1); e.ah = h + i1; e.bp = boxp_vertex(p, i2); e.bh = h + i2; e.n = n2;
   }
   return e;
 }
@@ -264,17 +276,20 @@ DE_DEV void contact_points(const EdgeW& e1, const EdgeW& e2, V2 n, Contacts& out
   }
 }
 
-DE_DEV double sat_max_sep(const BoxW& a, const BoxW& b, int& best) {
+DE_DEV double sat_max_sep(const BoxP& a, const BoxP& b, int& best) {
   double maxsep = -INFINITY;
   best = 0;
+  V2 bv[4];
 #pragma unroll
+  for (int j = 0; j < 4; ++j) bv[j] = boxp_vertex(b, j);
+#pragma unroll 1
   for (int i = 0; i < 4; ++i) {
-    V2 n = a.n[i];
-    double d0 = vdot(n, a.v[i]);
+    V2 n = boxp_normal(a, i);
+    double d0 = vdot(n, boxp_vertex(a, i));
     double minv = INFINITY;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      double d = vdot(n, b.v[j]) - d0;
+      double d = vdot(n, bv[j]) - d0;
       if (d < minv) minv = d;
     }
     if (minv > maxsep) { maxsep = minv; best = i; }
@@ -282,7 +297,7 @@ DE_DEV double sat_max_sep(const BoxW& a, const BoxW& b, int& best) {
   return maxsep;
 }
 
-DE_DEV void poly_to_poly(const BoxW& p1, int slot1, const BoxW& p2, int slot2, Contacts& out) {
+DE_DEV void poly_to_poly(const BoxP& p1, int slot1, const BoxP& p2, int slot2, Contacts& out) {
   out.count = 0;
   int ia, ib;
   double sa = sat_max_sep(p1, p2, ia);
@@ -290,31 +305,31 @@ DE_DEV void poly_to_poly(const BoxW& p1, int slot1, const BoxW& p2, int slot2, C
   double sb = sat_max_sep(p2, p1, ib);
   if (sb > 0.0) return;
   V2 n;
-  if (sa >= sb) n = sel4(p1.n, ia); else n = vneg(sel4(p2.n, ib));
+  if (sa >= sb) n = boxp_normal(p1, ia); else n = vneg(boxp_normal(p2, ib));
   contact_points(support_edge_poly(p1, slot1, n), support_edge_poly(p2, slot2, vneg(n)), n, out);
 }
 
-DE_DEV void circle_to_poly(V2 c, double r, const BoxW& poly, Contacts& out) {
+DE_DEV void circle_to_poly(V2 c, double r, const BoxP& poly, Contacts& out) {
   out.count = 0;
   double maxsep = -INFINITY;
   int best = 0;
-#pragma unroll
+#pragma unroll 1
   for (int i = 0; i < 4; ++i) {
-    double d = vdot(poly.n[i], vsub(c, poly.v[i]));
+    double d = vdot(boxp_normal(poly, i), vsub(c, boxp_vertex(poly, i)));
     if (d > maxsep) { maxsep = d; best = i; }
   }
   if (maxsep > r) return;
   if (maxsep <= 0.0) {
-    V2 fn = sel4(poly.n, best);
+    V2 fn = boxp_normal(poly, best);
     V2 n = vneg(fn);
     V2 pb = vsub(c, vmul(fn, maxsep));
     out.n = n; out.p1[0] = vadd(c, vmul(n, r)); out.p2[0] = pb; out.hash[0] = 0; out.count = 1;
   } else {
     double bestd = INFINITY;
     V2 bestp = c;
-#pragma unroll
+#pragma unroll 1
     for (int i = 0; i < 4; ++i) {
-      V2 a = poly.v[(i + 3) & 3], b = poly.v[i];
+      V2 a = boxp_vertex(poly, (i + 3) & 3), b = boxp_vertex(poly, i);
       V2 d = vsub(b, a);
       double t = fclamp01_cp(vdot(d, vsub(c, a)) / vlensq(d));
       V2 q = vadd(a, vmul(d, t));
@@ -324,7 +339,7 @@ DE_DEV void circle_to_poly(V2 c, double r, const BoxW& poly, Contacts& out) {
     if (bestd <= r * r) {
       double dist = dm_sqrt(bestd);
       V2 delta = vsub(bestp, c);
-      V2 n = (dist != 0.0) ? vmul(delta, 1.0 / dist) : vneg(sel4(poly.n, best));
+      V2 n = (dist != 0.0) ? vmul(delta, 1.0 / dist) : vneg(boxp_normal(poly, best));
       out.n = n; out.p1[0] = vadd(c, vmul(n, r)); out.p2[0] = bestp; out.hash[0] = 0; out.count = 1;
     }
   }
@@ -581,7 +596,53 @@ DE_DEV bool cb_begin(DrvLds& L, int i, int j, int lane, double& rew) {
 // more registers than the common no-contact path; as a separate function its spills and saves are only paid
 // when something actually touches.  Operates on the LDS tile; returns the few scalars it changes.
 // ------------------------------------------------------------------------------------------------
-DRV_PROF(__device__ unsigned long long g_dbgw[4096 * 4];)
+// cpArbiterApplyCachedImpulse for the (up to two) contacts of one arbiter
+DE_DEV void arb_warm_start(BodyV& a, BodyV& b, V2 n, const V2* r1, const V2* r2, const double* jn, const double* jt,
+                           int count) {
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    if (c < count) {
+      V2 j = vrotate(n, v2(jn[c], jt[c]));
+      j = vmul(j, 1.0);  // dt_coef = dt/prev_dt = 1
+      apply_impulse(a, vneg(j), r1[c]);
+      apply_impulse(b, j, r2[c]);
+    }
+  }
+}
+// one cpArbiterApplyImpulse pass over the contacts of one arbiter
+DE_DEV void arb_apply_impulse(BodyV& a, BodyV& b, V2 n, const V2* r1, const V2* r2, const double* nMass,
+                              const double* tMass, const double* bias, const double* bounce, double* jBias, double* jn,
+                              double* jt, int count, double arb_u) {
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    if (c < count) {
+      V2 vb1 = vadd(a.vb, vmul(vperp(r1[c]), a.wb));
+      V2 vb2 = vadd(b.vb, vmul(vperp(r2[c]), b.wb));
+      V2 vr = relative_velocity(a, b, r1[c], r2[c]);
+      double vbn = vdot(vsub(vb2, vb1), n);
+      double vrn = vdot(vr, n);
+      double vrt = vdot(vr, vperp(n));
+      double jbn = (bias[c] - vbn) * nMass[c];
+      double jbnOld = jBias[c];
+      jBias[c] = fmax_cp(jbnOld + jbn, 0.0);
+      double jnn = -(bounce[c] + vrn) * nMass[c];
+      double jnOld = jn[c];
+      jn[c] = fmax_cp(jnOld + jnn, 0.0);
+      double jtMax = arb_u * jn[c];
+      double jtt = -vrt * tMass[c];
+      double jtOld = jt[c];
+      jt[c] = fclamp_cp(jtOld + jtt, -jtMax, jtMax);
+      V2 jb = vmul(n, jBias[c] - jbnOld);
+      apply_bias_impulse(a, vneg(jb), r1[c]);
+      apply_bias_impulse(b, jb, r2[c]);
+      V2 jj = vrotate(n, v2(jn[c] - jnOld, jt[c] - jtOld));
+      apply_impulse(a, vneg(jj), r1[c]);
+      apply_impulse(b, jj, r2[c]);
+    }
+  }
+}
+
+DRV_PROF(__device__ unsigned long long g_dbgw[4096 * 12];)
 DRV_PROF(__device__ unsigned long long g_dbgp[4096 * 8];)
 struct ContactRet {
   uint64_t occ;
@@ -589,7 +650,7 @@ struct ContactRet {
   int err;
 };
 
-__device__ __noinline__ ContactRet drv_contact_path(int lane, int cand, uint64_t pairLo, uint64_t pairHi, uint64_t occ,
+__device__ __noinline__ ContactRet drv_contact_path(int lane, int cand, int dirty, int light, int A, uint64_t occ,
                                                     double rew, bool isCar, bool isPed) {
   DrvLds& L = g_L;
   int err = 0;
@@ -598,22 +659,39 @@ DRV_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
   DrvMailbox& M = L.u.mb;
   if (lane < DRV_NS) M.flag[lane] = 0;
   __syncthreads();
-  // ---- compact the candidate pairs of all 8 rounds into one dense list in canonical order, so that the narrowphase
-  //      runs once over up to 64 pairs instead of once per round that holds a candidate
+  // Two modes share one instance of the narrowphase.  mode 0 ("light", only when every slot was steady in the previous
+  // substep): test just the DIRTY candidates - pairs that are new or have a thawed body.  If none of them touches and
+  // none owns a slot, every remaining pair is unchanged and frozen, so the rest of this function would reproduce the
+  // previous substep: return and let the caller replay it.  Otherwise, and in mode 1, process every candidate.
+  bool lightOk = false;
+#pragma unroll 1
+  for (int mode = light ? 0 : 1; mode < 2; ++mode) {
+  const int bits = mode == 0 ? dirty : cand;
+  bool lightBad = false;
+  // ---- compact the pairs (bit i of lane j = pair (i, j)) into one dense list in canonical order, so that the
+  //      narrowphase runs once over up to 64 pairs
   int nCand = 0;
 #pragma unroll 1
-  for (int t = 0; t < DRV_NPAIR_ROUNDS; ++t) {
-    const bool c = (cand >> t) & 1;
+  for (int i = 0; i < A; ++i) {
+    const bool c = (bits >> i) & 1;
     const uint64_t m = wave_ballot(c);
     if (m == 0ull) continue;
     if (c) {
       const int idx = nCand + __popcll(m & lanemask_lt());
-      if (idx < DRV_CLIST) L.clist[idx] = (unsigned short)MY_PAIR(t); else err |= 1;  // overflow is reported, not silent
+      if (idx < DRV_CLIST) L.clist[idx] = (unsigned short)((i << 8) | lane); else err |= 1;  // overflow is reported
     }
     nCand += __popcll(m);
   }
   if (nCand > DRV_CLIST) nCand = DRV_CLIST;
   __syncthreads();
+  if (mode == 0) {  // a dirty pair that owns a slot rules the light mode out before any narrowphase work is spent on it
+    bool owns = false;
+    for (int k = lane; k < nCand; k += 64) {
+      const int pr = (int)L.clist[k];
+      for (uint64_t mm = occ; mm; mm &= mm - 1) owns = owns || L.s_pair[__builtin_ctzll(mm)] == pr;
+    }
+    if (wave_ballot(owns) != 0ull) continue;
+  }
 #pragma unroll 1
   for (int pass = 0; pass * 64 < nCand; ++pass) {
     const bool isCand = pass * 64 + lane < nCand;
@@ -622,31 +700,30 @@ DRV_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
     const int pr = isCand ? (int)L.clist[pass * 64 + lane] : 0xFFFF;
     if (isCand) {
       const int i = pr >> 8, j = pr & 0xFF;
-      BoxW b1;
-      box_world(b1, v2(L.px[i], L.py[i]), L.rc[i], L.rs[i], L.chx[i], L.chy[i]);
+      BoxP b1;
+      b1.p = v2(L.px[i], L.py[i]); b1.c = L.rc[i]; b1.s = L.rs[i]; b1.hx = L.chx[i]; b1.hy = L.chy[i];
       if (j >= DRV_SLOT_PED && j < DRV_SLOT_OBST) {
         circle_to_poly(v2(L.px[j], L.py[j]), 5.0, b1, ct);
       } else {  // car or static box: one instance of the SAT + clipping code for both
-        V2 p2;
-        double c2 = 1.0, s2 = 0.0, ex, ey;
-        if (j < DRV_SLOT_PED) { p2 = v2(L.px[j], L.py[j]); c2 = L.rc[j]; s2 = L.rs[j]; ex = L.chx[j]; ey = L.chy[j]; }
-        else { p2 = static_pos(L, j); ex = j >= DRV_SLOT_BLD ? 400.0 : 10.0; ey = j >= DRV_SLOT_BLD ? 225.0 : 10.0; }
-        BoxW b2;
-        box_world(b2, p2, c2, s2, ex, ey);
+        BoxP b2;
+        b2.c = 1.0; b2.s = 0.0;
+        if (j < DRV_SLOT_PED) { b2.p = v2(L.px[j], L.py[j]); b2.c = L.rc[j]; b2.s = L.rs[j]; b2.hx = L.chx[j]; b2.hy = L.chy[j]; }
+        else { b2.p = static_pos(L, j); b2.hx = j >= DRV_SLOT_BLD ? 400.0 : 10.0; b2.hy = j >= DRV_SLOT_BLD ? 225.0 : 10.0; }
         poly_to_poly(b1, i, b2, j, ct);
       }
     }
     const bool touch = isCand && ct.count > 0;
-    const uint64_t tmask = wave_ballot(touch);
-    if (tmask == 0ull) continue;
     // find my slot among the occupied ones
     int slot = -1;
-    if (touch) {
+    if (touch && mode != 0) {
       for (uint64_t mm = occ; mm; mm &= mm - 1) {
         int sidx = __builtin_ctzll(mm);
         if (L.s_pair[sidx] == pr) slot = sidx;
       }
     }
+    if (mode == 0) { lightBad = lightBad || touch; continue; }
+    const uint64_t tmask = wave_ballot(touch);
+    if (tmask == 0ull) continue;
     const bool needNew = touch && slot < 0;
     const uint64_t newMask = wave_ballot(needNew);
     if (newMask) {
@@ -676,6 +753,13 @@ DRV_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
     __syncthreads();
   }
   __syncthreads();
+  if (mode == 0 && wave_ballot(lightBad) == 0ull) { lightOk = true; break; }
+  }
+  if (lightOk) {
+    ContactRet ret;
+    ret.occ = occ; ret.rew = rew; ret.err = err | 8;
+    return ret;
+  }
 
 DRV_PROF(const unsigned long long T1 = __builtin_amdgcn_s_memtime();)
   // ---- slot lanes: cpArbiterUpdate for touched slots; ageing / expiry for the rest ----------------------
@@ -802,7 +886,23 @@ DRV_PROF(const unsigned long long T3 = __builtin_amdgcn_s_memtime();)
   // ---- velocity update (velocity_func: friction_* or default) -------------------------------------------
   velocity_update(L, lane, isCar, isPed);
 DRV_PROF(unsigned long long T4 = __builtin_amdgcn_s_memtime();)
-  if (activeMask) {
+  if (activeMask && maxLevel == 0) {
+    // No two active arbiters share a dynamic body: each lane keeps its two bodies in registers through the warm start
+    // and all 10 iterations, with one LDS load and one store (same arithmetic, no LDS round trip per iteration).
+    __syncthreads();
+    if (active) {
+      BodyV a, b;
+      body_load(L, bodyA, a);
+      body_load(L, bodyB, b);
+      if (a_state != ARB_FIRST) arb_warm_start(a, b, n, r1, r2, jn, jt, a_count);
+DRV_PROF(T4 = __builtin_amdgcn_s_memtime();)
+#pragma unroll 1
+      for (int iter = 0; iter < 10; ++iter) arb_apply_impulse(a, b, n, r1, r2, nMass, tMass, bias, bounce, jBias, jn, jt, a_count, arb_u);
+      body_store_vel(L, bodyA, a);
+      body_store_vel(L, bodyB, b);
+    }
+    __syncthreads();
+  } else if (activeMask) {
     __syncthreads();
     // ---- warm start (cpArbiterApplyCachedImpulse; skipped on first contact), level by level ------------
     for (int lv = 0; lv <= maxLevel; ++lv) {
@@ -810,15 +910,7 @@ DRV_PROF(unsigned long long T4 = __builtin_amdgcn_s_memtime();)
         BodyV a, b;
         body_load(L, bodyA, a);
         body_load(L, bodyB, b);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          if (c < a_count) {
-            V2 j = vrotate(n, v2(jn[c], jt[c]));
-            j = vmul(j, 1.0);  // dt_coef = dt/prev_dt = 1
-            apply_impulse(a, vneg(j), r1[c]);
-            apply_impulse(b, j, r2[c]);
-          }
-        }
+        arb_warm_start(a, b, n, r1, r2, jn, jt, a_count);
         body_store_vel(L, bodyA, a);
         body_store_vel(L, bodyB, b);
       }
@@ -832,33 +924,7 @@ DRV_PROF(T4 = __builtin_amdgcn_s_memtime();)
           BodyV a, b;
           body_load(L, bodyA, a);
           body_load(L, bodyB, b);
-#pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            if (c < a_count) {
-              V2 vb1 = vadd(a.vb, vmul(vperp(r1[c]), a.wb));
-              V2 vb2 = vadd(b.vb, vmul(vperp(r2[c]), b.wb));
-              V2 vr = relative_velocity(a, b, r1[c], r2[c]);
-              double vbn = vdot(vsub(vb2, vb1), n);
-              double vrn = vdot(vr, n);
-              double vrt = vdot(vr, vperp(n));
-              double jbn = (bias[c] - vbn) * nMass[c];
-              double jbnOld = jBias[c];
-              jBias[c] = fmax_cp(jbnOld + jbn, 0.0);
-              double jnn = -(bounce[c] + vrn) * nMass[c];
-              double jnOld = jn[c];
-              jn[c] = fmax_cp(jnOld + jnn, 0.0);
-              double jtMax = arb_u * jn[c];
-              double jtt = -vrt * tMass[c];
-              double jtOld = jt[c];
-              jt[c] = fclamp_cp(jtOld + jtt, -jtMax, jtMax);
-              V2 jb = vmul(n, jBias[c] - jbnOld);
-              apply_bias_impulse(a, vneg(jb), r1[c]);
-              apply_bias_impulse(b, jb, r2[c]);
-              V2 jj = vrotate(n, v2(jn[c] - jnOld, jt[c] - jtOld));
-              apply_impulse(a, vneg(jj), r1[c]);
-              apply_impulse(b, jj, r2[c]);
-            }
-          }
+          arb_apply_impulse(a, b, n, r1, r2, nMass, tMass, bias, bounce, jBias, jn, jt, a_count, arb_u);
           body_store_vel(L, bodyA, a);
           body_store_vel(L, bodyB, b);
         }
@@ -935,22 +1001,6 @@ DRV_PROF(if (lane < 8 && e < 4096) g_dbgp[e * 8 + lane] = 0ull;)
   const bool isBody = isCar || isPed;
   load_env(S, L, e, lane, A, nPed, nObst, occ);
 
-  // my 8 candidate pairs (canonical order index = round*64 + lane), packed 4 x u16 per 64-bit register so that the
-  // round loop can select one without dynamically indexed registers (no scratch)
-  uint64_t pairLo = 0ull, pairHi = 0ull;
-#pragma unroll
-  for (int t = 0; t < DRV_NPAIR_ROUNDS; ++t) {
-    int pr = C.pairs[t * 64 + lane];
-    int i = pr >> 8, j = pr & 0xFF;
-    bool ok = (pr != 0xFFFF) && i < A;
-    if (ok) {
-      if (j < DRV_SLOT_PED) ok = j < A;
-      else if (j < DRV_SLOT_OBST) ok = (j - DRV_SLOT_PED) < nPed;
-      else if (j < DRV_SLOT_BLD) ok = (j - DRV_SLOT_OBST) < nObst;
-    }
-    uint64_t v = (uint64_t)(ok ? pr : 0xFFFF);
-    if (t < 4) pairLo |= v << (16 * t); else pairHi |= v << (16 * (t - 4));
-  }
   int act0 = 1, act1 = 1;
   if (isCar) { act0 = actions[((size_t)e * A + lane) * 2 + 0]; act1 = actions[((size_t)e * A + lane) * 2 + 1]; }
   double rew = 0.0, posrew = 0.0, teamReward = 0.0;  // :252-254
@@ -961,10 +1011,12 @@ DRV_PROF(if (lane < 8 && e < 4096) g_dbgp[e * 8 + lane] = 0ull;)
   bool inertAll = (uniform_i(envi[EI_PAD]) & 1) != 0;
   // steady-replay state: the contact path ran (or was replayed) in the previous substep and reported every slot steady
   bool steadyAll = (uniform_i(envi[EI_PAD]) & 2) != 0;
-  int nFast = 0, nQuiet = 0, nContact = 0, nSlots = 0, nWhyCand = 0, nWhyMoving = 0, nWhyInert = 0, nSteady = 0;  // diagnostics
+  int nFast = 0, nQuiet = 0, nContact = 0, nSlots = 0, nWhyCand = 0, nWhyMoving = 0, nWhyInert = 0, nSteady = 0, nLight = 0;  // diagnostics
   __syncthreads();
 
+DRV_PROF(const unsigned long long K0 = __builtin_amdgcn_s_memtime(); unsigned long long tPh1 = 0, tBroad = 0, tFast = 0, tCont = 0, tBook = 0;)
   for (int it = 0; it < 10; ++it) {
+DRV_PROF(const unsigned long long A0 = __builtin_amdgcn_s_memtime();)
     // ======== phase 1a: car game logic (processAction at substep 0, tick) ===================================
     bool turned = false;  // Car.turn rotated the body in place: geometry changed even if every velocity is zero
     if (isCar) {
@@ -1096,7 +1148,6 @@ DRV_PROF(if (lane < 8 && e < 4096) g_dbgp[e * 8 + lane] = 0ull;)
       // frozen: at rest and the position update was absorbed by rounding (sub-ulp bias velocities of a resting contact)
       const bool frozen = !turned && vx == 0.0 && vy == 0.0 && w == 0.0 && npx == px && npy == py && nang == ang;
       L.still[lane] = (still ? 1 : 0) | (frozen ? 2 : 0);
-      float fcx = (float)npx, fcy = (float)npy, fhx = 6.0f, fhy = 6.0f;  // pedestrian circle r = 5 (+1 px margin)
       if (isCar) {
         if (nang != L.rotAng[lane]) car_refresh_rot(L, lane, nang);
         if (!aabbValid || !frozen) {  // frozen: same position and rotation => same box
@@ -1109,50 +1160,48 @@ DRV_PROF(if (lane < 8 && e < 4096) g_dbgp[e * 8 + lane] = 0ull;)
           }
           L.aabb[lane][0] = l - 0.0; L.aabb[lane][1] = b - 0.0; L.aabb[lane][2] = r + 0.0; L.aabb[lane][3] = t + 0.0;
         }
-        const double al = L.aabb[lane][0], ab = L.aabb[lane][1], ar = L.aabb[lane][2], at = L.aabb[lane][3];
-        fcx = (float)(0.5 * (al + ar)); fcy = (float)(0.5 * (ab + at));
-        fhx = (float)(0.5 * (ar - al)) + 1.0f; fhy = (float)(0.5 * (at - ab)) + 1.0f;
       }
-      L.u.pf.cx[lane] = fcx; L.u.pf.cy[lane] = fcy; L.u.pf.hx[lane] = fhx; L.u.pf.hy[lane] = fhy;
     }
     aabbValid = true;
     __syncthreads();
 
-    // ======== phase 2: broadphase on my 8 pairs: fp32 conservative prefilter, then the exact AABB test ==========
+DRV_PROF(const unsigned long long A1 = __builtin_amdgcn_s_memtime();)
+    // ======== phase 2: broadphase.  Lane = object j (slot id: cars, pedestrians, obstacles, buildings); the loop runs over
+    // the cars i < j whose box is broadcast from LDS.  cand bit i <=> cpBBIntersects(bb_i, bb_j) for the canonical pair
+    // (i, j); the pairs of one car are consecutive in canonical order and ascend with the lane.
     int cand = 0;
-    bool candMoving = false, candThawed = false;
-#pragma unroll 2
-    for (int t = 0; t < DRV_NPAIR_ROUNDS; ++t) {
-      const int pr = MY_PAIR(t);
-      if (pr != 0xFFFF) {
-        const int i = pr >> 8, j = pr & 0xFF;
-        float bx, by, bhx, bhy;
-        if (j < DRV_SLOT_OBST) { bx = L.u.pf.cx[j]; by = L.u.pf.cy[j]; bhx = L.u.pf.hx[j]; bhy = L.u.pf.hy[j]; }
-        else {
-          const V2 c = static_pos(L, j);
-          bx = (float)c.x; by = (float)c.y;
-          bhx = j >= DRV_SLOT_BLD ? 401.0f : 11.0f; bhy = j >= DRV_SLOT_BLD ? 226.0f : 11.0f;
-        }
-        const float dx = L.u.pf.cx[i] - bx, dy = L.u.pf.cy[i] - by;
-        if (__builtin_fabsf(dx) <= L.u.pf.hx[i] + bhx && __builtin_fabsf(dy) <= L.u.pf.hy[i] + bhy) {
-          const double al = L.aabb[i][0], ab = L.aabb[i][1], ar = L.aabb[i][2], at = L.aabb[i][3];
-          double bl, bb, br, bt;
-          if (j < DRV_SLOT_PED) { bl = L.aabb[j][0]; bb = L.aabb[j][1]; br = L.aabb[j][2]; bt = L.aabb[j][3]; }
-          else if (j < DRV_SLOT_OBST) { double cx = L.px[j], cy = L.py[j]; bl = cx - 5.0; bb = cy - 5.0; br = cx + 5.0; bt = cy + 5.0; }
-          else {
-            const V2 c = static_pos(L, j);
-            const double ex = j >= DRV_SLOT_BLD ? 400.0 : 10.0, ey = j >= DRV_SLOT_BLD ? 225.0 : 10.0;
-            // static box AABB = min/max of (c +- e) exactly as cached by cpShapeCacheBB with rot = (1,0)
-            bl = -ex + c.x; br = ex + c.x; bb = -ey + c.y; bt = ey + c.y;
-          }
-          if (al <= br && bl <= ar && ab <= bt && bb <= at) {
-            cand |= (1 << t);
-            const int si = L.still[i], sj = j >= DRV_SLOT_OBST ? 3 : L.still[j];
-            if (!(si & sj & 1)) candMoving = true;
-            if (!(si & sj & 2)) candThawed = true;
-          }
-        }
+    bool candMoving = false, removed = false;
+    int dirty = 0;
+    {
+      double bl = 0.0, bb = 0.0, br = -1.0, bt = -1.0;
+      bool live = false;
+      int sj = 3;  // statics are always still and frozen
+      if (lane < DRV_SLOT_PED) {
+        live = isCar; sj = L.still[lane];
+        bl = L.aabb[lane][0]; bb = L.aabb[lane][1]; br = L.aabb[lane][2]; bt = L.aabb[lane][3];
+      } else if (lane < DRV_SLOT_OBST) {
+        live = isPed; sj = L.still[lane];
+        const double cx = L.px[lane], cy = L.py[lane];
+        bl = cx - 5.0; bb = cy - 5.0; br = cx + 5.0; bt = cy + 5.0;
+      } else if (lane < DRV_SLOT_BLD + 4) {
+        live = lane >= DRV_SLOT_BLD || (lane - DRV_SLOT_OBST) < nObst;
+        const V2 c = static_pos(L, lane);
+        const double ex = lane >= DRV_SLOT_BLD ? 400.0 : 10.0, ey = lane >= DRV_SLOT_BLD ? 225.0 : 10.0;
+        // static box AABB = min/max of (c +- e) exactly as cached by cpShapeCacheBB with rot = (1,0)
+        bl = -ex + c.x; br = ex + c.x; bb = -ey + c.y; bt = ey + c.y;
       }
+      const int carStill = (int)(wave_ballot(isCar && (sj & 1)) & 0x3FFull);
+      const int carFrozen = (int)(wave_ballot(isCar && (sj & 2)) & 0x3FFull);
+#pragma unroll 5
+      for (int i = 0; i < DRV_MAXA; ++i) {  // rows >= A are never written but in bounds: the loads pipeline unconditionally
+        const double al = L.aabb[i][0], ab = L.aabb[i][1], ar = L.aabb[i][2], at = L.aabb[i][3];
+        if (live && i < A && lane > i && al <= br && bl <= ar && ab <= bt && bb <= at) cand |= (1 << i);
+      }
+      if (cand) candMoving = !(sj & 1) || (cand & ~carStill) != 0;
+      // clean pair: a candidate in the previous substep too, both bodies frozen since.  dirty: every other candidate.
+      const int clean = (lastCand >= 0 && (sj & 2)) ? (cand & lastCand & carFrozen) : 0;
+      dirty = cand & ~clean;
+      removed = lastCand < 0 || (lastCand & ~cand) != 0;
     }
     const uint64_t anyCand = wave_ballot(cand != 0);
     // Quiescent contact set: same candidate pairs as in the previous substep, every body in them exactly at rest and
@@ -1164,36 +1213,49 @@ DRV_PROF(if (lane < 8 && e < 4096) g_dbgp[e * 8 + lane] = 0ull;)
     // Steady replay: the contact path of the previous substep reported every slot steady, the candidate set is the
     // same and every body in it is frozen => this substep's contact path would read the same inputs and reproduce the
     // same outputs: slots unchanged, velocities stay zero, bias velocities equal to the saved ones.
-    const bool replay = !quiescent && steadyAll && !candChanged && wave_ballot(candThawed) == 0ull;
+    // If some pairs are dirty, the contact path first tests only those ("light" mode) and falls back to the full path
+    // when one of them touches or owns a slot.
+    const bool steadyOk = !quiescent && steadyAll && wave_ballot(removed) == 0ull;
+    const bool anyDirty = wave_ballot(dirty != 0) != 0ull;
+    bool replay = steadyOk && !anyDirty;
+    const bool light = steadyOk && anyDirty;
     if (!(anyCand == 0ull && occ == 0ull) && !quiescent && !replay) { if (candChanged) nWhyCand++; else if (anyMoving) nWhyMoving++; else nWhyInert++; }
     lastCand = cand;
-    __syncthreads();  // the prefilter aliases the contact mailbox
 
+DRV_PROF(const unsigned long long A2 = __builtin_amdgcn_s_memtime(); bool tookContact = false;)
     if (anyCand == 0ull && occ == 0ull) nFast++; else if (quiescent) nQuiet++; else if (replay) nSteady++; else nContact++;
     nSlots += __popcll(occ);
     if ((anyCand == 0ull && occ == 0ull) || quiescent) {
       // ---------- fast path: nothing touches and the contact cache is empty (or quiescent): velocity update only
       velocity_update(L, lane, isCar, isPed);
       if (anyCand == 0ull && occ == 0ull) steadyAll = false;
-    } else if (replay) {
+    } else if (!replay) {
+      // ---------- contact path (out of line): narrowphase -> contact cache -> callbacks -> prestep -> friction -> solver
+DRV_PROF(tookContact = true;)
+      ContactRet cr = drv_contact_path(lane, cand, dirty, light ? 1 : 0, A, occ, rew, isCar, isPed);
+      err |= cr.err & 1;
+      if (uniform_i(cr.err >> 3) & 1) {  // light mode: no dirty pair touches => replay
+        replay = true; nLight++;
+      } else {
+        occ = uniform_u64(cr.occ); rew = cr.rew;
+        inertAll = (uniform_i(cr.err >> 1) & 1) != 0;
+        steadyAll = (uniform_i(cr.err >> 2) & 1) != 0;
+        if (steadyAll && isBody) {  // bias velocities this solve produced: what a replay has to reinstate
+          double* vb = S.vbout + (size_t)e * 96 + lane;
+          vb[0] = L.vbx[lane]; vb[32] = L.vby[lane]; vb[64] = L.wb[lane];
+        }
+      }
+    }
+    if (replay) {
       velocity_update(L, lane, isCar, isPed);
       if (isBody) {
         const double* vb = S.vbout + (size_t)e * 96 + lane;
         L.vbx[lane] = vb[0]; L.vby[lane] = vb[32]; L.wb[lane] = vb[64];
       }
-    } else {
-      // ---------- contact path (out of line): narrowphase -> contact cache -> callbacks -> prestep -> friction -> solver
-      ContactRet cr = drv_contact_path(lane, cand, pairLo, pairHi, occ, rew, isCar, isPed);
-      occ = uniform_u64(cr.occ); rew = cr.rew; err |= cr.err & 1;
-      inertAll = (uniform_i(cr.err >> 1) & 1) != 0;
-      steadyAll = (uniform_i(cr.err >> 2) & 1) != 0;
-      if (steadyAll && isBody) {  // bias velocities this solve produced: what a replay has to reinstate
-        double* vb = S.vbout + (size_t)e * 96 + lane;
-        vb[0] = L.vbx[lane]; vb[32] = L.vby[lane]; vb[64] = L.wb[lane];
-      }
     }
     __syncthreads();
 
+DRV_PROF(const unsigned long long A3 = __builtin_amdgcn_s_memtime(); tPh1 += A1 - A0; tBroad += A2 - A1; if (tookContact) tCont += A3 - A2; else tFast += A3 - A2;)
     // ======== bookkeeping :280-287 =========================================================================
     elapsed += 1;
     bool notDone = false;
@@ -1205,6 +1267,7 @@ DRV_PROF(if (lane < 8 && e < 4096) g_dbgp[e * 8 + lane] = 0ull;)
     }
   }
 
+DRV_PROF(const unsigned long long K1 = __builtin_amdgcn_s_memtime();)
   // ---------------- end of env step :300-322 ----------------------------------------------------------------
   if (isCar) {
     rew += teamReward;
@@ -1219,7 +1282,7 @@ DRV_PROF(if (lane < 8 && e < 4096) g_dbgp[e * 8 + lane] = 0ull;)
     dones[e] = (uint8_t)(elapsed >= DRV_MAX_TIME);
     envi[EI_ELAPSED] = elapsed; envi[EI_ALLFIN] = allFinished; envi[EI_OCC] = (int)(uint32_t)occ;
     envi[EI_PAD] = (inertAll ? 1 : 0) | (steadyAll ? 2 : 0);
-    envi[EI_N_STEADY] += nSteady;
+    envi[EI_N_STEADY] += nSteady; envi[EI_N_LIGHT] += nLight;
     envi[EI_N_WHY_CAND] += nWhyCand; envi[EI_N_WHY_MOVING] += nWhyMoving; envi[EI_N_WHY_INERT] += nWhyInert;
     envi[EI_N_FAST] += nFast; envi[EI_N_QUIET] += nQuiet; envi[EI_N_CONTACT] += nContact; envi[EI_N_SLOTS] += nSlots;
   }
@@ -1228,7 +1291,7 @@ DRV_PROF(if (lane < 8 && e < 4096) g_dbgp[e * 8 + lane] = 0ull;)
   S.lastcand[(size_t)e * 64 + lane] = lastCand;
   store_env(S, L, e, lane, A, nPed, occ);
   if (obs) write_full_obs(L, lane, A, nPed, nObst, S.obs_dim, obs + (size_t)e * A * S.obs_dim);
-DRV_PROF(if (lane == 0 && e < 4096) { g_dbgw[e * 4] = __builtin_amdgcn_s_memtime() - KS; g_dbgw[e * 4 + 1] = nContact; g_dbgw[e * 4 + 2] = __popcll(occ); g_dbgw[e * 4 + 3] = nSteady + nQuiet; })
+DRV_PROF(if (lane == 0 && e < 4096) { unsigned long long* d = g_dbgw + e * 12; const unsigned long long KE = __builtin_amdgcn_s_memtime(); d[0] = KE - KS; d[1] = nContact; d[2] = __popcll(occ); d[3] = nSteady + nQuiet; d[4] = K0 - KS; d[5] = tPh1; d[6] = tBroad; d[7] = tFast; d[8] = tCont; d[9] = (K1 - K0) - tPh1 - tBroad - tFast - tCont; d[10] = KE - K1; d[11] = 0; })
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1339,7 +1402,7 @@ extern "C" __global__ void __launch_bounds__(64) drv_reset_kernel(DrvState S) {
   envi[EI_ELAPSED] = 0; envi[EI_ALLFIN] = 0; envi[EI_NPED] = nPed; envi[EI_NOBST] = nObst;
   envi[EI_EPISODE] = (int)(ep + 1); envi[EI_OCC] = 0; envi[EI_ERR] = 0;
   envi[EI_N_FAST] = 0; envi[EI_N_QUIET] = 0; envi[EI_N_CONTACT] = 0; envi[EI_N_SLOTS] = 0; envi[EI_PAD] = 0;
-  envi[EI_N_STEADY] = 0;
+  envi[EI_N_STEADY] = 0; envi[EI_N_LIGHT] = 0;
   envi[EI_N_WHY_CAND] = 0; envi[EI_N_WHY_MOVING] = 0; envi[EI_N_WHY_INERT] = 0;
   for (int k = 0; k < 64; ++k) S.lastcand[(size_t)e * 64 + k] = -1;
 }

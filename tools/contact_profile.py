@@ -6,10 +6,10 @@ import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PROF = os.path.join(ROOT, "dynenv_amd", "libdynenv_hip_prof.so")
+os.environ["DYNENV_HIP_LIB"] = PROF  # read by dynenv_amd._capi at import
 from dynenv_amd import build as _b
 if not os.path.exists(PROF) or any(os.path.getmtime(d) > os.path.getmtime(PROF) for d in _b.DEPS if os.path.exists(d)):
     _b.build(out=PROF, defines=("DRV_PROFILE",))
-os.environ["DYNENV_HIP_LIB"] = PROF
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 os.chdir(ROOT)
 import torch, numpy as np
@@ -35,7 +35,9 @@ for o in range(0, 25):
     mm = m & (d[:, 2] == o)
     if mm.any(): print("nContact=10 occ=%d n=%d mean %.0f" % (o, mm.sum(), c[mm].mean()))
 p = np.loadtxt("gpurun_out/dbgp.txt")
-print("top envs: total | narrow slots prestep velupd solver | calls levels touched")
-for k in top[:10]: print(int(c[k]), p[k].astype(int))
+print("top envs: total | load phase1 broad fast contact book store+obs | narrow slots prestep velupd solver | calls levels touched")
+for k in top[:10]: print(int(c[k]), d[k, 4:11].astype(int), p[k].astype(int))
 m = d[:, 1] == 10
-print("mean over nContact=10 envs:", p[m].mean(0).astype(int), "total", int(c[m].mean()))
+print("mean over nContact=10 envs:", d[m, 4:11].mean(0).astype(int), p[m].mean(0).astype(int), "total", int(c[m].mean()))
+m0 = d[:, 1] == 0
+print("mean over nContact=0 envs:", d[m0, 4:11].mean(0).astype(int), "total", int(c[m0].mean()))
