@@ -222,28 +222,45 @@ DE_DEV V2 boxp_normal(const BoxP& b, int i) {
   return v2(b.c * nx - b.s * ny, b.s * nx + b.c * ny);
 }
 
-DE_DEV int poly_support_index(const BoxP& p, V2 n) {
-  double mx = -INFINITY;
-  int index = 0;
-#pragma unroll 1
-  for (int i = 0; i < 4; ++i) {
-    double d = vdot(boxp_vertex(p, i), n);
-    if (d > mx) { mx = d; index = i; }
-  }
+// ---- quad-cooperative narrowphase: 4 adjacent lanes (a DPP quad) work on one pair, lane q owning axis / vertex /
+// edge q.  Every reduction replays the reference's sequential loop (index ascending, strict comparison) on the four
+// per-lane values, so results are bit-identical to the scalar code in oracle/cp_lite.c.  All four lanes of a quad
+// follow the same control flow (every branch condition is quad-uniform), so DPP reads never hit an inactive lane.
+template <int S> DE_DEV double quad_bcast(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, S * 0x55, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, S * 0x55, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// for (i = 0..3) if (v_i > best) { best = v_i; idx = i; }   starting from best = -inf, idx = 0
+DE_DEV void quad_argmax_first(double v, double& best, int& idx) {
+  best = -INFINITY; idx = 0;
+  double m;
+  m = quad_bcast<0>(v); if (m > best) { best = m; idx = 0; }
+  m = quad_bcast<1>(v); if (m > best) { best = m; idx = 1; }
+  m = quad_bcast<2>(v); if (m > best) { best = m; idx = 2; }
+  m = quad_bcast<3>(v); if (m > best) { best = m; idx = 3; }
+}
+
+DE_DEV int poly_support_index(const BoxP& p, V2 n, int q) {
+  double mx;
+  int index;
+  quad_argmax_first(vdot(boxp_vertex(p, q), n), mx, index);
   return index;
 }
 
-DE_DEV EdgeW support_edge_poly(const BoxP& p, int slot, V2 n) {
-  int i1 = poly_support_index(p, n);
+DE_DEV EdgeW support_edge_poly(const BoxP& p, int slot, V2 n, int q) {
+  int i1 = poly_support_index(p, n, q);
   int i0 = (i1 + 3) & 3;
   int i2 = (i1 + 1) & 3;
   int h = slot * 4;
   V2 n1 = boxp_normal(p, i1), n2 = boxp_normal(p, i2);
   EdgeW e;
+  V2 vm = boxp_vertex(p, i1);
   if (vdot(n, n1) > vdot(n, n2)) {
-    e.ap = boxp_vertex(p, i0); e.ah = h + i0; e.bp = boxp_vertex(p, i1); e.bh = h + i1; e.n = n1;
+    e.ap = boxp_vertex(p, i0); e.ah = h + i0; e.bp = vm; e.bh = h + i1; e.n = n1;
   } else {
-    e.ap = boxp_vertex(p, i1); e.ah = h + i1; e.bp = boxp_vertex(p, i2); e.bh = h + i2; e.n = n2;
+    e.ap = vm; e.ah = h + i1; e.bp = boxp_vertex(p, i2); e.bh = h + i2; e.n = n2;
   }
   return e;
 }
@@ -276,48 +293,40 @@ DE_DEV void contact_points(const EdgeW& e1, const EdgeW& e2, V2 n, Contacts& out
   }
 }
 
-DE_DEV double sat_max_sep(const BoxP& a, const BoxP& b, int& best) {
-  double maxsep = -INFINITY;
-  best = 0;
-  V2 bv[4];
+DE_DEV double sat_max_sep(const BoxP& a, const BoxP& b, int q, int& best) {
+  const V2 n = boxp_normal(a, q);
+  const double d0 = vdot(n, boxp_vertex(a, q));
+  double minv = INFINITY;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) bv[j] = boxp_vertex(b, j);
-#pragma unroll 1
-  for (int i = 0; i < 4; ++i) {
-    V2 n = boxp_normal(a, i);
-    double d0 = vdot(n, boxp_vertex(a, i));
-    double minv = INFINITY;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      double d = vdot(n, bv[j]) - d0;
-      if (d < minv) minv = d;
-    }
-    if (minv > maxsep) { maxsep = minv; best = i; }
+  for (int j = 0; j < 4; ++j) {
+    double d = vdot(n, boxp_vertex(b, j)) - d0;
+    if (d < minv) minv = d;
   }
+  double maxsep;
+  quad_argmax_first(minv, maxsep, best);
   return maxsep;
 }
 
-DE_DEV void poly_to_poly(const BoxP& p1, int slot1, const BoxP& p2, int slot2, Contacts& out) {
+DE_DEV void poly_to_poly(const BoxP& p1, int slot1, const BoxP& p2, int slot2, int q, Contacts& out) {
   out.count = 0;
   int ia, ib;
-  double sa = sat_max_sep(p1, p2, ia);
+  double sa = sat_max_sep(p1, p2, q, ia);
   if (sa > 0.0) return;
-  double sb = sat_max_sep(p2, p1, ib);
+  double sb = sat_max_sep(p2, p1, q, ib);
   if (sb > 0.0) return;
   V2 n;
   if (sa >= sb) n = boxp_normal(p1, ia); else n = vneg(boxp_normal(p2, ib));
-  contact_points(support_edge_poly(p1, slot1, n), support_edge_poly(p2, slot2, vneg(n)), n, out);
+  const EdgeW e1 = support_edge_poly(p1, slot1, n, q);
+  const EdgeW e2 = support_edge_poly(p2, slot2, vneg(n), q);
+  contact_points(e1, e2, n, out);
 }
 
-DE_DEV void circle_to_poly(V2 c, double r, const BoxP& poly, Contacts& out) {
+DE_DEV void circle_to_poly(V2 c, double r, const BoxP& poly, int q, Contacts& out) {
   out.count = 0;
-  double maxsep = -INFINITY;
-  int best = 0;
-#pragma unroll 1
-  for (int i = 0; i < 4; ++i) {
-    double d = vdot(boxp_normal(poly, i), vsub(c, boxp_vertex(poly, i)));
-    if (d > maxsep) { maxsep = d; best = i; }
-  }
+  double maxsep;
+  int best;
+  const V2 vq = boxp_vertex(poly, q);
+  quad_argmax_first(vdot(boxp_normal(poly, q), vsub(c, vq)), maxsep, best);
   if (maxsep > r) return;
   if (maxsep <= 0.0) {
     V2 fn = boxp_normal(poly, best);
@@ -325,17 +334,19 @@ DE_DEV void circle_to_poly(V2 c, double r, const BoxP& poly, Contacts& out) {
     V2 pb = vsub(c, vmul(fn, maxsep));
     out.n = n; out.p1[0] = vadd(c, vmul(n, r)); out.p2[0] = pb; out.hash[0] = 0; out.count = 1;
   } else {
+    // lane q: closest point on edge (v[q-1], v[q]); then for (i = 0..3) if (dsq_i < bestd) take it
+    const V2 a = boxp_vertex(poly, (q + 3) & 3), b = vq;
+    const V2 d = vsub(b, a);
+    const double t = fclamp01_cp(vdot(d, vsub(c, a)) / vlensq(d));
+    const V2 pt = vadd(a, vmul(d, t));
+    const double dsq = vlensq(vsub(pt, c));
     double bestd = INFINITY;
     V2 bestp = c;
-#pragma unroll 1
-    for (int i = 0; i < 4; ++i) {
-      V2 a = boxp_vertex(poly, (i + 3) & 3), b = boxp_vertex(poly, i);
-      V2 d = vsub(b, a);
-      double t = fclamp01_cp(vdot(d, vsub(c, a)) / vlensq(d));
-      V2 q = vadd(a, vmul(d, t));
-      double dsq = vlensq(vsub(q, c));
-      if (dsq < bestd) { bestd = dsq; bestp = q; }
-    }
+    double m;
+    m = quad_bcast<0>(dsq); if (m < bestd) { bestd = m; bestp = v2(quad_bcast<0>(pt.x), quad_bcast<0>(pt.y)); }
+    m = quad_bcast<1>(dsq); if (m < bestd) { bestd = m; bestp = v2(quad_bcast<1>(pt.x), quad_bcast<1>(pt.y)); }
+    m = quad_bcast<2>(dsq); if (m < bestd) { bestd = m; bestp = v2(quad_bcast<2>(pt.x), quad_bcast<2>(pt.y)); }
+    m = quad_bcast<3>(dsq); if (m < bestd) { bestd = m; bestp = v2(quad_bcast<3>(pt.x), quad_bcast<3>(pt.y)); }
     if (bestd <= r * r) {
       double dist = dm_sqrt(bestd);
       V2 delta = vsub(bestp, c);
@@ -693,26 +704,27 @@ DRV_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
     if (wave_ballot(owns) != 0ull) continue;
   }
 #pragma unroll 1
-  for (int pass = 0; pass * 64 < nCand; ++pass) {
-    const bool isCand = pass * 64 + lane < nCand;
+  for (int pass = 0; pass * 16 < nCand; ++pass) {  // 16 pairs per pass, one DPP quad of lanes each
+    const int q = lane & 3;
+    const bool isCand = pass * 16 + (lane >> 2) < nCand;
     Contacts ct;
     ct.count = 0;
-    const int pr = isCand ? (int)L.clist[pass * 64 + lane] : 0xFFFF;
+    const int pr = isCand ? (int)L.clist[pass * 16 + (lane >> 2)] : 0xFFFF;
     if (isCand) {
       const int i = pr >> 8, j = pr & 0xFF;
       BoxP b1;
       b1.p = v2(L.px[i], L.py[i]); b1.c = L.rc[i]; b1.s = L.rs[i]; b1.hx = L.chx[i]; b1.hy = L.chy[i];
       if (j >= DRV_SLOT_PED && j < DRV_SLOT_OBST) {
-        circle_to_poly(v2(L.px[j], L.py[j]), 5.0, b1, ct);
+        circle_to_poly(v2(L.px[j], L.py[j]), 5.0, b1, q, ct);
       } else {  // car or static box: one instance of the SAT + clipping code for both
         BoxP b2;
         b2.c = 1.0; b2.s = 0.0;
         if (j < DRV_SLOT_PED) { b2.p = v2(L.px[j], L.py[j]); b2.c = L.rc[j]; b2.s = L.rs[j]; b2.hx = L.chx[j]; b2.hy = L.chy[j]; }
         else { b2.p = static_pos(L, j); b2.hx = j >= DRV_SLOT_BLD ? 400.0 : 10.0; b2.hy = j >= DRV_SLOT_BLD ? 225.0 : 10.0; }
-        poly_to_poly(b1, i, b2, j, ct);
+        poly_to_poly(b1, i, b2, j, q, ct);
       }
     }
-    const bool touch = isCand && ct.count > 0;
+    const bool touch = isCand && q == 0 && ct.count > 0;  // lane 0 of the quad speaks for the pair
     // find my slot among the occupied ones
     int slot = -1;
     if (touch && mode != 0) {
