@@ -378,6 +378,12 @@ DE_DEV void body_load(const DrvLds& L, int idx, BodyV& b) {
     b.p = static_pos(L, idx); b.v = v2(0.0, 0.0); b.w = 0.0; b.vb = v2(0.0, 0.0); b.wb = 0.0; b.minv = 0.0; b.iinv = 0.0;
   }
 }
+// the solver's per-iteration view of a body: p, minv and iinv do not change while a substep is being solved
+DE_DEV void body_load_vel(const DrvLds& L, int idx, BodyV& b) {
+  if (idx < DRV_SLOT_OBST) {
+    b.v = v2(L.vx[idx], L.vy[idx]); b.w = L.w[idx]; b.vb = v2(L.vbx[idx], L.vby[idx]); b.wb = L.wb[idx];
+  }
+}
 DE_DEV void body_store_vel(DrvLds& L, int idx, const BodyV& b) {
   if (idx < DRV_SLOT_OBST) {
     L.vx[idx] = b.v.x; L.vy[idx] = b.v.y; L.w[idx] = b.w; L.vbx[idx] = b.vb.x; L.vby[idx] = b.vb.y; L.wb[idx] = b.wb;
@@ -629,8 +635,23 @@ DE_DEV void arb_apply_impulse(BodyV& a, BodyV& b, V2 n, const V2* r1, const V2* 
     if (c < count) {
       V2 vb1 = vadd(a.vb, vmul(vperp(r1[c]), a.wb));
       V2 vb2 = vadd(b.vb, vmul(vperp(r2[c]), b.wb));
-      V2 vr = relative_velocity(a, b, r1[c], r2[c]);
       double vbn = vdot(vsub(vb2, vb1), n);
+      // Bias-only contact (a resting contact that is still being pushed out of penetration): both bodies have all-zero
+      // (+0) velocities, no accumulated impulse and no bounce.  Then vr = +-0, jn and jt come out as +0 again and the
+      // velocity impulse is +-0, which leaves +0 velocities at +0: the velocity half of the pass is an exact no-op.
+      const long long zbits = __double_as_longlong(a.v.x) | __double_as_longlong(a.v.y) | __double_as_longlong(a.w) |
+                              __double_as_longlong(b.v.x) | __double_as_longlong(b.v.y) | __double_as_longlong(b.w) |
+                              __double_as_longlong(jn[c]) | __double_as_longlong(jt[c]);
+      if (zbits == 0ll && bounce[c] == 0.0) {
+        double jbn = (bias[c] - vbn) * nMass[c];
+        double jbnOld = jBias[c];
+        jBias[c] = fmax_cp(jbnOld + jbn, 0.0);
+        V2 jb = vmul(n, jBias[c] - jbnOld);
+        apply_bias_impulse(a, vneg(jb), r1[c]);
+        apply_bias_impulse(b, jb, r2[c]);
+        continue;
+      }
+      V2 vr = relative_velocity(a, b, r1[c], r2[c]);
       double vrn = vdot(vr, n);
       double vrt = vdot(vr, vperp(n));
       double jbn = (bias[c] - vbn) * nMass[c];
@@ -655,13 +676,17 @@ DE_DEV void arb_apply_impulse(BodyV& a, BodyV& b, V2 n, const V2* r1, const V2* 
 
 DRV_PROF(__device__ unsigned long long g_dbgw[4096 * 12];)
 DRV_PROF(__device__ unsigned long long g_dbgp[4096 * 8];)
+DRV_PROF(__device__ unsigned long long g_dbgr[16];)
+#ifndef DRV_CONTACT_INLINE
+#define DRV_CONTACT_INLINE __noinline__
+#endif
 struct ContactRet {
   uint64_t occ;
   double rew;
   int err;
 };
 
-__device__ __noinline__ ContactRet drv_contact_path(int lane, int cand, int dirty, int light, int A, uint64_t occ,
+__device__ DRV_CONTACT_INLINE ContactRet drv_contact_path(int lane, int cand, int dirty, int light, int A, uint64_t occ,
                                                     double rew, bool isCar, bool isPed) {
   DrvLds& L = g_L;
   int err = 0;
@@ -930,12 +955,13 @@ DRV_PROF(T4 = __builtin_amdgcn_s_memtime();)
     }
 DRV_PROF(T4 = __builtin_amdgcn_s_memtime();)
     // ---- 10 sequential-impulse iterations (cpArbiterApplyImpulse) ---------------------------------------
+    BodyV a, b;
+    if (active) { body_load(L, bodyA, a); body_load(L, bodyB, b); }  // statics stay all-zero; p, minv, iinv are invariant
     for (int iter = 0; iter < 10; ++iter) {
       for (int lv = 0; lv <= maxLevel; ++lv) {
         if (active && myLevel == lv) {
-          BodyV a, b;
-          body_load(L, bodyA, a);
-          body_load(L, bodyB, b);
+          body_load_vel(L, bodyA, a);
+          body_load_vel(L, bodyB, b);
           arb_apply_impulse(a, b, n, r1, r2, nMass, tMass, bias, bounce, jBias, jn, jt, a_count, arb_u);
           body_store_vel(L, bodyA, a);
           body_store_vel(L, bodyB, b);
@@ -964,6 +990,11 @@ DRV_PROF(T4 = __builtin_amdgcn_s_memtime();)
     }
   }
   const bool allSteady = wave_ballot(!steady) == 0ull;
+DRV_PROF(if (slotOcc) { int why = 0; const int pi = a_pair >> 8, pj = a_pair & 0xFF;
+  if (steady) why = 0; else if (!touched) why = 1; else if (freeMe) why = 2; else if (!hashSame) why = 3; else if (a_state != ARB_NORMAL || !wasNormal) why = 4;
+  else if (!restIn) why = 5; else if (!(L.s_jn0[lane] == jn[0] && L.s_jt0[lane] == jt[0] && L.s_jn1[lane] == jn[1] && L.s_jt1[lane] == jt[1])) why = 6; else why = 7;
+  atomicAdd(&g_dbgr[why], 1ull);
+  if (why == 6) { if (L.s_jn0[lane] == 0.0 && L.s_jn1[lane] == 0.0) atomicAdd(&g_dbgr[8], 1ull); if (pj >= DRV_SLOT_PED && pj < DRV_SLOT_OBST) atomicAdd(&g_dbgr[9], 1ull); else if (pj < DRV_SLOT_PED) atomicAdd(&g_dbgr[10], 1ull); else atomicAdd(&g_dbgr[11], 1ull); if (jn[0] != 0.0 || jn[1] != 0.0) atomicAdd(&g_dbgr[12], 1ull); } })
   if (slotOcc) {
     if (freeMe) L.s_pair[lane] = 0xFFFF;
     L.s_meta[lane] = a_state | (a_count << 8) | (a_age << 16);

@@ -41,3 +41,8 @@ m = d[:, 1] == 10
 print("mean over nContact=10 envs:", d[m, 4:11].mean(0).astype(int), p[m].mean(0).astype(int), "total", int(c[m].mean()))
 m0 = d[:, 1] == 0
 print("mean over nContact=0 envs:", d[m0, 4:11].mean(0).astype(int), "total", int(c[m0].mean()))
+r = np.loadtxt("gpurun_out/dbgr.txt")
+names = ["steady", "untouched", "freed", "contact ids changed", "first contact / not NORMAL", "bodies moving before prestep",
+         "accumulated impulses changed", "bodies moving after solve", "(6) with zero stored jn", "(6) car-ped", "(6) car-car", "(6) car-static", "(6) jn != 0 after"]
+print("slot outcomes over the whole run (per slot per contact-path call):")
+for n, v in zip(names, r): print("  %-34s %d" % (n, v))
