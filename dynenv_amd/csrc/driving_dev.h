@@ -79,6 +79,5 @@ struct DrvState {
   int* s_meta;    /* [E][NS]  state | count<<8 | age<<16 */
   uint32_t* s_hash; /* [2][E][NS] */
   double* s_imp;  /* [4][E][NS] jn0 jt0 jn1 jt1 */
-  int* lastcand;  /* [E][64] per-lane candidate mask of the last substep (-1 = unknown); envi[EI_PAD] = inert | steady<<1 */
-  double* vbout;  /* [E][3][32] bias velocities (vbx, vby, wb) left by the last steady contact solve, for replays */
+  int* lastcand;  /* [E][64] per-lane candidate mask of the last substep (-1 = unknown); envi[EI_PAD] = inert | steady<<1 | vbValid<<2 */
 };

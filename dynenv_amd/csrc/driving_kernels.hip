@@ -797,6 +797,7 @@ DRV_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
     ret.occ = occ; ret.rew = rew; ret.err = err | 8;
     return ret;
   }
+  if (isCar || isPed) { L.vbx[lane] = 0.0; L.vby[lane] = 0.0; L.wb[lane] = 0.0; }  // bias velocities restart from zero
 
 DRV_PROF(const unsigned long long T1 = __builtin_amdgcn_s_memtime();)
   // ---- slot lanes: cpArbiterUpdate for touched slots; ageing / expiry for the rest ----------------------
@@ -1054,6 +1055,7 @@ DRV_PROF(if (lane < 8 && e < 4096) g_dbgp[e * 8 + lane] = 0ull;)
   bool inertAll = (uniform_i(envi[EI_PAD]) & 1) != 0;
   // steady-replay state: the contact path ran (or was replayed) in the previous substep and reported every slot steady
   bool steadyAll = (uniform_i(envi[EI_PAD]) & 2) != 0;
+  bool vbValid = (uniform_i(envi[EI_PAD]) & 4) != 0;
   int nFast = 0, nQuiet = 0, nContact = 0, nSlots = 0, nWhyCand = 0, nWhyMoving = 0, nWhyInert = 0, nSteady = 0, nLight = 0;  // diagnostics
   __syncthreads();
 
@@ -1183,11 +1185,12 @@ DRV_PROF(const unsigned long long A0 = __builtin_amdgcn_s_memtime();)
     if (isBody) {
       const double px = L.px[lane], py = L.py[lane], ang = L.ang[lane];
       const double vx = L.vx[lane], vy = L.vy[lane], w = L.w[lane];
-      const double vbx = L.vbx[lane], vby = L.vby[lane], wb = L.wb[lane];
+      // bias velocities: L.vb* keep the output of the last contact solve (a replay needs it again); they count only if
+      // the previous substep solved or replayed contacts (vbValid), else cpBodyUpdatePosition saw zeros
+      const double vbx = vbValid ? L.vbx[lane] : 0.0, vby = vbValid ? L.vby[lane] : 0.0, wb = vbValid ? L.wb[lane] : 0.0;
       const double npx = px + (vx + vbx) * DE_DT, npy = py + (vy + vby) * DE_DT, nang = ang + (w + wb) * DE_DT;
       const bool still = !turned && vx == 0.0 && vy == 0.0 && w == 0.0 && vbx == 0.0 && vby == 0.0 && wb == 0.0;
       L.px[lane] = npx; L.py[lane] = npy; L.ang[lane] = nang;
-      L.vbx[lane] = 0.0; L.vby[lane] = 0.0; L.wb[lane] = 0.0;
       // frozen: at rest and the position update was absorbed by rounding (sub-ulp bias velocities of a resting contact)
       const bool frozen = !turned && vx == 0.0 && vy == 0.0 && w == 0.0 && npx == px && npy == py && nang == ang;
       L.still[lane] = (still ? 1 : 0) | (frozen ? 2 : 0);
@@ -1272,6 +1275,7 @@ DRV_PROF(const unsigned long long A2 = __builtin_amdgcn_s_memtime(); bool tookCo
       // ---------- fast path: nothing touches and the contact cache is empty (or quiescent): velocity update only
       velocity_update(L, lane, isCar, isPed);
       if (anyCand == 0ull && occ == 0ull) steadyAll = false;
+      vbValid = false;  // nothing was solved: the next position update sees zero bias velocities
     } else if (!replay) {
       // ---------- contact path (out of line): narrowphase -> contact cache -> callbacks -> prestep -> friction -> solver
 DRV_PROF(tookContact = true;)
@@ -1283,18 +1287,12 @@ DRV_PROF(tookContact = true;)
         occ = uniform_u64(cr.occ); rew = cr.rew;
         inertAll = (uniform_i(cr.err >> 1) & 1) != 0;
         steadyAll = (uniform_i(cr.err >> 2) & 1) != 0;
-        if (steadyAll && isBody) {  // bias velocities this solve produced: what a replay has to reinstate
-          double* vb = S.vbout + (size_t)e * 96 + lane;
-          vb[0] = L.vbx[lane]; vb[32] = L.vby[lane]; vb[64] = L.wb[lane];
-        }
+        vbValid = true;
       }
     }
-    if (replay) {
+    if (replay) {  // L.vb* still hold the bias velocities of the solve being replayed
       velocity_update(L, lane, isCar, isPed);
-      if (isBody) {
-        const double* vb = S.vbout + (size_t)e * 96 + lane;
-        L.vbx[lane] = vb[0]; L.vby[lane] = vb[32]; L.wb[lane] = vb[64];
-      }
+      vbValid = true;
     }
     __syncthreads();
 
@@ -1324,7 +1322,7 @@ DRV_PROF(const unsigned long long K1 = __builtin_amdgcn_s_memtime();)
   if (lane == 0) {
     dones[e] = (uint8_t)(elapsed >= DRV_MAX_TIME);
     envi[EI_ELAPSED] = elapsed; envi[EI_ALLFIN] = allFinished; envi[EI_OCC] = (int)(uint32_t)occ;
-    envi[EI_PAD] = (inertAll ? 1 : 0) | (steadyAll ? 2 : 0);
+    envi[EI_PAD] = (inertAll ? 1 : 0) | (steadyAll ? 2 : 0) | (vbValid ? 4 : 0);
     envi[EI_N_STEADY] += nSteady; envi[EI_N_LIGHT] += nLight;
     envi[EI_N_WHY_CAND] += nWhyCand; envi[EI_N_WHY_MOVING] += nWhyMoving; envi[EI_N_WHY_INERT] += nWhyInert;
     envi[EI_N_FAST] += nFast; envi[EI_N_QUIET] += nQuiet; envi[EI_N_CONTACT] += nContact; envi[EI_N_SLOTS] += nSlots;

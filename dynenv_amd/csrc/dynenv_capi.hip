@@ -328,7 +328,6 @@ int dynenv_create(const dynenv_cfg_t* cfg, dynenv_t** out) {
   rc |= dev_alloc(h, &S.s_hash, 2 * E * DRV_NS);
   rc |= dev_alloc(h, &S.s_imp, 4 * E * DRV_NS);
   rc |= dev_alloc(h, &S.lastcand, E * 64);
-  rc |= dev_alloc(h, &S.vbout, (size_t)E * 96);
   if (rc) { dynenv_destroy(h); return DYNENV_ERR_HIP; }
   DrvConst c;
   build_consts(c);
