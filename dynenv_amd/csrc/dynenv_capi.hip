@@ -486,7 +486,14 @@ int dynenv_error_flags(dynenv_t* h, int32_t* out) {
 // steady replays, 0...}
 int dynenv_debug_counters(dynenv_t* h, int64_t* out4) {
   if (!h || !out4) return fail(DYNENV_ERR_ARG, "null argument");
-  if (h->robocup) { for (int k = 0; k < 12; ++k) out4[k] = 0; return DYNENV_OK; }
+  if (h->robocup) {
+    for (int k = 0; k < 12; ++k) out4[k] = 0;
+#ifdef DRV_PROFILE
+    HIP_OK(hipDeviceSynchronize());
+    { static unsigned long long d[4096 * 12]; HIP_OK(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_rcprof), sizeof(d))); FILE* f = fopen("gpurun_out/rcprof.txt", "w"); for (int k = 0; k < 4096; ++k) { for (int q = 0; q < 12; ++q) fprintf(f, "%llu ", d[12*k+q]); fprintf(f, "\n"); } fclose(f); }
+#endif
+    return DYNENV_OK;
+  }
   HIP_OK(hipDeviceSynchronize());
   std::vector<int> envi((size_t)h->S.E * EI_COUNT);
   HIP_OK(hipMemcpy(envi.data(), h->S.envi, envi.size() * sizeof(int), hipMemcpyDeviceToHost));

@@ -699,6 +699,126 @@ DE_DEV void pair_material(int i, int j, double& e, double& u) {
 // Space.step(0.01) after the position update: contacts + joints + velocity update + solver + post-solve callbacks.
 // Out of line (large register footprint).  `cand`: my broadphase candidates; returns updated occupancy / error bit.
 // ------------------------------------------------------------------------------------------------
+// the two constraints of one robot (pivot + rotary limit between its feet), cpPivotJoint.c / cpRotaryLimitJoint.c
+struct RcJoint {
+  bool hasPivot, pivotFirst;
+  double kk0, kk1, kk2, kk3, pbx, pby, iSum, rbias, m, i;
+};
+struct RcFeet {
+  double vx0, vy0, w0, vx1, vy1, w1;
+};
+// ord 0 / 1: first / second constraint in the space's constraint order
+DE_DEV void joint_warm_start(const RcJoint& J, RcFeet& f, double jx, double jy, double jr, int ord) {
+  const bool doPivot = (ord == 0) == J.pivotFirst;
+  if (doPivot) {
+    if (J.hasPivot) {
+      const V2 j = vmul(v2(jx, jy), 1.0);
+      f.vx0 = f.vx0 + (-j.x) * J.m; f.vy0 = f.vy0 + (-j.y) * J.m; f.w0 += J.i * vcross(v2(0.0, 0.0), vneg(j));
+      f.vx1 = f.vx1 + j.x * J.m; f.vy1 = f.vy1 + j.y * J.m; f.w1 += J.i * vcross(v2(0.0, 0.0), j);
+    }
+  } else {
+    const double j = jr * 1.0;
+    f.w0 -= j * J.i;
+    f.w1 += j * J.i;
+  }
+}
+DE_DEV void joint_iterate(const RcJoint& J, RcFeet& f, double& jx, double& jy, double& jr, int ord) {
+  const bool doPivot = (ord == 0) == J.pivotFirst;
+  if (doPivot) {
+    if (J.hasPivot) {
+      // relative_velocity with r1 = r2 = 0
+      const V2 v1s = vadd(v2(f.vx0, f.vy0), vmul(vperp(v2(0.0, 0.0)), f.w0));
+      const V2 v2s = vadd(v2(f.vx1, f.vy1), vmul(vperp(v2(0.0, 0.0)), f.w1));
+      const V2 vr = vsub(v2s, v1s);
+      const V2 d = vsub(v2(J.pbx, J.pby), vr);
+      V2 j = v2(d.x * J.kk0 + d.y * J.kk1, d.x * J.kk2 + d.y * J.kk3);
+      const V2 jOld = v2(jx, jy);
+      jx = jx + j.x; jy = jy + j.y;
+      j = vsub(v2(jx, jy), jOld);
+      f.vx0 = f.vx0 + (-j.x) * J.m; f.vy0 = f.vy0 + (-j.y) * J.m; f.w0 += J.i * vcross(v2(0.0, 0.0), vneg(j));
+      f.vx1 = f.vx1 + j.x * J.m; f.vy1 = f.vy1 + j.y * J.m; f.w1 += J.i * vcross(v2(0.0, 0.0), j);
+    }
+  } else if (J.rbias != 0.0) {
+    const double wr = f.w1 - f.w0;
+    double j = -(J.rbias + wr) * J.iSum;
+    const double jOld = jr;
+    if (J.rbias < 0.0) jr = fmax_cp(jOld + j, 0.0); else jr = fmin_cp(jOld + j, 0.0);
+    j = jr - jOld;
+    f.w0 -= j * J.i;
+    f.w1 += j * J.i;
+  }
+}
+
+DE_DEV void joint_prestep(const RcLds& L, int lane, RcJoint& J, double& jx, double& jy, double& jr) {
+  const int la = 2 * lane, lb = 2 * lane + 1;
+  J.hasPivot = !(L.rflags[lane] & RF_JREM);
+  int posP = -1, posR = -1;
+  for (int i = 0; i < L.envi[RE_NCON]; ++i) {
+    const int cid = L.envi[RE_CORDER + i];
+    if (cid == 2 * lane) posP = i;
+    if (cid == 2 * lane + 1) posR = i;
+  }
+  J.pivotFirst = posP < posR;
+  jx = L.jx[lane]; jy = L.jy[lane]; jr = L.jrot[lane];
+  const double ma = rc_minv(la), mb = rc_minv(lb), ia = rc_iinv(la), ib = rc_iinv(lb);
+  J.m = ma; J.i = ia;  // both feet: same mass and inertia
+  J.kk0 = J.kk1 = J.kk2 = J.kk3 = 0.0; J.pbx = J.pby = 0.0;
+  if (J.hasPivot) {
+    // anchors are the body origins (PivotJoint(a, b, pos) with both bodies at pos): r1 = r2 = 0
+    const V2 pr1 = v2(0.0, 0.0), pr2 = v2(0.0, 0.0);
+    const double m_sum = ma + mb;
+    double k11 = m_sum, k12 = 0.0, k21 = 0.0, k22 = m_sum;
+    {
+      const double r1xsq = pr1.x * pr1.x * ia, r1ysq = pr1.y * pr1.y * ia, r1nxy = -pr1.x * pr1.y * ia;
+      k11 += r1ysq; k12 += r1nxy; k21 += r1nxy; k22 += r1xsq;
+    }
+    {
+      const double r2xsq = pr2.x * pr2.x * ib, r2ysq = pr2.y * pr2.y * ib, r2nxy = -pr2.x * pr2.y * ib;
+      k11 += r2ysq; k12 += r2nxy; k21 += r2nxy; k22 += r2xsq;
+    }
+    const double det = k11 * k22 - k12 * k21;
+    const double det_inv = 1.0 / det;
+    J.kk0 = k22 * det_inv; J.kk1 = -k12 * det_inv; J.kk2 = -k21 * det_inv; J.kk3 = k11 * det_inv;
+    const V2 delta = vsub(vadd(v2(L.px[lb], L.py[lb]), pr2), vadd(v2(L.px[la], L.py[la]), pr1));
+    J.pbx = delta.x * (-DE_PIVOT_BIAS_COEF / DE_DT); J.pby = delta.y * (-DE_PIVOT_BIAS_COEF / DE_DT);
+  }
+  {
+    const double dist = L.ang[lb] - L.ang[la];
+    double pdist = 0.0;
+    if (dist > 0.0) pdist = 0.0 - dist; else if (dist < 0.0) pdist = 0.0 - dist;
+    J.iSum = 1.0 / (ia + ib);
+    J.rbias = -DE_JOINT_BIAS_COEF * pdist / DE_DT;
+    if (J.rbias == 0.0) jr = 0.0;
+  }
+}
+
+// The common substep: no active arbiter.  Joints couple only the two feet of one robot, so each robot lane is independent
+// of every other lane: prestep, warm start and all 10 iterations run on registers (same arithmetic as the general path
+// in rc_physics, no LDS round trips, no barriers).  Out of line so that it gets its own small register allocation
+// instead of sharing rc_physics' (whose arbiter state pushed the joint constants to scratch inside the iteration loop).
+__device__ __noinline__ void rc_joints_only(int lane, int R) {
+  RcLds& L = g_R;
+  if (lane < R) {
+    const int la = 2 * lane, lb = 2 * lane + 1;
+    RcJoint J;
+    double jx, jy, jr;
+    joint_prestep(L, lane, J, jx, jy, jr);
+    RcFeet f;
+    f.vx0 = L.vx[la]; f.vy0 = L.vy[la]; f.w0 = L.w[la]; f.vx1 = L.vx[lb]; f.vy1 = L.vy[lb]; f.w1 = L.w[lb];
+    joint_warm_start(J, f, jx, jy, jr, 0); joint_warm_start(J, f, jx, jy, jr, 1);
+#pragma unroll 1
+    for (int iter = 0; iter < 10; ++iter) { joint_iterate(J, f, jx, jy, jr, 0); joint_iterate(J, f, jx, jy, jr, 1); }
+    L.vx[la] = f.vx0; L.vy[la] = f.vy0; L.w[la] = f.w0; L.vx[lb] = f.vx1; L.vy[lb] = f.vy1; L.w[lb] = f.w1;
+    L.jx[lane] = jx; L.jy[lane] = jy; L.jrot[lane] = jr;
+  }
+}
+
+#ifdef DRV_PROFILE
+#define RC_PROF(...) __VA_ARGS__
+#else
+#define RC_PROF(...)
+#endif
+RC_PROF(__device__ unsigned long long g_rcprof[4096 * 12];)
 struct RcStepRet {
   uint64_t occ;
   int err;
@@ -709,6 +829,7 @@ __device__ RC_PHYS_INLINE RcStepRet rc_physics(RcCtx c, int lane, int cand, uint
   RcMailbox& M = L.u.mb;
   int err = 0;
   const bool anyContactWork = wave_ballot(cand != 0) != 0ull || occ != 0ull;
+RC_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
   // --- contact detection / cache -------------------------------------------------------------------------
   bool touched = false, slotOcc = false, freeMe = false, active = false;
   int bodyA = 0, bodyB = 0, a_pair = 0xFFFF, a_state = ARB_FIRST_, a_count = 0, a_age = 0, rank = 0, nTouched = 0;
@@ -889,125 +1010,53 @@ __device__ RC_PHYS_INLINE RcStepRet rc_physics(RcCtx c, int lane, int cand, uint
       }
     }
   }
+RC_PROF(const unsigned long long T1 = __builtin_amdgcn_s_memtime();)
   // --- joints: prestep (cpPivotJoint / cpRotaryLimitJoint preStep), one robot per lane ------------------------
-  const bool isRobot = lane < c.R;
+  const bool jointsOnly = activeMask == 0ull;  // then rc_joints_only() below does prestep + solve out of line
+  // General path: robot r's joints live on lane 32 + r.  Those lanes are never slot lanes (RC_NS <= 32), so the joint's
+  // state OVERLAYS the registers that hold arbiter state on the slot lanes (jn/jt <-> accumulated joint impulses,
+  // nMass/tMass <-> pivot K^-1, bias <-> pivot bias, bounce <-> iSum / rotary bias).  Holding both sets at once pushed
+  // the joint constants to scratch inside the iteration loop.
+  static_assert(RC_NS <= 32, "joint lanes must not be slot lanes");
+  const int rl = lane - 32;
+  const bool isRobot = rl >= 0 && rl < c.R && !jointsOnly;
   bool hasPivot = false, pivotFirst = true;
-  double kk0 = 0.0, kk1 = 0.0, kk2 = 0.0, kk3 = 0.0, pbx = 0.0, pby = 0.0, iSum = 0.0, rbias = 0.0, jx = 0.0, jy = 0.0, jr = 0.0;
   if (isRobot) {
-    const int la = 2 * lane, lb = 2 * lane + 1;
-    hasPivot = !(L.rflags[lane] & RF_JREM);
-    int posP = -1, posR = -1;
-    for (int i = 0; i < L.envi[RE_NCON]; ++i) {
-      const int cid = L.envi[RE_CORDER + i];
-      if (cid == 2 * lane) posP = i;
-      if (cid == 2 * lane + 1) posR = i;
-    }
-    pivotFirst = posP < posR;
-    jx = L.jx[lane]; jy = L.jy[lane]; jr = L.jrot[lane];
-    const double ma = rc_minv(la), mb = rc_minv(lb), ia = rc_iinv(la), ib = rc_iinv(lb);
-    if (hasPivot) {
-      // anchors are the body origins (PivotJoint(a, b, pos) with both bodies at pos): r1 = r2 = 0
-      const V2 pr1 = v2(0.0, 0.0), pr2 = v2(0.0, 0.0);
-      const double m_sum = ma + mb;
-      double k11 = m_sum, k12 = 0.0, k21 = 0.0, k22 = m_sum;
-      {
-        const double r1xsq = pr1.x * pr1.x * ia, r1ysq = pr1.y * pr1.y * ia, r1nxy = -pr1.x * pr1.y * ia;
-        k11 += r1ysq; k12 += r1nxy; k21 += r1nxy; k22 += r1xsq;
-      }
-      {
-        const double r2xsq = pr2.x * pr2.x * ib, r2ysq = pr2.y * pr2.y * ib, r2nxy = -pr2.x * pr2.y * ib;
-        k11 += r2ysq; k12 += r2nxy; k21 += r2nxy; k22 += r2xsq;
-      }
-      const double det = k11 * k22 - k12 * k21;
-      const double det_inv = 1.0 / det;
-      kk0 = k22 * det_inv; kk1 = -k12 * det_inv; kk2 = -k21 * det_inv; kk3 = k11 * det_inv;
-      const V2 delta = vsub(vadd(v2(L.px[lb], L.py[lb]), pr2), vadd(v2(L.px[la], L.py[la]), pr1));
-      pbx = delta.x * (-DE_PIVOT_BIAS_COEF / DE_DT); pby = delta.y * (-DE_PIVOT_BIAS_COEF / DE_DT);
-    }
-    {
-      const double dist = L.ang[lb] - L.ang[la];
-      double pdist = 0.0;
-      if (dist > 0.0) pdist = 0.0 - dist; else if (dist < 0.0) pdist = 0.0 - dist;
-      iSum = 1.0 / (ia + ib);
-      rbias = -DE_JOINT_BIAS_COEF * pdist / DE_DT;
-      if (rbias == 0.0) jr = 0.0;
-    }
+    RcJoint Jp;
+    joint_prestep(L, rl, Jp, jn[0], jn[1], jt[0]);
+    hasPivot = Jp.hasPivot; pivotFirst = Jp.pivotFirst;
+    nMass[0] = Jp.kk0; nMass[1] = Jp.kk1; tMass[0] = Jp.kk2; tMass[1] = Jp.kk3; bias[0] = Jp.pbx; bias[1] = Jp.pby;
+    bounce[0] = Jp.iSum; bounce[1] = Jp.rbias;
   }
+#define RC_JOINT_VIEW(J)                                                                                       \
+  RcJoint J;                                                                                                   \
+  J.hasPivot = hasPivot; J.pivotFirst = pivotFirst; J.kk0 = nMass[0]; J.kk1 = nMass[1]; J.kk2 = tMass[0];      \
+  J.kk3 = tMass[1]; J.pbx = bias[0]; J.pby = bias[1]; J.iSum = bounce[0]; J.rbias = bounce[1];                 \
+  J.m = rc_minv(0); J.i = rc_iinv(0);
   __syncthreads();
+RC_PROF(const unsigned long long T2 = __builtin_amdgcn_s_memtime();)
   // --- velocity update ------------------------------------------------------------------------------------
   if (lane <= RC_BALL && (lane == RC_BALL || lane < 2 * c.R)) rc_velocity_update(L, lane);
   __syncthreads();
-  // --- warm start: arbiters (level by level), then joints ---------------------------------------------------
-  for (int lv = 0; lv <= maxLevel; ++lv) {
-    if (active && myLevel == lv && a_state != ARB_FIRST_) {
-      RBody a, b;
-      rbody_load(L, bodyA, a);
-      rbody_load(L, bodyB, b);
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        if (q < a_count) {
-          V2 j = vrotate(n, v2(jn[q], jt[q]));
-          j = vmul(j, 1.0);
-          rapply_impulse(a, vneg(j), r1[q]);
-          rapply_impulse(b, j, r2[q]);
-        }
-      }
-      rbody_store_vel(L, bodyA, a);
-      rbody_store_vel(L, bodyB, b);
-    }
-    __syncthreads();
-  }
-  if (isRobot) {
-    const int la = 2 * lane, lb = 2 * lane + 1;
-    const double ma = rc_minv(la), mb = rc_minv(lb), ia = rc_iinv(la), ib = rc_iinv(lb);
-    for (int ord = 0; ord < 2; ++ord) {
-      const bool doPivot = (ord == 0) == pivotFirst;
-      if (doPivot) {
-        if (hasPivot) {
-          const V2 j = vmul(v2(jx, jy), 1.0);
-          L.vx[la] = L.vx[la] + (-j.x) * ma; L.vy[la] = L.vy[la] + (-j.y) * ma; L.w[la] += ia * vcross(v2(0.0, 0.0), vneg(j));
-          L.vx[lb] = L.vx[lb] + j.x * mb; L.vy[lb] = L.vy[lb] + j.y * mb; L.w[lb] += ib * vcross(v2(0.0, 0.0), j);
-        }
-      } else {
-        const double j = jr * 1.0;
-        L.w[la] -= j * ia;
-        L.w[lb] += j * ib;
-      }
-    }
-  }
-  __syncthreads();
-  // --- 10 iterations: all arbiters (canonical order via levels), then all constraints ------------------------
-  for (int iter = 0; iter < 10; ++iter) {
+RC_PROF(const unsigned long long T3 = __builtin_amdgcn_s_memtime(); unsigned long long T4 = T3;)
+  const int la = 2 * rl, lb = 2 * rl + 1;
+  if (jointsOnly) {
+RC_PROF(T4 = __builtin_amdgcn_s_memtime();)
+    rc_joints_only(lane, c.R);
+  } else {
+    // --- warm start: arbiters (level by level), then joints -------------------------------------------------
     for (int lv = 0; lv <= maxLevel; ++lv) {
-      if (active && myLevel == lv) {
+      if (active && myLevel == lv && a_state != ARB_FIRST_) {
         RBody a, b;
         rbody_load(L, bodyA, a);
         rbody_load(L, bodyB, b);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           if (q < a_count) {
-            const V2 vb1 = vadd(a.vb, vmul(vperp(r1[q]), a.wb));
-            const V2 vb2 = vadd(b.vb, vmul(vperp(r2[q]), b.wb));
-            const V2 vr = rrelative_velocity(a, b, r1[q], r2[q]);
-            const double vbn = vdot(vsub(vb2, vb1), n);
-            const double vrn = vdot(vr, n);
-            const double vrt = vdot(vr, vperp(n));
-            const double jbn = (bias[q] - vbn) * nMass[q];
-            const double jbnOld = jBias[q];
-            jBias[q] = fmax_cp(jbnOld + jbn, 0.0);
-            const double jnn = -(bounce[q] + vrn) * nMass[q];
-            const double jnOld = jn[q];
-            jn[q] = fmax_cp(jnOld + jnn, 0.0);
-            const double jtMax = arb_u * jn[q];
-            const double jtt = -vrt * tMass[q];
-            const double jtOld = jt[q];
-            jt[q] = fclamp_cp(jtOld + jtt, -jtMax, jtMax);
-            const V2 jb = vmul(n, jBias[q] - jbnOld);
-            rapply_bias_impulse(a, vneg(jb), r1[q]);
-            rapply_bias_impulse(b, jb, r2[q]);
-            const V2 jj = vrotate(n, v2(jn[q] - jnOld, jt[q] - jtOld));
-            rapply_impulse(a, vneg(jj), r1[q]);
-            rapply_impulse(b, jj, r2[q]);
+            V2 j = vrotate(n, v2(jn[q], jt[q]));
+            j = vmul(j, 1.0);
+            rapply_impulse(a, vneg(j), r1[q]);
+            rapply_impulse(b, j, r2[q]);
           }
         }
         rbody_store_vel(L, bodyA, a);
@@ -1016,38 +1065,70 @@ __device__ RC_PHYS_INLINE RcStepRet rc_physics(RcCtx c, int lane, int cand, uint
       __syncthreads();
     }
     if (isRobot) {
-      const int la = 2 * lane, lb = 2 * lane + 1;
-      const double ma = rc_minv(la), mb = rc_minv(lb), ia = rc_iinv(la), ib = rc_iinv(lb);
       for (int ord = 0; ord < 2; ++ord) {
-        const bool doPivot = (ord == 0) == pivotFirst;
-        if (doPivot) {
-          if (hasPivot) {
-            // relative_velocity with r1 = r2 = 0
-            const V2 v1s = vadd(v2(L.vx[la], L.vy[la]), vmul(vperp(v2(0.0, 0.0)), L.w[la]));
-            const V2 v2s = vadd(v2(L.vx[lb], L.vy[lb]), vmul(vperp(v2(0.0, 0.0)), L.w[lb]));
-            const V2 vr = vsub(v2s, v1s);
-            const V2 d = vsub(v2(pbx, pby), vr);
-            V2 j = v2(d.x * kk0 + d.y * kk1, d.x * kk2 + d.y * kk3);
-            const V2 jOld = v2(jx, jy);
-            jx = jx + j.x; jy = jy + j.y;
-            j = vsub(v2(jx, jy), jOld);
-            L.vx[la] = L.vx[la] + (-j.x) * ma; L.vy[la] = L.vy[la] + (-j.y) * ma; L.w[la] += ia * vcross(v2(0.0, 0.0), vneg(j));
-            L.vx[lb] = L.vx[lb] + j.x * mb; L.vy[lb] = L.vy[lb] + j.y * mb; L.w[lb] += ib * vcross(v2(0.0, 0.0), j);
-          }
-        } else if (rbias != 0.0) {
-          const double wr = L.w[lb] - L.w[la];
-          double j = -(rbias + wr) * iSum;
-          const double jOld = jr;
-          if (rbias < 0.0) jr = fmax_cp(jOld + j, 0.0); else jr = fmin_cp(jOld + j, 0.0);
-          j = jr - jOld;
-          L.w[la] -= j * ia;
-          L.w[lb] += j * ib;
-        }
+        RC_JOINT_VIEW(J)
+        RcFeet f;
+        f.vx0 = L.vx[la]; f.vy0 = L.vy[la]; f.w0 = L.w[la]; f.vx1 = L.vx[lb]; f.vy1 = L.vy[lb]; f.w1 = L.w[lb];
+        joint_warm_start(J, f, jn[0], jn[1], jt[0], ord);
+        L.vx[la] = f.vx0; L.vy[la] = f.vy0; L.w[la] = f.w0; L.vx[lb] = f.vx1; L.vy[lb] = f.vy1; L.w[lb] = f.w1;
       }
     }
     __syncthreads();
+RC_PROF(T4 = __builtin_amdgcn_s_memtime();)
+    // --- 10 iterations: all arbiters (canonical order via levels), then all constraints ----------------------
+    for (int iter = 0; iter < 10; ++iter) {
+      for (int lv = 0; lv <= maxLevel; ++lv) {
+        if (active && myLevel == lv) {
+          RBody a, b;
+          rbody_load(L, bodyA, a);
+          rbody_load(L, bodyB, b);
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            if (q < a_count) {
+              const V2 vb1 = vadd(a.vb, vmul(vperp(r1[q]), a.wb));
+              const V2 vb2 = vadd(b.vb, vmul(vperp(r2[q]), b.wb));
+              const V2 vr = rrelative_velocity(a, b, r1[q], r2[q]);
+              const double vbn = vdot(vsub(vb2, vb1), n);
+              const double vrn = vdot(vr, n);
+              const double vrt = vdot(vr, vperp(n));
+              const double jbn = (bias[q] - vbn) * nMass[q];
+              const double jbnOld = jBias[q];
+              jBias[q] = fmax_cp(jbnOld + jbn, 0.0);
+              const double jnn = -(bounce[q] + vrn) * nMass[q];
+              const double jnOld = jn[q];
+              jn[q] = fmax_cp(jnOld + jnn, 0.0);
+              const double jtMax = arb_u * jn[q];
+              const double jtt = -vrt * tMass[q];
+              const double jtOld = jt[q];
+              jt[q] = fclamp_cp(jtOld + jtt, -jtMax, jtMax);
+              const V2 jb = vmul(n, jBias[q] - jbnOld);
+              rapply_bias_impulse(a, vneg(jb), r1[q]);
+              rapply_bias_impulse(b, jb, r2[q]);
+              const V2 jj = vrotate(n, v2(jn[q] - jnOld, jt[q] - jtOld));
+              rapply_impulse(a, vneg(jj), r1[q]);
+              rapply_impulse(b, jj, r2[q]);
+            }
+          }
+          rbody_store_vel(L, bodyA, a);
+          rbody_store_vel(L, bodyB, b);
+        }
+        __syncthreads();
+      }
+      if (isRobot) {
+        for (int ord = 0; ord < 2; ++ord) {
+          RC_JOINT_VIEW(J)
+          RcFeet f;
+          f.vx0 = L.vx[la]; f.vy0 = L.vy[la]; f.w0 = L.w[la]; f.vx1 = L.vx[lb]; f.vy1 = L.vy[lb]; f.w1 = L.w[lb];
+          joint_iterate(J, f, jn[0], jn[1], jt[0], ord);
+          L.vx[la] = f.vx0; L.vy[la] = f.vy0; L.w[la] = f.w0; L.vx[lb] = f.vx1; L.vy[lb] = f.vy1; L.w[lb] = f.w1;
+        }
+      }
+      __syncthreads();
+    }
   }
-  if (isRobot) { L.jx[lane] = jx; L.jy[lane] = jy; L.jrot[lane] = jr; }
+RC_PROF(const unsigned long long T5 = __builtin_amdgcn_s_memtime();)
+  if (isRobot) { L.jx[rl] = jn[0]; L.jy[rl] = jn[1]; L.jrot[rl] = jt[0]; }
+#undef RC_JOINT_VIEW
   // --- post-solve callbacks of the active arbiters, canonical order (scalar, lane 0) -------------------------
   if (anyContactWork) {
     for (int k = 0; k < nTouched; ++k) {
@@ -1067,6 +1148,7 @@ __device__ RC_PHYS_INLINE RcStepRet rc_physics(RcCtx c, int lane, int cand, uint
     occ &= ~wave_ballot(freeMe);
   }
   __syncthreads();
+RC_PROF(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* d = g_rcprof + blockIdx.x * 12; const unsigned long long T6 = __builtin_amdgcn_s_memtime(); d[3] += T1 - T0; d[4] += T2 - T1; d[5] += T3 - T2; d[6] += T4 - T3; d[7] += T5 - T4; d[8] += T6 - T5; d[9] += (unsigned long long)nTouched; d[10] += (unsigned long long)(maxLevel + 1); })
   RcStepRet ret;
   ret.occ = occ; ret.err = err;
   return ret;
@@ -1242,10 +1324,13 @@ rc_step_kernel(RcState S, const int* __restrict__ actions, float* __restrict__ o
   const int* myActions = actions + (size_t)e * R * 4;
   int snap = 0;
 
+RC_PROF(if (lane < 12 && e < 4096) g_rcprof[e * 12 + lane] = 0ull; const unsigned long long K0 = __builtin_amdgcn_s_memtime(); unsigned long long tG = 0, tP = 0, tB = 0;)
   for (int it = 0; it < 50; ++it) {
+RC_PROF(const unsigned long long A0 = __builtin_amdgcn_s_memtime();)
     // ---- sequential game logic (lane 0): processAction / tick per robot, then the ball (:465-475) ----------
     if (lane == 0) rc_game_logic(c, it, myActions);
     __syncthreads();
+RC_PROF(const unsigned long long A1 = __builtin_amdgcn_s_memtime();)
     // ---- cpBodyUpdatePosition + shape cache + AABB ------------------------------------------------------
     if (isBody) {
       const double npx = L.px[lane] + (L.vx[lane] + L.vbx[lane]) * DE_DT;
@@ -1276,6 +1361,7 @@ rc_step_kernel(RcState S, const int* __restrict__ actions, float* __restrict__ o
       L.u.pf.cx[lane] = fcx; L.u.pf.cy[lane] = fcy; L.u.pf.hx[lane] = fhx; L.u.pf.hy[lane] = fhy;
     }
     __syncthreads();
+RC_PROF(const unsigned long long A2 = __builtin_amdgcn_s_memtime();)
     // ---- broadphase ---------------------------------------------------------------------------------------
     int cand = 0;
 #pragma unroll 1
@@ -1297,6 +1383,7 @@ rc_step_kernel(RcState S, const int* __restrict__ actions, float* __restrict__ o
       }
     }
     __syncthreads();
+RC_PROF(const unsigned long long A3 = __builtin_amdgcn_s_memtime(); tG += A1 - A0; tP += A2 - A1; tB += A3 - A2;)
     // ---- contacts, joints, velocity update, solver, post-solve callbacks (out of line) -----------------------
     const RcStepRet sr = rc_physics(c, lane, cand, pairLo, pairHi, occ);
     occ = uniform_u64(sr.occ); err |= sr.err;
@@ -1307,6 +1394,7 @@ rc_step_kernel(RcState S, const int* __restrict__ actions, float* __restrict__ o
       ++snap;
     }
   }
+RC_PROF(if (lane == 0 && e < 4096) { unsigned long long* d = g_rcprof + e * 12; d[0] = tG; d[1] = tP; d[2] = tB; d[11] = __builtin_amdgcn_s_memtime() - K0; })
   // ---- end of env step :497-524 ------------------------------------------------------------------------------
   if (lane < R) {
     const double tr = lane < S.n ? L.teamRew[0] : L.teamRew[1];

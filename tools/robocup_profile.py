@@ -1,0 +1,29 @@
+"""Per-environment cycle breakdown of one RoboCup step (50 substeps) from the -DDRV_PROFILE build.
+Usage (GPU box):  python tools/robocup_profile.py [step]"""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PROF = os.path.join(ROOT, "dynenv_amd", "libdynenv_hip_prof.so")
+os.environ["DYNENV_HIP_LIB"] = PROF
+from dynenv_amd import build as _b
+if not os.path.exists(PROF) or any(os.path.getmtime(d) > os.path.getmtime(PROF) for d in _b.DEPS if os.path.exists(d)):
+    _b.build(out=PROF, defines=("DRV_PROFILE",))
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+os.chdir(ROOT)
+import torch, numpy as np
+from dynenv_amd import BatchedDynEnv, DynEnvType
+STEP = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+env = BatchedDynEnv(DynEnvType.ROBO_CUP, 4096, 5, seed=42)
+env.reset_flat()
+g = torch.Generator(device="cuda"); g.manual_seed(1)
+hi = torch.tensor([5, 3, 3, 7], device="cuda")  # MultiDiscrete([5, 3, 3, 7]) RoboCupEnvironment.py:342
+for s in range(STEP):
+    a = (torch.rand((4096, 10, 4), device="cuda", generator=g) * hi).to(torch.int32)
+    env.step_flat(a)
+env.debug_counters()
+d = np.loadtxt("gpurun_out/rcprof.txt")
+names = ["game logic", "position", "broadphase", "contacts+prestep", "joint prestep", "velocity", "warm start", "solver", "post-solve", "touched", "levels", "TOTAL"]
+print("per-env cycles of one step (50 substeps): mean / p99 / max")
+for k, n in enumerate(names):
+    c = d[:, k]
+    print("  %-18s %10.0f %10.0f %10.0f" % (n, c.mean(), np.percentile(c, 99), c.max()))
