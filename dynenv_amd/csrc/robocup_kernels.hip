@@ -378,24 +378,31 @@ DE_DEV void ball_free_kick_process(RcLds& L, int team) {  // :600-619
   }
 }
 
-DE_DEV void rc_ball_logic(const RcCtx& c, RcLds& L) {  // isBallOutOfField :622-732
-  bool finished = false;
+// isBallOutOfField :622-732, by the whole wave: the scalar decisions are computed redundantly (uniform) by every lane and
+// written by lane 0; the per-robot reward terms run one robot per lane; the two "closest robot" searches replay the
+// reference's ascending strict-< loop over the per-lane distances.
+DE_DEV void rc_ball_logic(const RcCtx& c, RcLds& L, int lane) {
+  bool finished = false, moved = false;
   int team = 0;
   const int n = c.n;
   const V2 pos = v2(L.px[RC_BALL], L.py[RC_BALL]);
   double cr0 = 0.0, cr1 = 0.0;
+  double x = pos.x, y = pos.y;
+  int goal0 = 0, goal1 = 0;
   const double outMin = RC_SIDE - 5.0, outMaxX = RC_W - RC_SIDE + 5.0, outMaxY = RC_H - RC_SIDE + 5.0;
+  const int nlk = L.envi[RE_NLK];
   if (pos.y < outMin || pos.x < outMin || pos.y > outMaxY || pos.x > outMaxX) {
-    double x = RC_W / 2.0, y = RC_H / 2.0;
-    team = L.envi[RE_NLK] ? robot_team(L, L.envi[RE_LK0]) : 1;
+    moved = true;
+    x = RC_W / 2.0; y = RC_H / 2.0;
+    team = nlk ? robot_team(L, L.envi[RE_LK0]) : 1;
     if (pos.y < outMin || pos.y > outMaxY) {
       x = team < 0 ? pos.x + 50.0 : pos.x - 50.0;
       y = pos.y < outMin ? outMin + 5.0 : outMaxY - 5.0;
     } else {
       if (pos.y < RC_H / 2.0 + 80.0 && pos.y > RC_H / 2.0 - 80.0) {
         finished = true;
-        if (pos.x < outMin) { cr0 += -25.0; cr1 += 25.0; L.envi[RE_GOAL1] += 1; }
-        else { cr0 += 25.0; cr1 += -25.0; L.envi[RE_GOAL0] += 1; }
+        if (pos.x < outMin) { cr0 += -25.0; cr1 += 25.0; goal1 = 1; }
+        else { cr0 += 25.0; cr1 += -25.0; goal0 = 1; }
       } else {
         if (pos.x < outMin) {
           if (team < 0) x = RC_SIDE + 60.0;
@@ -406,64 +413,107 @@ DE_DEV void rc_ball_logic(const RcCtx& c, RcLds& L) {  // isBallOutOfField :622-
         }
       }
     }
-    L.px[RC_BALL] = x; L.py[RC_BALL] = y; L.vx[RC_BALL] = 0.0; L.vy[RC_BALL] = 0.0; L.w[RC_BALL] = 0.0;
   }
-  ball_free_kick_process(L, -team);
   if (!finished) {
-    const double d = (L.px[RC_BALL] - L.envd[RD_BPREVX]) / 20.0;
+    const double d = (x - L.envd[RD_BPREVX]) / 20.0;
     cr0 += d;
     cr1 -= d;
   }
-  L.envd[RD_BPREVX] = L.px[RC_BALL]; L.envd[RD_BPREVY] = L.py[RC_BALL];
-  {
+  // per-robot terms (one robot per lane); a robot is either in lastKicked (discounted share) or not (penalty share)
+  bool inLk = false;
+  if (lane < c.R) {
     double disc = 1.0;
-    for (int i = 0; i < L.envi[RE_NLK]; ++i) {
-      const int id = L.envi[RE_LK0 + i];
-      const double rew = (id < n ? cr0 : cr1) * disc;
-      L.rrew[id] += rew;
-      L.rposrew[id] += dm_max(0.0, rew);
+    for (int i = 0; i < nlk; ++i) {
+      if (L.envi[RE_LK0 + i] == lane) {
+        inLk = true;
+        const double rew = (lane < n ? cr0 : cr1) * disc;
+        L.rrew[lane] += rew;
+        L.rposrew[lane] += dm_max(0.0, rew);
+      }
       disc *= 0.5;
     }
+    const bool cond1 = (lane == L.envi[RE_CLOSE0] || lane == L.envi[RE_CLOSE1]);
+    const bool cond2 = vlen(vsub(robot_pos(L, lane), pos)) < 150.0;
+    if ((cond1 || cond2) && !inLk) L.rrew[lane] += dm_min(0.0, (lane < n ? cr0 : cr1) * 0.5);
   }
-  for (int i = 0; i < c.R; ++i) {
-    const bool cond1 = (i == L.envi[RE_CLOSE0] || i == L.envi[RE_CLOSE1]);
-    const bool cond2 = vlen(vsub(robot_pos(L, i), pos)) < 150.0;
-    if (cond1 || cond2) {
-      if (!in_last_kicked(L, i)) L.rrew[i] += dm_min(0.0, (i < n ? cr0 : cr1) * 0.5);
-    }
+  // closest robot of each team to the (possibly reset) ball
+  double q = INFINITY;
+  if (lane < c.R) {
+    const V2 d = vsub(v2(x, y), robot_pos(L, lane));
+    q = d.x * d.x + d.y * d.y;
   }
-  L.teamRew[0] += cr0 * 0.1;
-  L.teamRew[1] += cr1 * 0.1;
-  {
-    const V2 bp = v2(L.px[RC_BALL], L.py[RC_BALL]);
-    int best0 = 0, best1 = 0;
-    double d0 = INFINITY, d1 = INFINITY;
-    for (int i = 0; i < n; ++i) {
-      V2 d = vsub(bp, robot_pos(L, i));
-      double q = d.x * d.x + d.y * d.y;
-      if (q < d0) { d0 = q; best0 = i; }
-    }
-    for (int i = 0; i < n; ++i) {
-      V2 d = vsub(bp, robot_pos(L, n + i));
-      double q = d.x * d.x + d.y * d.y;
-      if (q < d1) { d1 = q; best1 = i; }
-    }
+  int best0 = 0, best1 = 0;
+  double d0 = INFINITY, d1 = INFINITY;
+  for (int i = 0; i < n; ++i) {
+    const double qi = bcast_d(q, i);
+    if (qi < d0) { d0 = qi; best0 = i; }
+  }
+  for (int i = 0; i < n; ++i) {
+    const double qi = bcast_d(q, n + i);
+    if (qi < d1) { d1 = qi; best1 = i; }
+  }
+  __syncthreads();  // every lane has read the shared scalars it needs
+  if (lane == 0) {
+    if (moved) { L.px[RC_BALL] = x; L.py[RC_BALL] = y; L.vx[RC_BALL] = 0.0; L.vy[RC_BALL] = 0.0; L.w[RC_BALL] = 0.0; }
+    L.envi[RE_GOAL0] += goal0; L.envi[RE_GOAL1] += goal1;
+    ball_free_kick_process(L, -team);
+    L.envd[RD_BPREVX] = x; L.envd[RD_BPREVY] = y;
+    L.teamRew[0] += cr0 * 0.1;
+    L.teamRew[1] += cr1 * 0.1;
     L.envi[RE_CLOSE0] = best0;
     L.envi[RE_CLOSE1] = n + best1;
   }
 }
 
-// the sequential per-substep game logic (lane 0 only): for robot in agents: [processAction]; tick; then the ball
-__device__ RC_LOGIC_INLINE void rc_game_logic(RcCtx c, int it, const int* __restrict__ actions) {
-  RcLds& L = g_R;
-  for (int r = 0; r < c.R; ++r) {
-    if (it == 0) {
-      int act[4] = {actions[4 * r], actions[4 * r + 1], actions[4 * r + 2], actions[4 * r + 3]};
-      rc_process_action(c, L, r, act);
-    }
-    rc_tick(c, L, r);
+// Would robot r's tick touch anything another robot's tick reads or writes?  Events: the kick taking the pivot joint out
+// of / back into the constraint list (and the foot snapping back), a getting-up roll, the end of a penalty, entering or
+// leaving the defender set, leaving the field.  Conservative (may report an event where rc_tick finds none); evaluated
+// without side effects from the state before the tick.  Without an event rc_tick(r) reads shared state only and writes
+// robot r's own fields, so the ticks of all robots commute and run one per lane.
+DE_DEV bool rc_tick_has_event(const RcLds& L, int r) {
+  const double time = RC_TIME;
+  const int f = L.rflags[r];
+  bool ev = false;
+  const double moveT = L.moveT[r];
+  if (moveT > 0.0 && (f & RF_KICK)) {
+    const double mt = moveT - time;
+    if ((mt + time > 500.0 && mt <= 500.0 && !(f & RF_JREM)) || mt <= 300.0) ev = true;
   }
-  rc_ball_logic(c, L);
+  if ((f & RF_FALLEN) && L.fallT[r] - time < 0.0) ev = true;
+  if (f & RF_PENAL) {
+    if (L.penalT[r] - time <= 0.0) ev = true;
+  } else {
+    const int teamIdx = (f & RF_TEAMPOS) ? 0 : 1;
+    const V2 p = robot_pos(L, r);
+    const double robX = teamIdx ? RC_W - p.x : p.x;
+    const double penX = RC_SIDE + 60.0 + 5.0 / 2.0;
+    const bool isDef = (L.envi[RE_DEF0 + teamIdx] & (1 << r)) != 0;
+    const bool inArea = robX < penX && p.y > (RC_H / 2.0 - 110.0) && p.y < (RC_H / 2.0 + 110.0);
+    if (inArea != isDef) ev = true;
+  }
+  const V2 pos = robot_pos(L, r);
+  if (pos.y < 0.0 || pos.x < 0.0 || pos.y > RC_H || pos.x > RC_W) ev = true;
+  return ev;
+}
+
+// the per-substep game logic: for robot in agents: [processAction]; tick; then the ball.  Called by the whole wave.
+__device__ RC_LOGIC_INLINE void rc_game_logic(RcCtx c, int it, const int* __restrict__ actions, int lane) {
+  RcLds& L = g_R;
+  bool serial = it == 0;  // processAction draws the fall dice and may knock other robots over: keep the reference order
+  if (!serial) serial = wave_ballot(lane < c.R && rc_tick_has_event(L, lane)) != 0ull;
+  if (!serial) {
+    if (lane < c.R) rc_tick(c, L, lane);
+  } else if (lane == 0) {
+    for (int r = 0; r < c.R; ++r) {
+      if (it == 0) {
+        int act[4] = {actions[4 * r], actions[4 * r + 1], actions[4 * r + 2], actions[4 * r + 3]};
+        rc_process_action(c, L, r, act);
+      }
+      rc_tick(c, L, r);
+    }
+  }
+  __syncthreads();
+  rc_ball_logic(c, L, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1328,7 +1378,7 @@ RC_PROF(if (lane < 12 && e < 4096) g_rcprof[e * 12 + lane] = 0ull; const unsigne
   for (int it = 0; it < 50; ++it) {
 RC_PROF(const unsigned long long A0 = __builtin_amdgcn_s_memtime();)
     // ---- sequential game logic (lane 0): processAction / tick per robot, then the ball (:465-475) ----------
-    if (lane == 0) rc_game_logic(c, it, myActions);
+    rc_game_logic(c, it, myActions, lane);
     __syncthreads();
 RC_PROF(const unsigned long long A1 = __builtin_amdgcn_s_memtime();)
     // ---- cpBodyUpdatePosition + shape cache + AABB ------------------------------------------------------
