@@ -891,15 +891,35 @@ RC_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
   r1[0] = r1[1] = r2[0] = r2[1] = v2(0.0, 0.0);
   uint64_t touchedMask = 0ull, activeMask = 0ull;
   if (anyContactWork) {
+    // Compact the candidates of all rounds into one dense list in canonical order (round-major, lane-minor = pair index
+    // order), so that the narrowphase runs once over up to 64 pairs instead of once per round that holds a candidate
+    // (the two feet of one robot are a candidate pair in every substep).  The list borrows the mailbox's LDS, which
+    // is not live yet: every lane takes its entries into registers before the mailbox flags are cleared.
+    unsigned short* cl = reinterpret_cast<unsigned short*>(&L.u);
+    int nCand = 0;
+#pragma unroll 1
+    for (int t = 0; t < RC_NPAIR_ROUNDS; ++t) {
+      const bool cbit = (cand >> t) & 1;
+      const uint64_t m = wave_ballot(cbit);
+      if (m == 0ull) continue;
+      if (cbit) {
+        const int idx = nCand + __popcll(m & lanemask_lt());
+        if (idx < 128) cl[idx] = (unsigned short)RC_MY_PAIR(t); else err |= 1;  // overflow is reported through RE_ERR
+      }
+      nCand += __popcll(m);
+    }
+    if (nCand > 128) nCand = 128;
+    __syncthreads();
+    const int pr0 = lane < nCand ? (int)cl[lane] : 0xFFFF, pr1 = 64 + lane < nCand ? (int)cl[64 + lane] : 0xFFFF;
+    __syncthreads();
     if (lane < RC_NS) M.flag[lane] = 0;
     __syncthreads();
 #pragma unroll 1
-    for (int t = 0; t < RC_NPAIR_ROUNDS; ++t) {
-      const bool isCand = (cand >> t) & 1;
-      if (wave_ballot(isCand) == 0ull) continue;
+    for (int pass = 0; pass * 64 < nCand; ++pass) {
+      const int pr = pass ? pr1 : pr0;
+      const bool isCand = pr != 0xFFFF;
       RcContacts ct;
       ct.count = 0;
-      const int pr = RC_MY_PAIR(t);
       if (isCand) rc_narrowphase(L, pr >> 8, pr & 0xFF, ct);
       const bool touch = isCand && ct.count > 0;
       if (wave_ballot(touch) == 0ull) continue;
