@@ -156,6 +156,19 @@ static int rc_create(dynenv* h) {
   memset(&c, 0, sizeof(c));
   c.footInertia = moment_for_segment_host(4000.0, v2(-10.0, 10.0), v2(10.0, 10.0), 7.5);  // Robot.py:34
   c.ballInertia = 10.0 * (0.5 * (0.0 * 0.0 + 10.0 * 10.0) + 0.0);                          // Ball.py:9
+  {  // cpPivotJoint preStep with r1 = r2 = 0 (k_tensor + inverse), cpRotaryLimitJoint iSum: same operations, same order
+    const double ma = 1.0 / ROBOT_MASS, mb = 1.0 / ROBOT_MASS, ia = 1.0 / c.footInertia, ib = 1.0 / c.footInertia;
+    const double pr1x = 0.0, pr1y = 0.0, pr2x = 0.0, pr2y = 0.0;
+    const double m_sum = ma + mb;
+    double k11 = m_sum, k12 = 0.0, k21 = 0.0, k22 = m_sum;
+    { const double r1xsq = pr1x * pr1x * ia, r1ysq = pr1y * pr1y * ia, r1nxy = -pr1x * pr1y * ia; k11 += r1ysq; k12 += r1nxy; k21 += r1nxy; k22 += r1xsq; }
+    { const double r2xsq = pr2x * pr2x * ib, r2ysq = pr2y * pr2y * ib, r2nxy = -pr2x * pr2y * ib; k11 += r2ysq; k12 += r2nxy; k21 += r2nxy; k22 += r2xsq; }
+    const double det = k11 * k22 - k12 * k21;
+    const double det_inv = 1.0 / det;
+    c.jkk0 = k22 * det_inv; c.jkk1 = -k12 * det_inv; c.jkk2 = -k21 * det_inv; c.jkk3 = k11 * det_inv;
+    c.jiSum = 1.0 / (ia + ib);
+    c.footMinv = ma; c.footIinv = ia;
+  }
   int p = 0;
   for (int i = 0; i <= RC_BALL; ++i)
     for (int j = i + 1; j < RC_POST + 4; ++j) c.pairs[p++] = (uint16_t)((i << 8) | j);

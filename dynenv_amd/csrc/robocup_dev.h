@@ -30,7 +30,8 @@ enum { RR_HEAD = 0, RR_HEADMOV, RR_PREVX, RR_PREVY, RR_INITX, RR_INITY, RR_PENAL
 enum { RI_FLAGS = 0, RI_TOUCHC, RI_FALLC, RI_COUNT };
 // env ints
 enum { RE_ELAPSED = 0, RE_OWNED, RE_GOAL0, RE_GOAL1, RE_CLOSE0, RE_CLOSE1, RE_DEF0, RE_DEF1, RE_NLK, RE_LK0, RE_LK1, RE_LK2,
-       RE_LK3, RE_NCON, RE_EPISODE, RE_OCC, RE_ERR, RE_CORDER /* 20 entries */, RE_COUNT = RE_CORDER + 20 + 3 };
+       RE_LK3, RE_NCON, RE_EPISODE, RE_OCC, RE_ERR, RE_CORDER /* 20 entries */, RE_PIVFIRST = RE_CORDER + 20 /* bit r: robot r's pivot joint precedes its rotary limit in the constraint list */,
+       RE_COUNT = RE_CORDER + 20 + 3 };
 // env doubles
 enum { RD_FREECNT = 0, RD_GRACE, RD_PT0, RD_PT1, RD_BPREVX, RD_BPREVY, RD_COUNT = 8 };
 
@@ -48,6 +49,9 @@ enum { ARB_FIRST_ = 0, ARB_NORMAL_ = 1, ARB_IGNORE_ = 2, ARB_CACHED_ = 3 };  // 
 
 struct RcConst {
   double footInertia, ballInertia;
+  /* per-robot joint constants (both feet have the same mass and inertia; anchors at the body origins), computed on the
+     host with the expression sequence of cpPivotJoint/cpRotaryLimitJoint preStep: identical bits, no per-substep divisions */
+  double footMinv, footIinv, jkk0, jkk1, jkk2, jkk3, jiSum;
   uint16_t pairs[RC_NPAIR_ROUNDS * 64];
 };
 

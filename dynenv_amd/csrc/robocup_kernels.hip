@@ -130,13 +130,30 @@ DE_DEV void push_last_kicked(RcLds& L, int id) {
   L.envi[RE_NLK] = n + 1;
 }
 // constraint array bookkeeping (cpArrayDeleteObj swaps the last element into the hole; add appends)
+// derived from the constraint list: bit r = robot r's pivot (id 2r) precedes its rotary limit (id 2r+1).  Recomputed
+// whenever the list changes (rare: kicks, penalties) instead of searching the list in every substep.
+DE_DEV void refresh_pivot_first(RcLds& L) {
+  const int n = L.envi[RE_NCON];
+  int mask = 0;
+  for (int r = 0; r < 10; ++r) {  // DYNENV_MAX_ROBOTS
+    int posP = -1, posR = -1;
+    for (int i = 0; i < n; ++i) {
+      const int cid = L.envi[RE_CORDER + i];
+      if (cid == 2 * r) posP = i;
+      if (cid == 2 * r + 1) posR = i;
+    }
+    if (posP < posR) mask |= 1 << r;
+  }
+  L.envi[RE_PIVFIRST] = mask;
+}
 DE_DEV void con_remove(RcLds& L, int cid) {
   int n = L.envi[RE_NCON];
   for (int i = 0; i < n; ++i) {
-    if (L.envi[RE_CORDER + i] == cid) { L.envi[RE_CORDER + i] = L.envi[RE_CORDER + n - 1]; L.envi[RE_NCON] = n - 1; return; }
+    if (L.envi[RE_CORDER + i] == cid) { L.envi[RE_CORDER + i] = L.envi[RE_CORDER + n - 1]; L.envi[RE_NCON] = n - 1; break; }
   }
+  refresh_pivot_first(L);
 }
-DE_DEV void con_add(RcLds& L, int cid) { L.envi[RE_CORDER + L.envi[RE_NCON]] = cid; L.envi[RE_NCON] += 1; }
+DE_DEV void con_add(RcLds& L, int cid) { L.envi[RE_CORDER + L.envi[RE_NCON]] = cid; L.envi[RE_NCON] += 1; refresh_pivot_first(L); }
 
 DE_DEV void set_body_angle(RcLds& L, int b, double a) { L.ang[b] = a; }
 
@@ -802,33 +819,15 @@ DE_DEV void joint_iterate(const RcJoint& J, RcFeet& f, double& jx, double& jy, d
 DE_DEV void joint_prestep(const RcLds& L, int lane, RcJoint& J, double& jx, double& jy, double& jr) {
   const int la = 2 * lane, lb = 2 * lane + 1;
   J.hasPivot = !(L.rflags[lane] & RF_JREM);
-  int posP = -1, posR = -1;
-  for (int i = 0; i < L.envi[RE_NCON]; ++i) {
-    const int cid = L.envi[RE_CORDER + i];
-    if (cid == 2 * lane) posP = i;
-    if (cid == 2 * lane + 1) posR = i;
-  }
-  J.pivotFirst = posP < posR;
+  J.pivotFirst = (L.envi[RE_PIVFIRST] >> lane) & 1;
   jx = L.jx[lane]; jy = L.jy[lane]; jr = L.jrot[lane];
-  const double ma = rc_minv(la), mb = rc_minv(lb), ia = rc_iinv(la), ib = rc_iinv(lb);
-  J.m = ma; J.i = ia;  // both feet: same mass and inertia
+  J.m = RC.footMinv; J.i = RC.footIinv;  // both feet: same mass and inertia
   J.kk0 = J.kk1 = J.kk2 = J.kk3 = 0.0; J.pbx = J.pby = 0.0;
   if (J.hasPivot) {
-    // anchors are the body origins (PivotJoint(a, b, pos) with both bodies at pos): r1 = r2 = 0
+    // anchors are the body origins (PivotJoint(a, b, pos) with both bodies at pos): r1 = r2 = 0, so K^-1 is the
+    // per-build constant RC.jkk* (dynenv_capi.hip computes it with cpPivotJoint's own operation order)
+    J.kk0 = RC.jkk0; J.kk1 = RC.jkk1; J.kk2 = RC.jkk2; J.kk3 = RC.jkk3;
     const V2 pr1 = v2(0.0, 0.0), pr2 = v2(0.0, 0.0);
-    const double m_sum = ma + mb;
-    double k11 = m_sum, k12 = 0.0, k21 = 0.0, k22 = m_sum;
-    {
-      const double r1xsq = pr1.x * pr1.x * ia, r1ysq = pr1.y * pr1.y * ia, r1nxy = -pr1.x * pr1.y * ia;
-      k11 += r1ysq; k12 += r1nxy; k21 += r1nxy; k22 += r1xsq;
-    }
-    {
-      const double r2xsq = pr2.x * pr2.x * ib, r2ysq = pr2.y * pr2.y * ib, r2nxy = -pr2.x * pr2.y * ib;
-      k11 += r2ysq; k12 += r2nxy; k21 += r2nxy; k22 += r2xsq;
-    }
-    const double det = k11 * k22 - k12 * k21;
-    const double det_inv = 1.0 / det;
-    J.kk0 = k22 * det_inv; J.kk1 = -k12 * det_inv; J.kk2 = -k21 * det_inv; J.kk3 = k11 * det_inv;
     const V2 delta = vsub(vadd(v2(L.px[lb], L.py[lb]), pr2), vadd(v2(L.px[la], L.py[la]), pr1));
     J.pbx = delta.x * (-DE_PIVOT_BIAS_COEF / DE_DT); J.pby = delta.y * (-DE_PIVOT_BIAS_COEF / DE_DT);
   }
@@ -836,7 +835,7 @@ DE_DEV void joint_prestep(const RcLds& L, int lane, RcJoint& J, double& jx, doub
     const double dist = L.ang[lb] - L.ang[la];
     double pdist = 0.0;
     if (dist > 0.0) pdist = 0.0 - dist; else if (dist < 0.0) pdist = 0.0 - dist;
-    J.iSum = 1.0 / (ia + ib);
+    J.iSum = RC.jiSum;
     J.rbias = -DE_JOINT_BIAS_COEF * pdist / DE_DT;
     if (J.rbias == 0.0) jr = 0.0;
   }
@@ -1102,7 +1101,7 @@ RC_PROF(const unsigned long long T1 = __builtin_amdgcn_s_memtime();)
   RcJoint J;                                                                                                   \
   J.hasPivot = hasPivot; J.pivotFirst = pivotFirst; J.kk0 = nMass[0]; J.kk1 = nMass[1]; J.kk2 = tMass[0];      \
   J.kk3 = tMass[1]; J.pbx = bias[0]; J.pby = bias[1]; J.iSum = bounce[0]; J.rbias = bounce[1];                 \
-  J.m = rc_minv(0); J.i = rc_iinv(0);
+  J.m = RC.footMinv; J.i = RC.footIinv;
   __syncthreads();
 RC_PROF(const unsigned long long T2 = __builtin_amdgcn_s_memtime();)
   // --- velocity update ------------------------------------------------------------------------------------
@@ -1390,6 +1389,8 @@ rc_step_kernel(RcState S, const int* __restrict__ actions, float* __restrict__ o
   }
   __syncthreads();
   c.episode = (uint32_t)L.envi[RE_EPISODE];
+  if (lane == 0) refresh_pivot_first(L);
+  __syncthreads();
   const bool isBody = lane == RC_BALL || lane < 2 * R;
   const int* myActions = actions + (size_t)e * R * 4;
   int snap = 0;
