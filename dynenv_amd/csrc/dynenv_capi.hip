@@ -167,7 +167,7 @@ static int rc_create(dynenv* h) {
     const double det_inv = 1.0 / det;
     c.jkk0 = k22 * det_inv; c.jkk1 = -k12 * det_inv; c.jkk2 = -k21 * det_inv; c.jkk3 = k11 * det_inv;
     c.jiSum = 1.0 / (ia + ib);
-    c.footMinv = ma; c.footIinv = ia;
+    c.footMinv = ma; c.footIinv = ia; c.ballIinv = 1.0 / c.ballInertia;
   }
   int p = 0;
   for (int i = 0; i <= RC_BALL; ++i)

@@ -51,7 +51,7 @@ struct RcConst {
   double footInertia, ballInertia;
   /* per-robot joint constants (both feet have the same mass and inertia; anchors at the body origins), computed on the
      host with the expression sequence of cpPivotJoint/cpRotaryLimitJoint preStep: identical bits, no per-substep divisions */
-  double footMinv, footIinv, jkk0, jkk1, jkk2, jkk3, jiSum;
+  double ballIinv, footMinv, footIinv, jkk0, jkk1, jkk2, jkk3, jiSum;
   uint16_t pairs[RC_NPAIR_ROUNDS * 64];
 };
 

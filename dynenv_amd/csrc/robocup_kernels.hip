@@ -71,7 +71,7 @@ __shared__ RcLds g_R;
 #define RC_MY_PAIR(t) ((int)((((t) < 4 ? pairLo : pairHi) >> (16 * ((t)&3))) & 0xFFFFull))
 
 DE_DEV double rc_minv(int b) { return b == RC_BALL ? 1.0 / 10.0 : (b < RC_BALL ? 1.0 / ROBOT_MASS : 0.0); }
-DE_DEV double rc_iinv(int b) { return b == RC_BALL ? 1.0 / RC.ballInertia : (b < RC_BALL ? 1.0 / RC.footInertia : 0.0); }
+DE_DEV double rc_iinv(int b) { return b == RC_BALL ? RC.ballIinv : (b < RC_BALL ? RC.footIinv : 0.0); }  // host-side 1.0 / inertia
 DE_DEV V2 post_pos(int idx) {  // RoboCupEnvironment.py:295-302
   int k = idx - RC_POST;
   return v2((k & 2) ? RC_W - RC_SIDE : RC_SIDE, (k & 1) ? RC_H / 2.0 - 80.0 : RC_H / 2.0 + 80.0);
@@ -732,6 +732,11 @@ DE_DEV void rbody_load(const RcLds& L, int idx, RBody& b) {
     b.p = post_pos(idx); b.v = v2(0.0, 0.0); b.w = 0.0; b.vb = v2(0.0, 0.0); b.wb = 0.0; b.minv = 0.0; b.iinv = 0.0;
   }
 }
+DE_DEV void rbody_load_vel(const RcLds& L, int idx, RBody& b) {
+  if (idx <= RC_BALL) {
+    b.v = v2(L.vx[idx], L.vy[idx]); b.w = L.w[idx]; b.vb = v2(L.vbx[idx], L.vby[idx]); b.wb = L.wb[idx];
+  }
+}
 DE_DEV void rbody_store_vel(RcLds& L, int idx, const RBody& b) {
   if (idx <= RC_BALL) {
     L.vx[idx] = b.v.x; L.vy[idx] = b.v.y; L.w[idx] = b.w; L.vbx[idx] = b.vb.x; L.vby[idx] = b.vb.y; L.wb[idx] = b.wb;
@@ -1133,24 +1138,24 @@ RC_PROF(T4 = __builtin_amdgcn_s_memtime();)
       }
       __syncthreads();
     }
-    if (isRobot) {
-      for (int ord = 0; ord < 2; ++ord) {
-        RC_JOINT_VIEW(J)
-        RcFeet f;
-        f.vx0 = L.vx[la]; f.vy0 = L.vy[la]; f.w0 = L.w[la]; f.vx1 = L.vx[lb]; f.vy1 = L.vy[lb]; f.w1 = L.w[lb];
-        joint_warm_start(J, f, jn[0], jn[1], jt[0], ord);
-        L.vx[la] = f.vx0; L.vy[la] = f.vy0; L.w[la] = f.w0; L.vx[lb] = f.vx1; L.vy[lb] = f.vy1; L.w[lb] = f.w1;
-      }
+    if (isRobot) {  // both constraints of a robot in one LDS round trip: nobody else touches its feet in between
+      RC_JOINT_VIEW(J)
+      RcFeet f;
+      f.vx0 = L.vx[la]; f.vy0 = L.vy[la]; f.w0 = L.w[la]; f.vx1 = L.vx[lb]; f.vy1 = L.vy[lb]; f.w1 = L.w[lb];
+      joint_warm_start(J, f, jn[0], jn[1], jt[0], 0);
+      joint_warm_start(J, f, jn[0], jn[1], jt[0], 1);
+      L.vx[la] = f.vx0; L.vy[la] = f.vy0; L.w[la] = f.w0; L.vx[lb] = f.vx1; L.vy[lb] = f.vy1; L.w[lb] = f.w1;
     }
     __syncthreads();
 RC_PROF(T4 = __builtin_amdgcn_s_memtime();)
     // --- 10 iterations: all arbiters (canonical order via levels), then all constraints ----------------------
+    RBody a, b;
+    if (active) { rbody_load(L, bodyA, a); rbody_load(L, bodyB, b); }  // p, minv, iinv do not change during the solve
     for (int iter = 0; iter < 10; ++iter) {
       for (int lv = 0; lv <= maxLevel; ++lv) {
         if (active && myLevel == lv) {
-          RBody a, b;
-          rbody_load(L, bodyA, a);
-          rbody_load(L, bodyB, b);
+          rbody_load_vel(L, bodyA, a);
+          rbody_load_vel(L, bodyB, b);
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
             if (q < a_count) {
@@ -1184,13 +1189,12 @@ RC_PROF(T4 = __builtin_amdgcn_s_memtime();)
         __syncthreads();
       }
       if (isRobot) {
-        for (int ord = 0; ord < 2; ++ord) {
-          RC_JOINT_VIEW(J)
-          RcFeet f;
-          f.vx0 = L.vx[la]; f.vy0 = L.vy[la]; f.w0 = L.w[la]; f.vx1 = L.vx[lb]; f.vy1 = L.vy[lb]; f.w1 = L.w[lb];
-          joint_iterate(J, f, jn[0], jn[1], jt[0], ord);
-          L.vx[la] = f.vx0; L.vy[la] = f.vy0; L.w[la] = f.w0; L.vx[lb] = f.vx1; L.vy[lb] = f.vy1; L.w[lb] = f.w1;
-        }
+        RC_JOINT_VIEW(J)
+        RcFeet f;
+        f.vx0 = L.vx[la]; f.vy0 = L.vy[la]; f.w0 = L.w[la]; f.vx1 = L.vx[lb]; f.vy1 = L.vy[lb]; f.w1 = L.w[lb];
+        joint_iterate(J, f, jn[0], jn[1], jt[0], 0);
+        joint_iterate(J, f, jn[0], jn[1], jt[0], 1);
+        L.vx[la] = f.vx0; L.vy[la] = f.vy0; L.w[la] = f.w0; L.vx[lb] = f.vx1; L.vy[lb] = f.vy1; L.w[lb] = f.w1;
       }
       __syncthreads();
     }
