@@ -24,6 +24,8 @@ sys.path.insert(0, ROOT)
 B_ALG_DRIVING_FULL_A10 = 20 + 2550 + 2230 + (9280 + 8) + 80 + 1
 # RoboCup Full, A=10: actions 40 + state 3650 R + 3650 W + obs 10*5*66*4 + rewards 80 + done 1
 B_ALG_ROBOCUP_FULL_A10 = 40 + 3650 + 3650 + 13200 + 80 + 1
+# Driving Partial obs (configs[3]): as Full but the observation is 10 agents x 517 f32 (oracle/driving_partial.c layout)
+B_ALG_DRIVING_PARTIAL_A10 = 20 + 2550 + 2230 + 10 * 517 * 4 + 80 + 1
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -46,7 +48,7 @@ def host_core_share():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(E, n_players, A, seed, robocup=False, target_seconds=12.0):
+def cpu_baseline(E, n_players, A, seed, robocup=False, target_seconds=12.0, partial=False):
     """The CPU restatement (oracle, kind='port') timed on this box's host cores on a bounded sample of the same
     workload.  It is a C restatement, i.e. a much stronger baseline than the reference's Python+pymunk path, which
     cannot run here (pymunk absent; the reference never ships to the GPU box)."""
@@ -57,6 +59,9 @@ def cpu_baseline(E, n_players, A, seed, robocup=False, target_seconds=12.0):
     ol.build()
     if robocup:
         env = ol.OracleEnv(env_type=0, num_envs=E, n_players=n_players, seed=seed, threads=cores, flags=ol.ROBOCUP_DEFAULT_FLAGS)
+    elif partial:  # ObservationType.PARTIAL = 1, NoiseType.REALISTIC = 1 (cutils.py:29-51)
+        env = ol.OracleEnv(env_type=1, num_envs=E, n_players=n_players, obs_type=1, noise_type=1, noise_magnitude=3.0,
+                           seed=seed, threads=cores)
     else:
         env = ol.OracleEnv(env_type=1, num_envs=E, n_players=n_players, seed=seed, threads=cores)
     env.reset()
@@ -87,7 +92,7 @@ def cpu_baseline(E, n_players, A, seed, robocup=False, target_seconds=12.0):
     return {"value": value, "unit": "agent-steps/s", "cores": cores, "kind": "port",
             "sample": "%d steps of the same %d-env %s nPlayers=%d workload (first %d steps of an episode), "
                       "oracle/liboracle.so with %d OpenMP threads, %.1f s"
-                      % (n, E, "RoboCup" if robocup else "Driving", n_players, n, cores, dt),
+                      % (n, E, "RoboCup" if robocup else "Driving Partial-obs" if partial else "Driving", n_players, n, cores, dt),
             "cpu_model": model}
 
 
@@ -98,8 +103,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=600)   # 1 full episode
     ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
     ap.add_argument("--players", type=int, default=None)
-    ap.add_argument("--workload", choices=["driving", "robocup"], default="driving",
-                    help="driving = BASELINE configs[1] (the headline metric); robocup = configs[2], reported on request")
+    ap.add_argument("--workload", choices=["driving", "robocup", "driving_partial"], default="driving",
+                    help="driving = BASELINE configs[1] (the headline metric); robocup = configs[2]; driving_partial = "
+                         "configs[3] (Partial obs + Realistic noise magnitude 3); the latter two are reported on request")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the end-of-step all-gather (data-parallel consumer)")
@@ -125,6 +131,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     robocup = args.workload == "robocup"
+    partial = args.workload == "driving_partial"
     n_players = args.players if args.players is not None else (5 if robocup else 10)
     env_type = DynEnvType.ROBO_CUP if robocup else DynEnvType.DRIVE
     E = args.envs
@@ -133,15 +140,19 @@ def main():
         args.steps, args.warmup = 480, 240  # 2 + 1 episodes of 240 steps
     slab = gather = None
     out_buffers = None
+    obs_kw = {}
+    if partial:
+        from dynenv_amd import ObservationType, NoiseType
+        obs_kw = dict(observationType=ObservationType.PARTIAL, noiseType=NoiseType.REALISTIC, noiseMagnitude=3)
     if world > 1 and not args.no_gather:
-        probe = BatchedDynEnv(env_type, 1, n_players, device=device)
+        probe = BatchedDynEnv(env_type, 1, n_players, device=device, **obs_kw)
         T, D = probe.n_time_steps, probe.obs_dim
         probe.close()
         slab = PackedSlab(torch, device, E, T, A, D)
         out_buffers = (slab.obs, slab.rewards, slab.dones)
         gather = StepGather(torch, dist, slab)
     env = BatchedDynEnv(env_type, E, n_players, seed=args.seed, device=device, env_id_offset=rank * E,
-                        out_buffers=out_buffers)
+                        out_buffers=out_buffers, **obs_kw)
     # synthetic inputs: i.i.d. uniform actions (action_space MultiDiscrete([3,3])), resident in HBM
     g = torch.Generator(device=device).manual_seed(1234 + rank)
     if robocup:  # MultiDiscrete([5, 3, 3, 7]) RoboCupEnvironment.py:342
@@ -196,19 +207,19 @@ def main():
         k1.record()
         torch.cuda.synchronize(device)
         launch_ms = k0.elapsed_time(k1) / n_launch
-        b_alg = (B_ALG_ROBOCUP_FULL_A10 if robocup else B_ALG_DRIVING_FULL_A10) if A == 10 else None
+        b_alg = (B_ALG_ROBOCUP_FULL_A10 if robocup else B_ALG_DRIVING_PARTIAL_A10 if partial else B_ALG_DRIVING_FULL_A10) if A == 10 else None
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 with open(pmc) as f:
-                    traffic = json.load(f).get("drv_step_kernel_bytes_per_launch")
+                    traffic = json.load(f).get("drv_step_kernel_bytes_per_launch") if args.workload == "driving" else None
             except (OSError, ValueError):
                 traffic = None
         if b_alg is not None:
             achieved = b_alg * E / (launch_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "rc_step_kernel" if robocup else "drv_step_kernel",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "rc_step_kernel" if robocup else "drv_step_kernel + drv_partial_obs_kernel" if partial else "drv_step_kernel",
                         "launch_ms": launch_ms, "alg_bytes_per_env_step": b_alg, "env_steps_per_launch": E}
 
     if rank == 0:
@@ -221,9 +232,12 @@ def main():
             "config": {"workload": ("RoboCupEnvironment nPlayers=%d Full obs, 50 substeps/step, %d envs per GPU "
                                     "(BASELINE.json configs[2]), lock-step resets every 240 steps" % (n_players, E))
                        if robocup else
+                       ("DrivingEnvironment nPlayers=%d Partial obs + Realistic noise magnitude 3, %d envs per GPU "
+                        "(BASELINE.json configs[3]), 10 substeps/step, lock-step resets every 600 steps" % (A, E))
+                       if partial else
                        ("DrivingEnvironment nPlayers=%d Full obs, noise=0, %d envs per GPU "
                         "(BASELINE.json configs[1]), 10 substeps/step, lock-step resets every 600 steps" % (A, E)),
-                       "envs_per_gpu": E, "n_players": n_players, "n_agents": A, "obs": "full", "gather": bool(gather is not None),
+                       "envs_per_gpu": E, "n_players": n_players, "n_agents": A, "obs": "partial" if partial else "full", "gather": bool(gather is not None),
                        "parallelism": "env-shard x%d" % world},
             "env_steps_per_s": env_steps / elapsed,
             "gpu_ms_per_step_rank0": gpu_ms / args.steps,
@@ -231,7 +245,7 @@ def main():
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(E, n_players, A, args.seed, robocup)
+            out["cpu_baseline"] = cpu_baseline(E, n_players, A, args.seed, robocup, partial=partial)
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
         print(json.dumps(out))
