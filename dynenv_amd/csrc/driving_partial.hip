@@ -69,7 +69,7 @@ DE_DEV int pv_interact(int seen1, V2 point1, double angle1, const PvBlocker& b, 
   return ret;
 }
 
-extern "C" __global__ void __launch_bounds__(64)
+extern "C" __global__ void __launch_bounds__(64, 4)  // 128 VGPRs: all 4096 environments resident in one pass
 drv_partial_obs_kernel(DrvState S, int noiseType, double magn, float* __restrict__ obs) {
   PvLds& L = g_P;
   const int e = blockIdx.x, lane = threadIdx.x, A = S.A;
