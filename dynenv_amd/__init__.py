@@ -5,5 +5,6 @@ mirror of the reference's vectorised-environment interface.
 """
 from .enums import DynEnvType, NoiseType, ObservationType
 from .vec_env import BatchedDynEnv, make_dyn_env
+from .arranger import GpuInOutArranger, groups_for
 
-__all__ = ["BatchedDynEnv", "make_dyn_env", "DynEnvType", "NoiseType", "ObservationType"]
+__all__ = ["BatchedDynEnv", "make_dyn_env", "DynEnvType", "NoiseType", "ObservationType", "GpuInOutArranger", "groups_for"]

@@ -73,7 +73,23 @@ FLAG_RANDOM_INIT, FLAG_DETERMINISTIC_TURN, FLAG_CAN_FALL, FLAG_USE_OBS_REWARDS, 
 EXPORTS = ["dynenv_abi_version", "dynenv_last_error", "dynenv_create", "dynenv_destroy", "dynenv_layout",
            "dynenv_seed", "dynenv_reset", "dynenv_step", "dynenv_counts", "dynenv_episode_stats",
            "dynenv_state_size", "dynenv_get_state", "dynenv_set_state", "dynenv_sync", "dynenv_math_selftest",
-           "dynenv_error_flags", "dynenv_debug_counters"]
+           "dynenv_error_flags", "dynenv_debug_counters", "dynenv_arrange_scratch_ints", "dynenv_arrange_plan",
+           "dynenv_arrange_gather", "dynenv_arrange_scatter", "dynenv_arrange_pad"]
+
+ARR_MAX_TYPES = 4
+ARR_COUNT_CONST, ARR_COUNT_ENV, ARR_COUNT_ROW = 0, 1, 2
+
+
+class ArrType(C.Structure):  # dynenv_arr_type_t
+    _fields_ = [("offset", C.c_int32), ("feat", C.c_int32), ("cap", C.c_int32), ("count_mode", C.c_int32),
+                ("count_value", C.c_int32), ("count_index", C.c_int32), ("count_stride", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class ArrPlan(C.Structure):  # dynenv_arr_plan_t
+    _fields_ = [("n_types", C.c_int32), ("n_time", C.c_int32), ("n_players", C.c_int32), ("max_count", C.c_int32),
+                ("total", C.c_int64 * ARR_MAX_TYPES)]
+
 
 _lib = None
 
@@ -100,6 +116,15 @@ def load():
     lib.dynenv_seed.argtypes = [vp, C.c_uint64]
     lib.dynenv_reset.argtypes = [vp, vp, vp]
     lib.dynenv_step.argtypes = [vp, vp, vp, vp, vp, vp]
+    i32 = C.c_int32
+    lib.dynenv_arrange_scratch_ints.argtypes = [i32, i32, i32, i32]
+    lib.dynenv_arrange_scratch_ints.restype = C.c_int64
+    lib.dynenv_arrange_plan.argtypes = [vp, i32, i32, i32, i32, C.POINTER(ArrType), i32, vp, vp, vp, vp, vp,
+                                        C.POINTER(ArrPlan), vp]
+    lib.dynenv_arrange_gather.argtypes = [vp, i32, i32, i32, i32, C.POINTER(ArrType), i32, vp, vp, i32,
+                                          C.POINTER(vp), C.POINTER(vp), vp, vp]
+    lib.dynenv_arrange_scatter.argtypes = [vp, vp, C.c_int64, i32, vp, vp]
+    lib.dynenv_arrange_pad.argtypes = [C.POINTER(vp), vp, vp, i32, i32, i32, i32, i32, vp, vp]
     lib.dynenv_counts.argtypes = [vp, vp, vp]
     lib.dynenv_episode_stats.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.dynenv_state_size.argtypes = [vp]

@@ -1,0 +1,184 @@
+// arranger_kernels.hip — GPU-side ragged -> padded arranger on the dense observation tensor.
+//
+// Replaces the reference's InOutArranger.rearrange_inputs / rearrange_outputs (DynEnv/models/models.py:219-250, :252-274:
+// triple-nested Python over object arrays) with index kernels.  An observation row (env e, time t, agent a) holds, per
+// object type i of a group, `count_i` valid rows of `feat_i` floats at a fixed offset (capacity `cap_i`).  With
+// p = e*A + a (the reference chains environments player-major, models.py:222-223):
+//   inputs[i]  [N_i][feat_i]  all objects of type i in (t, p, k) order               (rearrange_inputs :238-245)
+//   slot[i]    [N_i]          row of that object in the padded tensor [T][maxCount][P][F] viewed as [T*maxCount*P][F]:
+//                             (t*maxCount + sum_{i'<i} count_i'(t,p) + k) * P + p     (rearrange_outputs :259-268)
+//   mask       [T][P][maxCount]  1 where slot >= objCounts[t][p]                      (ObsMask.createMask :166-180)
+// HBM-bound by construction (every byte is touched once); no LDS tiles needed beyond the block scan.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "dynenv.h"
+
+#define ARR_BLOCK 256
+
+struct ArrTypes {
+  dynenv_arr_type_t t[DYNENV_ARR_MAX_TYPES];
+  int n;
+};
+
+__device__ __forceinline__ int arr_count(const ArrTypes& ty, int i, const float* __restrict__ row, const int32_t* __restrict__ count_env, int e) {
+  const dynenv_arr_type_t& d = ty.t[i];
+  int c = d.count_value;
+  if (d.count_mode == DYNENV_ARR_COUNT_ENV) c = count_env[(size_t)e * d.count_stride + d.count_index];
+  else if (d.count_mode == DYNENV_ARR_COUNT_ROW) c = (int)row[d.count_index];
+  c = c < 0 ? 0 : c;
+  return c > d.cap ? d.cap : c;
+}
+
+// inclusive scan of one int per thread over a 256-thread block (4 waves): wave shuffles + one LDS hop
+__device__ __forceinline__ int arr_block_scan(int v, int* waveTot /* [4] shared */, int& blockTotal) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  if (lane == 63) waveTot[w] = x;
+  __syncthreads();
+  int add = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < ARR_BLOCK / 64; ++k) { const int t = waveTot[k]; if (k < w) add += t; tot += t; }
+  __syncthreads();
+  blockTotal = tot;
+  return x + add;
+}
+
+// K1: per (t, p): counts per type, objCounts, block-local exclusive prefix per type, block totals and block max
+extern "C" __global__ void __launch_bounds__(ARR_BLOCK)
+arr_count_kernel(const float* __restrict__ obs, int E, int T, int A, int D, ArrTypes ty, const int32_t* __restrict__ count_env,
+                 int32_t* __restrict__ counts, int32_t* __restrict__ obj_counts, int32_t* __restrict__ base,
+                 int32_t* __restrict__ blockTot /* [n+1][nBlocks]: per type totals, then block max of objCounts */) {
+  __shared__ int waveTot[ARR_BLOCK / 64];
+  const int P = E * A, TP = T * P, nBlocks = gridDim.x;
+  const int tp = blockIdx.x * ARR_BLOCK + threadIdx.x;
+  const bool live = tp < TP;
+  const int t = live ? tp / P : 0, p = live ? tp % P : 0, e = p / A, a = p % A;
+  const float* row = obs + (((size_t)e * T + t) * A + a) * D;
+  int sum = 0;
+  for (int i = 0; i < ty.n; ++i) {
+    const int c = live ? arr_count(ty, i, row, count_env, e) : 0;
+    sum += c;
+    int tot;
+    const int incl = arr_block_scan(c, waveTot, tot);
+    if (live) { counts[(size_t)i * TP + tp] = c; base[(size_t)i * TP + tp] = incl - c; }
+    if (threadIdx.x == 0) blockTot[(size_t)i * nBlocks + blockIdx.x] = tot;
+  }
+  if (live) obj_counts[tp] = sum;
+  // block max of objCounts
+  int m = sum;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { const int y = __shfl_xor(m, d, 64); m = y > m ? y : m; }
+  if ((threadIdx.x & 63) == 0) waveTot[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int mm = 0;
+    for (int k = 0; k < ARR_BLOCK / 64; ++k) mm = waveTot[k] > mm ? waveTot[k] : mm;
+    blockTot[(size_t)ty.n * nBlocks + blockIdx.x] = mm;
+  }
+}
+
+// K2: one block: exclusive scan of the block totals per type, grand totals, global max
+extern "C" __global__ void __launch_bounds__(ARR_BLOCK)
+arr_scan_blocks_kernel(int32_t* __restrict__ blockTot, int nBlocks, int nTypes, int64_t* __restrict__ result /* [n] totals, [n] = max */) {
+  __shared__ int waveTot[ARR_BLOCK / 64];
+  for (int i = 0; i < nTypes; ++i) {
+    int carry = 0;
+    for (int b0 = 0; b0 < nBlocks; b0 += ARR_BLOCK) {
+      const int b = b0 + threadIdx.x;
+      const int v = b < nBlocks ? blockTot[(size_t)i * nBlocks + b] : 0;
+      int tot;
+      const int incl = arr_block_scan(v, waveTot, tot);
+      if (b < nBlocks) blockTot[(size_t)i * nBlocks + b] = carry + incl - v;
+      carry += tot;
+    }
+    if (threadIdx.x == 0) result[i] = carry;
+  }
+  int m = 0;
+  for (int b = threadIdx.x; b < nBlocks; b += ARR_BLOCK) { const int v = blockTot[(size_t)nTypes * nBlocks + b]; m = v > m ? v : m; }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { const int y = __shfl_xor(m, d, 64); m = y > m ? y : m; }
+  if ((threadIdx.x & 63) == 0) waveTot[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int mm = 0;
+    for (int k = 0; k < ARR_BLOCK / 64; ++k) mm = waveTot[k] > mm ? waveTot[k] : mm;
+    result[nTypes] = mm;
+  }
+}
+
+// K2b: base += offset of its block
+extern "C" __global__ void __launch_bounds__(ARR_BLOCK)
+arr_add_offsets_kernel(int32_t* __restrict__ base, const int32_t* __restrict__ blockTot, int TP, int nBlocks, int nTypes) {
+  const int tp = blockIdx.x * ARR_BLOCK + threadIdx.x;
+  if (tp >= TP) return;
+  for (int i = 0; i < nTypes; ++i) base[(size_t)i * TP + tp] += blockTot[(size_t)i * nBlocks + blockIdx.x];
+}
+
+// K3: one thread per (t, p, j): j-th object slot of the player's padded list
+extern "C" __global__ void __launch_bounds__(ARR_BLOCK)
+arr_gather_kernel(const float* __restrict__ obs, int E, int T, int A, int D, ArrTypes ty, const int32_t* __restrict__ counts,
+                  const int32_t* __restrict__ base, int maxCount, int jSpan /* = max(capSum, maxCount) */,
+                  float* in0, float* in1, float* in2, float* in3, int32_t* sl0, int32_t* sl1, int32_t* sl2, int32_t* sl3,
+                  uint8_t* __restrict__ mask) {
+  const int P = E * A, TP = T * P;
+  const long long gid = (long long)blockIdx.x * ARR_BLOCK + threadIdx.x;
+  const int tp = (int)(gid / jSpan), j = (int)(gid % jSpan);
+  if (tp >= TP) return;
+  const int t = tp / P, p = tp % P, e = p / A, a = p % A;
+  int off = 0, type = -1, k = 0;
+  for (int i = 0; i < ty.n; ++i) {
+    const int c = counts[(size_t)i * TP + tp];
+    if (type < 0 && j < off + c) { type = i; k = j - off; }
+    off += c;
+  }
+  if (mask && j < maxCount) mask[(size_t)tp * maxCount + j] = (uint8_t)(j >= off);
+  if (type < 0) return;
+  const dynenv_arr_type_t d = ty.t[type];
+  const float* src = obs + (((size_t)e * T + t) * A + a) * D + d.offset + (size_t)k * d.feat;
+  const size_t n = (size_t)base[(size_t)type * TP + tp] + k;
+  float* in = type == 0 ? in0 : type == 1 ? in1 : type == 2 ? in2 : in3;
+  int32_t* sl = type == 0 ? sl0 : type == 1 ? sl1 : type == 2 ? sl2 : sl3;
+  if (in) { float* dst = in + n * d.feat; for (int f = 0; f < d.feat; ++f) dst[f] = src[f]; }
+  if (sl) sl[n] = (int32_t)(((long long)t * maxCount + j) * P + p);
+}
+
+// K4: padded[slot[n]][:] = emb[n][:]   (one thread per float)
+extern "C" __global__ void __launch_bounds__(ARR_BLOCK)
+arr_scatter_kernel(const float* __restrict__ emb, const int32_t* __restrict__ slot, long long N, int F, float* __restrict__ padded) {
+  const long long gid = (long long)blockIdx.x * ARR_BLOCK + threadIdx.x;
+  if (gid >= N * F) return;
+  const long long n = gid / F;
+  const int f = (int)(gid % F);
+  padded[(size_t)slot[n] * F + f] = emb[gid];
+}
+
+// K5: the padded tensor in one pass, no pre-zeroing: one thread per float4 of padded[t][j][p][:]; it finds the object
+// that owns slot j of player (t, p) from the counts (types in order) and copies its embedding, or writes zeros.
+extern "C" __global__ void __launch_bounds__(ARR_BLOCK)
+arr_pad_kernel(const float* __restrict__ e0, const float* __restrict__ e1, const float* __restrict__ e2, const float* __restrict__ e3,
+               const int32_t* __restrict__ counts, const int32_t* __restrict__ base, int nTypes, int T, int P, int maxCount, int F4,
+               float4* __restrict__ padded) {
+  // grid = (ceil(P*F4 / 256), T*maxCount): 32-bit index arithmetic only
+  const unsigned x = blockIdx.x * ARR_BLOCK + threadIdx.x;
+  if (x >= (unsigned)P * (unsigned)F4) return;
+  const int p = (int)(x / (unsigned)F4), f = (int)(x % (unsigned)F4);
+  const int t = (int)(blockIdx.y / (unsigned)maxCount), j = (int)(blockIdx.y % (unsigned)maxCount);
+  const size_t gid = (size_t)blockIdx.y * P * F4 + x;
+  const int tp = t * P + p, TP = T * P;
+  int off = 0;
+  const float* src = nullptr;
+  for (int i = 0; i < nTypes; ++i) {
+    const int c = counts[(size_t)i * TP + tp];
+    if (!src && j < off + c) {
+      const float* e = i == 0 ? e0 : i == 1 ? e1 : i == 2 ? e2 : e3;
+      if (e) src = e + ((size_t)base[(size_t)i * TP + tp] + (j - off)) * F4 * 4;
+    }
+    off += c;
+  }
+  padded[gid] = src ? reinterpret_cast<const float4*>(src)[f] : make_float4(0.f, 0.f, 0.f, 0.f);
+}

@@ -13,6 +13,7 @@
 #include "driving_kernels.hip"
 #include "robocup_kernels.hip"
 #include "driving_partial.hip"
+#include "arranger_kernels.hip"
 #include "dynenv.h"
 
 static thread_local std::string g_err;
@@ -612,6 +613,109 @@ int dynenv_set_state(dynenv_t* h, int32_t env, const void* blob, size_t nbytes) 
   HIP_OK(hipMemcpy(S.aux + (size_t)env * DRV_NB, aux, sizeof(aux), hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(S.envi + (size_t)env * EI_COUNT, envi, sizeof(envi), hipMemcpyHostToDevice));
   HIP_OK(hipMemset(S.lastcand + (size_t)env * 64, 0xFF, 64 * sizeof(int)));  // -1: quiescent shortcut state unknown
+  return DYNENV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ragged -> padded arranger (arranger_kernels.hip); replaces InOutArranger (reference models/models.py:208-274)
+// ------------------------------------------------------------------------------------------------
+static int arr_types(const dynenv_arr_type_t* types, int32_t n_types, int32_t D, ArrTypes& out) {
+  if (!types || n_types < 1 || n_types > DYNENV_ARR_MAX_TYPES) return fail(DYNENV_ERR_ARG, "arranger: 1..4 object types");
+  out.n = n_types;
+  for (int i = 0; i < n_types; ++i) {
+    const dynenv_arr_type_t& t = types[i];
+    if (t.feat < 1 || t.cap < 0 || t.offset < 0 || t.offset + t.feat * t.cap > D) return fail(DYNENV_ERR_ARG, "arranger: block outside the observation row");
+    if (t.count_mode == DYNENV_ARR_COUNT_ROW && (t.count_index < 0 || t.count_index >= D)) return fail(DYNENV_ERR_ARG, "arranger: count_index outside the observation row");
+    if (t.count_mode < 0 || t.count_mode > DYNENV_ARR_COUNT_ROW) return fail(DYNENV_ERR_ARG, "arranger: unknown count_mode");
+    out.t[i] = t;
+  }
+  return DYNENV_OK;
+}
+static int arr_have_device() {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(DYNENV_ERR_NO_DEVICE, "no HIP device visible: libdynenv_hip has no CPU fallback");
+  return DYNENV_OK;
+}
+
+int64_t dynenv_arrange_scratch_ints(int32_t E, int32_t T, int32_t A, int32_t n_types) {
+  const int64_t TP = (int64_t)E * T * A, nBlocks = (TP + ARR_BLOCK - 1) / ARR_BLOCK;
+  return (n_types + 1) * nBlocks + 2 * (DYNENV_ARR_MAX_TYPES + 1) /* int64 results */;
+}
+
+int dynenv_arrange_plan(const float* obs_dev, int32_t E, int32_t T, int32_t A, int32_t D, const dynenv_arr_type_t* types,
+                        int32_t n_types, const int32_t* count_env_dev, int32_t* counts_dev, int32_t* obj_counts_dev,
+                        int32_t* base_dev, int32_t* scratch_dev, dynenv_arr_plan_t* plan_host, void* stream) {
+  if (int rc = arr_have_device()) return rc;
+  if (!obs_dev || !counts_dev || !obj_counts_dev || !base_dev || !scratch_dev || !plan_host) return fail(DYNENV_ERR_ARG, "null argument");
+  if (E < 1 || T < 1 || A < 1 || D < 1 || (int64_t)E * T * A > (int64_t)1 << 30) return fail(DYNENV_ERR_ARG, "arranger: bad shape");
+  ArrTypes ty;
+  if (int rc = arr_types(types, n_types, D, ty)) return rc;
+  for (int i = 0; i < n_types; ++i)
+    if (types[i].count_mode == DYNENV_ARR_COUNT_ENV && !count_env_dev) return fail(DYNENV_ERR_ARG, "arranger: count_env_dev missing");
+  hipStream_t st = (hipStream_t)stream;
+  const int TP = E * T * A, nBlocks = (TP + ARR_BLOCK - 1) / ARR_BLOCK;
+  int32_t* blockTot = scratch_dev;
+  // int64 results live behind the block totals, 8-byte aligned
+  size_t off = (size_t)(n_types + 1) * nBlocks;
+  off = (off + 1) & ~(size_t)1;
+  int64_t* result = reinterpret_cast<int64_t*>(scratch_dev + off);
+  hipLaunchKernelGGL(arr_count_kernel, dim3(nBlocks), dim3(ARR_BLOCK), 0, st, obs_dev, E, T, A, D, ty, count_env_dev, counts_dev,
+                     obj_counts_dev, base_dev, blockTot);
+  hipLaunchKernelGGL(arr_scan_blocks_kernel, dim3(1), dim3(ARR_BLOCK), 0, st, blockTot, nBlocks, n_types, result);
+  hipLaunchKernelGGL(arr_add_offsets_kernel, dim3(nBlocks), dim3(ARR_BLOCK), 0, st, base_dev, blockTot, TP, nBlocks, n_types);
+  HIP_OK(hipGetLastError());
+  int64_t res[DYNENV_ARR_MAX_TYPES + 1];
+  HIP_OK(hipMemcpyAsync(res, result, sizeof(int64_t) * (n_types + 1), hipMemcpyDeviceToHost, st));
+  HIP_OK(hipStreamSynchronize(st));
+  plan_host->n_types = n_types; plan_host->n_time = T; plan_host->n_players = E * A; plan_host->max_count = (int32_t)res[n_types];
+  for (int i = 0; i < DYNENV_ARR_MAX_TYPES; ++i) plan_host->total[i] = i < n_types ? res[i] : 0;
+  return DYNENV_OK;
+}
+
+int dynenv_arrange_gather(const float* obs_dev, int32_t E, int32_t T, int32_t A, int32_t D, const dynenv_arr_type_t* types,
+                          int32_t n_types, const int32_t* counts_dev, const int32_t* base_dev, int32_t max_count,
+                          float* const* inputs_dev, int32_t* const* slot_dev, uint8_t* mask_dev, void* stream) {
+  if (int rc = arr_have_device()) return rc;
+  if (!obs_dev || !counts_dev || !base_dev) return fail(DYNENV_ERR_ARG, "null argument");
+  ArrTypes ty;
+  if (int rc = arr_types(types, n_types, D, ty)) return rc;
+  int capSum = 0;
+  for (int i = 0; i < n_types; ++i) capSum += types[i].cap;
+  const int jSpan = capSum > max_count ? capSum : (max_count > 0 ? max_count : 1);
+  const long long total = (long long)E * T * A * jSpan;
+  float* in[DYNENV_ARR_MAX_TYPES] = {nullptr, nullptr, nullptr, nullptr};
+  int32_t* sl[DYNENV_ARR_MAX_TYPES] = {nullptr, nullptr, nullptr, nullptr};
+  for (int i = 0; i < n_types; ++i) { if (inputs_dev) in[i] = inputs_dev[i]; if (slot_dev) sl[i] = slot_dev[i]; }
+  hipLaunchKernelGGL(arr_gather_kernel, dim3((unsigned)((total + ARR_BLOCK - 1) / ARR_BLOCK)), dim3(ARR_BLOCK), 0, (hipStream_t)stream,
+                     obs_dev, E, T, A, D, ty, counts_dev, base_dev, max_count, jSpan, in[0], in[1], in[2], in[3], sl[0], sl[1], sl[2], sl[3], mask_dev);
+  HIP_OK(hipGetLastError());
+  return DYNENV_OK;
+}
+
+int dynenv_arrange_scatter(const float* emb_dev, const int32_t* slot_dev, int64_t N, int32_t F, float* padded_dev, void* stream) {
+  if (int rc = arr_have_device()) return rc;
+  if (N == 0) return DYNENV_OK;
+  if (!emb_dev || !slot_dev || !padded_dev || N < 0 || F < 1) return fail(DYNENV_ERR_ARG, "bad argument");
+  const long long total = (long long)N * F;
+  hipLaunchKernelGGL(arr_scatter_kernel, dim3((unsigned)((total + ARR_BLOCK - 1) / ARR_BLOCK)), dim3(ARR_BLOCK), 0, (hipStream_t)stream,
+                     emb_dev, slot_dev, (long long)N, F, padded_dev);
+  HIP_OK(hipGetLastError());
+  return DYNENV_OK;
+}
+
+int dynenv_arrange_pad(const float* const* emb_dev, const int32_t* counts_dev, const int32_t* base_dev, int32_t n_types,
+                       int32_t T, int32_t P, int32_t max_count, int32_t F, float* padded_dev, void* stream) {
+  if (int rc = arr_have_device()) return rc;
+  if (!emb_dev || !counts_dev || !base_dev || !padded_dev) return fail(DYNENV_ERR_ARG, "null argument");
+  if (n_types < 1 || n_types > DYNENV_ARR_MAX_TYPES || T < 1 || P < 1 || max_count < 0 || F < 4 || (F & 3)) return fail(DYNENV_ERR_ARG, "arranger: bad shape (F must be a multiple of 4)");
+  if (max_count == 0) return DYNENV_OK;
+  const float* e[DYNENV_ARR_MAX_TYPES] = {nullptr, nullptr, nullptr, nullptr};
+  for (int i = 0; i < n_types; ++i) e[i] = emb_dev[i];
+  const long long perRow = (long long)P * (F / 4);
+  if (perRow > 0x7fffffffLL || (long long)T * max_count > 65535) return fail(DYNENV_ERR_ARG, "arranger: padded tensor too large for one launch");
+  hipLaunchKernelGGL(arr_pad_kernel, dim3((unsigned)((perRow + ARR_BLOCK - 1) / ARR_BLOCK), (unsigned)(T * max_count)), dim3(ARR_BLOCK), 0, (hipStream_t)stream,
+                     e[0], e[1], e[2], e[3], counts_dev, base_dev, n_types, T, P, max_count, F / 4, reinterpret_cast<float4*>(padded_dev));
+  HIP_OK(hipGetLastError());
   return DYNENV_OK;
 }
 

@@ -179,6 +179,49 @@ int dynenv_error_flags(dynenv_t* h, int32_t* out);
  * Synchronises the device. */
 int dynenv_debug_counters(dynenv_t* h, int64_t* out12);
 
+/* ---- ragged -> padded arranger.  Replaces InOutArranger.rearrange_inputs / rearrange_outputs of the
+ * reference's input layer (DynEnv/models/models.py:219-250, :252-274) on the dense observation tensor this library
+ * writes.  Pure functions of device buffers on the current HIP device (no handle).  A "group" is the list of object
+ * types the reference passes as one element of obs[..., 0] / obs[..., 1], e.g. Driving movable = (cars, obstacles,
+ * pedestrians).  P = E*A players, player index p = e*A + a (models.py:222-223).                                   ---- */
+#define DYNENV_ARR_MAX_TYPES 4
+#define DYNENV_ARR_COUNT_CONST 0 /* every (env, time, agent) row holds `count_value` objects of the type */
+#define DYNENV_ARR_COUNT_ENV 1   /* count = count_env[env * count_stride + count_index]   (dynenv_counts() layout) */
+#define DYNENV_ARR_COUNT_ROW 2   /* count = (int) obs_row[count_index]   (Driving Partial keeps list lengths in the row tail) */
+typedef struct dynenv_arr_type {
+  int32_t offset, feat, cap; /* block inside an observation row: float offset, features per object, row capacity */
+  int32_t count_mode, count_value, count_index, count_stride, reserved;
+} dynenv_arr_type_t;
+typedef struct dynenv_arr_plan {
+  int32_t n_types, n_time, n_players, max_count; /* max_count = max over (time, player) of the summed counts (:233) */
+  int64_t total[DYNENV_ARR_MAX_TYPES];           /* N_i = number of objects of type i over all (time, player) */
+} dynenv_arr_plan_t;
+
+/* ints of scratch dynenv_arrange_plan needs for E*T*A rows and n_types types */
+int64_t dynenv_arrange_scratch_ints(int32_t E, int32_t T, int32_t A, int32_t n_types);
+/* Phase 1 (rearrange_inputs :226-236): counts [n_types][T][P], obj_counts [T][P], base [n_types][T][P] = exclusive prefix
+ * sums in (time, player) order (where the objects of (t, p) start inside inputs[i]).  Synchronises the stream and fills
+ * *plan_host (the reference's `.item()` on maxCount is the same host round trip). */
+int dynenv_arrange_plan(const float* obs_dev, int32_t E, int32_t T, int32_t A, int32_t D, const dynenv_arr_type_t* types,
+                        int32_t n_types, const int32_t* count_env_dev, int32_t* counts_dev, int32_t* obj_counts_dev,
+                        int32_t* base_dev, int32_t* scratch_dev, dynenv_arr_plan_t* plan_host, void* stream);
+/* Phase 2 (rearrange_inputs :238-245 + the index arithmetic of rearrange_outputs :259-268): inputs_dev[i] float32
+ * [N_i][feat_i] in (time, player, object) order; slot_dev[i] int32 [N_i] = destination row of each object in the padded
+ * tensor [T][max_count][P][F] viewed as [T*max_count*P][F]; mask_dev uint8 [T][P][max_count], 1 = padding (createMask).
+ * Any of the pointers may be NULL to skip that output. */
+int dynenv_arrange_gather(const float* obs_dev, int32_t E, int32_t T, int32_t A, int32_t D, const dynenv_arr_type_t* types,
+                          int32_t n_types, const int32_t* counts_dev, const int32_t* base_dev, int32_t max_count,
+                          float* const* inputs_dev, int32_t* const* slot_dev, uint8_t* mask_dev, void* stream);
+/* Phase 3 (rearrange_outputs :257-268, catAndPad): padded[slot[n]][:] = emb[n][:] for the N embeddings of one type;
+ * padded_dev float32 [T][max_count][P][F] must have been zeroed by the caller (the padding). */
+int dynenv_arrange_scatter(const float* emb_dev, const int32_t* slot_dev, int64_t N, int32_t F, float* padded_dev, void* stream);
+/* Phase 3, fused (preferred): writes EVERY element of padded_dev float32 [T][max_count][P][F] in one pass - the
+ * embedding of the object that owns the slot, or zero - so no pre-zeroing and no second pass per type.  emb_dev[i] is
+ * float32 [N_i][F] (NULL for a type without objects); F must be a multiple of 4 and the buffers 16-byte aligned. */
+int dynenv_arrange_pad(const float* const* emb_dev, const int32_t* counts_dev, const int32_t* base_dev, int32_t n_types,
+                       int32_t T, int32_t P, int32_t max_count, int32_t F, float* padded_dev, void* stream);
+
+
 /* Device self-test of the deterministic math header: evaluates sincos/atan2/sqrt/div on n host-provided doubles and
  * returns the raw results so tests can compare them bit-for-bit with the host evaluation. out: [n,5]. */
 int dynenv_math_selftest(const double* x_host, const double* y_host, int32_t n, double* out_host, int32_t device_id);
