@@ -36,6 +36,7 @@ struct dynenv {
   bool robocup;
   bool partial;
   std::vector<void*> allocs;
+  std::vector<size_t> alloc_bytes;  // checkpoint = these arrays, in allocation order
 };
 
 // ---------------------------------------------------------------------------------------------- constants
@@ -120,6 +121,7 @@ static int dev_alloc(dynenv* h, T** out, size_t count) {
   HIP_OK(hipMalloc(&p, count * sizeof(T)));
   HIP_OK(hipMemset(p, 0, count * sizeof(T)));
   h->allocs.push_back(p);
+  h->alloc_bytes.push_back(count * sizeof(T));
   *out = (T*)p;
   return 0;
 }
@@ -716,6 +718,65 @@ int dynenv_arrange_pad(const float* const* emb_dev, const int32_t* counts_dev, c
   hipLaunchKernelGGL(arr_pad_kernel, dim3((unsigned)((perRow + ARR_BLOCK - 1) / ARR_BLOCK), (unsigned)(T * max_count)), dim3(ARR_BLOCK), 0, (hipStream_t)stream,
                      e[0], e[1], e[2], e[3], counts_dev, base_dev, n_types, T, P, max_count, F / 4, reinterpret_cast<float4*>(padded_dev));
   HIP_OK(hipGetLastError());
+  return DYNENV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact checkpoint: every device array of the handle, bit for bit
+// ------------------------------------------------------------------------------------------------
+struct CkptHeader {
+  char magic[8];  // "DYNCKPT1"
+  int32_t abi_version, n_arrays;
+  dynenv_cfg_t cfg;
+  uint64_t payload_bytes;
+};
+static size_t ckpt_payload(const dynenv* h) {
+  size_t n = 0;
+  for (size_t b : h->alloc_bytes) n += b;
+  return n;
+}
+size_t dynenv_checkpoint_size(const dynenv_t* h) { return h ? sizeof(CkptHeader) + ckpt_payload(h) : 0; }
+
+int dynenv_checkpoint_save(dynenv_t* h, void* buf_host, size_t nbytes) {
+  if (!h || !buf_host) return fail(DYNENV_ERR_ARG, "null argument");
+  if (nbytes < dynenv_checkpoint_size(h)) return fail(DYNENV_ERR_ARG, "checkpoint buffer too small");
+  HIP_OK(hipDeviceSynchronize());
+  CkptHeader hd;
+  memset(&hd, 0, sizeof(hd));
+  memcpy(hd.magic, "DYNCKPT1", 8);
+  hd.abi_version = DYNENV_ABI_VERSION; hd.n_arrays = (int32_t)h->allocs.size(); hd.cfg = h->cfg;
+  hd.cfg.seed = h->robocup ? h->R.seed : h->S.seed;
+  hd.payload_bytes = ckpt_payload(h);
+  char* out = (char*)buf_host;
+  memcpy(out, &hd, sizeof(hd));
+  out += sizeof(hd);
+  for (size_t i = 0; i < h->allocs.size(); ++i) {
+    HIP_OK(hipMemcpy(out, h->allocs[i], h->alloc_bytes[i], hipMemcpyDeviceToHost));
+    out += h->alloc_bytes[i];
+  }
+  return DYNENV_OK;
+}
+
+int dynenv_checkpoint_load(dynenv_t* h, const void* buf_host, size_t nbytes) {
+  if (!h || !buf_host) return fail(DYNENV_ERR_ARG, "null argument");
+  if (nbytes < sizeof(CkptHeader)) return fail(DYNENV_ERR_ARG, "not a checkpoint");
+  CkptHeader hd;
+  memcpy(&hd, buf_host, sizeof(hd));
+  if (memcmp(hd.magic, "DYNCKPT1", 8) != 0 || hd.abi_version != DYNENV_ABI_VERSION) return fail(DYNENV_ERR_ARG, "not a checkpoint of this ABI version");
+  const dynenv_cfg_t& a = hd.cfg; const dynenv_cfg_t& b = h->cfg;
+  if (a.env_type != b.env_type || a.num_envs != b.num_envs || a.n_players != b.n_players || a.obs_type != b.obs_type ||
+      a.noise_type != b.noise_type || a.noise_magnitude != b.noise_magnitude || a.env_id_offset != b.env_id_offset || a.flags != b.flags)
+    return fail(DYNENV_ERR_ARG, "checkpoint was taken from a differently configured handle");
+  if (hd.n_arrays != (int32_t)h->allocs.size() || hd.payload_bytes != ckpt_payload(h) || nbytes < sizeof(hd) + hd.payload_bytes)
+    return fail(DYNENV_ERR_ARG, "checkpoint layout does not match this build");
+  HIP_OK(hipDeviceSynchronize());
+  const char* in = (const char*)buf_host + sizeof(hd);
+  for (size_t i = 0; i < h->allocs.size(); ++i) {
+    HIP_OK(hipMemcpy(h->allocs[i], in, h->alloc_bytes[i], hipMemcpyHostToDevice));
+    in += h->alloc_bytes[i];
+  }
+  h->cfg.seed = a.seed;
+  if (h->robocup) h->R.seed = a.seed; else h->S.seed = a.seed;
   return DYNENV_OK;
 }
 

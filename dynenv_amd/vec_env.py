@@ -263,6 +263,22 @@ class BatchedDynEnv(object):
         _capi.check(self._lib.dynenv_set_state(self._h, env, C.byref(st), C.sizeof(st)), "dynenv_set_state")
         self._needs_reset = False
 
+    # ------------------------------------------------------------------ exact checkpoint
+    def checkpoint(self):
+        """Every device array of the handle, bit for bit, as a numpy uint8 array (contact cache, shortcut state, episode
+        counters and seed included): restore() + the same actions reproduces the run exactly, mid-episode too."""
+        import numpy as np
+        n = int(self._lib.dynenv_checkpoint_size(self._h))
+        buf = np.empty((n,), np.uint8)
+        _capi.check(self._lib.dynenv_checkpoint_save(self._h, C.c_void_p(buf.ctypes.data), n), "dynenv_checkpoint_save")
+        return buf
+
+    def restore(self, buf):
+        import numpy as np
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        _capi.check(self._lib.dynenv_checkpoint_load(self._h, C.c_void_p(buf.ctypes.data), buf.size), "dynenv_checkpoint_load")
+        self._needs_reset = False
+
     def refresh_obs(self):
         """Re-emit the observation of the current state (after set_state)."""
         raise NotImplementedError

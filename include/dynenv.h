@@ -179,6 +179,15 @@ int dynenv_error_flags(dynenv_t* h, int32_t* out);
  * Synchronises the device. */
 int dynenv_debug_counters(dynenv_t* h, int64_t* out12);
 
+/* ---- exact checkpoint (the reference has none).  Unlike the canonical per-env blob of
+ * dynenv_get_state (which drops the contact cache), a checkpoint is every device array of the handle bit for bit -
+ * bodies, contact cache, shortcut state, episode counters, seed - so that load + the same actions reproduces the run
+ * exactly from the middle of an episode.  Host buffers; the handle must have the configuration the checkpoint was taken
+ * with (env type, sizes, observation/noise type, flags, env_id_offset). ---- */
+size_t dynenv_checkpoint_size(const dynenv_t* h);
+int dynenv_checkpoint_save(dynenv_t* h, void* buf_host, size_t nbytes);
+int dynenv_checkpoint_load(dynenv_t* h, const void* buf_host, size_t nbytes);
+
 /* ---- ragged -> padded arranger.  Replaces InOutArranger.rearrange_inputs / rearrange_outputs of the
  * reference's input layer (DynEnv/models/models.py:219-250, :252-274) on the dense observation tensor this library
  * writes.  Pure functions of device buffers on the current HIP device (no handle).  A "group" is the list of object
