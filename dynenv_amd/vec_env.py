@@ -118,6 +118,63 @@ def _robocup_spaces(obs_type, allow_head_turn):
     return observation_space, action_space, reco
 
 
+class LazyInfo(dict):
+    """The per-environment `info` dict of the reference (subproc_vec_env.py:17-23, DrivingEnvironment.py:306-316) whose two
+    expensive entries - 'Full State' and 'Recon States', lists of per-agent arrays - are built from the step's single
+    host copy of the observations only when somebody reads them.  Everything else of the dict protocol
+    behaves as if they had been there all along."""
+    LAZY = ("Full State", "Recon States")
+
+    def __init__(self, make, eager=None):
+        dict.__init__(self, eager or {})
+        self._make = make
+
+    def _materialise(self):
+        if self._make is not None:
+            full, recon = self._make()
+            self._make = None
+            dict.__setitem__(self, "Full State", full)
+            dict.__setitem__(self, "Recon States", recon)
+
+    def __missing__(self, key):
+        if key in self.LAZY and self._make is not None:
+            self._materialise()
+            return dict.__getitem__(self, key)
+        raise KeyError(key)
+
+    def get(self, key, default=None):
+        if key in self.LAZY:
+            self._materialise()
+        return dict.get(self, key, default)
+
+    def __contains__(self, key):
+        return key in self.LAZY or dict.__contains__(self, key)
+
+    def __iter__(self):
+        self._materialise()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._materialise()
+        return dict.__len__(self)
+
+    def keys(self):
+        self._materialise()
+        return dict.keys(self)
+
+    def items(self):
+        self._materialise()
+        return dict.items(self)
+
+    def values(self):
+        self._materialise()
+        return dict.values(self)
+
+    def __repr__(self):
+        self._materialise()
+        return dict.__repr__(self)
+
+
 class BatchedDynEnv(object):
     """All `num_envs` environments of one GPU shard behind the reference's VecEnv surface."""
 
@@ -286,7 +343,7 @@ class BatchedDynEnv(object):
     # ------------------------------------------------------------------ reference-compatible (legacy) path
     def _compat_obs(self, obs_t, counts):
         """dense [E,T,A,D] -> object ndarray [E,T,A,3] of ((cars, obstacles, peds), (self, lanes), (1,1,1))"""
-        o = obs_t.detach().cpu().numpy()
+        o = obs_t if isinstance(obs_t, np.ndarray) else obs_t.detach().cpu().numpy()
         E, T, A, D = o.shape
         L = self.layout
         off, rows, feat = list(L.block_offset), list(L.block_rows), list(L.block_feat)
@@ -372,29 +429,28 @@ class BatchedDynEnv(object):
         rewards = self.rewards.cpu().numpy().copy()
         done = bool(self.last_done)
         dones = np.full((self.num_envs,), done, dtype=bool)
-        obs_np = self.obs.cpu().numpy()
+        obs_np = self.obs.cpu().numpy()  # the step's ONE device->host copy; obs and infos are views of / built from it
         infos = []
         stats = None
         if done:
             stats = [x.cpu().numpy() for x in self.episode_stats()]
-            term = self._compat_obs(self.obs, counts_before)
+            term = self._compat_obs(obs_np, counts_before)
         for e in range(self.num_envs):
-            full, recon = self._full_states(obs_np, counts_before, e)
-            info = {"Full State": full, "Recon States": recon}
+            eager = {}
             if done:
-                info["episode_r"] = stats[0][e].copy()
-                info["episode_p_r"] = stats[1][e].copy()
-                info["episode_o_r"] = stats[2][e].copy() if self.env_type == DynEnvType.ROBO_CUP else [0, ] * self.n_agents
-                info["episode_g"] = [int(stats[3][e, 0]), int(stats[3][e, 1])]
-                info["terminal_observation"] = [list(term[e, t]) for t in range(self.n_time_steps)]
-            infos.append(info)
+                eager["episode_r"] = stats[0][e].copy()
+                eager["episode_p_r"] = stats[1][e].copy()
+                eager["episode_o_r"] = stats[2][e].copy() if self.env_type == DynEnvType.ROBO_CUP else [0, ] * self.n_agents
+                eager["episode_g"] = [int(stats[3][e, 0]), int(stats[3][e, 1])]
+                eager["terminal_observation"] = [list(term[e, t]) for t in range(self.n_time_steps)]
+            infos.append(LazyInfo(lambda e=e: self._full_states(obs_np, counts_before, e), eager))
         if done:
             self.terminal_obs = self.obs.clone()
             self.reset_flat()
             counts = self.counts().cpu().numpy()
             obs = self._compat_obs(self.obs, counts)
         else:
-            obs = self._compat_obs(self.obs, counts_before)
+            obs = self._compat_obs(obs_np, counts_before)
         return obs, rewards, dones, tuple(infos)
 
     def step(self, actions):

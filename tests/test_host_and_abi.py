@@ -110,3 +110,26 @@ def test_shard_ranges():
     assert [shard_range(32768, r, 8) for r in (0, 7)] == [(0, 4096), (28672, 4096)]
     with pytest.raises(ValueError):
         shard_range(10, 0, 3)
+
+
+def test_lazy_info_behaves_like_the_eager_dict():
+    """'Full State' / 'Recon States' are built on first access, the dict protocol does not notice"""
+    from dynenv_amd.vec_env import LazyInfo
+    calls = []
+
+    def make():
+        calls.append(1)
+        return ["full"], ["recon"]
+    d = LazyInfo(make, {"episode_r": 1.5})
+    assert "episode_r" in d.keys.__self__ and not calls  # touching the eager part builds nothing
+    assert "Full State" in d and "Recon States" in d and not calls
+    assert d["episode_r"] == 1.5 and not calls
+    assert d["Recon States"] == ["recon"] and calls == [1]
+    assert d["Full State"] == ["full"] and calls == [1]
+    assert set(d.keys()) == {"episode_r", "Full State", "Recon States"} and len(d) == 3
+    d2 = LazyInfo(make)
+    assert d2.get("Full State") == ["full"] and d2.get("nope", 7) == 7
+    d3 = LazyInfo(make)
+    assert sorted(k for k in d3) == ["Full State", "Recon States"]
+    with pytest.raises(KeyError):
+        d3["episode_r"]
