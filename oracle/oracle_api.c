@@ -10,6 +10,7 @@
 
 #include "driving.h"
 #include "robocup.h"
+#include "robocup_partial.h"
 #include "dynenv.h"
 #include "dynenv_math.h"
 
@@ -40,13 +41,16 @@ int oracle_create(const dynenv_cfg_t* cfg, oracle_t** out) {
       o->drv[i].obsType = cfg->obs_type; o->drv[i].noiseType = cfg->noise_type; o->drv[i].noiseMagnitude = cfg->noise_magnitude;
     }
   } else if (cfg->env_type == DYNENV_ROBO_CUP) {
-    if (cfg->obs_type != DYNENV_OBS_FULL) { free(o); return DYNENV_ERR_UNSUPPORTED; }
+    if (cfg->obs_type != DYNENV_OBS_FULL && cfg->obs_type != DYNENV_OBS_PARTIAL) { free(o); return DYNENV_ERR_UNSUPPORTED; }
     o->n_agents = 2 * (cfg->n_players > RC_MAX_PLAYERS ? RC_MAX_PLAYERS : cfg->n_players);
-    o->obs_dim = rc_obs_dim(o->n_agents / 2);
+    o->obs_dim = cfg->obs_type == DYNENV_OBS_PARTIAL ? rc_partial_obs_dim() : rc_obs_dim(o->n_agents / 2);
     o->n_time_steps = 5;
     o->action_dim = 4;
     o->rc = (RoboCupEnv*)calloc((size_t)cfg->num_envs, sizeof(RoboCupEnv));
-    for (i = 0; i < cfg->num_envs; ++i) rc_init(&o->rc[i], cfg->n_players, cfg->seed, (uint32_t)(cfg->env_id_offset + i), cfg->flags);
+    for (i = 0; i < cfg->num_envs; ++i) {
+      rc_init(&o->rc[i], cfg->n_players, cfg->seed, (uint32_t)(cfg->env_id_offset + i), cfg->flags);
+      o->rc[i].obsType = cfg->obs_type; o->rc[i].noiseType = cfg->noise_type; o->rc[i].noiseMagnitude = cfg->noise_magnitude;
+    }
   } else {
     free(o);
     return DYNENV_ERR_UNSUPPORTED;
@@ -109,7 +113,12 @@ int oracle_reset(oracle_t* o, float* obs) {
       int t;
       rc_reset(&o->rc[e]);
       /* environment_base.py:217-222: nTimeSteps identical copies of the initial observation */
-      if (obs) for (t = 0; t < o->n_time_steps; ++t) rc_write_full_obs(&o->rc[e], obs + e * stride + (size_t)t * o->n_agents * o->obs_dim);
+      if (obs) for (t = 0; t < o->n_time_steps; ++t) {
+        float* dst = obs + e * stride + (size_t)t * o->n_agents * o->obs_dim;
+        /* Partial: nTimeSteps separate getAgentVision calls, each with fresh noise (draw keys: time word = t) */
+        if (o->rc[e].obsType == DYNENV_OBS_PARTIAL) rc_write_partial_obs(&o->rc[e], (uint32_t)t, dst);
+        else rc_write_full_obs(&o->rc[e], dst);
+      }
     }
   }
   return DYNENV_OK;
@@ -144,7 +153,7 @@ int oracle_episode_stats(oracle_t* o, double* ep_r, double* ep_pos_r, double* ep
       for (a = 0; a < A; ++a) {
         if (ep_r) ep_r[e * A + a] = r->episodeRewards[a];
         if (ep_pos_r) ep_pos_r[e * A + a] = r->episodePosRewards[a];
-        if (ep_obs_r) ep_obs_r[e * A + a] = 0.0;
+        if (ep_obs_r) ep_obs_r[e * A + a] = r->episodeObsRewards[a];
       }
       if (goals) { goals[2 * e] = r->goals[0]; goals[2 * e + 1] = r->goals[1]; }
     }
@@ -363,3 +372,7 @@ void oracle_rc_spots(const double* rnd18, double* out20) {
   rc_spots(rnd18, spots);
   for (t = 0; t < 2; ++t) for (i = 0; i < 5; ++i) { out20[(t * 5 + i) * 2] = spots[t][i].x; out20[(t * 5 + i) * 2 + 1] = spots[t][i].y; }
 }
+
+/* test hook: one snapshot of Partial observations of every robot of env, draw keys with time word `tkey` */
+int oracle_rc_partial_obs(oracle_t* o, int env, uint32_t tkey, float* out) { return rc_write_partial_obs(&o->rc[env], tkey, out); }
+double oracle_rc_process_seens(double lSum, const double* rSum, int nOthers, double bSum) { return rc_process_seens(lSum, rSum, nOthers, bSum); }

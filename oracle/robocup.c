@@ -8,6 +8,7 @@
  *   goalpostCollision dice   -> entity = pair key | 3<<16,    word 0                             (:1121)
  * Physics underneath is the unpinned Chipmunk restatement (cp_lite); game logic pinned by tests/golden/robocup_*. */
 #include "robocup.h"
+#include "robocup_partial.h"
 
 #include <math.h>
 #include <string.h>
@@ -522,6 +523,7 @@ void rc_init(RoboCupEnv* e, int nPlayers, uint64_t seed, uint32_t genv, int flag
   e->seed = seed; e->genv = genv; e->episode = 0;
   e->canFall = (flags & DYNENV_FLAG_CAN_FALL) != 0;
   e->allowHeadTurn = (flags & DYNENV_FLAG_ALLOW_HEAD_TURN) != 0;
+  e->useObsRewards = (flags & DYNENV_FLAG_USE_OBS_REWARDS) != 0;
 }
 
 /* _create_robot_spots :275-293 (randomInit = False), the 18 random.random() draws consumed in source order */
@@ -569,7 +571,7 @@ void rc_reset(RoboCupEnv* e) { /* __init__ :23-64 + _setup_scene :73-99 (randomI
   e->nDefenders[0] = e->nDefenders[1] = 0;
   e->penalTimes[0] = e->penalTimes[1] = 20000.0;
   e->teamRewards[0] = e->teamRewards[1] = 0.0;
-  for (i = 0; i < RC_MAX_ROBOTS; ++i) { e->robotRewards[i] = e->robotPosRewards[i] = e->episodeRewards[i] = e->episodePosRewards[i] = 0.0; }
+  for (i = 0; i < RC_MAX_ROBOTS; ++i) { e->robotRewards[i] = e->robotPosRewards[i] = e->episodeRewards[i] = e->episodePosRewards[i] = e->episodeObsRewards[i] = 0.0; }
   build_space(e);
   e->episode++;
 }
@@ -619,10 +621,32 @@ void rc_write_full_obs(const RoboCupEnv* e, float* out) {
 }
 
 /* ------------------------------------------------------------------ step :446-524 */
+/* processSeens (RoboCupEnvironment.py, `def processSeens`) for one robot: sums over the step's 5 snapshots of numLandMarks,
+ * of each other robot's seen flag, and of ballsSeen -> the observation reward */
+double rc_process_seens(double lSum, const double* rSum, int nOthers, double bSum) {
+  const double factor = 0.0025, bfactor = 0.01;
+  double lSeens = lSum / 5.0, rSeens = 0.0, bSeens = bSum;
+  int k;
+  lSeens = lSeens < 0.0 ? 0.0 : (lSeens > 3.0 ? 3.0 : lSeens);
+  for (k = 0; k < nOthers; ++k) rSeens += rSum[k] < 0.0 ? 0.0 : (rSum[k] > 2.0 ? 2.0 : rSum[k]);
+  bSeens = bSeens < 0.0 ? 0.0 : (bSeens > 3.0 ? 3.0 : bSeens);
+  return factor * (rSeens + lSeens) + bfactor * bSeens;
+}
+
 int rc_step(RoboCupEnv* e, const int32_t* actions, float* obs, double* rewards) {
-  int R = e->nRobots, n = e->nPlayers, i, a, t = 0, dim = rc_obs_dim(n);
+  int R = e->nRobots, n = e->nPlayers, i, a, k, t = 0;
+  const int partial = e->obsType == DYNENV_OBS_PARTIAL;
+  const int dim = partial ? RCP_DIM : rc_obs_dim(n);
+  double obsRewards[RC_MAX_ROBOTS];
+  /* processSeens inputs (:1563-1575): per robot the 5 snapshots' numLandMarks, robotsSeen arrays, ballsSeen */
+  double lSum[RC_MAX_ROBOTS], rSum[RC_MAX_ROBOTS][RC_MAX_ROBOTS], bSum[RC_MAX_ROBOTS];
+  float row[RCP_DIM];
   e->teamRewards[0] = e->teamRewards[1] = 0.0;
-  for (a = 0; a < RC_MAX_ROBOTS; ++a) e->robotRewards[a] = e->robotPosRewards[a] = 0.0;
+  for (a = 0; a < RC_MAX_ROBOTS; ++a) {
+    e->robotRewards[a] = e->robotPosRewards[a] = 0.0;
+    obsRewards[a] = 0.0; lSum[a] = bSum[a] = 0.0;
+    for (k = 0; k < RC_MAX_ROBOTS; ++k) rSum[a][k] = 0.0;
+  }
   for (i = 0; i < RC_STEP_ITER; ++i) {
     for (a = 0; a < R; ++a) {
       if (i == 0) rc_process_action(e, &e->robots[a], actions + 4 * a);
@@ -632,18 +656,29 @@ int rc_step(RoboCupEnv* e, const int32_t* actions, float* obs, double* rewards) 
     cpSpaceStep(&e->space, 1.0 / 100.0);
     e->elapsed += 1;
     if (i % 10 == 9) {
-      if (obs) rc_write_full_obs(e, obs + (size_t)t * R * dim);
+      if (partial) {
+        for (a = 0; a < R; ++a) {
+          float* o = obs ? obs + ((size_t)t * R + a) * dim : row;
+          if (rc_agent_vision(e, a, e->noiseType, e->noiseMagnitude, (uint32_t)e->elapsed, o)) e->obsOverflow = 1;
+          lSum[a] += (double)o[RCP_OFF_TAIL + 6];
+          bSum[a] += (double)o[RCP_OFF_TAIL + 7];
+          for (k = 0; k < R - 1; ++k) rSum[a][k] += (double)o[RCP_OFF_TAIL + 8 + k];
+        }
+      } else if (obs) rc_write_full_obs(e, obs + (size_t)t * R * dim);
       ++t;
     }
   }
+  if (partial && e->useObsRewards)
+    for (a = 0; a < R; ++a) obsRewards[a] += rc_process_seens(lSum[a], rSum[a], R - 1, bSum[a]);
   for (a = 0; a < R; ++a) {
     double tr = a < n ? e->teamRewards[0] : e->teamRewards[1];
     e->robotRewards[a] += tr;
-    e->robotRewards[a] += 0.0; /* obsRewards (zero for Full observations, processSeens :1565-1566) */
+    e->robotRewards[a] += obsRewards[a]; /* zero for Full observations (processSeens returns early, :1565-1566) */
     e->episodeRewards[a] += e->robotRewards[a];
     e->robotPosRewards[a] += dm_max(0.0, tr);
-    e->robotPosRewards[a] += 0.0;
+    e->robotPosRewards[a] += dm_max(obsRewards[a], 0.0); /* np.clip(obsRewards, a_min=0) :503 */
     e->episodePosRewards[a] += e->robotPosRewards[a];
+    e->episodeObsRewards[a] += obsRewards[a];
     rewards[a] = e->robotRewards[a];
   }
   return e->elapsed >= RC_MAX_TIME;

@@ -1,5 +1,5 @@
 /* robocup.h — ORACLE (test infrastructure): CPU restatement of DynEnv/RoboCupEnvironment.py (+ Robot.py, Ball.py,
- * Goalpost.py) on top of cp_lite.  Full observation only (configs[2]); Partial/Image are out of scope this round. */
+ * Goalpost.py) on top of cp_lite.  Full observation (configs[2]) and Partial observation (robocup_partial.c). */
 #ifndef ORACLE_ROBOCUP_H
 #define ORACLE_ROBOCUP_H
 
@@ -48,7 +48,11 @@ typedef struct RoboCupEnv {
   double penalTimes[2];
   double teamRewards[2], robotRewards[RC_MAX_ROBOTS], robotPosRewards[RC_MAX_ROBOTS];
   double episodeRewards[RC_MAX_ROBOTS], episodePosRewards[RC_MAX_ROBOTS];
-  int canFall, allowHeadTurn;
+  int canFall, allowHeadTurn, useObsRewards;
+  int obsType, noiseType;      /* ObservationType / NoiseType (cutils.py:29-51) */
+  double noiseMagnitude;
+  double episodeObsRewards[RC_MAX_ROBOTS];
+  int obsOverflow;
   uint64_t seed;
   uint32_t genv, episode;
 } RoboCupEnv;
@@ -59,6 +63,7 @@ void rc_reset(RoboCupEnv* e);
 void rc_write_full_obs(const RoboCupEnv* e, float* out /* [2n][obs_dim] */);
 int rc_step(RoboCupEnv* e, const int32_t* actions /* [2n][4] */, float* obs /* [5][2n][obs_dim] or NULL */, double* rewards);
 
+double rc_process_seens(double lSum, const double* rSum, int nOthers, double bSum);
 void rc_process_action(RoboCupEnv* e, Robot* r, const int32_t* action);
 void rc_tick(RoboCupEnv* e, Robot* r);
 int rc_is_ball_out_of_field(RoboCupEnv* e);
