@@ -25,6 +25,10 @@ def groups_for(env):
     def ty(offset, f, cap, mode=_capi.ARR_COUNT_CONST, value=0, index=0, stride=0):
         return _capi.ArrType(offset, f, cap, mode, value, index, stride, 0)
 
+    if env.env_type == DynEnvType.ROBO_CUP and env.observationType == ObservationType.PARTIAL:
+        t = off[6]  # tail: list lengths of balls, robots, goals, crosses, line crosses, lines
+        mk = lambda k: ty(off[k], feat[k], rows[k], _capi.ARR_COUNT_ROW, index=t + k)
+        return {"movable": [mk(0), mk(1)], "static": [mk(2), mk(3), mk(4), mk(5)]}
     if env.env_type == DynEnvType.ROBO_CUP:  # row = [ball 4 | self 8 | robots (A-1) x 6], see vec_env._compat_obs
         return {"movable": [ty(0, 4, 1, value=1), ty(12, 6, A - 1, value=A - 1)], "static": [ty(4, 8, 1, value=1)]}
     if env.observationType == ObservationType.PARTIAL:  # list lengths live in the last four floats of the row

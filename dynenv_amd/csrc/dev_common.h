@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "dynenv.h"
 #include "dynenv_math.h"
 
 #define DE_WAVE 64

@@ -140,7 +140,8 @@ static int rc_create(dynenv* h) {
   memset(&R, 0, sizeof(R));
   const size_t E = (size_t)cfg.num_envs;
   R.E = (int)E; R.n = cfg.n_players > 5 ? 5 : cfg.n_players; R.R = 2 * R.n;  // environment_base.py:57, maxPlayers = 5
-  R.obs_dim = 4 + 8 + (R.R - 1) * 6;
+  R.obs_type = cfg.obs_type; R.noise_type = cfg.noise_type; R.noise_magn = cfg.noise_magnitude;
+  R.obs_dim = cfg.obs_type == DYNENV_OBS_PARTIAL ? RCP_DIM : 4 + 8 + (R.R - 1) * 6;
   R.seed = cfg.seed; R.env_id_offset = cfg.env_id_offset; R.flags = cfg.flags;
   h->A = R.R; h->obs_dim = R.obs_dim; h->T = 5; h->action_dim = 4;
   int rc = 0;
@@ -150,6 +151,8 @@ static int rc_create(dynenv* h) {
   rc |= dev_alloc(h, &R.envi, E * RE_COUNT);
   rc |= dev_alloc(h, &R.envd, E * RD_COUNT);
   rc |= dev_alloc(h, &R.epr, 2 * E * 16);
+  rc |= dev_alloc(h, &R.epo, E * 16);
+  rc |= dev_alloc(h, &R.seen, E * 10 * RCP_SEEN_STRIDE);
   rc |= dev_alloc(h, &R.s_pair, E * RC_NS);
   rc |= dev_alloc(h, &R.s_meta, E * RC_NS);
   rc |= dev_alloc(h, &R.s_hash, 2 * E * RC_NS);
@@ -171,6 +174,30 @@ static int rc_create(dynenv* h) {
     c.jkk0 = k22 * det_inv; c.jkk1 = -k12 * det_inv; c.jkk2 = -k21 * det_inv; c.jkk3 = k11 * det_inv;
     c.jiSum = 1.0 / (ia + ib);
     c.footMinv = ma; c.footIinv = ia; c.ballIinv = 1.0 / c.ballInertia;
+  }
+  {  // the Partial-observation scene by vision lane (same expressions as oracle/robocup_partial.c rcp_scene)
+    const double W = RC_W, H = RC_H, s = RC_SIDE, pl = 60.0, pw = 110.0, cr = 75.0, pd = 130.0, gw = 80.0;
+    int i = 33;
+#define LN(ax, ay, bx, by, tx, ty) do { c.visPx[i] = ax; c.visPy[i] = ay; c.visQx[i] = bx; c.visQy[i] = by; c.visT0[i] = tx; c.visT1[i] = ty; ++i; } while (0)
+    LN(s, s, s, H - s, 1, 0); LN(W - s, s, W - s, H - s, -1, 0); LN(s, s, W - s, s, 0, 1); LN(s, H - s, W - s, H - s, 0, -1);
+    LN(W / 2, s, W / 2, H - s, 0, 0);
+    LN(s, H / 2 - pw, s + pl, H / 2 - pw, 1, 0.37); LN(s, H / 2 + pw, s + pl, H / 2 + pw, 1, -0.37);
+    LN(s + pl, H / 2 - pw, s + pl, H / 2 + pw, 0.87, 0);
+    LN(W - s - pl, H / 2 - pw, W - s, H / 2 - pw, -1, 0.37); LN(W - s - pl, H / 2 + pw, W - s, H / 2 + pw, -1, -0.37);
+    LN(W - s - pl, H / 2 - pw, W - s - pl, H / 2 + pw, -0.87, 0);
+#undef LN
+#define PT(k, x, y, tx, ty) do { c.visPx[k] = x; c.visPy[k] = y; c.visT0[k] = tx; c.visT1[k] = ty; } while (0)
+    PT(10, s, H / 2 + gw, 1, -0.27); PT(11, s, H / 2 - gw, 1, 0.27); PT(12, W - s, H / 2 + gw, -1, -0.27); PT(13, W - s, H / 2 - gw, -1, 0.27);
+    PT(14, 520.0, 370.0, 0, 0); PT(15, s + pd, 370.0, 1, 0); PT(16, W - (s + pd), 370.0, -1, 0);
+    i = 17;
+#define FC(x, y, tx, ty) do { PT(i, x, y, tx, ty); ++i; } while (0)
+    FC(s, s, 1, 1); FC(s, H - s, 1, -1); FC(W - s, s, -1, 1); FC(W - s, H - s, -1, -1);
+    FC(W / 2, s, 0, 1); FC(W / 2, H - s, 0, -1);
+    FC(W / 2, H / 2 - cr * 2, 0, 0.5); FC(W / 2, H / 2 + cr * 2, 0, -0.5);
+    FC(s, H / 2 - pw, 1, 0.37); FC(s, H / 2 + pw, 1, -0.37); FC(s + pl, H / 2 - pw, 0.87, 0.37); FC(s + pl, H / 2 + pw, 0.87, -0.37);
+    FC(W - s, H / 2 - pw, -1, 0.37); FC(W - s, H / 2 + pw, -1, -0.37); FC(W - s - pl, H / 2 - pw, -0.87, 0.37); FC(W - s - pl, H / 2 + pw, -0.87, -0.37);
+#undef FC
+#undef PT
   }
   int p = 0;
   for (int i = 0; i <= RC_BALL; ++i)
@@ -310,8 +337,8 @@ int dynenv_create(const dynenv_cfg_t* cfg, dynenv_t** out) {
   if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(DYNENV_ERR_ARG, "device_id out of range");
   HIP_OK(hipSetDevice(cfg->device_id));
   if (cfg->env_type != DYNENV_DRIVE && cfg->env_type != DYNENV_ROBO_CUP) return fail(DYNENV_ERR_ARG, "unknown env_type");
-  if (cfg->obs_type != DYNENV_OBS_FULL && !(cfg->obs_type == DYNENV_OBS_PARTIAL && cfg->env_type == DYNENV_DRIVE))
-    return fail(DYNENV_ERR_UNSUPPORTED, "Partial observations are built for Driving only; Image observations are out of scope");
+  if (cfg->obs_type != DYNENV_OBS_FULL && cfg->obs_type != DYNENV_OBS_PARTIAL)
+    return fail(DYNENV_ERR_UNSUPPORTED, "Image observations are out of scope");
   dynenv* h = new dynenv();
   h->cfg = *cfg;
   h->robocup = cfg->env_type == DYNENV_ROBO_CUP;
@@ -370,6 +397,17 @@ int dynenv_layout(const dynenv_t* h, dynenv_layout_t* L) {
   int A = h->A;
   L->num_envs = h->cfg.num_envs; L->n_agents = A; L->n_time_steps = h->T; L->obs_dim = h->obs_dim;
   L->action_dim = h->action_dim;
+  if (h->robocup && h->cfg.obs_type == DYNENV_OBS_PARTIAL) {
+    // ((balls, robots), (goals, crosses, line crosses, lines), (numLandMarks, robotsSeen, ballsSeen)) of getAgentVision;
+    // block 6 = the tail: 6 list lengths, numLandMarks, ballsSeen, robotsSeen[9]
+    const int off[7] = {RCP_OFF_BALL, RCP_OFF_ROB, RCP_OFF_GOAL, RCP_OFF_CROSS, RCP_OFF_FCROSS, RCP_OFF_LINE, RCP_OFF_TAIL};
+    const int rows[7] = {RCP_CAP_BALL, RCP_CAP_ROB, RCP_CAP_GOAL, RCP_CAP_CROSS, RCP_CAP_FCROSS, RCP_CAP_LINE, 1};
+    const int feat[7] = {5, 7, 6, 6, 8, 5, 17};
+    L->n_blocks = 7;
+    for (int i = 0; i < 7; ++i) { L->block_offset[i] = off[i]; L->block_rows[i] = rows[i]; L->block_feat[i] = feat[i]; }
+    L->steps_per_episode = RC_MAX_TIME / 50;
+    return DYNENV_OK;
+  }
   if (h->robocup) {
     L->n_blocks = 3;  // ((ball, robots), (self,)) of RoboCupEnvironment.py:440-443
     L->block_offset[0] = 0; L->block_rows[0] = 1; L->block_feat[0] = 4;

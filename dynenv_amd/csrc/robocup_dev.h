@@ -53,6 +53,10 @@ struct RcConst {
      host with the expression sequence of cpPivotJoint/cpRotaryLimitJoint preStep: identical bits, no per-substep divisions */
   double ballIinv, footMinv, footIinv, jkk0, jkk1, jkk2, jkk3, jiSum;
   uint16_t pairs[RC_NPAIR_ROUNDS * 64];
+  /* Partial observation (robocup_partial.hip): the scene by vision lane - 10..13 goalposts, 14..16 penalty crosses,
+     17..32 line crosses, 33..43 lines (P = first end point, Q = second); T0/T1 = the two tags of each entry
+     (RoboCupEnvironment._create_football_field / _create_goalposts) */
+  double visPx[48], visPy[48], visQx[48], visQy[48], visT0[48], visT1[48];
 };
 
 struct RcState {
@@ -65,6 +69,10 @@ struct RcState {
   int* envi;     /* [E][RE_COUNT] */
   double* envd;  /* [E][RD_COUNT] */
   double* epr;   /* [2][E][16] */
+  double* epo;   /* [E][16] episode sum of the observation rewards (processSeens) */
+  int* seen;     /* [E][10][12] per robot: numLandMarks sum, ballsSeen sum, robotsSeen[9] sums over the step's 5 snapshots */
+  int obs_type, noise_type;
+  double noise_magn;
   int* s_pair;   /* [E][NS] */
   int* s_meta;
   uint32_t* s_hash; /* [2][E][NS] */

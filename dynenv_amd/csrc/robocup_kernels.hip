@@ -1369,6 +1369,8 @@ DE_DEV void rc_write_obs(RcLds& L, int lane, int R, int obs_dim, float* __restri
 // ------------------------------------------------------------------------------------------------
 // THE RoboCup step kernel
 // ------------------------------------------------------------------------------------------------
+#include "robocup_partial.hip"
+
 extern "C" __global__ void __launch_bounds__(64, RC_WAVES_PER_SIMD)
 rc_step_kernel(RcState S, const int* __restrict__ actions, float* __restrict__ obs, double* __restrict__ rewards,
                uint8_t* __restrict__ dones) {
@@ -1395,6 +1397,10 @@ rc_step_kernel(RcState S, const int* __restrict__ actions, float* __restrict__ o
   c.episode = (uint32_t)L.envi[RE_EPISODE];
   if (lane == 0) refresh_pivot_first(L);
   __syncthreads();
+  const bool partial = S.obs_type == DYNENV_OBS_PARTIAL;
+  int* seen = S.seen + (size_t)e * 10 * RCP_SEEN_STRIDE;
+  if (partial) for (int i = lane; i < 10 * RCP_SEEN_STRIDE; i += DE_WAVE) seen[i] = 0;
+  int visOverflow = 0;
   const bool isBody = lane == RC_BALL || lane < 2 * R;
   const int* myActions = actions + (size_t)e * R * 4;
   int snap = 0;
@@ -1465,22 +1471,39 @@ RC_PROF(const unsigned long long A3 = __builtin_amdgcn_s_memtime(); tG += A1 - A
     if (lane == 0) L.envi[RE_ELAPSED] += 1;
     __syncthreads();
     if (it % 10 == 9) {
-      if (obs) rc_write_obs(L, lane, R, S.obs_dim, obs + ((size_t)e * 5 + snap) * R * S.obs_dim);
+      if (partial) {  // getAgentVision of every robot on the state of this snapshot (RoboCupEnvironment.step, i % 10 == 9)
+        RvArgs va;
+        va.seed = S.seed; va.genv = c.genv; va.episode = c.episode; va.tkey = (uint32_t)uniform_i(L.envi[RE_ELAPSED]);
+        va.R = R; va.n = S.n; va.noiseType = S.noise_type; va.magn = S.noise_magn;
+        visOverflow |= rc_partial_vision(va, lane, obs + ((size_t)e * 5 + snap) * R * RCP_DIM, seen);
+      } else if (obs) rc_write_obs(L, lane, R, S.obs_dim, obs + ((size_t)e * 5 + snap) * R * S.obs_dim);
       ++snap;
     }
   }
 RC_PROF(if (lane == 0 && e < 4096) { unsigned long long* d = g_rcprof + e * 12; d[0] = tG; d[1] = tP; d[2] = tB; d[11] = __builtin_amdgcn_s_memtime() - K0; })
   // ---- end of env step :497-524 ------------------------------------------------------------------------------
+  if (partial) __threadfence();  // the snapshot kernels' counters (global) are visible to the robot lanes
   if (lane < R) {
     const double tr = lane < S.n ? L.teamRew[0] : L.teamRew[1];
+    double obsRew = 0.0;
+    if (partial && (S.flags & 8)) {  // processSeens (useObsRewards): see oracle/robocup.c rc_process_seens
+      const int* sn = seen + lane * RCP_SEEN_STRIDE;
+      double lSeens = (double)sn[0] / 5.0, rSeens = 0.0, bSeens = (double)sn[1];
+      lSeens = lSeens < 0.0 ? 0.0 : (lSeens > 3.0 ? 3.0 : lSeens);
+      for (int k = 0; k < R - 1; ++k) { const double r = (double)sn[2 + k]; rSeens += r < 0.0 ? 0.0 : (r > 2.0 ? 2.0 : r); }
+      bSeens = bSeens < 0.0 ? 0.0 : (bSeens > 3.0 ? 3.0 : bSeens);
+      obsRew += (0.0025 * (rSeens + lSeens) + 0.01 * bSeens);
+    }
     double rew = L.rrew[lane] + tr;
-    rew += 0.0;
+    rew += obsRew;
     double prew = L.rposrew[lane] + dm_max(0.0, tr);
-    prew += 0.0;
+    prew += dm_max(obsRew, 0.0);
     double* er = S.epr + (size_t)e * 16 + lane;
     double* ep = S.epr + (size_t)S.E * 16 + (size_t)e * 16 + lane;
+    double* eo = S.epo + (size_t)e * 16 + lane;
     *er = *er + rew;
     *ep = *ep + prew;
+    *eo = *eo + obsRew;
     rewards[(size_t)e * R + lane] = rew;
   }
   __syncthreads();
@@ -1488,6 +1511,7 @@ RC_PROF(if (lane == 0 && e < 4096) { unsigned long long* d = g_rcprof + e * 12; 
     dones[e] = (uint8_t)(L.envi[RE_ELAPSED] >= RC_MAX_TIME);
     L.envi[RE_OCC] = (int)(uint32_t)occ;
     if (err) L.envi[RE_ERR] |= 1;
+    if (visOverflow) L.envi[RE_ERR] |= 2;
   }
   __syncthreads();
   rc_store_env(S, L, e, lane, occ);
@@ -1498,6 +1522,18 @@ extern "C" __global__ void __launch_bounds__(64) rc_obs_kernel(RcState S, float*
   const int e = blockIdx.x, lane = threadIdx.x;
   rc_load_env(S, L, e, lane, 0ull);
   __syncthreads();
+  if (S.obs_type == DYNENV_OBS_PARTIAL) {
+    // environment_base.py:217-222: nTimeSteps separate getAgentVision calls, each with fresh noise (draw keys: time = t)
+    int ov = 0;
+    for (int t = 0; t < 5; ++t) {
+      RvArgs va;
+      va.seed = S.seed; va.genv = (uint32_t)(S.env_id_offset + e); va.episode = (uint32_t)uniform_i(L.envi[RE_EPISODE]); va.tkey = (uint32_t)t;
+      va.R = S.R; va.n = S.n; va.noiseType = S.noise_type; va.magn = S.noise_magn;
+      ov |= rc_partial_vision(va, lane, obs + ((size_t)e * 5 + t) * S.R * RCP_DIM, nullptr);
+    }
+    if (ov && lane == 0) S.envi[(size_t)e * RE_COUNT + RE_ERR] |= 2;
+    return;
+  }
   for (int t = 0; t < 5; ++t)  // environment_base.py:217-222: nTimeSteps copies of the initial observation
     rc_write_obs(L, lane, S.R, S.obs_dim, obs + ((size_t)e * 5 + t) * S.R * S.obs_dim);
 }
@@ -1518,7 +1554,7 @@ extern "C" __global__ void __launch_bounds__(64) rc_reset_kernel(RcState S) {
   for (int k = 0; k < 16; ++k) {
     for (int f = 0; f < RR_COUNT; ++f) S.rob[(size_t)f * E * 16 + (size_t)e * 16 + k] = 0.0;
     for (int f = 0; f < RI_COUNT; ++f) S.robi[(size_t)f * E * 16 + (size_t)e * 16 + k] = 0;
-    S.epr[(size_t)e * 16 + k] = 0.0; S.epr[E * 16 + (size_t)e * 16 + k] = 0.0;
+    S.epr[(size_t)e * 16 + k] = 0.0; S.epr[E * 16 + (size_t)e * 16 + k] = 0.0; S.epo[(size_t)e * 16 + k] = 0.0;
   }
   for (int k = 0; k < RC_NS; ++k) { S.s_pair[(size_t)e * RC_NS + k] = 0xFFFF; S.s_meta[(size_t)e * RC_NS + k] = 0; }
   double rnd[18];
@@ -1581,7 +1617,7 @@ extern "C" __global__ void rc_stats_kernel(RcState S, double* ep_r, double* ep_p
   for (int a = 0; a < S.R; ++a) {
     if (ep_r) ep_r[(size_t)e * S.R + a] = S.epr[(size_t)e * 16 + a];
     if (ep_pos_r) ep_pos_r[(size_t)e * S.R + a] = S.epr[(size_t)S.E * 16 + (size_t)e * 16 + a];
-    if (ep_obs_r) ep_obs_r[(size_t)e * S.R + a] = 0.0;
+    if (ep_obs_r) ep_obs_r[(size_t)e * S.R + a] = S.epo[(size_t)e * 16 + a];
   }
   if (goals) { goals[2 * e] = S.envi[(size_t)e * RE_COUNT + RE_GOAL0]; goals[2 * e + 1] = S.envi[(size_t)e * RE_COUNT + RE_GOAL1]; }
 }

@@ -1,0 +1,372 @@
+// robocup_partial.hip — RoboCup PARTIAL observation on gfx950.
+//
+// Replaces RoboCupEnvironment.getAgentVision (detections, interactions, noise, misclassification, random false
+// positives, false-positive balls near robots, polar / line conversion) with cutils.isSeenInArea / isLineInArea /
+// doesInteract / addNoise / addNoiseLine / convertToPolar / normalizeLine, for every robot of an environment at each of
+// the step's five snapshots, inside rc_step_kernel (the observation needs the state AT the snapshot).  Mirrors
+// oracle/robocup_partial.c operation by operation (bit-identical rows); the RNG keying is described there.
+// For one agent the lanes are the things it might see:
+//   lane 0 ball | 1..9 the other robots | 10..13 goalposts | 14..16 penalty crosses | 17..32 line crosses | 33..43 lines
+//   | 44..53 the ten random false-positive trials.
+// List positions come from ballots + popcounts; the field-cross `insert(len(crossDets), ..)` quirk is replayed serially.
+#define RCP_CAP_BALL 32
+#define RCP_CAP_ROB 20
+#define RCP_CAP_GOAL 16
+#define RCP_CAP_CROSS 16
+#define RCP_CAP_FCROSS 28
+#define RCP_CAP_LINE 12
+#define RCP_OFF_BALL 0
+#define RCP_OFF_ROB (RCP_OFF_BALL + RCP_CAP_BALL * 5)
+#define RCP_OFF_GOAL (RCP_OFF_ROB + RCP_CAP_ROB * 7)
+#define RCP_OFF_CROSS (RCP_OFF_GOAL + RCP_CAP_GOAL * 6)
+#define RCP_OFF_FCROSS (RCP_OFF_CROSS + RCP_CAP_CROSS * 6)
+#define RCP_OFF_LINE (RCP_OFF_FCROSS + RCP_CAP_FCROSS * 8)
+#define RCP_OFF_TAIL (RCP_OFF_LINE + RCP_CAP_LINE * 5)
+#define RCP_DIM (RCP_OFF_TAIL + 6 + 2 + 9)
+#define RCP_SEEN_STRIDE 12  // per agent: lSum, bSum, rSum[9], pad
+
+#define RV_NONE 0
+#define RV_PARTIAL 1
+#define RV_DISTANT 2
+#define RV_NORMAL 3
+#define RV_MISCLASS 4
+#define RV_FOV (DM_PI / 4.0)
+#define RV_MAXVIS0 ((RC_W * 0.4) * (RC_W * 0.4))
+#define RV_MAXVIS1 ((RC_W * 0.8) * (RC_W * 0.8))
+#define RV_STD_NORM (2.0 / RC_W)
+#define RV_SIZE_NORM (10.0 / 5.0)
+
+struct RvDetTable {  // detections every lane may need (rotPt, `is not None`), aliasing the (dead) contact mailbox
+  double px[48], py[48];
+  int has[48];
+};
+
+DE_DEV dm_u32x4 rv_rng(uint64_t seed, uint32_t genv, uint32_t episode, uint32_t tkey, int agent, int kind, int index, int block) {
+  const uint32_t entity = (uint32_t)agent | ((uint32_t)kind << 4) | ((uint32_t)index << 8) | ((uint32_t)block << 16);
+  return dm_env_rng(seed, genv, episode, DM_RNG_OBS_NOISE, entity, tkey);
+}
+DE_DEV V2 rv_rot(V2 v, double c, double s) { return v2(v.x * c - v.y * s, v.x * s + v.y * c); }  // Vec2d.rotated
+DE_DEV double rv_scale(double val, double norm) { return ((val * norm) - 0.5) / 0.5; }
+DE_DEV double rv_normalize(double pt, double nf) { return ((pt * nf) - 0.0) * 2.0 * 1.0; }
+DE_DEV double rv_nas(double pt, double nf, double mean) { return (pt - mean) * nf * 1.0; }
+
+// cutils.doesInteract (obj1 = table entry i, obj2 = (has2, p2))
+DE_DEV int rv_interact(const RvDetTable& T, int i, bool has2, V2 p2, double radius, bool canOcclude) {
+  if (!T.has[i] || !has2) return 0;
+  const V2 p1 = v2(T.px[i], T.py[i]);
+  int type = 0;
+  if (vlen(vsub(p1, p2)) < radius) type = 1;
+  if (canOcclude) {
+    const double dist = vcross(p1, p2) / vlen(p1);
+    if (dm_abs(dist) < radius && vlensq(p1) < vlensq(p2)) type = 2;
+  }
+  return type;
+}
+
+struct RvArgs {
+  uint64_t seed;
+  uint32_t genv, episode, tkey;
+  int R, n, noiseType;
+  double magn;
+};
+
+// One snapshot: rows of all R agents -> out[R][RCP_DIM]; seen += the snapshot's (numLandMarks, ballsSeen, robotsSeen)
+__device__ __noinline__ int rc_partial_vision(RvArgs A, int lane, float* __restrict__ out, int* __restrict__ seen) {
+  RcLds& L = g_R;
+  RvDetTable& T = *reinterpret_cast<RvDetTable*>(&L.u);
+  const int R = A.R;
+  const double randBase = 0.01 * A.magn;
+  const uint64_t below = lanemask_lt();
+  int overflow = 0;
+  // lane role (fixed over agents)
+  const bool isBall = lane == 0, isRob = lane >= 1 && lane < R, isGoal = lane >= 10 && lane < 14, isCross = lane >= 14 && lane < 17;
+  const bool isFc = lane >= 17 && lane < 33, isLine = lane >= 33 && lane < 44, isTrial = lane >= 44 && lane < 54;
+  const bool isPoint = isBall || isRob || isGoal || isCross || isFc;
+#pragma unroll 1
+  for (int a = 0; a < R; ++a) {
+    float* __restrict__ row = out + (size_t)a * RCP_DIM;
+    for (int i = lane; i < RCP_DIM; i += DE_WAVE) row[i] = 0.0f;
+    const V2 pos = robot_pos(L, a);
+    const double angle = robot_angle(L, a), headAngle = angle + L.head[a];
+    const int team = robot_team(L, a);
+    const int aflags = L.rflags[a];
+    // one sincos call for the three uniform angles: lane 0 -> FoV edge 1, lane 1 -> FoV edge 2, others -> -headAngle
+    const DevSC sc0 = dev_sincos(lane == 0 ? headAngle + RV_FOV : (lane == 1 ? headAngle - RV_FOV : -headAngle));
+    const V2 vec1 = v2(1.0 * bcast_d(sc0.c, 0) - 0.0 * bcast_d(sc0.s, 0), 1.0 * bcast_d(sc0.s, 0) + 0.0 * bcast_d(sc0.c, 0));
+    const V2 vec2 = v2(1.0 * bcast_d(sc0.c, 1) - 0.0 * bcast_d(sc0.s, 1), 1.0 * bcast_d(sc0.s, 1) + 0.0 * bcast_d(sc0.c, 1));
+    const double cR = bcast_d(sc0.c, 2), sR = bcast_d(sc0.s, 2);
+    // ---- detections -------------------------------------------------------------------------------------
+    int seenT = RV_NONE;
+    bool has = false;
+    V2 p = v2(0.0, 0.0), p2 = v2(0.0, 0.0);  // rotPt (lines: pt1, pt2)
+    double size = 0.0, e3 = 0.0, e4 = 0.0, e5 = 0.0;
+    int robId = -1;
+    if (isPoint) {
+      V2 objp;
+      double maxDist = RV_MAXVIS0, radius = 5.0;
+      if (isBall) { objp = v2(L.px[RC_BALL], L.py[RC_BALL]); radius = BALL_R; e3 = (double)(L.envi[RE_OWNED] * team); }
+      else if (isRob) {
+        robId = (lane - 1) < a ? (lane - 1) : lane;
+        objp = robot_pos(L, robId); maxDist = RV_MAXVIS1; radius = ROBOT_TOTAL_RADIUS;
+        e3 = robot_angle(L, robId) - headAngle; e4 = (double)(team * robot_team(L, robId));
+        e5 = (aflags & (RF_FALLEN | RF_PENAL)) ? 1.0 : 0.0;
+      } else {
+        objp = v2(RC.visPx[lane], RC.visPy[lane]); e3 = RC.visT0[lane]; e4 = RC.visT1[lane];
+        if (isGoal) maxDist = RV_MAXVIS1;
+        if (isFc) e5 = 0.0 - headAngle;
+      }
+      const V2 point = vsub(objp, pos);
+      const double dist1 = vcross(vec1, point), dist2 = vcross(vec2, point);
+      size = radius;
+      if (dist1 < radius && dist2 > -radius) {
+        if (dist1 < -radius && dist2 > radius) seenT = vlensq(point) < maxDist ? RV_NORMAL : RV_DISTANT;
+        else seenT = RV_PARTIAL;
+        p = rv_rot(point, cR, sR);
+        has = true;
+      }
+    } else if (isLine) {  // cutils.isLineInArea
+      const V2 q1 = vsub(v2(RC.visPx[lane], RC.visPy[lane]), pos), q2 = vsub(v2(RC.visQx[lane], RC.visQy[lane]), pos);
+      e3 = RC.visT0[lane]; e4 = RC.visT1[lane];
+      const double dist11 = vcross(vec1, q1), dist12 = vcross(vec1, q2);
+      if (!(dist11 > 0.0 && dist12 > 0.0)) {
+        const double dist21 = vcross(vec2, q1), dist22 = vcross(vec2, q2);
+        if (!(dist21 < 0.0 && dist22 < 0.0)) {
+          V2 pt1, pt2;
+          seenT = RV_NORMAL;
+          if (dist11 <= 0.0 && dist21 >= 0.0) pt1 = q1;
+          else {
+            const V2 d = vsub(q2, q1);
+            const double i1 = vcross(q1, vec1) / (vcross(vec1, d) + 1e-7), i2 = vcross(q1, vec2) / (vcross(vec2, d) + 1e-7);
+            const double inter = (i1 < 1.0 && i2 < 1.0) ? (i1 > i2 ? i1 : (i2 > i1 ? i2 : i1)) : (i1 < i2 ? i1 : (i2 < i1 ? i2 : i1));
+            pt1 = vadd(q1, vmul(d, inter));
+            seenT = RV_PARTIAL;
+          }
+          if (dist12 <= 0.0 && dist22 >= 0.0) pt2 = q2;
+          else {
+            const V2 d = vsub(q1, q2);
+            const double i1 = vcross(q2, vec1) / vcross(vec1, d), i2 = vcross(q2, vec2) / vcross(vec2, d);
+            const double inter = (i1 < 1.0 && i2 < 1.0) ? (i1 > i2 ? i1 : (i2 > i1 ? i2 : i1)) : (i1 < i2 ? i1 : (i2 < i1 ? i2 : i1));
+            pt2 = vadd(q2, vmul(d, inter));
+            seenT = RV_PARTIAL;
+          }
+          if (vlensq(pt1) > RV_MAXVIS1 || vlensq(pt2) > RV_MAXVIS1) seenT = RV_DISTANT;
+          pt1 = rv_rot(pt1, cR, sR);
+          pt2 = rv_rot(pt2, cR, sR);
+          if (pt1.x < 0.0 || pt2.x < 0.0) seenT = RV_NONE;
+          p = pt1; p2 = pt2; has = true;
+        }
+      }
+    }
+    if (lane < 48) { T.px[lane] = p.x; T.py[lane] = p.y; T.has[lane] = (isPoint && has) ? 1 : 0; }
+    __syncthreads();
+    // ---- interactions ---------------------------------------------------------------------------------------
+    int inter = 0;
+    if (isPoint) {
+      for (int i = 1; i < R; ++i) {  // max over the robots (other than me) of doesInteract(rob, me, totalRadius * 2)
+        if (i == lane) continue;
+        const int t = rv_interact(T, i, has, p, ROBOT_TOTAL_RADIUS * 2.0, true);
+        inter = t > inter ? t : inter;
+      }
+      if (isBall) for (int k = 0; k < 4; ++k) {  // ballPostInter: doesInteract(ball, post, ballRadius * 8, False)
+        const int t = (has && T.has[10 + k]) ? ((vlen(vsub(p, v2(T.px[10 + k], T.py[10 + k]))) < BALL_R / 2.0 * 8.0) ? 1 : 0) : 0;
+        inter = t > inter ? t : inter;
+      }
+      if (isCross) {  // ballCrossInter: doesInteract(ball, cross, ballRadius * 4, False)
+        const int t = (T.has[0] && has) ? ((vlen(vsub(v2(T.px[0], T.py[0]), p)) < BALL_R / 2.0 * 4.0) ? 1 : 0) : 0;
+        inter = t > inter ? t : inter;
+      }
+    }
+    // ---- noise (cutils.addNoise on points, addNoiseLine on lines) ---------------------------------------------
+    if (isPoint) {
+      if (inter == 2) seenT = RV_NONE;
+      else if (seenT) {
+        const int kind = isBall ? 0 : isRob ? 1 : isGoal ? 2 : isCross ? 3 : 4;
+        const int index = isBall ? 0 : isRob ? lane - 1 : isGoal ? lane - 10 : isCross ? lane - 14 : lane - 17;
+        const bool misClass = isBall || isCross, angleNoise = isFc;
+        const double maxDist = (isRob || isGoal) ? RV_MAXVIS1 : RV_MAXVIS0;
+        const dm_u32x4 u0 = rv_rng(A.seed, A.genv, A.episode, A.tkey, a, kind, index, 0);
+        const dm_u32x4 u1 = rv_rng(A.seed, A.genv, A.episode, A.tkey, a, kind, index, 1);
+        const V2 noiseVec = vmul(v2(dm_unit(u0.v[0]) - 0.5, dm_unit(u0.v[1]) - 0.5), A.magn);
+        if (A.noiseType == 0) {
+          if (dm_unit(u0.v[2]) < randBase) seenT = RV_NONE;
+          p = vadd(p, noiseVec);
+          size *= (1.0 - (dm_unit(u1.v[0]) - 0.5) * 0.2);
+          if (angleNoise) e5 += (dm_unit(u1.v[1]) - 0.5) * A.magn / 10.0;
+        } else {
+          int st = seenT;
+          const double range = 0.25 + 3.75 * vlensq(p) / maxDist;
+          double multiplier = range;
+          if (inter == 1) multiplier = range * 2.0;
+          if (st == RV_DISTANT) multiplier = range * 3.0;
+          else if (st == RV_PARTIAL) multiplier = range * 4.0;
+          const V2 newPos = vadd(p, v2(noiseVec.x * multiplier / 4.0, noiseVec.y * multiplier / 4.0));
+          const double diff = vlen(newPos) - vlen(p);
+          if (dm_unit(u0.v[2]) < randBase * multiplier) st = RV_NONE;
+          if (misClass && dm_unit(u0.v[3]) < randBase * multiplier / 2.0) st = RV_MISCLASS;
+          seenT = st;
+          p = newPos;
+          size *= 1.0 + (dm_unit(u1.v[0]) * 0.1 * diff);
+          if (angleNoise) e5 += (dm_unit(u1.v[1]) - 0.5) * A.magn * multiplier / 180.0;
+        }
+      }
+    } else if (isLine && seenT) {
+      const dm_u32x4 u0 = rv_rng(A.seed, A.genv, A.episode, A.tkey, a, 5, lane - 33, 0);
+      const dm_u32x4 u1 = rv_rng(A.seed, A.genv, A.episode, A.tkey, a, 5, lane - 33, 1);
+      const V2 n1 = vmul(v2(dm_unit(u0.v[0]) - 0.5, dm_unit(u0.v[1]) - 0.5), A.magn);
+      const V2 n2 = vmul(v2(dm_unit(u0.v[2]) - 0.5, dm_unit(u0.v[3]) - 0.5), A.magn);
+      if (A.noiseType == 0) {
+        if (dm_unit(u1.v[0]) < randBase) seenT = RV_NONE;
+        p = vadd(p, n1);
+        p2 = vadd(p2, n2);
+      } else {
+        const double m1 = 0.25 + 3.75 * vlensq(p) / RV_MAXVIS1, m2 = 0.25 + 3.75 * vlensq(p2) / RV_MAXVIS1;
+        const double m = (m1 + m2) * 0.5;
+        if (dm_unit(u1.v[0]) < randBase * m) seenT = RV_NONE;
+        p = vadd(p, v2(n1.x * m1 / 2.0, n1.y * m1 / 2.0));
+        p2 = vadd(p2, v2(n2.x * m2 / 2.0, n2.y * m2 / 2.0));
+      }
+    }
+    // ---- the third element of the observation: (numLandMarks, robotsSeen, ballsSeen) ------------------------------
+    const bool robSeen = isRob && seenT != RV_NONE;
+    const bool ballsSeen = wave_ballot(isBall && seenT != RV_NONE && seenT != RV_MISCLASS) != 0ull;
+    // ---- misclassification swaps, filters, list positions ---------------------------------------------------------
+    const bool ballKeep = isBall && seenT != RV_NONE && seenT != RV_MISCLASS, ballToCross = isBall && seenT == RV_MISCLASS;
+    const bool crossKeep = isCross && seenT != RV_NONE && seenT != RV_MISCLASS, crossToBall = isCross && seenT == RV_MISCLASS;
+    const bool robKeep = robSeen, goalKeep = isGoal && seenT != RV_NONE, fcKeep = isFc && seenT != RV_NONE && seenT != RV_MISCLASS;
+    const bool lineKeep = isLine && seenT != RV_NONE;
+    const uint64_t mBallKeep = wave_ballot(ballKeep), mBallToCross = wave_ballot(ballToCross), mCrossKeep = wave_ballot(crossKeep);
+    const uint64_t mCrossToBall = wave_ballot(crossToBall), mRobKeep = wave_ballot(robKeep), mGoalKeep = wave_ballot(goalKeep);
+    const uint64_t mFcKeep = wave_ballot(fcKeep), mLineKeep = wave_ballot(lineKeep);
+    const int nBall0 = __popcll(mBallKeep) + __popcll(mCrossToBall), nCross0 = __popcll(mCrossKeep) + __popcll(mBallToCross);
+    const int nRob0 = __popcll(mRobKeep), nGoal0 = __popcll(mGoalKeep), nFc0 = __popcll(mFcKeep), nLine0 = __popcll(mLineKeep);
+    const int numLandMarks = nFc0 + nLine0 + nCross0 + nGoal0;
+    if (ballToCross) {  // the misclassified ball joins the crosses with two random tags
+      const dm_u32x4 u = rv_rng(A.seed, A.genv, A.episode, A.tkey, a, 6, 0, 0);
+      e3 = (double)dm_randint(u.v[0], -1, 1); e4 = (double)dm_randint(u.v[1], -1, 1);
+    }
+    if (crossToBall) e3 = 0.0;
+    // ---- random false positives (lanes 44..53 = trials 0..9) ------------------------------------------------------
+    int fpClass = -1;
+    if (isTrial) {
+      const int i = lane - 44;
+      const dm_u32x4 u = rv_rng(A.seed, A.genv, A.episode, A.tkey, a, 7, i, 0), u1 = rv_rng(A.seed, A.genv, A.episode, A.tkey, a, 7, i, 1);
+      if (dm_unit(u.v[0]) < randBase) {
+        fpClass = dm_randint(u.v[1], 0, 5);
+        const double d = dm_unit(u.v[2]) * dm_sqrt(RV_MAXVIS1);
+        const double an = dm_unit(u.v[3]) * 2.0 * RV_FOV - RV_FOV;
+        const DevSC sc = dev_sincos(an);
+        p = v2(d * sc.c - 0.0 * sc.s, d * sc.s + 0.0 * sc.c);
+        seenT = RV_NORMAL; has = true;
+        const double f = 1.0 - 0.4 * (dm_unit(u1.v[0]) - 0.5);
+        if (fpClass == 0) { size = BALL_R / 2.0 * 2.0 * f; e3 = 0.0; }
+        else if (fpClass == 1) {
+          size = ROBOT_TOTAL_RADIUS * f;
+          e3 = (dm_unit(u1.v[1]) - 0.5) * 2.0 * DM_PI; e4 = (dm_unit(u1.v[2]) > 0.5) ? -1.0 : 1.0; e5 = (dm_unit(u1.v[3]) > 0.9) ? 1.0 : 0.0;
+        } else if (fpClass <= 4) {
+          size = 5.0 * f; e3 = (double)dm_randint(u1.v[1], -1, 1); e4 = (double)dm_randint(u1.v[2], -1, 1);
+          if (fpClass == 4) e5 = dm_unit(u1.v[3]) * DM_PI * 2.0;
+        }
+      }
+    }
+    const uint64_t mFp0 = wave_ballot(fpClass == 0), mFp1 = wave_ballot(fpClass == 1), mFp2 = wave_ballot(fpClass == 2);
+    const uint64_t mFp3 = wave_ballot(fpClass == 3), mFp4 = wave_ballot(fpClass == 4);
+    // field crosses: fieldCrossDets.insert(len(crossDets), fp) replayed in trial order
+    int fcPos = fcKeep ? __popcll(mFcKeep & below) : -1;
+    {
+      int nCrossCur = nCross0, nFcCur = nFc0;
+      for (int i = 0; i < 10; ++i) {
+        const int ci = bcast_i(fpClass, 44 + i);
+        if (ci == 3) nCrossCur++;
+        else if (ci == 4) {
+          const int at = nCrossCur < nFcCur ? nCrossCur : nFcCur;
+          if (fcPos >= at) fcPos++;
+          if (lane == 44 + i) fcPos = at;
+          nFcCur++;
+        }
+      }
+    }
+    // ---- false-positive balls near robots (REALISTIC): robDets = kept real robots, then the FP robots ---------------
+    const int robPos = robKeep ? __popcll(mRobKeep & below) : (fpClass == 1 ? nRob0 + __popcll(mFp1 & below) : -1);
+    bool genBall = false;
+    V2 genP = v2(0.0, 0.0);
+    double genSize = 0.0;
+    if (A.noiseType == 1 && robPos >= 0 && seenT == RV_NORMAL) {
+      const dm_u32x4 u = rv_rng(A.seed, A.genv, A.episode, A.tkey, a, 8, robPos, 0), u1 = rv_rng(A.seed, A.genv, A.episode, A.tkey, a, 8, robPos, 1);
+      if (dm_unit(u.v[0]) < randBase * 10.0 && vlen(p) < 250.0) {
+        genBall = true;  // (the `rob[0] = NoSighting` coin changes nothing that is returned)
+        genP = vadd(p, vmul(v2(2.0 * dm_unit(u.v[2]) - 1.0, 2.0 * dm_unit(u.v[3]) - 1.0), ROBOT_TOTAL_RADIUS));
+        genSize = BALL_R / 2.0 * 2.0 * (1.0 - 0.4 * (dm_unit(u1.v[0]) - 0.5));
+      }
+    }
+    const uint64_t mGen = wave_ballot(genBall);
+    const int nBall = nBall0 + __popcll(mFp0) + __popcll(mGen), nRob = nRob0 + __popcll(mFp1), nGoal = nGoal0 + __popcll(mFp2);
+    const int nCross = nCross0 + __popcll(mFp3), nFc = nFc0 + __popcll(mFp4), nLine = nLine0;
+    __threadfence();  // the zero fill of the row is complete before the scattered entries land
+    // ---- conversion + placement ----------------------------------------------------------------------------------
+    const int closest = (a == L.envi[RE_CLOSE0] || a == L.envi[RE_CLOSE1]) ? 1 : 0;
+#define RV_BALL_ROW(P_, q_, sz_, own_)                                                                                  \
+  do {                                                                                                                  \
+    if ((P_) < RCP_CAP_BALL) {                                                                                          \
+      float* o = row + RCP_OFF_BALL + (P_)*5;                                                                           \
+      o[0] = (float)rv_normalize((q_).x, RV_STD_NORM); o[1] = (float)rv_normalize((q_).y, RV_STD_NORM);                 \
+      o[2] = (float)rv_nas((sz_), RV_SIZE_NORM, BALL_R / 2.0 * 2.0); o[3] = (float)(own_); o[4] = (float)closest;       \
+    } else overflow = 1;                                                                                                \
+  } while (0)
+    if (ballKeep) RV_BALL_ROW(0, p, size, e3);
+    if (crossToBall) { const int P = __popcll(mBallKeep) + __popcll(mCrossToBall & below); RV_BALL_ROW(P, p, size, 0.0); }
+    if (fpClass == 0) { const int P = nBall0 + __popcll(mFp0 & below); RV_BALL_ROW(P, p, size, 0.0); }
+    if (genBall) { const int P = nBall0 + __popcll(mFp0) + __popcll(mGen & below); RV_BALL_ROW(P, genP, genSize, 0.0); }
+    if (robPos >= 0) {
+      if (robPos < RCP_CAP_ROB) {
+        float* o = row + RCP_OFF_ROB + robPos * 7;
+        const DevSC sc = dev_sincos(e3);
+        o[0] = (float)rv_normalize(p.x, RV_STD_NORM); o[1] = (float)rv_normalize(p.y, RV_STD_NORM);
+        o[2] = (float)rv_nas(size, RV_SIZE_NORM, ROBOT_TOTAL_RADIUS); o[3] = (float)sc.c; o[4] = (float)sc.s; o[5] = (float)e4; o[6] = (float)e5;
+      } else overflow = 1;
+    }
+    {  // convertToPolar lists: goals, crosses (incl. the misclassified ball), field crosses
+      int P = -1, off = 0, cap = 0, feat = 6;
+      double sizeMean = 5.0;
+      if (goalKeep) { P = __popcll(mGoalKeep & below); off = RCP_OFF_GOAL; cap = RCP_CAP_GOAL; }
+      else if (fpClass == 2) { P = nGoal0 + __popcll(mFp2 & below); off = RCP_OFF_GOAL; cap = RCP_CAP_GOAL; }
+      else if (crossKeep) { P = __popcll(mCrossKeep & below); off = RCP_OFF_CROSS; cap = RCP_CAP_CROSS; }
+      else if (ballToCross) { P = __popcll(mCrossKeep); off = RCP_OFF_CROSS; cap = RCP_CAP_CROSS; }
+      else if (fpClass == 3) { P = nCross0 + __popcll(mFp3 & below); off = RCP_OFF_CROSS; cap = RCP_CAP_CROSS; }
+      else if (fcPos >= 0) { P = fcPos; off = RCP_OFF_FCROSS; cap = RCP_CAP_FCROSS; feat = 8; }
+      if (P >= 0) {
+        if (P < cap) {
+          float* o = row + off + P * feat;
+          const double dist = dm_sqrt(p.x * p.x + p.y * p.y);
+          const double ang = dev_atan2(p.y * (double)team, p.x * (double)team);
+          const DevSC sc = dev_sincos(ang);
+          o[0] = (float)rv_scale(dist, RV_STD_NORM); o[1] = (float)sc.c; o[2] = (float)sc.s;
+          o[3] = (float)((size - sizeMean) * RV_SIZE_NORM); o[4] = (float)(e3 * (double)team); o[5] = (float)(e4 * (double)team);
+          if (feat == 8) { const DevSC s5 = dev_sincos(e5); o[6] = (float)s5.c; o[7] = (float)(-s5.s); }
+        } else overflow = 1;
+      }
+    }
+    if (lineKeep) {  // normalizeLine
+      const int P = __popcll(mLineKeep & below);
+      float* o = row + RCP_OFF_LINE + P * 5;
+      const V2 diff = vsub(p2, p);
+      const double dist = dm_abs(p2.x * p.y - p2.y * p.x) / (vlen(diff) + 1e-7);
+      const DevSC sc = dev_sincos(dev_atan2(diff.y, diff.x));
+      o[0] = (float)rv_scale(dist, RV_STD_NORM); o[1] = (float)sc.c; o[2] = (float)sc.s; o[3] = (float)e3; o[4] = (float)e4;
+    }
+#undef RV_BALL_ROW
+    if (lane == 0) {
+      float* o = row + RCP_OFF_TAIL;
+      o[0] = (float)(nBall < RCP_CAP_BALL ? nBall : RCP_CAP_BALL); o[1] = (float)(nRob < RCP_CAP_ROB ? nRob : RCP_CAP_ROB);
+      o[2] = (float)(nGoal < RCP_CAP_GOAL ? nGoal : RCP_CAP_GOAL); o[3] = (float)(nCross < RCP_CAP_CROSS ? nCross : RCP_CAP_CROSS);
+      o[4] = (float)(nFc < RCP_CAP_FCROSS ? nFc : RCP_CAP_FCROSS); o[5] = (float)nLine;
+      o[6] = (float)numLandMarks; o[7] = ballsSeen ? 1.0f : 0.0f;
+      if (seen) { seen[a * RCP_SEEN_STRIDE + 0] += numLandMarks; seen[a * RCP_SEEN_STRIDE + 1] += ballsSeen ? 1 : 0; }
+    }
+    if (isRob) {
+      row[RCP_OFF_TAIL + 8 + (lane - 1)] = robSeen ? 1.0f : 0.0f;
+      if (seen) seen[a * RCP_SEEN_STRIDE + 2 + (lane - 1)] += robSeen ? 1 : 0;
+    }
+    __syncthreads();  // the detection table is rewritten by the next agent
+  }
+  return (int)(wave_ballot(overflow != 0) != 0ull);
+}

@@ -100,6 +100,18 @@ def _robocup_spaces(obs_type, allow_head_turn):
     robot_space = sp.Dict([("position", pos_xy), ("orientation", sp.Box(-1, 1, shape=(2,))), ("team", team),
                            ("penalized or penalized", sp.MultiBinary(1))])
     observation_space = sp.Tuple([sp.Tuple([ball_space, robot_space]), sp.Tuple([self_space, ])])
+    if obs_type == ObservationType.PARTIAL:  # RoboCupEnvironment.py:346-430, the `else` branch of _create_observation_space
+        rad = sp.Box(-mean * 2, +mean * 2, shape=(1,))
+        pos_radial = sp.Box(-1, +1, shape=(3,))
+        typ = sp.Box(-1, +1, shape=(2,))
+        line_space = sp.Dict([("position", pos_radial), ("type", typ)])
+        cross_space = goalpost_space = sp.Dict([("position", pos_radial), ("radius", rad), ("type", typ)])
+        field_cross_space = sp.Dict([("position", pos_radial), ("radius", rad), ("type", typ), ("angle", sp.Box(-1, +1, shape=(2,)))])
+        p_robot = sp.Dict([("position", pos_xy), ("radius", rad), ("orientation", sp.Box(-1, 1, shape=(2,))), ("team", team),
+                           ("penalized or penalized", sp.MultiBinary(1))])
+        p_ball = sp.Dict([("position", pos_xy), ("radius", rad), ("team", team), ("closest", sp.MultiBinary(1))])
+        observation_space = sp.Tuple([sp.Tuple([p_ball, p_robot]),
+                                      sp.Tuple([goalpost_space, cross_space, field_cross_space, line_space])])
     if allow_head_turn:
         action_space = sp.Tuple((sp.MultiDiscrete([5, 3, 3]), sp.Box(low=-3, high=3, shape=(1,))))
     else:
@@ -348,6 +360,19 @@ class BatchedDynEnv(object):
         L = self.layout
         off, rows, feat = list(L.block_offset), list(L.block_rows), list(L.block_feat)
         out = np.empty((E, T, A, 3), dtype=object)
+        if self.env_type == DynEnvType.ROBO_CUP and self.observationType == ObservationType.PARTIAL:
+            # getAgentVision: ((balls, robots), (goals, crosses, line crosses, lines), (numLandMarks, robotsSeen, ballsSeen))
+            tail = off[6]
+            for e in range(E):
+                for t in range(T):
+                    for a in range(A):
+                        r = o[e, t, a]
+                        n = [int(x) for x in r[tail:tail + 6]]
+                        lists = [r[off[k]:off[k] + n[k] * feat[k]].reshape(n[k], feat[k]) for k in range(6)]
+                        out[e, t, a, 0] = [lists[0], lists[1]]
+                        out[e, t, a, 1] = [lists[2], lists[3], lists[4], lists[5]]
+                        out[e, t, a, 2] = (int(r[tail + 6]), r[tail + 8:tail + 8 + (A - 1)].astype("uint8"), bool(r[tail + 7]))
+            return out
         if self.env_type == DynEnvType.ROBO_CUP:  # ((ball, robots), (self,), (1,1,1)) RoboCupEnvironment.py:440-443
             for e in range(E):
                 for t in range(T):
@@ -389,6 +414,8 @@ class BatchedDynEnv(object):
         L = self.layout
         off, rows = list(L.block_offset), list(L.block_rows)
         A = self.n_agents
+        if self.env_type == DynEnvType.ROBO_CUP and self.observationType == ObservationType.PARTIAL:
+            return None, None  # the Partial launch does not emit the noise-free full state (see the Driving note below)
         if self.env_type == DynEnvType.ROBO_CUP:  # getFullState(agent) = [ball, self, robots] (:1164-1188)
             recon = []
             for a in range(A):

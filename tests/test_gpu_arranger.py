@@ -64,13 +64,17 @@ def _ragged_from_compat(compat, group):
     return [[[list(compat[e, t, a, group]) for a in range(A)] for t in range(T)] for e in range(E)]
 
 
-@pytest.mark.parametrize("cfg", ["driving_full", "driving_partial", "robocup"])
+@pytest.mark.parametrize("cfg", ["driving_full", "driving_partial", "robocup", "robocup_partial"])
 def test_gpu_arranger_on_real_observations(cfg):
     import torch
     from dynenv_amd import BatchedDynEnv, DynEnvType, GpuInOutArranger, NoiseType, ObservationType, groups_for
     E = 6
     if cfg == "robocup":
         env = BatchedDynEnv(DynEnvType.ROBO_CUP, E, 2, seed=5)
+        hi = [5, 3, 3, 7]
+    elif cfg == "robocup_partial":
+        env = BatchedDynEnv(DynEnvType.ROBO_CUP, E, 3, observationType=ObservationType.PARTIAL, noiseType=NoiseType.REALISTIC,
+                            noiseMagnitude=5, seed=5)
         hi = [5, 3, 3, 7]
     elif cfg == "driving_partial":
         env = BatchedDynEnv(DynEnvType.DRIVE, E, 5, observationType=ObservationType.PARTIAL, noiseType=NoiseType.REALISTIC,
@@ -96,7 +100,7 @@ def test_gpu_arranger_on_real_observations(cfg):
         assert np.array_equal(countArr[0].cpu().numpy(), o_counts)
         assert np.array_equal(countArr[2].cpu().numpy(), o_obj)
         F = max(t.feat for t in types) + (0 if gi == 0 else 3)  # movable: as is (scatter path if odd); static: another width
-        F = F if cfg != "robocup" else ((F + 3) // 4) * 4  # a multiple of 4 takes the fused pad kernel
+        F = F if not cfg.startswith("robocup") else ((F + 3) // 4) * 4  # a multiple of 4 takes the fused pad kernel
         outs, o_outs = [], []
         for i in range(len(types)):
             got = inputs[i].cpu().numpy()

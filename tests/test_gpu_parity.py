@@ -342,3 +342,37 @@ def test_partial_compat_view(gpu):
     obs, rew, dones, infos = venv.step(np.ones((2, 10, 2), np.int64))
     assert obs.shape == (2, 1, 10, 3)
     venv.close()
+
+
+# ------------------------------------------------------------------------------------------------ RoboCup Partial (a17)
+@pytest.mark.parametrize("n,E,seed,noise,magn,steps", [(5, 16, 42, 1, 3.0, 40), (5, 8, 7, 0, 5.0, 25), (2, 8, 9, 1, 5.0, 25),
+                                                       (1, 4, 3, 1, 2.0, 15), (5, 8, 11, 1, 0.0, 15)])
+def test_robocup_partial_parity(gpu, n, E, seed, noise, magn, steps):
+    """RoboCup Partial observation (getAgentVision at the five snapshots of every step) + the
+    sighting-based observation rewards (processSeens): rows, rewards, dones and episode statistics identical to the oracle."""
+    dynenv_amd, _, _ = gpu
+    from dynenv_amd import NoiseType, ObservationType
+    fl = ol.ROBOCUP_DEFAULT_FLAGS
+    env = dynenv_amd.BatchedDynEnv(dynenv_amd.DynEnvType.ROBO_CUP, E, n, observationType=ObservationType.PARTIAL,
+                                   noiseType=NoiseType(noise), noiseMagnitude=magn, seed=seed, flags=fl)
+    ora = ol.OracleEnv(env_type=0, num_envs=E, n_players=n, obs_type=1, noise_type=noise, noise_magnitude=magn, seed=seed,
+                       flags=fl, threads=8)
+    og = env.reset_flat().cpu().numpy()
+    oc = ora.reset()
+    assert og.shape == oc.shape and og.shape[-1] == 793
+    np.testing.assert_array_equal(og, oc, err_msg="reset observations")
+    rng = np.random.default_rng(seed)
+    seen_rewards = False
+    for s in range(steps):
+        a = _rc_actions(rng, E, 2 * n)
+        og, rg, dg = env.step_flat(a, auto_reset=False)
+        oc, rc, dc = ora.step(a)
+        np.testing.assert_array_equal(og.cpu().numpy(), oc, err_msg="obs step %d" % s)
+        np.testing.assert_array_equal(rg.cpu().numpy(), rc, err_msg="rewards step %d" % s)
+        np.testing.assert_array_equal(dg.cpu().numpy(), dc, err_msg="dones step %d" % s)
+    assert env.error_flags() == 0 and ora.overflow() == 0
+    for g, o in zip([x.cpu().numpy() for x in env.episode_stats()], ora.episode_stats()):
+        np.testing.assert_array_equal(g, o)
+    obs_r = env.episode_stats()[2].cpu().numpy()
+    assert (obs_r > 0).any(), "observation rewards should have been paid"
+    env.close()
