@@ -26,6 +26,8 @@ B_ALG_DRIVING_FULL_A10 = 20 + 2550 + 2230 + (9280 + 8) + 80 + 1
 B_ALG_ROBOCUP_FULL_A10 = 40 + 3650 + 3650 + 13200 + 80 + 1
 # Driving Partial obs (configs[3]): as Full but the observation is 10 agents x 517 f32 (oracle/driving_partial.c layout)
 B_ALG_DRIVING_PARTIAL_A10 = 20 + 2550 + 2230 + 10 * 517 * 4 + 80 + 1
+# RoboCup Partial obs (§8 a17): as Full but the observation is 5 snapshots x 10 agents x 793 f32 (oracle/robocup_partial.h)
+B_ALG_ROBOCUP_PARTIAL_A10 = 40 + 3650 + 3650 + 5 * 10 * 793 * 4 + 80 + 1
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -58,7 +60,8 @@ def cpu_baseline(E, n_players, A, seed, robocup=False, target_seconds=12.0, part
     cores = host_core_share()
     ol.build()
     if robocup:
-        env = ol.OracleEnv(env_type=0, num_envs=E, n_players=n_players, seed=seed, threads=cores, flags=ol.ROBOCUP_DEFAULT_FLAGS)
+        env = ol.OracleEnv(env_type=0, num_envs=E, n_players=n_players, seed=seed, threads=cores, flags=ol.ROBOCUP_DEFAULT_FLAGS,
+                           **(dict(obs_type=1, noise_type=1, noise_magnitude=3.0) if partial else {}))
     elif partial:  # ObservationType.PARTIAL = 1, NoiseType.REALISTIC = 1 (cutils.py:29-51)
         env = ol.OracleEnv(env_type=1, num_envs=E, n_players=n_players, obs_type=1, noise_type=1, noise_magnitude=3.0,
                            seed=seed, threads=cores)
@@ -92,7 +95,7 @@ def cpu_baseline(E, n_players, A, seed, robocup=False, target_seconds=12.0, part
     return {"value": value, "unit": "agent-steps/s", "cores": cores, "kind": "port",
             "sample": "%d steps of the same %d-env %s nPlayers=%d workload (first %d steps of an episode), "
                       "oracle/liboracle.so with %d OpenMP threads, %.1f s"
-                      % (n, E, "RoboCup" if robocup else "Driving Partial-obs" if partial else "Driving", n_players, n, cores, dt),
+                      % (n, E, ("RoboCup Partial-obs" if partial else "RoboCup") if robocup else "Driving Partial-obs" if partial else "Driving", n_players, n, cores, dt),
             "cpu_model": model}
 
 
@@ -103,7 +106,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=600)   # 1 full episode
     ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
     ap.add_argument("--players", type=int, default=None)
-    ap.add_argument("--workload", choices=["driving", "robocup", "driving_partial"], default="driving",
+    ap.add_argument("--workload", choices=["driving", "robocup", "driving_partial", "robocup_partial"], default="driving",
                     help="driving = BASELINE configs[1] (the headline metric); robocup = configs[2]; driving_partial = "
                          "configs[3] (Partial obs + Realistic noise magnitude 3); the latter two are reported on request")
     ap.add_argument("--seed", type=int, default=42)
@@ -130,8 +133,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    robocup = args.workload == "robocup"
-    partial = args.workload == "driving_partial"
+    robocup = args.workload in ("robocup", "robocup_partial")
+    partial = args.workload in ("driving_partial", "robocup_partial")
     n_players = args.players if args.players is not None else (5 if robocup else 10)
     env_type = DynEnvType.ROBO_CUP if robocup else DynEnvType.DRIVE
     E = args.envs
@@ -207,7 +210,8 @@ def main():
         k1.record()
         torch.cuda.synchronize(device)
         launch_ms = k0.elapsed_time(k1) / n_launch
-        b_alg = (B_ALG_ROBOCUP_FULL_A10 if robocup else B_ALG_DRIVING_PARTIAL_A10 if partial else B_ALG_DRIVING_FULL_A10) if A == 10 else None
+        b_alg = ((B_ALG_ROBOCUP_PARTIAL_A10 if partial else B_ALG_ROBOCUP_FULL_A10) if robocup else
+                 B_ALG_DRIVING_PARTIAL_A10 if partial else B_ALG_DRIVING_FULL_A10) if A == 10 else None
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
@@ -219,7 +223,7 @@ def main():
         if b_alg is not None:
             achieved = b_alg * E / (launch_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "rc_step_kernel" if robocup else "drv_step_kernel + drv_partial_obs_kernel" if partial else "drv_step_kernel",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "rc_step_kernel (with rc_partial_vision)" if (robocup and partial) else "rc_step_kernel" if robocup else "drv_step_kernel + drv_partial_obs_kernel" if partial else "drv_step_kernel",
                         "launch_ms": launch_ms, "alg_bytes_per_env_step": b_alg, "env_steps_per_launch": E}
 
     if rank == 0:
@@ -229,8 +233,12 @@ def main():
             "metric": "agent-steps/s", "value": value, "unit": "agent-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("RoboCupEnvironment nPlayers=%d Full obs, 50 substeps/step, %d envs per GPU "
-                                    "(BASELINE.json configs[2]), lock-step resets every 240 steps" % (n_players, E))
+            "config": {"workload": ("RoboCupEnvironment nPlayers=%d Partial obs + Realistic noise magnitude 3, 50 substeps/step, "
+                                    "%d envs per GPU (SURVEY §8 a17; in no BASELINE config), lock-step resets every 240 steps"
+                                    % (n_players, E))
+                       if (robocup and partial) else
+                       ("RoboCupEnvironment nPlayers=%d Full obs, 50 substeps/step, %d envs per GPU "
+                        "(BASELINE.json configs[2]), lock-step resets every 240 steps" % (n_players, E))
                        if robocup else
                        ("DrivingEnvironment nPlayers=%d Partial obs + Realistic noise magnitude 3, %d envs per GPU "
                         "(BASELINE.json configs[3]), 10 substeps/step, lock-step resets every 600 steps" % (A, E))

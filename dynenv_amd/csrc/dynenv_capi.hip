@@ -152,7 +152,8 @@ static int rc_create(dynenv* h) {
   rc |= dev_alloc(h, &R.envd, E * RD_COUNT);
   rc |= dev_alloc(h, &R.epr, 2 * E * 16);
   rc |= dev_alloc(h, &R.epo, E * 16);
-  rc |= dev_alloc(h, &R.seen, E * 10 * RCP_SEEN_STRIDE);
+  rc |= dev_alloc(h, &R.snap, E * 5);
+  rc |= dev_alloc(h, &R.prew0, E * 16);
   rc |= dev_alloc(h, &R.s_pair, E * RC_NS);
   rc |= dev_alloc(h, &R.s_meta, E * RC_NS);
   rc |= dev_alloc(h, &R.s_hash, 2 * E * RC_NS);
@@ -452,7 +453,11 @@ int dynenv_reset(dynenv_t* h, float* obs_dev, void* stream) {
   if (h->robocup) {
     int E = h->R.E;
     hipLaunchKernelGGL(rc_reset_kernel, dim3((E + 63) / 64), dim3(64), 0, st, h->R);
-    if (obs_dev) hipLaunchKernelGGL(rc_obs_kernel, dim3(E), dim3(64), 0, st, h->R, obs_dev);
+    if (obs_dev) {
+      hipLaunchKernelGGL(rc_obs_kernel, dim3(E), dim3(64), 0, st, h->R, obs_dev);
+      if (h->R.obs_type == DYNENV_OBS_PARTIAL)
+        hipLaunchKernelGGL(rc_partial_obs_kernel, dim3(E), dim3(64), 0, st, h->R, obs_dev, (double*)nullptr);
+    }
     HIP_OK(hipGetLastError());
     return DYNENV_OK;
   }
@@ -472,6 +477,8 @@ int dynenv_step(dynenv_t* h, const int32_t* actions_dev, float* obs_dev, double*
   hipStream_t st = (hipStream_t)stream;
   if (h->robocup) {
     hipLaunchKernelGGL(rc_step_kernel, dim3(h->R.E), dim3(64), 0, st, h->R, (const int*)actions_dev, obs_dev, rewards_dev, dones_dev);
+    if (h->R.obs_type == DYNENV_OBS_PARTIAL)  // getAgentVision at the five snapshots + processSeens, second launch on the same stream
+      hipLaunchKernelGGL(rc_partial_obs_kernel, dim3(h->R.E), dim3(64), 0, st, h->R, obs_dev, rewards_dev);
     HIP_OK(hipGetLastError());
     return DYNENV_OK;
   }

@@ -59,6 +59,7 @@ struct RcConst {
   double visPx[48], visPy[48], visQx[48], visQy[48], visT0[48], visT1[48];
 };
 
+struct RvSnap;
 struct RcState {
   int E, n, R, obs_dim; /* n players per team, R = 2n robots */
   uint64_t seed;
@@ -70,7 +71,8 @@ struct RcState {
   double* envd;  /* [E][RD_COUNT] */
   double* epr;   /* [2][E][16] */
   double* epo;   /* [E][16] episode sum of the observation rewards (processSeens) */
-  int* seen;     /* [E][10][12] per robot: numLandMarks sum, ballsSeen sum, robotsSeen[9] sums over the step's 5 snapshots */
+  struct RvSnap* snap; /* [E][5] what getAgentVision reads, exported at the step's five snapshots (Partial observation) */
+  double* prew0; /* [E][16] positive part of the step's robot + team reward, before the observation reward (Partial) */
   int obs_type, noise_type;
   double noise_magn;
   int* s_pair;   /* [E][NS] */

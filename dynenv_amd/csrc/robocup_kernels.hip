@@ -1398,9 +1398,6 @@ rc_step_kernel(RcState S, const int* __restrict__ actions, float* __restrict__ o
   if (lane == 0) refresh_pivot_first(L);
   __syncthreads();
   const bool partial = S.obs_type == DYNENV_OBS_PARTIAL;
-  int* seen = S.seen + (size_t)e * 10 * RCP_SEEN_STRIDE;
-  if (partial) for (int i = lane; i < 10 * RCP_SEEN_STRIDE; i += DE_WAVE) seen[i] = 0;
-  int visOverflow = 0;
   const bool isBody = lane == RC_BALL || lane < 2 * R;
   const int* myActions = actions + (size_t)e * R * 4;
   int snap = 0;
@@ -1471,39 +1468,34 @@ RC_PROF(const unsigned long long A3 = __builtin_amdgcn_s_memtime(); tG += A1 - A
     if (lane == 0) L.envi[RE_ELAPSED] += 1;
     __syncthreads();
     if (it % 10 == 9) {
-      if (partial) {  // getAgentVision of every robot on the state of this snapshot (RoboCupEnvironment.step, i % 10 == 9)
-        RvArgs va;
-        va.seed = S.seed; va.genv = c.genv; va.episode = c.episode; va.tkey = (uint32_t)uniform_i(L.envi[RE_ELAPSED]);
-        va.R = R; va.n = S.n; va.noiseType = S.noise_type; va.magn = S.noise_magn;
-        visOverflow |= rc_partial_vision(va, lane, obs + ((size_t)e * 5 + snap) * R * RCP_DIM, seen);
+      if (partial) {  // export what getAgentVision reads of this snapshot; rc_partial_obs_kernel turns it into rows
+        RvSnap& sn = S.snap[(size_t)e * 5 + snap];
+        if (lane < 21) { sn.px[lane] = L.px[lane]; sn.py[lane] = L.py[lane]; }
+        if (lane < 20) sn.ang[lane] = L.ang[lane];
+        if (lane < 10) { sn.head[lane] = L.head[lane]; sn.rflags[lane] = L.rflags[lane]; }
+        if (lane == 0) { sn.owned = L.envi[RE_OWNED]; sn.close0 = L.envi[RE_CLOSE0]; sn.close1 = L.envi[RE_CLOSE1]; sn.tkey = L.envi[RE_ELAPSED]; }
       } else if (obs) rc_write_obs(L, lane, R, S.obs_dim, obs + ((size_t)e * 5 + snap) * R * S.obs_dim);
       ++snap;
     }
   }
 RC_PROF(if (lane == 0 && e < 4096) { unsigned long long* d = g_rcprof + e * 12; d[0] = tG; d[1] = tP; d[2] = tB; d[11] = __builtin_amdgcn_s_memtime() - K0; })
   // ---- end of env step :497-524 ------------------------------------------------------------------------------
-  if (partial) __threadfence();  // the snapshot kernels' counters (global) are visible to the robot lanes
   if (lane < R) {
     const double tr = lane < S.n ? L.teamRew[0] : L.teamRew[1];
-    double obsRew = 0.0;
-    if (partial && (S.flags & 8)) {  // processSeens (useObsRewards): see oracle/robocup.c rc_process_seens
-      const int* sn = seen + lane * RCP_SEEN_STRIDE;
-      double lSeens = (double)sn[0] / 5.0, rSeens = 0.0, bSeens = (double)sn[1];
-      lSeens = lSeens < 0.0 ? 0.0 : (lSeens > 3.0 ? 3.0 : lSeens);
-      for (int k = 0; k < R - 1; ++k) { const double r = (double)sn[2 + k]; rSeens += r < 0.0 ? 0.0 : (r > 2.0 ? 2.0 : r); }
-      bSeens = bSeens < 0.0 ? 0.0 : (bSeens > 3.0 ? 3.0 : bSeens);
-      obsRew += (0.0025 * (rSeens + lSeens) + 0.01 * bSeens);
-    }
     double rew = L.rrew[lane] + tr;
-    rew += obsRew;
     double prew = L.rposrew[lane] + dm_max(0.0, tr);
-    prew += dm_max(obsRew, 0.0);
-    double* er = S.epr + (size_t)e * 16 + lane;
-    double* ep = S.epr + (size_t)S.E * 16 + (size_t)e * 16 + lane;
-    double* eo = S.epo + (size_t)e * 16 + lane;
-    *er = *er + rew;
-    *ep = *ep + prew;
-    *eo = *eo + obsRew;
+    if (partial) {
+      // the observation reward (processSeens) is added by rc_partial_obs_kernel, which then updates the episode sums in
+      // the reference's order: episodeRewards += (robot + team + obs)
+      S.prew0[(size_t)e * 16 + lane] = prew;
+    } else {
+      rew += 0.0;   // obsRewards are zero for Full observations (processSeens returns early)
+      prew += 0.0;
+      double* er = S.epr + (size_t)e * 16 + lane;
+      double* ep = S.epr + (size_t)S.E * 16 + (size_t)e * 16 + lane;
+      *er = *er + rew;
+      *ep = *ep + prew;
+    }
     rewards[(size_t)e * R + lane] = rew;
   }
   __syncthreads();
@@ -1511,7 +1503,6 @@ RC_PROF(if (lane == 0 && e < 4096) { unsigned long long* d = g_rcprof + e * 12; 
     dones[e] = (uint8_t)(L.envi[RE_ELAPSED] >= RC_MAX_TIME);
     L.envi[RE_OCC] = (int)(uint32_t)occ;
     if (err) L.envi[RE_ERR] |= 1;
-    if (visOverflow) L.envi[RE_ERR] |= 2;
   }
   __syncthreads();
   rc_store_env(S, L, e, lane, occ);
@@ -1523,15 +1514,15 @@ extern "C" __global__ void __launch_bounds__(64) rc_obs_kernel(RcState S, float*
   rc_load_env(S, L, e, lane, 0ull);
   __syncthreads();
   if (S.obs_type == DYNENV_OBS_PARTIAL) {
-    // environment_base.py:217-222: nTimeSteps separate getAgentVision calls, each with fresh noise (draw keys: time = t)
-    int ov = 0;
+    // environment_base.py:217-222: nTimeSteps separate getAgentVision calls on the initial state, each with fresh noise
+    // (draw keys: time word = t); rc_partial_obs_kernel follows on the same stream
     for (int t = 0; t < 5; ++t) {
-      RvArgs va;
-      va.seed = S.seed; va.genv = (uint32_t)(S.env_id_offset + e); va.episode = (uint32_t)uniform_i(L.envi[RE_EPISODE]); va.tkey = (uint32_t)t;
-      va.R = S.R; va.n = S.n; va.noiseType = S.noise_type; va.magn = S.noise_magn;
-      ov |= rc_partial_vision(va, lane, obs + ((size_t)e * 5 + t) * S.R * RCP_DIM, nullptr);
+      RvSnap& sn = S.snap[(size_t)e * 5 + t];
+      if (lane < 21) { sn.px[lane] = L.px[lane]; sn.py[lane] = L.py[lane]; }
+      if (lane < 20) sn.ang[lane] = L.ang[lane];
+      if (lane < 10) { sn.head[lane] = L.head[lane]; sn.rflags[lane] = L.rflags[lane]; }
+      if (lane == 0) { sn.owned = L.envi[RE_OWNED]; sn.close0 = L.envi[RE_CLOSE0]; sn.close1 = L.envi[RE_CLOSE1]; sn.tkey = t; }
     }
-    if (ov && lane == 0) S.envi[(size_t)e * RE_COUNT + RE_ERR] |= 2;
     return;
   }
   for (int t = 0; t < 5; ++t)  // environment_base.py:217-222: nTimeSteps copies of the initial observation

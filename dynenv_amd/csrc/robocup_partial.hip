@@ -3,7 +3,9 @@
 // Replaces RoboCupEnvironment.getAgentVision (detections, interactions, noise, misclassification, random false
 // positives, false-positive balls near robots, polar / line conversion) with cutils.isSeenInArea / isLineInArea /
 // doesInteract / addNoise / addNoiseLine / convertToPolar / normalizeLine, for every robot of an environment at each of
-// the step's five snapshots, inside rc_step_kernel (the observation needs the state AT the snapshot).  Mirrors
+// the step's five snapshots.  rc_step_kernel exports the few state fields vision needs at each snapshot (RvSnap); the
+// observation kernel below (its own launch bounds: a 166-VGPR callee inside rc_step_kernel cost the step kernel a wave
+// per SIMD) turns them into rows and pays the sighting-based observation rewards (processSeens).  Mirrors
 // oracle/robocup_partial.c operation by operation (bit-identical rows); the RNG keying is described there.
 // For one agent the lanes are the things it might see:
 //   lane 0 ball | 1..9 the other robots | 10..13 goalposts | 14..16 penalty crosses | 17..32 line crosses | 33..43 lines
@@ -36,10 +38,26 @@
 #define RV_STD_NORM (2.0 / RC_W)
 #define RV_SIZE_NORM (10.0 / 5.0)
 
-struct RvDetTable {  // detections every lane may need (rotPt, `is not None`), aliasing the (dead) contact mailbox
+struct RvDetTable {  // detections every lane may need (rotPt, `is not None`)
   double px[48], py[48];
   int has[48];
 };
+// what getAgentVision reads of the environment, as exported by rc_step_kernel at a snapshot (or after a reset)
+struct RvSnap {
+  double px[21], py[21], ang[20], head[10];
+  int rflags[10], owned, close0, close1, tkey;
+  int pad[2];
+};
+struct RvLds {  // LDS of the observation kernel (2.7 KB: every environment of a 4096-env launch is resident)
+  double px[RC_NB], py[RC_NB], ang[RC_NB], head[16];
+  int rflags[16], owned, close0, close1, tkey;
+  RvDetTable T;
+  int seen[10 * RCP_SEEN_STRIDE];
+};
+__shared__ RvLds g_V;
+DE_DEV V2 rv_pos(const RvLds& V, int r) { return v2((V.px[2 * r] + V.px[2 * r + 1]) / 2.0, (V.py[2 * r] + V.py[2 * r + 1]) / 2.0); }  // Robot.getPos
+DE_DEV double rv_angle(const RvLds& V, int r) { return (V.ang[2 * r] + V.ang[2 * r + 1]) / 2.0; }
+DE_DEV int rv_team(const RvLds& V, int r) { return (V.rflags[r] & RF_TEAMPOS) ? 1 : -1; }
 
 DE_DEV dm_u32x4 rv_rng(uint64_t seed, uint32_t genv, uint32_t episode, uint32_t tkey, int agent, int kind, int index, int block) {
   const uint32_t entity = (uint32_t)agent | ((uint32_t)kind << 4) | ((uint32_t)index << 8) | ((uint32_t)block << 16);
@@ -71,9 +89,10 @@ struct RvArgs {
 };
 
 // One snapshot: rows of all R agents -> out[R][RCP_DIM]; seen += the snapshot's (numLandMarks, ballsSeen, robotsSeen)
-__device__ __noinline__ int rc_partial_vision(RvArgs A, int lane, float* __restrict__ out, int* __restrict__ seen) {
-  RcLds& L = g_R;
-  RvDetTable& T = *reinterpret_cast<RvDetTable*>(&L.u);
+DE_DEV int rc_partial_vision(const RvArgs& A, int lane, float* __restrict__ out, bool countSeen) {
+  RvLds& V = g_V;
+  RvDetTable& T = V.T;
+  int* seen = countSeen ? V.seen : nullptr;
   const int R = A.R;
   const double randBase = 0.01 * A.magn;
   const uint64_t below = lanemask_lt();
@@ -86,10 +105,10 @@ __device__ __noinline__ int rc_partial_vision(RvArgs A, int lane, float* __restr
   for (int a = 0; a < R; ++a) {
     float* __restrict__ row = out + (size_t)a * RCP_DIM;
     for (int i = lane; i < RCP_DIM; i += DE_WAVE) row[i] = 0.0f;
-    const V2 pos = robot_pos(L, a);
-    const double angle = robot_angle(L, a), headAngle = angle + L.head[a];
-    const int team = robot_team(L, a);
-    const int aflags = L.rflags[a];
+    const V2 pos = rv_pos(V, a);
+    const double angle = rv_angle(V, a), headAngle = angle + V.head[a];
+    const int team = rv_team(V, a);
+    const int aflags = V.rflags[a];
     // one sincos call for the three uniform angles: lane 0 -> FoV edge 1, lane 1 -> FoV edge 2, others -> -headAngle
     const DevSC sc0 = dev_sincos(lane == 0 ? headAngle + RV_FOV : (lane == 1 ? headAngle - RV_FOV : -headAngle));
     const V2 vec1 = v2(1.0 * bcast_d(sc0.c, 0) - 0.0 * bcast_d(sc0.s, 0), 1.0 * bcast_d(sc0.s, 0) + 0.0 * bcast_d(sc0.c, 0));
@@ -104,11 +123,11 @@ __device__ __noinline__ int rc_partial_vision(RvArgs A, int lane, float* __restr
     if (isPoint) {
       V2 objp;
       double maxDist = RV_MAXVIS0, radius = 5.0;
-      if (isBall) { objp = v2(L.px[RC_BALL], L.py[RC_BALL]); radius = BALL_R; e3 = (double)(L.envi[RE_OWNED] * team); }
+      if (isBall) { objp = v2(V.px[RC_BALL], V.py[RC_BALL]); radius = BALL_R; e3 = (double)(V.owned * team); }
       else if (isRob) {
         robId = (lane - 1) < a ? (lane - 1) : lane;
-        objp = robot_pos(L, robId); maxDist = RV_MAXVIS1; radius = ROBOT_TOTAL_RADIUS;
-        e3 = robot_angle(L, robId) - headAngle; e4 = (double)(team * robot_team(L, robId));
+        objp = rv_pos(V, robId); maxDist = RV_MAXVIS1; radius = ROBOT_TOTAL_RADIUS;
+        e3 = rv_angle(V, robId) - headAngle; e4 = (double)(team * rv_team(V, robId));
         e5 = (aflags & (RF_FALLEN | RF_PENAL)) ? 1.0 : 0.0;
       } else {
         objp = v2(RC.visPx[lane], RC.visPy[lane]); e3 = RC.visT0[lane]; e4 = RC.visT1[lane];
@@ -301,9 +320,9 @@ __device__ __noinline__ int rc_partial_vision(RvArgs A, int lane, float* __restr
     const uint64_t mGen = wave_ballot(genBall);
     const int nBall = nBall0 + __popcll(mFp0) + __popcll(mGen), nRob = nRob0 + __popcll(mFp1), nGoal = nGoal0 + __popcll(mFp2);
     const int nCross = nCross0 + __popcll(mFp3), nFc = nFc0 + __popcll(mFp4), nLine = nLine0;
-    __threadfence();  // the zero fill of the row is complete before the scattered entries land
+    __threadfence_block();  // s_waitcnt: the zero fill of the row has completed before the scattered entries are issued
     // ---- conversion + placement ----------------------------------------------------------------------------------
-    const int closest = (a == L.envi[RE_CLOSE0] || a == L.envi[RE_CLOSE1]) ? 1 : 0;
+    const int closest = (a == V.close0 || a == V.close1) ? 1 : 0;
 #define RV_BALL_ROW(P_, q_, sz_, own_)                                                                                  \
   do {                                                                                                                  \
     if ((P_) < RCP_CAP_BALL) {                                                                                          \
@@ -369,4 +388,58 @@ __device__ __noinline__ int rc_partial_vision(RvArgs A, int lane, float* __restr
     __syncthreads();  // the detection table is rewritten by the next agent
   }
   return (int)(wave_ballot(overflow != 0) != 0ull);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The observation kernel: one wave per environment, the step's five snapshots in turn (after a reset: five views of the
+// initial state with draw keys t = 0..4, environment_base.py:217-222).  With `rewards` it also applies processSeens:
+// the step kernel left rewards[e][a] = robot reward + team reward and prew0 = its positive part; this kernel adds the
+// observation reward in the reference's order of operations and only then updates the episode accumulators.
+// ------------------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(64, 4)
+rc_partial_obs_kernel(RcState S, float* __restrict__ obs, double* __restrict__ rewards) {
+  RvLds& V = g_V;
+  const int e = blockIdx.x, lane = threadIdx.x, R = S.R;
+  const RvSnap* snaps = S.snap + (size_t)e * 5;
+  for (int i = lane; i < 10 * RCP_SEEN_STRIDE; i += DE_WAVE) V.seen[i] = 0;
+  RvArgs va;
+  va.seed = S.seed; va.genv = (uint32_t)(S.env_id_offset + e);
+  va.episode = (uint32_t)uniform_i(S.envi[(size_t)e * RE_COUNT + RE_EPISODE]);
+  va.R = R; va.n = S.n; va.noiseType = S.noise_type; va.magn = S.noise_magn;
+  int ov = 0;
+#pragma unroll 1
+  for (int t = 0; t < 5; ++t) {
+    const RvSnap& sn = snaps[t];
+    if (lane < 21) { V.px[lane] = sn.px[lane]; V.py[lane] = sn.py[lane]; }
+    if (lane < 20) V.ang[lane] = sn.ang[lane];
+    if (lane < 10) { V.head[lane] = sn.head[lane]; V.rflags[lane] = sn.rflags[lane]; }
+    if (lane == 0) { V.owned = sn.owned; V.close0 = sn.close0; V.close1 = sn.close1; V.tkey = sn.tkey; }
+    __syncthreads();
+    va.tkey = (uint32_t)uniform_i(V.tkey);
+    ov |= rc_partial_vision(va, lane, obs + ((size_t)e * 5 + t) * R * RCP_DIM, rewards != nullptr);
+    __syncthreads();
+  }
+  if (ov && lane == 0) S.envi[(size_t)e * RE_COUNT + RE_ERR] |= 2;
+  if (rewards && lane < R) {
+    double obsRew = 0.0;
+    if (S.flags & 8) {  // useObsRewards; processSeens, see oracle/robocup.c rc_process_seens
+      const int* sn = V.seen + lane * RCP_SEEN_STRIDE;
+      double lSeens = (double)sn[0] / 5.0, rSeens = 0.0, bSeens = (double)sn[1];
+      lSeens = lSeens < 0.0 ? 0.0 : (lSeens > 3.0 ? 3.0 : lSeens);
+      for (int k = 0; k < R - 1; ++k) { const double r = (double)sn[2 + k]; rSeens += r < 0.0 ? 0.0 : (r > 2.0 ? 2.0 : r); }
+      bSeens = bSeens < 0.0 ? 0.0 : (bSeens > 3.0 ? 3.0 : bSeens);
+      obsRew += (0.0025 * (rSeens + lSeens) + 0.01 * bSeens);
+    }
+    double rew = rewards[(size_t)e * R + lane];
+    rew += obsRew;
+    double prew = S.prew0[(size_t)e * 16 + lane];
+    prew += dm_max(obsRew, 0.0);
+    double* er = S.epr + (size_t)e * 16 + lane;
+    double* ep = S.epr + (size_t)S.E * 16 + (size_t)e * 16 + lane;
+    double* eo = S.epo + (size_t)e * 16 + lane;
+    *er = *er + rew;
+    *ep = *ep + prew;
+    *eo = *eo + obsRew;
+    rewards[(size_t)e * R + lane] = rew;
+  }
 }
