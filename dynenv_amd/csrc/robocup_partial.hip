@@ -182,6 +182,7 @@ DE_DEV int rc_partial_vision(const RvArgs& A, int lane, float* __restrict__ out,
     int inter = 0;
     if (isPoint) {
       for (int i = 1; i < R; ++i) {  // max over the robots (other than me) of doesInteract(rob, me, totalRadius * 2)
+        if (!uniform_i(T.has[i])) continue;  // robot i is outside the field of view (None): NoInter for everybody
         if (i == lane) continue;
         const int t = rv_interact(T, i, has, p, ROBOT_TOTAL_RADIUS * 2.0, true);
         inter = t > inter ? t : inter;
@@ -195,16 +196,23 @@ DE_DEV int rc_partial_vision(const RvArgs& A, int lane, float* __restrict__ out,
         inter = t > inter ? t : inter;
       }
     }
+    // ---- one pair of Philox blocks per lane for its draw site: point noise (kind by role), line noise (kind 5) or
+    //      false-positive trial (kind 7) - the three groups live on disjoint lanes, so two calls serve them all
+    int rkind = 7, rindex = lane - 44;
+    if (isPoint) { rkind = isBall ? 0 : isRob ? 1 : isGoal ? 2 : isCross ? 3 : 4; rindex = isBall ? 0 : isRob ? lane - 1 : isGoal ? lane - 10 : isCross ? lane - 14 : lane - 17; }
+    else if (isLine) { rkind = 5; rindex = lane - 33; }
+    dm_u32x4 u0, u1;
+    u0.v[0] = u0.v[1] = u0.v[2] = u0.v[3] = 0u; u1 = u0;
+    if ((isPoint && inter != 2 && seenT) || (isLine && seenT) || isTrial) {
+      u0 = rv_rng(A.seed, A.genv, A.episode, A.tkey, a, rkind, rindex, 0);
+      u1 = rv_rng(A.seed, A.genv, A.episode, A.tkey, a, rkind, rindex, 1);
+    }
     // ---- noise (cutils.addNoise on points, addNoiseLine on lines) ---------------------------------------------
     if (isPoint) {
       if (inter == 2) seenT = RV_NONE;
       else if (seenT) {
-        const int kind = isBall ? 0 : isRob ? 1 : isGoal ? 2 : isCross ? 3 : 4;
-        const int index = isBall ? 0 : isRob ? lane - 1 : isGoal ? lane - 10 : isCross ? lane - 14 : lane - 17;
         const bool misClass = isBall || isCross, angleNoise = isFc;
         const double maxDist = (isRob || isGoal) ? RV_MAXVIS1 : RV_MAXVIS0;
-        const dm_u32x4 u0 = rv_rng(A.seed, A.genv, A.episode, A.tkey, a, kind, index, 0);
-        const dm_u32x4 u1 = rv_rng(A.seed, A.genv, A.episode, A.tkey, a, kind, index, 1);
         const V2 noiseVec = vmul(v2(dm_unit(u0.v[0]) - 0.5, dm_unit(u0.v[1]) - 0.5), A.magn);
         if (A.noiseType == 0) {
           if (dm_unit(u0.v[2]) < randBase) seenT = RV_NONE;
@@ -229,8 +237,6 @@ DE_DEV int rc_partial_vision(const RvArgs& A, int lane, float* __restrict__ out,
         }
       }
     } else if (isLine && seenT) {
-      const dm_u32x4 u0 = rv_rng(A.seed, A.genv, A.episode, A.tkey, a, 5, lane - 33, 0);
-      const dm_u32x4 u1 = rv_rng(A.seed, A.genv, A.episode, A.tkey, a, 5, lane - 33, 1);
       const V2 n1 = vmul(v2(dm_unit(u0.v[0]) - 0.5, dm_unit(u0.v[1]) - 0.5), A.magn);
       const V2 n2 = vmul(v2(dm_unit(u0.v[2]) - 0.5, dm_unit(u0.v[3]) - 0.5), A.magn);
       if (A.noiseType == 0) {
@@ -267,8 +273,7 @@ DE_DEV int rc_partial_vision(const RvArgs& A, int lane, float* __restrict__ out,
     // ---- random false positives (lanes 44..53 = trials 0..9) ------------------------------------------------------
     int fpClass = -1;
     if (isTrial) {
-      const int i = lane - 44;
-      const dm_u32x4 u = rv_rng(A.seed, A.genv, A.episode, A.tkey, a, 7, i, 0), u1 = rv_rng(A.seed, A.genv, A.episode, A.tkey, a, 7, i, 1);
+      const dm_u32x4 u = u0;
       if (dm_unit(u.v[0]) < randBase) {
         fpClass = dm_randint(u.v[1], 0, 5);
         const double d = dm_unit(u.v[2]) * dm_sqrt(RV_MAXVIS1);
@@ -335,42 +340,45 @@ DE_DEV int rc_partial_vision(const RvArgs& A, int lane, float* __restrict__ out,
     if (crossToBall) { const int P = __popcll(mBallKeep) + __popcll(mCrossToBall & below); RV_BALL_ROW(P, p, size, 0.0); }
     if (fpClass == 0) { const int P = nBall0 + __popcll(mFp0 & below); RV_BALL_ROW(P, p, size, 0.0); }
     if (genBall) { const int P = nBall0 + __popcll(mFp0) + __popcll(mGen & below); RV_BALL_ROW(P, genP, genSize, 0.0); }
+    // destination of my polar entry (goals, crosses incl. the misclassified ball, field crosses), if any
+    int P = -1, off = 0, cap = 0, feat = 6;
+    if (goalKeep) { P = __popcll(mGoalKeep & below); off = RCP_OFF_GOAL; cap = RCP_CAP_GOAL; }
+    else if (fpClass == 2) { P = nGoal0 + __popcll(mFp2 & below); off = RCP_OFF_GOAL; cap = RCP_CAP_GOAL; }
+    else if (crossKeep) { P = __popcll(mCrossKeep & below); off = RCP_OFF_CROSS; cap = RCP_CAP_CROSS; }
+    else if (ballToCross) { P = __popcll(mCrossKeep); off = RCP_OFF_CROSS; cap = RCP_CAP_CROSS; }
+    else if (fpClass == 3) { P = nCross0 + __popcll(mFp3 & below); off = RCP_OFF_CROSS; cap = RCP_CAP_CROSS; }
+    else if (fcPos >= 0) { P = fcPos; off = RCP_OFF_FCROSS; cap = RCP_CAP_FCROSS; feat = 8; }
+    // one sincos for the orientation angle of robot rows (e3) and of field-cross rows (e5); one atan2 + one sincos for the
+    // bearing of polar rows and the direction of line rows: the groups live on disjoint lanes
+    const V2 ldiff = vsub(p2, p);
+    DevSC scA; scA.s = 0.0; scA.c = 0.0;
+    if (robPos >= 0 || (P >= 0 && feat == 8)) scA = dev_sincos(robPos >= 0 ? e3 : e5);
+    DevSC scB; scB.s = 0.0; scB.c = 0.0;
+    if (P >= 0 || lineKeep) {
+      const double ang = lineKeep ? dev_atan2(ldiff.y, ldiff.x) : dev_atan2(p.y * (double)team, p.x * (double)team);
+      scB = dev_sincos(ang);
+    }
     if (robPos >= 0) {
       if (robPos < RCP_CAP_ROB) {
         float* o = row + RCP_OFF_ROB + robPos * 7;
-        const DevSC sc = dev_sincos(e3);
         o[0] = (float)rv_normalize(p.x, RV_STD_NORM); o[1] = (float)rv_normalize(p.y, RV_STD_NORM);
-        o[2] = (float)rv_nas(size, RV_SIZE_NORM, ROBOT_TOTAL_RADIUS); o[3] = (float)sc.c; o[4] = (float)sc.s; o[5] = (float)e4; o[6] = (float)e5;
+        o[2] = (float)rv_nas(size, RV_SIZE_NORM, ROBOT_TOTAL_RADIUS); o[3] = (float)scA.c; o[4] = (float)scA.s; o[5] = (float)e4; o[6] = (float)e5;
       } else overflow = 1;
     }
-    {  // convertToPolar lists: goals, crosses (incl. the misclassified ball), field crosses
-      int P = -1, off = 0, cap = 0, feat = 6;
-      double sizeMean = 5.0;
-      if (goalKeep) { P = __popcll(mGoalKeep & below); off = RCP_OFF_GOAL; cap = RCP_CAP_GOAL; }
-      else if (fpClass == 2) { P = nGoal0 + __popcll(mFp2 & below); off = RCP_OFF_GOAL; cap = RCP_CAP_GOAL; }
-      else if (crossKeep) { P = __popcll(mCrossKeep & below); off = RCP_OFF_CROSS; cap = RCP_CAP_CROSS; }
-      else if (ballToCross) { P = __popcll(mCrossKeep); off = RCP_OFF_CROSS; cap = RCP_CAP_CROSS; }
-      else if (fpClass == 3) { P = nCross0 + __popcll(mFp3 & below); off = RCP_OFF_CROSS; cap = RCP_CAP_CROSS; }
-      else if (fcPos >= 0) { P = fcPos; off = RCP_OFF_FCROSS; cap = RCP_CAP_FCROSS; feat = 8; }
-      if (P >= 0) {
-        if (P < cap) {
-          float* o = row + off + P * feat;
-          const double dist = dm_sqrt(p.x * p.x + p.y * p.y);
-          const double ang = dev_atan2(p.y * (double)team, p.x * (double)team);
-          const DevSC sc = dev_sincos(ang);
-          o[0] = (float)rv_scale(dist, RV_STD_NORM); o[1] = (float)sc.c; o[2] = (float)sc.s;
-          o[3] = (float)((size - sizeMean) * RV_SIZE_NORM); o[4] = (float)(e3 * (double)team); o[5] = (float)(e4 * (double)team);
-          if (feat == 8) { const DevSC s5 = dev_sincos(e5); o[6] = (float)s5.c; o[7] = (float)(-s5.s); }
-        } else overflow = 1;
-      }
+    if (P >= 0) {  // convertToPolar
+      if (P < cap) {
+        float* o = row + off + P * feat;
+        const double dist = dm_sqrt(p.x * p.x + p.y * p.y);
+        o[0] = (float)rv_scale(dist, RV_STD_NORM); o[1] = (float)scB.c; o[2] = (float)scB.s;
+        o[3] = (float)((size - 5.0) * RV_SIZE_NORM); o[4] = (float)(e3 * (double)team); o[5] = (float)(e4 * (double)team);
+        if (feat == 8) { o[6] = (float)scA.c; o[7] = (float)(-scA.s); }
+      } else overflow = 1;
     }
     if (lineKeep) {  // normalizeLine
-      const int P = __popcll(mLineKeep & below);
-      float* o = row + RCP_OFF_LINE + P * 5;
-      const V2 diff = vsub(p2, p);
-      const double dist = dm_abs(p2.x * p.y - p2.y * p.x) / (vlen(diff) + 1e-7);
-      const DevSC sc = dev_sincos(dev_atan2(diff.y, diff.x));
-      o[0] = (float)rv_scale(dist, RV_STD_NORM); o[1] = (float)sc.c; o[2] = (float)sc.s; o[3] = (float)e3; o[4] = (float)e4;
+      const int PL = __popcll(mLineKeep & below);
+      float* o = row + RCP_OFF_LINE + PL * 5;
+      const double dist = dm_abs(p2.x * p.y - p2.y * p.x) / (vlen(ldiff) + 1e-7);
+      o[0] = (float)rv_scale(dist, RV_STD_NORM); o[1] = (float)scB.c; o[2] = (float)scB.s; o[3] = (float)e3; o[4] = (float)e4;
     }
 #undef RV_BALL_ROW
     if (lane == 0) {
