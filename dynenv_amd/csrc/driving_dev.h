@@ -1,9 +1,10 @@
 // driving_dev.h — device-side data layout of the batched Driving environment (HBM SoA + LDS tile).
 //
 // Mapping: ONE WAVEFRONT (64 lanes) PER ENVIRONMENT.  Lane l doubles as
-//   * the owner of dynamic body l          (cars 0..9, pedestrians 10..29)        -> body state lives in VGPRs
-//   * the detector of collision pairs {l, 64+l, ..., 448+l} of the 485 canonical pairs (8 rounds)
-//   * the owner of contact-cache slot l    (l < DRV_NS persistent arbiters)        -> impulses live in VGPRs
+//   * object l of the scene: cars 0..9, pedestrians 10..29 (dynamic bodies, state in the LDS tile), obstacles 30..49,
+//     buildings 50..53 - for integration and for the broadphase (bit i of lane j's mask = canonical pair (car i, j))
+//   * one quarter of a candidate pair in the narrowphase (four lanes per pair)
+//   * the owner of contact-cache slot l    (l < DRV_NS persistent arbiters)
 // HBM layout is field-major with the 32 body slots of one env contiguous (`field[e][32]`), so a wave's load of one
 // field is a single 256-byte coalesced segment.
 #pragma once
@@ -14,7 +15,6 @@
 #define DRV_MAXO 20
 #define DRV_NB 32          /* dynamic body slots per env (30 used) */
 #define DRV_NS 24          /* persistent arbiter (contact cache) slots per env (LDS budget: 16 envs per CU) */
-#define DRV_NPAIR_ROUNDS 8 /* ceil(485 / 64) */
 #define DRV_SLOT_PED 10
 #define DRV_SLOT_OBST 30
 #define DRV_SLOT_BLD 50
@@ -61,7 +61,6 @@ struct DrvConst {
   double carMass[4], carInertia[4], carHx[4], carHy[4], carPower[4];
   double pedMass, pedInertia;
   double turnCos[2], turnSin[2]; /* cos/sin(-/+ 2*pi/180) */
-  uint16_t pairs[DRV_NPAIR_ROUNDS * 64]; /* (i<<8)|j in canonical order, 0xFFFF = none */
 };
 
 struct DrvState {

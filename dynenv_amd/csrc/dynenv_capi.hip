@@ -96,13 +96,6 @@ static void build_consts(DrvConst& c) {
   }
   c.pedMass = 90.0;  // Pedestrian.py:11-14
   c.pedInertia = 90.0 * (0.5 * (0.0 * 0.0 + 5.0 * 5.0) + 0.0);
-  // canonical pair order: (car i, partner j) for i ascending, j ascending over cars>i, peds, obstacles, buildings
-  int p = 0;
-  for (int i = 0; i < DRV_MAXA; ++i) {
-    for (int j = i + 1; j < DRV_MAXA; ++j) c.pairs[p++] = (uint16_t)((i << 8) | j);
-    for (int j = DRV_SLOT_PED; j < DRV_SLOT_BLD + 4; ++j) c.pairs[p++] = (uint16_t)((i << 8) | j);
-  }
-  for (; p < DRV_NPAIR_ROUNDS * 64; ++p) c.pairs[p] = 0xFFFF;
 }
 
 // the device code spells the road constants as literals (RoadK<R>): they must equal the computed ones bit for bit
