@@ -653,21 +653,20 @@ DE_DEV void arb_apply_impulse(BodyV& a, BodyV& b, V2 n, const V2* r1, const V2* 
       }
       V2 vr = relative_velocity(a, b, r1[c], r2[c]);
       double vrn = vdot(vr, n);
-      double vrt = vdot(vr, vperp(n));
       double jbn = (bias[c] - vbn) * nMass[c];
       double jbnOld = jBias[c];
       jBias[c] = fmax_cp(jbnOld + jbn, 0.0);
       double jnn = -(bounce[c] + vrn) * nMass[c];
       double jnOld = jn[c];
       jn[c] = fmax_cp(jnOld + jnn, 0.0);
-      double jtMax = arb_u * jn[c];
-      double jtt = -vrt * tMass[c];
-      double jtOld = jt[c];
-      jt[c] = fclamp_cp(jtOld + jtt, -jtMax, jtMax);
+      // Friction: no Driving shape sets one (Chipmunk default u = 0), so arb.u = 0 * 0 = +0 and jtMax = u * jn = +0.
+      // cpfclamp(x, -0, +0) = cpfmin(cpfmax(x, -0), +0) is +0 for EVERY x (also inf / NaN): jt stays +0 and its increment
+      // is +0 - +0 = +0.  The tangent speed, tMass and the clamp are therefore not evaluated; the +0 increment still goes
+      // through cpvrotate exactly as in the reference.
       V2 jb = vmul(n, jBias[c] - jbnOld);
       apply_bias_impulse(a, vneg(jb), r1[c]);
       apply_bias_impulse(b, jb, r2[c]);
-      V2 jj = vrotate(n, v2(jn[c] - jnOld, jt[c] - jtOld));
+      V2 jj = vrotate(n, v2(jn[c] - jnOld, 0.0));
       apply_impulse(a, vneg(jj), r1[c]);
       apply_impulse(b, jj, r2[c]);
     }
@@ -910,8 +909,7 @@ DRV_PROF(const unsigned long long T2 = __builtin_amdgcn_s_memtime();)
     for (int c = 0; c < 2; ++c) {
       if (c < a_count) {
         nMass[c] = 1.0 / (k_scalar_body(a, r1[c], n) + k_scalar_body(b, r2[c], n));
-        tMass[c] = 1.0 / (k_scalar_body(a, r1[c], vperp(n)) + k_scalar_body(b, r2[c], vperp(n)));
-        double dist = vdot(vadd(vsub(r2[c], r1[c]), body_delta), n);
+        double dist = vdot(vadd(vsub(r2[c], r1[c]), body_delta), n);  // (tMass is not needed: see arb_apply_impulse)
         bias[c] = -DE_CONTACT_BIAS_COEF * fmin_cp(0.0, dist + DE_COLLISION_SLOP) / DE_DT;
         jBias[c] = 0.0;
         bounce[c] = vdot(relative_velocity(a, b, r1[c], r2[c]), n) * arb_e;
