@@ -120,8 +120,13 @@ drv_partial_obs_kernel(DrvState S, int noiseType, double magn, float* __restrict
     V2 cor[4];
     cor[0] = cor[1] = cor[2] = cor[3] = v2(0.0, 0.0);
     const bool isSelf = isCarLane && lane == a;
-    if (isCarLane || isPedLane || isObsLane || isBldLane) {
-      V2 point; double hx = 0.0, hy = 0.0, oangle = 0.0, maxD = maxVis0, distD = maxVis1;
+    // one sincos call serves every lane of this pass: self -> its heading, the other objects -> heading relative to the
+    // agent, lane rows -> road direction relative to the agent, and lane 63 -> the rotation by -ang that every object's
+    // position needs (broadcast below)
+    const bool isObjLane = isCarLane || isPedLane || isObsLane || isBldLane;
+    V2 point = v2(0.0, 0.0);
+    double hx = 0.0, hy = 0.0, oangle = 0.0, maxD = maxVis0, distD = maxVis1;
+    if (isObjLane) {
       if (isCarLane) {
         const int f = L.flags[lane];
         point = v2(L.px[lane], L.py[lane]); oangle = L.ang[lane];
@@ -137,9 +142,17 @@ drv_partial_obs_kernel(DrvState S, int noiseType, double magn, float* __restrict
         point = v2((k & 2) ? 1385.0 : 365.0, (k & 1) ? 800.0 : 200.0); hx = 400.0; hy = 225.0; hasCorners = true;
         maxD = 20000000.0; distD = 20000000.0;
       }
+    }
+    const int lrow = lane - 54, lroad = lrow < 4 ? 0 : 1;
+    double sarg = -ang;  // lane 63 (and idle lanes)
+    if (isSelf) sarg = ang;
+    else if (isObjLane) sarg = oangle - ang;
+    else if (isLaneRow) sarg = C.roads[lroad].dirAngle - ang;
+    const DevSC sc1 = dev_sincos(sarg);
+    const double rotC = bcast_d(sc1.c, 63), rotS = bcast_d(sc1.s, 63);
+    if (isObjLane) {
       if (isSelf) {  // selfDet :755-756: absolute position, own corners, never filtered
-        const DevSC sc = dev_sincos(ang);
-        seen = SIGHT_NORMAL; pos = P; dc = sc.c; ds = sc.s;
+        seen = SIGHT_NORMAL; pos = P; dc = sc1.c; ds = sc1.s;
         const double lx[4] = {hx, -hx, -hx, hx}, ly[4] = {hy, hy, -hy, -hy};
 #pragma unroll
         for (int i = 0; i < 4; ++i) cor[i] = vadd(v2(lx[i], ly[i]), P);
@@ -154,9 +167,8 @@ drv_partial_obs_kernel(DrvState S, int noiseType, double magn, float* __restrict
 #pragma unroll
             for (int i = 0; i < 4; ++i) cor[i] = vadd(vsub(vadd(v2(lx[i], ly[i]), point), point), trPt);
           }
-          pos = pv_rotated(trPt, -ang);
-          const DevSC sc = dev_sincos(oangle - ang);
-          dc = sc.c; ds = sc.s;
+          pos = v2(trPt.x * rotC - trPt.y * rotS, trPt.x * rotS + trPt.y * rotC);  // trPt.rotated(-ang)
+          dc = sc1.c; ds = sc1.s;
         }
       }
     }
@@ -164,15 +176,14 @@ drv_partial_obs_kernel(DrvState S, int noiseType, double magn, float* __restrict
     double ldist = 0.0, lc = 0.0, ls = 0.0, ltype = 0.0;
     int lseen = SIGHT_NONE;
     if (isLaneRow) {
-      const int rowi = lane - 54;
-      const int r = rowi < 4 ? 0 : 1;
+      const int rowi = lrow;
+      const int r = lroad;
       const int n = r ? 1 : 2;
       const int i = (rowi - (r ? 4 : 0)) - n;
       const V2 pt = vsub(P, C.roads[r].p0);
       const double dist = vcross(C.roads[r].dir, pt) / C.roads[r].width;
       if (!(dm_abs(dist) > 10.0)) {
-        const DevSC sc = dev_sincos(C.roads[r].dirAngle - ang);
-        double cc = sc.c, ss = sc.s, distMult = 1.0, typeMult = 1.0;
+        double cc = sc1.c, ss = sc1.s, distMult = 1.0, typeMult = 1.0;
         if (cc >= 0.0) { typeMult = -1.0; cc *= -1.0; ss *= -1.0; distMult = -1.0; }
         lseen = SIGHT_NORMAL;
         ldist = ((dist + 0.5) + (double)i) * C.roads[r].width * 0.1 * distMult;
@@ -248,58 +259,69 @@ drv_partial_obs_kernel(DrvState S, int noiseType, double magn, float* __restrict
       if (alive && isPedLane && pedInter == INTER_OCCLUDE) seen = SIGHT_NONE;  // filterOcclude (row stays in the list)
     }
     // ---- phase 5: noise (addNoiseRect :479-542 on self / cars / pedestrians / obstacles; addNoiseLane :382-413) ---
-    if ((alive || isSelf) && seen != SIGHT_NONE) {
-      const int kind = isSelf ? 0 : (isCarLane ? 1 : (isPedLane ? 2 : 3));
+    // Objects and lane rows live on disjoint lanes: one pair of Philox blocks, one atan2 and one sincos serve both.
+    {
+      const bool objNoise = (alive || isSelf) && seen != SIGHT_NONE, laneNoise = isLaneRow && lseen != SIGHT_NONE;
+      const int kind = isLaneRow ? 4 : (isSelf ? 0 : (isCarLane ? 1 : (isPedLane ? 2 : 3)));
       const int idx = isSelf ? 0 : listIdx;
-      const bool misClass = (isCarLane && !isSelf) || isObsLane;
-      const double maxDist = isPedLane ? maxVis0 : maxVis1;
-      const dm_u32x4 u = pv_rng(S, genv, episode, elapsed, a, kind, idx, 0), u1 = pv_rng(S, genv, episode, elapsed, a, kind, idx, 1);
-      const V2 noiseVec = v2((dm_unit(u.v[0]) - 0.5) * magn, (dm_unit(u.v[1]) - 0.5) * magn);
-      if (noiseType == 0) {  // NoiseType.RANDOM
-        if (dm_unit(u.v[2]) < randBase) {
-          seen = SIGHT_NONE;
+      dm_u32x4 u, u1;
+      u.v[0] = u.v[1] = u.v[2] = u.v[3] = 0u; u1 = u;
+      double base = 0.0;
+      if (objNoise || laneNoise) {
+        u = pv_rng(S, genv, episode, elapsed, a, kind, idx, 0);
+        u1 = pv_rng(S, genv, episode, elapsed, a, kind, idx, 1);
+        base = dev_atan2(objNoise ? ds : ls, objNoise ? dc : lc);
+      }
+      double angArg = base;
+      bool applyAngle = false;
+      V2 newPos = pos;
+      if (objNoise) {
+        const bool misClass = (isCarLane && !isSelf) || isObsLane;
+        const double maxDist = isPedLane ? maxVis0 : maxVis1;
+        const V2 noiseVec = v2((dm_unit(u.v[0]) - 0.5) * magn, (dm_unit(u.v[1]) - 0.5) * magn);
+        if (noiseType == 0) {  // NoiseType.RANDOM
+          if (dm_unit(u.v[2]) < randBase) {
+            seen = SIGHT_NONE;
+          } else {
+            newPos = vadd(pos, noiseVec);
+            const double angleDiff = (dm_unit(u1.v[0]) - 0.5) * magn * PV_ANGLE_NOISE;
+            angArg = base + angleDiff;
+            applyAngle = true;
+          }
         } else {
-          const V2 newPos = vadd(pos, noiseVec);
-          const double angleDiff = (dm_unit(u1.v[0]) - 0.5) * magn * PV_ANGLE_NOISE;
-          const DevSC sc = dev_sincos(dev_atan2(ds, dc) + angleDiff);
-          dc = sc.c; ds = sc.s;
-          pos = newPos;
+          const double range = 0.25 + 3.75 * vlen(pos) / maxDist;  // C18
+          double multiplier = range;
+          if (pedInter == INTER_NEARBY && isPedLane) multiplier = range * 2.0;
+          if (seen == 2) multiplier = range * 3.0;
+          const V2 np = vadd(pos, vmul(noiseVec, multiplier));
+          if (dm_unit(u.v[2]) < randBase * multiplier) {
+            seen = SIGHT_NONE;
+          } else {
+            if (misClass && dm_unit(u.v[3]) < randBase * multiplier / 2.0) seen = SIGHT_MISCLASS;
+            const double angleDiff = (dm_unit(u1.v[0]) - 0.5) * magn * PV_ANGLE_NOISE * 0.25;
+            angArg = base + angleDiff;
+            applyAngle = true;
+            newPos = np;
+          }
         }
-      } else {
-        const double range = 0.25 + 3.75 * vlen(pos) / maxDist;  // C18
-        double multiplier = range;
-        if (pedInter == INTER_NEARBY && isPedLane) multiplier = range * 2.0;
-        if (seen == 2) multiplier = range * 3.0;
-        const V2 newPos = vadd(pos, vmul(noiseVec, multiplier));
-        if (dm_unit(u.v[2]) < randBase * multiplier) {
-          seen = SIGHT_NONE;
+      } else if (laneNoise) {
+        const double distNoise = (dm_unit(u.v[0]) - 0.5) * magn, angleDiff = (dm_unit(u.v[1]) - 0.5) * magn;
+        if (noiseType == 0) {
+          if (dm_unit(u.v[2]) < randBase) lseen = SIGHT_NONE;
+          ldist *= distNoise;  // C19
+          angArg = base + PV_ANGLE_NOISE * angleDiff;
         } else {
-          if (misClass && dm_unit(u.v[3]) < randBase * multiplier / 2.0) seen = SIGHT_MISCLASS;
-          const double angleDiff = (dm_unit(u1.v[0]) - 0.5) * magn * PV_ANGLE_NOISE * 0.25;
-          const DevSC sc = dev_sincos(dev_atan2(ds, dc) + angleDiff);
-          dc = sc.c; ds = sc.s;
-          pos = newPos;
+          const double multiplier1 = 0.25 + 3.75 * ldist * ldist / maxVis1;
+          if (dm_unit(u.v[2]) < randBase * multiplier1) lseen = SIGHT_NONE;
+          ldist += distNoise * multiplier1;
+          angArg = base + PV_ANGLE_NOISE * multiplier1 / 5.0 * angleDiff;
         }
       }
-    }
-    if (isLaneRow && lseen != SIGHT_NONE) {
-      const dm_u32x4 u = pv_rng(S, genv, episode, elapsed, a, 4, listIdx, 0);
-      const double distNoise = (dm_unit(u.v[0]) - 0.5) * magn, angleDiff = (dm_unit(u.v[1]) - 0.5) * magn;
-      double angl;
-      if (noiseType == 0) {
-        if (dm_unit(u.v[2]) < randBase) lseen = SIGHT_NONE;
-        ldist *= distNoise;  // C19
-        angl = dev_atan2(ls, lc);
-        angl += PV_ANGLE_NOISE * angleDiff;
-      } else {
-        const double multiplier1 = 0.25 + 3.75 * ldist * ldist / maxVis1;
-        if (dm_unit(u.v[2]) < randBase * multiplier1) lseen = SIGHT_NONE;
-        ldist += distNoise * multiplier1;
-        angl = dev_atan2(ls, lc);
-        angl += PV_ANGLE_NOISE * multiplier1 / 5.0 * angleDiff;
+      if (objNoise || laneNoise) {
+        const DevSC sc = dev_sincos(angArg);
+        if (applyAngle) { dc = sc.c; ds = sc.s; pos = newPos; }
+        if (laneNoise) { lc = sc.c; ls = sc.s; }
       }
-      const DevSC sc = dev_sincos(angl);
-      lc = sc.c; ls = sc.s;
     }
     // ---- phase 6: random false positives :824-874, evaluated by lanes 0..9 (trial = lane) ---------------------
     int fpClass = -1;
