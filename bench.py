@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the end-of-step all-gather (data-parallel consumer)")
+    ap.add_argument("--sync-gather", action="store_true",
+                    help="N > 1: wait for the all-gather of step k before launching step k+1 (lock-step consumer); by default "
+                         "the gather of step k overlaps the kernel of step k+1 through two ping-pong slabs")
     args = ap.parse_args()
 
     import torch
@@ -152,8 +155,9 @@ def main():
         T, D = probe.n_time_steps, probe.obs_dim
         probe.close()
         slab = PackedSlab(torch, device, E, T, A, D)
+        slab2 = None if args.sync_gather else PackedSlab(torch, device, E, T, A, D)
         out_buffers = (slab.obs, slab.rewards, slab.dones)
-        gather = StepGather(torch, dist, slab)
+        gather = StepGather(torch, dist, slab, slab2=slab2)
     env = BatchedDynEnv(env_type, E, n_players, seed=args.seed, device=device, env_id_offset=rank * E,
                         out_buffers=out_buffers, **obs_kw)
     # synthetic inputs: i.i.d. uniform actions (action_space MultiDiscrete([3,3])), resident in HBM
@@ -164,16 +168,30 @@ def main():
     else:
         pool = [torch.randint(0, 3, (E, A, 2), generator=g, device=device, dtype=torch.int32) for _ in range(64)]
 
+    step_no = [0]
+
     def one_step(i):
-        env.step_flat(pool[i & 63])
-        if gather is not None:
+        if gather is None:
+            env.step_flat(pool[i & 63])
+        elif args.sync_gather:
+            env.step_flat(pool[i & 63])
             gather()
+        else:  # all-gather of step k overlaps the kernel of step k+1; a slab is rewritten only after its gather was waited for
+            k = step_no[0]
+            step_no[0] += 1
+            gather.release(k)
+            sl = gather.slabs[k % 2]
+            env.use_buffers(sl.obs, sl.rewards, sl.dones)
+            env.step_flat(pool[i & 63])
+            gather.start(k)
 
     env.reset_flat()
     for i in range(args.warmup):
         one_step(i)
 
     def fence():
+        if gather is not None and not args.sync_gather:
+            gather.drain()
         torch.cuda.synchronize(device)
         if dist is not None:
             dist.barrier()
@@ -245,7 +263,7 @@ def main():
                        if partial else
                        ("DrivingEnvironment nPlayers=%d Full obs, noise=0, %d envs per GPU "
                         "(BASELINE.json configs[1]), 10 substeps/step, lock-step resets every 600 steps" % (A, E)),
-                       "envs_per_gpu": E, "n_players": n_players, "n_agents": A, "obs": "partial" if partial else "full", "gather": bool(gather is not None),
+                       "envs_per_gpu": E, "n_players": n_players, "n_agents": A, "obs": "partial" if partial else "full", "gather": (False if gather is None else "sync" if args.sync_gather else "overlapped (step k gathered during kernel k+1)"),
                        "parallelism": "env-shard x%d" % world},
             "env_steps_per_s": env_steps / elapsed,
             "gpu_ms_per_step_rank0": gpu_ms / args.steps,

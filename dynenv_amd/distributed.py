@@ -48,16 +48,55 @@ class PackedSlab(object):
 
 
 class StepGather(object):
-    """All-gather of the packed step outputs.  Works on any backend (nccl=RCCL on MI355X, gloo on CPU)."""
+    """All-gather of the packed step outputs.  Works on any backend (nccl=RCCL on MI355X, gloo on CPU).
 
-    def __init__(self, torch, dist, slab, group=None):
-        self.torch, self.dist, self.slab, self.group = torch, dist, slab, group
+    Blocking use: `views = gather()` after the step wrote `slab`.
+    Pipelined use (two slabs): `h = gather.start(k)` after step k wrote `slabs[k % 2]`; the collective runs on the
+    process group's own stream while the kernel of step k+1 writes the other slab; `h.wait()` makes the current stream wait
+    for it and returns the gathered views.  A slab is reused only after the gather that read it has been waited for."""
+
+    def __init__(self, torch, dist, slab, group=None, slab2=None):
+        self.torch, self.dist, self.group = torch, dist, group
+        self.slabs = [slab] + ([slab2] if slab2 is not None else [])
+        self.slab = slab
         self.world_size = dist.get_world_size(group)
-        self.gbuf = torch.zeros((self.world_size * slab.nbytes,), dtype=torch.uint8, device=slab.buf.device)
+        self.gbufs = [torch.zeros((self.world_size * s.nbytes,), dtype=torch.uint8, device=s.buf.device) for s in self.slabs]
+        self.gbuf = self.gbufs[0]
+        self._pending = [None] * len(self.slabs)
 
     def __call__(self):
         self.dist.all_gather_into_tensor(self.gbuf, self.slab.buf, group=self.group)
         return self.slab.gathered_views(self.gbuf, self.world_size)
+
+    class _Handle(object):
+        def __init__(self, owner, idx, work):
+            self.owner, self.idx, self.work = owner, idx, work
+
+        def wait(self):
+            if self.work is not None:
+                self.work.wait()
+                self.work = None
+            o = self.owner
+            return o.slabs[self.idx].gathered_views(o.gbufs[self.idx], o.world_size)
+
+    def start(self, k):
+        """Begin the all-gather of slabs[k % n]; returns a handle whose wait() yields the gathered views."""
+        i = k % len(self.slabs)
+        work = self.dist.all_gather_into_tensor(self.gbufs[i], self.slabs[i].buf, group=self.group, async_op=True)
+        h = StepGather._Handle(self, i, work)
+        self._pending[i] = h
+        return h
+
+    def release(self, k):
+        """Before slabs[k % n] is overwritten: wait for the gather that still reads it (no-op if none is pending)."""
+        i = k % len(self.slabs)
+        if self._pending[i] is not None:
+            self._pending[i].wait()
+            self._pending[i] = None
+
+    def drain(self):
+        for i in range(len(self.slabs)):
+            self.release(i)
 
 
 class ShardedDynEnv(object):
@@ -74,14 +113,31 @@ class ShardedDynEnv(object):
         T, A, D = probe.n_time_steps, probe.n_agents, probe.obs_dim
         probe.close()
         self.slab = PackedSlab(torch, torch.device(device), per, T, A, D)
+        self.slab2 = PackedSlab(torch, torch.device(device), per, T, A, D) if gather else None
         self.env = BatchedDynEnv(env_type, per, num_players, seed=seed, device=device, env_id_offset=off,
                                  out_buffers=(self.slab.obs, self.slab.rewards, self.slab.dones), **kw)
-        self.gather = StepGather(torch, dist, self.slab) if gather else None
+        self.gather = StepGather(torch, dist, self.slab, slab2=self.slab2) if gather else None
+        self._k = 0
 
     def reset(self):
+        if self.gather is not None:  # back to slab 0, with no gather still reading it
+            self.gather.drain()
+            self.env.use_buffers(self.slab.obs, self.slab.rewards, self.slab.dones)
+            self._k = 1  # the next step writes slab 1 while nothing reads slab 0 asynchronously
         self.env.reset_flat()
         return self.gather() if self.gather else (self.env.obs, self.env.rewards, self.env.dones)
 
-    def step(self, local_actions):
+    def step(self, local_actions, wait=True):
+        """wait=True: the reference's lock-step semantics (the global view of this step is returned).
+        wait=False: returns a handle; the all-gather overlaps the next step's kernel (`handle.wait()` -> views)."""
+        if self.gather is None:
+            self.env.step_flat(local_actions)
+            return self.env.obs, self.env.rewards, self.env.dones
+        k = self._k
+        self._k += 1
+        self.gather.release(k)
+        sl = self.gather.slabs[k % 2]
+        self.env.use_buffers(sl.obs, sl.rewards, sl.dones)
         self.env.step_flat(local_actions)
-        return self.gather() if self.gather else (self.env.obs, self.env.rewards, self.env.dones)
+        h = self.gather.start(k)
+        return h.wait() if wait else h

@@ -246,6 +246,11 @@ class BatchedDynEnv(object):
         self._pending = None
         self.closed = False
 
+    def use_buffers(self, obs, rewards, dones):
+        """Switch the output buffers of the next reset/step (ping-pong slabs of dynenv_amd.distributed.StepGather)."""
+        assert tuple(obs.shape) == tuple(self.obs.shape) and obs.dtype == self.obs.dtype and obs.is_contiguous()
+        self.obs, self.rewards, self.dones = obs, rewards, dones
+
     # ------------------------------------------------------------------ fast path
     def _stream(self):
         return C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)

@@ -19,7 +19,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, total_envs, steps, out_dir):
+def _worker(rank, world, port, total_envs, steps, out_dir, pipelined=False):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     import torch
@@ -33,7 +33,8 @@ def _worker(rank, world, port, total_envs, steps, out_dir):
     A = 10
     ora = ol.OracleEnv(env_type=1, num_envs=per, n_players=A, seed=42, env_id_offset=off)
     slab = PackedSlab(torch, torch.device("cpu"), per, ora.T, A, ora.D)
-    gather = StepGather(torch, dist, slab)
+    slab2 = PackedSlab(torch, torch.device("cpu"), per, ora.T, A, ora.D) if pipelined else None
+    gather = StepGather(torch, dist, slab, slab2=slab2)
     rng = np.random.default_rng(123)
     all_actions = rng.integers(0, 3, size=(steps, total_envs, A, 2)).astype(np.int32)
 
@@ -46,11 +47,30 @@ def _worker(rank, world, port, total_envs, steps, out_dir):
     obs = ora.reset()
     g_obs, _, _ = publish(obs, ora.rewards, ora.dones)
     outs = [g_obs.reshape(total_envs, ora.T, A, ora.D).clone().numpy()]
-    for s in range(steps):
-        o, r, d = ora.step(all_actions[s, off:off + per])
-        g_obs, g_rew, g_done = publish(o, r, d)
-        outs.append((g_obs.reshape(total_envs, ora.T, A, ora.D).clone().numpy(),
-                     g_rew.reshape(total_envs, A).clone().numpy(), g_done.reshape(total_envs).clone().numpy()))
+
+    def snapshot(views):
+        g_obs, g_rew, g_done = views
+        return (g_obs.reshape(total_envs, ora.T, A, ora.D).clone().numpy(),
+                g_rew.reshape(total_envs, A).clone().numpy(), g_done.reshape(total_envs).clone().numpy())
+
+    if pipelined:
+        # the bench.py / ShardedDynEnv(wait=False) protocol: step k writes slabs[k % 2], its gather is started and only
+        # waited for when the slab is about to be rewritten (or the consumer asks for the views)
+        handles = []
+        for s in range(steps):
+            gather.release(s)
+            sl = gather.slabs[s % 2]
+            o, r, d = ora.step(all_actions[s, off:off + per])
+            sl.obs.copy_(torch.from_numpy(o)); sl.rewards.copy_(torch.from_numpy(r)); sl.dones.copy_(torch.from_numpy(d))
+            handles.append(gather.start(s))
+            if s >= 1:  # consume step s-1 one step late
+                outs.append(snapshot(handles[s - 1].wait()))
+        outs.append(snapshot(handles[-1].wait()))
+        gather.drain()
+    else:
+        for s in range(steps):
+            o, r, d = ora.step(all_actions[s, off:off + per])
+            outs.append(snapshot(publish(o, r, d)))
     if rank == 0:
         np.savez(os.path.join(out_dir, "gathered.npz"), obs0=outs[0], obs=np.stack([x[0] for x in outs[1:]]),
                  rew=np.stack([x[1] for x in outs[1:]]), done=np.stack([x[2] for x in outs[1:]]), actions=all_actions)
@@ -58,11 +78,12 @@ def _worker(rank, world, port, total_envs, steps, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_gather_and_shard_invariance(tmp_path, oracle_built):
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_two_rank_gather_and_shard_invariance(tmp_path, oracle_built, pipelined):
     import torch.multiprocessing as mp
     total, steps, world = 8, 6, 2
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, total, steps, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, total, steps, str(tmp_path), pipelined), nprocs=world, join=True)
     z = np.load(os.path.join(str(tmp_path), "gathered.npz"))
     import oracle_lib as ol
     single = ol.OracleEnv(env_type=1, num_envs=total, n_players=10, seed=42, env_id_offset=0)
