@@ -112,10 +112,18 @@ def main():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the end-of-step all-gather (data-parallel consumer)")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="rehearsal on a one-GPU box: run the N > 1 code path (slab, pack, all-gather, unpack) with world_size 1")
     ap.add_argument("--sync-gather", action="store_true",
                     help="N > 1: wait for the all-gather of step k before launching step k+1 (lock-step consumer); by default "
                          "the gather of step k overlaps the kernel of step k+1 through two ping-pong slabs")
     args = ap.parse_args()
+
+    # stdout carries exactly one JSON line: anything libraries print meanwhile (RCCL's version banner at init, ...) is
+    # diverted to stderr at the file-descriptor level until the result is printed
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     from dynenv_amd import BatchedDynEnv, DynEnvType
@@ -131,9 +139,10 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_gather:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     robocup = args.workload in ("robocup", "robocup_partial")
@@ -150,12 +159,14 @@ def main():
     if partial:
         from dynenv_amd import ObservationType, NoiseType
         obs_kw = dict(observationType=ObservationType.PARTIAL, noiseType=NoiseType.REALISTIC, noiseMagnitude=3)
-    if world > 1 and not args.no_gather:
+    if (world > 1 or args.force_gather) and not args.no_gather:
         probe = BatchedDynEnv(env_type, 1, n_players, device=device, **obs_kw)
         T, D = probe.n_time_steps, probe.obs_dim
+        from dynenv_amd.distributed import shared_tail_split
+        split = shared_tail_split(probe)  # Driving Full: the 160 floats every agent row repeats travel once per env
         probe.close()
-        slab = PackedSlab(torch, device, E, T, A, D)
-        slab2 = None if args.sync_gather else PackedSlab(torch, device, E, T, A, D)
+        slab = PackedSlab(torch, device, E, T, A, D, split=split)
+        slab2 = None if args.sync_gather else PackedSlab(torch, device, E, T, A, D, split=split)
         out_buffers = (slab.obs, slab.rewards, slab.dones)
         gather = StepGather(torch, dist, slab, slab2=slab2)
     env = BatchedDynEnv(env_type, E, n_players, seed=args.seed, device=device, env_id_offset=rank * E,
@@ -274,7 +285,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(E, n_players, A, args.seed, robocup, partial=partial)
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

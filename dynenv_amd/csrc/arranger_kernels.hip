@@ -182,3 +182,30 @@ arr_pad_kernel(const float* __restrict__ e0, const float* __restrict__ e1, const
   }
   padded[gid] = src ? reinterpret_cast<const float4*>(src)[f] : make_float4(0.f, 0.f, 0.f, 0.f);
 }
+
+// ------------------------------------------------------------------------------------------------
+// De-duplicated transport format of an observation tensor whose agent rows share a tail (Driving Full: obstacles,
+// pedestrians and lane rows are the same 160 floats for all 10 agents of an environment): per (env, time) the A agent
+// prefixes of `split` floats, then the tail of D - split floats once.  Used around the multi-GPU all-gather (2.6x fewer
+// bytes over xGMI); unpack restores the dense tensor bit for bit.
+// ------------------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(ARR_BLOCK)
+obs_pack_kernel(const float* __restrict__ obs, long long nET, int A, int D, int split, float* __restrict__ packed) {
+  const int P = A * split + (D - split);
+  const long long gid = (long long)blockIdx.x * ARR_BLOCK + threadIdx.x;
+  if (gid >= nET * P) return;
+  const long long et = gid / P;
+  const int k = (int)(gid % P);
+  const float* row = obs + (size_t)et * A * D;
+  packed[gid] = k < A * split ? row[(size_t)(k / split) * D + (k % split)] : row[split + (k - A * split)];
+}
+extern "C" __global__ void __launch_bounds__(ARR_BLOCK)
+obs_unpack_kernel(const float* __restrict__ packed, long long nET, int A, int D, int split, float* __restrict__ obs) {
+  const int P = A * split + (D - split);
+  const long long gid = (long long)blockIdx.x * ARR_BLOCK + threadIdx.x;
+  if (gid >= nET * A * D) return;
+  const long long et = gid / ((long long)A * D);
+  const int r = (int)(gid % ((long long)A * D)), a = r / D, f = r % D;
+  const float* src = packed + (size_t)et * P;
+  obs[gid] = f < split ? src[a * split + f] : src[A * split + (f - split)];
+}

@@ -759,6 +759,27 @@ int dynenv_arrange_pad(const float* const* emb_dev, const int32_t* counts_dev, c
   return DYNENV_OK;
 }
 
+int dynenv_obs_pack(const float* obs_dev, int64_t n_env_time, int32_t A, int32_t D, int32_t split, float* packed_dev, void* stream) {
+  if (int rc = arr_have_device()) return rc;
+  if (!obs_dev || !packed_dev || n_env_time < 0 || A < 1 || D < 1 || split < 0 || split > D) return fail(DYNENV_ERR_ARG, "bad argument");
+  const long long total = (long long)n_env_time * ((long long)A * split + (D - split));
+  if (total == 0) return DYNENV_OK;
+  hipLaunchKernelGGL(obs_pack_kernel, dim3((unsigned)((total + ARR_BLOCK - 1) / ARR_BLOCK)), dim3(ARR_BLOCK), 0, (hipStream_t)stream,
+                     obs_dev, (long long)n_env_time, A, D, split, packed_dev);
+  HIP_OK(hipGetLastError());
+  return DYNENV_OK;
+}
+int dynenv_obs_unpack(const float* packed_dev, int64_t n_env_time, int32_t A, int32_t D, int32_t split, float* obs_dev, void* stream) {
+  if (int rc = arr_have_device()) return rc;
+  if (!obs_dev || !packed_dev || n_env_time < 0 || A < 1 || D < 1 || split < 0 || split > D) return fail(DYNENV_ERR_ARG, "bad argument");
+  const long long total = (long long)n_env_time * A * D;
+  if (total == 0) return DYNENV_OK;
+  hipLaunchKernelGGL(obs_unpack_kernel, dim3((unsigned)((total + ARR_BLOCK - 1) / ARR_BLOCK)), dim3(ARR_BLOCK), 0, (hipStream_t)stream,
+                     packed_dev, (long long)n_env_time, A, D, split, obs_dev);
+  HIP_OK(hipGetLastError());
+  return DYNENV_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // exact checkpoint: every device array of the handle, bit for bit
 // ------------------------------------------------------------------------------------------------

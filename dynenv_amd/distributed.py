@@ -17,34 +17,72 @@ def shard_range(total_envs, rank, world_size):
 
 
 class PackedSlab(object):
-    """One flat byte buffer per rank holding obs|rewards|dones so a single collective moves a whole step."""
+    """One flat byte buffer per rank holding obs|rewards|dones so a single collective moves a whole step.
 
-    def __init__(self, torch, device, E, T, A, D):
+    split=None: the obs region is the dense tensor itself (the step kernel writes into it, nothing is copied).
+    split=k (GPU only): every agent row of an (env, time) ends in the same D-k floats (Driving Full: obstacles,
+    pedestrians, lanes); the slab then carries the de-duplicated form (dynenv_obs_pack, 2.6x fewer bytes for A=10) -
+    the step kernel writes a separate dense tensor, pack() fills the slab, unpack() restores dense views after the gather."""
+
+    def __init__(self, torch, device, E, T, A, D, split=None):
         self.torch = torch
-        self.E, self.T, self.A, self.D = E, T, A, D
-        self.obs_bytes = E * T * A * D * 4
+        self.E, self.T, self.A, self.D, self.split = E, T, A, D, split
+        self.row = A * D if split is None else A * split + (D - split)  # floats per (env, time)
+        self.obs_bytes = E * T * self.row * 4
         self.rew_off = (self.obs_bytes + 255) // 256 * 256
         self.rew_bytes = E * A * 8
         self.done_off = (self.rew_off + self.rew_bytes + 255) // 256 * 256
         self.nbytes = (self.done_off + E + 255) // 256 * 256
         self.buf = torch.zeros((self.nbytes,), dtype=torch.uint8, device=device)
-        self.obs, self.rewards, self.dones = self.views(self.buf)
+        obs, self.rewards, self.dones = self.views(self.buf)
+        if split is None:
+            self.obs = obs
+        else:
+            self._packed = obs
+            self.obs = torch.zeros((E, T, A, D), dtype=torch.float32, device=device)
+            self._lib = None
 
     def views(self, buf):
         t = self.torch
-        obs = buf[:self.obs_bytes].view(t.float32).view(self.E, self.T, self.A, self.D)
+        obs = buf[:self.obs_bytes].view(t.float32)
+        obs = obs.view(self.E, self.T, self.A, self.D) if self.split is None else obs.view(self.E, self.T, self.row)
         rew = buf[self.rew_off:self.rew_off + self.rew_bytes].view(t.float64).view(self.E, self.A)
         dones = buf[self.done_off:self.done_off + self.E]
         return obs, rew, dones
 
-    def gathered_views(self, gbuf, world_size):
-        """Zero-copy [G, E_loc, ...] views into the gathered buffer."""
+    def _capi(self):
+        if self._lib is None:
+            from . import _capi
+            self._lib = (_capi, _capi.load())
+        return self._lib
+
+    def pack(self):
+        """dense self.obs -> the slab's de-duplicated obs region (a no-op without split); on the current stream"""
+        if self.split is None:
+            return
+        import ctypes as C
+        capi, lib = self._capi()
+        st = C.c_void_p(self.torch.cuda.current_stream(self.buf.device).cuda_stream)
+        capi.check(lib.dynenv_obs_pack(C.c_void_p(self.obs.data_ptr()), self.E * self.T, self.A, self.D, self.split,
+                                       C.c_void_p(self._packed.data_ptr()), st), "dynenv_obs_pack")
+
+    def gathered_views(self, gbuf, world_size, dense_out=None):
+        """[G, E_loc, ...] views into the gathered buffer (zero-copy; with split the obs are unpacked into dense_out)."""
         t = self.torch
         g = gbuf.view(world_size, self.nbytes)
-        obs = g[:, :self.obs_bytes].view(t.float32).view(world_size, self.E, self.T, self.A, self.D)
         rew = g[:, self.rew_off:self.rew_off + self.rew_bytes].view(t.float64).view(world_size, self.E, self.A)
         dones = g[:, self.done_off:self.done_off + self.E]
-        return obs, rew, dones
+        if self.split is None:
+            obs = g[:, :self.obs_bytes].view(t.float32).view(world_size, self.E, self.T, self.A, self.D)
+            return obs, rew, dones
+        import ctypes as C
+        capi, lib = self._capi()
+        st = C.c_void_p(t.cuda.current_stream(self.buf.device).cuda_stream)
+        for r in range(world_size):  # the packed obs regions of the ranks are not contiguous in the gathered buffer
+            src = g[r, :self.obs_bytes]
+            capi.check(lib.dynenv_obs_unpack(C.c_void_p(src.data_ptr()), self.E * self.T, self.A, self.D, self.split,
+                                             C.c_void_p(dense_out[r].data_ptr()), st), "dynenv_obs_unpack")
+        return dense_out, rew, dones
 
 
 class StepGather(object):
@@ -63,10 +101,13 @@ class StepGather(object):
         self.gbufs = [torch.zeros((self.world_size * s.nbytes,), dtype=torch.uint8, device=s.buf.device) for s in self.slabs]
         self.gbuf = self.gbufs[0]
         self._pending = [None] * len(self.slabs)
+        self.dense = [torch.zeros((self.world_size, s.E, s.T, s.A, s.D), dtype=torch.float32, device=s.buf.device)
+                      if s.split is not None else None for s in self.slabs]
 
     def __call__(self):
+        self.slab.pack()
         self.dist.all_gather_into_tensor(self.gbuf, self.slab.buf, group=self.group)
-        return self.slab.gathered_views(self.gbuf, self.world_size)
+        return self.slab.gathered_views(self.gbuf, self.world_size, self.dense[0])
 
     class _Handle(object):
         def __init__(self, owner, idx, work):
@@ -77,11 +118,12 @@ class StepGather(object):
                 self.work.wait()
                 self.work = None
             o = self.owner
-            return o.slabs[self.idx].gathered_views(o.gbufs[self.idx], o.world_size)
+            return o.slabs[self.idx].gathered_views(o.gbufs[self.idx], o.world_size, o.dense[self.idx])
 
     def start(self, k):
         """Begin the all-gather of slabs[k % n]; returns a handle whose wait() yields the gathered views."""
         i = k % len(self.slabs)
+        self.slabs[i].pack()
         work = self.dist.all_gather_into_tensor(self.gbufs[i], self.slabs[i].buf, group=self.group, async_op=True)
         h = StepGather._Handle(self, i, work)
         self._pending[i] = h
@@ -99,6 +141,15 @@ class StepGather(object):
             self.release(i)
 
 
+def shared_tail_split(env):
+    """Float offset from which every agent row of an (env, time) is identical, or None.  Driving Full: the obstacle,
+    pedestrian and lane blocks (DrivingEnvironment.getFullState gives every agent the same lists)."""
+    from .enums import DynEnvType, ObservationType
+    if env.env_type == DynEnvType.DRIVE and env.observationType == ObservationType.FULL:
+        return int(env.layout.block_offset[2])
+    return None
+
+
 class ShardedDynEnv(object):
     """One process per GPU: local BatchedDynEnv over this rank's env range + optional end-of-step all-gather."""
 
@@ -111,9 +162,10 @@ class ShardedDynEnv(object):
         device = kw.pop("device", "cuda:%d" % torch.cuda.current_device())
         probe = BatchedDynEnv(env_type, 1, num_players, seed=seed, device=device, **kw)
         T, A, D = probe.n_time_steps, probe.n_agents, probe.obs_dim
+        split = shared_tail_split(probe)
         probe.close()
-        self.slab = PackedSlab(torch, torch.device(device), per, T, A, D)
-        self.slab2 = PackedSlab(torch, torch.device(device), per, T, A, D) if gather else None
+        self.slab = PackedSlab(torch, torch.device(device), per, T, A, D, split=split if gather else None)
+        self.slab2 = PackedSlab(torch, torch.device(device), per, T, A, D, split=split) if gather else None
         self.env = BatchedDynEnv(env_type, per, num_players, seed=seed, device=device, env_id_offset=off,
                                  out_buffers=(self.slab.obs, self.slab.rewards, self.slab.dones), **kw)
         self.gather = StepGather(torch, dist, self.slab, slab2=self.slab2) if gather else None

@@ -179,6 +179,13 @@ int dynenv_error_flags(dynenv_t* h, int32_t* out);
  * Synchronises the device. */
 int dynenv_debug_counters(dynenv_t* h, int64_t* out12);
 
+/* ---- de-duplicated transport format for the multi-GPU all-gather.  Where every agent row of an (env, time) ends in the
+ * same tail (Driving Full: obstacles, pedestrians, lane rows = 160 of 232 floats), the packed form holds the A prefixes
+ * of `split` floats followed by the tail once: A*split + (D - split) floats instead of A*D.  n_env_time = E*T rows of
+ * [A][D].  unpack(pack(x)) == x bit for bit when the tails are identical (they are written from one LDS copy). ---- */
+int dynenv_obs_pack(const float* obs_dev, int64_t n_env_time, int32_t A, int32_t D, int32_t split, float* packed_dev, void* stream);
+int dynenv_obs_unpack(const float* packed_dev, int64_t n_env_time, int32_t A, int32_t D, int32_t split, float* obs_dev, void* stream);
+
 /* ---- exact checkpoint (the reference has none).  Unlike the canonical per-env blob of
  * dynenv_get_state (which drops the contact cache), a checkpoint is every device array of the handle bit for bit -
  * bodies, contact cache, shortcut state, episode counters, seed - so that load + the same actions reproduces the run

@@ -42,3 +42,22 @@ def test_sharded_env_pipelined_gather_rccl_world1():
         assert torch.equal(go[0], o) and torch.equal(gr[0], r)
     finally:
         dist.destroy_process_group()
+
+
+def test_obs_pack_unpack_roundtrip():
+    import ctypes as C
+    import torch
+    from dynenv_amd import _capi
+    lib = _capi.load()
+    ET, A, D, split = 37, 10, 232, 72
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn((ET, A, D), device="cuda", generator=g)
+    x[:, :, split:] = x[:, :1, split:]  # every agent row shares the tail
+    P = A * split + (D - split)
+    packed = torch.empty((ET, P), device="cuda")
+    y = torch.empty_like(x)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _capi.check(lib.dynenv_obs_pack(C.c_void_p(x.data_ptr()), ET, A, D, split, C.c_void_p(packed.data_ptr()), st), "pack")
+    _capi.check(lib.dynenv_obs_unpack(C.c_void_p(packed.data_ptr()), ET, A, D, split, C.c_void_p(y.data_ptr()), st), "unpack")
+    assert torch.equal(x, y)
+    assert torch.equal(packed[:, :A * split].reshape(ET, A, split), x[:, :, :split]) and torch.equal(packed[:, A * split:], x[:, 0, split:])
