@@ -989,11 +989,13 @@ DRV_PROF(T4 = __builtin_amdgcn_s_memtime();)
     }
   }
   const bool allSteady = wave_ballot(!steady) == 0ull;
+DRV_PROF(if (active) { const int pi = a_pair >> 8, pj = a_pair & 0xFF; const bool fz = (L.still[pi] & 2) && (pj >= DRV_SLOT_OBST || (L.still[pj] & 2));
+  atomicAdd(&g_dbgr[13], 1ull); if (fz && steady) atomicAdd(&g_dbgr[14], 1ull); if (maxLevel > 0) { atomicAdd(&g_dbgr[15], 1ull); if (fz && steady) atomicAdd(&g_dbgr[12], 1ull); } })
 DRV_PROF(if (slotOcc) { int why = 0; const int pi = a_pair >> 8, pj = a_pair & 0xFF;
   if (steady) why = 0; else if (!touched) why = 1; else if (freeMe) why = 2; else if (!hashSame) why = 3; else if (a_state != ARB_NORMAL || !wasNormal) why = 4;
   else if (!restIn) why = 5; else if (!(L.s_jn0[lane] == jn[0] && L.s_jt0[lane] == jt[0] && L.s_jn1[lane] == jn[1] && L.s_jt1[lane] == jt[1])) why = 6; else why = 7;
   atomicAdd(&g_dbgr[why], 1ull);
-  if (why == 6) { if (L.s_jn0[lane] == 0.0 && L.s_jn1[lane] == 0.0) atomicAdd(&g_dbgr[8], 1ull); if (pj >= DRV_SLOT_PED && pj < DRV_SLOT_OBST) atomicAdd(&g_dbgr[9], 1ull); else if (pj < DRV_SLOT_PED) atomicAdd(&g_dbgr[10], 1ull); else atomicAdd(&g_dbgr[11], 1ull); if (jn[0] != 0.0 || jn[1] != 0.0) atomicAdd(&g_dbgr[12], 1ull); } })
+  if (why == 6) { if (L.s_jn0[lane] == 0.0 && L.s_jn1[lane] == 0.0) atomicAdd(&g_dbgr[8], 1ull); if (pj >= DRV_SLOT_PED && pj < DRV_SLOT_OBST) atomicAdd(&g_dbgr[9], 1ull); else if (pj < DRV_SLOT_PED) atomicAdd(&g_dbgr[10], 1ull); else atomicAdd(&g_dbgr[11], 1ull); } })
   if (slotOcc) {
     if (freeMe) L.s_pair[lane] = 0xFFFF;
     L.s_meta[lane] = a_state | (a_count << 8) | (a_age << 16);

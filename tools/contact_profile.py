@@ -43,6 +43,8 @@ m0 = d[:, 1] == 0
 print("mean over nContact=0 envs:", d[m0, 4:11].mean(0).astype(int), "total", int(c[m0].mean()))
 r = np.loadtxt("gpurun_out/dbgr.txt")
 names = ["steady", "untouched", "freed", "contact ids changed", "first contact / not NORMAL", "bodies moving before prestep",
-         "accumulated impulses changed", "bodies moving after solve", "(6) with zero stored jn", "(6) car-ped", "(6) car-car", "(6) car-static", "(6) jn != 0 after"]
+         "accumulated impulses changed", "bodies moving after solve", "(6) with zero stored jn", "(6) car-ped", "(6) car-car", "(6) car-static",
+         "active arbiters in multi-level calls that are frozen + steady", "active arbiters (all full-path calls)",
+         "... of which frozen + steady", "active arbiters in multi-level calls"]
 print("slot outcomes over the whole run (per slot per contact-path call):")
 for n, v in zip(names, r): print("  %-34s %d" % (n, v))
