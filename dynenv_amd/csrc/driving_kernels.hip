@@ -796,7 +796,6 @@ DRV_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
     ret.occ = occ; ret.rew = rew; ret.err = err | 8;
     return ret;
   }
-  if (isCar || isPed) { L.vbx[lane] = 0.0; L.vby[lane] = 0.0; L.wb[lane] = 0.0; }  // bias velocities restart from zero
 
 DRV_PROF(const unsigned long long T1 = __builtin_amdgcn_s_memtime();)
   // ---- slot lanes: cpArbiterUpdate for touched slots; ageing / expiry for the rest ----------------------
@@ -805,6 +804,7 @@ DRV_PROF(const unsigned long long T1 = __builtin_amdgcn_s_memtime();)
   int bodyA = 0, bodyB = 0;
   int a_pair = 0xFFFF, a_state = ARB_FIRST, a_count = 0, a_age = 0;
   bool hashSame = false;  // same contact ids in the same order as when the slot was last written
+  bool prevSteady = false, prevInert = false;  // how this slot came out of its previous evaluation (persisted in s_meta)
   double jn[2] = {0.0, 0.0}, jt[2] = {0.0, 0.0};
   V2 n = v2(0.0, 0.0), r1[2], r2[2];
   r1[0] = r1[1] = r2[0] = r2[1] = v2(0.0, 0.0);
@@ -814,7 +814,8 @@ DRV_PROF(const unsigned long long T1 = __builtin_amdgcn_s_memtime();)
     a_pair = L.s_pair[lane];
     int meta = L.s_meta[lane];
     a_state = meta & 0xFF; a_count = (meta >> 8) & 0xFF; a_age = (meta >> 16) & 0xFF;
-    if (flag & 2) { a_state = ARB_FIRST; a_count = 0; a_age = 0; }
+    prevSteady = (meta >> 24) & 1; prevInert = (meta >> 25) & 1;
+    if (flag & 2) { a_state = ARB_FIRST; a_count = 0; a_age = 0; prevSteady = false; prevInert = false; }
     if (touched) {
       const int i = a_pair >> 8, j = a_pair & 0xFF;
       // narrowphase order: shape type ascending => pedestrian circle first for car-ped pairs
@@ -877,8 +878,48 @@ DRV_PROF(const unsigned long long T1 = __builtin_amdgcn_s_memtime();)
   }
   const uint64_t freeMask = wave_ballot(freeMe);
 
+  // ---- component replay.  A touched, solvable slot is CLEAN if it came out of its previous evaluation steady, is not a
+  // first contact, has the same contact ids, and both its bodies are frozen (at rest, position unchanged since the
+  // previous substep): evaluating it again would read the same inputs.  That only reproduces the previous outputs if
+  // the whole connected component of the contact graph (arbiters sharing a dynamic body) is clean, because the
+  // Gauss-Seidel sweep couples exactly those.  Dirtiness therefore spreads from every other occupied slot over shared
+  // dynamic bodies until it stops; clean components are skipped: their slots stay as they are, their bodies keep zero
+  // velocity and the bias velocities of the previous solve (still in L.vb*, see vbValid).
+  const bool solvable = touched && a_state != ARB_IGNORE;
+  bool cleanSlot = false;
+  int myBodies = 0;  // bit b: dynamic body b belongs to my slot
+  if (slotOcc) {
+    const int pi = a_pair >> 8, pj = a_pair & 0xFF;
+    myBodies = (1 << pi) | (pj < DRV_SLOT_OBST ? (1 << pj) : 0);
+    cleanSlot = solvable && prevSteady && a_state == ARB_NORMAL && hashSame && (L.still[pi] & 2) &&
+                (pj >= DRV_SLOT_OBST || (L.still[pj] & 2));
+  }
+  int dirtyBodies = 0;
+  {
+    const uint64_t occLanes = wave_ballot(slotOcc);
+    bool slotDirty = slotOcc && !cleanSlot && !(touched && a_state == ARB_IGNORE);
+    for (int round = 0; round < DRV_NS; ++round) {
+      int m = 0;
+      for (uint64_t mm = occLanes; mm; mm &= mm - 1) {
+        const int b = __builtin_ctzll(mm);
+        m |= bcast_i(slotDirty ? myBodies : 0, b);
+      }
+      if (m == dirtyBodies) break;
+      dirtyBodies = m;
+      slotDirty = slotDirty || (cleanSlot && (myBodies & dirtyBodies) != 0);
+    }
+    cleanSlot = cleanSlot && (myBodies & dirtyBodies) == 0;
+  }
+  const bool skipped = cleanSlot;  // solved before with identical inputs: replayed
+  {  // bias velocities restart from zero, except on the bodies of skipped components (they keep the previous solve's)
+    int keep = 0;
+    const uint64_t skipLanes = wave_ballot(skipped);
+    for (uint64_t mm = skipLanes; mm; mm &= mm - 1) keep |= bcast_i(myBodies, __builtin_ctzll(mm));
+    if ((isCar || isPed) && !((keep >> lane) & 1)) { L.vbx[lane] = 0.0; L.vby[lane] = 0.0; L.wb[lane] = 0.0; }
+  }
+
   // ---- active arbiters: levels (arbiters sharing a dynamic body keep their canonical sequential order) --
-  const bool active = touched && a_state != ARB_IGNORE;
+  const bool active = solvable && !skipped;
   const uint64_t activeMask = wave_ballot(active);
   int myLevel = 0, maxLevel = -1, blvl = 0;
   for (int k = 0; k < nTouched; ++k) {
@@ -976,7 +1017,7 @@ DRV_PROF(T4 = __builtin_amdgcn_s_memtime();)
   // bit for bit: the slot record is unchanged (same contact ids, same accumulated impulses, NORMAL before and after, or
   // ignored) and both bodies were at rest before the prestep and after the solve.  See DESIGN.md "steady replay".
   bool steady = true;
-  if (slotOcc) {
+  if (slotOcc && !skipped) {
     steady = touched && !freeMe && hashSame;
     if (steady && a_state != ARB_IGNORE) {
       steady = a_state == ARB_NORMAL && wasNormal && restIn && L.s_jn0[lane] == jn[0] && L.s_jt0[lane] == jt[0] &&
@@ -989,6 +1030,15 @@ DRV_PROF(T4 = __builtin_amdgcn_s_memtime();)
     }
   }
   const bool allSteady = wave_ballot(!steady) == 0ull;
+  // inert: touched, not first contact, and (ignored | zero bias and zero accumulated impulses on every contact)
+  bool inert = true;
+  if (slotOcc && skipped) inert = prevInert;
+  else if (slotOcc) {
+    inert = touched && !freeMe &&
+            (a_state == ARB_IGNORE ||
+             (a_state == ARB_NORMAL && wasNormal && bias[0] == 0.0 && bias[1] == 0.0 && jn[0] == 0.0 && jt[0] == 0.0 &&
+              jn[1] == 0.0 && jt[1] == 0.0 && jBias[0] == 0.0 && jBias[1] == 0.0));
+  }
 DRV_PROF(if (active) { const int pi = a_pair >> 8, pj = a_pair & 0xFF; const bool fz = (L.still[pi] & 2) && (pj >= DRV_SLOT_OBST || (L.still[pj] & 2));
   atomicAdd(&g_dbgr[13], 1ull); if (fz && steady) atomicAdd(&g_dbgr[14], 1ull); if (maxLevel > 0) { atomicAdd(&g_dbgr[15], 1ull); if (fz && steady) atomicAdd(&g_dbgr[12], 1ull); } })
 DRV_PROF(if (slotOcc) { int why = 0; const int pi = a_pair >> 8, pj = a_pair & 0xFF;
@@ -998,18 +1048,10 @@ DRV_PROF(if (slotOcc) { int why = 0; const int pi = a_pair >> 8, pj = a_pair & 0
   if (why == 6) { if (L.s_jn0[lane] == 0.0 && L.s_jn1[lane] == 0.0) atomicAdd(&g_dbgr[8], 1ull); if (pj >= DRV_SLOT_PED && pj < DRV_SLOT_OBST) atomicAdd(&g_dbgr[9], 1ull); else if (pj < DRV_SLOT_PED) atomicAdd(&g_dbgr[10], 1ull); else atomicAdd(&g_dbgr[11], 1ull); } })
   if (slotOcc) {
     if (freeMe) L.s_pair[lane] = 0xFFFF;
-    L.s_meta[lane] = a_state | (a_count << 8) | (a_age << 16);
+    L.s_meta[lane] = a_state | (a_count << 8) | (a_age << 16) | (steady ? (1 << 24) : 0) | (inert ? (1 << 25) : 0);
     if (touched) { L.s_jn0[lane] = jn[0]; L.s_jt0[lane] = jt[0]; L.s_jn1[lane] = jn[1]; L.s_jt1[lane] = jt[1]; }
   }
   occ &= ~freeMask;
-  // inert: touched, not first contact, and (ignored | zero bias and zero accumulated impulses on every contact)
-  bool inert = true;
-  if (slotOcc) {
-    inert = touched && !freeMe &&
-            (a_state == ARB_IGNORE ||
-             (a_state == ARB_NORMAL && wasNormal && bias[0] == 0.0 && bias[1] == 0.0 && jn[0] == 0.0 && jt[0] == 0.0 &&
-              jn[1] == 0.0 && jt[1] == 0.0 && jBias[0] == 0.0 && jBias[1] == 0.0));
-  }
   const bool allInert = wave_ballot(!inert) == 0ull;
 DRV_PROF(const unsigned long long T5 = __builtin_amdgcn_s_memtime();)
 DRV_PROF(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* d = g_dbgp + blockIdx.x * 8; d[0] += T1 - T0; d[1] += T2 - T1; d[2] += T3 - T2; d[3] += T4 - T3; d[4] += T5 - T4; d[5] += 1ull; d[6] += (unsigned long long)(maxLevel + 1); d[7] += (unsigned long long)nTouched; })
