@@ -895,7 +895,7 @@ DRV_PROF(const unsigned long long T1 = __builtin_amdgcn_s_memtime();)
                 (pj >= DRV_SLOT_OBST || (L.still[pj] & 2));
   }
   int dirtyBodies = 0;
-  {
+  if (wave_ballot(cleanSlot) != 0ull) {  // (usually nothing is clean: no closure to compute)
     const uint64_t occLanes = wave_ballot(slotOcc);
     bool slotDirty = slotOcc && !cleanSlot && !(touched && a_state == ARB_IGNORE);
     for (int round = 0; round < DRV_NS; ++round) {
