@@ -200,12 +200,13 @@ obs_pack_kernel(const float* __restrict__ obs, long long nET, int A, int D, int 
   packed[gid] = k < A * split ? row[(size_t)(k / split) * D + (k % split)] : row[split + (k - A * split)];
 }
 extern "C" __global__ void __launch_bounds__(ARR_BLOCK)
-obs_unpack_kernel(const float* __restrict__ packed, long long nET, int A, int D, int split, float* __restrict__ obs) {
+obs_unpack_kernel(const float* __restrict__ packed, long long nET, int A, int D, int split, float* __restrict__ obs,
+                  long long srcStride /* floats between the packed blocks of consecutive ranks (blockIdx.y) */) {
   const int P = A * split + (D - split);
   const long long gid = (long long)blockIdx.x * ARR_BLOCK + threadIdx.x;
   if (gid >= nET * A * D) return;
   const long long et = gid / ((long long)A * D);
   const int r = (int)(gid % ((long long)A * D)), a = r / D, f = r % D;
-  const float* src = packed + (size_t)et * P;
-  obs[gid] = f < split ? src[a * split + f] : src[A * split + (f - split)];
+  const float* src = packed + (size_t)blockIdx.y * srcStride + (size_t)et * P;
+  obs[(size_t)blockIdx.y * nET * A * D + gid] = f < split ? src[a * split + f] : src[A * split + (f - split)];
 }

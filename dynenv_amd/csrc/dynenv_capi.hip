@@ -775,7 +775,19 @@ int dynenv_obs_unpack(const float* packed_dev, int64_t n_env_time, int32_t A, in
   const long long total = (long long)n_env_time * A * D;
   if (total == 0) return DYNENV_OK;
   hipLaunchKernelGGL(obs_unpack_kernel, dim3((unsigned)((total + ARR_BLOCK - 1) / ARR_BLOCK)), dim3(ARR_BLOCK), 0, (hipStream_t)stream,
-                     packed_dev, (long long)n_env_time, A, D, split, obs_dev);
+                     packed_dev, (long long)n_env_time, A, D, split, obs_dev, 0ll);
+  HIP_OK(hipGetLastError());
+  return DYNENV_OK;
+}
+int dynenv_obs_unpack_ranks(const float* packed_dev, int64_t src_stride_floats, int32_t n_ranks, int64_t n_env_time, int32_t A,
+                            int32_t D, int32_t split, float* obs_dev, void* stream) {
+  if (int rc = arr_have_device()) return rc;
+  if (!obs_dev || !packed_dev || n_env_time < 0 || A < 1 || D < 1 || split < 0 || split > D || n_ranks < 1 || n_ranks > 65535 || src_stride_floats < 0)
+    return fail(DYNENV_ERR_ARG, "bad argument");
+  const long long total = (long long)n_env_time * A * D;
+  if (total == 0) return DYNENV_OK;
+  hipLaunchKernelGGL(obs_unpack_kernel, dim3((unsigned)((total + ARR_BLOCK - 1) / ARR_BLOCK), (unsigned)n_ranks), dim3(ARR_BLOCK), 0,
+                     (hipStream_t)stream, packed_dev, (long long)n_env_time, A, D, split, obs_dev, (long long)src_stride_floats);
   HIP_OK(hipGetLastError());
   return DYNENV_OK;
 }

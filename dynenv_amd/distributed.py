@@ -78,10 +78,9 @@ class PackedSlab(object):
         import ctypes as C
         capi, lib = self._capi()
         st = C.c_void_p(t.cuda.current_stream(self.buf.device).cuda_stream)
-        for r in range(world_size):  # the packed obs regions of the ranks are not contiguous in the gathered buffer
-            src = g[r, :self.obs_bytes]
-            capi.check(lib.dynenv_obs_unpack(C.c_void_p(src.data_ptr()), self.E * self.T, self.A, self.D, self.split,
-                                             C.c_void_p(dense_out[r].data_ptr()), st), "dynenv_obs_unpack")
+        # the packed obs regions of the ranks sit `nbytes` apart in the gathered buffer: one launch unpacks them all
+        capi.check(lib.dynenv_obs_unpack_ranks(C.c_void_p(g.data_ptr()), self.nbytes // 4, world_size, self.E * self.T, self.A,
+                                               self.D, self.split, C.c_void_p(dense_out.data_ptr()), st), "dynenv_obs_unpack_ranks")
         return dense_out, rew, dones
 
 

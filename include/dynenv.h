@@ -185,6 +185,9 @@ int dynenv_debug_counters(dynenv_t* h, int64_t* out12);
  * [A][D].  unpack(pack(x)) == x bit for bit when the tails are identical (they are written from one LDS copy). ---- */
 int dynenv_obs_pack(const float* obs_dev, int64_t n_env_time, int32_t A, int32_t D, int32_t split, float* packed_dev, void* stream);
 int dynenv_obs_unpack(const float* packed_dev, int64_t n_env_time, int32_t A, int32_t D, int32_t split, float* obs_dev, void* stream);
+/* the gathered buffer of an all-gather: n_ranks packed blocks `src_stride_floats` apart -> obs_dev [n_ranks][n_env_time][A][D], one launch */
+int dynenv_obs_unpack_ranks(const float* packed_dev, int64_t src_stride_floats, int32_t n_ranks, int64_t n_env_time, int32_t A,
+                            int32_t D, int32_t split, float* obs_dev, void* stream);
 
 /* ---- exact checkpoint (the reference has none).  Unlike the canonical per-env blob of
  * dynenv_get_state (which drops the contact cache), a checkpoint is every device array of the handle bit for bit -
