@@ -378,40 +378,47 @@ class BatchedDynEnv(object):
                         out[e, t, a, 1] = [lists[2], lists[3], lists[4], lists[5]]
                         out[e, t, a, 2] = (int(r[tail + 6]), r[tail + 8:tail + 8 + (A - 1)].astype("uint8"), bool(r[tail + 7]))
             return out
+        # Views into `o` (a fresh host copy per step), blocks reshaped once for the whole batch: the per-(env, time, agent)
+        # Python work is only the assembly of the reference's nested lists.
+        ones = (1, 1, 1)
         if self.env_type == DynEnvType.ROBO_CUP:  # ((ball, robots), (self,), (1,1,1)) RoboCupEnvironment.py:440-443
+            ball = o[..., 0:4].reshape(E, T, A, 1, 4)
+            selfr = o[..., 4:12].reshape(E, T, A, 1, 8)
+            robs = o[..., 12:12 + (A - 1) * 6].reshape(E, T, A, A - 1, 6)
             for e in range(E):
                 for t in range(T):
                     for a in range(A):
-                        r = o[e, t, a]
-                        out[e, t, a, 0] = [r[0:4].reshape(1, 4).copy(), r[12:12 + (A - 1) * 6].reshape(A - 1, 6).copy()]
-                        out[e, t, a, 1] = [r[4:12].reshape(1, 8).copy(), ]
-                        out[e, t, a, 2] = (1, 1, 1)
+                        out[e, t, a, 0] = [ball[e, t, a], robs[e, t, a]]
+                        out[e, t, a, 1] = [selfr[e, t, a], ]
+                        out[e, t, a, 2] = ones
             return out
         if self.observationType == ObservationType.PARTIAL:  # ragged rows of getAgentVision, lengths in the last 4 floats
+            cars = o[..., off[1]:off[1] + rows[1] * 7].reshape(E, T, A, rows[1], 7)
+            obst = o[..., off[2]:off[2] + rows[2] * 6].reshape(E, T, A, rows[2], 6)
+            peds = o[..., off[3]:off[3] + rows[3] * 2].reshape(E, T, A, rows[3], 2)
+            lanes = o[..., off[4]:off[4] + rows[4] * 4].reshape(E, T, A, rows[4], 4)
+            selfr = o[..., 0:9].reshape(E, T, A, 1, 9)
+            n = o[..., D - 4:].astype(np.int64)
             for e in range(E):
                 for t in range(T):
                     for a in range(A):
-                        r = o[e, t, a]
-                        nc, no, npd, nl = (int(x) for x in r[-4:])
-                        out[e, t, a, 0] = [r[off[1]:off[1] + nc * 7].reshape(nc, 7).copy(),
-                                           r[off[2]:off[2] + no * 6].reshape(no, 6).copy(),
-                                           r[off[3]:off[3] + npd * 2].reshape(npd, 2).copy()]
-                        out[e, t, a, 1] = [r[0:9].reshape(1, 9).copy(), r[off[4]:off[4] + nl * 4].reshape(nl, 4).copy()]
-                        out[e, t, a, 2] = (1, 1, 1)
+                        nc, no, npd, nl = n[e, t, a]
+                        out[e, t, a, 0] = [cars[e, t, a, :nc], obst[e, t, a, :no], peds[e, t, a, :npd]]
+                        out[e, t, a, 1] = [selfr[e, t, a], lanes[e, t, a, :nl]]
+                        out[e, t, a, 2] = ones
             return out
+        selfr = o[..., off[0]:off[0] + 9].reshape(E, T, A, 1, 9)
+        cars = o[..., off[1]:off[1] + rows[1] * 7].reshape(E, T, A, rows[1], 7)
+        obst = o[..., off[2]:off[2] + rows[2] * 4].reshape(E, T, A, rows[2], 4)
+        peds = o[..., off[3]:off[3] + rows[3] * 2].reshape(E, T, A, rows[3], 2)
+        lanes = o[..., off[4]:off[4] + rows[4] * 5].reshape(E, T, A, rows[4], 5)
         for e in range(E):
             n_obst, n_ped = int(counts[e, 0]), int(counts[e, 1])
             for t in range(T):
                 for a in range(A):
-                    r = o[e, t, a]
-                    selfr = r[off[0]:off[0] + 9].reshape(1, 9).copy()
-                    cars = r[off[1]:off[1] + rows[1] * 7].reshape(rows[1], 7).copy()
-                    obst = r[off[2]:off[2] + n_obst * 4].reshape(n_obst, 4).copy()
-                    peds = r[off[3]:off[3] + n_ped * 2].reshape(n_ped, 2).copy()
-                    lanes = r[off[4]:off[4] + rows[4] * 5].reshape(rows[4], 5).copy()
-                    out[e, t, a, 0] = [cars, obst, peds]
-                    out[e, t, a, 1] = [selfr, lanes]
-                    out[e, t, a, 2] = (1, 1, 1)
+                    out[e, t, a, 0] = [cars[e, t, a], obst[e, t, a, :n_obst], peds[e, t, a, :n_ped]]
+                    out[e, t, a, 1] = [selfr[e, t, a], lanes[e, t, a]]
+                    out[e, t, a, 2] = ones
         return out
 
     def _full_states(self, obs_np, counts, e):
