@@ -1374,7 +1374,7 @@ DRV_PROF(const unsigned long long K1 = __builtin_amdgcn_s_memtime();)
   S.lastcand[(size_t)e * 64 + lane] = lastCand;
   store_env(S, L, e, lane, A, nPed, occ);
   if (obs) write_full_obs(L, lane, A, nPed, nObst, S.obs_dim, obs + (size_t)e * A * S.obs_dim);
-DRV_PROF(if (lane == 0 && e < 4096) { unsigned long long* d = g_dbgw + e * 12; const unsigned long long KE = __builtin_amdgcn_s_memtime(); d[0] = KE - KS; d[1] = nContact; d[2] = __popcll(occ); d[3] = nSteady + nQuiet; d[4] = K0 - KS; d[5] = tPh1; d[6] = tBroad; d[7] = tFast; d[8] = tCont; d[9] = (K1 - K0) - tPh1 - tBroad - tFast - tCont; d[10] = KE - K1; d[11] = 0; })
+DRV_PROF(if (lane == 0 && e < 4096) { unsigned long long* d = g_dbgw + e * 12; const unsigned long long KE = __builtin_amdgcn_s_memtime(); d[0] = KE - KS; d[1] = nContact; d[2] = __popcll(occ); d[3] = nSteady + nQuiet; d[4] = K0 - KS; d[5] = tPh1; d[6] = tBroad; d[7] = tFast; d[8] = tCont; d[9] = (K1 - K0) - tPh1 - tBroad - tFast - tCont; d[10] = KE - K1; d[11] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned long long)__builtin_amdgcn_s_getreg(63492); })
 }
 
 // ------------------------------------------------------------------------------------------------
