@@ -114,9 +114,12 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="skip the end-of-step all-gather (data-parallel consumer)")
     ap.add_argument("--force-gather", action="store_true",
                     help="rehearsal on a one-GPU box: run the N > 1 code path (slab, pack, all-gather, unpack) with world_size 1")
+    ap.add_argument("--transport", choices=("compact", "tail", "dense"), default="compact",
+                    help="N > 1: form in which observations cross xGMI (compact = the most compact exact form of the layout)")
+    ap.add_argument("--ring", type=int, default=4, help="N > 1: slabs in flight (the host runs at most this many steps ahead of the transports)")
     ap.add_argument("--sync-gather", action="store_true",
                     help="N > 1: wait for the all-gather of step k before launching step k+1 (lock-step consumer); by default "
-                         "the gather of step k overlaps the kernel of step k+1 through two ping-pong slabs")
+                         "the transport of step k runs on a side stream beside the following kernels (ring of --ring slabs)")
     args = ap.parse_args()
 
     # stdout carries exactly one JSON line: anything libraries print meanwhile (RCCL's version banner at init, ...) is
@@ -162,13 +165,14 @@ def main():
     if (world > 1 or args.force_gather) and not args.no_gather:
         probe = BatchedDynEnv(env_type, 1, n_players, device=device, **obs_kw)
         T, D = probe.n_time_steps, probe.obs_dim
-        from dynenv_amd.distributed import shared_tail_split
-        split = shared_tail_split(probe)  # Driving Full: the 160 floats every agent row repeats travel once per env
+        from dynenv_amd.distributed import transport_layout, shared_tail_split
+        # Driving Full: self blocks + the shared tail travel once per env (exact; 250 instead of 2320 floats for 10 agents)
+        layout = {} if args.transport == "dense" else dict(split=shared_tail_split(probe)) if args.transport == "tail" else transport_layout(probe)
         probe.close()
-        slab = PackedSlab(torch, device, E, T, A, D, split=split)
-        slab2 = None if args.sync_gather else PackedSlab(torch, device, E, T, A, D, split=split)
+        slab = PackedSlab(torch, device, E, T, A, D, **layout)
+        more = [] if args.sync_gather else [PackedSlab(torch, device, E, T, A, D, **layout) for _ in range(args.ring - 1)]
         out_buffers = (slab.obs, slab.rewards, slab.dones)
-        gather = StepGather(torch, dist, slab, slab2=slab2)
+        gather = StepGather(torch, dist, slab, more=more)
     env = BatchedDynEnv(env_type, E, n_players, seed=args.seed, device=device, env_id_offset=rank * E,
                         out_buffers=out_buffers, **obs_kw)
     # synthetic inputs: i.i.d. uniform actions (action_space MultiDiscrete([3,3])), resident in HBM
@@ -191,7 +195,7 @@ def main():
             k = step_no[0]
             step_no[0] += 1
             gather.release(k)
-            sl = gather.slabs[k % 2]
+            sl = gather.slabs[k % len(gather.slabs)]
             env.use_buffers(sl.obs, sl.rewards, sl.dones)
             env.step_flat(pool[i & 63])
             gather.start(k)
@@ -274,7 +278,8 @@ def main():
                        if partial else
                        ("DrivingEnvironment nPlayers=%d Full obs, noise=0, %d envs per GPU "
                         "(BASELINE.json configs[1]), 10 substeps/step, lock-step resets every 600 steps" % (A, E)),
-                       "envs_per_gpu": E, "n_players": n_players, "n_agents": A, "obs": "partial" if partial else "full", "gather": (False if gather is None else "sync" if args.sync_gather else "overlapped (step k gathered during kernel k+1)"),
+                       "envs_per_gpu": E, "n_players": n_players, "n_agents": A, "obs": "partial" if partial else "full", "gather": (False if gather is None else "sync" if args.sync_gather else "overlapped (transport of step k on a side stream beside the next kernels, ring of %d slabs)" % args.ring),
+                       "gather_bytes_per_rank": (None if slab is None else slab.nbytes),
                        "parallelism": "env-shard x%d" % world},
             "env_steps_per_s": env_steps / elapsed,
             "gpu_ms_per_step_rank0": gpu_ms / args.steps,

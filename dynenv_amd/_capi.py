@@ -75,7 +75,8 @@ EXPORTS = ["dynenv_abi_version", "dynenv_last_error", "dynenv_create", "dynenv_d
            "dynenv_state_size", "dynenv_get_state", "dynenv_set_state", "dynenv_sync", "dynenv_math_selftest",
            "dynenv_error_flags", "dynenv_debug_counters", "dynenv_arrange_scratch_ints", "dynenv_arrange_plan",
            "dynenv_arrange_gather", "dynenv_arrange_scatter", "dynenv_arrange_pad", "dynenv_checkpoint_size",
-           "dynenv_checkpoint_save", "dynenv_checkpoint_load", "dynenv_obs_pack", "dynenv_obs_unpack", "dynenv_obs_unpack_ranks"]
+           "dynenv_checkpoint_save", "dynenv_checkpoint_load", "dynenv_obs_pack", "dynenv_obs_unpack", "dynenv_obs_unpack_ranks",
+           "dynenv_obs_pack_peers", "dynenv_obs_unpack_peers_ranks"]
 
 ARR_MAX_TYPES = 4
 ARR_COUNT_CONST, ARR_COUNT_ENV, ARR_COUNT_ROW = 0, 1, 2
@@ -128,6 +129,8 @@ def load():
     lib.dynenv_obs_pack.argtypes = [vp, C.c_int64, i32, i32, i32, vp, vp]
     lib.dynenv_obs_unpack.argtypes = [vp, C.c_int64, i32, i32, i32, vp, vp]
     lib.dynenv_obs_unpack_ranks.argtypes = [vp, C.c_int64, i32, C.c_int64, i32, i32, i32, vp, vp]
+    lib.dynenv_obs_pack_peers.argtypes = [vp, C.c_int64, i32, i32, vp, vp]
+    lib.dynenv_obs_unpack_peers_ranks.argtypes = [vp, C.c_int64, i32, C.c_int64, i32, i32, vp, vp]
     lib.dynenv_checkpoint_size.argtypes = [vp]
     lib.dynenv_checkpoint_size.restype = C.c_size_t
     lib.dynenv_checkpoint_save.argtypes = [vp, vp, C.c_size_t]

@@ -792,6 +792,37 @@ int dynenv_obs_unpack_ranks(const float* packed_dev, int64_t src_stride_floats, 
   return DYNENV_OK;
 }
 
+int dynenv_obs_pack_peers(const float* obs_dev, int64_t n_env_time, int32_t A, int32_t D, float* packed_dev, void* stream) {
+  if (int rc = arr_have_device()) return rc;
+  if (!obs_dev || !packed_dev || n_env_time < 0 || A < 1 || D < PEER_SELF + (A - 1) * PEER_COLS) return fail(DYNENV_ERR_ARG, "bad argument");
+  const long long total = (long long)n_env_time * (A * PEER_SELF + (D - PEER_SELF - (A - 1) * PEER_COLS));
+  if (total == 0) return DYNENV_OK;
+  hipLaunchKernelGGL(obs_pack_peers_kernel, dim3((unsigned)((total + ARR_BLOCK - 1) / ARR_BLOCK)), dim3(ARR_BLOCK), 0, (hipStream_t)stream,
+                     obs_dev, (long long)n_env_time, A, D, packed_dev);
+  HIP_OK(hipGetLastError());
+  return DYNENV_OK;
+}
+int dynenv_obs_unpack_peers_ranks(const float* packed_dev, int64_t src_stride_floats, int32_t n_ranks, int64_t n_env_time, int32_t A,
+                                  int32_t D, float* obs_dev, void* stream) {
+  if (int rc = arr_have_device()) return rc;
+  if (!obs_dev || !packed_dev || n_env_time < 0 || A < 1 || D < PEER_SELF + (A - 1) * PEER_COLS || n_ranks < 1 || n_ranks > 65535 ||
+      src_stride_floats < 0)
+    return fail(DYNENV_ERR_ARG, "bad argument");
+  const long long total = (long long)n_env_time * A * D;
+  if (total == 0) return DYNENV_OK;
+  const bool vec = (D % 4) == 0 && ((uintptr_t)obs_dev % 16) == 0;
+  const long long threads = vec ? total / 4 : total;
+  const dim3 grid((unsigned)((threads + ARR_BLOCK - 1) / ARR_BLOCK), (unsigned)n_ranks);
+  if (vec)
+    hipLaunchKernelGGL(obs_unpack_peers4_kernel, grid, dim3(ARR_BLOCK), 0, (hipStream_t)stream, packed_dev, (long long)n_env_time, A, D,
+                       obs_dev, (long long)src_stride_floats);
+  else
+    hipLaunchKernelGGL(obs_unpack_peers1_kernel, grid, dim3(ARR_BLOCK), 0, (hipStream_t)stream, packed_dev, (long long)n_env_time, A, D,
+                       obs_dev, (long long)src_stride_floats);
+  HIP_OK(hipGetLastError());
+  return DYNENV_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // exact checkpoint: every device array of the handle, bit for bit
 // ------------------------------------------------------------------------------------------------

@@ -188,6 +188,14 @@ int dynenv_obs_unpack(const float* packed_dev, int64_t n_env_time, int32_t A, in
 /* the gathered buffer of an all-gather: n_ranks packed blocks `src_stride_floats` apart -> obs_dev [n_ranks][n_env_time][A][D], one launch */
 int dynenv_obs_unpack_ranks(const float* packed_dev, int64_t src_stride_floats, int32_t n_ranks, int64_t n_env_time, int32_t A,
                             int32_t D, int32_t split, float* obs_dev, void* stream);
+/* Peer-compacted transport format of a Driving Full observation (reference: DrivingEnvironment.getFullState,
+ * DrivingEnvironment.py:686-747).  Agent a's row is [self 9 | the other A-1 cars x 7 | tail]; the 7 floats of car c are
+ * columns {0..5, 8} of c's own self block, so per (env, time) the A self blocks plus the tail once carry everything:
+ * 9A + (D - 9 - 7(A-1)) floats instead of A*D.  unpack_peers_ranks expands n_ranks gathered blocks (src_stride_floats
+ * apart) into the dense [n_ranks][n_env_time][A][D] tensor, bit for bit. */
+int dynenv_obs_pack_peers(const float* obs_dev, int64_t n_env_time, int32_t A, int32_t D, float* packed_dev, void* stream);
+int dynenv_obs_unpack_peers_ranks(const float* packed_dev, int64_t src_stride_floats, int32_t n_ranks, int64_t n_env_time,
+                                  int32_t A, int32_t D, float* obs_dev, void* stream);
 
 /* ---- exact checkpoint (the reference has none).  Unlike the canonical per-env blob of
  * dynenv_get_state (which drops the contact cache), a checkpoint is every device array of the handle bit for bit -

@@ -1,5 +1,5 @@
 """ShardedDynEnv on the GPU with the RCCL backend (world_size 1: one GPU box): the pipelined all-gather protocol
-(step k gathered while the kernel of step k+1 runs, ping-pong slabs) returns exactly what a plain BatchedDynEnv computes."""
+(the transport of step k runs on a side stream beside the following kernels, ring of slabs) returns exactly what a plain BatchedDynEnv computes."""
 import os
 import socket
 
@@ -61,3 +61,37 @@ def test_obs_pack_unpack_roundtrip():
     _capi.check(lib.dynenv_obs_unpack(C.c_void_p(packed.data_ptr()), ET, A, D, split, C.c_void_p(y.data_ptr()), st), "unpack")
     assert torch.equal(x, y)
     assert torch.equal(packed[:, :A * split].reshape(ET, A, split), x[:, :, :split]) and torch.equal(packed[:, A * split:], x[:, 0, split:])
+
+
+@pytest.mark.parametrize("A,tail", [(10, 160), (2, 160), (3, 21), (1, 8)])
+def test_obs_peer_compaction_roundtrip(A, tail):
+    """Driving Full rows rebuilt from the A self blocks + the tail once (dynenv_obs_pack_peers / unpack_peers_ranks)."""
+    import ctypes as C
+    import torch
+    from dynenv_amd import _capi
+    lib = _capi.load()
+    ET, G, S, K = 29, 3, 9, 7
+    carsEnd = S + (A - 1) * K
+    D = carsEnd + tail
+    P = A * S + tail
+    g = torch.Generator(device="cuda").manual_seed(A)
+    selfb = torch.randn((G, ET, A, S), device="cuda", generator=g)
+    tl = torch.randn((G, ET, tail), device="cuda", generator=g)
+    x = torch.empty((G, ET, A, D), device="cuda")
+    cols = [0, 1, 2, 3, 4, 5, 8]
+    for a in range(A):
+        x[:, :, a, :S] = selfb[:, :, a]
+        others = [c for c in range(A) if c != a]
+        for q, c in enumerate(others):
+            x[:, :, a, S + q * K:S + (q + 1) * K] = selfb[:, :, c][..., cols]
+        x[:, :, a, carsEnd:] = tl
+    stride = P * ET + 64  # the gathered blocks of consecutive ranks are further apart than their obs regions
+    packed = torch.zeros((G, stride), device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for r in range(G):
+        _capi.check(lib.dynenv_obs_pack_peers(C.c_void_p(x[r].data_ptr()), ET, A, D, C.c_void_p(packed[r].data_ptr()), st), "pack")
+    want = torch.cat([selfb.reshape(G, ET, A * S), tl], dim=2).reshape(G, ET * P)
+    assert torch.equal(packed[:, :ET * P], want)
+    y = torch.full_like(x, float("nan"))
+    _capi.check(lib.dynenv_obs_unpack_peers_ranks(C.c_void_p(packed.data_ptr()), stride, G, ET, A, D, C.c_void_p(y.data_ptr()), st), "unpack")
+    assert torch.equal(x, y)
