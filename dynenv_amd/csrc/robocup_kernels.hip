@@ -779,38 +779,48 @@ struct RcJoint {
 struct RcFeet {
   double vx0, vy0, w0, vx1, vy1, w1;
 };
-// ord 0 / 1: first / second constraint in the space's constraint order
-DE_DEV void joint_warm_start(const RcJoint& J, RcFeet& f, double jx, double jy, double jr, int ord) {
-  const bool doPivot = (ord == 0) == J.pivotFirst;
-  if (doPivot) {
-    if (J.hasPivot) {
-      const V2 j = vmul(v2(jx, jy), 1.0);
-      f.vx0 = f.vx0 + (-j.x) * J.m; f.vy0 = f.vy0 + (-j.y) * J.m; f.w0 += J.i * vcross(v2(0.0, 0.0), vneg(j));
-      f.vx1 = f.vx1 + j.x * J.m; f.vy1 = f.vy1 + j.y * J.m; f.w1 += J.i * vcross(v2(0.0, 0.0), j);
-    }
-  } else {
-    const double j = jr * 1.0;
-    f.w0 -= j * J.i;
-    f.w1 += j * J.i;
+// ord 0 / 1: first / second constraint in the space's constraint order.
+// CLEAN: the caller has checked that none of the six foot velocities is -0 and that both angular velocities are finite.
+// The pivot's anchors are the body origins (r1 = r2 = 0), so cpPivotJoint's "v + perp(r) * w" adds (+-0, +-0) to each
+// velocity and its angular impulse "i_inv * cross(r, j)" adds +-0 to each w.  x + (+-0) is x bit for bit unless x is -0,
+// and a sum or difference is -0 only if both operands are zeros, so "no -0" survives every update in here: the 18 fp64
+// operations that only produce those zeros are dropped (the caller verifies afterwards that no impulse became inf/NaN,
+// the one case in which 0 * j would not have been a zero, and otherwise redoes the solve with CLEAN = false).
+template <bool CLEAN>
+DE_DEV void pivot_warm_start(const RcJoint& J, RcFeet& f, double jx, double jy) {
+  if (J.hasPivot) {
+    const V2 j = vmul(v2(jx, jy), 1.0);
+    f.vx0 = f.vx0 + (-j.x) * J.m; f.vy0 = f.vy0 + (-j.y) * J.m;
+    if (!CLEAN) f.w0 += J.i * vcross(v2(0.0, 0.0), vneg(j));
+    f.vx1 = f.vx1 + j.x * J.m; f.vy1 = f.vy1 + j.y * J.m;
+    if (!CLEAN) f.w1 += J.i * vcross(v2(0.0, 0.0), j);
   }
 }
-DE_DEV void joint_iterate(const RcJoint& J, RcFeet& f, double& jx, double& jy, double& jr, int ord) {
-  const bool doPivot = (ord == 0) == J.pivotFirst;
-  if (doPivot) {
-    if (J.hasPivot) {
-      // relative_velocity with r1 = r2 = 0
-      const V2 v1s = vadd(v2(f.vx0, f.vy0), vmul(vperp(v2(0.0, 0.0)), f.w0));
-      const V2 v2s = vadd(v2(f.vx1, f.vy1), vmul(vperp(v2(0.0, 0.0)), f.w1));
-      const V2 vr = vsub(v2s, v1s);
-      const V2 d = vsub(v2(J.pbx, J.pby), vr);
-      V2 j = v2(d.x * J.kk0 + d.y * J.kk1, d.x * J.kk2 + d.y * J.kk3);
-      const V2 jOld = v2(jx, jy);
-      jx = jx + j.x; jy = jy + j.y;
-      j = vsub(v2(jx, jy), jOld);
-      f.vx0 = f.vx0 + (-j.x) * J.m; f.vy0 = f.vy0 + (-j.y) * J.m; f.w0 += J.i * vcross(v2(0.0, 0.0), vneg(j));
-      f.vx1 = f.vx1 + j.x * J.m; f.vy1 = f.vy1 + j.y * J.m; f.w1 += J.i * vcross(v2(0.0, 0.0), j);
-    }
-  } else if (J.rbias != 0.0) {
+DE_DEV void rotary_warm_start(const RcJoint& J, RcFeet& f, double jr) {
+  const double j = jr * 1.0;
+  f.w0 -= j * J.i;
+  f.w1 += j * J.i;
+}
+template <bool CLEAN>
+DE_DEV void pivot_iterate(const RcJoint& J, RcFeet& f, double& jx, double& jy) {
+  if (J.hasPivot) {
+    // relative_velocity with r1 = r2 = 0
+    const V2 v1s = CLEAN ? v2(f.vx0, f.vy0) : vadd(v2(f.vx0, f.vy0), vmul(vperp(v2(0.0, 0.0)), f.w0));
+    const V2 v2s = CLEAN ? v2(f.vx1, f.vy1) : vadd(v2(f.vx1, f.vy1), vmul(vperp(v2(0.0, 0.0)), f.w1));
+    const V2 vr = vsub(v2s, v1s);
+    const V2 d = vsub(v2(J.pbx, J.pby), vr);
+    V2 j = v2(d.x * J.kk0 + d.y * J.kk1, d.x * J.kk2 + d.y * J.kk3);
+    const V2 jOld = v2(jx, jy);
+    jx = jx + j.x; jy = jy + j.y;
+    j = vsub(v2(jx, jy), jOld);
+    f.vx0 = f.vx0 + (-j.x) * J.m; f.vy0 = f.vy0 + (-j.y) * J.m;
+    if (!CLEAN) f.w0 += J.i * vcross(v2(0.0, 0.0), vneg(j));
+    f.vx1 = f.vx1 + j.x * J.m; f.vy1 = f.vy1 + j.y * J.m;
+    if (!CLEAN) f.w1 += J.i * vcross(v2(0.0, 0.0), j);
+  }
+}
+DE_DEV void rotary_iterate(const RcJoint& J, RcFeet& f, double& jr) {
+  if (J.rbias != 0.0) {
     const double wr = f.w1 - f.w0;
     double j = -(J.rbias + wr) * J.iSum;
     const double jOld = jr;
@@ -819,6 +829,13 @@ DE_DEV void joint_iterate(const RcJoint& J, RcFeet& f, double& jx, double& jy, d
     f.w0 -= j * J.i;
     f.w1 += j * J.i;
   }
+}
+// general path: the ord-th constraint of this robot in the space's constraint order
+DE_DEV void joint_warm_start(const RcJoint& J, RcFeet& f, double jx, double jy, double jr, int ord) {
+  if ((ord == 0) == J.pivotFirst) pivot_warm_start<false>(J, f, jx, jy); else rotary_warm_start(J, f, jr);
+}
+DE_DEV void joint_iterate(const RcJoint& J, RcFeet& f, double& jx, double& jy, double& jr, int ord) {
+  if ((ord == 0) == J.pivotFirst) pivot_iterate<false>(J, f, jx, jy); else rotary_iterate(J, f, jr);
 }
 
 DE_DEV void joint_prestep(const RcLds& L, int lane, RcJoint& J, double& jx, double& jy, double& jr) {
@@ -850,6 +867,29 @@ DE_DEV void joint_prestep(const RcLds& L, int lane, RcJoint& J, double& jx, doub
 // of every other lane: prestep, warm start and all 10 iterations run on registers (same arithmetic as the general path
 // in rc_physics, no LDS round trips, no barriers).  Out of line so that it gets its own small register allocation
 // instead of sharing rc_physics' (whose arbiter state pushed the joint constants to scratch inside the iteration loop).
+// Warm start + 10 iterations of one robot's two constraints, in registers.  A robot runs (pivot, rotary) or (rotary, pivot)
+// per iteration depending on where its pivot sits in the constraint list (it moves to the end when a kick re-adds it).
+// Lanes of both kinds share one instruction stream: the rotary-first lanes take their first rotary pass up front, then
+// every lane alternates pivot, rotary - each lane still sees exactly its own sequence (R P R P ... R P resp. P R ... P R),
+// and each block is issued once per iteration instead of once per order.
+template <bool CLEAN>
+DE_DEV void joints_solve(const RcJoint& J, RcFeet& f, double& jx, double& jy, double& jr) {
+  const bool pf = J.pivotFirst;
+  if (!pf) rotary_warm_start(J, f, jr);
+  pivot_warm_start<CLEAN>(J, f, jx, jy);
+  if (pf) rotary_warm_start(J, f, jr);
+  if (!pf) rotary_iterate(J, f, jr);
+#pragma unroll 1
+  for (int iter = 0; iter < 10; ++iter) {
+    pivot_iterate<CLEAN>(J, f, jx, jy);
+    if (pf || iter < 9) rotary_iterate(J, f, jr);
+  }
+}
+#ifdef DRV_PROFILE
+__device__ unsigned long long g_rcclean[8];
+#endif
+DE_DEV bool is_negzero(double x) { return __double_as_longlong(x) == (long long)0x8000000000000000ull; }
+DE_DEV bool is_finite(double x) { return __builtin_fabs(x) < INFINITY; }
 __device__ __noinline__ void rc_joints_only(int lane, int R) {
   RcLds& L = g_R;
   if (lane < R) {
@@ -859,9 +899,24 @@ __device__ __noinline__ void rc_joints_only(int lane, int R) {
     joint_prestep(L, lane, J, jx, jy, jr);
     RcFeet f;
     f.vx0 = L.vx[la]; f.vy0 = L.vy[la]; f.w0 = L.w[la]; f.vx1 = L.vx[lb]; f.vy1 = L.vy[lb]; f.w1 = L.w[lb];
-    joint_warm_start(J, f, jx, jy, jr, 0); joint_warm_start(J, f, jx, jy, jr, 1);
-#pragma unroll 1
-    for (int iter = 0; iter < 10; ++iter) { joint_iterate(J, f, jx, jy, jr, 0); joint_iterate(J, f, jx, jy, jr, 1); }
+    // fast path (see joint_iterate): no -0 among the velocities, finite w, finite accumulated impulses
+    bool clean = !(is_negzero(f.vx0) || is_negzero(f.vy0) || is_negzero(f.w0) || is_negzero(f.vx1) || is_negzero(f.vy1) ||
+                   is_negzero(f.w1)) && is_finite(f.w0) && is_finite(f.w1) && is_finite(jx) && is_finite(jy);
+#ifdef DRV_PROFILE
+    atomicAdd(&g_rcclean[clean ? 0 : 1], 1ull);
+    if (!clean) { int why = (is_negzero(f.vx0) || is_negzero(f.vy0) || is_negzero(f.vx1) || is_negzero(f.vy1)) ? 2 : (is_negzero(f.w0) || is_negzero(f.w1)) ? 3 : (!is_finite(jx) || !is_finite(jy)) ? 4 : 5; atomicAdd(&g_rcclean[why], 1ull); }
+#endif
+    if (clean) {
+      joints_solve<true>(J, f, jx, jy, jr);
+      // every pivot impulse that was applied is a difference of finite jx / jy values iff these stayed finite
+      clean = is_finite(jx) && is_finite(jy) && is_finite(f.vx0) && is_finite(f.vy0) && is_finite(f.vx1) && is_finite(f.vy1) &&
+              is_finite(f.w0) && is_finite(f.w1);
+      if (!clean) {  // never seen; redo from the unchanged LDS state with the reference's full arithmetic
+        joint_prestep(L, lane, J, jx, jy, jr);
+        f.vx0 = L.vx[la]; f.vy0 = L.vy[la]; f.w0 = L.w[la]; f.vx1 = L.vx[lb]; f.vy1 = L.vy[lb]; f.w1 = L.w[lb];
+      }
+    }
+    if (!clean) joints_solve<false>(J, f, jx, jy, jr);
     L.vx[la] = f.vx0; L.vy[la] = f.vy0; L.w[la] = f.w0; L.vx[lb] = f.vx1; L.vy[lb] = f.vy1; L.w[lb] = f.w1;
     L.jx[lane] = jx; L.jy[lane] = jy; L.jrot[lane] = jr;
   }
