@@ -432,13 +432,17 @@ DE_DEV void rc_ball_logic(const RcCtx& c, RcLds& L, int lane) {
     }
   }
   if (!finished) {
-    const double d = (x - L.envd[RD_BPREVX]) / 20.0;
+    const double dx = x - L.envd[RD_BPREVX];
+    const double d = dx == 0.0 ? dx : dx / 20.0;  // +-0 / 20 is that same zero: a resting ball skips the division
     cr0 += d;
     cr1 -= d;
   }
-  // per-robot terms (one robot per lane); a robot is either in lastKicked (discounted share) or not (penalty share)
+  // per-robot terms (one robot per lane); a robot is either in lastKicked (discounted share) or not (penalty share).
+  // With both team terms zero every per-robot term is +-0, and adding +-0 cannot change rrew / rposrew: they start each
+  // step as +0 and are only ever updated by += / -=, which never yields -0 from a non-(-0) accumulator.
   bool inLk = false;
-  if (lane < c.R) {
+  const bool anyTeamTerm = !(cr0 == 0.0 && cr1 == 0.0);
+  if (anyTeamTerm && lane < c.R) {
     double disc = 1.0;
     for (int i = 0; i < nlk; ++i) {
       if (L.envi[RE_LK0 + i] == lane) {
@@ -1451,6 +1455,7 @@ rc_step_kernel(RcState S, const int* __restrict__ actions, float* __restrict__ o
   c.canFall = (S.flags & 4) != 0; c.allowHead = (S.flags & 16) != 0;
   int err = 0;
   uint64_t pairLo = 0ull, pairHi = 0ull;
+  int feetPairs = 0;  // bit t: my pair of round t is the two feet of one robot
 #pragma unroll
   for (int t = 0; t < RC_NPAIR_ROUNDS; ++t) {
     int pr = RC.pairs[t * 64 + lane];
@@ -1460,6 +1465,7 @@ rc_step_kernel(RcState S, const int* __restrict__ actions, float* __restrict__ o
     if (ok && j < RC_BALL) ok = j < 2 * R;
     uint64_t v = (uint64_t)(ok ? pr : 0xFFFF);
     if (t < 4) pairLo |= v << (16 * t); else pairHi |= v << (16 * (t - 4));
+    if (ok && j < RC_BALL && j == i + 1 && !(i & 1)) feetPairs |= 1 << t;
   }
   __syncthreads();
   c.episode = (uint32_t)L.envi[RE_EPISODE];
@@ -1509,11 +1515,14 @@ RC_PROF(const unsigned long long A1 = __builtin_amdgcn_s_memtime();)
     __syncthreads();
 RC_PROF(const unsigned long long A2 = __builtin_amdgcn_s_memtime();)
     // ---- broadphase ---------------------------------------------------------------------------------------
-    int cand = 0;
+    // The two feet of one robot overlap in every substep: they are candidates without a test (a candidate whose boxes
+    // do not overlap is harmless - shapes that touch have overlapping boxes, so the narrowphase finds nothing), which
+    // keeps the double-precision box test below for the rare real prefilter hits.
+    int cand = feetPairs;
 #pragma unroll 1
     for (int t = 0; t < RC_NPAIR_ROUNDS; ++t) {
       const int pr = RC_MY_PAIR(t);
-      if (pr != 0xFFFF) {
+      if (pr != 0xFFFF && !((feetPairs >> t) & 1)) {
         const int i = pr >> 8, j = pr & 0xFF;
         float bx, by, bhx, bhy;
         if (j <= RC_BALL) { bx = L.u.pf.cx[j]; by = L.u.pf.cy[j]; bhx = L.u.pf.hx[j]; bhy = L.u.pf.hy[j]; }
