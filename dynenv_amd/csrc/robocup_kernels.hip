@@ -850,12 +850,17 @@ DE_DEV void rotary_iterate(const RcJoint& J, RcFeet& f, double& jr) {
     f.w1 += j * J.i;
   }
 }
-// general path: the ord-th constraint of this robot in the space's constraint order
-DE_DEV void joint_warm_start(const RcJoint& J, RcFeet& f, double jx, double jy, double jr, int ord) {
-  if ((ord == 0) == J.pivotFirst) pivot_warm_start<false>(J, f, jx, jy); else rotary_warm_start(J, f, jr);
+// general path: both constraints of this robot in the space's constraint order.  The pivot block is issued once for all
+// lanes, between the rotary block of the rotary-first robots and that of the pivot-first ones.
+DE_DEV void joints_warm_start_ordered(const RcJoint& J, RcFeet& f, double jx, double jy, double jr) {
+  if (!J.pivotFirst) rotary_warm_start(J, f, jr);
+  pivot_warm_start<false>(J, f, jx, jy);
+  if (J.pivotFirst) rotary_warm_start(J, f, jr);
 }
-DE_DEV void joint_iterate(const RcJoint& J, RcFeet& f, double& jx, double& jy, double& jr, int ord) {
-  if ((ord == 0) == J.pivotFirst) pivot_iterate<false>(J, f, jx, jy); else rotary_iterate(J, f, jr);
+DE_DEV void joints_iterate_ordered(const RcJoint& J, RcFeet& f, double& jx, double& jy, double& jr) {
+  if (!J.pivotFirst) rotary_iterate(J, f, jr);
+  pivot_iterate<false>(J, f, jx, jy);
+  if (J.pivotFirst) rotary_iterate(J, f, jr);
 }
 
 DE_DEV void joint_prestep(const RcLds& L, int lane, RcJoint& J, double& jx, double& jy, double& jr) {
@@ -1159,6 +1164,28 @@ RC_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
 RC_PROF(const unsigned long long T1 = __builtin_amdgcn_s_memtime();)
   // --- joints: prestep (cpPivotJoint / cpRotaryLimitJoint preStep), one robot per lane ------------------------
   const bool jointsOnly = activeMask == 0ull;  // then rc_joints_only() below does prestep + solve out of line
+#ifdef DRV_PROFILE
+  if (!jointsOnly) {  // how many general substeps consist of single-contact arbiters that touch pairwise different robots?
+    const int ra = bodyA < RC_BALL ? (bodyA >> 1) : -1, rb = bodyB < RC_BALL ? (bodyB >> 1) : -2;
+    bool clash = false;
+    for (uint64_t mm = activeMask; mm; mm &= mm - 1) {
+      const int o = __builtin_ctzll(mm);
+      const int oa = bcast_i(ra, o), ob = bcast_i(rb, o);
+      if (active && o != lane && (oa == ra || ob == ra || oa == rb || ob == rb)) clash = true;
+      // the ball shared by two arbiters couples them as well
+      const int oA = bcast_i(bodyA, o), oB = bcast_i(bodyB, o);
+      if (active && o != lane && (oA == RC_BALL || oB == RC_BALL) && (bodyA == RC_BALL || bodyB == RC_BALL)) clash = true;
+    }
+    const bool two = active && a_count > 1;
+    const bool anyClash = wave_ballot(clash) != 0ull, anyTwo = wave_ballot(two) != 0ull;
+    if (lane == 0) {
+      atomicAdd(&g_rcclean[6], 1ull);
+      if (!anyClash && !anyTwo) atomicAdd(&g_rcclean[7], 1ull);
+      if (!anyClash && anyTwo) atomicAdd(&g_rcclean[5], 1ull);
+      if (__popcll(activeMask) == 1) atomicAdd(&g_rcclean[4], 1ull);
+    }
+  }
+#endif
   // General path: robot r's joints live on lane 32 + r.  Those lanes are never slot lanes (RC_NS <= 32), so the joint's
   // state OVERLAYS the registers that hold arbiter state on the slot lanes (jn/jt <-> accumulated joint impulses,
   // nMass/tMass <-> pivot K^-1, bias <-> pivot bias, bounce <-> iSum / rotary bias).  Holding both sets at once pushed
@@ -1214,8 +1241,7 @@ RC_PROF(T4 = __builtin_amdgcn_s_memtime();)
       RC_JOINT_VIEW(J)
       RcFeet f;
       f.vx0 = L.vx[la]; f.vy0 = L.vy[la]; f.w0 = L.w[la]; f.vx1 = L.vx[lb]; f.vy1 = L.vy[lb]; f.w1 = L.w[lb];
-      joint_warm_start(J, f, jn[0], jn[1], jt[0], 0);
-      joint_warm_start(J, f, jn[0], jn[1], jt[0], 1);
+      joints_warm_start_ordered(J, f, jn[0], jn[1], jt[0]);
       L.vx[la] = f.vx0; L.vy[la] = f.vy0; L.w[la] = f.w0; L.vx[lb] = f.vx1; L.vy[lb] = f.vy1; L.w[lb] = f.w1;
     }
     __syncthreads();
@@ -1264,8 +1290,7 @@ RC_PROF(T4 = __builtin_amdgcn_s_memtime();)
         RC_JOINT_VIEW(J)
         RcFeet f;
         f.vx0 = L.vx[la]; f.vy0 = L.vy[la]; f.w0 = L.w[la]; f.vx1 = L.vx[lb]; f.vy1 = L.vy[lb]; f.w1 = L.w[lb];
-        joint_iterate(J, f, jn[0], jn[1], jt[0], 0);
-        joint_iterate(J, f, jn[0], jn[1], jt[0], 1);
+        joints_iterate_ordered(J, f, jn[0], jn[1], jt[0]);
         L.vx[la] = f.vx0; L.vy[la] = f.vy0; L.w[la] = f.w0; L.vx[lb] = f.vx1; L.vy[lb] = f.vy1; L.w[lb] = f.w1;
       }
       __syncthreads();
