@@ -544,7 +544,6 @@ int dynenv_debug_counters(dynenv_t* h, int64_t* out4) {
     for (int k = 0; k < 12; ++k) out4[k] = 0;
 #ifdef DRV_PROFILE
     HIP_OK(hipDeviceSynchronize());
-    { unsigned long long c[8]; HIP_OK(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_rcclean), sizeof(c))); fprintf(stderr, "joints-only solves: clean %llu, full %llu; general substeps %llu: isolated single-contact arbiters %llu, isolated with a 2-contact arbiter %llu, exactly one active arbiter %llu\n", c[0], c[1], c[6], c[7], c[5], c[4]); }
     { static unsigned long long d[4096 * 12]; HIP_OK(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_rcprof), sizeof(d))); FILE* f = fopen("gpurun_out/rcprof.txt", "w"); for (int k = 0; k < 4096; ++k) { for (int q = 0; q < 12; ++q) fprintf(f, "%llu ", d[12*k+q]); fprintf(f, "\n"); } fclose(f); }
 #endif
     return DYNENV_OK;

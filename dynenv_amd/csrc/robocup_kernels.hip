@@ -676,6 +676,17 @@ DE_DEV void closest_seg_seg(V2 p1, V2 q1, V2 p2, V2 q2, V2& c1, V2& c2) {
   c1 = vadd(p1, vmul(d1, s));
   c2 = vadd(p2, vmul(d2, t));
 }
+DE_DEV bool capsules_far_apart(const SegW& s1, const SegW& s2) {
+  const double M = FOOT_RADIUS + FOOT_RADIUS + 1e-3;
+  const double da = vdot(vsub(s2.ta, s1.ta), s1.tn), db = vdot(vsub(s2.tb, s1.ta), s1.tn);
+  return (da > M && db > M) || (da < -M && db < -M);
+}
+DE_DEV bool feet_far_apart(const RcLds& L, int r) {
+  SegW s1, s2;
+  seg_world(L, 2 * r, s1);
+  seg_world(L, 2 * r + 1, s2);
+  return capsules_far_apart(s1, s2);
+}
 DE_DEV void rc_narrowphase(const RcLds& L, int i, int j, RcContacts& out) {  // pair i < j in canonical slot order
   out.count = 0;
   if (j < RC_BALL) {  // capsule - capsule
@@ -686,11 +697,7 @@ DE_DEV void rc_narrowphase(const RcLds& L, int i, int j, RcContacts& out) {  // 
     // two radii plus a margin far above any rounding of the exact test below, the closest points are further apart than
     // that as well and the pair cannot touch.  This is what the two feet of one robot (a candidate pair in every substep:
     // parallel capsules 20 apart) look like; it spares them the closest-point computation with its four divisions.
-    {
-      const double M = FOOT_RADIUS + FOOT_RADIUS + 1e-3;
-      const double da = vdot(vsub(s2.ta, s1.ta), s1.tn), db = vdot(vsub(s2.tb, s1.ta), s1.tn);
-      if ((da > M && db > M) || (da < -M && db < -M)) return;
-    }
+    if (capsules_far_apart(s1, s2)) return;
     V2 a, b;
     closest_seg_seg(s1.ta, s1.tb, s2.ta, s2.tb, a, b);
     const V2 delta = vsub(b, a);
@@ -910,9 +917,6 @@ DE_DEV void joints_solve(const RcJoint& J, RcFeet& f, double& jx, double& jy, do
     if (pf || iter < 9) rotary_iterate(J, f, jr);
   }
 }
-#ifdef DRV_PROFILE
-__device__ unsigned long long g_rcclean[8];
-#endif
 __device__ __noinline__ void rc_joints_only(int lane, int R) {
   RcLds& L = g_R;
   if (lane < R) {
@@ -924,10 +928,6 @@ __device__ __noinline__ void rc_joints_only(int lane, int R) {
     f.vx0 = L.vx[la]; f.vy0 = L.vy[la]; f.w0 = L.w[la]; f.vx1 = L.vx[lb]; f.vy1 = L.vy[lb]; f.w1 = L.w[lb];
     // fast path (see joint_iterate): no -0 among the velocities, finite w, finite accumulated impulses
     bool clean = feet_clean(f) && is_finite(jx) && is_finite(jy);
-#ifdef DRV_PROFILE
-    atomicAdd(&g_rcclean[clean ? 0 : 1], 1ull);
-    if (!clean) { int why = (is_negzero(f.vx0) || is_negzero(f.vy0) || is_negzero(f.vx1) || is_negzero(f.vy1)) ? 2 : (is_negzero(f.w0) || is_negzero(f.w1)) ? 3 : (!is_finite(jx) || !is_finite(jy)) ? 4 : 5; atomicAdd(&g_rcclean[why], 1ull); }
-#endif
     if (clean) {
       joints_solve<true>(J, f, jx, jy, jr);
       // every pivot impulse that was applied is a difference of finite jx / jy values iff these stayed finite
@@ -1164,28 +1164,6 @@ RC_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
 RC_PROF(const unsigned long long T1 = __builtin_amdgcn_s_memtime();)
   // --- joints: prestep (cpPivotJoint / cpRotaryLimitJoint preStep), one robot per lane ------------------------
   const bool jointsOnly = activeMask == 0ull;  // then rc_joints_only() below does prestep + solve out of line
-#ifdef DRV_PROFILE
-  if (!jointsOnly) {  // how many general substeps consist of single-contact arbiters that touch pairwise different robots?
-    const int ra = bodyA < RC_BALL ? (bodyA >> 1) : -1, rb = bodyB < RC_BALL ? (bodyB >> 1) : -2;
-    bool clash = false;
-    for (uint64_t mm = activeMask; mm; mm &= mm - 1) {
-      const int o = __builtin_ctzll(mm);
-      const int oa = bcast_i(ra, o), ob = bcast_i(rb, o);
-      if (active && o != lane && (oa == ra || ob == ra || oa == rb || ob == rb)) clash = true;
-      // the ball shared by two arbiters couples them as well
-      const int oA = bcast_i(bodyA, o), oB = bcast_i(bodyB, o);
-      if (active && o != lane && (oA == RC_BALL || oB == RC_BALL) && (bodyA == RC_BALL || bodyB == RC_BALL)) clash = true;
-    }
-    const bool two = active && a_count > 1;
-    const bool anyClash = wave_ballot(clash) != 0ull, anyTwo = wave_ballot(two) != 0ull;
-    if (lane == 0) {
-      atomicAdd(&g_rcclean[6], 1ull);
-      if (!anyClash && !anyTwo) atomicAdd(&g_rcclean[7], 1ull);
-      if (!anyClash && anyTwo) atomicAdd(&g_rcclean[5], 1ull);
-      if (__popcll(activeMask) == 1) atomicAdd(&g_rcclean[4], 1ull);
-    }
-  }
-#endif
   // General path: robot r's joints live on lane 32 + r.  Those lanes are never slot lanes (RC_NS <= 32), so the joint's
   // state OVERLAYS the registers that hold arbiter state on the slot lanes (jn/jt <-> accumulated joint impulses,
   // nMass/tMass <-> pivot K^-1, bias <-> pivot bias, bounce <-> iSum / rotary bias).  Holding both sets at once pushed
@@ -1565,8 +1543,24 @@ RC_PROF(const unsigned long long A2 = __builtin_amdgcn_s_memtime();)
     __syncthreads();
 RC_PROF(const unsigned long long A3 = __builtin_amdgcn_s_memtime(); tG += A1 - A0; tP += A2 - A1; tB += A3 - A2;)
     // ---- contacts, joints, velocity update, solver, post-solve callbacks (out of line) -----------------------
-    const RcStepRet sr = rc_physics(c, lane, cand, pairLo, pairHi, occ);
-    occ = uniform_u64(sr.occ); err |= sr.err;
+    // The common substep never enters rc_physics (whose register footprint costs ~150 scratch accesses per lane and
+    // call in callee-saved registers): no cached arbiter, the only candidates are the robots' own feet pairs, and the
+    // narrowphase's separating-axis early out rejects every one of them.  What rc_physics does then is exactly this:
+    // velocity update, then every robot's joints (prestep, warm start, 10 iterations) in registers.
+    bool quiet = occ == 0ull && wave_ballot((cand & ~feetPairs) != 0) == 0ull;
+    if (quiet) {
+      const bool far = lane < R ? feet_far_apart(L, lane) : true;
+      quiet = wave_ballot(!far) == 0ull;
+    }
+    if (quiet) {
+      if (isBody) rc_velocity_update(L, lane);
+      __syncthreads();
+      rc_joints_only(lane, R);
+      __syncthreads();
+    } else {
+      const RcStepRet sr = rc_physics(c, lane, cand, pairLo, pairHi, occ);
+      occ = uniform_u64(sr.occ); err |= sr.err;
+    }
     if (lane == 0) L.envi[RE_ELAPSED] += 1;
     __syncthreads();
     if (it % 10 == 9) {
