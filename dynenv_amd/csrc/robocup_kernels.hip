@@ -15,7 +15,7 @@ __constant__ RcConst RC;
 #define RC_PHYS_INLINE __noinline__
 #endif
 #ifndef RC_LOGIC_INLINE
-#define RC_LOGIC_INLINE __noinline__
+#define RC_LOGIC_INLINE __forceinline__
 #endif
 #ifndef RC_WAVES_PER_SIMD
 #define RC_WAVES_PER_SIMD 4
@@ -518,6 +518,18 @@ DE_DEV bool rc_tick_has_event(const RcLds& L, int r) {
 }
 
 // the per-substep game logic: for robot in agents: [processAction]; tick; then the ball.  Called by the whole wave.
+// The sequential form (first substep, or a cross-robot event) is out of line; the common lane-parallel form is inlined
+// into the step kernel's loop so that it costs no call (callee-saved registers travel through scratch on every call).
+__device__ __noinline__ void rc_game_serial(RcCtx c, int it, const int* __restrict__ actions) {
+  RcLds& L = g_R;
+  for (int r = 0; r < c.R; ++r) {
+    if (it == 0) {
+      int act[4] = {actions[4 * r], actions[4 * r + 1], actions[4 * r + 2], actions[4 * r + 3]};
+      rc_process_action(c, L, r, act);
+    }
+    rc_tick(c, L, r);
+  }
+}
 __device__ RC_LOGIC_INLINE void rc_game_logic(RcCtx c, int it, const int* __restrict__ actions, int lane) {
   RcLds& L = g_R;
   bool serial = it == 0;  // processAction draws the fall dice and may knock other robots over: keep the reference order
@@ -525,13 +537,7 @@ __device__ RC_LOGIC_INLINE void rc_game_logic(RcCtx c, int it, const int* __rest
   if (!serial) {
     if (lane < c.R) rc_tick(c, L, lane);
   } else if (lane == 0) {
-    for (int r = 0; r < c.R; ++r) {
-      if (it == 0) {
-        int act[4] = {actions[4 * r], actions[4 * r + 1], actions[4 * r + 2], actions[4 * r + 3]};
-        rc_process_action(c, L, r, act);
-      }
-      rc_tick(c, L, r);
-    }
+    rc_game_serial(c, it, actions);
   }
   __syncthreads();
   rc_ball_logic(c, L, lane);
