@@ -1079,6 +1079,9 @@ DRV_PROF(if (lane < 8 && e < 4096) g_dbgp[e * 8 + lane] = 0ull;)
   const int nObst = uniform_i(envi[EI_NOBST]);
   const uint32_t episode = (uint32_t)uniform_i(envi[EI_EPISODE]);
   uint64_t occ = (uint64_t)(uint32_t)uniform_i(envi[EI_OCC]);
+  // Environments with live contacts are the long ones and the launch ends with the slowest: their waves get issue priority
+  // over the (three) lighter waves they share a SIMD with, from the first instruction on.
+  if (occ != 0ull) __builtin_amdgcn_s_setprio(3);
   int err = 0;
   const uint32_t genv = (uint32_t)(S.env_id_offset + e);
 
@@ -1321,6 +1324,7 @@ DRV_PROF(const unsigned long long A2 = __builtin_amdgcn_s_memtime(); bool tookCo
     } else if (!replay) {
       // ---------- contact path (out of line): narrowphase -> contact cache -> callbacks -> prestep -> friction -> solver
 DRV_PROF(tookContact = true;)
+      __builtin_amdgcn_s_setprio(3);  // an environment on the contact path is on the launch's critical path: issue it first
       ContactRet cr = drv_contact_path(lane, cand, dirty, light ? 1 : 0, A, occ, rew, isCar, isPed);
       err |= cr.err & 1;
       if (uniform_i(cr.err >> 3) & 1) {  // light mode: no dirty pair touches => replay

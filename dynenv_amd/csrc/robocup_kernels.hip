@@ -1458,6 +1458,9 @@ rc_step_kernel(RcState S, const int* __restrict__ actions, float* __restrict__ o
   RcLds& L = g_R;
   const int e = blockIdx.x, lane = threadIdx.x, R = S.R;
   uint64_t occ = (uint64_t)(uint32_t)uniform_i(S.envi[(size_t)e * RE_COUNT + RE_OCC]);
+  // Environments with live contacts are the long ones and the launch ends with the slowest: their waves get issue priority
+  // over the (three) lighter waves they share a SIMD with, from the first instruction on.
+  if (occ != 0ull) __builtin_amdgcn_s_setprio(3);
   rc_load_env(S, L, e, lane, occ);
   RcCtx c;
   c.seed = S.seed; c.genv = (uint32_t)(S.env_id_offset + e); c.n = S.n; c.R = R;
@@ -1564,6 +1567,7 @@ RC_PROF(const unsigned long long A3 = __builtin_amdgcn_s_memtime(); tG += A1 - A
       rc_joints_only(lane, R);
       __syncthreads();
     } else {
+      __builtin_amdgcn_s_setprio(3);  // an environment with contact work is on the launch's critical path: issue it first
       const RcStepRet sr = rc_physics(c, lane, cand, pairLo, pairHi, occ);
       occ = uniform_u64(sr.occ); err |= sr.err;
     }
