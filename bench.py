@@ -256,7 +256,7 @@ def main():
         if b_alg is not None:
             achieved = b_alg * E / (launch_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "rc_step_kernel (with rc_partial_vision)" if (robocup and partial) else "rc_step_kernel" if robocup else "drv_step_kernel + drv_partial_obs_kernel" if partial else "drv_step_kernel",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "rc_step_kernel + rc_partial_obs_kernel" if (robocup and partial) else "rc_step_kernel" if robocup else "drv_step_partial_kernel (step + fused getAgentVision)" if partial else "drv_step_kernel",
                         "launch_ms": launch_ms, "alg_bytes_per_env_step": b_alg, "env_steps_per_launch": E}
 
     if rank == 0:

@@ -63,6 +63,14 @@ struct DrvConst {
   double turnCos[2], turnSin[2]; /* cos/sin(-/+ 2*pi/180) */
 };
 
+// per-lane inputs of the Partial observation of one environment (lane = body slot / obstacle / car index)
+struct PvIn {
+  double px, py, ang; /* body slot `lane` (< 32), 0 for unused slots */
+  double ox, oy;      /* obstacle `lane` (< nObst) */
+  double gx, gy;      /* goal of car `lane` (< A) */
+  int flags;          /* flag word of body slot `lane` */
+};
+
 struct DrvState {
   int E, A, obs_dim, pad0;
   uint64_t seed;

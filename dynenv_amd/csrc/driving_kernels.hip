@@ -1063,9 +1063,11 @@ DRV_PROF(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* d = g_dbgp + 
 // ------------------------------------------------------------------------------------------------
 // THE step kernel: grid = E blocks of one wavefront
 // ------------------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(64, DRV_WAVES_PER_SIMD)
-drv_step_kernel(DrvState S, const int* __restrict__ actions, float* __restrict__ obs, double* __restrict__ rewards,
-                uint8_t* __restrict__ dones) {
+__device__ __noinline__ void drv_partial_obs_fused(const DrvState& S, int e, int lane, int nPed, int nObst, int elapsed, uint32_t episode,
+                                                   PvIn in, int noiseType, double magn, float* __restrict__ obs);  // driving_partial.hip
+template <bool PARTIAL>
+DE_DEV void drv_step_body(const DrvState& S, const int* __restrict__ actions, float* __restrict__ obs, double* __restrict__ rewards,
+                          uint8_t* __restrict__ dones, float* __restrict__ pobs, int pvNoise, double pvMagn) {
 DRV_PROF(const unsigned long long KS = __builtin_amdgcn_s_memtime();)
   DrvLds& L = g_L;
   const int e = blockIdx.x;
@@ -1378,7 +1380,29 @@ DRV_PROF(const unsigned long long K1 = __builtin_amdgcn_s_memtime();)
   S.lastcand[(size_t)e * 64 + lane] = lastCand;
   store_env(S, L, e, lane, A, nPed, occ);
   if (obs) write_full_obs(L, lane, A, nPed, nObst, S.obs_dim, obs + (size_t)e * A * S.obs_dim);
+  if (PARTIAL && pobs) {  // Partial observation of this environment, fused (see drv_partial_obs_fused)
+    PvIn in;
+    in.px = in.py = in.ang = in.ox = in.oy = in.gx = in.gy = 0.0; in.flags = 0;
+    if (lane < DRV_NB && (lane < A || (lane >= DRV_SLOT_PED && lane < DRV_SLOT_PED + nPed))) {
+      in.px = L.px[lane]; in.py = L.py[lane]; in.ang = L.ang[lane]; in.flags = L.flags[lane];
+    }
+    if (lane < nObst) { in.ox = L.ox[lane]; in.oy = L.oy[lane]; }
+    if (lane < A) { in.gx = L.goalx[lane]; in.gy = L.goaly[lane]; }
+    drv_partial_obs_fused(S, e, lane, nPed, nObst, elapsed, episode, in, pvNoise, pvMagn, pobs);
+  }
 DRV_PROF(if (lane == 0 && e < 4096) { unsigned long long* d = g_dbgw + e * 12; const unsigned long long KE = __builtin_amdgcn_s_memtime(); d[0] = KE - KS; d[1] = nContact; d[2] = __popcll(occ); d[3] = nSteady + nQuiet; d[4] = K0 - KS; d[5] = tPh1; d[6] = tBroad; d[7] = tFast; d[8] = tCont; d[9] = (K1 - K0) - tPh1 - tBroad - tFast - tCont; d[10] = KE - K1; d[11] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned long long)__builtin_amdgcn_s_getreg(63492); })
+}
+
+extern "C" __global__ void __launch_bounds__(64, DRV_WAVES_PER_SIMD)
+drv_step_kernel(DrvState S, const int* __restrict__ actions, float* __restrict__ obs, double* __restrict__ rewards,
+                uint8_t* __restrict__ dones) {
+  drv_step_body<false>(S, actions, obs, rewards, dones, nullptr, 0, 0.0);
+}
+// Partial observation: same step, then each wave writes its environment's observation (fused getAgentVision)
+extern "C" __global__ void __launch_bounds__(64, DRV_WAVES_PER_SIMD)
+drv_step_partial_kernel(DrvState S, const int* __restrict__ actions, double* __restrict__ rewards, uint8_t* __restrict__ dones,
+                        float* __restrict__ pobs, int pvNoise, double pvMagn) {
+  drv_step_body<true>(S, actions, nullptr, rewards, dones, pobs, pvNoise, pvMagn);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -69,26 +69,15 @@ DE_DEV int pv_interact(int seen1, V2 point1, double angle1, const PvBlocker& b, 
   return ret;
 }
 
-extern "C" __global__ void __launch_bounds__(64, 4)  // 128 VGPRs: all 4096 environments resident in one pass
-drv_partial_obs_kernel(DrvState S, int noiseType, double magn, float* __restrict__ obs) {
-  PvLds& L = g_P;
-  const int e = blockIdx.x, lane = threadIdx.x, A = S.A;
-  const size_t E = (size_t)S.E;
+// The observation of every agent of environment e.  `in` carries the per-lane state (from HBM in the stand-alone kernel,
+// straight from the step kernel's LDS tile in the fused call); L is this wave's scratch tile.
+DE_DEV void pv_env(const DrvState& S, PvLds& L, const int e, const int lane, const int nPed, const int nObst, const int elapsed,
+                   const uint32_t episode, const PvIn& in, const int noiseType, const double magn, float* __restrict__ obs) {
+  const int A = S.A;
   int* envi = S.envi + (size_t)e * EI_COUNT;
-  const int nPed = uniform_i(envi[EI_NPED]), nObst = uniform_i(envi[EI_NOBST]), elapsed = uniform_i(envi[EI_ELAPSED]);
-  const uint32_t episode = (uint32_t)uniform_i(envi[EI_EPISODE]);
   const uint32_t genv = (uint32_t)(S.env_id_offset + e);
-  if (lane < DRV_NB) {
-    const bool used = lane < A || (lane >= DRV_SLOT_PED && lane < DRV_SLOT_PED + nPed);
-    const double* b = S.body + (size_t)e * DRV_NB + lane;
-    L.px[lane] = used ? b[BF_PX * E * DRV_NB] : 0.0; L.py[lane] = used ? b[BF_PY * E * DRV_NB] : 0.0;
-    L.ang[lane] = used ? b[BF_ANG * E * DRV_NB] : 0.0;
-    L.flags[lane] = used ? S.flags[(size_t)e * DRV_NB + lane] : 0;
-  }
-  if (lane < DRV_MAXO) {
-    L.ox[lane] = lane < nObst ? S.obst[(size_t)e * DRV_MAXO + lane] : 0.0;
-    L.oy[lane] = lane < nObst ? S.obst[E * DRV_MAXO + (size_t)e * DRV_MAXO + lane] : 0.0;
-  }
+  if (lane < DRV_NB) { L.px[lane] = in.px; L.py[lane] = in.py; L.ang[lane] = in.ang; L.flags[lane] = in.flags; }
+  if (lane < DRV_MAXO) { L.ox[lane] = in.ox; L.oy[lane] = in.oy; }
   __syncthreads();
   const double randBase = 0.01 * magn;
   const double maxVis0 = (DRV_W * 0.4) * (DRV_W * 0.4), maxVis1 = (DRV_W * 0.6) * (DRV_W * 0.6);
@@ -444,7 +433,7 @@ drv_partial_obs_kernel(DrvState S, int noiseType, double magn, float* __restrict
       row[0] = (float)pv_normalize(pos.x, (5.0 * 2.0 / DRV_W), 5.0); row[1] = (float)pv_normalize(pos.y, (5.0 * 2.0 / DRV_H), 5.0);
       row[2] = (float)dc; row[3] = (float)ds;
       row[4] = (float)pv_normalize(C.carHy[typeA], 1.0 / 7.5, 0.5); row[5] = (float)pv_normalize(C.carHx[typeA], 1.0 / 15.0, 0.5);
-      const double gx = S.carx[CF_GOALX * E * 16 + (size_t)e * 16 + a], gy = S.carx[CF_GOALY * E * 16 + (size_t)e * 16 + a];
+      const double gx = in.gx, gy = in.gy;  // isSelf: lane == a
       row[6] = (float)pv_normalize(gx, (5.0 * 2.0 / DRV_W), 5.0); row[7] = (float)pv_normalize(gy, (5.0 * 2.0 / DRV_H), 5.0);
       row[8] = (float)CF_FIN(L.flags[a]);
       row[PV_DIM - 4] = (float)(nOutCars < PV_CAP_CARS ? nOutCars : PV_CAP_CARS);
@@ -458,4 +447,41 @@ drv_partial_obs_kernel(DrvState S, int noiseType, double magn, float* __restrict
     __syncthreads();
   }
   if (wave_ballot(overflow != 0) && lane == 0) envi[EI_ERR] = envi[EI_ERR] | 2;
+}
+
+DE_DEV PvIn pv_load_inputs(const DrvState& S, int e, int lane, int nPed, int nObst) {
+  const size_t E = (size_t)S.E;
+  const int A = S.A;
+  PvIn in;
+  in.px = in.py = in.ang = in.ox = in.oy = in.gx = in.gy = 0.0; in.flags = 0;
+  if (lane < DRV_NB) {
+    const bool used = lane < A || (lane >= DRV_SLOT_PED && lane < DRV_SLOT_PED + nPed);
+    const double* b = S.body + (size_t)e * DRV_NB + lane;
+    if (used) { in.px = b[BF_PX * E * DRV_NB]; in.py = b[BF_PY * E * DRV_NB]; in.ang = b[BF_ANG * E * DRV_NB]; in.flags = S.flags[(size_t)e * DRV_NB + lane]; }
+  }
+  if (lane < nObst) { in.ox = S.obst[(size_t)e * DRV_MAXO + lane]; in.oy = S.obst[E * DRV_MAXO + (size_t)e * DRV_MAXO + lane]; }
+  if (lane < A) { in.gx = S.carx[CF_GOALX * E * 16 + (size_t)e * 16 + lane]; in.gy = S.carx[CF_GOALY * E * 16 + (size_t)e * 16 + lane]; }
+  return in;
+}
+
+// stand-alone launch (after reset / set_state, where no step kernel ran)
+extern "C" __global__ void __launch_bounds__(64, 4)  // 128 VGPRs: all 4096 environments resident in one pass
+drv_partial_obs_kernel(DrvState S, int noiseType, double magn, float* __restrict__ obs) {
+  const int e = blockIdx.x, lane = threadIdx.x;
+  const int* envi = S.envi + (size_t)e * EI_COUNT;
+  const int nPed = uniform_i(envi[EI_NPED]), nObst = uniform_i(envi[EI_NOBST]), elapsed = uniform_i(envi[EI_ELAPSED]);
+  const uint32_t episode = (uint32_t)uniform_i(envi[EI_EPISODE]);
+  const PvIn in = pv_load_inputs(S, e, lane, nPed, nObst);
+  pv_env(S, g_P, e, lane, nPed, nObst, elapsed, episode, in, noiseType, magn, obs);
+}
+
+// Fused call at the end of drv_step_kernel: the wave that has just finished environment e's step produces its Partial
+// observation right away, from the state still in its LDS tile, while the waves of heavier environments are still
+// stepping - the observation work of the light environments fills the launch's tail instead of a second launch.  The
+// scratch tile aliases the step kernel's (no longer needed) LDS tile.
+static_assert(sizeof(PvLds) <= sizeof(DrvLds), "the Partial observation tile must fit in the step kernel's LDS tile");
+__device__ __noinline__ void drv_partial_obs_fused(const DrvState& S, int e, int lane, int nPed, int nObst, int elapsed, uint32_t episode,
+                                                   PvIn in, int noiseType, double magn, float* __restrict__ obs) {
+  __syncthreads();  // every lane has taken what it needs out of the step tile
+  pv_env(S, *reinterpret_cast<PvLds*>(&g_L), e, lane, nPed, nObst, elapsed, episode, in, noiseType, magn, obs);
 }
