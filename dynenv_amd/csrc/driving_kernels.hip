@@ -1064,7 +1064,13 @@ DRV_PROF(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* d = g_dbgp + 
 // THE step kernel: grid = E blocks of one wavefront
 // ------------------------------------------------------------------------------------------------
 __device__ __noinline__ void drv_partial_obs_fused(const DrvState& S, int e, int lane, int nPed, int nObst, int elapsed, uint32_t episode,
-                                                   PvIn in, int noiseType, double magn, float* __restrict__ obs);  // driving_partial.hip
+                                                   PvIn in, int noiseType, double magn, float* __restrict__ obs, int nAgents);  // driving_partial.hip
+#ifndef DRV_DEFER_MIN_CONTACT
+#define DRV_DEFER_MIN_CONTACT 5 /* contact-path substeps (of 10) from which an environment defers its Partial observation */
+#endif
+#ifndef DRV_FUSED_AGENTS
+#define DRV_FUSED_AGENTS 7 /* agent passes a light environment runs in the step launch */
+#endif
 template <bool PARTIAL>
 DE_DEV void drv_step_body(const DrvState& S, const int* __restrict__ actions, float* __restrict__ obs, double* __restrict__ rewards,
                           uint8_t* __restrict__ dones, float* __restrict__ pobs, int pvNoise, double pvMagn) {
@@ -1380,7 +1386,12 @@ DRV_PROF(const unsigned long long K1 = __builtin_amdgcn_s_memtime();)
   S.lastcand[(size_t)e * 64 + lane] = lastCand;
   store_env(S, L, e, lane, A, nPed, occ);
   if (obs) write_full_obs(L, lane, A, nPed, nObst, S.obs_dim, obs + (size_t)e * A * S.obs_dim);
-  if (PARTIAL && pobs) {  // Partial observation of this environment, fused (see drv_partial_obs_fused)
+  // Partial observation of this environment, fused (see drv_partial_obs_fused): the first `fusedAgents` agent passes run
+  // here, the rest is left to the deferred launch.  An environment that spent the step on the contact path is among the
+  // last to finish and defers everything; a light one keeps as many passes as fit before the heavy ones are done.
+  const int fusedAgents = !(PARTIAL && pobs) ? 0 : nContact >= DRV_DEFER_MIN_CONTACT ? 0 : (A < DRV_FUSED_AGENTS ? A : DRV_FUSED_AGENTS);
+  if (PARTIAL && lane == 0) envi[EI_DEFER_OBS] = fusedAgents;  // first agent the deferred launch has to do
+  if (PARTIAL && fusedAgents > 0) {
     PvIn in;
     in.px = in.py = in.ang = in.ox = in.oy = in.gx = in.gy = 0.0; in.flags = 0;
     if (lane < DRV_NB && (lane < A || (lane >= DRV_SLOT_PED && lane < DRV_SLOT_PED + nPed))) {
@@ -1388,7 +1399,7 @@ DRV_PROF(const unsigned long long K1 = __builtin_amdgcn_s_memtime();)
     }
     if (lane < nObst) { in.ox = L.ox[lane]; in.oy = L.oy[lane]; }
     if (lane < A) { in.gx = L.goalx[lane]; in.gy = L.goaly[lane]; }
-    drv_partial_obs_fused(S, e, lane, nPed, nObst, elapsed, episode, in, pvNoise, pvMagn, pobs);
+    drv_partial_obs_fused(S, e, lane, nPed, nObst, elapsed, episode, in, pvNoise, pvMagn, pobs, fusedAgents);
   }
 DRV_PROF(if (lane == 0 && e < 4096) { unsigned long long* d = g_dbgw + e * 12; const unsigned long long KE = __builtin_amdgcn_s_memtime(); d[0] = KE - KS; d[1] = nContact; d[2] = __popcll(occ); d[3] = nSteady + nQuiet; d[4] = K0 - KS; d[5] = tPh1; d[6] = tBroad; d[7] = tFast; d[8] = tCont; d[9] = (K1 - K0) - tPh1 - tBroad - tFast - tCont; d[10] = KE - K1; d[11] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned long long)__builtin_amdgcn_s_getreg(63492); })
 }

@@ -72,7 +72,8 @@ DE_DEV int pv_interact(int seen1, V2 point1, double angle1, const PvBlocker& b, 
 // The observation of every agent of environment e.  `in` carries the per-lane state (from HBM in the stand-alone kernel,
 // straight from the step kernel's LDS tile in the fused call); L is this wave's scratch tile.
 DE_DEV void pv_env(const DrvState& S, PvLds& L, const int e, const int lane, const int nPed, const int nObst, const int elapsed,
-                   const uint32_t episode, const PvIn& in, const int noiseType, const double magn, float* __restrict__ obs) {
+                   const uint32_t episode, const PvIn& in, const int noiseType, const double magn, float* __restrict__ obs,
+                   const int aBegin, const int aEnd) {
   const int A = S.A;
   int* envi = S.envi + (size_t)e * EI_COUNT;
   const uint32_t genv = (uint32_t)(S.env_id_offset + e);
@@ -92,7 +93,7 @@ DE_DEV void pv_env(const DrvState& S, PvLds& L, const int e, const int lane, con
   (void)carLanes;
 
 #pragma unroll 1
-  for (int a = 0; a < A; ++a) {
+  for (int a = aBegin; a < aEnd; ++a) {
     float* __restrict__ grow = obs + ((size_t)e * A + a) * PV_DIM;
     float* row = L.row;
     for (int i = lane; i < PV_DIM; i += DE_WAVE) row[i] = 0.0f;
@@ -472,7 +473,7 @@ drv_partial_obs_kernel(DrvState S, int noiseType, double magn, float* __restrict
   const int nPed = uniform_i(envi[EI_NPED]), nObst = uniform_i(envi[EI_NOBST]), elapsed = uniform_i(envi[EI_ELAPSED]);
   const uint32_t episode = (uint32_t)uniform_i(envi[EI_EPISODE]);
   const PvIn in = pv_load_inputs(S, e, lane, nPed, nObst);
-  pv_env(S, g_P, e, lane, nPed, nObst, elapsed, episode, in, noiseType, magn, obs);
+  pv_env(S, g_P, e, lane, nPed, nObst, elapsed, episode, in, noiseType, magn, obs, 0, S.A);
 }
 
 // Fused call at the end of drv_step_kernel: the wave that has just finished environment e's step produces its Partial
@@ -481,7 +482,22 @@ drv_partial_obs_kernel(DrvState S, int noiseType, double magn, float* __restrict
 // scratch tile aliases the step kernel's (no longer needed) LDS tile.
 static_assert(sizeof(PvLds) <= sizeof(DrvLds), "the Partial observation tile must fit in the step kernel's LDS tile");
 __device__ __noinline__ void drv_partial_obs_fused(const DrvState& S, int e, int lane, int nPed, int nObst, int elapsed, uint32_t episode,
-                                                   PvIn in, int noiseType, double magn, float* __restrict__ obs) {
+                                                   PvIn in, int noiseType, double magn, float* __restrict__ obs, int nAgents) {
   __syncthreads();  // every lane has taken what it needs out of the step tile
-  pv_env(S, *reinterpret_cast<PvLds*>(&g_L), e, lane, nPed, nObst, elapsed, episode, in, noiseType, magn, obs);
+  pv_env(S, *reinterpret_cast<PvLds*>(&g_L), e, lane, nPed, nObst, elapsed, episode, in, noiseType, magn, obs, 0, nAgents);
+}
+
+// The agent passes the step launch left over (EI_DEFER_OBS = first agent not done there): all of them for the environments
+// that spent the step on the contact path and finish last - ten passes run by their one wave would sit on the launch's
+// critical path, a lone wave being latency bound at ~50 k cycles per pass - and the last few of the light ones.  One
+// wave per (environment, agent) spreads them over the whole chip.
+extern "C" __global__ void __launch_bounds__(64, 4)
+drv_partial_obs_deferred_kernel(DrvState S, int noiseType, double magn, float* __restrict__ obs) {
+  const int e = blockIdx.x, a = blockIdx.y, lane = threadIdx.x;
+  const int* envi = S.envi + (size_t)e * EI_COUNT;
+  if (a < uniform_i(envi[EI_DEFER_OBS])) return;  // done in the step launch
+  const int nPed = uniform_i(envi[EI_NPED]), nObst = uniform_i(envi[EI_NOBST]), elapsed = uniform_i(envi[EI_ELAPSED]);
+  const uint32_t episode = (uint32_t)uniform_i(envi[EI_EPISODE]);
+  const PvIn in = pv_load_inputs(S, e, lane, nPed, nObst);
+  pv_env(S, g_P, e, lane, nPed, nObst, elapsed, episode, in, noiseType, magn, obs, a, a + 1);
 }

@@ -478,8 +478,12 @@ int dynenv_step(dynenv_t* h, const int32_t* actions_dev, float* obs_dev, double*
   // Partial: getAgentVision for every agent (DrivingEnvironment.py:294) is fused into the step kernel - each wave writes its
   // environment's observation as soon as its step is done, which fills the launch's tail
   if (h->partial && obs_dev)
+  {
     hipLaunchKernelGGL(drv_step_partial_kernel, dim3(h->S.E), dim3(64), 0, st, h->S, (const int*)actions_dev, rewards_dev, dones_dev, obs_dev,
                        (int)h->cfg.noise_type, (double)h->cfg.noise_magnitude);
+    hipLaunchKernelGGL(drv_partial_obs_deferred_kernel, dim3(h->S.E, h->S.A), dim3(64), 0, st, h->S, (int)h->cfg.noise_type,
+                       (double)h->cfg.noise_magnitude, obs_dev);
+  }
   else
     hipLaunchKernelGGL(drv_step_kernel, dim3(h->S.E), dim3(64), 0, st, h->S, (const int*)actions_dev, h->partial ? (float*)nullptr : obs_dev,
                        rewards_dev, dones_dev);
