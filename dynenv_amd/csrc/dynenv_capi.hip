@@ -469,9 +469,12 @@ int dynenv_step(dynenv_t* h, const int32_t* actions_dev, float* obs_dev, double*
   if (!h || !actions_dev || !rewards_dev || !dones_dev) return fail(DYNENV_ERR_ARG, "null argument");
   hipStream_t st = (hipStream_t)stream;
   if (h->robocup) {
-    hipLaunchKernelGGL(rc_step_kernel, dim3(h->R.E), dim3(64), 0, st, h->R, (const int*)actions_dev, obs_dev, rewards_dev, dones_dev);
-    if (h->R.obs_type == DYNENV_OBS_PARTIAL)  // getAgentVision at the five snapshots + processSeens, second launch on the same stream
-      hipLaunchKernelGGL(rc_partial_obs_kernel, dim3(h->R.E), dim3(64), 0, st, h->R, obs_dev, rewards_dev);
+    if (h->R.obs_type == DYNENV_OBS_PARTIAL && obs_dev)  // getAgentVision at the five snapshots + processSeens fused into the launch
+      hipLaunchKernelGGL(rc_step_partial_kernel, dim3(h->R.E), dim3(64), 0, st, h->R, (const int*)actions_dev, obs_dev, rewards_dev, dones_dev);
+    else if (h->R.obs_type == DYNENV_OBS_PARTIAL)
+      return fail(DYNENV_ERR_ARG, "RoboCup Partial: the observation buffer is required (the processSeens rewards come out of the same pass)");
+    else
+      hipLaunchKernelGGL(rc_step_kernel, dim3(h->R.E), dim3(64), 0, st, h->R, (const int*)actions_dev, obs_dev, rewards_dev, dones_dev);
     HIP_OK(hipGetLastError());
     return DYNENV_OK;
   }

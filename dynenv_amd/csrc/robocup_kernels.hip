@@ -1452,9 +1452,9 @@ DE_DEV void rc_write_obs(RcLds& L, int lane, int R, int obs_dim, float* __restri
 // ------------------------------------------------------------------------------------------------
 #include "robocup_partial.hip"
 
-extern "C" __global__ void __launch_bounds__(64, RC_WAVES_PER_SIMD)
-rc_step_kernel(RcState S, const int* __restrict__ actions, float* __restrict__ obs, double* __restrict__ rewards,
-               uint8_t* __restrict__ dones) {
+template <bool PARTIAL>
+DE_DEV void rc_step_body(const RcState& S, const int* __restrict__ actions, float* __restrict__ obs, double* __restrict__ rewards,
+                         uint8_t* __restrict__ dones) {
   RcLds& L = g_R;
   const int e = blockIdx.x, lane = threadIdx.x, R = S.R;
   uint64_t occ = (uint64_t)(uint32_t)uniform_i(S.envi[(size_t)e * RE_COUNT + RE_OCC]);
@@ -1483,7 +1483,7 @@ rc_step_kernel(RcState S, const int* __restrict__ actions, float* __restrict__ o
   c.episode = (uint32_t)L.envi[RE_EPISODE];
   if (lane == 0) refresh_pivot_first(L);
   __syncthreads();
-  const bool partial = S.obs_type == DYNENV_OBS_PARTIAL;
+  const bool partial = PARTIAL;
   const bool isBody = lane == RC_BALL || lane < 2 * R;
   const int* myActions = actions + (size_t)e * R * 4;
   int snap = 0;
@@ -1612,6 +1612,17 @@ RC_PROF(if (lane == 0 && e < 4096) { unsigned long long* d = g_rcprof + e * 12; 
   }
   __syncthreads();
   rc_store_env(S, L, e, lane, occ);
+  if (PARTIAL && obs) rc_partial_obs_fused(S, e, lane, obs, rewards);  // getAgentVision at the five snapshots + processSeens
+}
+extern "C" __global__ void __launch_bounds__(64, RC_WAVES_PER_SIMD)
+rc_step_kernel(RcState S, const int* __restrict__ actions, float* __restrict__ obs, double* __restrict__ rewards,
+               uint8_t* __restrict__ dones) {
+  rc_step_body<false>(S, actions, obs, rewards, dones);
+}
+extern "C" __global__ void __launch_bounds__(64, RC_WAVES_PER_SIMD)
+rc_step_partial_kernel(RcState S, const int* __restrict__ actions, float* __restrict__ obs, double* __restrict__ rewards,
+                       uint8_t* __restrict__ dones) {
+  rc_step_body<true>(S, actions, obs, rewards, dones);
 }
 
 extern "C" __global__ void __launch_bounds__(64) rc_obs_kernel(RcState S, float* __restrict__ obs) {

@@ -89,8 +89,7 @@ struct RvArgs {
 };
 
 // One snapshot: rows of all R agents -> out[R][RCP_DIM]; seen += the snapshot's (numLandMarks, ballsSeen, robotsSeen)
-DE_DEV int rc_partial_vision(const RvArgs& A, int lane, float* __restrict__ out, bool countSeen) {
-  RvLds& V = g_V;
+DE_DEV int rc_partial_vision(const RvArgs& A, RvLds& V, int lane, float* __restrict__ out, bool countSeen) {
   RvDetTable& T = V.T;
   int* seen = countSeen ? V.seen : nullptr;
   const int R = A.R;
@@ -404,10 +403,8 @@ DE_DEV int rc_partial_vision(const RvArgs& A, int lane, float* __restrict__ out,
 // the step kernel left rewards[e][a] = robot reward + team reward and prew0 = its positive part; this kernel adds the
 // observation reward in the reference's order of operations and only then updates the episode accumulators.
 // ------------------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(64, 4)
-rc_partial_obs_kernel(RcState S, float* __restrict__ obs, double* __restrict__ rewards) {
-  RvLds& V = g_V;
-  const int e = blockIdx.x, lane = threadIdx.x, R = S.R;
+DE_DEV void rv_env(const RcState& S, RvLds& V, const int e, const int lane, float* __restrict__ obs, double* __restrict__ rewards) {
+  const int R = S.R;
   const RvSnap* snaps = S.snap + (size_t)e * 5;
   for (int i = lane; i < 10 * RCP_SEEN_STRIDE; i += DE_WAVE) V.seen[i] = 0;
   RvArgs va;
@@ -424,7 +421,7 @@ rc_partial_obs_kernel(RcState S, float* __restrict__ obs, double* __restrict__ r
     if (lane == 0) { V.owned = sn.owned; V.close0 = sn.close0; V.close1 = sn.close1; V.tkey = sn.tkey; }
     __syncthreads();
     va.tkey = (uint32_t)uniform_i(V.tkey);
-    ov |= rc_partial_vision(va, lane, obs + ((size_t)e * 5 + t) * R * RCP_DIM, rewards != nullptr);
+    ov |= rc_partial_vision(va, V, lane, obs + ((size_t)e * 5 + t) * R * RCP_DIM, rewards != nullptr);
     __syncthreads();
   }
   if (ov && lane == 0) S.envi[(size_t)e * RE_COUNT + RE_ERR] |= 2;
@@ -450,4 +447,19 @@ rc_partial_obs_kernel(RcState S, float* __restrict__ obs, double* __restrict__ r
     *eo = *eo + obsRew;
     rewards[(size_t)e * R + lane] = rew;
   }
+}
+// stand-alone launch: after reset / set_state (rewards == nullptr)
+extern "C" __global__ void __launch_bounds__(64, 4)
+rc_partial_obs_kernel(RcState S, float* __restrict__ obs, double* __restrict__ rewards) {
+  rv_env(S, g_V, blockIdx.x, threadIdx.x, obs, rewards);
+}
+// Fused call at the end of rc_step_partial_kernel: the wave that has finished environment e's step turns its five snapshots
+// into observation rows right away, while the waves of the environments with contact work are still stepping (two thirds
+// of a RoboCup launch are such a tail).  The tile aliases the step kernel's LDS tile, which is no longer needed; the
+// snapshots, rewards and prew0 this wave wrote to HBM are read back after a device-scope fence.
+static_assert(sizeof(RvLds) <= sizeof(RcLds), "the vision tile must fit in the step kernel's LDS tile");
+__device__ __noinline__ void rc_partial_obs_fused(const RcState& S, int e, int lane, float* __restrict__ obs, double* __restrict__ rewards) {
+  __threadfence();
+  __syncthreads();
+  rv_env(S, *reinterpret_cast<RvLds*>(&g_R), e, lane, obs, rewards);
 }
