@@ -673,6 +673,42 @@ DE_DEV void arb_apply_impulse(BodyV& a, BodyV& b, V2 n, const V2* r1, const V2* 
   }
 }
 
+// The bias half of cpArbiterApplyImpulse alone (exactly the bias-only branch above), for solves in which EVERY active
+// arbiter is bias-only.  Nothing in such a solve writes v, w, jn or jt, so the condition - evaluated once, after the warm
+// start - holds for all 10 iterations and the loop needs neither the per-pass test nor the velocities themselves.
+DE_DEV void arb_apply_bias_only(BodyV& a, BodyV& b, V2 n, const V2* r1, const V2* r2, const double* nMass, const double* bias,
+                                double* jBias, int count) {
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    if (c < count) {
+      V2 vb1 = vadd(a.vb, vmul(vperp(r1[c]), a.wb));
+      V2 vb2 = vadd(b.vb, vmul(vperp(r2[c]), b.wb));
+      double vbn = vdot(vsub(vb2, vb1), n);
+      double jbn = (bias[c] - vbn) * nMass[c];
+      double jbnOld = jBias[c];
+      jBias[c] = fmax_cp(jbnOld + jbn, 0.0);
+      V2 jb = vmul(n, jBias[c] - jbnOld);
+      apply_bias_impulse(a, vneg(jb), r1[c]);
+      apply_bias_impulse(b, jb, r2[c]);
+    }
+  }
+}
+DE_DEV bool arb_is_bias_only(const BodyV& a, const BodyV& b, const double* jn, const double* jt, const double* bounce, int count) {
+  long long z = __double_as_longlong(a.v.x) | __double_as_longlong(a.v.y) | __double_as_longlong(a.w) |
+                __double_as_longlong(b.v.x) | __double_as_longlong(b.v.y) | __double_as_longlong(b.w);
+  bool ok = true;
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+    if (c < count) { z |= __double_as_longlong(jn[c]) | __double_as_longlong(jt[c]); ok = ok && bounce[c] == 0.0; }
+  return ok && z == 0ll;
+}
+DE_DEV void body_load_bias(const DrvLds& L, int idx, BodyV& b) {
+  if (idx < DRV_SLOT_OBST) { b.vb = v2(L.vbx[idx], L.vby[idx]); b.wb = L.wb[idx]; }
+}
+DE_DEV void body_store_bias(DrvLds& L, int idx, const BodyV& b) {
+  if (idx < DRV_SLOT_OBST) { L.vbx[idx] = b.vb.x; L.vby[idx] = b.vb.y; L.wb[idx] = b.wb; }
+}
+
 DRV_PROF(__device__ unsigned long long g_dbgw[4096 * 12];)
 DRV_PROF(__device__ unsigned long long g_dbgp[4096 * 8];)
 DRV_PROF(__device__ unsigned long long g_dbgr[16];)
@@ -973,8 +1009,13 @@ DRV_PROF(unsigned long long T4 = __builtin_amdgcn_s_memtime();)
       body_load(L, bodyB, b);
       if (a_state != ARB_FIRST) arb_warm_start(a, b, n, r1, r2, jn, jt, a_count);
 DRV_PROF(T4 = __builtin_amdgcn_s_memtime();)
+      if (wave_ballot(!arb_is_bias_only(a, b, jn, jt, bounce, a_count)) == 0ull) {  // all resting contacts: bias half only
 #pragma unroll 1
-      for (int iter = 0; iter < 10; ++iter) arb_apply_impulse(a, b, n, r1, r2, nMass, tMass, bias, bounce, jBias, jn, jt, a_count, arb_u);
+        for (int iter = 0; iter < 10; ++iter) arb_apply_bias_only(a, b, n, r1, r2, nMass, bias, jBias, a_count);
+      } else {
+#pragma unroll 1
+        for (int iter = 0; iter < 10; ++iter) arb_apply_impulse(a, b, n, r1, r2, nMass, tMass, bias, bounce, jBias, jn, jt, a_count, arb_u);
+      }
       body_store_vel(L, bodyA, a);
       body_store_vel(L, bodyB, b);
     }
@@ -996,17 +1037,38 @@ DRV_PROF(T4 = __builtin_amdgcn_s_memtime();)
 DRV_PROF(T4 = __builtin_amdgcn_s_memtime();)
     // ---- 10 sequential-impulse iterations (cpArbiterApplyImpulse) ---------------------------------------
     BodyV a, b;
-    if (active) { body_load(L, bodyA, a); body_load(L, bodyB, b); }  // statics stay all-zero; p, minv, iinv are invariant
-    for (int iter = 0; iter < 10; ++iter) {
-      for (int lv = 0; lv <= maxLevel; ++lv) {
-        if (active && myLevel == lv) {
-          body_load_vel(L, bodyA, a);
-          body_load_vel(L, bodyB, b);
-          arb_apply_impulse(a, b, n, r1, r2, nMass, tMass, bias, bounce, jBias, jn, jt, a_count, arb_u);
-          body_store_vel(L, bodyA, a);
-          body_store_vel(L, bodyB, b);
+    bool biasOnly = true;
+    if (active) {  // statics stay all-zero; p, minv, iinv are invariant
+      body_load(L, bodyA, a); body_load(L, bodyB, b);
+      biasOnly = arb_is_bias_only(a, b, jn, jt, bounce, a_count);
+    }
+    if (wave_ballot(!biasOnly) == 0ull) {
+      // every active arbiter is a resting contact being pushed out of penetration (the pile-ups that make up the launch's
+      // tail): only bias velocities move, through LDS, level by level
+      for (int iter = 0; iter < 10; ++iter) {
+        for (int lv = 0; lv <= maxLevel; ++lv) {
+          if (active && myLevel == lv) {
+            body_load_bias(L, bodyA, a);
+            body_load_bias(L, bodyB, b);
+            arb_apply_bias_only(a, b, n, r1, r2, nMass, bias, jBias, a_count);
+            body_store_bias(L, bodyA, a);
+            body_store_bias(L, bodyB, b);
+          }
+          __syncthreads();
         }
-        __syncthreads();
+      }
+    } else {
+      for (int iter = 0; iter < 10; ++iter) {
+        for (int lv = 0; lv <= maxLevel; ++lv) {
+          if (active && myLevel == lv) {
+            body_load_vel(L, bodyA, a);
+            body_load_vel(L, bodyB, b);
+            arb_apply_impulse(a, b, n, r1, r2, nMass, tMass, bias, bounce, jBias, jn, jt, a_count, arb_u);
+            body_store_vel(L, bodyA, a);
+            body_store_vel(L, bodyB, b);
+          }
+          __syncthreads();
+        }
       }
     }
   }
