@@ -469,8 +469,10 @@ int dynenv_step(dynenv_t* h, const int32_t* actions_dev, float* obs_dev, double*
   if (!h || !actions_dev || !rewards_dev || !dones_dev) return fail(DYNENV_ERR_ARG, "null argument");
   hipStream_t st = (hipStream_t)stream;
   if (h->robocup) {
-    if (h->R.obs_type == DYNENV_OBS_PARTIAL && obs_dev)  // getAgentVision at the five snapshots + processSeens fused into the launch
+    if (h->R.obs_type == DYNENV_OBS_PARTIAL && obs_dev) {  // getAgentVision at the five snapshots + processSeens fused into the launch
       hipLaunchKernelGGL(rc_step_partial_kernel, dim3(h->R.E), dim3(64), 0, st, h->R, (const int*)actions_dev, obs_dev, rewards_dev, dones_dev);
+      hipLaunchKernelGGL(rc_partial_obs_deferred_kernel, dim3(h->R.E), dim3(320), 0, st, h->R, obs_dev, rewards_dev);
+    }
     else if (h->R.obs_type == DYNENV_OBS_PARTIAL)
       return fail(DYNENV_ERR_ARG, "RoboCup Partial: the observation buffer is required (the processSeens rewards come out of the same pass)");
     else

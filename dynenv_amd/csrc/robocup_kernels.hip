@@ -1452,6 +1452,9 @@ DE_DEV void rc_write_obs(RcLds& L, int lane, int R, int obs_dim, float* __restri
 // ------------------------------------------------------------------------------------------------
 #include "robocup_partial.hip"
 
+#ifndef RC_DEFER_MIN_GENERAL
+#define RC_DEFER_MIN_GENERAL 25 /* rc_physics substeps (of 50) from which an environment defers its Partial observation */
+#endif
 template <bool PARTIAL>
 DE_DEV void rc_step_body(const RcState& S, const int* __restrict__ actions, float* __restrict__ obs, double* __restrict__ rewards,
                          uint8_t* __restrict__ dones) {
@@ -1486,7 +1489,7 @@ DE_DEV void rc_step_body(const RcState& S, const int* __restrict__ actions, floa
   const bool partial = PARTIAL;
   const bool isBody = lane == RC_BALL || lane < 2 * R;
   const int* myActions = actions + (size_t)e * R * 4;
-  int snap = 0;
+  int snap = 0, nGeneral = 0;  // substeps that went through rc_physics
 
 RC_PROF(if (lane < 12 && e < 4096) g_rcprof[e * 12 + lane] = 0ull; const unsigned long long K0 = __builtin_amdgcn_s_memtime(); unsigned long long tG = 0, tP = 0, tB = 0;)
   for (int it = 0; it < 50; ++it) {
@@ -1568,6 +1571,7 @@ RC_PROF(const unsigned long long A3 = __builtin_amdgcn_s_memtime(); tG += A1 - A
       __syncthreads();
     } else {
       __builtin_amdgcn_s_setprio(3);  // an environment with contact work is on the launch's critical path: issue it first
+      ++nGeneral;
       const RcStepRet sr = rc_physics(c, lane, cand, pairLo, pairHi, occ);
       occ = uniform_u64(sr.occ); err |= sr.err;
     }
@@ -1605,14 +1609,18 @@ RC_PROF(if (lane == 0 && e < 4096) { unsigned long long* d = g_rcprof + e * 12; 
     rewards[(size_t)e * R + lane] = rew;
   }
   __syncthreads();
+  // Partial: an environment that spent much of the step in rc_physics is among the last to finish and leaves its vision
+  // to the deferred launch (five waves per environment) instead of appending 50 agent passes to the critical path
+  const bool deferObs = PARTIAL && obs && nGeneral >= RC_DEFER_MIN_GENERAL;
   if (lane == 0) {
     dones[e] = (uint8_t)(L.envi[RE_ELAPSED] >= RC_MAX_TIME);
     L.envi[RE_OCC] = (int)(uint32_t)occ;
     if (err) L.envi[RE_ERR] |= 1;
+    L.envi[RE_DEFER_OBS] = deferObs ? 1 : 0;
   }
   __syncthreads();
   rc_store_env(S, L, e, lane, occ);
-  if (PARTIAL && obs) rc_partial_obs_fused(S, e, lane, obs, rewards);  // getAgentVision at the five snapshots + processSeens
+  if (PARTIAL && obs && !deferObs) rc_partial_obs_fused(S, e, lane, obs, rewards);  // getAgentVision at the five snapshots + processSeens
 }
 extern "C" __global__ void __launch_bounds__(64, RC_WAVES_PER_SIMD)
 rc_step_kernel(RcState S, const int* __restrict__ actions, float* __restrict__ obs, double* __restrict__ rewards,

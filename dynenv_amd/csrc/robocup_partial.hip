@@ -403,32 +403,35 @@ DE_DEV int rc_partial_vision(const RvArgs& A, RvLds& V, int lane, float* __restr
 // the step kernel left rewards[e][a] = robot reward + team reward and prew0 = its positive part; this kernel adds the
 // observation reward in the reference's order of operations and only then updates the episode accumulators.
 // ------------------------------------------------------------------------------------------------
-DE_DEV void rv_env(const RcState& S, RvLds& V, const int e, const int lane, float* __restrict__ obs, double* __restrict__ rewards) {
-  const int R = S.R;
-  const RvSnap* snaps = S.snap + (size_t)e * 5;
-  for (int i = lane; i < 10 * RCP_SEEN_STRIDE; i += DE_WAVE) V.seen[i] = 0;
+DE_DEV RvArgs rv_args(const RcState& S, int e) {
   RvArgs va;
   va.seed = S.seed; va.genv = (uint32_t)(S.env_id_offset + e);
   va.episode = (uint32_t)uniform_i(S.envi[(size_t)e * RE_COUNT + RE_EPISODE]);
-  va.R = R; va.n = S.n; va.noiseType = S.noise_type; va.magn = S.noise_magn;
-  int ov = 0;
-#pragma unroll 1
-  for (int t = 0; t < 5; ++t) {
-    const RvSnap& sn = snaps[t];
-    if (lane < 21) { V.px[lane] = sn.px[lane]; V.py[lane] = sn.py[lane]; }
-    if (lane < 20) V.ang[lane] = sn.ang[lane];
-    if (lane < 10) { V.head[lane] = sn.head[lane]; V.rflags[lane] = sn.rflags[lane]; }
-    if (lane == 0) { V.owned = sn.owned; V.close0 = sn.close0; V.close1 = sn.close1; V.tkey = sn.tkey; }
-    __syncthreads();
-    va.tkey = (uint32_t)uniform_i(V.tkey);
-    ov |= rc_partial_vision(va, V, lane, obs + ((size_t)e * 5 + t) * R * RCP_DIM, rewards != nullptr);
-    __syncthreads();
-  }
-  if (ov && lane == 0) S.envi[(size_t)e * RE_COUNT + RE_ERR] |= 2;
-  if (rewards && lane < R) {
+  va.R = S.R; va.n = S.n; va.noiseType = S.noise_type; va.magn = S.noise_magn;
+  va.tkey = 0;
+  return va;
+}
+// snapshot t of environment e -> its R observation rows (+ the snapshot's seen counts into V.seen)
+DE_DEV int rv_snapshot(const RcState& S, RvLds& V, RvArgs va, int e, int lane, int t, float* __restrict__ obs, bool countSeen) {
+  const RvSnap& sn = S.snap[(size_t)e * 5 + t];
+  if (lane < 21) { V.px[lane] = sn.px[lane]; V.py[lane] = sn.py[lane]; }
+  if (lane < 20) V.ang[lane] = sn.ang[lane];
+  if (lane < 10) { V.head[lane] = sn.head[lane]; V.rflags[lane] = sn.rflags[lane]; }
+  if (lane == 0) { V.owned = sn.owned; V.close0 = sn.close0; V.close1 = sn.close1; V.tkey = sn.tkey; }
+  __syncthreads();
+  va.tkey = (uint32_t)uniform_i(V.tkey);
+  const int ov = rc_partial_vision(va, V, lane, obs + ((size_t)e * 5 + t) * S.R * RCP_DIM, countSeen);
+  __syncthreads();
+  return ov;
+}
+// processSeens (oracle/robocup.c rc_process_seens) on the seen counts of the five snapshots, then the episode sums in
+// the reference's order of operations
+DE_DEV void rv_finalize(const RcState& S, const int* seen, int e, int lane, double* __restrict__ rewards) {
+  const int R = S.R;
+  if (lane < R) {
     double obsRew = 0.0;
-    if (S.flags & 8) {  // useObsRewards; processSeens, see oracle/robocup.c rc_process_seens
-      const int* sn = V.seen + lane * RCP_SEEN_STRIDE;
+    if (S.flags & 8) {  // useObsRewards
+      const int* sn = seen + lane * RCP_SEEN_STRIDE;
       double lSeens = (double)sn[0] / 5.0, rSeens = 0.0, bSeens = (double)sn[1];
       lSeens = lSeens < 0.0 ? 0.0 : (lSeens > 3.0 ? 3.0 : lSeens);
       for (int k = 0; k < R - 1; ++k) { const double r = (double)sn[2 + k]; rSeens += r < 0.0 ? 0.0 : (r > 2.0 ? 2.0 : r); }
@@ -448,6 +451,15 @@ DE_DEV void rv_env(const RcState& S, RvLds& V, const int e, const int lane, floa
     rewards[(size_t)e * R + lane] = rew;
   }
 }
+DE_DEV void rv_env(const RcState& S, RvLds& V, const int e, const int lane, float* __restrict__ obs, double* __restrict__ rewards) {
+  for (int i = lane; i < 10 * RCP_SEEN_STRIDE; i += DE_WAVE) V.seen[i] = 0;
+  const RvArgs va = rv_args(S, e);
+  int ov = 0;
+#pragma unroll 1
+  for (int t = 0; t < 5; ++t) ov |= rv_snapshot(S, V, va, e, lane, t, obs, rewards != nullptr);
+  if (ov && lane == 0) S.envi[(size_t)e * RE_COUNT + RE_ERR] |= 2;
+  if (rewards) rv_finalize(S, V.seen, e, lane, rewards);
+}
 // stand-alone launch: after reset / set_state (rewards == nullptr)
 extern "C" __global__ void __launch_bounds__(64, 4)
 rc_partial_obs_kernel(RcState S, float* __restrict__ obs, double* __restrict__ rewards) {
@@ -462,4 +474,27 @@ __device__ __noinline__ void rc_partial_obs_fused(const RcState& S, int e, int l
   __threadfence();
   __syncthreads();
   rv_env(S, *reinterpret_cast<RvLds*>(&g_R), e, lane, obs, rewards);
+}
+
+// The environments that held a contact through the step finish last; their 50 agent passes run by one lone, latency-bound
+// wave would sit on the launch's critical path.  They set RE_DEFER_OBS instead and this launch gives each of them five
+// waves, one per snapshot (own tile each; the barriers inside the vision code sit at wave-uniform positions, so the five
+// waves simply pass them together); the seen counts are integer sums, so adding the five tiles' counts reproduces the
+// sequential accumulation exactly, and wave 0 finishes with processSeens.
+__shared__ RvLds g_V5[5];
+extern "C" __global__ void __launch_bounds__(320)
+rc_partial_obs_deferred_kernel(RcState S, float* __restrict__ obs, double* __restrict__ rewards) {
+  const int e = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (uniform_i(S.envi[(size_t)e * RE_COUNT + RE_DEFER_OBS]) == 0) return;
+  RvLds& V = g_V5[w];
+  for (int i = lane; i < 10 * RCP_SEEN_STRIDE; i += DE_WAVE) V.seen[i] = 0;
+  const int ov = rv_snapshot(S, V, rv_args(S, e), e, lane, w, obs, true);
+  if (ov && lane == 0) atomicOr(&S.envi[(size_t)e * RE_COUNT + RE_ERR], 2);
+  __syncthreads();
+  if (w == 0) {
+    for (int i = lane; i < 10 * RCP_SEEN_STRIDE; i += DE_WAVE)
+      g_V5[0].seen[i] = g_V5[0].seen[i] + g_V5[1].seen[i] + g_V5[2].seen[i] + g_V5[3].seen[i] + g_V5[4].seen[i];
+  }
+  __syncthreads();
+  if (w == 0) rv_finalize(S, g_V5[0].seen, e, lane, rewards);
 }
