@@ -147,6 +147,8 @@ static int rc_create(dynenv* h) {
   rc |= dev_alloc(h, &R.epo, E * 16);
   rc |= dev_alloc(h, &R.snap, E * 5);
   rc |= dev_alloc(h, &R.prew0, E * 16);
+  rc |= dev_alloc(h, &R.seenPart, (size_t)E * 5 * 10 * RCP_SEEN_STRIDE);
+  rc |= dev_alloc(h, &R.deferList, (size_t)E + 1);
   rc |= dev_alloc(h, &R.s_pair, E * RC_NS);
   rc |= dev_alloc(h, &R.s_meta, E * RC_NS);
   rc |= dev_alloc(h, &R.s_hash, 2 * E * RC_NS);
@@ -470,8 +472,11 @@ int dynenv_step(dynenv_t* h, const int32_t* actions_dev, float* obs_dev, double*
   hipStream_t st = (hipStream_t)stream;
   if (h->robocup) {
     if (h->R.obs_type == DYNENV_OBS_PARTIAL && obs_dev) {  // getAgentVision at the five snapshots + processSeens fused into the launch
+      HIP_OK(hipMemsetAsync(h->R.deferList, 0, sizeof(int), st));
       hipLaunchKernelGGL(rc_step_partial_kernel, dim3(h->R.E), dim3(64), 0, st, h->R, (const int*)actions_dev, obs_dev, rewards_dev, dones_dev);
-      hipLaunchKernelGGL(rc_partial_obs_deferred_kernel, dim3(h->R.E), dim3(320), 0, st, h->R, obs_dev, rewards_dev);
+      const int nb = h->R.E < RC_DEFER_BLOCKS ? h->R.E : RC_DEFER_BLOCKS;  // the deferred environments are few: blocks stride over their list
+      hipLaunchKernelGGL(rc_partial_obs_deferred_kernel, dim3(nb, 5, h->R.R), dim3(64), 0, st, h->R, obs_dev);
+      hipLaunchKernelGGL(rc_partial_finalize_kernel, dim3(nb), dim3(64), 0, st, h->R, rewards_dev);
     }
     else if (h->R.obs_type == DYNENV_OBS_PARTIAL)
       return fail(DYNENV_ERR_ARG, "RoboCup Partial: the observation buffer is required (the processSeens rewards come out of the same pass)");

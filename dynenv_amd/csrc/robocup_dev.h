@@ -74,6 +74,8 @@ struct RcState {
   double* epo;   /* [E][16] episode sum of the observation rewards (processSeens) */
   struct RvSnap* snap; /* [E][5] what getAgentVision reads, exported at the step's five snapshots (Partial observation) */
   double* prew0; /* [E][16] positive part of the step's robot + team reward, before the observation reward (Partial) */
+  int* seenPart; /* [E][5][120] per-snapshot seen counts of the environments whose vision runs in the deferred launch */
+  int* deferList; /* [E + 1]: [0] = number of environments deferred in this step (zeroed before every step launch), then their ids */
   int obs_type, noise_type;
   double noise_magn;
   int* s_pair;   /* [E][NS] */

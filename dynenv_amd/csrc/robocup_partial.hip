@@ -89,7 +89,7 @@ struct RvArgs {
 };
 
 // One snapshot: rows of all R agents -> out[R][RCP_DIM]; seen += the snapshot's (numLandMarks, ballsSeen, robotsSeen)
-DE_DEV int rc_partial_vision(const RvArgs& A, RvLds& V, int lane, float* __restrict__ out, bool countSeen) {
+DE_DEV int rc_partial_vision(const RvArgs& A, RvLds& V, int lane, float* __restrict__ out, bool countSeen, int aBegin, int aEnd) {
   RvDetTable& T = V.T;
   int* seen = countSeen ? V.seen : nullptr;
   const int R = A.R;
@@ -101,7 +101,7 @@ DE_DEV int rc_partial_vision(const RvArgs& A, RvLds& V, int lane, float* __restr
   const bool isFc = lane >= 17 && lane < 33, isLine = lane >= 33 && lane < 44, isTrial = lane >= 44 && lane < 54;
   const bool isPoint = isBall || isRob || isGoal || isCross || isFc;
 #pragma unroll 1
-  for (int a = 0; a < R; ++a) {
+  for (int a = aBegin; a < aEnd; ++a) {
     float* __restrict__ row = out + (size_t)a * RCP_DIM;
     for (int i = lane; i < RCP_DIM; i += DE_WAVE) row[i] = 0.0f;
     const V2 pos = rv_pos(V, a);
@@ -412,7 +412,8 @@ DE_DEV RvArgs rv_args(const RcState& S, int e) {
   return va;
 }
 // snapshot t of environment e -> its R observation rows (+ the snapshot's seen counts into V.seen)
-DE_DEV int rv_snapshot(const RcState& S, RvLds& V, RvArgs va, int e, int lane, int t, float* __restrict__ obs, bool countSeen) {
+DE_DEV int rv_snapshot(const RcState& S, RvLds& V, RvArgs va, int e, int lane, int t, float* __restrict__ obs, bool countSeen,
+                       int aBegin, int aEnd) {
   const RvSnap& sn = S.snap[(size_t)e * 5 + t];
   if (lane < 21) { V.px[lane] = sn.px[lane]; V.py[lane] = sn.py[lane]; }
   if (lane < 20) V.ang[lane] = sn.ang[lane];
@@ -420,7 +421,7 @@ DE_DEV int rv_snapshot(const RcState& S, RvLds& V, RvArgs va, int e, int lane, i
   if (lane == 0) { V.owned = sn.owned; V.close0 = sn.close0; V.close1 = sn.close1; V.tkey = sn.tkey; }
   __syncthreads();
   va.tkey = (uint32_t)uniform_i(V.tkey);
-  const int ov = rc_partial_vision(va, V, lane, obs + ((size_t)e * 5 + t) * S.R * RCP_DIM, countSeen);
+  const int ov = rc_partial_vision(va, V, lane, obs + ((size_t)e * 5 + t) * S.R * RCP_DIM, countSeen, aBegin, aEnd);
   __syncthreads();
   return ov;
 }
@@ -456,7 +457,7 @@ DE_DEV void rv_env(const RcState& S, RvLds& V, const int e, const int lane, floa
   const RvArgs va = rv_args(S, e);
   int ov = 0;
 #pragma unroll 1
-  for (int t = 0; t < 5; ++t) ov |= rv_snapshot(S, V, va, e, lane, t, obs, rewards != nullptr);
+  for (int t = 0; t < 5; ++t) ov |= rv_snapshot(S, V, va, e, lane, t, obs, rewards != nullptr, 0, S.R);
   if (ov && lane == 0) S.envi[(size_t)e * RE_COUNT + RE_ERR] |= 2;
   if (rewards) rv_finalize(S, V.seen, e, lane, rewards);
 }
@@ -477,24 +478,42 @@ __device__ __noinline__ void rc_partial_obs_fused(const RcState& S, int e, int l
 }
 
 // The environments that held a contact through the step finish last; their 50 agent passes run by one lone, latency-bound
-// wave would sit on the launch's critical path.  They set RE_DEFER_OBS instead and this launch gives each of them five
-// waves, one per snapshot (own tile each; the barriers inside the vision code sit at wave-uniform positions, so the five
-// waves simply pass them together); the seen counts are integer sums, so adding the five tiles' counts reproduces the
-// sequential accumulation exactly, and wave 0 finishes with processSeens.
-__shared__ RvLds g_V5[5];
-extern "C" __global__ void __launch_bounds__(320)
-rc_partial_obs_deferred_kernel(RcState S, float* __restrict__ obs, double* __restrict__ rewards) {
-  const int e = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (uniform_i(S.envi[(size_t)e * RE_COUNT + RE_DEFER_OBS]) == 0) return;
-  RvLds& V = g_V5[w];
-  for (int i = lane; i < 10 * RCP_SEEN_STRIDE; i += DE_WAVE) V.seen[i] = 0;
-  const int ov = rv_snapshot(S, V, rv_args(S, e), e, lane, w, obs, true);
-  if (ov && lane == 0) atomicOr(&S.envi[(size_t)e * RE_COUNT + RE_ERR], 2);
-  __syncthreads();
-  if (w == 0) {
-    for (int i = lane; i < 10 * RCP_SEEN_STRIDE; i += DE_WAVE)
-      g_V5[0].seen[i] = g_V5[0].seen[i] + g_V5[1].seen[i] + g_V5[2].seen[i] + g_V5[3].seen[i] + g_V5[4].seen[i];
+// wave (~26 us per pass) would sit on the launch's critical path.  They append themselves to deferList instead and this
+// launch gives each of them one wave per (snapshot, agent); each leaves its agent's seen counts of its snapshot in
+// seenPart.  The counts are integer sums, so adding the parts reproduces the sequential accumulation exactly;
+// rc_partial_finalize_kernel does that and processSeens.  (The order of the list varies from run to run; nothing depends
+// on it.)
+#define RC_DEFER_BLOCKS 512
+extern "C" __global__ void __launch_bounds__(64, 4)
+rc_partial_obs_deferred_kernel(RcState S, float* __restrict__ obs) {
+  const int t = blockIdx.y, a = blockIdx.z, lane = threadIdx.x;
+  const int count = uniform_i(S.deferList[0]);
+  RvLds& V = g_V;
+  for (int k = blockIdx.x; k < count; k += gridDim.x) {
+    const int e = uniform_i(S.deferList[1 + k]);
+    for (int i = lane; i < 10 * RCP_SEEN_STRIDE; i += DE_WAVE) V.seen[i] = 0;
+    const int ov = rv_snapshot(S, V, rv_args(S, e), e, lane, t, obs, true, a, a + 1);
+    if (ov && lane == 0) atomicOr(&S.envi[(size_t)e * RE_COUNT + RE_ERR], 2);
+    int* part = S.seenPart + ((size_t)e * 5 + t) * 10 * RCP_SEEN_STRIDE + a * RCP_SEEN_STRIDE;
+    if (lane < RCP_SEEN_STRIDE) part[lane] = V.seen[a * RCP_SEEN_STRIDE + lane];
+    __syncthreads();
   }
-  __syncthreads();
-  if (w == 0) rv_finalize(S, g_V5[0].seen, e, lane, rewards);
+}
+extern "C" __global__ void __launch_bounds__(64)
+rc_partial_finalize_kernel(RcState S, double* __restrict__ rewards) {
+  const int lane = threadIdx.x;
+  const int count = uniform_i(S.deferList[0]);
+  RvLds& V = g_V;
+  for (int k = blockIdx.x; k < count; k += gridDim.x) {
+    const int e = uniform_i(S.deferList[1 + k]);
+    const int* part = S.seenPart + (size_t)e * 5 * 10 * RCP_SEEN_STRIDE;
+    for (int i = lane; i < 10 * RCP_SEEN_STRIDE; i += DE_WAVE) {
+      int s = 0;
+      for (int t = 0; t < 5; ++t) s += part[t * 10 * RCP_SEEN_STRIDE + i];
+      V.seen[i] = s;
+    }
+    __syncthreads();
+    rv_finalize(S, V.seen, e, lane, rewards);
+    __syncthreads();
+  }
 }
