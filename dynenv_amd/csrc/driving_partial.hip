@@ -30,6 +30,12 @@ struct PvBlocker {  // an object as `elem2` of doesInteractPoly: view-blocking i
   double posx, posy, angle2, minA, maxA, p1x, p1y, p2x, p2y, pmx, pmy;
   int seen, extreme;
 };
+struct PvPedSlot {  // phase 4: a visible pedestrian's inputs and running maxima, overlaid on its (unused) blocker entry
+  double posx, posy, angle1;
+  int seen, carPed, obsPed;
+};
+static_assert(sizeof(PvPedSlot) <= sizeof(PvBlocker), "pedestrian slot must fit a blocker entry");
+static_assert(10 * sizeof(PvBlocker) >= 61 * sizeof(int), "index lists must fit the entries of lanes 54..63");
 struct PvLds {
   double px[DRV_NB], py[DRV_NB], ang[DRV_NB];
   double ox[DRV_MAXO], oy[DRV_MAXO];
@@ -234,9 +240,35 @@ DE_DEV void pv_env(const DrvState& S, PvLds& L, const int e, const int lane, con
     int pedInter = INTER_NONE;
     {
       int carPed = INTER_NONE, obsPed = INTER_NONE;
-      if (alive && isPedLane) {
-        for (uint64_t mm = carMask; mm; mm &= mm - 1) { int t = pv_interact(seen, pos, angle1, L.blk[__builtin_ctzll(mm)], 400.0); carPed = t > carPed ? t : carPed; }
-        for (uint64_t mm = obsMask; mm; mm &= mm - 1) { int t = pv_interact(seen, pos, angle1, L.blk[__builtin_ctzll(mm)], 400.0); obsPed = t > obsPed ? t : obsPed; }
+      // Every visible pedestrian against every visible car and obstacle: one (pedestrian, blocker) pair per lane and
+      // round instead of one blocker per iteration with only the pedestrian lanes busy.  The pedestrians' inputs and their
+      // two running maxima live in the blocker-table entries of the pedestrian lanes (never blockers themselves), the two
+      // index lists in those of lanes 54..63; max is order independent, so the LDS atomics reproduce the loops exactly.
+      const int nP = __popcll(pedMask), nC = __popcll(carMask), nB = nC + __popcll(obsMask);
+      if (nP > 0 && nB > 0) {
+        int* lists = reinterpret_cast<int*>(&L.blk[54]);  // [0..19] pedestrian lanes, [32..60] blocker lanes
+        if (alive && isPedLane) {
+          PvPedSlot& ps = *reinterpret_cast<PvPedSlot*>(&L.blk[lane]);
+          ps.posx = pos.x; ps.posy = pos.y; ps.angle1 = angle1; ps.seen = seen; ps.carPed = INTER_NONE; ps.obsPed = INTER_NONE;
+          lists[listIdx] = lane;
+        }
+        if (alive && isCarLane) lists[32 + listIdx] = lane;
+        if (alive && isObsLane) lists[32 + nC + listIdx] = lane;
+        __syncthreads();
+        const int nPairs = nP * nB;
+        const unsigned inv = (65536u + (unsigned)nB - 1u) / (unsigned)nB;  // p / nB == (p * inv) >> 16 for p < 640, nB <= 29
+        for (int p = lane; p < nPairs; p += DE_WAVE) {
+          const int pi = (int)(((unsigned)p * inv) >> 16), bi = p - pi * nB;
+          const int bl = lists[32 + bi];
+          PvPedSlot& ps = *reinterpret_cast<PvPedSlot*>(&L.blk[lists[pi]]);
+          const int t = pv_interact(ps.seen, v2(ps.posx, ps.posy), ps.angle1, L.blk[bl], 400.0);
+          if (t > INTER_NONE) atomicMax(bl < DRV_SLOT_PED ? &ps.carPed : &ps.obsPed, t);
+        }
+        __syncthreads();
+        if (alive && isPedLane) {
+          const PvPedSlot& ps = *reinterpret_cast<const PvPedSlot*>(&L.blk[lane]);
+          carPed = ps.carPed; obsPed = ps.obsPed;
+        }
       }
       // pedInter = max(carPedInter, obsPedInter): Python LIST comparison -> first differing pedestrian decides (C12)
       const uint64_t diff = wave_ballot(alive && isPedLane && carPed != obsPed);
