@@ -31,7 +31,6 @@ enum { RI_FLAGS = 0, RI_TOUCHC, RI_FALLC, RI_COUNT };
 // env ints
 enum { RE_ELAPSED = 0, RE_OWNED, RE_GOAL0, RE_GOAL1, RE_CLOSE0, RE_CLOSE1, RE_DEF0, RE_DEF1, RE_NLK, RE_LK0, RE_LK1, RE_LK2,
        RE_LK3, RE_NCON, RE_EPISODE, RE_OCC, RE_ERR, RE_CORDER /* 20 entries */, RE_PIVFIRST = RE_CORDER + 20 /* bit r: robot r's pivot joint precedes its rotary limit in the constraint list */,
-       RE_DEFER_OBS = RE_CORDER + 21 /* Partial: 1 = this step's vision is left to rc_partial_obs_deferred_kernel */,
        RE_COUNT = RE_CORDER + 20 + 3 };
 // env doubles
 enum { RD_FREECNT = 0, RD_GRACE, RD_PT0, RD_PT1, RD_BPREVX, RD_BPREVY, RD_COUNT = 8 };

@@ -1616,7 +1616,6 @@ RC_PROF(if (lane == 0 && e < 4096) { unsigned long long* d = g_rcprof + e * 12; 
     dones[e] = (uint8_t)(L.envi[RE_ELAPSED] >= RC_MAX_TIME);
     L.envi[RE_OCC] = (int)(uint32_t)occ;
     if (err) L.envi[RE_ERR] |= 1;
-    L.envi[RE_DEFER_OBS] = deferObs ? 1 : 0;
     if (deferObs) S.deferList[1 + atomicAdd(&S.deferList[0], 1)] = e;
   }
   __syncthreads();

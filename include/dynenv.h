@@ -151,7 +151,9 @@ int dynenv_reset(dynenv_t* h, float* obs_dev, void* stream);
 /* One environment step for all E environments (10 / 50 physics substeps fused in one launch).
  *   actions_dev  int32 [E, A, action_dim]      obs_dev float32 [E, T, A, obs_dim]
  *   rewards_dev  float64 [E, A]                dones_dev uint8 [E]
- * Does NOT auto-reset: the host mirror calls dynenv_reset after a terminal step (SubprocVecEnv semantics). */
+ * Does NOT auto-reset: the host mirror calls dynenv_reset after a terminal step (SubprocVecEnv semantics).
+ * obs_dev may be NULL (no observation written) except for RoboCup with Partial observations, whose rewards contain the
+ * observation reward of processSeens (RoboCupEnvironment.py:497-524) and come out of the same pass: DYNENV_ERR_ARG then. */
 int dynenv_step(dynenv_t* h, const int32_t* actions_dev, float* obs_dev, double* rewards_dev, uint8_t* dones_dev,
                 void* stream);
 
