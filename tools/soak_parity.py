@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def run(cfg, E, seed):
+def run(cfg, E, seed, players=None):
     import numpy as np
     import torch
     import oracle_lib as ol
@@ -23,6 +23,8 @@ def run(cfg, E, seed):
         et, oet, n, hi, steps, flags = DynEnvType.ROBO_CUP, 0, 5, [5, 3, 3, 7], 240, ol.ROBOCUP_DEFAULT_FLAGS
     else:
         et, oet, n, hi, steps, flags = DynEnvType.DRIVE, 1, 10, [3, 3], 600, 0
+    if players is not None:
+        n = players
     kw, okw = (part, opart) if cfg.endswith("partial") else ({}, {})
     env = BatchedDynEnv(et, E, n, seed=seed, flags=flags, **kw)
     ora = ol.OracleEnv(env_type=oet, num_envs=E, n_players=n, seed=seed, flags=flags, threads=16, **okw)
@@ -58,11 +60,15 @@ def run(cfg, E, seed):
         tot = c["fast"] + c["quiescent"] + c["contact"] + c["steady"]
         extra = " paths: fast %.3f quiescent %.3f replay %.3f (light %.3f) full %.3f" % (
             c["fast"] / tot, c["quiescent"] / tot, (c["steady"] + c["light"]) / tot, c["light"] / tot, (c["contact"] - c["light"]) / tot)
-    print("soak OK: %s, %d envs x %d steps bit-identical to the oracle (%.0f s)%s" % (cfg, E, steps, time.time() - t0, extra), flush=True)
+    print("soak OK: %s nPlayers=%d, %d envs x %d steps bit-identical to the oracle (%.0f s)%s" % (cfg, n, E, steps, time.time() - t0, extra), flush=True)
     env.close(); ora.close()
 
 
 if __name__ == "__main__":
+    # usage: soak_parity.py [cfg[:nPlayers[:envs]] ...]
     cfgs = sys.argv[1:] or ["driving", "robocup", "driving_partial", "robocup_partial"]
     for c in cfgs:
-        run(c, 4096 if not c.endswith("partial") else 1024, 20261003)
+        parts = c.split(":")
+        players = int(parts[1]) if len(parts) > 1 else None
+        E = int(parts[2]) if len(parts) > 2 else (4096 if not parts[0].endswith("partial") else 1024)
+        run(parts[0], E, 20261003, players)
