@@ -133,3 +133,26 @@ def test_lazy_info_behaves_like_the_eager_dict():
     assert sorted(k for k in d3) == ["Full State", "Recon States"]
     with pytest.raises(KeyError):
         d3["episode_r"]
+
+
+def test_packed_slab_layouts_on_cpu():
+    """Transport formats of the multi-GPU slab: dense, shared-tail de-duplicated, peer-compacted (sizes and views only;
+    the pack / expand kernels are GPU tests)."""
+    import torch
+    from dynenv_amd.distributed import PackedSlab
+    E, T, A, D = 8, 1, 10, 232
+    dense = PackedSlab(torch, torch.device("cpu"), E, T, A, D)
+    tail = PackedSlab(torch, torch.device("cpu"), E, T, A, D, split=72)
+    peers = PackedSlab(torch, torch.device("cpu"), E, T, A, D, peers=True)
+    assert (dense.row, tail.row, peers.row) == (A * D, A * 72 + 160, A * 9 + 160)
+    assert dense.obs.shape == (E, T, A, D) and dense.obs.data_ptr() == dense.buf.data_ptr()  # the kernel writes the slab itself
+    for s in (tail, peers):
+        assert s.packed and s.obs.shape == (E, T, A, D) and s.obs.data_ptr() != s.buf.data_ptr()
+    for s in (dense, tail, peers):
+        assert s.rew_off % 256 == 0 and s.done_off % 256 == 0 and s.nbytes % 256 == 0
+        assert s.rewards.shape == (E, A) and s.rewards.dtype == torch.float64 and s.dones.shape == (E,)
+        g = torch.zeros((3 * s.nbytes,), dtype=torch.uint8)
+        if not s.packed:
+            o, r, d = s.gathered_views(g, 3)
+            assert o.shape == (3, E, T, A, D) and r.shape == (3, E, A) and d.shape == (3, E)
+    assert peers.nbytes < tail.nbytes < dense.nbytes
