@@ -679,6 +679,14 @@ void cpSpaceStep(cpSpace* s, double dt) {
   /* refresh world geometry of dynamic shapes, then collide all pairs in canonical slot order */
   for (i = 0; i < s->n_shapes; ++i)
     if (s->shapes[i]->body->type == CP_BODY_DYNAMIC) cpShapeCacheBB(s->shapes[i]);
+  if (s->test_free_flight) { /* golden tests: the generator's Space stand-in detects and solves nothing */
+    for (i = 0; i < s->n_bodies; ++i) {
+      cpBody* b = s->bodies[i];
+      if (b->velocity_func) b->velocity_func(b, s->gravity, pow(s->damping, dt), dt);
+      else cpBodyUpdateVelocity(b, s->gravity, pow(s->damping, dt), dt);
+    }
+    return;
+  }
   for (i = 0; i < s->n_shapes; ++i) {
     for (j = i + 1; j < s->n_shapes; ++j) {
       cpShape *a = s->shapes[i], *b = s->shapes[j];
@@ -738,6 +746,34 @@ void cpSpaceStep(cpSpace* s, double dt) {
     cpArbiter* arb = s->active[i];
     if (arb->handler->post_solve) arb->handler->post_solve(arb, s, arb->handler->data);
   }
+}
+
+/* ---------------------------------------------------------------- golden-test hook */
+int cpSpaceTestCallback(cpSpace* s, int slotA, int slotB, int which) {
+  cpShape *a = 0, *b = 0, *t;
+  cpArbiter arb;
+  int i;
+  for (i = 0; i < s->n_shapes; ++i) {
+    if (s->shapes[i]->slot == slotA) a = s->shapes[i];
+    if (s->shapes[i]->slot == slotB) b = s->shapes[i];
+  }
+  if (!a || !b) return -1;
+  if (a->type > b->type) { t = a; a = b; b = t; } /* cpCollide: shape types ascending */
+  memset(&arb, 0, sizeof(arb));
+  arb.a = a; arb.b = b; arb.body_a = a->body; arb.body_b = b->body;
+  for (i = 0; i < s->n_handlers; ++i) {
+    cpHandler* h = &s->handlers[i];
+    if ((h->typeA == a->collision_type && h->typeB == b->collision_type) ||
+        (h->typeA == b->collision_type && h->typeB == a->collision_type)) {
+      arb.handler = h;
+      arb.swapped = (a->collision_type != h->typeA);
+      if (which == 0) return h->begin ? h->begin(&arb, s, h->data) : 1;
+      if (which == 1 && h->post_solve) h->post_solve(&arb, s, h->data);
+      if (which == 2 && h->separate) h->separate(&arb, s, h->data);
+      return 1;
+    }
+  }
+  return 1;
 }
 
 /* ---------------------------------------------------------------- queries */

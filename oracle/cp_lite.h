@@ -130,6 +130,8 @@ typedef struct cpSpace {
   cpHandler handlers[CP_MAX_HANDLERS];
   cpHandler default_handler;
   int overflow; /* set if a fixed capacity was exceeded */
+  int test_free_flight; /* golden tests only: cpSpaceStep = position update + velocity functions, nothing collides, no
+                           constraint is solved (what the generator scripts' Space stand-in does, tests/golden/gen_golden.py) */
 } cpSpace;
 
 /* vector helpers */
@@ -169,5 +171,8 @@ double cpMomentForCircle(double m, double r1, double r2);
 double cpMomentForSegment(double m, cpv a, cpv b, double r);
 /* space.point_query(p, maxDist, filter=all): shapes whose surface distance < maxDist */
 int cpSpacePointQuery(cpSpace* s, cpv p, double maxDist, cpShape** out, int cap);
+/* golden tests only: run one handler callback of the shape pair (slots) the way cpSpaceStep would hand it over:
+ * which = 0 begin (returns its value), 1 post_solve, 2 separate; -1 if a shape is missing, 1 without a handler */
+int cpSpaceTestCallback(cpSpace* s, int slotA, int slotB, int which);
 
 #endif

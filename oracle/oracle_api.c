@@ -376,3 +376,49 @@ void oracle_rc_spots(const double* rnd18, double* out20) {
 /* test hook: one snapshot of Partial observations of every robot of env, draw keys with time word `tkey` */
 int oracle_rc_partial_obs(oracle_t* o, int env, uint32_t tkey, float* out) { return rc_write_partial_obs(&o->rc[env], tkey, out); }
 double oracle_rc_process_seens(double lSum, const double* rSum, int nOthers, double bSum) { return rc_process_seens(lSum, rSum, nOthers, bSum); }
+
+/* ---- golden-test hooks added in round 2 (tests/test_oracle_golden_callbacks.py, *_composition.py) ---- */
+int rc_test_callback(RoboCupEnv* e, int slotA, int slotB, int which);
+/* Driving begin callbacks carCrash / pedHit / carHit (DrivingEnvironment.py:591-683) on the shape pair (slots) */
+int oracle_drv_begin(oracle_t* o, int env, int slotA, int slotB, double* rew10) {
+  DrivingEnv* e = &o->drv[env];
+  int i, r;
+  for (i = 0; i < DYNENV_MAX_CARS; ++i) e->carRewards[i] = 0.0;
+  r = cpSpaceTestCallback(&e->space, slotA, slotB, 0);
+  for (i = 0; i < DYNENV_MAX_CARS; ++i) rew10[i] = e->carRewards[i];
+  return r;
+}
+/* RoboCup handler callbacks: which = 0 begin, 1 post_solve (robotCollision / goalpostCollision), 2 separate */
+int oracle_rc_callback(oracle_t* o, int env, int slotA, int slotB, int which, double* rew22) {
+  int i, r;
+  rc_test_zero_rewards(&o->rc[env]);
+  for (i = 0; i < o->rc[env].space.n_shapes; ++i) cpShapeCacheBB(o->rc[env].space.shapes[i]); /* fall() queries the cache */
+  r = rc_test_callback(&o->rc[env], slotA, slotB, which);
+  rc_test_get_rewards(&o->rc[env], rew22);
+  return r;
+}
+void oracle_rc_fall(oracle_t* o, int env, int robot, int punish, double* rew22) {
+  int i;
+  rc_test_zero_rewards(&o->rc[env]);
+  for (i = 0; i < o->rc[env].space.n_shapes; ++i) cpShapeCacheBB(o->rc[env].space.shapes[i]);
+  rc_fall(&o->rc[env], &o->rc[env].robots[robot], punish);
+  rc_test_get_rewards(&o->rc[env], rew22);
+}
+/* every dynamic body's velocity function once (consumes the forces fall() applied), as Space.step would next */
+void oracle_velocity_update(oracle_t* o, int env) {
+  cpSpace* s = o->drv ? &o->drv[env].space : &o->rc[env].space;
+  int i;
+  for (i = 0; i < s->n_bodies; ++i) {
+    cpBody* b = s->bodies[i];
+    if (b->velocity_func) b->velocity_func(b, s->gravity, 1.0, 0.01);
+    else cpBodyUpdateVelocity(b, s->gravity, 1.0, 0.01);
+  }
+}
+/* composition fixtures: Space.step = position update + velocity functions only (the generators' Space stand-in) */
+void oracle_set_free_flight(oracle_t* o, int on) {
+  int e;
+  for (e = 0; e < o->cfg.num_envs; ++e) {
+    if (o->drv) o->drv[e].space.test_free_flight = on;
+    else o->rc[e].space.test_free_flight = on;
+  }
+}

@@ -742,29 +742,8 @@ void rc_set_state(RoboCupEnv* e, const dynenv_robocup_state_t* st) {
 }
 
 /* ------------------------------------------------------------------ test hooks (golden tests) */
-int rc_test_begin(RoboCupEnv* e, int slotA, int slotB) { /* run the `begin` handler of the pair as Chipmunk would */
-  cpShape *a = 0, *b = 0, *t;
-  cpArbiter arb;
-  int i;
-  for (i = 0; i < e->space.n_shapes; ++i) {
-    if (e->space.shapes[i]->slot == slotA) a = e->space.shapes[i];
-    if (e->space.shapes[i]->slot == slotB) b = e->space.shapes[i];
-  }
-  if (!a || !b) return -1;
-  if (a->type > b->type) { t = a; a = b; b = t; } /* cpCollide type ordering */
-  memset(&arb, 0, sizeof(arb));
-  arb.a = a; arb.b = b; arb.body_a = a->body; arb.body_b = b->body;
-  for (i = 0; i < e->space.n_handlers; ++i) {
-    cpHandler* h = &e->space.handlers[i];
-    if ((h->typeA == a->collision_type && h->typeB == b->collision_type) ||
-        (h->typeA == b->collision_type && h->typeB == a->collision_type)) {
-      arb.handler = h;
-      arb.swapped = (a->collision_type != h->typeA);
-      return h->begin(&arb, &e->space, h->data);
-    }
-  }
-  return 1;
-}
+int rc_test_begin(RoboCupEnv* e, int slotA, int slotB) { return cpSpaceTestCallback(&e->space, slotA, slotB, 0); }
+int rc_test_callback(RoboCupEnv* e, int slotA, int slotB, int which) { return cpSpaceTestCallback(&e->space, slotA, slotB, which); }
 void rc_test_zero_rewards(RoboCupEnv* e) {
   int i;
   e->teamRewards[0] = e->teamRewards[1] = 0.0;
