@@ -124,11 +124,17 @@ int oracle_reset(oracle_t* o, float* obs) {
   return DYNENV_OK;
 }
 
+/* head: the continuous head channel [E][A] of RoboCup with allowHeadTurn (RoboCupEnvironment.py:339-342), or NULL */
+int oracle_step_head(oracle_t* o, const int32_t* actions, const double* head, float* obs, double* rewards, uint8_t* dones);
 int oracle_step(oracle_t* o, const int32_t* actions, float* obs, double* rewards, uint8_t* dones) {
+  return oracle_step_head(o, actions, 0, obs, rewards, dones);
+}
+int oracle_step_head(oracle_t* o, const int32_t* actions, const double* head, float* obs, double* rewards, uint8_t* dones) {
   int e, E = o->cfg.num_envs, A = o->n_agents;
   size_t stride = (size_t)o->n_time_steps * A * o->obs_dim;
 #pragma omp parallel for schedule(static) num_threads(o->threads)
   for (e = 0; e < E; ++e) {
+    if (o->rc) o->rc[e].headActions = head ? head + (size_t)e * A : 0;
     int d = o->drv ? drv_step(&o->drv[e], actions + (size_t)e * A * 2, obs ? obs + e * stride : 0, rewards + (size_t)e * A)
                    : rc_step(&o->rc[e], actions + (size_t)e * A * 4, obs ? obs + e * stride : 0, rewards + (size_t)e * A);
     dones[e] = (uint8_t)d;

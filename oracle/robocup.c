@@ -169,10 +169,13 @@ static void robot_kick(Robot* r, int foot) {
 
 /* ------------------------------------------------------------------ processAction :527-581 */
 void rc_process_action(RoboCupEnv* e, Robot* robot, const int32_t* action) {
-  int move = action[0], turn = action[1], kick = action[2], head = action[3];
+  int move = action[0], turn = action[1], kick = action[2];
+  double head = (double)action[3]; /* a float with allowHeadTurn (Box(-3, 3)), an int otherwise: exact either way */
   int canMove;
   dm_u32x4 u = rc_rng(e, (uint32_t)robot->id);
-  if (!e->allowHeadTurn) head -= 3;
+  if (e->allowHeadTurn && e->headActions) head = e->headActions[robot->id];
+  if (e->deterministicTurn) head = (double)(-3 * robot->team); /* :529-530 */
+  if (!e->allowHeadTurn) head -= 3.0;
   canMove = !(robot->penalized || robot->kicking || robot->fallen);
   if (move > 0 && canMove) {
     double r = e->canFall ? dm_unit(u.v[0]) : 0.0;
@@ -184,7 +187,7 @@ void rc_process_action(RoboCupEnv* e, Robot* robot, const int32_t* action) {
     if (r > 0.999) { rc_fall(e, robot, 0); return; }
     robot_turn(robot, turn - 1);
   }
-  if (head) { robot->headMoving = (double)head * DM_PI / 720.0; robot->moveTime = 500.0; } /* turnHead :136-138 */
+  if (head != 0.0) { robot->headMoving = head * DM_PI / 720.0; robot->moveTime = 500.0; } /* turnHead :136-138 */
   if (kick > 0 && move == 0 && turn == 0 && canMove) {
     double r = e->canFall ? dm_unit(u.v[2]) : 0.0;
     if (r > 0.99) { rc_fall(e, robot, 0); return; }
@@ -524,6 +527,8 @@ void rc_init(RoboCupEnv* e, int nPlayers, uint64_t seed, uint32_t genv, int flag
   e->canFall = (flags & DYNENV_FLAG_CAN_FALL) != 0;
   e->allowHeadTurn = (flags & DYNENV_FLAG_ALLOW_HEAD_TURN) != 0;
   e->useObsRewards = (flags & DYNENV_FLAG_USE_OBS_REWARDS) != 0;
+  e->randomInit = (flags & DYNENV_FLAG_RANDOM_INIT) != 0;
+  e->deterministicTurn = (flags & DYNENV_FLAG_DETERMINISTIC_TURN) != 0;
 }
 
 /* _create_robot_spots :275-293 (randomInit = False), the 18 random.random() draws consumed in source order */
@@ -541,16 +546,52 @@ void rc_spots(const double* rnd, cpv spots[2][5]) {
   spots[1][4] = cpv_(RC_W - (RC_SIDE + 20.0), RC_H / 2.0 + (rnd[17] - 0.5) * 50.0);
 }
 
-void rc_reset(RoboCupEnv* e) { /* __init__ :23-64 + _setup_scene :73-99 (randomInit = False) */
-  cpv spots[2][5];
-  int perm[2][5], t, i;
+/* _create_robot_spots :241-272 (randomInit = True): one random spot in each of 10 field cells (20 random.random() draws in
+ * source order), the goal-side cells go to the two teams, the 8 middle ones are dealt by np.random.permutation(8) */
+void rc_spots_random(const double* rnd, const int* perm8, cpv spots[2][5]) {
+  static const double xL[7] = {RC_SIDE + 10.0, RC_SIDE + 50.0, RC_SIDE + 250.0, RC_SIDE + 450.0, RC_SIDE + 650.0, RC_SIDE + 850.0, RC_SIDE + 890.0};
+  static const double yL[3] = {RC_SIDE + 20.0, RC_SIDE + 300.0, RC_SIDE + 580.0};
+  cpv rs[10];
+  int i, j, k = 0, d = 0, cnt[2] = {1, 1};
+  for (i = 0; i < 6; ++i) {
+    const int edge = (i == 0 || i == 5);
+    for (j = 0; j < (edge ? 1 : 2); ++j) {
+      const double yBeg = edge ? yL[0] : yL[j], yEnd = edge ? yL[2] : yL[j + 1];
+      const double x = xL[i] + rnd[d] * (xL[i + 1] - xL[i]);
+      const double y = yBeg + rnd[d + 1] * (yEnd - yBeg);
+      d += 2;
+      rs[k++] = cpv_(x, y);
+    }
+  }
+  spots[0][0] = rs[0]; spots[1][0] = rs[9];
+  for (i = 0; i < 8; ++i) { const int t = i < 4 ? 0 : 1; spots[t][cnt[t]++] = rs[perm8[i] + 1]; }
+}
+
+void rc_reset(RoboCupEnv* e) { /* __init__ :23-64 + _setup_scene :73-99 */
+  cpv spots[2][5], ballPos = cpv_(520.0, 370.0); /* W // 2, H // 2 */
+  int perm[2][5], t, i, owned = 1;
   uint32_t ep = e->episode;
-  double rnd[18];
-  for (i = 0; i < 18; ++i) {
+  double rnd[24];
+  for (i = 0; i < 24; ++i) {
     dm_u32x4 u = dm_env_rng(e->seed, e->genv, ep, DM_RNG_ROBO_RESET, (uint32_t)i, 0);
     rnd[i] = dm_unit(u.v[0]);
   }
-  rc_spots(rnd, spots);
+  if (e->randomInit) {
+    int perm8[8];
+    for (i = 0; i < 8; ++i) perm8[i] = i;
+    for (i = 0; i < 7; ++i) { /* np.random.permutation(8) -> Fisher-Yates */
+      dm_u32x4 u = dm_env_rng(e->seed, e->genv, ep, DM_RNG_ROBO_RESET, (uint32_t)(48 + i), 0);
+      int j = i + dm_randint(u.v[0], 0, 7 - i);
+      int tmp = perm8[i]; perm8[i] = perm8[j]; perm8[j] = tmp;
+    }
+    rc_spots_random(rnd, perm8, spots);
+    /* _create_ball :325-331: position anywhere on the field, random ownership (the 4th draw only if owned) */
+    ballPos = cpv_(rnd[20] * FIELD_W + RC_SIDE, rnd[21] * FIELD_H + RC_SIDE);
+    owned = rnd[22] > 0.4 ? 1 : 0;
+    if (owned != 0 && rnd[23] > 0.5) owned *= -1;
+  } else {
+    rc_spots(rnd, spots);
+  }
   /* np.random.permutation(5) x2 -> Fisher-Yates */
   for (t = 0; t < 2; ++t) {
     for (i = 0; i < 5; ++i) perm[t][i] = i;
@@ -562,11 +603,13 @@ void rc_reset(RoboCupEnv* e) { /* __init__ :23-64 + _setup_scene :73-99 (randomI
   }
   for (i = 0; i < e->nPlayers; ++i) setup_robot(e, i, spots[0][perm[0][i]], 1);
   for (i = 0; i < e->nPlayers; ++i) setup_robot(e, e->nPlayers + i, spots[1][perm[1][i]], -1);
-  setup_ball_and_posts(e, cpv_(520.0, 370.0)); /* W // 2, H // 2 */
+  if (e->deterministicTurn) /* :317-319 */
+    for (i = 0; i < e->nRobots; ++i) e->robots[i].headAngle = (double)e->robots[i].team * ROBOT_HEAD_MAX;
+  setup_ball_and_posts(e, ballPos);
   e->ballPrevPos = e->ballBody.p;
   e->nLastKicked = 0;
   e->elapsed = 0;
-  e->ballOwned = 1; e->ballFreeCntr = 9999.0; e->gracePeriod = 0.0;
+  e->ballOwned = owned; e->ballFreeCntr = 9999.0; e->gracePeriod = 0.0;
   e->goals[0] = e->goals[1] = 0; e->closestID[0] = e->closestID[1] = 0;
   e->nDefenders[0] = e->nDefenders[1] = 0;
   e->penalTimes[0] = e->penalTimes[1] = 20000.0;

@@ -48,7 +48,8 @@ typedef struct RoboCupEnv {
   double penalTimes[2];
   double teamRewards[2], robotRewards[RC_MAX_ROBOTS], robotPosRewards[RC_MAX_ROBOTS];
   double episodeRewards[RC_MAX_ROBOTS], episodePosRewards[RC_MAX_ROBOTS];
-  int canFall, allowHeadTurn, useObsRewards;
+  int canFall, allowHeadTurn, useObsRewards, randomInit, deterministicTurn; /* class switches RoboCupEnvironment.py:18-21, :24 */
+  const double* headActions; /* continuous head channel of this step ([2n], allowHeadTurn: Box(-3,3) :339-342) or NULL */
   int obsType, noiseType;      /* ObservationType / NoiseType (cutils.py:29-51) */
   double noiseMagnitude;
   double episodeObsRewards[RC_MAX_ROBOTS];
@@ -71,6 +72,7 @@ void rc_penalize(RoboCupEnv* e, Robot* r);
 void rc_fall(RoboCupEnv* e, Robot* r, int punish);
 cpv rc_robot_pos(const Robot* r);
 void rc_spots(const double* rnd18, cpv spots[2][5]);
+void rc_spots_random(const double* rnd20, const int* perm8, cpv spots[2][5]);
 void rc_get_state(const RoboCupEnv* e, dynenv_robocup_state_t* st);
 void rc_set_state(RoboCupEnv* e, const dynenv_robocup_state_t* st);
 

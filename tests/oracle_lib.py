@@ -138,10 +138,16 @@ class OracleEnv:
         self.l.oracle_reset(self.h, _p(self.obs))
         return self.obs
 
-    def step(self, actions):
+    def step(self, actions, head=None):
+        """head: the continuous head channel [E, A] float64 of RoboCup with allowHeadTurn (Box(-3, 3)), else None"""
         a = np.ascontiguousarray(actions, dtype=np.int32)
         assert a.shape == (self.E, self.A, self.K), a.shape
-        self.l.oracle_step(self.h, _p(a), _p(self.obs), _p(self.rewards), _p(self.dones))
+        if head is None:
+            self.l.oracle_step(self.h, _p(a), _p(self.obs), _p(self.rewards), _p(self.dones))
+        else:
+            hd = np.ascontiguousarray(head, dtype=np.float64)
+            assert hd.shape == (self.E, self.A), hd.shape
+            self.l.oracle_step_head(self.h, _p(a), _p(hd), _p(self.obs), _p(self.rewards), _p(self.dones))
         return self.obs, self.rewards, self.dones
 
     def step_noobs(self, actions):
