@@ -468,12 +468,19 @@ int dynenv_reset(dynenv_t* h, float* obs_dev, void* stream) {
 
 int dynenv_step(dynenv_t* h, const int32_t* actions_dev, float* obs_dev, double* rewards_dev, uint8_t* dones_dev,
                 void* stream) {
+  return dynenv_step_head(h, actions_dev, nullptr, obs_dev, rewards_dev, dones_dev, stream);
+}
+
+int dynenv_step_head(dynenv_t* h, const int32_t* actions_dev, const double* head_dev, float* obs_dev, double* rewards_dev,
+                     uint8_t* dones_dev, void* stream) {
   if (!h || !actions_dev || !rewards_dev || !dones_dev) return fail(DYNENV_ERR_ARG, "null argument");
+  if (head_dev && !(h->robocup && (h->cfg.flags & DYNENV_FLAG_ALLOW_HEAD_TURN)))
+    return fail(DYNENV_ERR_ARG, "the continuous head channel exists for RoboCup with DYNENV_FLAG_ALLOW_HEAD_TURN only");
   hipStream_t st = (hipStream_t)stream;
   if (h->robocup) {
     if (h->R.obs_type == DYNENV_OBS_PARTIAL && obs_dev) {  // getAgentVision at the five snapshots + processSeens fused into the launch
       HIP_OK(hipMemsetAsync(h->R.deferList, 0, sizeof(int), st));
-      hipLaunchKernelGGL(rc_step_partial_kernel, dim3(h->R.E), dim3(64), 0, st, h->R, (const int*)actions_dev, obs_dev, rewards_dev, dones_dev);
+      hipLaunchKernelGGL(rc_step_partial_kernel, dim3(h->R.E), dim3(64), 0, st, h->R, (const int*)actions_dev, head_dev, obs_dev, rewards_dev, dones_dev);
       const int nb = h->R.E < RC_DEFER_BLOCKS ? h->R.E : RC_DEFER_BLOCKS;  // the deferred environments are few: blocks stride over their list
       hipLaunchKernelGGL(rc_partial_obs_deferred_kernel, dim3(nb, 5, h->R.R), dim3(64), 0, st, h->R, obs_dev);
       hipLaunchKernelGGL(rc_partial_finalize_kernel, dim3(nb), dim3(64), 0, st, h->R, rewards_dev);
@@ -481,7 +488,7 @@ int dynenv_step(dynenv_t* h, const int32_t* actions_dev, float* obs_dev, double*
     else if (h->R.obs_type == DYNENV_OBS_PARTIAL)
       return fail(DYNENV_ERR_ARG, "RoboCup Partial: the observation buffer is required (the processSeens rewards come out of the same pass)");
     else
-      hipLaunchKernelGGL(rc_step_kernel, dim3(h->R.E), dim3(64), 0, st, h->R, (const int*)actions_dev, obs_dev, rewards_dev, dones_dev);
+      hipLaunchKernelGGL(rc_step_kernel, dim3((h->R.E + RC_FULL_EPW - 1) / RC_FULL_EPW), dim3(64), 0, st, h->R, (const int*)actions_dev, head_dev, obs_dev, rewards_dev, dones_dev);
     HIP_OK(hipGetLastError());
     return DYNENV_OK;
   }

@@ -20,6 +20,16 @@ __constant__ RcConst RC;
 #ifndef RC_WAVES_PER_SIMD
 #define RC_WAVES_PER_SIMD 4
 #endif
+#ifndef RC_FULL_EPW
+#define RC_FULL_EPW 1 /* environments per wave of rc_step_kernel (Full observations): 1 or 2, see Grp<> */
+#endif
+#ifndef RC_RPL
+#define RC_RPL (RC_FULL_EPW == 2) /* robocup_rpl.hip: one lane per robot, the common substep in registers (0: the foot-per-lane rc_step_body) */
+#endif
+#ifndef RC_QUIET_JOINTS_INLINE
+#define RC_QUIET_JOINTS_INLINE 0 /* the quiet substep's joint solve inlined into the step loop (EPW = 2 always inlines) */
+#endif
+
 
 #define ROBOT_VELOCITY 50.0
 #define ROBOT_MASS 4000.0
@@ -42,11 +52,14 @@ struct RcObsStage {
 struct RcPrefilter {
   float cx[RC_NB], cy[RC_NB], hx[RC_NB], hy[RC_NB];
 };
+struct RcRplExchange {  // robocup_rpl.hip: what crosses lanes in the register-resident substep
+  double q[16];                     // squared distance robot - ball (closest-robot searches)
+  float bx[16], by[16], br[16];     // robot / ball bounding boxes of the contact prefilter
+};
 struct __align__(16) RcLds {
   // bodies: feet 0..19, ball 20 (home location of the state); posts 21..24 are constants
   double px[RC_NB], py[RC_NB], vx[RC_NB], vy[RC_NB], ang[RC_NB], w[RC_NB], vbx[RC_NB], vby[RC_NB], wb[RC_NB];
   double fx[RC_NB], fy[RC_NB], tq[RC_NB];
-  double rc[RC_NB], rs[RC_NB], rotAng[RC_NB];
   // shape cache as of the last position integration (what pymunk's spatial queries and the narrowphase see)
   double cpx[RC_NB], cpy[RC_NB], crc[RC_NB], crs[RC_NB];
   double aabb[21][4];
@@ -57,18 +70,56 @@ struct __align__(16) RcLds {
   double envd[RD_COUNT], teamRew[2];
   int rflags[16], touchc[16], fallc[16];
   int envi[RE_COUNT];
-  int still[RC_NB];
   int s_pair[RC_NS], s_meta[RC_NS], s_hash0[RC_NS], s_hash1[RC_NS];
   double s_jn0[RC_NS], s_jt0[RC_NS], s_jn1[RC_NS], s_jt1[RC_NS];
+  unsigned short candList[128];  // compacted broadphase candidates (pair codes) in canonical order
   union {
     RcMailbox mb;
     RcObsStage ob;
     RcPrefilter pf;
+    RcRplExchange rq;
   } u;
 };
+// LDS tiles: the one-environment-per-wave kernels (Partial observations, the observation kernel after a reset) use g_R,
+// the two-environments-per-wave step kernel one tile per half wave.  A kernel only allocates what it references.
 __shared__ RcLds g_R;
+__shared__ RcLds g_R2[2];
 
-#define RC_MY_PAIR(t) ((int)((((t) < 4 ? pairLo : pairHi) >> (16 * ((t)&3))) & 0xFFFFull))
+// Grp<EPW>: the lanes that serve ONE environment.  EPW = 1: the whole wave (cross-lane traffic through v_readlane with
+// wave-uniform indices, masks in SGPRs).  EPW = 2: a half wave (32 lanes: feet 0..19, ball 20, robots 0..9, contact
+// slots 0..15, the general solve's joints on 16..25); "uniform" then means uniform within the half, masks are the half's
+// 32 bits of the wave ballot and broadcasts go through ds_bpermute.  A launch of E environments needs E / 2 waves, which
+// fit the chip at two waves per SIMD with 256 VGPRs each - no scratch, nothing out of line in the hot loop.
+template <int EPW> struct Grp;
+template <> struct Grp<1> {
+  static constexpr int W = 64, JL0 = 32, OBS_BALL_LANE = 32;
+  DE_DEV static int lane() { return (int)threadIdx.x; }
+  DE_DEV static int id() { return 0; }
+  DE_DEV static RcLds& tile() { return g_R; }
+  DE_DEV static uint64_t ballot(bool p) { return __ballot(p); }
+  DE_DEV static uint64_t lt_mask() { return ::lanemask_lt(); }
+  DE_DEV static int bcast_i(int v, int src) { return ::bcast_i(v, src); }
+  DE_DEV static double bcast_d(double v, int src) { return ::bcast_d(v, src); }
+  DE_DEV static uint64_t uniform_u64(uint64_t v) { return ::uniform_u64(v); }
+  DE_DEV static int uniform_i(int v) { return ::uniform_i(v); }
+};
+template <> struct Grp<2> {
+  static constexpr int W = 32, JL0 = 16, OBS_BALL_LANE = 31;
+  DE_DEV static int lane() { return (int)threadIdx.x & 31; }
+  DE_DEV static int id() { return ((int)threadIdx.x >> 5) & 1; }
+  DE_DEV static RcLds& tile() { return g_R2[((int)threadIdx.x >> 5) & 1]; }
+  DE_DEV static uint64_t ballot(bool p) {
+    const uint64_t b = __ballot(p);
+    return (threadIdx.x & 32) ? (b >> 32) : (b & 0xFFFFFFFFull);
+  }
+  DE_DEV static uint64_t lt_mask() { return (1ull << ((int)threadIdx.x & 31)) - 1ull; }
+  DE_DEV static int bcast_i(int v, int src) { return __shfl(v, ((int)threadIdx.x & 32) | src, 64); }
+  DE_DEV static double bcast_d(double v, int src) { return __shfl(v, ((int)threadIdx.x & 32) | src, 64); }
+  DE_DEV static uint64_t uniform_u64(uint64_t v) { return v; }
+  DE_DEV static int uniform_i(int v) { return v; }
+};
+
+#define RC_MY_PAIR(t) ((int)((((t) < 4 ? pairLo : (t) < 8 ? pairHi : pairTop) >> (16 * ((t)&3))) & 0xFFFFull))
 
 DE_DEV double rc_minv(int b) { return b == RC_BALL ? 1.0 / 10.0 : (b < RC_BALL ? 1.0 / ROBOT_MASS : 0.0); }
 DE_DEV double rc_iinv(int b) { return b == RC_BALL ? RC.ballIinv : (b < RC_BALL ? RC.footIinv : 0.0); }  // host-side 1.0 / inertia
@@ -113,7 +164,7 @@ DE_DEV void rc_velocity_update(RcLds& L, int b) {
 struct RcCtx {
   uint64_t seed;
   uint32_t genv, episode;
-  int n, R, canFall, allowHead;
+  int n, R, canFall, allowHead, detTurn;
 };
 
 DE_DEV dm_u32x4 rc_rng(const RcCtx& c, const RcLds& L, uint32_t entity) {
@@ -178,8 +229,9 @@ DE_DEV void free_penalty_spot(const RcCtx& c, const RcLds& L, int r, V2& spot, d
   spot.y = lower ? RC_H - RC_SIDE : RC_SIDE;
 }
 
+template <int EPW>
 __device__ __noinline__ void rc_penalize(const RcCtx& c, int r) {  // :824-859
-  RcLds& L = g_R;
+  RcLds& L = Grp<EPW>::tile();
   const int teamIdx = robot_team(L, r) > 0 ? 0 : 1;
   int f = L.rflags[r];
   f |= RF_PENAL;
@@ -216,8 +268,9 @@ DE_DEV double shape_point_dist(const RcLds& L, int s, V2 p) {
   return dm_sqrt(vdot(d, d)) - FOOT_RADIUS;
 }
 
+template <int EPW>
 __device__ __noinline__ void rc_fall(const RcCtx& c, int r, int punish) {  // :735-791
-  RcLds& L = g_R;
+  RcLds& L = Grp<EPW>::tile();
   const V2 pos = robot_pos(L, r);
   if (punish) L.rrew[r] -= 2.0;
   for (int s = 0; s <= RC_BALL; ++s) {  // canonical slot order; goalposts are static (forces never integrated)
@@ -240,19 +293,22 @@ __device__ __noinline__ void rc_fall(const RcCtx& c, int r, int punish) {  // :7
   L.rflags[r] |= RF_FALLEN;
   L.fallc[r] += 1;
   L.fallT[r] = 4000.0;
-  if (L.fallc[r] > 2) rc_penalize(c, r);
+  if (L.fallc[r] > 2) rc_penalize<EPW>(c, r);
 }
 
-DE_DEV void rc_process_action(const RcCtx& c, RcLds& L, int r, const int* action) {  // :527-581
+template <int EPW>
+DE_DEV void rc_process_action(const RcCtx& c, RcLds& L, int r, const int* action, const double* headAct) {  // :527-581
   const int move = action[0], turn = action[1], kick = action[2];
-  int head = action[3];
+  double head = (double)action[3];  // a float with allowHeadTurn (Box(-3, 3), :339-342), an int otherwise: exact either way
   const dm_u32x4 u = rc_rng(c, L, (uint32_t)r);
-  if (!c.allowHead) head -= 3;
+  if (c.allowHead && headAct) head = headAct[r];
+  if (c.detTurn) head = (double)(-3 * robot_team(L, r));  // :529-530
+  if (!c.allowHead) head -= 3.0;
   const int f0 = L.rflags[r];
   const bool canMove = !(f0 & (RF_PENAL | RF_KICK | RF_FALLEN));
   if (move > 0 && canMove) {
     const double rr = c.canFall ? dm_unit(u.v[0]) : 0.0;
-    if (rr > 0.999) { rc_fall(c, r, 0); return; }
+    if (rr > 0.999) { rc_fall<EPW>(c, r, 0); return; }
     if (!(L.rflags[r] & (RF_KICK | RF_PENAL | RF_FALLEN))) {  // Robot.step :103-119
       L.moveT[r] = 500.0;
       const int dir = move - 1;
@@ -272,16 +328,16 @@ DE_DEV void rc_process_action(const RcCtx& c, RcLds& L, int r, const int* action
   }
   if (turn > 0 && canMove) {
     const double rr = c.canFall ? dm_unit(u.v[1]) : 0.0;
-    if (rr > 0.999) { rc_fall(c, r, 0); return; }
+    if (rr > 0.999) { rc_fall<EPW>(c, r, 0); return; }
     if (!(L.rflags[r] & (RF_KICK | RF_PENAL | RF_FALLEN))) {  // Robot.turn :122-125
       L.moveT[r] = 500.0;
       L.w[2 * r] += (turn - 1) ? 20.0 : -20.0;
     }
   }
-  if (head) { L.headmov[r] = (double)head * DM_PI / 720.0; L.moveT[r] = 500.0; }  // Robot.turnHead :136-138
+  if (head != 0.0) { L.headmov[r] = head * DM_PI / 720.0; L.moveT[r] = 500.0; }  // Robot.turnHead :136-138
   if (kick > 0 && move == 0 && turn == 0 && canMove) {
     const double rr = c.canFall ? dm_unit(u.v[2]) : 0.0;
-    if (rr > 0.99) { rc_fall(c, r, 0); return; }
+    if (rr > 0.99) { rc_fall<EPW>(c, r, 0); return; }
     int f = L.rflags[r];
     if (!(f & (RF_KICK | RF_PENAL | RF_FALLEN))) {  // Robot.kick :128-133
       const int foot = kick - 1;
@@ -294,6 +350,7 @@ DE_DEV void rc_process_action(const RcCtx& c, RcLds& L, int r, const int* action
   }
 }
 
+template <int EPW>
 DE_DEV void rc_tick(const RcCtx& c, RcLds& L, int r) {  // :862-1007
   const double time = RC_TIME;
   if (L.moveT[r] > 0.0) {
@@ -335,7 +392,7 @@ DE_DEV void rc_tick(const RcCtx& c, RcLds& L, int r) {  // :862-1007
     if (L.fallT[r] < 0.0) {
       const dm_u32x4 u = rc_rng(c, L, (uint32_t)r | (1u << 8));
       const double rr = dm_unit(u.v[0]);
-      if (rr > 0.9 && !(L.rflags[r] & RF_PENAL) && c.canFall) { rc_fall(c, r, 0); return; }
+      if (rr > 0.9 && !(L.rflags[r] & RF_PENAL) && c.canFall) { rc_fall<EPW>(c, r, 0); return; }
       L.rflags[r] &= ~RF_FALLEN;
       L.fallc[r] = 0;
     }
@@ -359,7 +416,7 @@ DE_DEV void rc_tick(const RcCtx& c, RcLds& L, int r) {  // :862-1007
     const bool isDef = (L.envi[RE_DEF0 + teamIdx] & bit) != 0;
     if (robX < penX && p.y > (RC_H / 2.0 - 110.0) && p.y < (RC_H / 2.0 + 110.0)) {
       if (!isDef) {
-        if (__popc(L.envi[RE_DEF0 + teamIdx]) >= 2) rc_penalize(c, r);
+        if (__popc(L.envi[RE_DEF0 + teamIdx]) >= 2) rc_penalize<EPW>(c, r);
         else L.envi[RE_DEF0 + teamIdx] |= bit;
       }
     } else if (isDef) {
@@ -367,7 +424,7 @@ DE_DEV void rc_tick(const RcCtx& c, RcLds& L, int r) {  // :862-1007
     }
   }
   const V2 pos = robot_pos(L, r);
-  if (pos.y < 0.0 || pos.x < 0.0 || pos.y > RC_H || pos.x > RC_W) rc_penalize(c, r);
+  if (pos.y < 0.0 || pos.x < 0.0 || pos.y > RC_H || pos.x > RC_W) rc_penalize<EPW>(c, r);
   if (pos.x != L.prevx[r] || pos.y != L.prevy[r]) {
     if ((r == L.envi[RE_CLOSE0] || r == L.envi[RE_CLOSE1]) && !(L.rflags[r] & RF_PENAL)) {
       const V2 ballPos = v2(L.px[RC_BALL], L.py[RC_BALL]);
@@ -398,6 +455,7 @@ DE_DEV void ball_free_kick_process(RcLds& L, int team) {  // :600-619
 // isBallOutOfField :622-732, by the whole wave: the scalar decisions are computed redundantly (uniform) by every lane and
 // written by lane 0; the per-robot reward terms run one robot per lane; the two "closest robot" searches replay the
 // reference's ascending strict-< loop over the per-lane distances.
+template <int EPW>
 DE_DEV void rc_ball_logic(const RcCtx& c, RcLds& L, int lane) {
   bool finished = false, moved = false;
   int team = 0;
@@ -466,11 +524,11 @@ DE_DEV void rc_ball_logic(const RcCtx& c, RcLds& L, int lane) {
   int best0 = 0, best1 = 0;
   double d0 = INFINITY, d1 = INFINITY;
   for (int i = 0; i < n; ++i) {
-    const double qi = bcast_d(q, i);
+    const double qi = Grp<EPW>::bcast_d(q, i);
     if (qi < d0) { d0 = qi; best0 = i; }
   }
   for (int i = 0; i < n; ++i) {
-    const double qi = bcast_d(q, n + i);
+    const double qi = Grp<EPW>::bcast_d(q, n + i);
     if (qi < d1) { d1 = qi; best1 = i; }
   }
   __syncthreads();  // every lane has read the shared scalars it needs
@@ -520,32 +578,35 @@ DE_DEV bool rc_tick_has_event(const RcLds& L, int r) {
 // the per-substep game logic: for robot in agents: [processAction]; tick; then the ball.  Called by the whole wave.
 // The sequential form (first substep, or a cross-robot event) is out of line; the common lane-parallel form is inlined
 // into the step kernel's loop so that it costs no call (callee-saved registers travel through scratch on every call).
-__device__ __noinline__ void rc_game_serial(RcCtx c, int it, const int* __restrict__ actions) {
-  RcLds& L = g_R;
+template <int EPW>
+__device__ __noinline__ void rc_game_serial(RcCtx c, int it, const int* __restrict__ actions, const double* __restrict__ headAct) {
+  RcLds& L = Grp<EPW>::tile();
   for (int r = 0; r < c.R; ++r) {
     if (it == 0) {
       int act[4] = {actions[4 * r], actions[4 * r + 1], actions[4 * r + 2], actions[4 * r + 3]};
-      rc_process_action(c, L, r, act);
+      rc_process_action<EPW>(c, L, r, act, headAct);
     }
-    rc_tick(c, L, r);
+    rc_tick<EPW>(c, L, r);
   }
 }
-__device__ RC_LOGIC_INLINE void rc_game_logic(RcCtx c, int it, const int* __restrict__ actions, int lane) {
-  RcLds& L = g_R;
+template <int EPW>
+__device__ RC_LOGIC_INLINE void rc_game_logic(RcCtx c, int it, const int* __restrict__ actions, const double* __restrict__ headAct, int lane) {
+  RcLds& L = Grp<EPW>::tile();
   bool serial = it == 0;  // processAction draws the fall dice and may knock other robots over: keep the reference order
-  if (!serial) serial = wave_ballot(lane < c.R && rc_tick_has_event(L, lane)) != 0ull;
+  if (!serial) serial = Grp<EPW>::ballot(lane < c.R && rc_tick_has_event(L, lane)) != 0ull;
   if (!serial) {
-    if (lane < c.R) rc_tick(c, L, lane);
+    if (lane < c.R) rc_tick<EPW>(c, L, lane);
   } else if (lane == 0) {
-    rc_game_serial(c, it, actions);
+    rc_game_serial<EPW>(c, it, actions, headAct);
   }
   __syncthreads();
-  rc_ball_logic(c, L, lane);
+  rc_ball_logic<EPW>(c, L, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
 // collision callbacks (lane 0), RoboCupEnvironment.py:1010-1146
 // ------------------------------------------------------------------------------------------------
+template <int EPW>
 DE_DEV bool rc_cb_begin(const RcCtx& c, RcLds& L, int i, int j) {  // pair (i < j), returns "keep"
   if (j < RC_BALL) {  // robotPushingDet: shapes in collision order (a = lower slot)
     const int r1 = i >> 1, r2 = j >> 1;
@@ -564,7 +625,7 @@ DE_DEV bool rc_cb_begin(const RcCtx& c, RcLds& L, int i, int j) {  // pair (i < 
   if (j == RC_BALL) {  // ballCollision (foot i, ball)
     const int r = i >> 1;
     if (L.envi[RE_OWNED] != 0) {
-      if (robot_team(L, r) != L.envi[RE_OWNED] && !(L.rflags[r] & RF_PENAL) && c.canFall) rc_penalize(c, r);
+      if (robot_team(L, r) != L.envi[RE_OWNED] && !(L.rflags[r] & RF_PENAL) && c.canFall) rc_penalize<EPW>(c, r);
       else { L.envi[RE_OWNED] = 0; L.envd[RD_GRACE] = 0.0; L.envd[RD_FREECNT] = 0.0; }
     }
     push_last_kicked(L, r);
@@ -573,6 +634,7 @@ DE_DEV bool rc_cb_begin(const RcCtx& c, RcLds& L, int i, int j) {  // pair (i < 
   return true;  // foot-goalpost and ball-goalpost: default begin
 }
 
+template <int EPW>
 DE_DEV void rc_cb_post_solve(const RcCtx& c, RcLds& L, int i, int j) {
   if (!c.canFall) return;
   const uint32_t key = (uint32_t)(i * 32 + j);
@@ -584,25 +646,25 @@ DE_DEV void rc_cb_post_solve(const RcCtx& c, RcLds& L, int i, int j) {
     const dm_u32x4 u = rc_rng(c, L, key | (2u << 16));
     double rr = dm_unit(u.v[0]);
     if (rr > dm_powi((L.rflags[r1] & RF_PUSH) ? 0.99995 : 0.9999, L.touchc[r1]) && !(L.rflags[r1] & RF_FALLEN)) {
-      rc_fall(c, r1, (L.rflags[r1] & RF_PUSH) ? 1 : 0);
+      rc_fall<EPW>(c, r1, (L.rflags[r1] & RF_PUSH) ? 1 : 0);
       L.touchc[r1] = 0;
     }
     rr = dm_unit(u.v[1]);
     if (rr > dm_powi((L.rflags[r2] & RF_PUSH) ? 0.99995 : 0.9999, L.touchc[r2]) && !(L.rflags[r2] & RF_FALLEN)) {
-      rc_fall(c, r2, (L.rflags[r2] & RF_PUSH) ? 1 : 0);
+      rc_fall<EPW>(c, r2, (L.rflags[r2] & RF_PUSH) ? 1 : 0);
       L.touchc[r2] = 0;
     }
     const bool p1 = L.rflags[r1] & RF_PUSH, p2 = L.rflags[r2] & RF_PUSH;
     const bool diffTeam = robot_team(L, r1) != robot_team(L, r2);
-    if (p1 && !p2 && (L.rflags[r2] & RF_FALLEN) && diffTeam) { rc_penalize(c, r1); L.touchc[r1] = 0; }
-    else if (p2 && !p1 && (L.rflags[r1] & RF_FALLEN) && diffTeam) { rc_penalize(c, r2); L.touchc[r2] = 0; }
+    if (p1 && !p2 && (L.rflags[r2] & RF_FALLEN) && diffTeam) { rc_penalize<EPW>(c, r1); L.touchc[r1] = 0; }
+    else if (p2 && !p1 && (L.rflags[r1] & RF_FALLEN) && diffTeam) { rc_penalize<EPW>(c, r2); L.touchc[r2] = 0; }
   } else if (j > RC_BALL && i < RC_BALL) {  // goalpostCollision :1106-1125
     const int r = i >> 1;
     if (L.rflags[r] & RF_FALLEN) { L.touchc[r] = 0; return; }
     if (!(L.rflags[r] & RF_TOUCH)) { L.rflags[r] |= RF_TOUCH; L.touchc[r] = 0; }
     L.touchc[r] += 1;
     const dm_u32x4 u = rc_rng(c, L, key | (3u << 16));
-    if (dm_unit(u.v[0]) > dm_powi(0.9998, L.touchc[r])) rc_fall(c, r, 1);
+    if (dm_unit(u.v[0]) > dm_powi(0.9998, L.touchc[r])) rc_fall<EPW>(c, r, 1);
   }
 }
 
@@ -923,8 +985,9 @@ DE_DEV void joints_solve(const RcJoint& J, RcFeet& f, double& jx, double& jy, do
     if (pf || iter < 9) rotary_iterate(J, f, jr);
   }
 }
-__device__ __noinline__ void rc_joints_only(int lane, int R) {
-  RcLds& L = g_R;
+template <int EPW>
+DE_DEV void rc_joints_only_inl(int lane, int R) {
+  RcLds& L = Grp<EPW>::tile();
   if (lane < R) {
     const int la = 2 * lane, lb = 2 * lane + 1;
     RcJoint J;
@@ -950,6 +1013,14 @@ __device__ __noinline__ void rc_joints_only(int lane, int R) {
   }
 }
 
+// out of line at 128 VGPRs (one environment per wave: its own small register allocation), inlined where the budget is 256
+__device__ __noinline__ void rc_joints_only_ool(int lane, int R) { rc_joints_only_inl<1>(lane, R); }
+template <int EPW>
+DE_DEV void rc_joints_only(int lane, int R) {
+  if (EPW == 1) rc_joints_only_ool(lane, R);
+  else rc_joints_only_inl<EPW>(lane, R);
+}
+
 #ifdef DRV_PROFILE
 #define RC_PROF(...) __VA_ARGS__
 #else
@@ -961,11 +1032,14 @@ struct RcStepRet {
   int err;
 };
 
-__device__ RC_PHYS_INLINE RcStepRet rc_physics(RcCtx c, int lane, int cand, uint64_t pairLo, uint64_t pairHi, uint64_t occ) {
-  RcLds& L = g_R;
+template <int EPW>
+DE_DEV RcStepRet rc_physics_inl(RcCtx c, int lane, int cand, uint64_t pairLo, uint64_t pairHi, uint64_t pairTop, uint64_t occ) {
+  typedef Grp<EPW> G;
+  constexpr int W = G::W, NROUNDS = (RC_NPAIR_ROUNDS * 64) / W;
+  RcLds& L = G::tile();
   RcMailbox& M = L.u.mb;
   int err = 0;
-  const bool anyContactWork = wave_ballot(cand != 0) != 0ull || occ != 0ull;
+  const bool anyContactWork = G::ballot(cand != 0) != 0ull || occ != 0ull;
 RC_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
   // --- contact detection / cache -------------------------------------------------------------------------
   bool touched = false, slotOcc = false, freeMe = false, active = false;
@@ -982,34 +1056,31 @@ RC_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
     // order), so that the narrowphase runs once over up to 64 pairs instead of once per round that holds a candidate
     // (the two feet of one robot are a candidate pair in every substep).  The list borrows the mailbox's LDS, which
     // is not live yet: every lane takes its entries into registers before the mailbox flags are cleared.
-    unsigned short* cl = reinterpret_cast<unsigned short*>(&L.u);
+    unsigned short* cl = L.candList;
     int nCand = 0;
 #pragma unroll 1
-    for (int t = 0; t < RC_NPAIR_ROUNDS; ++t) {
+    for (int t = 0; t < NROUNDS; ++t) {
       const bool cbit = (cand >> t) & 1;
-      const uint64_t m = wave_ballot(cbit);
+      const uint64_t m = G::ballot(cbit);
       if (m == 0ull) continue;
       if (cbit) {
-        const int idx = nCand + __popcll(m & lanemask_lt());
+        const int idx = nCand + __popcll(m & G::lt_mask());
         if (idx < 128) cl[idx] = (unsigned short)RC_MY_PAIR(t); else err |= 1;  // overflow is reported through RE_ERR
       }
       nCand += __popcll(m);
     }
     if (nCand > 128) nCand = 128;
-    __syncthreads();
-    const int pr0 = lane < nCand ? (int)cl[lane] : 0xFFFF, pr1 = 64 + lane < nCand ? (int)cl[64 + lane] : 0xFFFF;
-    __syncthreads();
     if (lane < RC_NS) M.flag[lane] = 0;
     __syncthreads();
 #pragma unroll 1
-    for (int pass = 0; pass * 64 < nCand; ++pass) {
-      const int pr = pass ? pr1 : pr0;
+    for (int pass = 0; pass * W < nCand; ++pass) {
+      const int pr = pass * W + lane < nCand ? (int)cl[pass * W + lane] : 0xFFFF;
       const bool isCand = pr != 0xFFFF;
       RcContacts ct;
       ct.count = 0;
       if (isCand) rc_narrowphase(L, pr >> 8, pr & 0xFF, ct);
       const bool touch = isCand && ct.count > 0;
-      if (wave_ballot(touch) == 0ull) continue;
+      if (G::ballot(touch) == 0ull) continue;
       int slot = -1;
       if (touch) {
         for (uint64_t mm = occ; mm; mm &= mm - 1) {
@@ -1018,10 +1089,10 @@ RC_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
         }
       }
       const bool needNew = touch && slot < 0;
-      const uint64_t newMask = wave_ballot(needNew);
+      const uint64_t newMask = G::ballot(needNew);
       if (newMask) {
         const uint64_t slotBits = (1ull << RC_NS) - 1ull;
-        int rk = __popcll(newMask & lanemask_lt());
+        int rk = __popcll(newMask & G::lt_mask());
         uint64_t fm = (~occ) & slotBits;
         if (needNew) {
           for (int r = 0; r < rk; ++r) fm &= fm - 1;
@@ -1078,17 +1149,17 @@ RC_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
         a_age = 0;
       }
     }
-    touchedMask = wave_ballot(touched);
+    touchedMask = G::ballot(touched);
     nTouched = __popcll(touchedMask);
     for (uint64_t mm = touchedMask; mm; mm &= mm - 1) {
       int b = __builtin_ctzll(mm);
-      int pk = bcast_i(a_pair, b);
+      int pk = G::bcast_i(a_pair, b);
       rank += (pk < a_pair) ? 1 : 0;
     }
     // canonical order: r1/r2 relative to the bodies' CURRENT positions (an earlier begin callback may have teleported
     // a robot: ballCollision -> penalize), then the begin callback of first contacts (scalar, lane 0)
     for (int k = 0; k < nTouched; ++k) {
-      const uint64_t who = wave_ballot(touched && rank == k);
+      const uint64_t who = G::ballot(touched && rank == k);
       const int b = __builtin_ctzll(who);
       if (lane == b) {
         const V2 pa = bodyA <= RC_BALL ? v2(L.px[bodyA], L.py[bodyA]) : post_pos(bodyA);
@@ -1100,10 +1171,10 @@ RC_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
           r2[1] = vsub(v2(M.p2x[lane][1], M.p2y[lane][1]), pb);
         }
       }
-      const int st = bcast_i(a_state, b);
+      const int st = G::bcast_i(a_state, b);
       if (st != ARB_FIRST_) continue;
-      const int pk = bcast_i(a_pair, b);
-      if (lane == 0) rc_cb_begin(c, L, pk >> 8, pk & 0xFF);  // every RoboCup begin handler returns True
+      const int pk = G::bcast_i(a_pair, b);
+      if (lane == 0) rc_cb_begin<EPW>(c, L, pk >> 8, pk & 0xFF);  // every RoboCup begin handler returns True
       __syncthreads();
     }
     // separate callbacks + expiry of untouched slots, canonical order over ALL occupied slots
@@ -1113,19 +1184,19 @@ RC_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
     }
     {
       const bool sepMe = slotOcc && !touched && a_state != ARB_CACHED_;
-      const uint64_t sepMask = wave_ballot(sepMe);
+      const uint64_t sepMask = G::ballot(sepMe);
       if (sepMask) {
         int srank = 0;
         for (uint64_t mm = sepMask; mm; mm &= mm - 1) {
           int b = __builtin_ctzll(mm);
-          int pk = bcast_i(a_pair, b);
+          int pk = G::bcast_i(a_pair, b);
           srank += (pk < a_pair) ? 1 : 0;
         }
         const int ns = __popcll(sepMask);
         for (int k = 0; k < ns; ++k) {
-          const uint64_t who = wave_ballot(sepMe && srank == k);
+          const uint64_t who = G::ballot(sepMe && srank == k);
           const int b = __builtin_ctzll(who);
-          const int pk = bcast_i(a_pair, b);
+          const int pk = G::bcast_i(a_pair, b);
           if (lane == 0) rc_cb_separate(L, pk >> 8, pk & 0xFF);
           __syncthreads();
         }
@@ -1134,15 +1205,15 @@ RC_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
     }
     // levels of the active arbiters
     active = touched && a_state != ARB_IGNORE_;
-    activeMask = wave_ballot(active);
+    activeMask = G::ballot(active);
     int blvl = 0;
     for (int k = 0; k < nTouched; ++k) {
-      const uint64_t who = wave_ballot(active && rank == k);
+      const uint64_t who = G::ballot(active && rank == k);
       if (who == 0ull) continue;
       const int b = __builtin_ctzll(who);
-      const int ba = bcast_i(bodyA, b), bb2 = bcast_i(bodyB, b);
-      const int la = ba <= RC_BALL ? bcast_i(blvl, ba) : 0;
-      const int lb = bb2 <= RC_BALL ? bcast_i(blvl, bb2) : 0;
+      const int ba = G::bcast_i(bodyA, b), bb2 = G::bcast_i(bodyB, b);
+      const int la = ba <= RC_BALL ? G::bcast_i(blvl, ba) : 0;
+      const int lb = bb2 <= RC_BALL ? G::bcast_i(blvl, bb2) : 0;
       const int lv = la > lb ? la : lb;
       if (lane == b) myLevel = lv;
       if (lane == ba || lane == bb2) blvl = lv + 1;
@@ -1174,8 +1245,8 @@ RC_PROF(const unsigned long long T1 = __builtin_amdgcn_s_memtime();)
   // state OVERLAYS the registers that hold arbiter state on the slot lanes (jn/jt <-> accumulated joint impulses,
   // nMass/tMass <-> pivot K^-1, bias <-> pivot bias, bounce <-> iSum / rotary bias).  Holding both sets at once pushed
   // the joint constants to scratch inside the iteration loop.
-  static_assert(RC_NS <= 32, "joint lanes must not be slot lanes");
-  const int rl = lane - 32;
+  static_assert(RC_NS <= G::JL0 && G::JL0 + RC_MAXR <= W, "joint lanes must not be slot lanes");
+  const int rl = lane - G::JL0;
   const bool isRobot = rl >= 0 && rl < c.R && !jointsOnly;
   bool hasPivot = false, pivotFirst = true;
   if (isRobot) {
@@ -1199,7 +1270,7 @@ RC_PROF(const unsigned long long T3 = __builtin_amdgcn_s_memtime(); unsigned lon
   const int la = 2 * rl, lb = 2 * rl + 1;
   if (jointsOnly) {
 RC_PROF(T4 = __builtin_amdgcn_s_memtime();)
-    rc_joints_only(lane, c.R);
+    rc_joints_only<EPW>(lane, c.R);
   } else {
     // --- warm start: arbiters (level by level), then joints -------------------------------------------------
     for (int lv = 0; lv <= maxLevel; ++lv) {
@@ -1286,11 +1357,11 @@ RC_PROF(const unsigned long long T5 = __builtin_amdgcn_s_memtime();)
   // --- post-solve callbacks of the active arbiters, canonical order (scalar, lane 0) -------------------------
   if (anyContactWork) {
     for (int k = 0; k < nTouched; ++k) {
-      const uint64_t who = wave_ballot(active && rank == k);
+      const uint64_t who = G::ballot(active && rank == k);
       if (who == 0ull) continue;
       const int b = __builtin_ctzll(who);
-      const int pk = bcast_i(a_pair, b);
-      if (lane == 0) rc_cb_post_solve(c, L, pk >> 8, pk & 0xFF);
+      const int pk = G::bcast_i(a_pair, b);
+      if (lane == 0) rc_cb_post_solve<EPW>(c, L, pk >> 8, pk & 0xFF);
       __syncthreads();
     }
     if (active && a_state == ARB_FIRST_) a_state = ARB_NORMAL_;
@@ -1299,19 +1370,35 @@ RC_PROF(const unsigned long long T5 = __builtin_amdgcn_s_memtime();)
       L.s_meta[lane] = a_state | (a_count << 8) | (a_age << 16);
       if (touched) { L.s_jn0[lane] = jn[0]; L.s_jt0[lane] = jt[0]; L.s_jn1[lane] = jn[1]; L.s_jt1[lane] = jt[1]; }
     }
-    occ &= ~wave_ballot(freeMe);
+    occ &= ~G::ballot(freeMe);
   }
   __syncthreads();
-RC_PROF(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* d = g_rcprof + blockIdx.x * 12; const unsigned long long T6 = __builtin_amdgcn_s_memtime(); d[3] += T1 - T0; d[4] += T2 - T1; d[5] += T3 - T2; d[6] += T4 - T3; d[7] += T5 - T4; d[8] += T6 - T5; d[9] += (unsigned long long)nTouched; d[10] += (unsigned long long)(maxLevel + 1); })
+RC_PROF(if (lane == 0 && blockIdx.x * EPW + G::id() < 4096) { unsigned long long* d = g_rcprof + (blockIdx.x * EPW + G::id()) * 12; const unsigned long long T6 = __builtin_amdgcn_s_memtime(); d[3] += T1 - T0; d[4] += T2 - T1; d[5] += T3 - T2; d[6] += T4 - T3; d[7] += T5 - T4; d[8] += T6 - T5; d[9] += (unsigned long long)nTouched; d[10] += (unsigned long long)(maxLevel + 1); })
   RcStepRet ret;
   ret.occ = occ; ret.err = err;
   return ret;
 }
 
+__device__ RC_PHYS_INLINE RcStepRet rc_physics_ool(RcCtx c, int lane, int cand, uint64_t pairLo, uint64_t pairHi, uint64_t occ) {
+  return rc_physics_inl<1>(c, lane, cand, pairLo, pairHi, 0ull, occ);
+}
+__device__ __noinline__ RcStepRet rc_physics_ool2(RcCtx c, int lane, int cand, uint64_t pairLo, uint64_t pairHi, uint64_t pairTop, uint64_t occ) {
+  return rc_physics_inl<2>(c, lane, cand, pairLo, pairHi, pairTop, occ);
+}
+template <int EPW>
+DE_DEV RcStepRet rc_physics(RcCtx c, int lane, int cand, uint64_t pairLo, uint64_t pairHi, uint64_t pairTop, uint64_t occ) {
+  if (EPW == 1) return rc_physics_ool(c, lane, cand, pairLo, pairHi, occ);
+#ifdef RC_PHYS2_OOL  /* analysis builds: keeps the general path out of the step kernel's listing */
+  return rc_physics_ool2(c, lane, cand, pairLo, pairHi, pairTop, occ);
+#else
+  return rc_physics_inl<EPW>(c, lane, cand, pairLo, pairHi, pairTop, occ);
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------
 // HBM <-> LDS
 // ------------------------------------------------------------------------------------------------
-DE_DEV void rc_load_env(const RcState& S, RcLds& L, int e, int lane, uint64_t occ) {
+DE_DEV void rc_load_env(const RcState& S, RcLds& L, int e, int lane, uint64_t occ, int W = 64) {  // W: lanes serving this environment
   const size_t E = (size_t)S.E;
   if (lane < RC_NB) {
     const bool used = lane == RC_BALL || lane < 2 * S.R;
@@ -1326,8 +1413,6 @@ DE_DEV void rc_load_env(const RcState& S, RcLds& L, int e, int lane, uint64_t oc
     // shape cache (position / rotation at the last integration) is stored in the 4 spare body fields
     L.cpx[lane] = used ? b[(RB_COUNT + 0) * E * RC_NB] : 0.0; L.cpy[lane] = used ? b[(RB_COUNT + 1) * E * RC_NB] : 0.0;
     L.crc[lane] = used ? b[(RB_COUNT + 2) * E * RC_NB] : 1.0; L.crs[lane] = used ? b[(RB_COUNT + 3) * E * RC_NB] : 0.0;
-    L.rc[lane] = 1.0; L.rs[lane] = 0.0; L.rotAng[lane] = 0.0;  // rot cache: rebuilt on first use (rotValid flag below)
-    L.still[lane] = 0;
   }
   if (lane < 16) {
     const bool used = lane < S.R;
@@ -1343,7 +1428,7 @@ DE_DEV void rc_load_env(const RcState& S, RcLds& L, int e, int lane, uint64_t oc
     L.fallc[lane] = used ? ri[RI_FALLC * E * 16] : 0;
     L.rrew[lane] = 0.0; L.rposrew[lane] = 0.0;
   }
-  if (lane < RE_COUNT) L.envi[lane] = S.envi[(size_t)e * RE_COUNT + lane];
+  for (int k = lane; k < RE_COUNT; k += W) L.envi[k] = S.envi[(size_t)e * RE_COUNT + k];
   if (lane < RD_COUNT) L.envd[lane] = S.envd[(size_t)e * RD_COUNT + lane];
   if (lane < 2) L.teamRew[lane] = 0.0;
   if (lane < RC_NS) {
@@ -1357,7 +1442,7 @@ DE_DEV void rc_load_env(const RcState& S, RcLds& L, int e, int lane, uint64_t oc
   }
 }
 
-DE_DEV void rc_store_env(const RcState& S, const RcLds& L, int e, int lane, uint64_t occ) {
+DE_DEV void rc_store_env(const RcState& S, const RcLds& L, int e, int lane, uint64_t occ, int W = 64) {
   const size_t E = (size_t)S.E;
   if (lane == RC_BALL || lane < 2 * S.R) {
     double* b = S.body + (size_t)e * RC_NB + lane;
@@ -1378,7 +1463,7 @@ DE_DEV void rc_store_env(const RcState& S, const RcLds& L, int e, int lane, uint
     int* ri = S.robi + (size_t)e * 16 + lane;
     ri[RI_FLAGS * E * 16] = L.rflags[lane]; ri[RI_TOUCHC * E * 16] = L.touchc[lane]; ri[RI_FALLC * E * 16] = L.fallc[lane];
   }
-  if (lane < RE_COUNT) S.envi[(size_t)e * RE_COUNT + lane] = L.envi[lane];
+  for (int k = lane; k < RE_COUNT; k += W) S.envi[(size_t)e * RE_COUNT + k] = L.envi[k];
   if (lane < RD_COUNT) S.envd[(size_t)e * RD_COUNT + lane] = L.envd[lane];
   if (lane < RC_NS && ((occ >> lane) & 1ull)) {
     size_t o = (size_t)e * RC_NS + lane;
@@ -1396,7 +1481,7 @@ DE_DEV void rc_store_env(const RcState& S, const RcLds& L, int e, int lane, uint
 #define RC_STD_NORM (2.0 / RC_W)
 DE_DEV double norm_after_scale(double pt, double nf, double mean) { return (pt - mean) * nf; }  // x team applied as a sign
 
-DE_DEV void rc_write_obs(RcLds& L, int lane, int R, int obs_dim, float* __restrict__ out) {
+DE_DEV void rc_write_obs(RcLds& L, int lane, int R, int obs_dim, float* __restrict__ out, int W = 64) {
   RcObsStage& O = L.u.ob;
   __syncthreads();
   if (lane < R) {
@@ -1414,14 +1499,14 @@ DE_DEV void rc_write_obs(RcLds& L, int lane, int R, int obs_dim, float* __restri
     O.team[lane] = (f & RF_TEAMPOS) ? 1.0f : -1.0f;
     O.down[lane] = (f & (RF_FALLEN | RF_PENAL)) ? 1.0f : 0.0f;
   }
-  if (lane == 32) {
+  if (lane == W - 1) {
     O.bx = (float)norm_after_scale(L.px[RC_BALL], RC_STD_NORM, RC_W / 2.0);
     O.by = (float)norm_after_scale(L.py[RC_BALL], RC_STD_NORM, RC_H / 2.0);
   }
   __syncthreads();
   const float owned = (float)L.envi[RE_OWNED];
   const int c0 = L.envi[RE_CLOSE0], c1 = L.envi[RE_CLOSE1];
-  for (int idx = lane; idx < R * obs_dim; idx += DE_WAVE) {
+  for (int idx = lane; idx < R * obs_dim; idx += W) {
     const int a = idx / obs_dim, ff = idx - a * obs_dim;
     const float team = O.team[a];
     float x;
@@ -1455,31 +1540,36 @@ DE_DEV void rc_write_obs(RcLds& L, int lane, int R, int obs_dim, float* __restri
 #ifndef RC_DEFER_MIN_GENERAL
 #define RC_DEFER_MIN_GENERAL 25 /* rc_physics substeps (of 50) from which an environment defers its Partial observation */
 #endif
-template <bool PARTIAL>
-DE_DEV void rc_step_body(const RcState& S, const int* __restrict__ actions, float* __restrict__ obs, double* __restrict__ rewards,
-                         uint8_t* __restrict__ dones) {
-  RcLds& L = g_R;
-  const int e = blockIdx.x, lane = threadIdx.x, R = S.R;
-  uint64_t occ = (uint64_t)(uint32_t)uniform_i(S.envi[(size_t)e * RE_COUNT + RE_OCC]);
+template <bool PARTIAL, int EPW>
+DE_DEV void rc_step_body(const RcState& S, const int* __restrict__ actions, const double* __restrict__ headActions, float* __restrict__ obs,
+                         double* __restrict__ rewards, uint8_t* __restrict__ dones) {
+  typedef Grp<EPW> G;
+  constexpr int W = G::W, NROUNDS = (RC_NPAIR_ROUNDS * 64) / W;
+  static_assert(!PARTIAL || EPW == 1, "the fused Partial observation works on one environment per wave");
+  const int e = (int)blockIdx.x * EPW + G::id(), lane = G::lane(), R = S.R;
+  if (e >= S.E) return;  // an odd batch: the last wave's second half has no environment (its lanes are off from here on)
+  RcLds& L = G::tile();
+  uint64_t occ = (uint64_t)(uint32_t)G::uniform_i(S.envi[(size_t)e * RE_COUNT + RE_OCC]);
   // Environments with live contacts are the long ones and the launch ends with the slowest: their waves get issue priority
-  // over the (three) lighter waves they share a SIMD with, from the first instruction on.
+  // over the lighter waves they share a SIMD with, from the first instruction on.
   if (occ != 0ull) __builtin_amdgcn_s_setprio(3);
-  rc_load_env(S, L, e, lane, occ);
+  rc_load_env(S, L, e, lane, occ, W);
   RcCtx c;
   c.seed = S.seed; c.genv = (uint32_t)(S.env_id_offset + e); c.n = S.n; c.R = R;
-  c.canFall = (S.flags & 4) != 0; c.allowHead = (S.flags & 16) != 0;
+  c.canFall = (S.flags & DYNENV_FLAG_CAN_FALL) != 0; c.allowHead = (S.flags & DYNENV_FLAG_ALLOW_HEAD_TURN) != 0;
+  c.detTurn = (S.flags & DYNENV_FLAG_DETERMINISTIC_TURN) != 0;
   int err = 0;
-  uint64_t pairLo = 0ull, pairHi = 0ull;
+  uint64_t pairLo = 0ull, pairHi = 0ull, pairTop = 0ull;
   int feetPairs = 0;  // bit t: my pair of round t is the two feet of one robot
 #pragma unroll
-  for (int t = 0; t < RC_NPAIR_ROUNDS; ++t) {
-    int pr = RC.pairs[t * 64 + lane];
+  for (int t = 0; t < NROUNDS; ++t) {
+    int pr = RC.pairs[t * W + lane];
     int i = pr >> 8, j = pr & 0xFF;
     bool ok = pr != 0xFFFF;
     if (ok && i < RC_BALL) ok = i < 2 * R;
     if (ok && j < RC_BALL) ok = j < 2 * R;
     uint64_t v = (uint64_t)(ok ? pr : 0xFFFF);
-    if (t < 4) pairLo |= v << (16 * t); else pairHi |= v << (16 * (t - 4));
+    if (t < 4) pairLo |= v << (16 * t); else if (t < 8) pairHi |= v << (16 * (t - 4)); else pairTop |= v << (16 * (t - 8));
     if (ok && j < RC_BALL && j == i + 1 && !(i & 1)) feetPairs |= 1 << t;
   }
   __syncthreads();
@@ -1489,13 +1579,16 @@ DE_DEV void rc_step_body(const RcState& S, const int* __restrict__ actions, floa
   const bool partial = PARTIAL;
   const bool isBody = lane == RC_BALL || lane < 2 * R;
   const int* myActions = actions + (size_t)e * R * 4;
+  const double* myHead = headActions ? headActions + (size_t)e * R : nullptr;
   int snap = 0, nGeneral = 0;  // substeps that went through rc_physics
+  double rotC = 1.0, rotS = 0.0, rotAng = 0.0;  // (cos, sin) of my body's angle as of rotAng
+  bool rotValid = false;
 
 RC_PROF(if (lane < 12 && e < 4096) g_rcprof[e * 12 + lane] = 0ull; const unsigned long long K0 = __builtin_amdgcn_s_memtime(); unsigned long long tG = 0, tP = 0, tB = 0;)
   for (int it = 0; it < 50; ++it) {
 RC_PROF(const unsigned long long A0 = __builtin_amdgcn_s_memtime();)
     // ---- sequential game logic (lane 0): processAction / tick per robot, then the ball (:465-475) ----------
-    rc_game_logic(c, it, myActions, lane);
+    rc_game_logic<EPW>(c, it, myActions, myHead, lane);
     __syncthreads();
 RC_PROF(const unsigned long long A1 = __builtin_amdgcn_s_memtime();)
     // ---- cpBodyUpdatePosition + shape cache + AABB ------------------------------------------------------
@@ -1507,11 +1600,11 @@ RC_PROF(const unsigned long long A1 = __builtin_amdgcn_s_memtime();)
       L.vbx[lane] = 0.0; L.vby[lane] = 0.0; L.wb[lane] = 0.0;
       float fcx, fcy, fhx, fhy;
       if (lane != RC_BALL) {
-        if (nang != L.rotAng[lane] || L.still[lane] == 0) {  // still[] doubles as "rot cache valid" (0 at kernel entry)
+        if (nang != rotAng || !rotValid) {  // this lane's rotation cache (registers): invalid at kernel entry
           const DevSC sc = dev_sincos(nang);
-          L.rc[lane] = sc.c; L.rs[lane] = sc.s; L.rotAng[lane] = nang; L.still[lane] = 1;
+          rotC = sc.c; rotS = sc.s; rotAng = nang; rotValid = true;
         }
-        L.cpx[lane] = npx; L.cpy[lane] = npy; L.crc[lane] = L.rc[lane]; L.crs[lane] = L.rs[lane];
+        L.cpx[lane] = npx; L.cpy[lane] = npy; L.crc[lane] = rotC; L.crs[lane] = rotS;
         SegW s;
         seg_world(L, lane, s);
         double l, r, b, t;
@@ -1535,7 +1628,7 @@ RC_PROF(const unsigned long long A2 = __builtin_amdgcn_s_memtime();)
     // keeps the double-precision box test below for the rare real prefilter hits.
     int cand = feetPairs;
 #pragma unroll 1
-    for (int t = 0; t < RC_NPAIR_ROUNDS; ++t) {
+    for (int t = 0; t < NROUNDS; ++t) {
       const int pr = RC_MY_PAIR(t);
       if (pr != 0xFFFF && !((feetPairs >> t) & 1)) {
         const int i = pr >> 8, j = pr & 0xFF;
@@ -1554,26 +1647,29 @@ RC_PROF(const unsigned long long A2 = __builtin_amdgcn_s_memtime();)
     }
     __syncthreads();
 RC_PROF(const unsigned long long A3 = __builtin_amdgcn_s_memtime(); tG += A1 - A0; tP += A2 - A1; tB += A3 - A2;)
-    // ---- contacts, joints, velocity update, solver, post-solve callbacks (out of line) -----------------------
-    // The common substep never enters rc_physics (whose register footprint costs ~150 scratch accesses per lane and
-    // call in callee-saved registers): no cached arbiter, the only candidates are the robots' own feet pairs, and the
-    // narrowphase's separating-axis early out rejects every one of them.  What rc_physics does then is exactly this:
+    // ---- contacts, joints, velocity update, solver, post-solve callbacks -----------------------------------------
+    // The common substep never enters rc_physics: no cached arbiter, the only candidates are the robots' own feet pairs, and
+    // the narrowphase's separating-axis early out rejects every one of them.  What rc_physics does then is exactly this:
     // velocity update, then every robot's joints (prestep, warm start, 10 iterations) in registers.
-    bool quiet = occ == 0ull && wave_ballot((cand & ~feetPairs) != 0) == 0ull;
+    bool quiet = occ == 0ull && G::ballot((cand & ~feetPairs) != 0) == 0ull;
     if (quiet) {
       const bool far = lane < R ? feet_far_apart(L, lane) : true;
-      quiet = wave_ballot(!far) == 0ull;
+      quiet = G::ballot(!far) == 0ull;
     }
     if (quiet) {
       if (isBody) rc_velocity_update(L, lane);
       __syncthreads();
-      rc_joints_only(lane, R);
+#if RC_QUIET_JOINTS_INLINE
+      rc_joints_only_inl<EPW>(lane, R);
+#else
+      rc_joints_only<EPW>(lane, R);
+#endif
       __syncthreads();
     } else {
       __builtin_amdgcn_s_setprio(3);  // an environment with contact work is on the launch's critical path: issue it first
       ++nGeneral;
-      const RcStepRet sr = rc_physics(c, lane, cand, pairLo, pairHi, occ);
-      occ = uniform_u64(sr.occ); err |= sr.err;
+      const RcStepRet sr = rc_physics<EPW>(c, lane, cand, pairLo, pairHi, pairTop, occ);
+      occ = G::uniform_u64(sr.occ); err |= sr.err;
     }
     if (lane == 0) L.envi[RE_ELAPSED] += 1;
     __syncthreads();
@@ -1584,7 +1680,7 @@ RC_PROF(const unsigned long long A3 = __builtin_amdgcn_s_memtime(); tG += A1 - A
         if (lane < 20) sn.ang[lane] = L.ang[lane];
         if (lane < 10) { sn.head[lane] = L.head[lane]; sn.rflags[lane] = L.rflags[lane]; }
         if (lane == 0) { sn.owned = L.envi[RE_OWNED]; sn.close0 = L.envi[RE_CLOSE0]; sn.close1 = L.envi[RE_CLOSE1]; sn.tkey = L.envi[RE_ELAPSED]; }
-      } else if (obs) rc_write_obs(L, lane, R, S.obs_dim, obs + ((size_t)e * 5 + snap) * R * S.obs_dim);
+      } else if (obs) rc_write_obs(L, lane, R, S.obs_dim, obs + ((size_t)e * 5 + snap) * R * S.obs_dim, W);
       ++snap;
     }
   }
@@ -1619,18 +1715,28 @@ RC_PROF(if (lane == 0 && e < 4096) { unsigned long long* d = g_rcprof + e * 12; 
     if (deferObs) S.deferList[1 + atomicAdd(&S.deferList[0], 1)] = e;
   }
   __syncthreads();
-  rc_store_env(S, L, e, lane, occ);
-  if (PARTIAL && obs && !deferObs) rc_partial_obs_fused(S, e, lane, obs, rewards);  // getAgentVision at the five snapshots + processSeens
+  rc_store_env(S, L, e, lane, occ, W);
+  if constexpr (PARTIAL) {
+    if (obs && !deferObs) rc_partial_obs_fused(S, e, lane, obs, rewards);  // getAgentVision at the five snapshots + processSeens
+  }
+}
+#include "robocup_rpl.hip"
+
+// Full observations.  RC_FULL_EPW = 2: two environments per wave, E / 2 waves at two per SIMD (256 VGPRs, everything inline,
+// no scratch); = 1: one environment per wave at four per SIMD (128 VGPRs, the general path out of line).
+extern "C" __global__ void __launch_bounds__(64, RC_FULL_EPW == 2 ? 2 : RC_WAVES_PER_SIMD)
+rc_step_kernel(RcState S, const int* __restrict__ actions, const double* __restrict__ headActions, float* __restrict__ obs,
+               double* __restrict__ rewards, uint8_t* __restrict__ dones) {
+#if RC_RPL
+  rc_step_rpl_body<RC_FULL_EPW>(S, actions, headActions, obs, rewards, dones);  // one lane per robot, the common substep in registers
+#else
+  rc_step_body<false, RC_FULL_EPW>(S, actions, headActions, obs, rewards, dones);
+#endif
 }
 extern "C" __global__ void __launch_bounds__(64, RC_WAVES_PER_SIMD)
-rc_step_kernel(RcState S, const int* __restrict__ actions, float* __restrict__ obs, double* __restrict__ rewards,
-               uint8_t* __restrict__ dones) {
-  rc_step_body<false>(S, actions, obs, rewards, dones);
-}
-extern "C" __global__ void __launch_bounds__(64, RC_WAVES_PER_SIMD)
-rc_step_partial_kernel(RcState S, const int* __restrict__ actions, float* __restrict__ obs, double* __restrict__ rewards,
-                       uint8_t* __restrict__ dones) {
-  rc_step_body<true>(S, actions, obs, rewards, dones);
+rc_step_partial_kernel(RcState S, const int* __restrict__ actions, const double* __restrict__ headActions, float* __restrict__ obs,
+                       double* __restrict__ rewards, uint8_t* __restrict__ dones) {
+  rc_step_body<true, 1>(S, actions, headActions, obs, rewards, dones);
 }
 
 extern "C" __global__ void __launch_bounds__(64) rc_obs_kernel(RcState S, float* __restrict__ obs) {
@@ -1655,7 +1761,7 @@ extern "C" __global__ void __launch_bounds__(64) rc_obs_kernel(RcState S, float*
 }
 
 // ------------------------------------------------------------------------------------------------
-// reset: one thread per environment (RoboCupEnvironment.__init__ + _setup_scene, randomInit = False)
+// reset: one thread per environment (RoboCupEnvironment.__init__ + _setup_scene :73-99, :239-336; both randomInit modes)
 // ------------------------------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(64) rc_reset_kernel(RcState S) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1673,10 +1779,45 @@ extern "C" __global__ void __launch_bounds__(64) rc_reset_kernel(RcState S) {
     S.epr[(size_t)e * 16 + k] = 0.0; S.epr[E * 16 + (size_t)e * 16 + k] = 0.0; S.epo[(size_t)e * 16 + k] = 0.0;
   }
   for (int k = 0; k < RC_NS; ++k) { S.s_pair[(size_t)e * RC_NS + k] = 0xFFFF; S.s_meta[(size_t)e * RC_NS + k] = 0; }
-  double rnd[18];
-  for (int i = 0; i < 18; ++i) rnd[i] = dm_unit(dm_env_rng(S.seed, genv, ep, DM_RNG_ROBO_RESET, (uint32_t)i, 0).v[0]);
+  double rnd[24];
+  for (int i = 0; i < 24; ++i) rnd[i] = dm_unit(dm_env_rng(S.seed, genv, ep, DM_RNG_ROBO_RESET, (uint32_t)i, 0).v[0]);
   const double centX = RC_W / 2.0;
+  const bool randomInit = (S.flags & DYNENV_FLAG_RANDOM_INIT) != 0, detTurn = (S.flags & DYNENV_FLAG_DETERMINISTIC_TURN) != 0;
   V2 spots[2][5];  // _create_robot_spots :275-293
+  V2 ballPos = v2(520.0, 370.0);  // W // 2, H // 2
+  int owned = 1;
+  if (randomInit) {
+    // :241-272: one random spot in each of 10 field cells (20 random.random() draws in source order); the goal-side cells go
+    // to the two teams, np.random.permutation(8) deals the 8 middle ones
+    const double xL[7] = {RC_SIDE + 10.0, RC_SIDE + 50.0, RC_SIDE + 250.0, RC_SIDE + 450.0, RC_SIDE + 650.0, RC_SIDE + 850.0, RC_SIDE + 890.0};
+    const double yL[3] = {RC_SIDE + 20.0, RC_SIDE + 300.0, RC_SIDE + 580.0};
+    V2 rs[10];
+    int k = 0, d = 0;
+    for (int i = 0; i < 6; ++i) {
+      const bool edge = i == 0 || i == 5;
+      for (int j = 0; j < (edge ? 1 : 2); ++j) {
+        const double yBeg = edge ? yL[0] : yL[j], yEnd = edge ? yL[2] : yL[j + 1];
+        const double x = xL[i] + rnd[d] * (xL[i + 1] - xL[i]);
+        const double y = yBeg + rnd[d + 1] * (yEnd - yBeg);
+        d += 2;
+        rs[k++] = v2(x, y);
+      }
+    }
+    int perm8[8];
+    for (int i = 0; i < 8; ++i) perm8[i] = i;
+    for (int i = 0; i < 7; ++i) {
+      dm_u32x4 u = dm_env_rng(S.seed, genv, ep, DM_RNG_ROBO_RESET, (uint32_t)(48 + i), 0);
+      int j = i + dm_randint(u.v[0], 0, 7 - i);
+      int tmp = perm8[i]; perm8[i] = perm8[j]; perm8[j] = tmp;
+    }
+    int cnt[2] = {1, 1};
+    spots[0][0] = rs[0]; spots[1][0] = rs[9];
+    for (int i = 0; i < 8; ++i) { const int t = i < 4 ? 0 : 1; spots[t][cnt[t]++] = rs[perm8[i] + 1]; }
+    // _create_ball :325-331
+    ballPos = v2(rnd[20] * 900.0 + RC_SIDE, rnd[21] * 600.0 + RC_SIDE);
+    owned = rnd[22] > 0.4 ? 1 : 0;
+    if (owned != 0 && rnd[23] > 0.5) owned *= -1;
+  } else {
   spots[0][0] = v2(centX - (5.0 * 2.0 + ROBOT_TOTAL_RADIUS) - rnd[0] * 50.0, RC_H / 2.0 + (rnd[1] - 0.5) * 25.0);
   spots[0][1] = v2(centX - (ROBOT_TOTAL_RADIUS + 5.0 * 2.0) - rnd[2] * 50.0, RC_SIDE + 600.0 / 4.0 + (rnd[3] - 0.5) * 50.0);
   spots[0][2] = v2(centX - (ROBOT_TOTAL_RADIUS + 5.0 * 2.0) - rnd[4] * 50.0, RC_SIDE + 3.0 * 600.0 / 4.0 + (rnd[5] - 0.5) * 50.0);
@@ -1687,6 +1828,7 @@ extern "C" __global__ void __launch_bounds__(64) rc_reset_kernel(RcState S) {
   spots[1][2] = v2(centX + (ROBOT_TOTAL_RADIUS + 5.0 / 2.0 + 75.0) + rnd[13] * 50.0, RC_SIDE + 3.0 * 600.0 / 4.0 + (rnd[14] - 0.5) * 50.0);
   spots[1][3] = v2(centX + (RC_SIDE + 900.0 / 4.0) + rnd[15] * 50.0, RC_SIDE + 600.0 / 2.0 + (rnd[16] - 0.5) * 50.0);
   spots[1][4] = v2(RC_W - (RC_SIDE + 20.0), RC_H / 2.0 + (rnd[17] - 0.5) * 50.0);
+  }
   int perm[2][5];
   for (int t = 0; t < 2; ++t) {
     for (int i = 0; i < 5; ++i) perm[t][i] = i;
@@ -1712,19 +1854,20 @@ extern "C" __global__ void __launch_bounds__(64) rc_reset_kernel(RcState S) {
     // prevPos = getPos() = (p + p) / 2
     S.rob[RR_PREVX * E * 16 + r] = (pos.x + pos.x) / 2.0; S.rob[RR_PREVY * E * 16 + r] = (pos.y + pos.y) / 2.0;
     S.robi[RI_FLAGS * E * 16 + r] = team > 0 ? RF_TEAMPOS : 0;
+    if (detTurn) S.rob[RR_HEAD * E * 16 + r] = (double)team * ROBOT_HEAD_MAX;  // :317-319
   }
   {
     size_t b = (size_t)e * RC_NB + RC_BALL;
-    S.body[RB_PX * E * RC_NB + b] = 520.0; S.body[RB_PY * E * RC_NB + b] = 370.0;
-    S.body[(RB_COUNT + 0) * E * RC_NB + b] = 520.0; S.body[(RB_COUNT + 1) * E * RC_NB + b] = 370.0;
+    S.body[RB_PX * E * RC_NB + b] = ballPos.x; S.body[RB_PY * E * RC_NB + b] = ballPos.y;
+    S.body[(RB_COUNT + 0) * E * RC_NB + b] = ballPos.x; S.body[(RB_COUNT + 1) * E * RC_NB + b] = ballPos.y;
   }
   for (int k = 0; k < RE_COUNT; ++k) envi[k] = 0;
-  envi[RE_OWNED] = 1; envi[RE_EPISODE] = (int)(ep + 1);
+  envi[RE_OWNED] = owned; envi[RE_EPISODE] = (int)(ep + 1);
   envi[RE_NCON] = 2 * S.R;
   for (int k = 0; k < 2 * S.R; ++k) envi[RE_CORDER + k] = k;  // add order: joint, rotJoint per robot (:321-323)
   for (int k = 0; k < RD_COUNT; ++k) envd[k] = 0.0;
   envd[RD_FREECNT] = 9999.0; envd[RD_GRACE] = 0.0; envd[RD_PT0] = 20000.0; envd[RD_PT1] = 20000.0;
-  envd[RD_BPREVX] = 520.0; envd[RD_BPREVY] = 370.0;
+  envd[RD_BPREVX] = ballPos.x; envd[RD_BPREVY] = ballPos.y;
 }
 
 extern "C" __global__ void rc_stats_kernel(RcState S, double* ep_r, double* ep_pos_r, double* ep_obs_r, int* goals) {

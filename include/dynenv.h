@@ -47,7 +47,9 @@ extern "C" {
 #define DYNENV_ERR_UNSUPPORTED (-4)
 #define DYNENV_ERR_ACTION (-5) /* reference raises on malformed actions, DrivingEnvironment.py:262-263,365-368 */
 
-/* RoboCup class-level switches (RoboCupEnvironment.py:18-21) */
+/* RoboCup class-level switches (RoboCupEnvironment.py:18-21): randomInit (:241, :326 random robot spots, ball position and
+ * ownership), deterministicTurn (:317 head starts at team * headMaxAngle, :529 the head action is forced to -3 * team),
+ * canFall, useObsRewards; and the constructor's allowHeadTurn (:24, :339, :539).  All five are implemented. */
 #define DYNENV_FLAG_RANDOM_INIT 1
 #define DYNENV_FLAG_DETERMINISTIC_TURN 2
 #define DYNENV_FLAG_CAN_FALL 4
@@ -156,6 +158,14 @@ int dynenv_reset(dynenv_t* h, float* obs_dev, void* stream);
  * observation reward of processSeens (RoboCupEnvironment.py:497-524) and come out of the same pass: DYNENV_ERR_ARG then. */
 int dynenv_step(dynenv_t* h, const int32_t* actions_dev, float* obs_dev, double* rewards_dev, uint8_t* dones_dev,
                 void* stream);
+
+/* dynenv_step with the reference's continuous head action: RoboCup built with allowHeadTurn (make_dyn_env's
+ * use_continuous_actions, DynEnv/__init__.py:11) takes Tuple((MultiDiscrete([5, 3, 3]), Box(-3, 3, (1,))))
+ * (RoboCupEnvironment.py:339-342); head_dev float64 [E, A] carries the Box channel (turnHead(head), Robot.py:136-138),
+ * actions_dev[..., 3] is ignored then.  head_dev == NULL: the discrete head action of actions_dev[..., 3] (what dynenv_step
+ * does).  DYNENV_ERR_ARG unless the handle is RoboCup with DYNENV_FLAG_ALLOW_HEAD_TURN. */
+int dynenv_step_head(dynenv_t* h, const int32_t* actions_dev, const double* head_dev, float* obs_dev, double* rewards_dev,
+                     uint8_t* dones_dev, void* stream);
 
 /* Per-env object counts of the current episode: int32 [E, 2] = (n_obstacles, n_pedestrians) (Driving). */
 int dynenv_counts(dynenv_t* h, int32_t* counts_dev, void* stream);
