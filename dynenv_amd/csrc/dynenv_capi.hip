@@ -149,6 +149,7 @@ static int rc_create(dynenv* h) {
   rc |= dev_alloc(h, &R.prew0, E * 16);
   rc |= dev_alloc(h, &R.seenPart, (size_t)E * 5 * 10 * RCP_SEEN_STRIDE);
   rc |= dev_alloc(h, &R.deferList, (size_t)E + 1);
+  rc |= dev_alloc(h, &R.sched, (size_t)2 * E + 1);
   rc |= dev_alloc(h, &R.s_pair, E * RC_NS);
   rc |= dev_alloc(h, &R.s_meta, E * RC_NS);
   rc |= dev_alloc(h, &R.s_hash, 2 * E * RC_NS);
@@ -488,7 +489,14 @@ int dynenv_step_head(dynenv_t* h, const int32_t* actions_dev, const double* head
     else if (h->R.obs_type == DYNENV_OBS_PARTIAL)
       return fail(DYNENV_ERR_ARG, "RoboCup Partial: the observation buffer is required (the processSeens rewards come out of the same pass)");
     else
+#if RC_SCHED
+    {  // heavy environments solo, the others two per wave (robocup_kernels.hip "the scheduled step"); the table is scratch
+      hipLaunchKernelGGL(rc_schedule_kernel, dim3(1), dim3(1024), 0, st, h->R, h->R.sched);
+      hipLaunchKernelGGL(rc_step_sched_kernel, dim3(h->R.E), dim3(64), 0, st, h->R, (const int*)h->R.sched, (const int*)actions_dev, head_dev, obs_dev, rewards_dev, dones_dev);
+    }
+#else
       hipLaunchKernelGGL(rc_step_kernel, dim3((h->R.E + RC_FULL_EPW - 1) / RC_FULL_EPW), dim3(64), 0, st, h->R, (const int*)actions_dev, head_dev, obs_dev, rewards_dev, dones_dev);
+#endif
     HIP_OK(hipGetLastError());
     return DYNENV_OK;
   }

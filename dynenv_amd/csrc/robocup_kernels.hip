@@ -23,6 +23,9 @@ __constant__ RcConst RC;
 #ifndef RC_FULL_EPW
 #define RC_FULL_EPW 1 /* environments per wave of rc_step_kernel (Full observations): 1 or 2, see Grp<> */
 #endif
+#ifndef RC_SCHED
+#define RC_SCHED 0 /* 1: dynenv_step launches rc_schedule_kernel + rc_step_sched_kernel for Full observations */
+#endif
 #ifndef RC_RPL
 #define RC_RPL (RC_FULL_EPW == 2) /* robocup_rpl.hip: one lane per robot, the common substep in registers (0: the foot-per-lane rc_step_body) */
 #endif
@@ -96,6 +99,33 @@ template <> struct Grp<1> {
   DE_DEV static int lane() { return (int)threadIdx.x; }
   DE_DEV static int id() { return 0; }
   DE_DEV static RcLds& tile() { return g_R; }
+  DE_DEV static uint64_t ballot(bool p) { return __ballot(p); }
+  DE_DEV static uint64_t lt_mask() { return ::lanemask_lt(); }
+  DE_DEV static int bcast_i(int v, int src) { return ::bcast_i(v, src); }
+  DE_DEV static double bcast_d(double v, int src) { return ::bcast_d(v, src); }
+  DE_DEV static uint64_t uniform_u64(uint64_t v) { return ::uniform_u64(v); }
+  DE_DEV static int uniform_i(int v) { return ::uniform_i(v); }
+};
+// Grp<3>: Grp<1>'s lane roles and wave-uniform cross-lane traffic for an environment that has a whole wave to itself inside the
+// two-tiles-per-wave kernel (rc_step_sched_kernel's "solo" mode): its tile is the wave's first one, nothing is out of line
+// (the kernel's budget is 256 VGPRs).
+template <> struct Grp<3> {
+  static constexpr int W = 64, JL0 = 32, OBS_BALL_LANE = 32;
+  DE_DEV static int lane() { return (int)threadIdx.x; }
+  DE_DEV static int id() { return 0; }
+  DE_DEV static RcLds& tile() { return g_R2[0]; }
+  DE_DEV static uint64_t ballot(bool p) { return __ballot(p); }
+  DE_DEV static uint64_t lt_mask() { return ::lanemask_lt(); }
+  DE_DEV static int bcast_i(int v, int src) { return ::bcast_i(v, src); }
+  DE_DEV static double bcast_d(double v, int src) { return ::bcast_d(v, src); }
+  DE_DEV static uint64_t uniform_u64(uint64_t v) { return ::uniform_u64(v); }
+  DE_DEV static int uniform_i(int v) { return ::uniform_i(v); }
+};
+template <> struct Grp<4> {  // Grp<3> on the wave's second tile
+  static constexpr int W = 64, JL0 = 32, OBS_BALL_LANE = 32;
+  DE_DEV static int lane() { return (int)threadIdx.x; }
+  DE_DEV static int id() { return 0; }
+  DE_DEV static RcLds& tile() { return g_R2[1]; }
   DE_DEV static uint64_t ballot(bool p) { return __ballot(p); }
   DE_DEV static uint64_t lt_mask() { return ::lanemask_lt(); }
   DE_DEV static int bcast_i(int v, int src) { return ::bcast_i(v, src); }
@@ -1018,7 +1048,7 @@ __device__ __noinline__ void rc_joints_only_ool(int lane, int R) { rc_joints_onl
 template <int EPW>
 DE_DEV void rc_joints_only(int lane, int R) {
   if (EPW == 1) rc_joints_only_ool(lane, R);
-  else rc_joints_only_inl<EPW>(lane, R);
+  else rc_joints_only_inl<EPW>(lane, R);  // (2, 3: a 256-VGPR kernel)
 }
 
 #ifdef DRV_PROFILE
@@ -1373,7 +1403,7 @@ RC_PROF(const unsigned long long T5 = __builtin_amdgcn_s_memtime();)
     occ &= ~G::ballot(freeMe);
   }
   __syncthreads();
-RC_PROF(if (lane == 0 && blockIdx.x * EPW + G::id() < 4096) { unsigned long long* d = g_rcprof + (blockIdx.x * EPW + G::id()) * 12; const unsigned long long T6 = __builtin_amdgcn_s_memtime(); d[3] += T1 - T0; d[4] += T2 - T1; d[5] += T3 - T2; d[6] += T4 - T3; d[7] += T5 - T4; d[8] += T6 - T5; d[9] += (unsigned long long)nTouched; d[10] += (unsigned long long)(maxLevel + 1); })
+RC_PROF(if (lane == 0 && c.genv < 4096u) { unsigned long long* d = g_rcprof + c.genv * 12;  /* (profile runs: env_id_offset 0) */ const unsigned long long T6 = __builtin_amdgcn_s_memtime(); d[3] += T1 - T0; d[4] += T2 - T1; d[5] += T3 - T2; d[6] += T4 - T3; d[7] += T5 - T4; d[8] += T6 - T5; d[9] += (unsigned long long)nTouched; d[10] += (unsigned long long)(maxLevel + 1); })
   RcStepRet ret;
   ret.occ = occ; ret.err = err;
   return ret;
@@ -1382,12 +1412,17 @@ RC_PROF(if (lane == 0 && blockIdx.x * EPW + G::id() < 4096) { unsigned long long
 __device__ RC_PHYS_INLINE RcStepRet rc_physics_ool(RcCtx c, int lane, int cand, uint64_t pairLo, uint64_t pairHi, uint64_t occ) {
   return rc_physics_inl<1>(c, lane, cand, pairLo, pairHi, 0ull, occ);
 }
+__device__ __noinline__ RcStepRet rc_physics_ool3(RcCtx c, int lane, int cand, uint64_t pairLo, uint64_t pairHi, uint64_t occ) {
+  return rc_physics_inl<3>(c, lane, cand, pairLo, pairHi, 0ull, occ);
+}
 __device__ __noinline__ RcStepRet rc_physics_ool2(RcCtx c, int lane, int cand, uint64_t pairLo, uint64_t pairHi, uint64_t pairTop, uint64_t occ) {
   return rc_physics_inl<2>(c, lane, cand, pairLo, pairHi, pairTop, occ);
 }
 template <int EPW>
 DE_DEV RcStepRet rc_physics(RcCtx c, int lane, int cand, uint64_t pairLo, uint64_t pairHi, uint64_t pairTop, uint64_t occ) {
   if (EPW == 1) return rc_physics_ool(c, lane, cand, pairLo, pairHi, occ);
+  if (EPW == 3) return rc_physics_ool3(c, lane, cand, pairLo, pairHi, occ);
+  if (EPW == 4) return rc_physics_inl<4>(c, lane, cand, pairLo, pairHi, 0ull, occ);  // (only ever called from the out-of-line rpl_general_physics<4>)
 #ifdef RC_PHYS2_OOL  /* analysis builds: keeps the general path out of the step kernel's listing */
   return rc_physics_ool2(c, lane, cand, pairLo, pairHi, pairTop, occ);
 #else
@@ -1541,13 +1576,13 @@ DE_DEV void rc_write_obs(RcLds& L, int lane, int R, int obs_dim, float* __restri
 #define RC_DEFER_MIN_GENERAL 25 /* rc_physics substeps (of 50) from which an environment defers its Partial observation */
 #endif
 template <bool PARTIAL, int EPW>
-DE_DEV void rc_step_body(const RcState& S, const int* __restrict__ actions, const double* __restrict__ headActions, float* __restrict__ obs,
+DE_DEV void rc_step_body(const RcState& S, const int e, const int* __restrict__ actions, const double* __restrict__ headActions, float* __restrict__ obs,
                          double* __restrict__ rewards, uint8_t* __restrict__ dones) {
   typedef Grp<EPW> G;
   constexpr int W = G::W, NROUNDS = (RC_NPAIR_ROUNDS * 64) / W;
   static_assert(!PARTIAL || EPW == 1, "the fused Partial observation works on one environment per wave");
-  const int e = (int)blockIdx.x * EPW + G::id(), lane = G::lane(), R = S.R;
-  if (e >= S.E) return;  // an odd batch: the last wave's second half has no environment (its lanes are off from here on)
+  const int lane = G::lane(), R = S.R;
+  if (e < 0 || e >= S.E) return;  // (two environments per wave: a half without an environment; its lanes are off from here on)
   RcLds& L = G::tile();
   uint64_t occ = (uint64_t)(uint32_t)G::uniform_i(S.envi[(size_t)e * RE_COUNT + RE_OCC]);
   // Environments with live contacts are the long ones and the launch ends with the slowest: their waves get issue priority
@@ -1728,15 +1763,70 @@ extern "C" __global__ void __launch_bounds__(64, RC_FULL_EPW == 2 ? 2 : RC_WAVES
 rc_step_kernel(RcState S, const int* __restrict__ actions, const double* __restrict__ headActions, float* __restrict__ obs,
                double* __restrict__ rewards, uint8_t* __restrict__ dones) {
 #if RC_RPL
-  rc_step_rpl_body<RC_FULL_EPW>(S, actions, headActions, obs, rewards, dones);  // one lane per robot, the common substep in registers
+  rc_step_rpl_body<RC_FULL_EPW>(S, (int)blockIdx.x * RC_FULL_EPW + Grp<RC_FULL_EPW>::id(), actions, headActions, obs, rewards, dones);  // one lane per robot, the common substep in registers
 #else
-  rc_step_body<false, RC_FULL_EPW>(S, actions, headActions, obs, rewards, dones);
+  rc_step_body<false, RC_FULL_EPW>(S, (int)blockIdx.x * RC_FULL_EPW + Grp<RC_FULL_EPW>::id(), actions, headActions, obs, rewards, dones);
 #endif
+}
+
+// ---- the scheduled step: who runs where is decided per step from the contact caches ------------------------------------------
+// An environment that enters the step with a cached arbiter (bodies in touch: it will spend the step in the general solve, and
+// contacts persist for many steps) gets a wave of its own and the foot-per-lane code with wave-uniform control flow
+// (rc_step_body<false, 3>); all others share waves two by two in the register-resident layout (rc_step_rpl_body<2>).  Waves
+// are numbered heavy environments first, so the long ones start first.  The table is rebuilt before every step launch by
+// rc_schedule_kernel (one block; a prefix sum over the E occupancy words - deterministic, unlike an atomic queue):
+// table[0] = number of waves with work, table[1 + 2 b], table[2 + 2 b] = the environments of wave b (-1: none; a solo wave
+// has -2 in the second place).
+extern "C" __global__ void __launch_bounds__(1024) rc_schedule_kernel(RcState S, int* __restrict__ table) {
+  __shared__ int waveHeavy[16], waveLight[16];
+  __shared__ int totHeavy;
+  const int tid = threadIdx.x, wave = tid >> 6, ln = tid & 63;
+  const int E = S.E, per = (E + 1023) / 1024;  // contiguous chunk of environments per thread keeps ids ascending
+  int nh = 0, nl = 0;
+  for (int k = 0; k < per; ++k) {
+    const int e = tid * per + k;
+    if (e < E) { if (S.envi[(size_t)e * RE_COUNT + RE_OCC] != 0) ++nh; else ++nl; }
+  }
+  // exclusive scan over the threads: inside the wave by shuffles, across the 16 waves through LDS
+  int ih = nh, il = nl;
+  for (int d = 1; d < 64; d <<= 1) {
+    const int th = __shfl_up(ih, d, 64), tl = __shfl_up(il, d, 64);
+    if (ln >= d) { ih += th; il += tl; }
+  }
+  if (ln == 63) { waveHeavy[wave] = ih; waveLight[wave] = il; }
+  __syncthreads();
+  int baseH = 0, baseL = 0, allH = 0;
+  for (int w = 0; w < 16; ++w) { if (w < wave) { baseH += waveHeavy[w]; baseL += waveLight[w]; } allH += waveHeavy[w]; }
+  if (tid == 0) totHeavy = allH;
+  __syncthreads();
+  int oh = baseH + ih - nh, ol = baseL + il - nl;  // my first heavy / light ordinal
+  for (int k = 0; k < per; ++k) {
+    const int e = tid * per + k;
+    if (e < E) {
+      if (S.envi[(size_t)e * RE_COUNT + RE_OCC] != 0) { table[1 + 2 * oh] = e; table[2 + 2 * oh] = -2; ++oh; }
+      else { table[1 + 2 * (allH + (ol >> 1)) + (ol & 1)] = e; ++ol; }
+    }
+  }
+  __syncthreads();
+  if (tid == 1023) {  // the last thread knows the totals
+    const int nLight = ol;
+    if (nLight & 1) table[2 + 2 * (totHeavy + (nLight >> 1))] = -2;  // an odd one out runs solo too (the paired layout wants both halves alive)
+    table[0] = totHeavy + ((nLight + 1) >> 1);
+  }
+}
+extern "C" __global__ void __launch_bounds__(64, 2)
+rc_step_sched_kernel(RcState S, const int* __restrict__ table, const int* __restrict__ actions, const double* __restrict__ headActions,
+                     float* __restrict__ obs, double* __restrict__ rewards, uint8_t* __restrict__ dones) {
+  const int b = blockIdx.x;
+  if (b >= table[0]) return;
+  const int e0 = table[1 + 2 * b], e1 = table[2 + 2 * b];
+  if (e1 == -2) rc_step_body<false, 3>(S, uniform_i(e0), actions, headActions, obs, rewards, dones);
+  else rc_step_rpl_body<2>(S, Grp<2>::id() ? e1 : e0, actions, headActions, obs, rewards, dones);
 }
 extern "C" __global__ void __launch_bounds__(64, RC_WAVES_PER_SIMD)
 rc_step_partial_kernel(RcState S, const int* __restrict__ actions, const double* __restrict__ headActions, float* __restrict__ obs,
                        double* __restrict__ rewards, uint8_t* __restrict__ dones) {
-  rc_step_body<true, 1>(S, actions, headActions, obs, rewards, dones);
+  rc_step_body<true, 1>(S, (int)blockIdx.x, actions, headActions, obs, rewards, dones);
 }
 
 extern "C" __global__ void __launch_bounds__(64) rc_obs_kernel(RcState S, float* __restrict__ obs) {

@@ -521,12 +521,12 @@ template <int EPW>
 __device__ __noinline__ RcStepRet rpl_general_physics(RcCtx c, int lane, uint64_t occ, uint64_t pairLo, uint64_t pairHi, uint64_t pairTop, int feetPairs) {
   typedef Grp<EPW> G;
   constexpr int NROUNDS = (RC_NPAIR_ROUNDS * 64) / G::W;
-  if (EPW == 1) {  // 128 VGPRs: the pair table is not kept across the step, fetch it now
+  if (EPW != 2) {  // the caller does not keep a pair table for this lane layout: fetch it now
     const RplPairs p = rpl_my_pairs<EPW>(lane, c.R);
     pairLo = p.lo; pairHi = p.hi; pairTop = p.top; feetPairs = p.feet;
   }
   const int cand = rpl_full_broadphase<NROUNDS>(G::tile(), lane, c.R, pairLo, pairHi, pairTop, feetPairs);
-  const RcStepRet sr = rc_physics_inl<EPW>(c, lane, cand, pairLo, pairHi, pairTop, occ);
+  const RcStepRet sr = rc_physics_inl<EPW == 1 ? 1 : EPW>(c, lane, cand, pairLo, pairHi, pairTop, occ);
   __syncthreads();
   return sr;
 }
@@ -554,12 +554,12 @@ DE_DEV void rpl_rotations(RplBody& b0, RplBody& b1, bool need0, bool need1, int 
 }
 
 template <int EPW>
-DE_DEV void rc_step_rpl_body(const RcState& S, const int* __restrict__ actions, const double* __restrict__ headActions, float* __restrict__ obs,
+DE_DEV void rc_step_rpl_body(const RcState& S, const int e, const int* __restrict__ actions, const double* __restrict__ headActions, float* __restrict__ obs,
                              double* __restrict__ rewards, uint8_t* __restrict__ dones) {
   typedef Grp<EPW> G;
   constexpr int W = G::W;
-  const int e = (int)blockIdx.x * EPW + G::id(), lane = G::lane(), R = S.R;
-  if (e >= S.E) return;  // an odd batch at two environments per wave: the last wave's second half has no environment
+  const int lane = G::lane(), R = S.R;
+  if (e < 0 || e >= S.E) return;  // (two environments per wave: a half without an environment)
   RcLds& L = G::tile();
   uint64_t occ = (uint64_t)(uint32_t)G::uniform_i(S.envi[(size_t)e * RE_COUNT + RE_OCC]);
   if (occ != 0ull) __builtin_amdgcn_s_setprio(3);
@@ -595,6 +595,7 @@ DE_DEV void rc_step_rpl_body(const RcState& S, const int* __restrict__ actions, 
   // hasForce: ... forces of a fall() that the next velocity update has to consume (then that substep takes the LDS path).
   bool posInRegs = false, vbLive = true, hasForce = rpl_any_force<EPW>(L, lane, R);
   int snap = 0;
+  const bool bothHalves = EPW == 2 && __popcll(__ballot(true)) == 64;  // (an odd batch leaves the last wave's second half empty)
 RC_PROF(if (lane < 12 && e < 4096) g_rcprof[e * 12 + lane] = 0ull; const unsigned long long K0 = __builtin_amdgcn_s_memtime(); unsigned long long tG = 0, tP = 0, tQ = 0, tS = 0, nSlow = 0, nGen = 0;)
   for (int it = 0; it < 50; ++it) {
 RC_PROF(const unsigned long long A0 = __builtin_amdgcn_s_memtime();)
@@ -649,7 +650,48 @@ RC_PROF(const unsigned long long A2 = __builtin_amdgcn_s_memtime(); nGen += !qui
       if (!RPL_ROBOT_REGS(EPW)) rpl_load_robot(L, lane, R, r, false, true);
       if (isRobot) rpl_joints(b0, b1, r, v, lane);
       if (!RPL_ROBOT_REGS(EPW)) rpl_store_robot(L, lane, R, r, false, true);
-    } else {  // (an environment with contact work is on the launch's critical path: issue it first)
+    }
+    if (EPW == 2) {
+      // Two environments per wave: the general path of ONE of them runs with the whole wave on that environment's tile - the
+      // foot-per-lane code with wave-uniform control flow (Grp<3> / Grp<4>), twice as fast as its half-wave form.  Both
+      // halves flush first (so that no register of the resident layout is live across the out-of-line call) and reload after.
+      const uint64_t needW = __ballot(!quiet);
+      const bool need0 = (needW & 0xFFFFFFFFull) != 0ull, need1 = (needW >> 32) != 0ull;
+      if ((need0 && need1) || (needW != 0ull && !bothHalves)) {
+        // both environments have contact work: side by side in their halves (the half-wave form costs one what it costs two)
+        if (!quiet) {
+          __builtin_amdgcn_s_setprio(3);
+          rpl_flush<EPW>(L, lane, R, b0, b1, r, v, true);
+          posInRegs = false;
+          __syncthreads();
+          const RcStepRet sr = rpl_general_physics<EPW>(c, lane, occ, pairs.lo, pairs.hi, pairs.top, pairs.feet);
+          occ = sr.occ; err |= sr.err;
+          rpl_reload<EPW>(L, lane, R, b0, b1, r, v);
+          vbLive = true;
+          hasForce = rpl_any_force<EPW>(L, lane, R);
+        }
+      } else if (needW != 0ull) {
+        __builtin_amdgcn_s_setprio(3);  // (an environment with contact work is on the launch's critical path: issue it first)
+        rpl_flush<EPW>(L, lane, R, b0, b1, r, v, true);
+        posInRegs = false;
+        __syncthreads();
+        const int wl = (int)threadIdx.x;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if ((needW >> (32 * h)) & 0xFFFFFFFFull) {
+            RcCtx ch = c;
+            ch.genv = (uint32_t)__builtin_amdgcn_readlane((int)c.genv, 32 * h);
+            ch.episode = (uint32_t)__builtin_amdgcn_readlane((int)c.episode, 32 * h);
+            const uint64_t occh = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)occ, 32 * h);
+            const RcStepRet sr = h == 0 ? rpl_general_physics<3>(ch, wl, occh, 0ull, 0ull, 0ull, 0) : rpl_general_physics<4>(ch, wl, occh, 0ull, 0ull, 0ull, 0);
+            if (G::id() == h) { occ = sr.occ; err |= sr.err; }
+          }
+        }
+        rpl_reload<EPW>(L, lane, R, b0, b1, r, v);
+        vbLive = true;  // (a half that did not solve finds zeros there)
+        hasForce = rpl_any_force<EPW>(L, lane, R);  // a post-solve callback may have made a robot fall
+      }
+    } else if (!quiet) {  // (an environment with contact work is on the launch's critical path: issue it first)
       __builtin_amdgcn_s_setprio(3);
       rpl_flush<EPW>(L, lane, R, b0, b1, r, v, true);
       posInRegs = false;
