@@ -99,6 +99,87 @@ def cpu_baseline(E, n_players, A, seed, robocup=False, target_seconds=12.0, part
             "cpu_model": model}
 
 
+WORKLOADS = {
+    # name: (robocup, partial, players, steps per episode, B_alg, dominant kernel, BASELINE reference)
+    "driving": (False, False, 10, 600, B_ALG_DRIVING_FULL_A10, "drv_step_kernel", "BASELINE.json configs[1]"),
+    "robocup": (True, False, 5, 240, B_ALG_ROBOCUP_FULL_A10, "rc_step_kernel", "BASELINE.json configs[2]"),
+    "driving_partial": (False, True, 10, 600, B_ALG_DRIVING_PARTIAL_A10, "drv_step_partial_kernel", "BASELINE.json configs[3]"),
+    "robocup_partial": (True, True, 5, 240, B_ALG_ROBOCUP_PARTIAL_A10, "rc_step_partial_kernel", "SURVEY §8 a17; in no BASELINE config"),
+}
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes (profiles/pmc_traffic.json,
+    written by tools/pmc_traffic_all.sh on the GPU box; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f).get(kernel + "_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def episode_leg(torch, device, workload, E, seed, n_players=None):
+    """One whole episode of `workload` (every step of it, the lock-step reset excluded), timed with HIP events on the launch
+    stream: the episode mean is what a training run sees - a window at the start of an episode flatters Driving, whose
+    contact work grows over the episode."""
+    from dynenv_amd import BatchedDynEnv, DynEnvType, NoiseType, ObservationType
+    robocup, partial, players, ep_steps, b_alg, kernel, ref = WORKLOADS[workload]
+    players = n_players if n_players is not None else players
+    A = 2 * players if robocup else players
+    kw = dict(observationType=ObservationType.PARTIAL, noiseType=NoiseType.REALISTIC, noiseMagnitude=3) if partial else {}
+    env = BatchedDynEnv(DynEnvType.ROBO_CUP if robocup else DynEnvType.DRIVE, E, players, seed=seed, device=device, **kw)
+    g = torch.Generator(device=device).manual_seed(4321)
+    if robocup:
+        hi = torch.tensor([5, 3, 3, 7], device=device)
+        pool = [(torch.rand((E, A, 4), generator=g, device=device) * hi).to(torch.int32) for _ in range(16)]
+    else:
+        pool = [torch.randint(0, 3, (E, A, 2), generator=g, device=device, dtype=torch.int32) for _ in range(16)]
+    env.reset_flat()
+    for i in range(10):  # untimed: first-touch of the buffers, then a fresh episode
+        env.step_flat(pool[i & 15], auto_reset=False)
+    env.reset_flat()
+    torch.cuda.synchronize(device)
+    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    k0.record()
+    for i in range(ep_steps):
+        env.step_flat(pool[i & 15], auto_reset=False)
+    k1.record()
+    torch.cuda.synchronize(device)
+    ms = k0.elapsed_time(k1) / ep_steps
+    err = env.error_flags()
+    env.close()
+    out = {"workload": workload, "reference": ref, "envs": E, "n_agents": A, "steps": ep_steps, "ms_per_step": ms,
+           "value": E * A / (ms * 1e-3), "unit": "agent-steps/s", "kernel_error_flags": err}
+    if A == 10:
+        achieved = b_alg * E / (ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                           "traffic": measured_traffic(kernel), "kernel": kernel, "launch_ms": ms, "alg_bytes_per_env_step": b_alg,
+                           "env_steps_per_launch": E}
+    return out
+
+
+def plumbing_leg(torch, device, seed):
+    """BASELINE.json configs[0] / BASELINE.md B0: DrivingEnvironment nPlayers=2, Full obs, noise 0, ONE environment - on the GPU
+    (one wave) and on one host thread through the oracle, one whole episode each."""
+    gpu = episode_leg(torch, device, "driving", 1, seed, n_players=2)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as ol
+    ol.build()
+    env = ol.OracleEnv(env_type=1, num_envs=1, n_players=2, seed=seed, threads=1)
+    env.reset()
+    rng = np.random.default_rng(0)
+    acts = rng.integers(0, 3, size=(600, 1, 2, 2)).astype(np.int32)
+    t0 = time.perf_counter()
+    for a in acts:
+        env.step(a)
+    dt = time.perf_counter() - t0
+    return {"workload": "DrivingEnvironment nPlayers=2 Full obs, noise=0, 1 env (BASELINE.json configs[0])", "steps": 600,
+            "gpu_env_steps_per_s": 1.0 / (gpu["ms_per_step"] * 1e-3), "gpu_ms_per_step": gpu["ms_per_step"],
+            "cpu_port_env_steps_per_s": 600 / dt, "cpu_threads": 1,
+            "note": "one environment cannot fill a GPU (one wave of 64 lanes): this leg is the plumbing check BASELINE.md asks for"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,6 +192,8 @@ def main():
                          "configs[3] (Partial obs + Realistic noise magnitude 3); the latter two are reported on request")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the whole-episode leg, the other BASELINE configurations and the configs[0] plumbing leg (N = 1 only)")
     ap.add_argument("--no-gather", action="store_true", help="skip the end-of-step all-gather (data-parallel consumer)")
     ap.add_argument("--force-gather", action="store_true",
                     help="rehearsal on a one-GPU box: run the N > 1 code path (slab, pack, all-gather, unpack) with world_size 1")
@@ -228,64 +311,44 @@ def main():
         elapsed = float(t.item())
     err = env.error_flags()
 
-    # roofline leg: the dominant kernel alone (no resets, no collective), HIP events on the launch stream
+    # roofline leg: the dominant kernel over one WHOLE episode (no reset, no collective), HIP events on the launch stream
     roofline = None
+    full = None
+    ep_steps = WORKLOADS[args.workload][3]
     if rank == 0:
-        env.reset_flat()
-        for i in range(50):
-            env.step_flat(pool[i & 63], auto_reset=False)
-        n_launch = 400
-        torch.cuda.synchronize(device)
-        k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        k0.record()
-        for i in range(n_launch):
-            env.step_flat(pool[i & 63], auto_reset=False)
-        k1.record()
-        torch.cuda.synchronize(device)
-        launch_ms = k0.elapsed_time(k1) / n_launch
-        b_alg = ((B_ALG_ROBOCUP_PARTIAL_A10 if partial else B_ALG_ROBOCUP_FULL_A10) if robocup else
-                 B_ALG_DRIVING_PARTIAL_A10 if partial else B_ALG_DRIVING_FULL_A10) if A == 10 else None
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                with open(pmc) as f:
-                    traffic = json.load(f).get("drv_step_kernel_bytes_per_launch") if args.workload == "driving" else None
-            except (OSError, ValueError):
-                traffic = None
-        if b_alg is not None:
-            achieved = b_alg * E / (launch_ms * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "rc_step_kernel + rc_partial_obs_kernel" if (robocup and partial) else "rc_step_kernel" if robocup else "drv_step_partial_kernel (step + fused getAgentVision)" if partial else "drv_step_kernel",
-                        "launch_ms": launch_ms, "alg_bytes_per_env_step": b_alg, "env_steps_per_launch": E}
+        full = episode_leg(torch, device, args.workload, E, args.seed, n_players=n_players)
+        roofline = full.get("roofline")
 
     if rank == 0:
         env_steps = E * world * args.steps
         value = env_steps * A / elapsed
+        what = ("RoboCupEnvironment nPlayers=%d %s, 50 substeps/step" % (n_players, "Partial obs + Realistic noise magnitude 3" if partial else "Full obs")
+                if robocup else
+                "DrivingEnvironment nPlayers=%d %s, 10 substeps/step" % (A, "Partial obs + Realistic noise magnitude 3" if partial else "Full obs, noise=0"))
+        workload_text = ("%s, %d envs per GPU (%s), lock-step resets every %d steps; timed: steps %d..%d of the %d-step episodes "
+                         "(after %d warm-up steps) - the whole-episode mean is in ms_per_step_full_episode"
+                         % (what, E, WORKLOADS[args.workload][6], ep_steps, args.warmup, args.warmup + args.steps - 1, ep_steps, args.warmup))
         out = {
             "metric": "agent-steps/s", "value": value, "unit": "agent-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("RoboCupEnvironment nPlayers=%d Partial obs + Realistic noise magnitude 3, 50 substeps/step, "
-                                    "%d envs per GPU (SURVEY §8 a17; in no BASELINE config), lock-step resets every 240 steps"
-                                    % (n_players, E))
-                       if (robocup and partial) else
-                       ("RoboCupEnvironment nPlayers=%d Full obs, 50 substeps/step, %d envs per GPU "
-                        "(BASELINE.json configs[2]), lock-step resets every 240 steps" % (n_players, E))
-                       if robocup else
-                       ("DrivingEnvironment nPlayers=%d Partial obs + Realistic noise magnitude 3, %d envs per GPU "
-                        "(BASELINE.json configs[3]), 10 substeps/step, lock-step resets every 600 steps" % (A, E))
-                       if partial else
-                       ("DrivingEnvironment nPlayers=%d Full obs, noise=0, %d envs per GPU "
-                        "(BASELINE.json configs[1]), 10 substeps/step, lock-step resets every 600 steps" % (A, E)),
+            "config": {"workload": workload_text,
                        "envs_per_gpu": E, "n_players": n_players, "n_agents": A, "obs": "partial" if partial else "full", "gather": (False if gather is None else "sync" if args.sync_gather else "overlapped (transport of step k on a side stream beside the next kernels, ring of %d slabs)" % args.ring),
                        "gather_bytes_per_rank": (None if slab is None else slab.nbytes),
-                       "parallelism": "env-shard x%d" % world},
+                       "parallelism": "env-shard x%d" % world,
+                       "rccl_world_size": (dist.get_world_size() if dist is not None else None)},
             "env_steps_per_s": env_steps / elapsed,
             "gpu_ms_per_step_rank0": gpu_ms / args.steps,
             "kernel_error_flags": err,
             "roofline": roofline,
         }
+        if full is not None:  # the same kernel over one whole episode: the mean a training run sees
+            out["ms_per_step_full_episode"] = full["ms_per_step"]
+            out["value_full_episode"] = full["value"] * world
+        if world == 1 and not args.no_extra_legs and gather is None:
+            env.close()
+            out["other_configs"] = [episode_leg(torch, device, w, E, args.seed) for w in WORKLOADS if w != args.workload]
+            out["plumbing_config0"] = plumbing_leg(torch, device, args.seed)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(E, n_players, A, args.seed, robocup, partial=partial)
         elif not args.no_cpu_baseline:
