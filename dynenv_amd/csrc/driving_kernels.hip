@@ -1162,6 +1162,9 @@ DRV_PROF(if (lane < 8 && e < 4096) g_dbgp[e * 8 + lane] = 0ull;)
 
   int act0 = 1, act1 = 1;
   if (isCar) { act0 = actions[((size_t)e * A + lane) * 2 + 0]; act1 = actions[((size_t)e * A + lane) * 2 + 1]; }
+  // action_space is MultiDiscrete([3, 3]) (:170-174); the reference raises on a malformed action (:365-368), here the car
+  // coasts (acc = steer = 0) and the environment's error flag (bit 1, dynenv_error_flags) records it
+  if ((unsigned)act0 > 2u || (unsigned)act1 > 2u) { act0 = 1; act1 = 1; err |= 2; }
   double rew = 0.0, posrew = 0.0, teamReward = 0.0;  // :252-254
   bool aabbValid = false;
   // quiescent-shortcut state carried across launches: candidate mask of the previous substep (-1: unknown) and
@@ -1443,8 +1446,8 @@ DRV_PROF(const unsigned long long K1 = __builtin_amdgcn_s_memtime();)
     envi[EI_N_WHY_CAND] += nWhyCand; envi[EI_N_WHY_MOVING] += nWhyMoving; envi[EI_N_WHY_INERT] += nWhyInert;
     envi[EI_N_FAST] += nFast; envi[EI_N_QUIET] += nQuiet; envi[EI_N_CONTACT] += nContact; envi[EI_N_SLOTS] += nSlots;
   }
-  const uint64_t errMask = wave_ballot(err != 0);
-  if (errMask && lane == 0) envi[EI_ERR] = envi[EI_ERR] | 1;
+  const int errBits = (wave_ballot((err & 1) != 0) ? 1 : 0) | (wave_ballot((err & 2) != 0) ? 2 : 0);
+  if (errBits && lane == 0) envi[EI_ERR] = envi[EI_ERR] | errBits;
   S.lastcand[(size_t)e * 64 + lane] = lastCand;
   store_env(S, L, e, lane, A, nPed, occ);
   if (obs) write_full_obs(L, lane, A, nPed, nObst, S.obs_dim, obs + (size_t)e * A * S.obs_dim);

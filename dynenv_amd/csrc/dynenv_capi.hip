@@ -21,6 +21,18 @@ static int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
 }
+// Every entry point runs on the handle's device and leaves the calling thread's current device as it found it (a process may
+// hold handles on several devices next to torch's own current device).
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() { if (prev >= 0) { int cur = -1; if (hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev); } }
+};
+#define ON_DEVICE(h) DeviceGuard guard_((h)->cfg.device_id); if (!guard_.ok) return fail(DYNENV_ERR_HIP, "hipSetDevice failed")
 #define HIP_OK(expr)                                                                                   \
   do {                                                                                                 \
     hipError_t _e = (expr);                                                                            \
@@ -221,7 +233,7 @@ static int rows_h2d(T* dst, const T* src, size_t nfields, size_t E, size_t width
 static int rc_get_state_host(dynenv* h, int32_t env, void* blob, size_t nbytes) {
   const RcState& R = h->R;
   if (env < 0 || env >= R.E || nbytes < sizeof(dynenv_robocup_state_t)) return fail(DYNENV_ERR_ARG, "bad env index / size");
-  HIP_OK(hipSetDevice(h->cfg.device_id));
+  ON_DEVICE(h);
   HIP_OK(hipDeviceSynchronize());
   const size_t E = (size_t)R.E;
   static thread_local double body[RB_COUNT + 4][RC_NB], rob[RR_COUNT][16], envd[RD_COUNT], epr[2][16];
@@ -267,7 +279,7 @@ static int rc_set_state_host(dynenv* h, int32_t env, const void* blob, size_t nb
   if (env < 0 || env >= R.E || nbytes < sizeof(dynenv_robocup_state_t)) return fail(DYNENV_ERR_ARG, "bad env index / size");
   const dynenv_robocup_state_t* st = (const dynenv_robocup_state_t*)blob;
   if (st->n_robots != R.R) return fail(DYNENV_ERR_ARG, "state blob does not match this handle's layout");
-  HIP_OK(hipSetDevice(h->cfg.device_id));
+  ON_DEVICE(h);
   HIP_OK(hipDeviceSynchronize());
   const size_t E = (size_t)R.E;
   static thread_local double body[RB_COUNT + 4][RC_NB], rob[RR_COUNT][16], envd[RD_COUNT], epr[2][16];
@@ -332,8 +344,14 @@ int dynenv_create(const dynenv_cfg_t* cfg, dynenv_t** out) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(DYNENV_ERR_NO_DEVICE, "no HIP device visible: libdynenv_hip has no CPU fallback");
   if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(DYNENV_ERR_ARG, "device_id out of range");
-  HIP_OK(hipSetDevice(cfg->device_id));
+  DeviceGuard guard_(cfg->device_id);  // (the __constant__ tables are uploaded to this device below)
+  if (!guard_.ok) return fail(DYNENV_ERR_HIP, "hipSetDevice failed");
   if (cfg->env_type != DYNENV_DRIVE && cfg->env_type != DYNENV_ROBO_CUP) return fail(DYNENV_ERR_ARG, "unknown env_type");
+  const int32_t known = DYNENV_FLAG_RANDOM_INIT | DYNENV_FLAG_DETERMINISTIC_TURN | DYNENV_FLAG_CAN_FALL | DYNENV_FLAG_USE_OBS_REWARDS |
+                        DYNENV_FLAG_ALLOW_HEAD_TURN;
+  if (cfg->flags & ~known) return fail(DYNENV_ERR_UNSUPPORTED, "unknown bits in dynenv_cfg.flags");
+  if (cfg->env_type == DYNENV_DRIVE && cfg->flags != 0)
+    return fail(DYNENV_ERR_UNSUPPORTED, "dynenv_cfg.flags are RoboCup's class switches; DrivingEnvironment has none (continuous actions are broken in the reference, DrivingEnvironment.py:360-368)");
   if (cfg->obs_type != DYNENV_OBS_FULL && cfg->obs_type != DYNENV_OBS_PARTIAL)
     return fail(DYNENV_ERR_UNSUPPORTED, "Image observations are out of scope");
   dynenv* h = new dynenv();
@@ -383,7 +401,7 @@ int dynenv_create(const dynenv_cfg_t* cfg, dynenv_t** out) {
 
 void dynenv_destroy(dynenv_t* h) {
   if (!h) return;
-  hipSetDevice(h->cfg.device_id);
+  DeviceGuard guard_(h->cfg.device_id);
   for (void* p : h->allocs) hipFree(p);
   delete h;
 }
@@ -445,12 +463,12 @@ int dynenv_seed(dynenv_t* h, uint64_t seed) {
 int dynenv_reset(dynenv_t* h, float* obs_dev, void* stream) {
   if (!h) return fail(DYNENV_ERR_ARG, "null handle");
   hipStream_t st = (hipStream_t)stream;
-  HIP_OK(hipSetDevice(h->cfg.device_id));
+  ON_DEVICE(h);
   if (h->robocup) {
     int E = h->R.E;
     hipLaunchKernelGGL(rc_reset_kernel, dim3((E + 63) / 64), dim3(64), 0, st, h->R);
     if (obs_dev) {
-      hipLaunchKernelGGL(rc_obs_kernel, dim3(E), dim3(64), 0, st, h->R, obs_dev);
+      hipLaunchKernelGGL(rc_obs_kernel, dim3(E), dim3(64), 0, st, h->R, obs_dev, 0);
       if (h->R.obs_type == DYNENV_OBS_PARTIAL)
         hipLaunchKernelGGL(rc_partial_obs_kernel, dim3(E), dim3(64), 0, st, h->R, obs_dev, (double*)nullptr);
     }
@@ -467,6 +485,21 @@ int dynenv_reset(dynenv_t* h, float* obs_dev, void* stream) {
   return DYNENV_OK;
 }
 
+int dynenv_full_obs_dim(const dynenv_t* h) {
+  if (!h) return fail(DYNENV_ERR_ARG, "null handle");
+  return h->robocup ? 4 + 8 + (h->R.R - 1) * 6 : 9 + (h->A - 1) * 7 + DRV_MAXO * 4 + DRV_MAXP * 2 + DRV_LANE_ROWS * 5;
+}
+
+int dynenv_full_obs(dynenv_t* h, float* full_dev, void* stream) {
+  if (!h || !full_dev) return fail(DYNENV_ERR_ARG, "null argument");
+  ON_DEVICE(h);
+  hipStream_t st = (hipStream_t)stream;
+  if (h->robocup) hipLaunchKernelGGL(rc_obs_kernel, dim3(h->R.E), dim3(64), 0, st, h->R, full_dev, 1);
+  else hipLaunchKernelGGL(drv_obs_kernel, dim3(h->S.E), dim3(64), 0, st, h->S, full_dev);
+  HIP_OK(hipGetLastError());
+  return DYNENV_OK;
+}
+
 int dynenv_step(dynenv_t* h, const int32_t* actions_dev, float* obs_dev, double* rewards_dev, uint8_t* dones_dev,
                 void* stream) {
   return dynenv_step_head(h, actions_dev, nullptr, obs_dev, rewards_dev, dones_dev, stream);
@@ -477,6 +510,7 @@ int dynenv_step_head(dynenv_t* h, const int32_t* actions_dev, const double* head
   if (!h || !actions_dev || !rewards_dev || !dones_dev) return fail(DYNENV_ERR_ARG, "null argument");
   if (head_dev && !(h->robocup && (h->cfg.flags & DYNENV_FLAG_ALLOW_HEAD_TURN)))
     return fail(DYNENV_ERR_ARG, "the continuous head channel exists for RoboCup with DYNENV_FLAG_ALLOW_HEAD_TURN only");
+  ON_DEVICE(h);
   hipStream_t st = (hipStream_t)stream;
   if (h->robocup) {
     if (h->R.obs_type == DYNENV_OBS_PARTIAL && obs_dev) {  // getAgentVision at the five snapshots + processSeens fused into the launch
@@ -518,6 +552,7 @@ int dynenv_step_head(dynenv_t* h, const int32_t* actions_dev, const double* head
 
 int dynenv_counts(dynenv_t* h, int32_t* counts_dev, void* stream) {
   if (!h || !counts_dev) return fail(DYNENV_ERR_ARG, "null argument");
+  ON_DEVICE(h);
   if (h->robocup) { HIP_OK(hipMemsetAsync(counts_dev, 0, sizeof(int32_t) * 2 * h->R.E, (hipStream_t)stream)); return DYNENV_OK; }
   int E = h->S.E;
   hipLaunchKernelGGL(drv_counts_kernel, dim3((E + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->S, (int*)counts_dev);
@@ -527,6 +562,7 @@ int dynenv_counts(dynenv_t* h, int32_t* counts_dev, void* stream) {
 
 int dynenv_episode_stats(dynenv_t* h, double* ep_r, double* ep_pos_r, double* ep_obs_r, int32_t* goals, void* stream) {
   if (!h) return fail(DYNENV_ERR_ARG, "null handle");
+  ON_DEVICE(h);
   if (h->robocup) {
     int E = h->R.E;
     hipLaunchKernelGGL(rc_stats_kernel, dim3((E + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->R, ep_r, ep_pos_r, ep_obs_r, (int*)goals);
@@ -544,6 +580,7 @@ size_t dynenv_state_size(const dynenv_t* h) { return (h && h->robocup) ? sizeof(
 
 int dynenv_sync(dynenv_t* h, void* stream) {
   if (!h) return fail(DYNENV_ERR_ARG, "null handle");
+  ON_DEVICE(h);
   HIP_OK(hipStreamSynchronize((hipStream_t)stream));
   return DYNENV_OK;
 }
@@ -551,6 +588,7 @@ int dynenv_sync(dynenv_t* h, void* stream) {
 // error flags raised by the kernels (bit0: contact cache overflow), OR-ed over all envs
 int dynenv_error_flags(dynenv_t* h, int32_t* out) {
   if (!h || !out) return fail(DYNENV_ERR_ARG, "null argument");
+  ON_DEVICE(h);
   HIP_OK(hipDeviceSynchronize());
   if (h->robocup) {
     std::vector<int> ev((size_t)h->R.E * RE_COUNT);
@@ -573,6 +611,7 @@ int dynenv_error_flags(dynenv_t* h, int32_t* out) {
 // steady replays, 0...}
 int dynenv_debug_counters(dynenv_t* h, int64_t* out4) {
   if (!h || !out4) return fail(DYNENV_ERR_ARG, "null argument");
+  ON_DEVICE(h);
   if (h->robocup) {
     for (int k = 0; k < 12; ++k) out4[k] = 0;
 #ifdef DRV_PROFILE
@@ -599,7 +638,7 @@ int dynenv_get_state(dynenv_t* h, int32_t env, void* blob, size_t nbytes) {
   if (!h || !blob) return fail(DYNENV_ERR_ARG, "null argument");
   if (h->robocup) return rc_get_state_host(h, env, blob, nbytes);
   if (env < 0 || env >= h->S.E || nbytes < sizeof(dynenv_driving_state_t)) return fail(DYNENV_ERR_ARG, "bad env index / size");
-  HIP_OK(hipSetDevice(h->cfg.device_id));
+  ON_DEVICE(h);
   HIP_OK(hipDeviceSynchronize());
   const DrvState& S = h->S;
   const size_t E = (size_t)S.E;
@@ -649,7 +688,7 @@ int dynenv_set_state(dynenv_t* h, int32_t env, const void* blob, size_t nbytes) 
   const dynenv_driving_state_t* st = (const dynenv_driving_state_t*)blob;
   if (st->n_cars != h->S.A || st->n_peds > DRV_MAXP || st->n_obst > DRV_MAXO || st->n_peds < 0 || st->n_obst < 0)
     return fail(DYNENV_ERR_ARG, "state blob does not match this handle's layout");
-  HIP_OK(hipSetDevice(h->cfg.device_id));
+  ON_DEVICE(h);
   HIP_OK(hipDeviceSynchronize());
   const DrvState& S = h->S;
   const size_t E = (size_t)S.E;
@@ -875,6 +914,7 @@ size_t dynenv_checkpoint_size(const dynenv_t* h) { return h ? sizeof(CkptHeader)
 int dynenv_checkpoint_save(dynenv_t* h, void* buf_host, size_t nbytes) {
   if (!h || !buf_host) return fail(DYNENV_ERR_ARG, "null argument");
   if (nbytes < dynenv_checkpoint_size(h)) return fail(DYNENV_ERR_ARG, "checkpoint buffer too small");
+  ON_DEVICE(h);
   HIP_OK(hipDeviceSynchronize());
   CkptHeader hd;
   memset(&hd, 0, sizeof(hd));
@@ -894,6 +934,7 @@ int dynenv_checkpoint_save(dynenv_t* h, void* buf_host, size_t nbytes) {
 
 int dynenv_checkpoint_load(dynenv_t* h, const void* buf_host, size_t nbytes) {
   if (!h || !buf_host) return fail(DYNENV_ERR_ARG, "null argument");
+  ON_DEVICE(h);
   if (nbytes < sizeof(CkptHeader)) return fail(DYNENV_ERR_ARG, "not a checkpoint");
   CkptHeader hd;
   memcpy(&hd, buf_host, sizeof(hd));

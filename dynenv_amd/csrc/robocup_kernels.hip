@@ -334,6 +334,9 @@ DE_DEV void rc_process_action(const RcCtx& c, RcLds& L, int r, const int* action
   if (c.allowHead && headAct) head = headAct[r];
   if (c.detTurn) head = (double)(-3 * robot_team(L, r));  // :529-530
   if (!c.allowHead) head -= 3.0;
+  // the reference raises on a malformed action (:543-550); here the robot keeps still and the environment's error flag (bit 1,
+  // dynenv_error_flags) records it - never an out-of-range index below
+  if (move < 0 || move > 4 || turn < 0 || turn > 2 || kick < 0 || kick > 2 || !(dm_abs(head) <= 6.0)) { L.envi[RE_ERR] |= 2; return; }
   const int f0 = L.rflags[r];
   const bool canMove = !(f0 & (RF_PENAL | RF_KICK | RF_FALLEN));
   if (move > 0 && canMove) {
@@ -1829,11 +1832,18 @@ rc_step_partial_kernel(RcState S, const int* __restrict__ actions, const double*
   rc_step_body<true, 1>(S, (int)blockIdx.x, actions, headActions, obs, rewards, dones);
 }
 
-extern "C" __global__ void __launch_bounds__(64) rc_obs_kernel(RcState S, float* __restrict__ obs) {
+// fullOnce = 0: the observation tensor after a reset (nTimeSteps rows per environment, the configured observation type);
+// fullOnce = 1: ONE noise-free Full observation of the current state [E, A, 66], whatever the observation type - what
+// info['Full State'] / info['Recon States'] are made of (RoboCupEnvironment.py:511-512), dynenv_full_obs
+extern "C" __global__ void __launch_bounds__(64) rc_obs_kernel(RcState S, float* __restrict__ obs, int fullOnce) {
   RcLds& L = g_R;
   const int e = blockIdx.x, lane = threadIdx.x;
   rc_load_env(S, L, e, lane, 0ull);
   __syncthreads();
+  if (fullOnce) {
+    rc_write_obs(L, lane, S.R, 4 + 8 + (S.R - 1) * 6, obs + (size_t)e * S.R * (4 + 8 + (S.R - 1) * 6));
+    return;
+  }
   if (S.obs_type == DYNENV_OBS_PARTIAL) {
     // environment_base.py:217-222: nTimeSteps separate getAgentVision calls on the initial state, each with fresh noise
     // (draw keys: time word = t); rc_partial_obs_kernel follows on the same stream

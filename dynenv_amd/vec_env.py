@@ -187,6 +187,124 @@ class LazyInfo(dict):
         return dict.__repr__(self)
 
 
+class LazyObsArray(object):
+    """The reference's observation `np.ndarray(dtype=object)` of shape [E, T, A, 3] (subproc_vec_env.py:201 over
+    DrivingEnvironment.py:123 / RoboCupEnvironment.py:442) without the E*T*A Python objects: it keeps the step's dense host
+    copy [E, T, A, D] and builds an element - `(movable-object arrays, static/self arrays, seen info)` - when it is indexed.
+    Indexing follows numpy's basic rules (ints, slices, Ellipsis); a sub-array is again lazy (`obs[..., :-1]`,
+    `obs[..., -1]` as models/train.py:67-68 does); `np.asarray(obs)` / `obs.materialize()` gives the reference's eager object array."""
+    dtype = np.dtype(object)
+
+    def __init__(self, owner, dense, counts, sel=None, box=None):
+        # `dense`: the step's observations [E, T, A, D] - a numpy array, or a device tensor (a snapshot the step made in HBM)
+        # that is copied to the host the first time an element is looked at; `box` shares that copy among sub-arrays
+        self._owner, self._counts = owner, counts
+        self._box = box if box is not None else [dense]
+        E, T, A, _ = dense.shape
+        self._sel = sel if sel is not None else (range(E), range(T), range(A), range(3))  # per axis: range (kept) or int (dropped)
+
+    @property
+    def _dense(self):
+        d = self._box[0]
+        if not isinstance(d, np.ndarray):
+            d = self._box[0] = d.cpu().numpy()
+        return d
+
+    @property
+    def shape(self):
+        return tuple(len(s) for s in self._sel if not isinstance(s, int))
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    def __len__(self):
+        sh = self.shape
+        if not sh:
+            raise TypeError("len() of unsized object")
+        return sh[0]
+
+    def _element(self, e, t, a, k):
+        return self._owner._compat_element(self._dense, self._counts, e, t, a)[k]
+
+    def __getitem__(self, idx):
+        if not isinstance(idx, tuple):
+            idx = (idx,)
+        kept = [i for i, s in enumerate(self._sel) if not isinstance(s, int)]
+        if any(i is Ellipsis for i in idx):
+            p = [i for i, x in enumerate(idx) if x is Ellipsis][0]
+            idx = idx[:p] + (slice(None),) * (len(kept) - (len(idx) - 1)) + idx[p + 1:]
+        if len(idx) > len(kept):
+            raise IndexError("too many indices for array")
+        idx = idx + (slice(None),) * (len(kept) - len(idx))
+        sel = list(self._sel)
+        for ax, i in zip(kept, idx):
+            r = sel[ax]
+            if isinstance(i, slice):
+                sel[ax] = r[i]
+            else:
+                sel[ax] = r[int(i)]   # IndexError like numpy when out of range
+        if all(isinstance(x, int) for x in sel):
+            return self._element(*sel)
+        return LazyObsArray(self._owner, self._box[0], self._counts, tuple(sel), self._box)
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+    def materialize(self):
+        """The eager object ndarray of this (sub-)array, element for element what the reference returns."""
+        E, T, A, _ = self._dense.shape
+        if all(isinstance(x, range) and x == range(n) for x, n in zip(self._sel, (E, T, A, 3))) and hasattr(self._owner, "_compat_obs"):
+            return self._owner._compat_obs(self._dense, self._counts)  # the whole array: the batched builder
+        axes = [([s] if isinstance(s, int) else list(s)) for s in self._sel]
+        out = np.empty(tuple(len(a) for a in axes), dtype=object)
+        for ie, e in enumerate(axes[0]):
+            for it, t in enumerate(axes[1]):
+                for ia, a in enumerate(axes[2]):
+                    el = self._owner._compat_element(self._dense, self._counts, e, t, a)
+                    for ik, k in enumerate(axes[3]):
+                        out[ie, it, ia, ik] = el[k]
+        return out.reshape(self.shape)
+
+    def __array__(self, dtype=None, copy=None):
+        return self.materialize()
+
+    def tolist(self):
+        return self.materialize().tolist()
+
+    def __repr__(self):
+        return "LazyObsArray(shape=%r, dtype=object)" % (self.shape,)
+
+
+class LazyInfos(object):
+    """The per-environment `info` dicts of one step as a read-only sequence (the reference returns a tuple of dicts,
+    subproc_vec_env.py:109-111): a dict is built when it is asked for and kept, so a consumer that never looks at
+    `info` pays nothing for 4096 of them."""
+
+    def __init__(self, n, make):
+        self._n, self._make, self._cache = n, make, {}
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return tuple(self[k] for k in range(*i.indices(self._n)))
+        i = int(i)
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        d = self._cache.get(i)
+        if d is None:
+            d = self._cache[i] = self._make(i)
+        return d
+
+    def __iter__(self):
+        return (self[i] for i in range(self._n))
+
+
 class BatchedDynEnv(object):
     """All `num_envs` environments of one GPU shard behind the reference's VecEnv surface."""
 
@@ -194,7 +312,7 @@ class BatchedDynEnv(object):
 
     def __init__(self, env_type, num_envs, num_players, observationType=ObservationType.FULL,
                  noiseType=NoiseType.REALISTIC, noiseMagnitude=0, use_continuous_actions=False, seed=42,
-                 device=None, env_id_offset=0, flags=0, out_buffers=None):
+                 device=None, env_id_offset=0, flags=None, out_buffers=None, eager_compat=False):
         import torch  # device memory + streams only
         if not torch.cuda.is_available():
             raise _capi.DynEnvError("dynenv_amd needs an MI355X (HIP device); there is no CPU fallback")
@@ -206,12 +324,17 @@ class BatchedDynEnv(object):
             raise NotImplementedError("continuous actions are broken in the reference Driving env (acc/steer unbound)")
         if observationType == ObservationType.IMAGE:
             raise NotImplementedError("Image observations are out of scope (SURVEY.md §2)")
-        if env_type == DynEnvType.ROBO_CUP and flags == 0:
-            # class-level switches of the reference (RoboCupEnvironment.py:18-21): canFall=True, useObsRewards=True;
-            # make_dyn_env passes allowHeadTurn=use_continuous_actions (DynEnv/__init__.py:9-11)
-            flags = _capi.FLAG_CAN_FALL | _capi.FLAG_USE_OBS_REWARDS
-            if use_continuous_actions:
-                flags |= _capi.FLAG_ALLOW_HEAD_TURN
+        if flags is None:  # the reference's defaults; an explicit value (0 included: canFall = useObsRewards = False) is taken as is
+            flags = 0
+            if env_type == DynEnvType.ROBO_CUP:
+                # class-level switches of the reference (RoboCupEnvironment.py:18-21): canFall=True, useObsRewards=True,
+                # randomInit=False, deterministicTurn=False; make_dyn_env passes allowHeadTurn=use_continuous_actions
+                # (DynEnv/__init__.py:9-11)
+                flags = _capi.FLAG_CAN_FALL | _capi.FLAG_USE_OBS_REWARDS
+                if use_continuous_actions:
+                    flags |= _capi.FLAG_ALLOW_HEAD_TURN
+        self.flags = int(flags)
+        self.eager_compat = bool(eager_compat)  # step()/reset() return the eager object ndarray / tuple of dicts instead of the lazy forms
         self.env_type = env_type
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.cfg = _capi.Cfg(_capi.DYNENV_ABI_VERSION, int(env_type), int(num_envs), int(num_players),
@@ -239,7 +362,9 @@ class BatchedDynEnv(object):
             self.dones = torch.zeros((E,), dtype=torch.uint8, device=self.device)
         else:  # e.g. views into a packed all-gather slab (dynenv_amd.distributed)
             self.obs, self.rewards, self.dones = out_buffers
-        self._actions = torch.zeros((E, A, self.action_dim), dtype=torch.int32, device=self.device)
+        self.allow_head_turn = env_type == DynEnvType.ROBO_CUP and bool(self.flags & _capi.FLAG_ALLOW_HEAD_TURN)
+        self.full_obs_dim = int(self._lib.dynenv_full_obs_dim(self._h))
+        self._counts_np = None
         self.terminal_obs = None
         self._episode_step = 0
         self._needs_reset = True
@@ -259,11 +384,29 @@ class BatchedDynEnv(object):
         _capi.check(self._lib.dynenv_reset(self._h, C.c_void_p(self.obs.data_ptr()), self._stream()), "dynenv_reset")
         self._episode_step = 0
         self._needs_reset = False
+        self._counts_np = None  # the scene (obstacle / pedestrian counts) changed
         return self.obs
 
     def _stage_actions(self, actions):
+        """-> (int32 [E, A, action_dim] on the device, float64 [E, A] head channel or None).  With allowHeadTurn the 4th action is
+        the reference's continuous head turn (Box(-3, 3), RoboCupEnvironment.py:339-342): any float in the 4th column (or a
+        (discrete [E, A, 3], head [E, A]) pair) travels as float64 and is not truncated."""
         torch = self._torch
-        if isinstance(actions, torch.Tensor):
+        head = None
+        if self.allow_head_turn:
+            if isinstance(actions, (tuple, list)) and len(actions) == 2:
+                disc, hd = actions
+                disc = torch.as_tensor(np.asarray(disc) if not isinstance(disc, torch.Tensor) else disc)
+                hd = torch.as_tensor(np.asarray(hd, dtype=np.float64) if not isinstance(hd, torch.Tensor) else hd)
+                actions = torch.cat([disc.to(torch.float64), hd.to(torch.float64).reshape(disc.shape[0], disc.shape[1], 1)], -1)
+            a_f = actions if isinstance(actions, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(actions, dtype=np.float64))
+            if a_f.dim() == 3 and a_f.shape[-1] == 4:
+                head = a_f[..., 3].to(device=self.device, dtype=torch.float64).contiguous()
+                a = a_f.to(device=self.device).to(torch.int32).contiguous()
+                a[..., 3] = 0
+            else:
+                a = a_f.to(device=self.device).to(torch.int32).contiguous()
+        elif isinstance(actions, torch.Tensor):
             a = actions
             if a.device != self.device or a.dtype != torch.int32 or not a.is_contiguous():
                 a = a.to(device=self.device, dtype=torch.int32).contiguous()
@@ -273,24 +416,32 @@ class BatchedDynEnv(object):
             # DrivingEnvironment.py:262-263
             raise Exception("Error: There must be %d actions for every %s" %
                             (self.action_dim, "car" if self.env_type == DynEnvType.DRIVE else "robot"))
-        return a
+        return a, head
 
     def step_flat(self, actions, auto_reset=True, validate=False):
         """One env step of every environment: ONE kernel launch on torch's current stream."""
         if self._needs_reset:
             raise _capi.DynEnvError("call reset() before step()")
         torch = self._torch
-        a = self._stage_actions(actions)
+        a, head = self._stage_actions(actions)
         if validate and self.env_type == DynEnvType.DRIVE:
             if bool(((a < 0) | (a > 2)).any()):  # DrivingEnvironment.py:365-368
                 raise Exception("Error: Acceleration must be between +/-3")
         if validate and self.env_type == DynEnvType.ROBO_CUP:  # RoboCupEnvironment.py:543-550
-            hi = torch.tensor([4, 2, 2, 6], device=a.device, dtype=a.dtype)
-            if bool(((a < 0) | (a > hi)).any()):
+            hi = torch.tensor([4, 2, 2], device=a.device, dtype=a.dtype)
+            if bool(((a[..., :3] < 0) | (a[..., :3] > hi)).any()):
                 raise Exception("Error: Robot movement must be categorical in the range [0-4]")
-        _capi.check(self._lib.dynenv_step(self._h, C.c_void_p(a.data_ptr()), C.c_void_p(self.obs.data_ptr()),
-                                          C.c_void_p(self.rewards.data_ptr()), C.c_void_p(self.dones.data_ptr()),
-                                          self._stream()), "dynenv_step")
+            bad_head = (head.abs() > 6).any() if head is not None else ((a[..., 3] < 0) | (a[..., 3] > 6)).any()
+            if bool(bad_head):
+                raise Exception("Error: Head turn must be between +/-6")
+        if head is not None:
+            _capi.check(self._lib.dynenv_step_head(self._h, C.c_void_p(a.data_ptr()), C.c_void_p(head.data_ptr()),
+                                                   C.c_void_p(self.obs.data_ptr()), C.c_void_p(self.rewards.data_ptr()),
+                                                   C.c_void_p(self.dones.data_ptr()), self._stream()), "dynenv_step_head")
+        else:
+            _capi.check(self._lib.dynenv_step(self._h, C.c_void_p(a.data_ptr()), C.c_void_p(self.obs.data_ptr()),
+                                              C.c_void_p(self.rewards.data_ptr()), C.c_void_p(self.dones.data_ptr()),
+                                              self._stream()), "dynenv_step")
         self._episode_step += 1
         self.last_done = self._episode_step >= self.steps_per_episode  # fixed-length episodes (SURVEY F6)
         if self.last_done and auto_reset:
@@ -352,10 +503,27 @@ class BatchedDynEnv(object):
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
         _capi.check(self._lib.dynenv_checkpoint_load(self._h, C.c_void_p(buf.ctypes.data), buf.size), "dynenv_checkpoint_load")
         self._needs_reset = False
+        self._counts_np = None
+        # the host's position in the (lock-step, fixed-length) episode follows the restored device state: auto-reset and
+        # `dones` are driven by it
+        substeps = 50 if self.env_type == DynEnvType.ROBO_CUP else 10
+        self._episode_step = int(self.get_state(0).elapsed) // substeps
+
+    def full_state_obs(self):
+        """The noise-free Full observation of the current state, [E, A, full_obs_dim] float32 on the device, whatever the
+        observation type (getFullState: what info['Full State'] / info['Recon States'] are made of)."""
+        out = self._torch.empty((self.num_envs, self.n_agents, self.full_obs_dim), dtype=self._torch.float32, device=self.device)
+        _capi.check(self._lib.dynenv_full_obs(self._h, C.c_void_p(out.data_ptr()), self._stream()), "dynenv_full_obs")
+        return out
 
     def refresh_obs(self):
-        """Re-emit the observation of the current state (after set_state)."""
-        raise NotImplementedError
+        """Re-emit the observation of the current state into `self.obs` (after set_state / restore).  Full observations only:
+        a Partial observation is a noisy draw keyed by the step that produced it."""
+        if self.observationType != ObservationType.FULL:
+            raise NotImplementedError("refresh_obs re-emits Full observations; use full_state_obs() for the true state")
+        full = self.full_state_obs()
+        self.obs.copy_(full.unsqueeze(1).expand(-1, self.n_time_steps, -1, -1))
+        return self.obs
 
     # ------------------------------------------------------------------ reference-compatible (legacy) path
     def _compat_obs(self, obs_t, counts):
@@ -421,32 +589,61 @@ class BatchedDynEnv(object):
                     out[e, t, a, 2] = ones
         return out
 
-    def _full_states(self, obs_np, counts, e):
-        """info['Full State'] / info['Recon States'] (DrivingEnvironment.py:306-307) from agent rows of env e."""
+    def _compat_element(self, o, counts, e, t, a):
+        """One element [e, t, a] of the reference's observation array: [movable-object arrays, static / self arrays, seen info]
+        (the same views / values `_compat_obs` assembles for the whole batch)."""
         L = self.layout
-        off, rows = list(L.block_offset), list(L.block_rows)
-        A = self.n_agents
+        off, rows, feat = list(L.block_offset), list(L.block_rows), list(L.block_feat)
+        A, D = self.n_agents, self.obs_dim
+        r = o[e, t, a]
         if self.env_type == DynEnvType.ROBO_CUP and self.observationType == ObservationType.PARTIAL:
-            return None, None  # the Partial launch does not emit the noise-free full state (see the Driving note below)
+            tail = off[6]
+            n = [int(x) for x in r[tail:tail + 6]]
+            lists = [r[off[k]:off[k] + n[k] * feat[k]].reshape(n[k], feat[k]) for k in range(6)]
+            return [[lists[0], lists[1]], [lists[2], lists[3], lists[4], lists[5]],
+                    (int(r[tail + 6]), r[tail + 8:tail + 8 + (A - 1)].astype("uint8"), bool(r[tail + 7]))]
+        if self.env_type == DynEnvType.ROBO_CUP:
+            return [[r[0:4].reshape(1, 4), r[12:12 + (A - 1) * 6].reshape(A - 1, 6)], [r[4:12].reshape(1, 8), ], (1, 1, 1)]
+        if self.observationType == ObservationType.PARTIAL:
+            nc, no, npd, nl = [int(x) for x in r[D - 4:]]
+            return [[r[off[1]:off[1] + rows[1] * 7].reshape(rows[1], 7)[:nc], r[off[2]:off[2] + rows[2] * 6].reshape(rows[2], 6)[:no],
+                     r[off[3]:off[3] + rows[3] * 2].reshape(rows[3], 2)[:npd]],
+                    [r[0:9].reshape(1, 9), r[off[4]:off[4] + rows[4] * 4].reshape(rows[4], 4)[:nl]], (1, 1, 1)]
+        n_obst, n_ped = int(counts[e, 0]), int(counts[e, 1])
+        return [[r[off[1]:off[1] + rows[1] * 7].reshape(rows[1], 7), r[off[2]:off[2] + rows[2] * 4].reshape(rows[2], 4)[:n_obst],
+                 r[off[3]:off[3] + rows[3] * 2].reshape(rows[3], 2)[:n_ped]],
+                [r[off[0]:off[0] + 9].reshape(1, 9), r[off[4]:off[4] + rows[4] * 5].reshape(rows[4], 5)], (1, 1, 1)]
+
+    def _host_counts(self):
+        """(n_obstacles, n_pedestrians) per environment on the host: they change at a reset only, so one copy per episode."""
+        if self._counts_np is None:
+            self._counts_np = self.counts().cpu().numpy()
+        return self._counts_np
+
+    def _wrap_obs(self, obs_np, counts):
+        return self._compat_obs(obs_np, counts) if self.eager_compat else LazyObsArray(self, obs_np, counts)
+
+    def _full_states(self, full_np, counts, e):
+        """info['Full State'] / info['Recon States'] (DrivingEnvironment.py:306-307, RoboCupEnvironment.py:511-512) of env e from
+        the noise-free Full rows [E, A, full_obs_dim] of the state after the step (whatever the observation type)."""
+        A = self.n_agents
         if self.env_type == DynEnvType.ROBO_CUP:  # getFullState(agent) = [ball, self, robots] (:1164-1188)
             recon = []
             for a in range(A):
-                r = obs_np[e, -1, a]
+                r = full_np[e, a]
                 recon.append([r[0:4].reshape(1, 4).copy(), r[4:12].reshape(1, 8).copy(),
                               r[12:12 + (A - 1) * 6].reshape(A - 1, 6).copy()])
             return recon[0], recon  # (the reference's agent=None variant is un-normalised; not reproduced)
         n_obst, n_ped = int(counts[e, 0]), int(counts[e, 1])
-        if self.observationType == ObservationType.PARTIAL:
-            # info['Full State'] needs the noise-free full state, which the Partial launch does not emit (only the
-            # out-of-scope reconstruction losses of the reference's trainer consume it)
-            return None, None
+        o1 = 9 + (A - 1) * 7
+        o2, o3 = o1 + 80, o1 + 120
         recon = []
         for a in range(A):
-            r = obs_np[e, -1, a]
-            recon.append([r[0:9].reshape(1, 9).copy(), r[off[1]:off[1] + rows[1] * 7].reshape(rows[1], 7).copy(),
-                          r[off[2]:off[2] + n_obst * 4].reshape(n_obst, 4).copy(),
-                          r[off[3]:off[3] + n_ped * 2].reshape(n_ped, 2).copy(),
-                          r[off[4]:off[4] + rows[4] * 5].reshape(rows[4], 5).copy()])
+            r = full_np[e, a]
+            recon.append([r[0:9].reshape(1, 9).copy(), r[9:o1].reshape(A - 1, 7).copy(),
+                          r[o1:o1 + n_obst * 4].reshape(n_obst, 4).copy(),
+                          r[o2:o2 + n_ped * 2].reshape(n_ped, 2).copy(),
+                          r[o3:o3 + 40].reshape(8, 5).copy()])
         # complete state: every car row = own [x,y,cos,sin,w,h] + finished
         cars = np.stack([np.concatenate([recon[a][0][0, :6], recon[a][0][0, 8:9]]) for a in range(A)]).astype(np.float32)
         full = [cars, recon[0][2], recon[0][3], recon[0][4]]
@@ -454,27 +651,37 @@ class BatchedDynEnv(object):
 
     def reset(self):
         self.reset_flat()
-        counts = self.counts().cpu().numpy()
-        return self._compat_obs(self.obs, counts)
+        return self._wrap_obs(self.obs.clone() if not self.eager_compat else self.obs.cpu().numpy(), self._host_counts())
 
     def step_async(self, actions):
         self._pending = actions
 
     def step_wait(self):
         actions, self._pending = self._pending, None
-        a = np.asarray(actions)
-        counts_before = self.counts().cpu().numpy()
-        self.step_flat(a, auto_reset=False, validate=True)
+        counts = self._host_counts()
+        self.step_flat(actions if self.allow_head_turn else np.asarray(actions), auto_reset=False, validate=True)
+        # the state behind info['Full State'] / info['Recon States']: with Full observations it is the step's last snapshot; with
+        # Partial ones a noise-free Full row is emitted now (one short launch) and copied to the host only if somebody asks
+        full_dev = self.full_state_obs() if self.observationType != ObservationType.FULL else None
         rewards = self.rewards.cpu().numpy().copy()
         done = bool(self.last_done)
         dones = np.full((self.num_envs,), done, dtype=bool)
-        obs_np = self.obs.cpu().numpy()  # the step's ONE device->host copy; obs and infos are views of / built from it
-        infos = []
-        stats = None
+        # The step's observations stay in HBM (a snapshot: self.obs is rewritten by the next step) until somebody looks at them:
+        # ONE device->host copy then serves obs and infos alike.  (A fresh 38 MB host buffer per step costs ~20 ms of page
+        # faults at 4096 envs - more than the step.)
+        lazy_obs = LazyObsArray(self, self.obs.clone() if not self.eager_compat else self.obs.cpu().numpy(), counts)
+        cache = {}
+
+        def full_np():
+            if "full" not in cache:
+                cache["full"] = full_dev.cpu().numpy() if full_dev is not None else lazy_obs._dense[:, -1]
+            return cache["full"]
+        stats = term = None
         if done:
             stats = [x.cpu().numpy() for x in self.episode_stats()]
-            term = self._compat_obs(obs_np, counts_before)
-        for e in range(self.num_envs):
+            term = self._compat_obs(lazy_obs._dense, counts)
+
+        def make_info(e):
             eager = {}
             if done:
                 eager["episode_r"] = stats[0][e].copy()
@@ -482,15 +689,17 @@ class BatchedDynEnv(object):
                 eager["episode_o_r"] = stats[2][e].copy() if self.env_type == DynEnvType.ROBO_CUP else [0, ] * self.n_agents
                 eager["episode_g"] = [int(stats[3][e, 0]), int(stats[3][e, 1])]
                 eager["terminal_observation"] = [list(term[e, t]) for t in range(self.n_time_steps)]
-            infos.append(LazyInfo(lambda e=e: self._full_states(obs_np, counts_before, e), eager))
+            return LazyInfo(lambda: self._full_states(full_np(), counts, e), eager)
+        infos = LazyInfos(self.num_envs, make_info)
+        if self.eager_compat:
+            infos = tuple(infos)
         if done:
             self.terminal_obs = self.obs.clone()
             self.reset_flat()
-            counts = self.counts().cpu().numpy()
-            obs = self._compat_obs(self.obs, counts)
+            obs = self._wrap_obs(self.obs.clone() if not self.eager_compat else self.obs.cpu().numpy(), self._host_counts())
         else:
-            obs = self._compat_obs(obs_np, counts_before)
-        return obs, rewards, dones, tuple(infos)
+            obs = self._compat_obs(lazy_obs._dense, counts) if self.eager_compat else lazy_obs
+        return obs, rewards, dones, infos
 
     def step(self, actions):
         self.step_async(actions)
@@ -520,11 +729,11 @@ class BatchedDynEnv(object):
     def env_method(self, method_name, *method_args, indices=None, **method_kwargs):
         idx = self._get_indices(indices)
         if method_name == "get_agent_locs":
-            o = self.obs.cpu().numpy()
+            o = self.full_state_obs().cpu().numpy()  # getFullState(agent): the true state, whatever the observation type
             if self.env_type == DynEnvType.ROBO_CUP:  # RoboCupEnvironment.py:434-435: self rows [:, 0:6]
-                return [[o[e, -1, a, 4:10].reshape(1, 6).copy() for a in range(self.n_agents)] for e in idx]
+                return [[o[e, a, 4:10].reshape(1, 6).copy() for a in range(self.n_agents)] for e in idx]
             # DrivingEnvironment.py:126-127: self rows [x, y, cos, sin] per agent
-            return [[o[e, -1, a, 0:4].reshape(1, 4).copy() for a in range(self.n_agents)] for e in idx]
+            return [[o[e, a, 0:4].reshape(1, 4).copy() for a in range(self.n_agents)] for e in idx]
         if method_name == "set_random_seed":
             return self.seed(*method_args)
         raise NotImplementedError(method_name)

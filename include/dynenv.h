@@ -159,6 +159,14 @@ int dynenv_reset(dynenv_t* h, float* obs_dev, void* stream);
 int dynenv_step(dynenv_t* h, const int32_t* actions_dev, float* obs_dev, double* rewards_dev, uint8_t* dones_dev,
                 void* stream);
 
+/* The noise-free Full observation of the CURRENT state, whatever the handle's observation type: full_dev float32
+ * [E, A, dynenv_full_obs_dim(h)] in the Full layout (Driving: self 9 | cars (A-1) x 7 | obstacles 20 x 4 | pedestrians 20 x 2 |
+ * lanes 8 x 5; RoboCup: ball 4 | self 8 | robots (A-1) x 6).  This is what the reference puts into info['Full State'] /
+ * info['Recon States'] after every step in every observation mode (getFullState, DrivingEnvironment.py:306-307,
+ * RoboCupEnvironment.py:511-512) and what a caller needs after dynenv_set_state / dynenv_checkpoint_load. */
+int dynenv_full_obs_dim(const dynenv_t* h);
+int dynenv_full_obs(dynenv_t* h, float* full_dev, void* stream);
+
 /* dynenv_step with the reference's continuous head action: RoboCup built with allowHeadTurn (make_dyn_env's
  * use_continuous_actions, DynEnv/__init__.py:11) takes Tuple((MultiDiscrete([5, 3, 3]), Box(-3, 3, (1,))))
  * (RoboCupEnvironment.py:339-342); head_dev float64 [E, A] carries the Box channel (turnHead(head), Robot.py:136-138),
@@ -181,7 +189,9 @@ int dynenv_set_state(dynenv_t* h, int32_t env_idx, const void* host_blob, size_t
 
 int dynenv_sync(dynenv_t* h, void* stream);
 
-/* OR over all environments of the kernels' error flags (bit 0: contact cache overflow, a pair was dropped).
+/* OR over all environments of the kernels' error flags (bit 0: contact cache overflow, a pair was dropped; bit 1: an action
+ * outside the action space was seen - the reference raises there, DrivingEnvironment.py:365-368 / RoboCupEnvironment.py:543-550;
+ * here that agent's action is ignored for the step and the flag stays up until the next reset).
  * Synchronises the device. */
 int dynenv_error_flags(dynenv_t* h, int32_t* out);
 

@@ -138,6 +138,9 @@ static void car_crash(Car* c) { /* Car.py:111-117 */
 void drv_process_action(DrivingEnv* e, int index, const int32_t* action) { /* :357-373 */
   int acc = action[0] - 1;
   int steer = (action[1] - 1) * 2;
+  /* action_space is MultiDiscrete([3, 3]); the reference raises on a malformed action (:365-368), the batched step lets the
+   * car coast instead (the HIP kernel also raises its environment's error flag) */
+  if (action[0] < 0 || action[0] > 2 || action[1] < 0 || action[1] > 2) { acc = 0; steer = 0; }
   car_accelerate(&e->cars[index], acc);
   if (steer != 0) car_turn(&e->cars[index], steer);
 }

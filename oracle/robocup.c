@@ -176,6 +176,9 @@ void rc_process_action(RoboCupEnv* e, Robot* robot, const int32_t* action) {
   if (e->allowHeadTurn && e->headActions) head = e->headActions[robot->id];
   if (e->deterministicTurn) head = (double)(-3 * robot->team); /* :529-530 */
   if (!e->allowHeadTurn) head -= 3.0;
+  /* the reference raises on a malformed action (:543-550); the batched step cannot: the robot keeps still (the HIP kernel also
+   * raises its environment's error flag) */
+  if (move < 0 || move > 4 || turn < 0 || turn > 2 || kick < 0 || kick > 2 || !(dm_abs(head) <= 6.0)) return;
   canMove = !(robot->penalized || robot->kicking || robot->fallen);
   if (move > 0 && canMove) {
     double r = e->canFall ? dm_unit(u.v[0]) : 0.0;

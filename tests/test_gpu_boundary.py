@@ -1,0 +1,243 @@
+"""The drop-in boundary on the GPU (round 2): lazy compat observations / infos equal the eager forms element for element,
+info['Full State'] with Partial observations equals the oracle's noise-free state rows, RoboCup's class switches
+(randomInit, deterministicTurn) and the continuous head channel against the oracle, malformed actions, checkpoint / replay
+across an episode end, refresh_obs, the device guard."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu(oracle_built):
+    import torch
+    import dynenv_amd
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return dynenv_amd, torch, oracle_built
+
+
+def _acts(rng, env):
+    E, A = env.num_envs, env.n_agents
+    if env.action_dim == 2:
+        return rng.integers(0, 3, (E, A, 2)).astype(np.int32)
+    return np.stack([rng.integers(0, k, (E, A)) for k in (5, 3, 3, 7)], -1).astype(np.int32)
+
+
+def _same(a, b):
+    if isinstance(a, (list, tuple)):
+        assert type(a) is type(b) and len(a) == len(b)
+        for x, y in zip(a, b):
+            _same(x, y)
+    elif isinstance(a, np.ndarray):
+        assert a.shape == b.shape and a.dtype == b.dtype
+        np.testing.assert_array_equal(a, b)
+    else:
+        assert a == b
+
+
+CONFIGS = [("DRIVE", 10, {}), ("DRIVE", 10, "partial"), ("ROBO_CUP", 5, {}), ("ROBO_CUP", 5, "partial")]
+
+
+@pytest.mark.parametrize("kind,n,obs", CONFIGS)
+def test_lazy_compat_equals_eager_element_for_element(gpu, kind, n, obs):
+    dynenv_amd, torch, _ = gpu
+    from dynenv_amd import DynEnvType, NoiseType, ObservationType
+    kw = dict(observationType=ObservationType.PARTIAL, noiseType=NoiseType.REALISTIC, noiseMagnitude=3) if obs else {}
+    E = 6
+    env = dynenv_amd.BatchedDynEnv(getattr(DynEnvType, kind), E, n, seed=5, **kw)
+    rng = np.random.default_rng(1)
+    lazy = env.reset()
+    for s in range(3):
+        lazy, rew, dones, infos = env.step(_acts(rng, env))
+    eager = env._compat_obs(lazy._dense, lazy._counts)      # the round-1 eager builder on the same host copy
+    assert lazy.shape == eager.shape == (E, env.n_time_steps, env.n_agents, 3) and lazy.dtype == object
+    full = np.asarray(lazy)
+    assert full.dtype == object and full.shape == eager.shape
+    for idx in np.ndindex(*eager.shape):
+        _same(full[idx], eager[idx])
+        _same(lazy[idx], eager[idx])
+    # the reference's consumers slice it like this (models/train.py:67-68)
+    assert lazy[..., :-1].shape == eager[..., :-1].shape and lazy[..., -1].shape == eager[..., -1].shape
+    _same(lazy[..., -1][2, 0, 1], eager[..., -1][2, 0, 1])
+    _same(lazy[1:4, :, ::2][1, 0, 1, 1], eager[1:4, :, ::2][1, 0, 1, 1])
+    _same(lazy[-1][0][-1][0], eager[-1][0][-1][0])
+    assert len(lazy) == E and sum(1 for _ in lazy) == E
+    with pytest.raises(IndexError):
+        lazy[E]
+    # infos: a lazy sequence of dicts with the reference's keys
+    assert len(infos) == E and set(infos[0]) >= {"Full State", "Recon States"}
+    assert infos[E - 1] is infos[-1]
+    env.close()
+
+
+@pytest.mark.parametrize("kind,n", [("DRIVE", 10), ("DRIVE", 4), ("ROBO_CUP", 5), ("ROBO_CUP", 2)])
+def test_full_state_with_partial_observations_is_the_oracles_true_state(gpu, kind, n):
+    """info['Full State'] / info['Recon States'] come from getFullState - the noise-free state - in every observation mode
+    (DrivingEnvironment.py:306-307, RoboCupEnvironment.py:511-512): the Partial handle's rows equal the Full observation of an
+    oracle that runs the same seed and actions."""
+    dynenv_amd, torch, _ = gpu
+    from dynenv_amd import DynEnvType, NoiseType, ObservationType
+    E = 5
+    robocup = kind == "ROBO_CUP"
+    flags = ol.ROBOCUP_DEFAULT_FLAGS if robocup else 0
+    env = dynenv_amd.BatchedDynEnv(getattr(DynEnvType, kind), E, n, seed=9, flags=flags, observationType=ObservationType.PARTIAL,
+                                   noiseType=NoiseType.REALISTIC, noiseMagnitude=3)
+    ora = ol.OracleEnv(env_type=0 if robocup else 1, num_envs=E, n_players=n, seed=9, flags=flags)  # Full observations
+    env.reset()
+    ora.reset()
+    rng = np.random.default_rng(2)
+    A = env.n_agents
+    for s in range(4):
+        a = _acts(rng, env)
+        obs, rew, dones, infos = env.step(a)
+        oc, _, _ = ora.step(a)
+        np.testing.assert_array_equal(env.full_state_obs().cpu().numpy(), oc[:, -1], err_msg="step %d" % s)
+        for e in (0, E - 1):
+            recon = infos[e]["Recon States"]
+            assert len(recon) == A
+            for ag in range(A):
+                if robocup:
+                    np.testing.assert_array_equal(recon[ag][0], oc[e, -1, ag, 0:4].reshape(1, 4))
+                    np.testing.assert_array_equal(recon[ag][1], oc[e, -1, ag, 4:12].reshape(1, 8))
+                    np.testing.assert_array_equal(recon[ag][2], oc[e, -1, ag, 12:12 + (A - 1) * 6].reshape(A - 1, 6))
+                else:
+                    np.testing.assert_array_equal(recon[ag][0], oc[e, -1, ag, 0:9].reshape(1, 9))
+                    np.testing.assert_array_equal(recon[ag][1], oc[e, -1, ag, 9:9 + (A - 1) * 7].reshape(A - 1, 7))
+            assert infos[e]["Full State"] is not None
+        locs = env.env_method("get_agent_locs", indices=[1])[0]   # the true poses, not the noisy self rows
+        for ag in range(A):
+            np.testing.assert_array_equal(locs[ag][0], oc[1, -1, ag, 4:10] if robocup else oc[1, -1, ag, 0:4])
+    env.close()
+
+
+@pytest.mark.parametrize("flags", [ol.FLAG_RANDOM_INIT | ol.FLAG_CAN_FALL, ol.FLAG_DETERMINISTIC_TURN | ol.FLAG_CAN_FALL,
+                                   ol.FLAG_RANDOM_INIT | ol.FLAG_DETERMINISTIC_TURN, 0])
+def test_robocup_class_switches_against_the_oracle(gpu, flags):
+    """randomInit (random robot spots, ball position and ownership), deterministicTurn (head preset + forced head action),
+    and canFall = useObsRewards = False (flags = 0 is an explicit choice, not "defaults")."""
+    dynenv_amd, torch, _ = gpu
+    E, n = 16, 5
+    env = dynenv_amd.BatchedDynEnv(dynenv_amd.DynEnvType.ROBO_CUP, E, n, seed=21, flags=flags)
+    ora = ol.OracleEnv(env_type=0, num_envs=E, n_players=n, seed=21, flags=flags)
+    assert env.cfg.flags == flags
+    np.testing.assert_array_equal(env.reset_flat().cpu().numpy(), ora.reset())
+    rng = np.random.default_rng(3)
+    for s in range(12):
+        a = _acts(rng, env)
+        og, rg, dg = env.step_flat(a)
+        oc, rc, dc = ora.step(a)
+        np.testing.assert_array_equal(rg.cpu().numpy(), rc, err_msg="rewards step %d" % s)
+        np.testing.assert_array_equal(og.cpu().numpy(), oc, err_msg="obs step %d" % s)
+    if flags & ol.FLAG_RANDOM_INIT:
+        owned = {env.get_state(e).ball_owned for e in range(E)}
+        assert len(owned) > 1, "randomInit draws the ball ownership"
+    env.close()
+
+
+def test_robocup_continuous_head_channel(gpu):
+    """make_dyn_env(use_continuous_actions=True) -> allowHeadTurn: the 4th action is the reference's Box(-3, 3) head turn and
+    reaches Robot.turnHead as a float (dynenv_step_head), bit-identical to the oracle"""
+    dynenv_amd, torch, _ = gpu
+    from dynenv_amd import DynEnvType, NoiseType, ObservationType, make_dyn_env
+    E, n = 8, 5
+    venv, name = make_dyn_env(DynEnvType.ROBO_CUP, E, n, False, ObservationType.FULL, NoiseType.REALISTIC, 0, True, seed=4)
+    assert venv.allow_head_turn and len(venv.action_space.spaces) == 2
+    flags = ol.ROBOCUP_DEFAULT_FLAGS | ol.FLAG_ALLOW_HEAD_TURN
+    ora = ol.OracleEnv(env_type=0, num_envs=E, n_players=n, seed=4, flags=flags)
+    np.testing.assert_array_equal(venv.reset_flat().cpu().numpy(), ora.reset())
+    rng = np.random.default_rng(5)
+    for s in range(10):
+        a = _acts(rng, venv).astype(np.float64)
+        a[..., 3] = np.round((rng.random((E, 2 * n)) - 0.5) * 6.0, 3) * (rng.random((E, 2 * n)) > 0.2)
+        og, rg, dg = venv.step_flat(a, validate=True)
+        oc, rc, dc = ora.step(a.astype(np.int32), head=a[..., 3])
+        np.testing.assert_array_equal(rg.cpu().numpy(), rc, err_msg="rewards step %d" % s)
+        np.testing.assert_array_equal(og.cpu().numpy(), oc, err_msg="obs step %d" % s)
+    heads = {venv.get_state(0).robots[r].head_angle for r in range(2 * n)}
+    assert any(abs(h) > 1e-6 and abs(h * 720 / np.pi - round(h * 720 / np.pi)) > 1e-6 for h in heads), "fractional head turns must show"
+    with pytest.raises(Exception):
+        bad = _acts(rng, venv).astype(np.float64)
+        bad[..., 3] = 7.5
+        venv.step_flat(bad, validate=True)
+    venv.close()
+
+
+@pytest.mark.parametrize("kind", ["DRIVE", "ROBO_CUP"])
+def test_malformed_actions_raise_a_flag_and_move_nothing(gpu, kind):
+    """the reference raises on an action outside the action space; the batched kernels ignore that agent's action for the step
+    (the oracle does the same) and report error bit 1 - never an out-of-range index"""
+    dynenv_amd, torch, _ = gpu
+    robocup = kind == "ROBO_CUP"
+    E, n = 4, 5 if robocup else 10
+    flags = ol.ROBOCUP_DEFAULT_FLAGS if robocup else 0
+    env = dynenv_amd.BatchedDynEnv(getattr(dynenv_amd.DynEnvType, kind), E, n, seed=8, flags=flags)
+    ora = ol.OracleEnv(env_type=0 if robocup else 1, num_envs=E, n_players=n, seed=8, flags=flags)
+    env.reset_flat(); ora.reset()
+    rng = np.random.default_rng(6)
+    a = _acts(rng, env)
+    a[1, 2, 0] = 9
+    a[2, 0, 1] = -3
+    if robocup:
+        a[3, 4, 2] = 5
+    og, rg, dg = env.step_flat(a)           # validate=False: straight into the kernel
+    oc, rc, dc = ora.step(a)
+    np.testing.assert_array_equal(rg.cpu().numpy(), rc)
+    np.testing.assert_array_equal(og.cpu().numpy(), oc)
+    assert env.error_flags() & 2
+    with pytest.raises(Exception):
+        env.step_flat(a, validate=True)
+    env.close()
+
+
+@pytest.mark.parametrize("kind,n", [("DRIVE", 10), ("ROBO_CUP", 5)])
+def test_checkpoint_and_replay_across_an_episode_end(gpu, kind, n, tmp_path):
+    """restore() puts the host's episode position where the device state is: a checkpoint taken near the end of an episode and
+    restored into a FRESH handle resets at the same step as the original run and stays bit-identical after the reset"""
+    dynenv_amd, torch, _ = gpu
+    robocup = kind == "ROBO_CUP"
+    E = 8
+    mk = lambda: dynenv_amd.BatchedDynEnv(getattr(dynenv_amd.DynEnvType, kind), E, n, seed=13)
+    env = mk()
+    env.reset_flat()
+    rng = np.random.default_rng(7)
+    S = env.steps_per_episode
+    acts = [_acts(rng, env) for _ in range(S + 12)]
+    for s in range(S - 6):
+        env.step_flat(acts[s])
+    ck = env.checkpoint()
+    ref = []
+    for s in range(S - 6, S + 12):
+        o, r, d = env.step_flat(acts[s])
+        ref.append((o.cpu().numpy().copy(), r.cpu().numpy().copy(), bool(env.last_done)))
+    assert [x[2] for x in ref].count(True) == 1 and ref[5][2], "the episode ends 6 steps after the checkpoint"
+    env2 = mk()
+    env2.restore(ck)
+    assert env2._episode_step == S - 6
+    for k, s in enumerate(range(S - 6, S + 12)):
+        o, r, d = env2.step_flat(acts[s])
+        assert bool(env2.last_done) == ref[k][2], "step %d" % s
+        np.testing.assert_array_equal(r.cpu().numpy(), ref[k][1], err_msg="rewards step %d" % s)
+        np.testing.assert_array_equal(o.cpu().numpy(), ref[k][0], err_msg="obs step %d" % s)
+    env.close(); env2.close()
+
+
+def test_refresh_obs_and_device_guard(gpu):
+    dynenv_amd, torch, _ = gpu
+    env = dynenv_amd.BatchedDynEnv(dynenv_amd.DynEnvType.DRIVE, 4, 10, seed=3)
+    dev = torch.cuda.current_device()
+    obs0 = env.reset_flat().clone()
+    env.obs.zero_()
+    np.testing.assert_array_equal(env.refresh_obs().cpu().numpy(), obs0.cpu().numpy())
+    st = env.get_state(2)
+    env.set_state(2, st)
+    np.testing.assert_array_equal(env.refresh_obs().cpu().numpy(), obs0.cpu().numpy())
+    assert torch.cuda.current_device() == dev
+    with pytest.raises(dynenv_amd._capi.DynEnvError):
+        dynenv_amd.BatchedDynEnv(dynenv_amd.DynEnvType.DRIVE, 4, 10, flags=4)      # RoboCup's switches mean nothing to Driving
+    with pytest.raises(dynenv_amd._capi.DynEnvError):
+        dynenv_amd.BatchedDynEnv(dynenv_amd.DynEnvType.ROBO_CUP, 4, 5, flags=64)   # unknown bit
+    env.close()

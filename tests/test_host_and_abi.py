@@ -156,3 +156,46 @@ def test_packed_slab_layouts_on_cpu():
             o, r, d = s.gathered_views(g, 3)
             assert o.shape == (3, E, T, A, D) and r.shape == (3, E, A) and d.shape == (3, E)
     assert peers.nbytes < tail.nbytes < dense.nbytes
+
+
+def test_lazy_obs_array_indexes_like_the_object_ndarray():
+    """LazyObsArray (the compat observation of step() / reset()) follows numpy's basic indexing on [E, T, A, 3]"""
+    from dynenv_amd.vec_env import LazyInfos, LazyObsArray
+
+    class Owner(object):
+        def _compat_element(self, dense, counts, e, t, a):
+            return [("mov", e, t, a), ("stat", e, t, a), (1, 1, 1)]
+    E, T, A = 4, 2, 3
+    dense = np.zeros((E, T, A, 7), np.float32)
+    lazy = LazyObsArray(Owner(), dense, None)
+    ref = np.empty((E, T, A, 3), dtype=object)
+    for e in range(E):
+        for t in range(T):
+            for a in range(A):
+                for k, v in enumerate(Owner()._compat_element(dense, None, e, t, a)):
+                    ref[e, t, a, k] = v
+    assert lazy.shape == ref.shape and lazy.ndim == 4 and lazy.dtype == object and len(lazy) == E
+    full = np.asarray(lazy)
+    assert full.shape == ref.shape and all(full[i] == ref[i] for i in np.ndindex(*ref.shape))
+    cases = [(1, 0, 2, 1), (-1, -1, -1, -1), (Ellipsis, -1), (Ellipsis, slice(None, -1)), (slice(1, 3),), (2,), (slice(None), 1),
+             (0, Ellipsis, 2), (slice(None, None, 2), slice(None), slice(1, None), 0), (Ellipsis,)]
+    for idx in cases:
+        got, exp = lazy[idx], ref[idx]
+        if isinstance(exp, np.ndarray):
+            assert got.shape == exp.shape, idx
+            g = np.asarray(got)
+            assert all(g[i] == exp[i] for i in np.ndindex(*exp.shape)), idx
+        else:
+            assert got == exp, idx
+    assert lazy[1][0][2][0] == ref[1][0][2][0]
+    assert [x.shape for x in lazy] == [(T, A, 3)] * E
+    with pytest.raises(IndexError):
+        lazy[E]
+    with pytest.raises(IndexError):
+        lazy[0, 0, 0, 0, 0]
+    made = []
+    infos = LazyInfos(5, lambda i: made.append(i) or {"i": i})
+    assert len(infos) == 5 and not made
+    assert infos[3]["i"] == 3 and infos[-2] is infos[3] and made == [3]
+    assert [d["i"] for d in infos] == [0, 1, 2, 3, 4] and sorted(made) == [0, 1, 2, 3, 4]
+    assert isinstance(infos[1:3], tuple) and len(infos[1:3]) == 2

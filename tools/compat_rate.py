@@ -1,18 +1,47 @@
-import sys, time
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
-from dynenv_amd import make_dyn_env, DynEnvType, ObservationType, NoiseType
-for E in (64, 1024):
+"""Rate of the reference-compatible step() at BASELINE's batch size: the lazy observation / info containers
+(what a drop-in caller gets), the same with the caller touching EVERY element, the eager object array of round 1, and the
+PCIe-inclusive floor (step_flat + one device->host copy of the observations).   Usage (GPU box): python tools/compat_rate.py"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from dynenv_amd import DynEnvType, NoiseType, ObservationType, make_dyn_env
+
+
+def rate(venv, a, n, touch):
+    venv.step(a)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        obs, rew, dones, infos = venv.step(a)
+        if touch:
+            np.asarray(obs)
+    return (time.perf_counter() - t0) / n
+
+
+for E in (1024, 4096):
+    a = np.ones((E, 10, 2), np.int64)
     venv, _ = make_dyn_env(DynEnvType.DRIVE, E, 10, False, ObservationType.FULL, NoiseType.REALISTIC, 0, False)
     venv.reset()
-    a = np.ones((E, 10, 2), np.int64)
-    venv.step(a)
-    t0 = time.perf_counter(); n = 5
-    for _ in range(n): venv.step(a)
-    dt = (time.perf_counter() - t0) / n
-    # host copy only (what a C caller with host buffers would pay): obs D2H
-    torch.cuda.synchronize(); t1 = time.perf_counter()
-    for _ in range(20): venv.step_flat(torch.ones((E, 10, 2), dtype=torch.int32, device="cuda")); h = venv.obs.cpu()
-    torch.cuda.synchronize(); dt2 = (time.perf_counter() - t1) / 20
-    print("E=%d compat step(): %.1f ms/step = %.2f M agent-steps/s ; step_flat + obs D2H: %.3f ms/step = %.1f M agent-steps/s" % (E, dt * 1e3, E * 10 / dt / 1e6, dt2 * 1e3, E * 10 / dt2 / 1e6))
+    lazy = rate(venv, a, 20, False)
+    touched = rate(venv, a, 3, True)
     venv.close()
+    venv, _ = make_dyn_env(DynEnvType.DRIVE, E, 10, False, ObservationType.FULL, NoiseType.REALISTIC, 0, False, eager_compat=True)
+    venv.reset()
+    eager = rate(venv, a, 3, False)
+    ad = torch.ones((E, 10, 2), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(20):
+        venv.step_flat(ad, auto_reset=False)
+        venv.obs.cpu()
+    torch.cuda.synchronize()
+    floor = (time.perf_counter() - t1) / 20
+    venv.close()
+    print("E=%d Driving Full: compat step() lazy %.2f ms = %.1f M agent-steps/s | every element touched %.1f ms = %.2f M | eager "
+          "(round 1 form) %.1f ms = %.2f M | step_flat + obs D2H %.2f ms = %.1f M"
+          % (E, lazy * 1e3, E * 10 / lazy / 1e6, touched * 1e3, E * 10 / touched / 1e6, eager * 1e3, E * 10 / eager / 1e6,
+             floor * 1e3, E * 10 / floor / 1e6))
