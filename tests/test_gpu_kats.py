@@ -1,0 +1,131 @@
+"""Hand-derivable physics known answers on the HIP path (through set_state / get_state of the C ABI), beside the oracle:
+scenes small enough that contact point, normal and impulse follow from first principles, so that the kernels are checked
+against the formula and not only against the oracle (tests/test_oracle_physics.py runs the same family on the oracle's
+two-body sandbox).  -m gpu."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+BIAS = 0.061259621561307376  # 1 - collisionBias ** dt (Space defaults)
+SLOP = 0.1
+
+
+@pytest.fixture(scope="module")
+def gpu(oracle_built):
+    import torch
+    import dynenv_amd
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return dynenv_amd
+
+
+def ball_friction(vx, vy, w):
+    """cutils.apply_friction with friction_ball's coefficients (2.8e-2, 1e-3, spin 5e-2) and m = 10, as pinned by the goldens"""
+    factor, rot_factor, spin = 2.8e-2 * 10.0, 1e-3 * 10.0, 5e-2
+    length = 1.0 / (abs(vx) + abs(vy) + 1e-5)
+    a0 = vx * factor * length
+    a1 = vy * factor * length
+    a0 += a1 * spin * w
+    a1 -= a0 * spin * w
+    vx = 0.0 if abs(vx) < factor else vx - a0
+    vy = 0.0 if abs(vy) < factor else vy - a1
+    w = 0.0 if abs(w) < rot_factor else w - (rot_factor if w > 0 else -rot_factor)
+    return vx, vy, w
+
+
+def predict_ball_off_post(p, v, post, substeps, e=0.98 * 0.95):
+    """Ball (circle r = 10, m = 10) against a static goalpost (r = 10): per substep position update, then - in the substep that
+    first finds |c_post - c_ball| < 20 - the normal n = (c_post - c_ball) / |..| and the restitution target e * (v . n) taken
+    BEFORE the velocity function runs, the velocity function (friction), and the solve: v_n' = -e v_n(pre-friction), v_t
+    unchanged (u = u_ball * u_post = 0).  A separating contact exchanges no further impulse.  -> velocity after `substeps`."""
+    p, v = np.array(p, float), np.array(v, float)
+    touched = False
+    hit = None
+    for k in range(substeps):
+        p = p + v * 0.01
+        d = np.array(post) - p
+        dist = np.hypot(*d)
+        first = dist < 20.0 and not touched
+        if first:
+            n = d / dist
+            target = -e * (v @ n)
+        vx, vy, _ = ball_friction(v[0], v[1], 0.0)
+        v = np.array([vx, vy])
+        if first:
+            v = v + (target - v @ n) * n
+            touched = True
+            hit = k
+    return v, hit
+
+
+def _robocup_pair(dynenv_amd, seed=3):
+    flags = ol.FLAG_USE_OBS_REWARDS  # canFall off: no dice anywhere
+    env = dynenv_amd.BatchedDynEnv(dynenv_amd.DynEnvType.ROBO_CUP, 1, 5, seed=seed, flags=flags)
+    ora = ol.OracleEnv(env_type=0, num_envs=1, n_players=5, seed=seed, flags=flags)
+    env.reset_flat()
+    ora.reset()
+    return env, ora
+
+
+@pytest.mark.parametrize("p,v", [((125.0, 450.0), (-100.0, 0.0)),      # head-on
+                                 ((118.0, 462.0), (-90.0, -20.0)),     # oblique: normal off both axes
+                                 ((70.0, 332.0), (3.0, -80.0))])       # the other post of that goal, from above
+def test_kat_ball_bounces_off_a_goalpost(gpu, p, v):
+    env, ora = _robocup_pair(gpu)
+    st = ora.get_state(0)
+    st.bpx, st.bpy, st.bvx, st.bvy, st.bw = p[0], p[1], v[0], v[1], 0.0
+    st.bprevx, st.bprevy = p
+    env.set_state(0, st)
+    ora.set_state(0, st)
+    a = np.zeros((1, 10, 4), np.int32)
+    a[..., 3] = 3  # head action 3 = no head turn; nobody moves
+    og, rg, dg = env.step_flat(a)
+    oc, rc, dc = ora.step(a)
+    sg, so = env.get_state(0), ora.get_state(0)
+    assert [sg.bpx, sg.bpy, sg.bvx, sg.bvy, sg.bw] == [so.bpx, so.bpy, so.bvx, so.bvy, so.bw], "HIP == oracle, bit for bit"
+    post = (70.0, 450.0) if p[1] > 370 else (70.0, 290.0)
+    vexp, hit = predict_ball_off_post(p, v, post, 50)
+    assert hit is not None and 5 < hit < 45, "the bounce must fall inside the step"
+    np.testing.assert_allclose([sg.bvx, sg.bvy], vexp, rtol=1e-9, atol=1e-9)
+    assert sg.bw == 0.0
+    env.close()
+
+
+@pytest.mark.parametrize("car_type,pen0", [(0, 2.0), (3, 0.9)])
+def test_kat_resting_car_is_pushed_out_of_an_obstacle_geometrically(gpu, car_type, pen0):
+    """A car at rest overlapping a (static) obstacle by pen_0, face to face: the begin callback crashes it, no real velocity ever
+    appears, and the position correction alone acts: bias velocity = biasCoef (pen - slop) / dt, applied by the next position
+    update, hence  pen - slop = (pen_0 - slop) (1 - biasCoef)^k  after k position updates (10 s - 1 after s env steps; a
+    two-point manifold, symmetric: no rotation).  Runs through the Driving kernel's steady-state shortcuts."""
+    dynenv_amd = gpu
+    half_len = [10.0, 15.0, 20.0, 25.0][car_type]
+    env = dynenv_amd.BatchedDynEnv(dynenv_amd.DynEnvType.DRIVE, 1, 2, seed=5)
+    ora = ol.OracleEnv(env_type=1, num_envs=1, n_players=2, seed=5)
+    env.reset_flat()
+    ora.reset()
+    st = ora.get_state(0)
+    st.n_peds, st.n_obst = 0, 1
+    cx, cy = 300.0, 445.0   # the walkway strip between the buildings (y < 425) and the horizontal road (y > 460)
+    c = st.cars[0]
+    c.px, c.py, c.vx, c.vy, c.angle, c.w, c.dirx, c.diry = cx, cy, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0
+    c.prevx, c.prevy, c.type, c.finished, c.crashed, c.fric, c.lane_pos = cx, cy, car_type, 0, 0, 0, 4
+    o = st.cars[1]
+    o.px, o.py, o.vx, o.vy, o.w, o.prevx, o.prevy = 1500.0, 900.0, 0.0, 0.0, 0.0, 1500.0, 900.0
+    st.obst_x[0], st.obst_y[0] = cx + half_len + 10.0 - pen0, cy
+    env.set_state(0, st)
+    ora.set_state(0, st)
+    a = np.ones((1, 2, 2), np.int32)  # coast
+    for s in range(1, 5):
+        env.step_flat(a)
+        ora.step(a)
+        g, r = env.get_state(0).cars[0], ora.get_state(0).cars[0]
+        assert [g.px, g.py, g.vx, g.vy, g.angle, g.w] == [r.px, r.py, r.vx, r.vy, r.angle, r.w], "HIP == oracle, step %d" % s
+        pen = (g.px + half_len) - (st.obst_x[0] - 10.0)
+        np.testing.assert_allclose(pen - SLOP, (pen0 - SLOP) * (1.0 - BIAS) ** (10 * s - 1), rtol=1e-5)
+        # (the two contacts are relaxed one after the other, not simultaneously: the bias impulses leave a rotation of 1e-13 rad for
+        #  the short car and 1e-7 rad for the long one, which is where the 1e-5 on the closed form comes from)
+        assert g.vx == 0.0 and g.vy == 0.0 and g.w == 0.0 and abs(g.angle) < 1e-6 and abs(g.py - cy) < 1e-6 and g.crashed == 1
+    assert env.error_flags() == 0
+    env.close()
