@@ -123,9 +123,9 @@ def test_kat_resting_car_is_pushed_out_of_an_obstacle_geometrically(gpu, car_typ
         g, r = env.get_state(0).cars[0], ora.get_state(0).cars[0]
         assert [g.px, g.py, g.vx, g.vy, g.angle, g.w] == [r.px, r.py, r.vx, r.vy, r.angle, r.w], "HIP == oracle, step %d" % s
         pen = (g.px + half_len) - (st.obst_x[0] - 10.0)
-        np.testing.assert_allclose(pen - SLOP, (pen0 - SLOP) * (1.0 - BIAS) ** (10 * s - 1), rtol=1e-5)
+        np.testing.assert_allclose(pen - SLOP, (pen0 - SLOP) * (1.0 - BIAS) ** (10 * s - 1), rtol=1e-4)
         # (the two contacts are relaxed one after the other, not simultaneously: the bias impulses leave a rotation of 1e-13 rad for
-        #  the short car and 1e-7 rad for the long one, which is where the 1e-5 on the closed form comes from)
+        #  the short car and 1e-7 rad for the long one, which is where the 1e-4 on the closed form comes from)
         assert g.vx == 0.0 and g.vy == 0.0 and g.w == 0.0 and abs(g.angle) < 1e-6 and abs(g.py - cy) < 1e-6 and g.crashed == 1
     assert env.error_flags() == 0
     env.close()
