@@ -18,6 +18,49 @@ def shard_range(total_envs, rank, world_size):
     return rank * per, per
 
 
+# ---- the compacted transport formats, stated as index maps in numpy.  The HIP kernels (csrc/dynenv_capi.hip dynenv_obs_pack*,
+# dynenv_obs_unpack*) implement exactly these; PackedSlab uses the numpy form for CPU tensors (gloo tests), and
+# tests/test_gpu_sharded.py holds the kernels to it.
+PEER_SELF, PEER_COLS = 9, 7
+PEER_COL_MAP = (0, 1, 2, 3, 4, 5, 8)  # car c's row in another agent's list = these columns of c's own self block
+                                      # (x, y, cos, sin, w, h, finished: DrivingEnvironment.getFullState :703-721)
+
+
+def pack_tail_np(obs, split):
+    """[N, A, D] -> [N, A * split + (D - split)]: the A row prefixes, then the tail every row shares (taken from agent 0)."""
+    n, a, d = obs.shape
+    return np.concatenate([obs[:, :, :split].reshape(n, a * split), obs[:, 0, split:]], axis=1)
+
+
+def unpack_tail_np(packed, a, d, split):
+    n = packed.shape[0]
+    out = np.empty((n, a, d), packed.dtype)
+    out[:, :, :split] = packed[:, :a * split].reshape(n, a, split)
+    out[:, :, split:] = packed[:, None, a * split:]
+    return out
+
+
+def pack_peers_np(obs):
+    """Driving Full [N, A, D] -> [N, A * 9 + tail]: the A self blocks, then the obstacle / pedestrian / lane tail once."""
+    n, a, d = obs.shape
+    cars_end = PEER_SELF + (a - 1) * PEER_COLS
+    return np.concatenate([obs[:, :, :PEER_SELF].reshape(n, a * PEER_SELF), obs[:, 0, cars_end:]], axis=1)
+
+
+def unpack_peers_np(packed, a, d):
+    """Row of agent i = [self_i | for c != i ascending: self_c[PEER_COL_MAP] | tail]"""
+    n = packed.shape[0]
+    cars_end = PEER_SELF + (a - 1) * PEER_COLS
+    selfb = packed[:, :a * PEER_SELF].reshape(n, a, PEER_SELF)
+    out = np.empty((n, a, d), packed.dtype)
+    for i in range(a):
+        out[:, i, :PEER_SELF] = selfb[:, i]
+        for q, c in enumerate([c for c in range(a) if c != i]):
+            out[:, i, PEER_SELF + q * PEER_COLS:PEER_SELF + (q + 1) * PEER_COLS] = selfb[:, c][:, list(PEER_COL_MAP)]
+        out[:, i, cars_end:] = packed[:, a * PEER_SELF:]
+    return out
+
+
 class PackedSlab(object):
     """One flat byte buffer per rank holding obs|rewards|dones so a single collective moves a whole step.
 
@@ -29,7 +72,7 @@ class PackedSlab(object):
     With split / peers the step kernel writes a separate dense tensor (`obs`), pack() fills the slab and gathered_views()
     expands the gathered slabs of all ranks into a dense [G, E, T, A, D] tensor again, bit for bit."""
 
-    PEER_SELF, PEER_COLS = 9, 7
+    PEER_SELF, PEER_COLS = PEER_SELF, PEER_COLS
 
     def __init__(self, torch, device, E, T, A, D, split=None, peers=False):
         self.torch = torch
@@ -71,6 +114,11 @@ class PackedSlab(object):
         """dense self.obs -> the slab's compacted obs region (a no-op for the dense layout); on the current stream"""
         if not self.packed:
             return
+        if self.buf.device.type == "cpu":  # the index maps in numpy (gloo tests; a CPU tensor never meets the HIP library)
+            o = self.obs.numpy().reshape(self.E * self.T, self.A, self.D)
+            p = pack_peers_np(o) if self.peers else pack_tail_np(o, self.split)
+            self._packed.copy_(self.torch.from_numpy(p).view(self.E, self.T, self.row))
+            return
         import ctypes as C
         capi, lib = self._capi()
         st = C.c_void_p(self.torch.cuda.current_stream(self.buf.device).cuda_stream)
@@ -89,6 +137,11 @@ class PackedSlab(object):
         if not self.packed:
             obs = g[:, :self.obs_bytes].view(t.float32).view(world_size, self.E, self.T, self.A, self.D)
             return obs, rew, dones
+        if gbuf.device.type == "cpu":
+            p = g[:, :self.obs_bytes].contiguous().view(t.float32).numpy().reshape(world_size * self.E * self.T, self.row)
+            o = unpack_peers_np(p, self.A, self.D) if self.peers else unpack_tail_np(p, self.A, self.D, self.split)
+            dense_out.copy_(t.from_numpy(o).view(world_size, self.E, self.T, self.A, self.D))
+            return dense_out, rew, dones
         import ctypes as C
         capi, lib = self._capi()
         st = C.c_void_p(t.cuda.current_stream(self.buf.device).cuda_stream)

@@ -19,7 +19,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, total_envs, steps, out_dir, pipelined=False):
+def _worker(rank, world, port, total_envs, steps, out_dir, pipelined=False, robocup=False, transport="dense"):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     import torch
@@ -31,12 +31,22 @@ def _worker(rank, world, port, total_envs, steps, out_dir, pipelined=False):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     off, per = shard_range(total_envs, rank, world)
     A = 10
-    ora = ol.OracleEnv(env_type=1, num_envs=per, n_players=A, seed=42, env_id_offset=off)
-    slab = PackedSlab(torch, torch.device("cpu"), per, ora.T, A, ora.D)
-    slab2 = PackedSlab(torch, torch.device("cpu"), per, ora.T, A, ora.D) if pipelined else None
+    if robocup:
+        ora = ol.OracleEnv(env_type=0, num_envs=per, n_players=5, seed=42, env_id_offset=off, flags=ol.ROBOCUP_DEFAULT_FLAGS)
+    else:
+        ora = ol.OracleEnv(env_type=1, num_envs=per, n_players=A, seed=42, env_id_offset=off)
+    # the transport formats of dynenv_amd.distributed on CPU tensors (their index maps in numpy): dense, shared-tail, peer-compacted
+    layout = {} if transport == "dense" else dict(split=9 + (A - 1) * 7) if transport == "tail" else dict(peers=True)
+    slab = PackedSlab(torch, torch.device("cpu"), per, ora.T, A, ora.D, **layout)
+    slab2 = PackedSlab(torch, torch.device("cpu"), per, ora.T, A, ora.D, **layout) if pipelined else None
     gather = StepGather(torch, dist, slab, slab2=slab2)
+    if transport != "dense":
+        assert slab.nbytes < PackedSlab(torch, torch.device("cpu"), per, ora.T, A, ora.D).nbytes // 2
     rng = np.random.default_rng(123)
-    all_actions = rng.integers(0, 3, size=(steps, total_envs, A, 2)).astype(np.int32)
+    if robocup:
+        all_actions = np.stack([rng.integers(0, k, size=(steps, total_envs, A)) for k in (5, 3, 3, 7)], -1).astype(np.int32)
+    else:
+        all_actions = rng.integers(0, 3, size=(steps, total_envs, A, 2)).astype(np.int32)
 
     def publish(obs, rew, done):
         slab.obs.copy_(torch.from_numpy(obs))
@@ -78,15 +88,17 @@ def _worker(rank, world, port, total_envs, steps, out_dir, pipelined=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("pipelined", [False, True])
-def test_two_rank_gather_and_shard_invariance(tmp_path, oracle_built, pipelined):
+@pytest.mark.parametrize("pipelined,robocup,transport", [(False, False, "dense"), (True, False, "dense"), (True, False, "compact"),
+                                                         (False, False, "tail"), (True, True, "dense")])
+def test_two_rank_gather_and_shard_invariance(tmp_path, oracle_built, pipelined, robocup, transport):
     import torch.multiprocessing as mp
     total, steps, world = 8, 6, 2
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, total, steps, str(tmp_path), pipelined), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, total, steps, str(tmp_path), pipelined, robocup, transport), nprocs=world, join=True)
     z = np.load(os.path.join(str(tmp_path), "gathered.npz"))
     import oracle_lib as ol
-    single = ol.OracleEnv(env_type=1, num_envs=total, n_players=10, seed=42, env_id_offset=0)
+    single = (ol.OracleEnv(env_type=0, num_envs=total, n_players=5, seed=42, env_id_offset=0, flags=ol.ROBOCUP_DEFAULT_FLAGS) if robocup
+              else ol.OracleEnv(env_type=1, num_envs=total, n_players=10, seed=42, env_id_offset=0))
     o0 = single.reset()
     np.testing.assert_array_equal(z["obs0"], o0)
     for s in range(steps):

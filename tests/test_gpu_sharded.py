@@ -9,15 +9,20 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _process_group_teardown():
+    yield
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def test_sharded_env_pipelined_gather_rccl_world1():
     import torch
     import torch.distributed as dist
     from dynenv_amd import BatchedDynEnv, DynEnvType
     from dynenv_amd.distributed import ShardedDynEnv
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    _rccl_world1()
     try:
         E, A, steps = 64, 10, 24
         sh = ShardedDynEnv(DynEnvType.DRIVE, E, A, gather=True, seed=3, device="cuda:0")
@@ -41,7 +46,7 @@ def test_sharded_env_pipelined_gather_rccl_world1():
         o, r, d = ref.step_flat(acts[0])
         assert torch.equal(go[0], o) and torch.equal(gr[0], r)
     finally:
-        dist.destroy_process_group()
+        pass  # the process group (RCCL, world_size 1) is shared by this module's tests
 
 
 def test_obs_pack_unpack_roundtrip():
@@ -95,3 +100,89 @@ def test_obs_peer_compaction_roundtrip(A, tail):
     y = torch.full_like(x, float("nan"))
     _capi.check(lib.dynenv_obs_unpack_peers_ranks(C.c_void_p(packed.data_ptr()), stride, G, ET, A, D, C.c_void_p(y.data_ptr()), st), "unpack")
     assert torch.equal(x, y)
+
+
+def _rccl_world1():
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    return torch, dist
+
+
+def test_pack_kernels_follow_the_numpy_index_maps_on_real_observations():
+    """dynenv_obs_pack / dynenv_obs_pack_peers on observations the step kernel wrote == dynenv_amd.distributed.pack_*_np (the
+    format's definition, checked on the CPU against the oracle in tests/test_host_and_abi.py), and the unpack kernels invert them"""
+    import ctypes as C
+    import torch
+    from dynenv_amd import BatchedDynEnv, DynEnvType, _capi
+    from dynenv_amd.distributed import pack_peers_np, pack_tail_np
+    lib = _capi.load()
+    E, A = 32, 10
+    env = BatchedDynEnv(DynEnvType.DRIVE, E, A, seed=11, device="cuda:0")
+    env.reset_flat()
+    rng = np.random.default_rng(2)
+    for _ in range(30):
+        env.step_flat(rng.integers(0, 3, (E, A, 2)).astype(np.int32))
+    D, split = env.obs_dim, 9 + (A - 1) * 7
+    x = env.obs.reshape(E, A, D).contiguous()
+    xn = x.cpu().numpy()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p_tail = torch.empty((E, A * split + D - split), device="cuda")
+    p_peer = torch.empty((E, A * 9 + D - split), device="cuda")
+    _capi.check(lib.dynenv_obs_pack(C.c_void_p(x.data_ptr()), E, A, D, split, C.c_void_p(p_tail.data_ptr()), st), "pack")
+    _capi.check(lib.dynenv_obs_pack_peers(C.c_void_p(x.data_ptr()), E, A, D, C.c_void_p(p_peer.data_ptr()), st), "pack_peers")
+    np.testing.assert_array_equal(p_tail.cpu().numpy(), pack_tail_np(xn, split))
+    np.testing.assert_array_equal(p_peer.cpu().numpy(), pack_peers_np(xn))
+    y = torch.full_like(x, float("nan"))
+    _capi.check(lib.dynenv_obs_unpack_peers_ranks(C.c_void_p(p_peer.data_ptr()), p_peer.numel(), 1, E, A, D, C.c_void_p(y.data_ptr()), st), "unpack")
+    assert torch.equal(x, y)
+    env.close()
+
+
+@pytest.mark.parametrize("kind,transport", [("DRIVE", "tail"), ("DRIVE", "dense"), ("ROBO_CUP", "auto"), ("DRIVE_PARTIAL", "auto")])
+def test_pipelined_gather_over_rccl_other_transports_and_environments(kind, transport):
+    """the whole N > 1 path at world_size 1 for the shared-tail and dense transports and for the environments whose
+    observations travel dense (RoboCup, Partial observations): gathered views == a plain BatchedDynEnv, bit for bit"""
+    torch, dist = _rccl_world1()
+    from dynenv_amd import BatchedDynEnv, DynEnvType, NoiseType, ObservationType
+    from dynenv_amd.distributed import PackedSlab, StepGather, shared_tail_split, transport_layout
+    robocup = kind == "ROBO_CUP"
+    kw = dict(observationType=ObservationType.PARTIAL, noiseType=NoiseType.REALISTIC, noiseMagnitude=3) if kind == "DRIVE_PARTIAL" else {}
+    et = DynEnvType.ROBO_CUP if robocup else DynEnvType.DRIVE
+    E, n, steps = 32, 5 if robocup else 10, 10
+    probe = BatchedDynEnv(et, 1, n, device="cuda:0", **kw)
+    T, A, D = probe.n_time_steps, probe.n_agents, probe.obs_dim
+    if transport == "auto":
+        layout = transport_layout(probe)
+        assert layout == {}, "only Driving Full observations have a compacted form"
+    else:
+        layout = dict(split=shared_tail_split(probe)) if transport == "tail" else {}
+    probe.close()
+    slabs = [PackedSlab(torch, torch.device("cuda:0"), E, T, A, D, **layout) for _ in range(3)]
+    gather = StepGather(torch, dist, slabs[0], more=slabs[1:])
+    env = BatchedDynEnv(et, E, n, seed=6, device="cuda:0", out_buffers=(slabs[0].obs, slabs[0].rewards, slabs[0].dones), **kw)
+    ref = BatchedDynEnv(et, E, n, seed=6, device="cuda:0", **kw)
+    env.reset_flat(); ref.reset_flat()
+    rng = np.random.default_rng(1)
+    hi = (5, 3, 3, 7) if robocup else (3, 3)
+    handles, want = [], []
+    for k in range(steps):
+        a = torch.tensor(np.stack([rng.integers(0, h, (E, A)) for h in hi], -1).astype(np.int32), device="cuda:0")
+        gather.release(k)
+        sl = gather.slabs[k % 3]
+        env.use_buffers(sl.obs, sl.rewards, sl.dones)
+        env.step_flat(a, auto_reset=False)
+        handles.append(gather.start(k))
+        o, r, d = ref.step_flat(a, auto_reset=False)
+        want.append((o.clone(), r.clone()))
+        if k >= 1:
+            go, gr, gd = handles[k - 1].wait()
+            assert torch.equal(go[0], want[k - 1][0]) and torch.equal(gr[0], want[k - 1][1]), "step %d" % (k - 1)
+    go, gr, gd = handles[-1].wait()
+    assert torch.equal(go[0], want[-1][0]) and torch.equal(gr[0], want[-1][1])
+    gather.drain()
+    env.close(); ref.close()

@@ -199,3 +199,46 @@ def test_lazy_obs_array_indexes_like_the_object_ndarray():
     assert infos[3]["i"] == 3 and infos[-2] is infos[3] and made == [3]
     assert [d["i"] for d in infos] == [0, 1, 2, 3, 4] and sorted(made) == [0, 1, 2, 3, 4]
     assert isinstance(infos[1:3], tuple) and len(infos[1:3]) == 2
+
+
+@pytest.mark.parametrize("A", [10, 4, 2])
+def test_compacted_transport_index_maps_on_real_observations(oracle_built, A):
+    """The multi-GPU transport formats as index maps (dynenv_amd.distributed.pack_*_np / unpack_*_np, what the pack / unpack
+    kernels implement): on real Driving Full observations pack -> unpack gives the dense tensor back bit for bit - i.e. the
+    "other cars" block of every agent row IS columns {0..5, 8} of those cars' self blocks and the tail IS shared."""
+    import oracle_lib as ol
+    from dynenv_amd.distributed import pack_peers_np, pack_tail_np, unpack_peers_np, unpack_tail_np
+    E = 6
+    ora = ol.OracleEnv(env_type=1, num_envs=E, n_players=A, seed=17)
+    obs = ora.reset().copy()
+    rng = np.random.default_rng(4)
+    for s in range(25):
+        obs, _, _ = ora.step(rng.integers(0, 3, (E, A, 2)).astype(np.int32))
+    D = ora.D
+    o = obs.reshape(E, A, D)
+    split = 9 + (A - 1) * 7
+    p = pack_peers_np(o)
+    assert p.shape == (E, A * 9 + (D - split))
+    np.testing.assert_array_equal(unpack_peers_np(p, A, D), o)
+    t = pack_tail_np(o, split)
+    assert t.shape == (E, A * split + (D - split))
+    np.testing.assert_array_equal(unpack_tail_np(t, A, D, split), o)
+
+
+def test_transport_layout_falls_back_to_dense_where_rows_are_not_redundant():
+    """only Driving Full has the redundancy the compacted formats exploit; everything else travels dense"""
+    from dynenv_amd import DynEnvType, ObservationType
+    from dynenv_amd.distributed import shared_tail_split, transport_layout
+
+    class Probe(object):
+        def __init__(self, env_type, obs, A=10):
+            self.env_type, self.observationType, self.n_agents = env_type, obs, A
+
+            class L(object):
+                block_offset = [0, 9, 9 + (A - 1) * 7, 0, 0, 0, 0, 0]
+            self.layout = L()
+    assert transport_layout(Probe(DynEnvType.DRIVE, ObservationType.FULL)) == dict(peers=True)
+    assert shared_tail_split(Probe(DynEnvType.DRIVE, ObservationType.FULL)) == 72
+    for et, ob in ((DynEnvType.DRIVE, ObservationType.PARTIAL), (DynEnvType.ROBO_CUP, ObservationType.FULL),
+                   (DynEnvType.ROBO_CUP, ObservationType.PARTIAL)):
+        assert transport_layout(Probe(et, ob)) == {} and shared_tail_split(Probe(et, ob)) is None
