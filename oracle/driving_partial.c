@@ -232,7 +232,6 @@ int drv_agent_vision(const DrivingEnv* e, int agentIdx, int noiseType, double ma
   Det self, cars[PCAP_CARS + 16], obst[PCAP_OBST + 16], peds[PCAP_PEDS + 16], build[4];
   int carSrc[PCAP_CARS + 16]; /* original agent index of the real car rows (noise stream id) */
   LaneDet lanes[PCAP_LANES + 16];
-  int laneSrc[PCAP_LANES + 16];
   int nCars = 0, nObst = 0, nPeds = 0, nLanes = 0, i, j, k, overflow = 0;
   int pedInter[PCAP_PEDS + 16];
   double s, c;
@@ -296,7 +295,7 @@ int drv_agent_vision(const DrivingEnv* e, int agentIdx, int noiseType, double ma
         for (r = 0; r < 2; ++r) {
           int cnt = car_lane_distances(&e->roads[r], P, ang, tmp);
           for (i = 0; i < cnt; ++i) {
-            if (tmp[i].seen != SIGHT_NONE) { laneSrc[nLanes] = row + i; lanes[nLanes++] = tmp[i]; }
+            if (tmp[i].seen != SIGHT_NONE) lanes[nLanes++] = tmp[i];
           }
           row += 2 * e->roads[r].nLanes;
         }

@@ -10,7 +10,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+LIB_PATH = os.environ.get("ORACLE_LIB", os.path.join(ORACLE_DIR, "liboracle.so"))  # override: the sanitizer build (make -C oracle asan)
 
 
 class Cfg(C.Structure):
@@ -73,7 +73,8 @@ ROBOCUP_DEFAULT_FLAGS = FLAG_CAN_FALL | FLAG_USE_OBS_REWARDS  # class switches, 
 
 
 def build():
-    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+    if "ORACLE_LIB" not in os.environ:
+        subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
 
 
 _lib = None
