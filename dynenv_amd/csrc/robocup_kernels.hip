@@ -1664,9 +1664,9 @@ RC_PROF(const unsigned long long A2 = __builtin_amdgcn_s_memtime();)
     // The two feet of one robot overlap in every substep: they are candidates without a test (a candidate whose boxes
     // do not overlap is harmless - shapes that touch have overlapping boxes, so the narrowphase finds nothing), which
     // keeps the double-precision box test below for the rare real prefilter hits.
-    int cand = feetPairs;
-#pragma unroll 1
-    for (int t = 0; t < NROUNDS; ++t) {
+    int cand = feetPairs, pre = 0;
+#pragma unroll
+    for (int t = 0; t < NROUNDS; ++t) {  // the fp32 prefilter of all my pairs first: their LDS reads are in flight together
       const int pr = RC_MY_PAIR(t);
       if (pr != 0xFFFF && !((feetPairs >> t) & 1)) {
         const int i = pr >> 8, j = pr & 0xFF;
@@ -1674,14 +1674,19 @@ RC_PROF(const unsigned long long A2 = __builtin_amdgcn_s_memtime();)
         if (j <= RC_BALL) { bx = L.u.pf.cx[j]; by = L.u.pf.cy[j]; bhx = L.u.pf.hx[j]; bhy = L.u.pf.hy[j]; }
         else { const V2 pc = post_pos(j); bx = (float)pc.x; by = (float)pc.y; bhx = 11.0f; bhy = 11.0f; }
         const float dx = L.u.pf.cx[i] - bx, dy = L.u.pf.cy[i] - by;
-        if (__builtin_fabsf(dx) <= L.u.pf.hx[i] + bhx && __builtin_fabsf(dy) <= L.u.pf.hy[i] + bhy) {
-          const double al = L.aabb[i][0], ab = L.aabb[i][1], ar = L.aabb[i][2], at = L.aabb[i][3];
-          double bl, bb, br, bt;
-          if (j <= RC_BALL) { bl = L.aabb[j][0]; bb = L.aabb[j][1]; br = L.aabb[j][2]; bt = L.aabb[j][3]; }
-          else { const V2 pc = post_pos(j); bl = pc.x - POST_R; bb = pc.y - POST_R; br = pc.x + POST_R; bt = pc.y + POST_R; }
-          if (al <= br && bl <= ar && ab <= bt && bb <= at) cand |= (1 << t);
-        }
+        if (__builtin_fabsf(dx) <= L.u.pf.hx[i] + bhx && __builtin_fabsf(dy) <= L.u.pf.hy[i] + bhy) pre |= 1 << t;
       }
+    }
+#pragma unroll 1
+    for (int mm = pre; mm; mm &= mm - 1) {  // the exact test (cpBBIntersects) of the pairs that passed (rare)
+      const int t = __builtin_ctz(mm);
+      const int pr = RC_MY_PAIR(t);
+      const int i = pr >> 8, j = pr & 0xFF;
+      const double al = L.aabb[i][0], ab = L.aabb[i][1], ar = L.aabb[i][2], at = L.aabb[i][3];
+      double bl, bb, br, bt;
+      if (j <= RC_BALL) { bl = L.aabb[j][0]; bb = L.aabb[j][1]; br = L.aabb[j][2]; bt = L.aabb[j][3]; }
+      else { const V2 pc = post_pos(j); bl = pc.x - POST_R; bb = pc.y - POST_R; br = pc.x + POST_R; bt = pc.y + POST_R; }
+      if (al <= br && bl <= ar && ab <= bt && bb <= at) cand |= (1 << t);
     }
     __syncthreads();
 RC_PROF(const unsigned long long A3 = __builtin_amdgcn_s_memtime(); tG += A1 - A0; tP += A2 - A1; tB += A3 - A2;)
