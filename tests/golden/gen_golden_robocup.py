@@ -6,7 +6,7 @@ from /root/reference with minimal pymunk/gym/pygame/cv2 placeholders and its pur
 states: processAction (Robot.step/turn/kick/turnHead), tick (move timer, head clamp, kick FSM incl. joint remove/add,
 getup, penalty timers, illegal defender, leave-field, approach-ball reward), isBallOutOfField + ballFreeKickProcess,
 penalize + getFreePenaltySpot, the `begin` callbacks ballCollision / robotPushingDet, and getFullState/get_full_obs.
-`fall()` needs pymunk's spatial query and is NOT pinned here.  Fixtures: tests/golden/robocup_unit.npz.
+`fall()` needs pymunk's spatial query: it is pinned, with a geometric `point_query` stand-in, by gen_golden_robocup_r2.py.  Fixtures: tests/golden/robocup_unit.npz.
 
 The getup dice (`random.random()` in tick, RoboCupEnvironment.py:932) is served from the Philox block the oracle uses.
 """
