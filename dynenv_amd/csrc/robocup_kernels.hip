@@ -29,6 +29,9 @@ __constant__ RcConst RC;
 #ifndef RC_RPL
 #define RC_RPL (RC_FULL_EPW == 2) /* robocup_rpl.hip: one lane per robot, the common substep in registers (0: the foot-per-lane rc_step_body) */
 #endif
+#ifndef RC_SPLIT_BIAS
+#define RC_SPLIT_BIAS 1 /* general solve: an arbiter's position-correction (bias) impulses run on lane slot + 16 beside its velocity impulses */
+#endif
 #ifndef RC_QUIET_JOINTS_INLINE
 #define RC_QUIET_JOINTS_INLINE 0 /* the quiet substep's joint solve inlined into the step loop (EPW = 2 always inlines) */
 #endif
@@ -46,6 +49,10 @@ __constant__ RcConst RC;
 struct RcMailbox {
   double p1x[RC_NS][2], p1y[RC_NS][2], p2x[RC_NS][2], p2y[RC_NS][2], nx[RC_NS], ny[RC_NS];
   int hash[RC_NS][2], count[RC_NS], flag[RC_NS];
+};
+struct RcArbShare {  // what an arbiter's slot lane hands to its bias lane (slot + 16) after the prestep
+  double d[RC_NS][14];  // n, r1[0], r1[1], r2[0], r2[1], nMass[0..1], bias[0..1]
+  int code[RC_NS];      // bodyA | bodyB << 8 | count << 16 | level << 24
 };
 struct RcObsStage {
   float rx[RC_MAXR], ry[RC_MAXR], rcs[RC_MAXR], rsn[RC_MAXR], hc[RC_MAXR], hs[RC_MAXR], ahc[RC_MAXR], ahs[RC_MAXR];
@@ -78,6 +85,7 @@ struct __align__(16) RcLds {
   unsigned short candList[128];  // compacted broadphase candidates (pair codes) in canonical order
   union {
     RcMailbox mb;
+    RcArbShare sh;
     RcObsStage ob;
     RcPrefilter pf;
     RcRplExchange rq;
@@ -1069,9 +1077,14 @@ template <int EPW>
 DE_DEV RcStepRet rc_physics_inl(RcCtx c, int lane, int cand, uint64_t pairLo, uint64_t pairHi, uint64_t pairTop, uint64_t occ) {
   typedef Grp<EPW> G;
   constexpr int W = G::W, NROUNDS = (RC_NPAIR_ROUNDS * 64) / W;
+  // SPLIT: the two impulse chains of an arbiter's contact - velocity (normal + tangent) and position correction (bias) -
+  // read and write disjoint body fields (v, w against v_bias, w_bias) and run the same instruction sequence up to the
+  // impulse vector; a lone wave pays per instruction, not per lane, so the bias chain moves to lane slot + 16.
+  constexpr bool SPLIT = RC_SPLIT_BIAS && W == 64 && RC_NS == 16 && G::JL0 == 32;
   RcLds& L = G::tile();
   RcMailbox& M = L.u.mb;
   int err = 0;
+  bool biasLane = false;
   const bool anyContactWork = G::ballot(cand != 0) != 0ull || occ != 0ull;
 RC_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
   // --- contact detection / cache -------------------------------------------------------------------------
@@ -1270,6 +1283,33 @@ RC_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
         }
       }
     }
+    if constexpr (SPLIT) {
+      if (activeMask != 0ull) {
+        RcArbShare& H = L.u.sh;  // overlays the mailbox, which nobody reads any more
+        __syncthreads();
+        if (active) {
+          H.code[lane] = bodyA | (bodyB << 8) | (a_count << 16) | (myLevel << 24);
+          double* d = H.d[lane];
+          d[0] = n.x; d[1] = n.y; d[2] = r1[0].x; d[3] = r1[0].y; d[4] = r1[1].x; d[5] = r1[1].y;
+          d[6] = r2[0].x; d[7] = r2[0].y; d[8] = r2[1].x; d[9] = r2[1].y;
+          d[10] = nMass[0]; d[11] = nMass[1]; d[12] = bias[0]; d[13] = bias[1];
+        }
+        __syncthreads();
+        const int sl = lane - 16;
+        if (sl >= 0 && sl < RC_NS && ((activeMask >> sl) & 1ull)) {
+          biasLane = true;
+          const int code = H.code[sl];
+          bodyA = code & 0xFF; bodyB = (code >> 8) & 0xFF; a_count = (code >> 16) & 0xFF; myLevel = (code >> 24) & 0xFF;
+          const double* d = H.d[sl];
+          n = v2(d[0], d[1]); r1[0] = v2(d[2], d[3]); r1[1] = v2(d[4], d[5]); r2[0] = v2(d[6], d[7]); r2[1] = v2(d[8], d[9]);
+          nMass[0] = d[10]; nMass[1] = d[11];
+          // the bias chain in the velocity chain's form: jbn = (bias - vbn) nMass = -((-bias) + vbn) nMass (the two can only
+          // differ in the sign of a zero jbn, which jBias = max(jBias + jbn, 0) with jBias >= +0 absorbs); no tangent part
+          bounce[0] = -d[12]; bounce[1] = -d[13];
+          jn[0] = jn[1] = jt[0] = jt[1] = 0.0; tMass[0] = tMass[1] = 0.0; arb_u = 0.0;
+        }
+      }
+    }
   }
 RC_PROF(const unsigned long long T1 = __builtin_amdgcn_s_memtime();)
   // --- joints: prestep (cpPivotJoint / cpRotaryLimitJoint preStep), one robot per lane ------------------------
@@ -1337,6 +1377,59 @@ RC_PROF(T4 = __builtin_amdgcn_s_memtime();)
     // --- 10 iterations: all arbiters (canonical order via levels), then all constraints ----------------------
     RBody a, b;
     if (active) { rbody_load(L, bodyA, a); rbody_load(L, bodyB, b); }  // p, minv, iinv do not change during the solve
+    if constexpr (SPLIT) {
+      // velocity lanes (the slot lanes) work on (v, w), bias lanes on (v_bias, w_bias): same code, other fields
+      double* const fX = biasLane ? L.vbx : L.vx;
+      double* const fY = biasLane ? L.vby : L.vy;
+      double* const fW = biasLane ? L.wb : L.w;
+      const bool solveMe = active || biasLane;
+      const bool aDyn = bodyA <= RC_BALL, bDyn = bodyB <= RC_BALL;
+      if (biasLane) {
+        a.minv = aDyn ? rc_minv(bodyA) : 0.0; a.iinv = aDyn ? rc_iinv(bodyA) : 0.0;
+        b.minv = bDyn ? rc_minv(bodyB) : 0.0; b.iinv = bDyn ? rc_iinv(bodyB) : 0.0;
+        a.v = b.v = v2(0.0, 0.0); a.w = b.w = 0.0;
+      }
+      for (int iter = 0; iter < 10; ++iter) {
+        for (int lv = 0; lv <= maxLevel; ++lv) {
+          if (solveMe && myLevel == lv) {
+            if (aDyn) { a.v = v2(fX[bodyA], fY[bodyA]); a.w = fW[bodyA]; }
+            if (bDyn) { b.v = v2(fX[bodyB], fY[bodyB]); b.w = fW[bodyB]; }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              if (q < a_count) {
+                const V2 vr = rrelative_velocity(a, b, r1[q], r2[q]);
+                const double vrn = vdot(vr, n);
+                const double vrt = vdot(vr, vperp(n));
+                const double jnn = -(bounce[q] + vrn) * nMass[q];
+                const double jnOld = jn[q];
+                jn[q] = fmax_cp(jnOld + jnn, 0.0);
+                const double jtMax = arb_u * jn[q];
+                const double jtt = -vrt * tMass[q];
+                const double jtOld = jt[q];
+                jt[q] = fclamp_cp(jtOld + jtt, -jtMax, jtMax);
+                const double dj = jn[q] - jnOld;
+                const V2 jr = vrotate(n, v2(dj, jt[q] - jtOld));
+                const V2 jl = vmul(n, dj);  // the bias impulse has no tangent term: not even a zero one (sign of zero)
+                const V2 jj = biasLane ? jl : jr;
+                rapply_impulse(a, vneg(jj), r1[q]);
+                rapply_impulse(b, jj, r2[q]);
+              }
+            }
+            if (aDyn) { fX[bodyA] = a.v.x; fY[bodyA] = a.v.y; fW[bodyA] = a.w; }
+            if (bDyn) { fX[bodyB] = b.v.x; fY[bodyB] = b.v.y; fW[bodyB] = b.w; }
+          }
+          __syncthreads();
+        }
+        if (isRobot) {
+          RC_JOINT_VIEW(J)
+          RcFeet f;
+          f.vx0 = L.vx[la]; f.vy0 = L.vy[la]; f.w0 = L.w[la]; f.vx1 = L.vx[lb]; f.vy1 = L.vy[lb]; f.w1 = L.w[lb];
+          joints_iterate_ordered(J, f, jn[0], jn[1], jt[0]);
+          L.vx[la] = f.vx0; L.vy[la] = f.vy0; L.w[la] = f.w0; L.vx[lb] = f.vx1; L.vy[lb] = f.vy1; L.w[lb] = f.w1;
+        }
+        __syncthreads();
+      }
+    } else
     for (int iter = 0; iter < 10; ++iter) {
       for (int lv = 0; lv <= maxLevel; ++lv) {
         if (active && myLevel == lv) {
