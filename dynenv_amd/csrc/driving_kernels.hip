@@ -998,7 +998,7 @@ DRV_PROF(const unsigned long long T2 = __builtin_amdgcn_s_memtime();)
 DRV_PROF(const unsigned long long T3 = __builtin_amdgcn_s_memtime();)
   // ---- velocity update (velocity_func: friction_* or default) -------------------------------------------
   velocity_update(L, lane, isCar, isPed);
-DRV_PROF(unsigned long long T4 = __builtin_amdgcn_s_memtime();)
+DRV_PROF(unsigned long long T4 = __builtin_amdgcn_s_memtime(); int profMode = 0;)
   if (activeMask && maxLevel == 0) {
     // No two active arbiters share a dynamic body: each lane keeps its two bodies in registers through the warm start
     // and all 10 iterations, with one LDS load and one store (same arithmetic, no LDS round trip per iteration).
@@ -1010,9 +1010,11 @@ DRV_PROF(unsigned long long T4 = __builtin_amdgcn_s_memtime();)
       if (a_state != ARB_FIRST) arb_warm_start(a, b, n, r1, r2, jn, jt, a_count);
 DRV_PROF(T4 = __builtin_amdgcn_s_memtime();)
       if (wave_ballot(!arb_is_bias_only(a, b, jn, jt, bounce, a_count)) == 0ull) {  // all resting contacts: bias half only
+DRV_PROF(profMode = 1;)
 #pragma unroll 1
         for (int iter = 0; iter < 10; ++iter) arb_apply_bias_only(a, b, n, r1, r2, nMass, bias, jBias, a_count);
       } else {
+DRV_PROF(profMode = 2;)
 #pragma unroll 1
         for (int iter = 0; iter < 10; ++iter) arb_apply_impulse(a, b, n, r1, r2, nMass, tMass, bias, bounce, jBias, jn, jt, a_count, arb_u);
       }
@@ -1045,6 +1047,7 @@ DRV_PROF(T4 = __builtin_amdgcn_s_memtime();)
     if (wave_ballot(!biasOnly) == 0ull) {
       // every active arbiter is a resting contact being pushed out of penetration (the pile-ups that make up the launch's
       // tail): only bias velocities move, through LDS, level by level
+DRV_PROF(profMode = 3;)
       for (int iter = 0; iter < 10; ++iter) {
         for (int lv = 0; lv <= maxLevel; ++lv) {
           if (active && myLevel == lv) {
@@ -1058,6 +1061,7 @@ DRV_PROF(T4 = __builtin_amdgcn_s_memtime();)
         }
       }
     } else {
+DRV_PROF(profMode = 4;)
       for (int iter = 0; iter < 10; ++iter) {
         for (int lv = 0; lv <= maxLevel; ++lv) {
           if (active && myLevel == lv) {
@@ -1116,7 +1120,8 @@ DRV_PROF(if (slotOcc) { int why = 0; const int pi = a_pair >> 8, pj = a_pair & 0
   occ &= ~freeMask;
   const bool allInert = wave_ballot(!inert) == 0ull;
 DRV_PROF(const unsigned long long T5 = __builtin_amdgcn_s_memtime();)
-DRV_PROF(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* d = g_dbgp + blockIdx.x * 8; d[0] += T1 - T0; d[1] += T2 - T1; d[2] += T3 - T2; d[3] += T4 - T3; d[4] += T5 - T4; d[5] += 1ull; d[6] += (unsigned long long)(maxLevel + 1); d[7] += (unsigned long long)nTouched; })
+DRV_PROF(const int profModeW = __ballot(profMode == 1) ? 1 : __ballot(profMode == 2) ? 2 : __ballot(profMode == 3) ? 3 : __ballot(profMode == 4) ? 4 : 0;)
+DRV_PROF(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* d = g_dbgp + blockIdx.x * 8; d[0] += T1 - T0; d[1] += T2 - T1; d[2] += T3 - T2; d[3] += T4 - T3; d[4] += T5 - T4; d[5] += 1ull; d[6] += (unsigned long long)(maxLevel + 1) + ((unsigned long long)(maxLevel + 1) << (12 * profModeW)); d[7] += (unsigned long long)nTouched; })
   ContactRet ret;
   ret.occ = occ; ret.rew = rew; ret.err = err | (allInert ? 2 : 0) | (allSteady ? 4 : 0);
   return ret;

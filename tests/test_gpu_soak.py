@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("cfg,E", [("driving", 4096), ("robocup", 4096), ("driving_partial", 1024), ("robocup_partial", 1024)])
+@pytest.mark.parametrize("cfg,E", [("driving", 4096), ("robocup", 4096), ("driving_partial", 4096), ("robocup_partial", 4096)])
 def test_full_episode_full_batch_parity(oracle_built, cfg, E):
     import soak_parity
     soak_parity.run(cfg, E, 20261003)

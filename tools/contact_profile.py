@@ -34,7 +34,14 @@ m = d[:, 1] == 10
 for o in range(0, 25):
     mm = m & (d[:, 2] == o)
     if mm.any(): print("nContact=10 occ=%d n=%d mean %.0f" % (o, mm.sum(), c[mm].mean()))
-p = np.loadtxt("gpurun_out/dbgp.txt")
+praw = np.loadtxt("gpurun_out/dbgp.txt", dtype=np.uint64)
+p = praw.astype(float)
+lv = praw[:, 6]
+modes = np.stack([(lv >> np.uint64(12 * k)) & np.uint64(0xFFF) for k in range(1, 5)], 1)  # level passes (x10 iterations) per solver mode
+p[:, 6] = (lv & np.uint64(0xFFF)).astype(float)
+print("solver level passes by mode [single bias-only, single general, multi bias-only, multi general] of the top envs:")
+for k in top[:10]: print("  ", int(c[k]), modes[k])
+print("all envs:", modes.sum(0))
 print("top envs: total | load phase1 broad fast contact book store+obs | narrow slots prestep velupd solver | calls levels touched")
 for k in top[:10]: print(int(c[k]), d[k, 4:11].astype(int), p[k].astype(int))
 m = d[:, 1] == 10

@@ -27,3 +27,6 @@ print("per-env cycles of one step (50 substeps): mean / p99 / max")
 for k, n in enumerate(names):
     c = d[:, k]
     print("  %-18s %10.0f %10.0f %10.0f" % (n, c.mean(), np.percentile(c, 99), c.max()))
+top = np.argsort(-d[:, 11])[:12]
+print("slowest environments: " + " | ".join(names))
+for k in top: print("  ", " ".join("%8d" % v for v in d[k]))
