@@ -675,6 +675,13 @@ DE_DEV bool rc_cb_begin(const RcCtx& c, RcLds& L, int i, int j) {  // pair (i < 
   return true;  // foot-goalpost and ball-goalpost: default begin
 }
 
+// `rr > base ** n` (the fall dice of the collision callbacks) without the power in the common case: (1 - x)^n >= 1 - n x
+// (Bernoulli), `xOver` is a little more than 1 - base and dm_powi's rounding error (~n 2^-53 relative) is far inside the
+// margin, so a die at or below the bound cannot exceed the threshold; every other die is compared with the exact power.
+DE_DEV bool rc_dice_exceeds(double rr, double base, double xOver, int n) {
+  if (rr <= 1.0 - (double)n * xOver - 1e-6) return false;
+  return rr > dm_powi(base, n);
+}
 template <int EPW>
 DE_DEV void rc_cb_post_solve(const RcCtx& c, RcLds& L, int i, int j) {
   if (!c.canFall) return;
@@ -682,30 +689,36 @@ DE_DEV void rc_cb_post_solve(const RcCtx& c, RcLds& L, int i, int j) {
   if (j < RC_BALL) {  // robotCollision :1039-1088
     const int r1 = i >> 1, r2 = j >> 1;
     if (r1 == r2) return;
-    if (!(L.rflags[r1] & (RF_FALLEN | RF_PENAL))) L.touchc[r1] += 1;
-    if (!(L.rflags[r2] & (RF_FALLEN | RF_PENAL))) L.touchc[r2] += 1;
+    // both robots' flags and counters in one LDS round trip; rc_fall(r) / rc_penalize(r) only ever change robot r's own
+    const int f1 = L.rflags[r1], f2 = L.rflags[r2];
+    int t1 = L.touchc[r1], t2 = L.touchc[r2];
+    if (!(f1 & (RF_FALLEN | RF_PENAL))) t1 += 1;
+    if (!(f2 & (RF_FALLEN | RF_PENAL))) t2 += 1;
+    L.touchc[r1] = t1; L.touchc[r2] = t2;
     const dm_u32x4 u = rc_rng(c, L, key | (2u << 16));
-    double rr = dm_unit(u.v[0]);
-    if (rr > dm_powi((L.rflags[r1] & RF_PUSH) ? 0.99995 : 0.9999, L.touchc[r1]) && !(L.rflags[r1] & RF_FALLEN)) {
-      rc_fall<EPW>(c, r1, (L.rflags[r1] & RF_PUSH) ? 1 : 0);
+    const bool p1 = f1 & RF_PUSH, p2 = f2 & RF_PUSH;
+    if (!(f1 & RF_FALLEN) && rc_dice_exceeds(dm_unit(u.v[0]), p1 ? 0.99995 : 0.9999, p1 ? 5.0001e-5 : 1.0001e-4, t1)) {
+      rc_fall<EPW>(c, r1, p1 ? 1 : 0);
       L.touchc[r1] = 0;
     }
-    rr = dm_unit(u.v[1]);
-    if (rr > dm_powi((L.rflags[r2] & RF_PUSH) ? 0.99995 : 0.9999, L.touchc[r2]) && !(L.rflags[r2] & RF_FALLEN)) {
-      rc_fall<EPW>(c, r2, (L.rflags[r2] & RF_PUSH) ? 1 : 0);
+    if (!(f2 & RF_FALLEN) && rc_dice_exceeds(dm_unit(u.v[1]), p2 ? 0.99995 : 0.9999, p2 ? 5.0001e-5 : 1.0001e-4, t2)) {
+      rc_fall<EPW>(c, r2, p2 ? 1 : 0);
       L.touchc[r2] = 0;
     }
-    const bool p1 = L.rflags[r1] & RF_PUSH, p2 = L.rflags[r2] & RF_PUSH;
-    const bool diffTeam = robot_team(L, r1) != robot_team(L, r2);
-    if (p1 && !p2 && (L.rflags[r2] & RF_FALLEN) && diffTeam) { rc_penalize<EPW>(c, r1); L.touchc[r1] = 0; }
-    else if (p2 && !p1 && (L.rflags[r1] & RF_FALLEN) && diffTeam) { rc_penalize<EPW>(c, r2); L.touchc[r2] = 0; }
+    if (p1 != p2) {  // (the pushing bits are not touched by a fall; the fallen bits are: read them again)
+      const bool diffTeam = robot_team(L, r1) != robot_team(L, r2);
+      if (p1 && (L.rflags[r2] & RF_FALLEN) && diffTeam) { rc_penalize<EPW>(c, r1); L.touchc[r1] = 0; }
+      else if (p2 && (L.rflags[r1] & RF_FALLEN) && diffTeam) { rc_penalize<EPW>(c, r2); L.touchc[r2] = 0; }
+    }
   } else if (j > RC_BALL && i < RC_BALL) {  // goalpostCollision :1106-1125
     const int r = i >> 1;
-    if (L.rflags[r] & RF_FALLEN) { L.touchc[r] = 0; return; }
-    if (!(L.rflags[r] & RF_TOUCH)) { L.rflags[r] |= RF_TOUCH; L.touchc[r] = 0; }
-    L.touchc[r] += 1;
+    int f = L.rflags[r], t = L.touchc[r];
+    if (f & RF_FALLEN) { L.touchc[r] = 0; return; }
+    if (!(f & RF_TOUCH)) { L.rflags[r] = f | RF_TOUCH; t = 0; }
+    t += 1;
+    L.touchc[r] = t;
     const dm_u32x4 u = rc_rng(c, L, key | (3u << 16));
-    if (dm_unit(u.v[0]) > dm_powi(0.9998, L.touchc[r])) rc_fall<EPW>(c, r, 1);
+    if (rc_dice_exceeds(dm_unit(u.v[0]), 0.9998, 2.0001e-4, t)) rc_fall<EPW>(c, r, 1);
   }
 }
 
