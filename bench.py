@@ -203,6 +203,10 @@ def main():
     ap.add_argument("--sync-gather", action="store_true",
                     help="N > 1: wait for the all-gather of step k before launching step k+1 (lock-step consumer); by default "
                          "the transport of step k runs on a side stream beside the following kernels (ring of --ring slabs)")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="rehearsal of an N > 1 launch on a box with ONE GPU: every rank uses cuda:0 and the process group is gloo "
+                         "(RCCL refuses two ranks on one device); slabs, pack / unpack kernels, side stream and ring are the real ones. "
+                         "The line it prints says so in config.parallelism and is not a measurement")
     args = ap.parse_args()
 
     # stdout carries exactly one JSON line: anything libraries print meanwhile (RCCL's version banner at init, ...) is
@@ -222,6 +226,8 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 through torch.distributed.run (one process per GPU)")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if args.rehearse_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -229,7 +235,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.rehearse_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     robocup = args.workload in ("robocup", "robocup_partial")
     partial = args.workload in ("driving_partial", "robocup_partial")
@@ -335,7 +344,7 @@ def main():
             "config": {"workload": workload_text,
                        "envs_per_gpu": E, "n_players": n_players, "n_agents": A, "obs": "partial" if partial else "full", "gather": (False if gather is None else "sync" if args.sync_gather else "overlapped (transport of step k on a side stream beside the next kernels, ring of %d slabs)" % args.ring),
                        "gather_bytes_per_rank": (None if slab is None else slab.nbytes),
-                       "parallelism": "env-shard x%d" % world,
+                       "parallelism": "env-shard x%d" % world + (" (REHEARSAL: all ranks on one GPU, gloo)" if args.rehearse_one_gpu else ""),
                        "rccl_world_size": (dist.get_world_size() if dist is not None else None)},
             "env_steps_per_s": env_steps / elapsed,
             "gpu_ms_per_step_rank0": gpu_ms / args.steps,
@@ -343,8 +352,8 @@ def main():
             "roofline": roofline,
         }
         if full is not None:  # the same kernel over one whole episode: the mean a training run sees
-            out["ms_per_step_full_episode"] = full["ms_per_step"]
-            out["value_full_episode"] = full["value"] * world
+            out["ms_per_step_full_episode"] = full["ms_per_step"]  # (N > 1: rank 0's kernel alone, no transport)
+            out["value_full_episode"] = full["value"] if world == 1 else None
         if world == 1 and not args.no_extra_legs and gather is None:
             env.close()
             out["other_configs"] = [episode_leg(torch, device, w, E, args.seed) for w in WORKLOADS if w != args.workload]

@@ -186,3 +186,84 @@ def test_pipelined_gather_over_rccl_other_transports_and_environments(kind, tran
     assert torch.equal(go[0], want[-1][0]) and torch.equal(gr[0], want[-1][1])
     gather.drain()
     env.close(); ref.close()
+
+
+def _two_rank_worker(rank, world, port, kind, out_dir):
+    """one of two processes that share the box's single GPU: the process group is gloo (RCCL refuses two ranks on one device),
+    everything else - slabs in HBM, pack kernels, side stream, ring, unpack for G = 2 - is the path the 8-GPU run takes"""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dynenv_amd import BatchedDynEnv, DynEnvType
+    from dynenv_amd.distributed import ShardedDynEnv, shard_range
+    robocup = kind == "ROBO_CUP"
+    et = DynEnvType.ROBO_CUP if robocup else DynEnvType.DRIVE
+    total, n, steps = 48, 5 if robocup else 10, 14
+    sh = ShardedDynEnv(et, total, n, gather=True, seed=9, device="cuda:0")
+    off, per = shard_range(total, rank, world)
+    A = sh.env.n_agents
+    rng = np.random.default_rng(5)
+    hi = (5, 3, 3, 7) if robocup else (3, 3)
+    acts = [np.stack([rng.integers(0, h, (total, A)) for h in hi], -1).astype(np.int32) for _ in range(steps)]
+    ref = BatchedDynEnv(et, total, n, seed=9, device="cuda:0") if rank == 0 else None
+    g_obs, _, _ = sh.reset()
+    ok = True
+    if rank == 0:
+        ok = ok and torch.equal(g_obs.reshape(ref.obs.shape), ref.reset_flat())
+    handles, want = [], []
+    for k in range(steps):
+        handles.append(sh.step(torch.tensor(acts[k][off:off + per], device="cuda:0"), wait=False))
+        if rank == 0:
+            o, r, d = ref.step_flat(torch.tensor(acts[k], device="cuda:0"), auto_reset=True)
+            want.append((o.clone(), r.clone(), d.clone()))
+        if k >= 2:  # consume two steps late
+            go, gr, gd = handles[k - 2].wait()
+            if rank == 0:
+                w = want[k - 2]
+                ok = ok and torch.equal(go.reshape(w[0].shape), w[0]) and torch.equal(gr.reshape(w[1].shape), w[1]) and torch.equal(gd.reshape(w[2].shape), w[2])
+    for k in (steps - 2, steps - 1):
+        go, gr, gd = handles[k].wait()
+        if rank == 0:
+            w = want[k]
+            ok = ok and torch.equal(go.reshape(w[0].shape), w[0]) and torch.equal(gr.reshape(w[1].shape), w[1])
+    sh.gather.drain()
+    torch.cuda.synchronize()
+    if rank == 0:
+        with open(os.path.join(out_dir, "ok.txt"), "w") as f:
+            f.write("ok" if ok else "MISMATCH")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["DRIVE", "ROBO_CUP"])
+def test_two_ranks_sharing_the_gpu_match_one_big_batch(tmp_path, kind):
+    """world_size 2 with BOTH ranks on this box's one GPU (gloo process group over device tensors): rank g owns environments
+    [24 g, 24 g + 24), the gathered global views of the pipelined protocol equal a single 48-environment BatchedDynEnv bit for
+    bit - shard-count invariance and the G = 2 transport (compacted for Driving, dense for RoboCup) on the real kernels"""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_two_rank_worker, args=(2, port, kind, str(tmp_path)), nprocs=2, join=True)
+    assert open(os.path.join(str(tmp_path), "ok.txt")).read() == "ok"
+
+
+def test_bench_launched_like_the_driver_with_two_ranks_on_this_gpu():
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` as the driver starts the scaling runs, with
+    --rehearse-one-gpu (both ranks on cuda:0, gloo): one JSON line on stdout, n_gpus 2, all ranks' environments counted"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "8", "--warmup", "3", "--envs", "256", "--rehearse-one-gpu"]
+    r = subprocess.run(cmd, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 8 and d["warmup"] == 3 and d["scaling"] == "weak" and d["kernel_error_flags"] == 0
+    assert d["config"]["rccl_world_size"] == 2 and "REHEARSAL" in d["config"]["parallelism"]
+    assert abs(d["env_steps_per_s"] - 2 * 256 * 8 / (d["ms_per_step"] * 8e-3)) < 1e-6 * d["env_steps_per_s"]
+    assert d["roofline"]["frac"] > 0 and d["cpu_baseline"] is None
