@@ -735,6 +735,7 @@ DRV_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
   // none owns a slot, every remaining pair is unchanged and frozen, so the rest of this function would reproduce the
   // previous substep: return and let the caller replay it.  Otherwise, and in mode 1, process every candidate.
   bool lightOk = false;
+DRV_PROF(int profCand = 0;)
 #pragma unroll 1
   for (int mode = light ? 0 : 1; mode < 2; ++mode) {
   const int bits = mode == 0 ? dirty : cand;
@@ -754,6 +755,7 @@ DRV_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
     nCand += __popcll(m);
   }
   if (nCand > DRV_CLIST) nCand = DRV_CLIST;
+DRV_PROF(profCand += nCand;)
   __syncthreads();
   if (mode == 0) {  // a dirty pair that owns a slot rules the light mode out before any narrowphase work is spent on it
     bool owns = false;
@@ -1121,7 +1123,7 @@ DRV_PROF(if (slotOcc) { int why = 0; const int pi = a_pair >> 8, pj = a_pair & 0
   const bool allInert = wave_ballot(!inert) == 0ull;
 DRV_PROF(const unsigned long long T5 = __builtin_amdgcn_s_memtime();)
 DRV_PROF(const int profModeW = __ballot(profMode == 1) ? 1 : __ballot(profMode == 2) ? 2 : __ballot(profMode == 3) ? 3 : __ballot(profMode == 4) ? 4 : 0;)
-DRV_PROF(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* d = g_dbgp + blockIdx.x * 8; d[0] += T1 - T0; d[1] += T2 - T1; d[2] += T3 - T2; d[3] += T4 - T3; d[4] += T5 - T4; d[5] += 1ull; d[6] += (unsigned long long)(maxLevel + 1) + ((unsigned long long)(maxLevel + 1) << (12 * profModeW)); d[7] += (unsigned long long)nTouched; })
+DRV_PROF(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* d = g_dbgp + blockIdx.x * 8; d[0] += T1 - T0; d[1] += T2 - T1; d[2] += T3 - T2; d[3] += T4 - T3; d[4] += T5 - T4; d[5] += 1ull + (light ? (1ull << 16) : 0ull); d[6] += (unsigned long long)(maxLevel + 1) + ((unsigned long long)(maxLevel + 1) << (12 * profModeW)); d[7] += (unsigned long long)nTouched + ((unsigned long long)profCand << 16); })
   ContactRet ret;
   ret.occ = occ; ret.rew = rew; ret.err = err | (allInert ? 2 : 0) | (allSteady ? 4 : 0);
   return ret;
@@ -1183,6 +1185,7 @@ DRV_PROF(if (lane < 8 && e < 4096) g_dbgp[e * 8 + lane] = 0ull;)
   __syncthreads();
 
 DRV_PROF(const unsigned long long K0 = __builtin_amdgcn_s_memtime(); unsigned long long tPh1 = 0, tBroad = 0, tFast = 0, tCont = 0, tBook = 0;)
+  bool lightOff = false;
   for (int it = 0; it < 10; ++it) {
 DRV_PROF(const unsigned long long A0 = __builtin_amdgcn_s_memtime();)
     // ======== phase 1a: car game logic (processAction at substep 0, tick) ===================================
@@ -1387,7 +1390,9 @@ DRV_PROF(const unsigned long long A1 = __builtin_amdgcn_s_memtime();)
     const bool steadyOk = !quiescent && steadyAll && wave_ballot(removed) == 0ull;
     const bool anyDirty = wave_ballot(dirty != 0) != 0ull;
     bool replay = steadyOk && !anyDirty;
-    const bool light = steadyOk && anyDirty;
+    // (a light-mode attempt that fails is paid on top of the full path, and what made it fail - a moving car leaning on a
+    // resting pile - persists: after a failure the rest of the step goes straight to the full path.  Both give the same result.)
+    const bool light = steadyOk && anyDirty && !lightOff;
     if (!(anyCand == 0ull && occ == 0ull) && !quiescent && !replay) { if (candChanged) nWhyCand++; else if (anyMoving) nWhyMoving++; else nWhyInert++; }
     lastCand = cand;
 
@@ -1405,6 +1410,7 @@ DRV_PROF(tookContact = true;)
       __builtin_amdgcn_s_setprio(3);  // an environment on the contact path is on the launch's critical path: issue it first
       ContactRet cr = drv_contact_path(lane, cand, dirty, light ? 1 : 0, A, occ, rew, isCar, isPed);
       err |= cr.err & 1;
+      if (light && !(uniform_i(cr.err >> 3) & 1)) lightOff = true;
       if (uniform_i(cr.err >> 3) & 1) {  // light mode: no dirty pair touches => replay
         replay = true; nLight++;
       } else {

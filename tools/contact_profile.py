@@ -21,7 +21,7 @@ g = torch.Generator(device="cuda"); g.manual_seed(1)
 for s in range(STEP):
     a = torch.randint(0, 3, (4096, 10, 2), dtype=torch.int32, device="cuda", generator=g)
     env.step_flat(a)
-env.debug_counters()
+print("substep path counters of the whole run:", env.debug_counters())
 d = np.loadtxt("gpurun_out/dbgw.txt")
 c = d[:, 0]
 print("cycles: mean %.0f  p50 %.0f p90 %.0f p99 %.0f max %.0f" % (c.mean(), *np.percentile(c, [50, 90, 99]), c.max()))
@@ -39,6 +39,12 @@ p = praw.astype(float)
 lv = praw[:, 6]
 modes = np.stack([(lv >> np.uint64(12 * k)) & np.uint64(0xFFF) for k in range(1, 5)], 1)  # level passes (x10 iterations) per solver mode
 p[:, 6] = (lv & np.uint64(0xFFF)).astype(float)
+ltry = (praw[:, 5] >> np.uint64(16)).astype(float)  # contact-path calls that ran to the end after a failed light-mode attempt
+p[:, 5] = (praw[:, 5] & np.uint64(0xFFFF)).astype(float)
+print("full-path calls that started with a failed light-mode attempt, top envs:", [int(ltry[k]) for k in top[:10]], " all envs: %d of %d calls" % (ltry.sum(), p[:, 5].sum()))
+ncand = (praw[:, 7] >> np.uint64(16)).astype(float)  # candidate pairs handed to the narrowphase, summed over the step's calls
+p[:, 7] = (praw[:, 7] & np.uint64(0xFFFF)).astype(float)
+print("narrowphase candidates per contact-path call, top envs:", [round(ncand[k] / max(p[k, 5], 1), 1) for k in top[:10]], " all contact envs: mean %.1f" % (ncand[p[:, 5] > 0] / p[p[:, 5] > 0, 5]).mean())
 print("solver level passes by mode [single bias-only, single general, multi bias-only, multi general] of the top envs:")
 for k in top[:10]: print("  ", int(c[k]), modes[k])
 print("all envs:", modes.sum(0))
