@@ -712,9 +712,107 @@ DE_DEV void body_store_bias(DrvLds& L, int idx, const BodyV& b) {
 DRV_PROF(__device__ unsigned long long g_dbgw[4096 * 12];)
 DRV_PROF(__device__ unsigned long long g_dbgp[4096 * 8];)
 DRV_PROF(__device__ unsigned long long g_dbgr[16];)
+#ifndef DRV_SPLIT_BIAS
+#define DRV_SPLIT_BIAS 0 /* 1: multi-level solves with live velocities run an arbiter's bias impulses on lane slot + 32 beside its velocity
+                            impulses (what RC_SPLIT_BIAS does for RoboCup).  Bit-identical, and measured SLOWER here (0.252 against 0.245 ms per
+                            step, inline 0.262): the rare call costs drv_contact_path callee-saved registers on every one of its calls */
+#endif
 #ifndef DRV_CONTACT_INLINE
 #define DRV_CONTACT_INLINE __noinline__
 #endif
+#if DRV_SPLIT_BIAS
+struct DrvSplitIO {
+  V2 n, r1[2], r2[2];
+  double nMass[2], bias[2], bounce[2], jn[2], jt[2], jBias[2];
+};
+// The 10 iterations of a multi-level solve with live velocities, out of line (its registers are only paid for when it runs).
+__device__ __noinline__ DrvSplitIO drv_solve_multilevel_split(int lane, bool active, int bodyA, int bodyB, int a_count, int myLevel, int maxLevel, DrvSplitIO io) {
+  DrvLds& L = g_L;
+  const V2 n = io.n;
+  V2 r1[2] = {io.r1[0], io.r1[1]}, r2[2] = {io.r2[0], io.r2[1]};
+  double nMass[2] = {io.nMass[0], io.nMass[1]}, bias[2] = {io.bias[0], io.bias[1]}, bounce[2] = {io.bounce[0], io.bounce[1]};
+  double jn[2] = {io.jn[0], io.jn[1]}, jt[2] = {io.jt[0], io.jt[1]}, jBias[2] = {io.jBias[0], io.jBias[1]};
+  BodyV a, b;
+  if (active) { body_load(L, bodyA, a); body_load(L, bodyB, b); }
+      // The two impulse chains of a contact - velocity (v, w, jn) and position correction (v_bias, w_bias, jBias) - touch
+      // disjoint fields and are the same instruction sequence up to the impulse vector.  A lone wave pays per instruction,
+      // not per lane: the bias chain of slot s runs on lane s + 32, which takes the arbiter's constants over the lanes.
+      static_assert(DRV_NS <= 32, "bias lanes are slot lanes + 32");
+      const bool biasCand = lane >= 32 && lane < 32 + DRV_NS;
+      const int srcLane = biasCand ? lane - 32 : lane;
+      const int code = __shfl(active ? (bodyA | (bodyB << 8) | (a_count << 16) | (myLevel << 24)) : -1, srcLane);
+      const bool biasLane = biasCand && code >= 0;
+      V2 sn = v2(__shfl(n.x, srcLane), __shfl(n.y, srcLane)), sr1[2], sr2[2];
+      double sMass[2], tgt[2], acc[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        sr1[c] = v2(__shfl(r1[c].x, srcLane), __shfl(r1[c].y, srcLane));
+        sr2[c] = v2(__shfl(r2[c].x, srcLane), __shfl(r2[c].y, srcLane));
+        sMass[c] = __shfl(nMass[c], srcLane);
+        // jbn = (bias - vbn) nMass in the velocity chain's form -((-bias) + vbn) nMass: the two can only differ in the sign of
+        // a zero jbn, which jBias = max(jBias + jbn, 0) with jBias >= +0 absorbs
+        const double sb = __shfl(bias[c], srcLane);
+        tgt[c] = biasLane ? -sb : bounce[c];
+        acc[c] = biasLane ? 0.0 : jn[c];
+      }
+      int sA = bodyA, sB = bodyB, sCount = a_count, sLevel = myLevel;
+      if (biasLane) { sA = code & 0xFF; sB = (code >> 8) & 0xFF; sCount = (code >> 16) & 0xFF; sLevel = (code >> 24) & 0xFF; }
+      const bool solveMe = active || biasLane;
+      const bool aDyn = sA < DRV_SLOT_OBST, bDyn = sB < DRV_SLOT_OBST;
+      double* const fX = biasLane ? L.vbx : L.vx;
+      double* const fY = biasLane ? L.vby : L.vy;
+      double* const fW = biasLane ? L.wb : L.w;
+      if (biasLane) {
+        a.minv = aDyn ? L.minv[sA] : 0.0; a.iinv = aDyn ? L.iinv[sA] : 0.0;
+        b.minv = bDyn ? L.minv[sB] : 0.0; b.iinv = bDyn ? L.iinv[sB] : 0.0;
+        a.v = b.v = v2(0.0, 0.0); a.w = b.w = 0.0;
+      }
+      for (int iter = 0; iter < 10; ++iter) {
+        for (int lv = 0; lv <= maxLevel; ++lv) {
+          if (solveMe && sLevel == lv) {
+            if (aDyn) { a.v = v2(fX[sA], fY[sA]); a.w = fW[sA]; }
+            if (bDyn) { b.v = v2(fX[sB], fY[sB]); b.w = fW[sB]; }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              if (c < sCount) {
+                if (!biasLane) {  // the velocity half of a resting contact is an exact no-op (see arb_apply_impulse)
+                  const long long zbits = __double_as_longlong(a.v.x) | __double_as_longlong(a.v.y) | __double_as_longlong(a.w) |
+                                          __double_as_longlong(b.v.x) | __double_as_longlong(b.v.y) | __double_as_longlong(b.w) |
+                                          __double_as_longlong(acc[c]) | __double_as_longlong(jt[c]);
+                  if (zbits == 0ll && tgt[c] == 0.0) continue;
+                }
+                const V2 vr = relative_velocity(a, b, sr1[c], sr2[c]);
+                const double vrn = vdot(vr, sn);
+                const double jnn = -(tgt[c] + vrn) * sMass[c];
+                const double jnOld = acc[c];
+                acc[c] = fmax_cp(jnOld + jnn, 0.0);
+                const double dj = acc[c] - jnOld;
+                const V2 jr = vrotate(sn, v2(dj, 0.0));  // (friction: see arb_apply_impulse)
+                const V2 jl = vmul(sn, dj);
+                const V2 jj = biasLane ? jl : jr;
+                apply_impulse(a, vneg(jj), sr1[c]);
+                apply_impulse(b, jj, sr2[c]);
+              }
+            }
+            if (aDyn) { fX[sA] = a.v.x; fY[sA] = a.v.y; fW[sA] = a.w; }
+            if (bDyn) { fX[sB] = b.v.x; fY[sB] = b.v.y; fW[sB] = b.w; }
+          }
+          __syncthreads();
+        }
+      }
+      {  // accumulated impulses back to the slot lanes: jn from their own chain, jBias from lane + 32
+        const int back = lane < DRV_NS ? lane + 32 : lane;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const double other = __shfl(acc[c], back);
+          if (active) { jn[c] = acc[c]; jBias[c] = other; }
+        }
+      }
+  io.jn[0] = jn[0]; io.jn[1] = jn[1]; io.jBias[0] = jBias[0]; io.jBias[1] = jBias[1];
+  return io;
+}
+#endif
+
 struct ContactRet {
   uint64_t occ;
   double rew;
@@ -1064,6 +1162,15 @@ DRV_PROF(profMode = 3;)
       }
     } else {
 DRV_PROF(profMode = 4;)
+#if DRV_SPLIT_BIAS
+      {
+        DrvSplitIO io;
+        io.n = n; io.r1[0] = r1[0]; io.r1[1] = r1[1]; io.r2[0] = r2[0]; io.r2[1] = r2[1];
+        for (int c = 0; c < 2; ++c) { io.nMass[c] = nMass[c]; io.bias[c] = bias[c]; io.bounce[c] = bounce[c]; io.jn[c] = jn[c]; io.jt[c] = jt[c]; io.jBias[c] = jBias[c]; }
+        io = drv_solve_multilevel_split(lane, active, bodyA, bodyB, a_count, myLevel, maxLevel, io);
+        for (int c = 0; c < 2; ++c) { jn[c] = io.jn[c]; jBias[c] = io.jBias[c]; }
+      }
+#else
       for (int iter = 0; iter < 10; ++iter) {
         for (int lv = 0; lv <= maxLevel; ++lv) {
           if (active && myLevel == lv) {
@@ -1076,6 +1183,7 @@ DRV_PROF(profMode = 4;)
           __syncthreads();
         }
       }
+#endif
     }
   }
   // arbiters that were active this step are NORMAL from the next step on (cpSpaceStep resets the state)
