@@ -717,8 +717,19 @@ DRV_PROF(__device__ unsigned long long g_dbgr[16];)
                             impulses (what RC_SPLIT_BIAS does for RoboCup).  Bit-identical, and measured SLOWER here (0.252 against 0.245 ms per
                             step, inline 0.262): the rare call costs drv_contact_path callee-saved registers on every one of its calls */
 #endif
+// Which half of a substep is out of line.  DRV_INVERT = 1 (default): the COMMON part (game logic, position update, broadphase:
+// drv_light_substep, 88 VGPRs, nothing to save) is the function and the contact path is inlined into the kernel, which as the
+// outermost frame never saves a register: the per-call save / restore of 47 callee-saved VGPRs that the round-1 layout
+// (DRV_INVERT = 0: contact path out of line) paid - 3/4 of that kernel's HBM traffic - is gone (236 -> 76 MB per launch).
+#ifndef DRV_INVERT
+#define DRV_INVERT 1
+#endif
 #ifndef DRV_CONTACT_INLINE
+#if DRV_INVERT
+#define DRV_CONTACT_INLINE __forceinline__
+#else
 #define DRV_CONTACT_INLINE __noinline__
+#endif
 #endif
 #if DRV_SPLIT_BIAS
 struct DrvSplitIO {
@@ -1248,6 +1259,214 @@ __device__ __noinline__ void drv_partial_obs_fused(const DrvState& S, int e, int
 #ifndef DRV_FUSED_AGENTS
 #define DRV_FUSED_AGENTS 7 /* agent passes a light environment runs in the step launch */
 #endif
+#if DRV_INVERT
+struct DrvLightRet {
+  double rew, posrew;
+  int cand, dirty, bits;
+};
+struct DrvSeedOnly { uint64_t seed; };
+__device__ __noinline__ DrvLightRet drv_light_substep(int it_, int lane, int A_, int nPed_, int nObst_, int elapsed_, int act0, int act1, int lastCand,
+                                                      uint32_t seedLo, uint32_t seedHi, uint32_t genv_, uint32_t episode_, int stateBits, double rew, double posrew) {
+  DrvLds& L = g_L;
+  const int it = uniform_i(it_), A = uniform_i(A_), nPed = uniform_i(nPed_), nObst = uniform_i(nObst_), elapsed = uniform_i(elapsed_);
+  const uint32_t genv = (uint32_t)uniform_i((int)genv_), episode = (uint32_t)uniform_i((int)episode_);
+  DrvSeedOnly S;
+  S.seed = ((uint64_t)(uint32_t)uniform_i((int)seedHi) << 32) | (uint64_t)(uint32_t)uniform_i((int)seedLo);
+  const bool isCar = lane < A;
+  const bool isPed = lane >= DRV_SLOT_PED && lane < DRV_SLOT_PED + nPed;
+  const bool isBody = isCar || isPed;
+  const bool vbValid = (uniform_i(stateBits) & 1) != 0;
+  bool aabbValid = (uniform_i(stateBits) & 2) != 0;
+    bool turned = false;  // Car.turn rotated the body in place: geometry changed even if every velocity is zero
+    if (isCar) {
+      int f = L.flags[lane];
+      const double px = L.px[lane], py = L.py[lane];
+      double vx = L.vx[lane], vy = L.vy[lane];
+      if (it == 0) {  // processAction :357-373 -> Car.accelerate (Car.py:55-94), Car.turn (Car.py:97-108)
+        const int acc = act0 - 1, steer = (act1 - 1) * 2;
+        if (!CF_FIN(f)) {
+          double dirx = L.dirx[lane], diry = L.diry[lane];
+          double power = (double)acc;
+          double moveDir = vx * dirx + vy * diry;
+          bool skip = false;
+          if (acc < 0) power = (double)acc * 0.75;
+          if (acc == 0) power = (moveDir == 0.0) ? 0.0 : (moveDir > 0.0 ? -2.0 : 2.0);
+          else if (acc < 0 && moveDir > 0.0) skip = true;
+          else if (acc > 0 && moveDir < 0.0) skip = true;
+          if (!skip) {
+            const double cs = L.rc[lane], sn = L.rs[lane];  // = dm_sincos(ang): the cache is refreshed on every change
+            vx = vx + L.cpower[lane] * power * cs;
+            vy = vy + L.cpower[lane] * power * sn;
+            if (acc == 0 && (vx * dirx + vy * diry) * moveDir < 0.0) { vx = 0.0; vy = 0.0; }
+          }
+          if (steer != 0) {
+            const double rot = (double)steer * (DM_PI / 180.0);
+            const double ang = L.ang[lane] + rot;
+            const DevSC rsc = dev_sincos(rot);
+            const double sn = rsc.s, cs = rsc.c;
+            const double dx = dirx * cs - diry * sn, dy = dirx * sn + diry * cs;
+            L.dirx[lane] = dx; L.diry[lane] = dy;
+            const double nvx = vx * cs - vy * sn, nvy = vx * sn + vy * cs;
+            vx = nvx; vy = nvy;
+            L.ang[lane] = ang;
+            car_refresh_rot(L, lane, ang);
+            turned = true;
+          }
+        }
+      }
+      // tick :376-426
+      const V2 pos = v2(px, py);
+      int lp = LP_OffRoad;
+      {
+        int rp = road_pos<0>(pos, L.cosRel0[lane]);
+        if (rp < lp) lp = rp;
+        rp = road_pos<1>(pos, L.cosRel1[lane]);
+        if (rp < lp) lp = rp;
+      }
+      const double dnow = vlen(vsub(pos, v2(L.goalx[lane], L.goaly[lane])));
+      const double diff = L.dprev[lane] - dnow;
+      if (!CF_FIN(f)) { const double d50 = diff / 50.0; rew += d50; posrew += dm_max(0.0, d50); }
+      L.prevx[lane] = px; L.prevy[lane] = py; L.dprev[lane] = dnow;
+      if (lp >= LP_OverRoad) {
+        if (!CF_FIN(f)) {
+          if (lp == LP_OverRoad && dnow < 100.0) {
+            lp = LP_AtGoal;
+            f |= (1 << 4) | (1 << 6);  // finished, friction_car_crashed
+            rew += (double)(DRV_MAX_TIME - elapsed) / 100.0;
+            posrew += (double)(DRV_MAX_TIME - elapsed) / 100.0;
+          } else {
+            f |= CF_CRASH_BITS;
+            rew -= vlen(v2(vx, vy)) / 5.0;
+          }
+        }
+      } else if (lp == LP_InOpposingLane) {
+        if (!CF_FIN(f)) rew -= vlen(v2(vx, vy)) / 10000.0;
+      }
+      f = CF_SET_LP(f, lp);
+      if (px >= DRV_W + 50.0 || px <= -50.0 || py >= DRV_H + 50.0 || py <= -50.0) { vx = 0.0; vy = 0.0; }  // prevPos == pos here
+      L.flags[lane] = f;
+      L.vx[lane] = vx; L.vy[lane] = vy;
+    } else if (isPed) {
+      // ======== phase 1b: pedestrian FSM (move :429-506) ====================================================
+      const int f = L.flags[lane];
+      if (!PF_DEAD(f)) {
+        double vx = L.vx[lane], vy = L.vy[lane];
+        int moving = L.moving[lane];
+        int crossing = PF_CROSSING(f), beginc = PF_BEGIN(f), side = PF_SIDE(f);
+        const V2 pos = v2(L.px[lane], L.py[lane]);
+        const bool isOffRoad = drv_is_off_road(pos);
+        const bool isOut = drv_is_out(pos);
+        if (moving > 0) {
+          moving = (moving - DRV_TIME_DIFF > 0) ? moving - DRV_TIME_DIFF : 0;
+          if (crossing) {
+            if (!beginc && isOffRoad) { moving = 0; crossing = 0; vx = 0.0; vy = 0.0; }
+            else if (beginc && !isOffRoad) { beginc = 0; }
+          }
+          if (isOut) { moving = 0; vx = 0.0; vy = 0.0; }
+        } else {
+          if (!crossing) {
+            dm_u32x4 u = dm_env_rng(S.seed, genv, episode, DM_RNG_PED_MOVE, (uint32_t)(lane - DRV_SLOT_PED), (uint32_t)elapsed);
+            const bool r1 = PF_ROAD(f) != 0;
+            const V2 rdir = r1 ? v2(RoadK<1>::dirx, RoadK<1>::diry) : v2(RoadK<0>::dirx, RoadK<0>::diry);
+            const V2 rnrm = r1 ? v2(RoadK<1>::nx, RoadK<1>::ny) : v2(RoadK<0>::nx, RoadK<0>::ny);
+            V2 dir = rdir;
+            moving = dm_randint(u.v[0], 5000, 30000);
+            int speed = dm_randint(u.v[1], -2, 2);
+            if (!isOffRoad) {
+              crossing = 1; beginc = 0;
+              if (speed == 0) speed = 2;
+            } else if (isOut) {
+              dir = drv_is_out(vadd(pos, rdir)) ? vneg(rdir) : rdir;
+            } else if (dm_unit(u.v[2]) < 0.05) {
+              crossing = 1; beginc = 1;
+              dir = side ? rnrm : vneg(rnrm);
+              side = side ? 0 : 1;
+              speed = dm_randint(u.v[3], 1, 2);
+            }
+            const V2 nv = vmul(vmul(dir, (double)PF_SPEED(f)), (double)speed);
+            vx = nv.x; vy = nv.y;
+          } else if (isOffRoad) {
+            crossing = 0; beginc = 0;
+          }
+        }
+        L.moving[lane] = moving;
+        L.flags[lane] = PEDF_PACK(PF_ROAD(f), side, 0, crossing, beginc, PF_SPEED(f));
+        L.vx[lane] = vx; L.vy[lane] = vy;
+      }
+    }
+
+    // ======== phase 1c: cpBodyUpdatePosition for every body (one instance of the code for cars + pedestrians) ===
+    if (isBody) {
+      const double px = L.px[lane], py = L.py[lane], ang = L.ang[lane];
+      const double vx = L.vx[lane], vy = L.vy[lane], w = L.w[lane];
+      // bias velocities: L.vb* keep the output of the last contact solve (a replay needs it again); they count only if
+      // the previous substep solved or replayed contacts (vbValid), else cpBodyUpdatePosition saw zeros
+      const double vbx = vbValid ? L.vbx[lane] : 0.0, vby = vbValid ? L.vby[lane] : 0.0, wb = vbValid ? L.wb[lane] : 0.0;
+      const double npx = px + (vx + vbx) * DE_DT, npy = py + (vy + vby) * DE_DT, nang = ang + (w + wb) * DE_DT;
+      const bool still = !turned && vx == 0.0 && vy == 0.0 && w == 0.0 && vbx == 0.0 && vby == 0.0 && wb == 0.0;
+      L.px[lane] = npx; L.py[lane] = npy; L.ang[lane] = nang;
+      // frozen: at rest and the position update was absorbed by rounding (sub-ulp bias velocities of a resting contact)
+      const bool frozen = !turned && vx == 0.0 && vy == 0.0 && w == 0.0 && npx == px && npy == py && nang == ang;
+      L.still[lane] = (still ? 1 : 0) | (frozen ? 2 : 0);
+      if (isCar) {
+        if (nang != L.rotAng[lane]) car_refresh_rot(L, lane, nang);
+        if (!aabbValid || !frozen) {  // frozen: same position and rotation => same box
+          BoxW bw;
+          box_world(bw, v2(npx, npy), L.rc[lane], L.rs[lane], L.chx[lane], L.chy[lane]);
+          double l = INFINITY, r = -INFINITY, b = INFINITY, t = -INFINITY;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            l = fmin_cp(l, bw.v[k].x); r = fmax_cp(r, bw.v[k].x); b = fmin_cp(b, bw.v[k].y); t = fmax_cp(t, bw.v[k].y);
+          }
+          L.aabb[lane][0] = l - 0.0; L.aabb[lane][1] = b - 0.0; L.aabb[lane][2] = r + 0.0; L.aabb[lane][3] = t + 0.0;
+        }
+      }
+    }
+    aabbValid = true;
+    __syncthreads();
+
+    // ======== phase 2: broadphase.  Lane = object j (slot id: cars, pedestrians, obstacles, buildings); the loop runs over
+    // the cars i < j whose box is broadcast from LDS.  cand bit i <=> cpBBIntersects(bb_i, bb_j) for the canonical pair
+    // (i, j); the pairs of one car are consecutive in canonical order and ascend with the lane.
+    int cand = 0;
+    bool candMoving = false, removed = false;
+    int dirty = 0;
+    {
+      double bl = 0.0, bb = 0.0, br = -1.0, bt = -1.0;
+      bool live = false;
+      int sj = 3;  // statics are always still and frozen
+      if (lane < DRV_SLOT_PED) {
+        live = isCar; sj = L.still[lane];
+        bl = L.aabb[lane][0]; bb = L.aabb[lane][1]; br = L.aabb[lane][2]; bt = L.aabb[lane][3];
+      } else if (lane < DRV_SLOT_OBST) {
+        live = isPed; sj = L.still[lane];
+        const double cx = L.px[lane], cy = L.py[lane];
+        bl = cx - 5.0; bb = cy - 5.0; br = cx + 5.0; bt = cy + 5.0;
+      } else if (lane < DRV_SLOT_BLD + 4) {
+        live = lane >= DRV_SLOT_BLD || (lane - DRV_SLOT_OBST) < nObst;
+        const V2 c = static_pos(L, lane);
+        const double ex = lane >= DRV_SLOT_BLD ? 400.0 : 10.0, ey = lane >= DRV_SLOT_BLD ? 225.0 : 10.0;
+        // static box AABB = min/max of (c +- e) exactly as cached by cpShapeCacheBB with rot = (1,0)
+        bl = -ex + c.x; br = ex + c.x; bb = -ey + c.y; bt = ey + c.y;
+      }
+      const int carStill = (int)(wave_ballot(isCar && (sj & 1)) & 0x3FFull);
+      const int carFrozen = (int)(wave_ballot(isCar && (sj & 2)) & 0x3FFull);
+#pragma unroll 5
+      for (int i = 0; i < DRV_MAXA; ++i) {  // rows >= A are never written but in bounds: the loads pipeline unconditionally
+        const double al = L.aabb[i][0], ab = L.aabb[i][1], ar = L.aabb[i][2], at = L.aabb[i][3];
+        if (live && i < A && lane > i && al <= br && bl <= ar && ab <= bt && bb <= at) cand |= (1 << i);
+      }
+      if (cand) candMoving = !(sj & 1) || (cand & ~carStill) != 0;
+      // clean pair: a candidate in the previous substep too, both bodies frozen since.  dirty: every other candidate.
+      const int clean = (lastCand >= 0 && (sj & 2)) ? (cand & lastCand & carFrozen) : 0;
+      dirty = cand & ~clean;
+      removed = lastCand < 0 || (lastCand & ~cand) != 0;
+    }
+  DrvLightRet ret;
+  ret.rew = rew; ret.posrew = posrew; ret.cand = cand; ret.dirty = dirty; ret.bits = (candMoving ? 1 : 0) | (removed ? 2 : 0);
+  return ret;
+}
+#endif
 template <bool PARTIAL>
 DE_DEV void drv_step_body(const DrvState& S, const int* __restrict__ actions, float* __restrict__ obs, double* __restrict__ rewards,
                           uint8_t* __restrict__ dones, float* __restrict__ pobs, int pvNoise, double pvMagn) {
@@ -1297,6 +1516,15 @@ DRV_PROF(const unsigned long long K0 = __builtin_amdgcn_s_memtime(); unsigned lo
   for (int it = 0; it < 10; ++it) {
 DRV_PROF(const unsigned long long A0 = __builtin_amdgcn_s_memtime();)
     // ======== phase 1a: car game logic (processAction at substep 0, tick) ===================================
+#if DRV_INVERT
+    const DrvLightRet lr = drv_light_substep(it, lane, A, nPed, nObst, elapsed, act0, act1, lastCand, (uint32_t)S.seed, (uint32_t)(S.seed >> 32), genv, episode,
+                                             (vbValid ? 1 : 0) | (aabbValid ? 2 : 0), rew, posrew);
+    rew = lr.rew; posrew = lr.posrew;
+    const int cand = lr.cand, dirty = lr.dirty;
+    const bool candMoving = (lr.bits & 1) != 0, removed = (lr.bits & 2) != 0;
+    aabbValid = true;
+DRV_PROF(const unsigned long long A1 = A0;)
+#else
     bool turned = false;  // Car.turn rotated the body in place: geometry changed even if every velocity is zero
     if (isCar) {
       int f = L.flags[lane];
@@ -1483,6 +1711,7 @@ DRV_PROF(const unsigned long long A1 = __builtin_amdgcn_s_memtime();)
       dirty = cand & ~clean;
       removed = lastCand < 0 || (lastCand & ~cand) != 0;
     }
+#endif
     const uint64_t anyCand = wave_ballot(cand != 0);
     // Quiescent contact set: same candidate pairs as in the previous substep, every body in them exactly at rest and
     // every cached arbiter inert (zero bias, zero accumulated impulse, not first contact).  Then narrowphase, arbiter
