@@ -391,7 +391,10 @@ DE_DEV void rc_process_action(const RcCtx& c, RcLds& L, int r, const int* action
   }
 }
 
-template <int EPW>
+// NOEV: the caller has established !rc_tick_has_event(L, r) on the state before the tick.  The branches that only an event
+// reaches (kick end, getting up, end of a penalty, the defender set, leaving the field - everything that calls rc_fall /
+// rc_penalize or touches shared state) are then dead and compiled out: the lane-parallel tick contains no call.
+template <int EPW, bool NOEV = false>
 DE_DEV void rc_tick(const RcCtx& c, RcLds& L, int r) {  // :862-1007
   const double time = RC_TIME;
   if (L.moveT[r] > 0.0) {
@@ -405,7 +408,7 @@ DE_DEV void rc_tick(const RcCtx& c, RcLds& L, int r) {  // :862-1007
       const int fb = 2 * r + ((f & RF_FOOT) ? 1 : 0);
       const double mt = L.moveT[r];
       if (mt + time > 500.0 && mt <= 500.0) {
-        if (!(f & RF_JREM)) { con_remove(L, 2 * r); f |= RF_JREM; }
+        if (!NOEV && !(f & RF_JREM)) { con_remove(L, 2 * r); f |= RF_JREM; }
         const DevSC sc = dev_sincos(L.ang[fb]);
         const double vxl = ROBOT_VELOCITY * 3.0;
         L.vx[fb] = vxl * sc.c - 0.0 * sc.s; L.vy[fb] = vxl * sc.s + 0.0 * sc.c;
@@ -414,7 +417,7 @@ DE_DEV void rc_tick(const RcCtx& c, RcLds& L, int r) {  // :862-1007
         const DevSC sc = dev_sincos(L.ang[fb]);
         const double vxl = ROBOT_VELOCITY * 2.5;
         L.vx[fb] = -(vxl * sc.c - 0.0 * sc.s); L.vy[fb] = -(vxl * sc.s + 0.0 * sc.c);
-      } else if (mt <= 300.0) {
+      } else if (!NOEV && mt <= 300.0) {
         L.vx[fb] = 0.0; L.vy[fb] = 0.0;
         f &= ~RF_KICK;
         L.px[fb] = L.initx[r]; L.py[fb] = L.inity[r];
@@ -430,7 +433,7 @@ DE_DEV void rc_tick(const RcCtx& c, RcLds& L, int r) {  // :862-1007
   }
   if (L.rflags[r] & RF_FALLEN) {
     L.fallT[r] -= time;
-    if (L.fallT[r] < 0.0) {
+    if (!NOEV && L.fallT[r] < 0.0) {
       const dm_u32x4 u = rc_rng(c, L, (uint32_t)r | (1u << 8));
       const double rr = dm_unit(u.v[0]);
       if (rr > 0.9 && !(L.rflags[r] & RF_PENAL) && c.canFall) { rc_fall<EPW>(c, r, 0); return; }
@@ -440,7 +443,7 @@ DE_DEV void rc_tick(const RcCtx& c, RcLds& L, int r) {  // :862-1007
   }
   if (L.rflags[r] & RF_PENAL) {
     L.penalT[r] -= time;
-    if (L.penalT[r] <= 0.0) {
+    if (!NOEV && L.penalT[r] <= 0.0) {
       L.penalT[r] = 0.0;
       L.rflags[r] &= ~(RF_PENAL | RF_FALLEN);
       L.fallc[r] = 0;
@@ -448,7 +451,7 @@ DE_DEV void rc_tick(const RcCtx& c, RcLds& L, int r) {  // :862-1007
       free_penalty_spot(c, L, r, p, angle);
       for (int k = 0; k < 2; ++k) { L.px[2 * r + k] = p.x; L.py[2 * r + k] = p.y; set_body_angle(L, 2 * r + k, angle); }
     }
-  } else {
+  } else if (!NOEV) {  // (no event: in the penalty area exactly if already a defender - nothing to do)
     const int teamIdx = robot_team(L, r) > 0 ? 0 : 1;
     const V2 p = robot_pos(L, r);
     const double robX = teamIdx ? RC_W - p.x : p.x;
@@ -465,7 +468,7 @@ DE_DEV void rc_tick(const RcCtx& c, RcLds& L, int r) {  // :862-1007
     }
   }
   const V2 pos = robot_pos(L, r);
-  if (pos.y < 0.0 || pos.x < 0.0 || pos.y > RC_H || pos.x > RC_W) rc_penalize<EPW>(c, r);
+  if (!NOEV && (pos.y < 0.0 || pos.x < 0.0 || pos.y > RC_H || pos.x > RC_W)) rc_penalize<EPW>(c, r);
   if (pos.x != L.prevx[r] || pos.y != L.prevy[r]) {
     if ((r == L.envi[RE_CLOSE0] || r == L.envi[RE_CLOSE1]) && !(L.rflags[r] & RF_PENAL)) {
       const V2 ballPos = v2(L.px[RC_BALL], L.py[RC_BALL]);
@@ -636,7 +639,7 @@ __device__ RC_LOGIC_INLINE void rc_game_logic(RcCtx c, int it, const int* __rest
   bool serial = it == 0;  // processAction draws the fall dice and may knock other robots over: keep the reference order
   if (!serial) serial = Grp<EPW>::ballot(lane < c.R && rc_tick_has_event(L, lane)) != 0ull;
   if (!serial) {
-    if (lane < c.R) rc_tick<EPW>(c, L, lane);
+    if (lane < c.R) rc_tick<EPW, true>(c, L, lane);
   } else if (lane == 0) {
     rc_game_serial<EPW>(c, it, actions, headAct);
   }
@@ -1684,6 +1687,110 @@ DE_DEV void rc_write_obs(RcLds& L, int lane, int R, int obs_dim, float* __restri
 #ifndef RC_DEFER_MIN_GENERAL
 #define RC_DEFER_MIN_GENERAL 25 /* rc_physics substeps (of 50) from which an environment defers its Partial observation */
 #endif
+#ifndef RC_INVERT
+#define RC_INVERT 0 /* 1 (one environment per wave only): the common part of a substep is the out-of-line function, rc_physics is inlined into the kernel */
+#endif
+#if RC_INVERT
+struct RcCommonRet {
+  double rotC, rotS, rotAng;
+  int cand, bits;  // bits: 1 quiet, 2 rotValid
+};
+template <int EPW>
+__device__ __noinline__ RcCommonRet rc_common_substep(RcCtx c, int it_, int lane, const int* __restrict__ myActions, const double* __restrict__ myHead,
+                                                      uint64_t pairLo, uint64_t pairHi, uint64_t pairTop, int feetPairs, uint64_t occ_, double rotC, double rotS, double rotAng, int rotValid_) {
+  typedef Grp<EPW> G;
+  constexpr int W = G::W, NROUNDS = (RC_NPAIR_ROUNDS * 64) / W;
+  RcLds& L = G::tile();
+  const int it = G::uniform_i(it_), R = c.R;
+  const uint64_t occ = G::uniform_u64(occ_);
+  const bool isBody = lane == RC_BALL || lane < 2 * R;
+  bool rotValid = rotValid_ != 0;
+    // ---- sequential game logic (lane 0): processAction / tick per robot, then the ball (:465-475) ----------
+    rc_game_logic<EPW>(c, it, myActions, myHead, lane);
+    __syncthreads();
+    // ---- cpBodyUpdatePosition + shape cache + AABB ------------------------------------------------------
+    if (isBody) {
+      const double npx = L.px[lane] + (L.vx[lane] + L.vbx[lane]) * DE_DT;
+      const double npy = L.py[lane] + (L.vy[lane] + L.vby[lane]) * DE_DT;
+      const double nang = L.ang[lane] + (L.w[lane] + L.wb[lane]) * DE_DT;
+      L.px[lane] = npx; L.py[lane] = npy; L.ang[lane] = nang;
+      L.vbx[lane] = 0.0; L.vby[lane] = 0.0; L.wb[lane] = 0.0;
+      float fcx, fcy, fhx, fhy;
+      if (lane != RC_BALL) {
+        if (nang != rotAng || !rotValid) {  // this lane's rotation cache (registers): invalid at kernel entry
+          const DevSC sc = dev_sincos(nang);
+          rotC = sc.c; rotS = sc.s; rotAng = nang; rotValid = true;
+        }
+        L.cpx[lane] = npx; L.cpy[lane] = npy; L.crc[lane] = rotC; L.crs[lane] = rotS;
+        SegW s;
+        seg_world(L, lane, s);
+        double l, r, b, t;
+        if (s.ta.x < s.tb.x) { l = s.ta.x; r = s.tb.x; } else { l = s.tb.x; r = s.ta.x; }
+        if (s.ta.y < s.tb.y) { b = s.ta.y; t = s.tb.y; } else { b = s.tb.y; t = s.ta.y; }
+        L.aabb[lane][0] = l - FOOT_RADIUS; L.aabb[lane][1] = b - FOOT_RADIUS; L.aabb[lane][2] = r + FOOT_RADIUS; L.aabb[lane][3] = t + FOOT_RADIUS;
+      } else {
+        L.cpx[lane] = npx; L.cpy[lane] = npy;
+        L.aabb[lane][0] = npx - BALL_R; L.aabb[lane][1] = npy - BALL_R; L.aabb[lane][2] = npx + BALL_R; L.aabb[lane][3] = npy + BALL_R;
+      }
+      const double al = L.aabb[lane][0], ab = L.aabb[lane][1], ar = L.aabb[lane][2], at = L.aabb[lane][3];
+      fcx = (float)(0.5 * (al + ar)); fcy = (float)(0.5 * (ab + at));
+      fhx = (float)(0.5 * (ar - al)) + 1.0f; fhy = (float)(0.5 * (at - ab)) + 1.0f;
+      L.u.pf.cx[lane] = fcx; L.u.pf.cy[lane] = fcy; L.u.pf.hx[lane] = fhx; L.u.pf.hy[lane] = fhy;
+    }
+    __syncthreads();
+    // ---- broadphase ---------------------------------------------------------------------------------------
+    // The two feet of one robot overlap in every substep: they are candidates without a test (a candidate whose boxes
+    // do not overlap is harmless - shapes that touch have overlapping boxes, so the narrowphase finds nothing), which
+    // keeps the double-precision box test below for the rare real prefilter hits.
+    int cand = feetPairs, pre = 0;
+#pragma unroll
+    for (int t = 0; t < NROUNDS; ++t) {  // the fp32 prefilter of all my pairs first: their LDS reads are in flight together
+      const int pr = RC_MY_PAIR(t);
+      if (pr != 0xFFFF && !((feetPairs >> t) & 1)) {
+        const int i = pr >> 8, j = pr & 0xFF;
+        float bx, by, bhx, bhy;
+        if (j <= RC_BALL) { bx = L.u.pf.cx[j]; by = L.u.pf.cy[j]; bhx = L.u.pf.hx[j]; bhy = L.u.pf.hy[j]; }
+        else { const V2 pc = post_pos(j); bx = (float)pc.x; by = (float)pc.y; bhx = 11.0f; bhy = 11.0f; }
+        const float dx = L.u.pf.cx[i] - bx, dy = L.u.pf.cy[i] - by;
+        if (__builtin_fabsf(dx) <= L.u.pf.hx[i] + bhx && __builtin_fabsf(dy) <= L.u.pf.hy[i] + bhy) pre |= 1 << t;
+      }
+    }
+#pragma unroll 1
+    for (int mm = pre; mm; mm &= mm - 1) {  // the exact test (cpBBIntersects) of the pairs that passed (rare)
+      const int t = __builtin_ctz(mm);
+      const int pr = RC_MY_PAIR(t);
+      const int i = pr >> 8, j = pr & 0xFF;
+      const double al = L.aabb[i][0], ab = L.aabb[i][1], ar = L.aabb[i][2], at = L.aabb[i][3];
+      double bl, bb, br, bt;
+      if (j <= RC_BALL) { bl = L.aabb[j][0]; bb = L.aabb[j][1]; br = L.aabb[j][2]; bt = L.aabb[j][3]; }
+      else { const V2 pc = post_pos(j); bl = pc.x - POST_R; bb = pc.y - POST_R; br = pc.x + POST_R; bt = pc.y + POST_R; }
+      if (al <= br && bl <= ar && ab <= bt && bb <= at) cand |= (1 << t);
+    }
+    __syncthreads();
+    // ---- contacts, joints, velocity update, solver, post-solve callbacks -----------------------------------------
+    // The common substep never enters rc_physics: no cached arbiter, the only candidates are the robots' own feet pairs, and
+    // the narrowphase's separating-axis early out rejects every one of them.  What rc_physics does then is exactly this:
+    // velocity update, then every robot's joints (prestep, warm start, 10 iterations) in registers.
+    bool quiet = occ == 0ull && G::ballot((cand & ~feetPairs) != 0) == 0ull;
+    if (quiet) {
+      const bool far = lane < R ? feet_far_apart(L, lane) : true;
+      quiet = G::ballot(!far) == 0ull;
+    }
+    if (quiet) {
+      if (isBody) rc_velocity_update(L, lane);
+      __syncthreads();
+#if RC_QUIET_JOINTS_INLINE
+      rc_joints_only_inl<EPW>(lane, R);
+#else
+      rc_joints_only<EPW>(lane, R);
+#endif
+      __syncthreads();
+    }
+  RcCommonRet ret;
+  ret.rotC = rotC; ret.rotS = rotS; ret.rotAng = rotAng; ret.cand = cand; ret.bits = (quiet ? 1 : 0) | (rotValid ? 2 : 0);
+  return ret;
+}
+#endif
 template <bool PARTIAL, int EPW>
 DE_DEV void rc_step_body(const RcState& S, const int e, const int* __restrict__ actions, const double* __restrict__ headActions, float* __restrict__ obs,
                          double* __restrict__ rewards, uint8_t* __restrict__ dones) {
@@ -1731,6 +1838,14 @@ DE_DEV void rc_step_body(const RcState& S, const int e, const int* __restrict__ 
 RC_PROF(if (lane < 12 && e < 4096) g_rcprof[e * 12 + lane] = 0ull; const unsigned long long K0 = __builtin_amdgcn_s_memtime(); unsigned long long tG = 0, tP = 0, tB = 0;)
   for (int it = 0; it < 50; ++it) {
 RC_PROF(const unsigned long long A0 = __builtin_amdgcn_s_memtime();)
+#if RC_INVERT
+    const RcCommonRet cr = rc_common_substep<EPW>(c, it, lane, myActions, myHead, pairLo, pairHi, pairTop, feetPairs, occ, rotC, rotS, rotAng, rotValid ? 1 : 0);
+    rotC = cr.rotC; rotS = cr.rotS; rotAng = cr.rotAng; rotValid = (cr.bits & 2) != 0;
+    const int cand = cr.cand;
+    const bool quiet = G::uniform_i(cr.bits & 1) != 0;
+RC_PROF(const unsigned long long A1 = A0, A2 = A0, A3 = A0;)
+    if (quiet) {
+#else
     // ---- sequential game logic (lane 0): processAction / tick per robot, then the ball (:465-475) ----------
     rc_game_logic<EPW>(c, it, myActions, myHead, lane);
     __syncthreads();
@@ -1814,6 +1929,7 @@ RC_PROF(const unsigned long long A3 = __builtin_amdgcn_s_memtime(); tG += A1 - A
       rc_joints_only<EPW>(lane, R);
 #endif
       __syncthreads();
+#endif
     } else {
       __builtin_amdgcn_s_setprio(3);  // an environment with contact work is on the launch's critical path: issue it first
       ++nGeneral;
