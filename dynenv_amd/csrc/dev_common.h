@@ -70,6 +70,11 @@ __device__ __noinline__ static DevSC dev_sincos(double x) {
   dm_sincos(x, &r.s, &r.c);
   return r;
 }
+DE_DEV DevSC dev_sincos_inl(double x) {  // for functions that must not contain a call (their live values would need callee-saved registers)
+  DevSC r;
+  dm_sincos(x, &r.s, &r.c);
+  return r;
+}
 __device__ __noinline__ static double dev_atan2(double y, double x) { return dm_atan2(y, x); }
 DE_DEV double dev_cos(double x) { return dev_sincos(x).c; }
 

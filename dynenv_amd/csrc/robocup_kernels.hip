@@ -32,8 +32,21 @@ __constant__ RcConst RC;
 #ifndef RC_SPLIT_BIAS
 #define RC_SPLIT_BIAS 1 /* general solve: an arbiter's position-correction (bias) impulses run on lane slot + 16 beside its velocity impulses */
 #endif
+// RC_INVERT = 1 (default for one environment per wave): the COMMON part of a substep (game logic, position update, broadphase,
+// the quiet substep's joints) is an out-of-line function of its own, rc_common_substep - 102 VGPRs, no call inside, nothing
+// saved, nothing spilled - instead of living inline in a kernel whose register allocation it shared with everything else
+// (87 spilled VGPRs, ~50 scratch instructions per substep and wave: 2.1 GB of HBM traffic per launch, now 0.6 GB, all of it
+// the general path's).  The one call the common part could make (the sequential game logic) is made by the kernel.
+#ifndef RC_INVERT
+#define RC_INVERT (RC_FULL_EPW == 1)
+#endif
+#if RC_INVERT
+#define RC_COMMON_SINCOS(x) dev_sincos_inl(x)
+#else
+#define RC_COMMON_SINCOS(x) dev_sincos(x)
+#endif
 #ifndef RC_QUIET_JOINTS_INLINE
-#define RC_QUIET_JOINTS_INLINE 0 /* the quiet substep's joint solve inlined into the step loop (EPW = 2 always inlines) */
+#define RC_QUIET_JOINTS_INLINE RC_INVERT /* the quiet substep's joint solve inlined into the step loop (EPW = 2 always inlines) */
 #endif
 
 
@@ -409,12 +422,12 @@ DE_DEV void rc_tick(const RcCtx& c, RcLds& L, int r) {  // :862-1007
       const double mt = L.moveT[r];
       if (mt + time > 500.0 && mt <= 500.0) {
         if (!NOEV && !(f & RF_JREM)) { con_remove(L, 2 * r); f |= RF_JREM; }
-        const DevSC sc = dev_sincos(L.ang[fb]);
+        const DevSC sc = NOEV ? RC_COMMON_SINCOS(L.ang[fb]) : dev_sincos(L.ang[fb]);
         const double vxl = ROBOT_VELOCITY * 3.0;
         L.vx[fb] = vxl * sc.c - 0.0 * sc.s; L.vy[fb] = vxl * sc.s + 0.0 * sc.c;
       }
       if (mt + time > 400.0 && mt <= 400.0) {
-        const DevSC sc = dev_sincos(L.ang[fb]);
+        const DevSC sc = NOEV ? RC_COMMON_SINCOS(L.ang[fb]) : dev_sincos(L.ang[fb]);
         const double vxl = ROBOT_VELOCITY * 2.5;
         L.vx[fb] = -(vxl * sc.c - 0.0 * sc.s); L.vy[fb] = -(vxl * sc.s + 0.0 * sc.c);
       } else if (!NOEV && mt <= 300.0) {
@@ -632,6 +645,14 @@ __device__ __noinline__ void rc_game_serial(RcCtx c, int it, const int* __restri
     }
     rc_tick<EPW>(c, L, r);
   }
+}
+// RC_INVERT: the kernel has already decided `serial` and, if so, run rc_game_serial (the only call of the game logic)
+template <int EPW>
+DE_DEV void rc_game_logic_rest(RcCtx c, bool serial, int lane) {
+  RcLds& L = Grp<EPW>::tile();
+  if (!serial && lane < c.R) rc_tick<EPW, true>(c, L, lane);
+  __syncthreads();
+  rc_ball_logic<EPW>(c, L, lane);
 }
 template <int EPW>
 __device__ RC_LOGIC_INLINE void rc_game_logic(RcCtx c, int it, const int* __restrict__ actions, const double* __restrict__ headAct, int lane) {
@@ -1687,26 +1708,24 @@ DE_DEV void rc_write_obs(RcLds& L, int lane, int R, int obs_dim, float* __restri
 #ifndef RC_DEFER_MIN_GENERAL
 #define RC_DEFER_MIN_GENERAL 25 /* rc_physics substeps (of 50) from which an environment defers its Partial observation */
 #endif
-#ifndef RC_INVERT
-#define RC_INVERT 0 /* 1 (one environment per wave only): the common part of a substep is the out-of-line function, rc_physics is inlined into the kernel */
-#endif
 #if RC_INVERT
 struct RcCommonRet {
   double rotC, rotS, rotAng;
   int cand, bits;  // bits: 1 quiet, 2 rotValid
 };
 template <int EPW>
-__device__ __noinline__ RcCommonRet rc_common_substep(RcCtx c, int it_, int lane, const int* __restrict__ myActions, const double* __restrict__ myHead,
+__device__ __noinline__ RcCommonRet rc_common_substep(RcCtx c, int serial_, int lane,
                                                       uint64_t pairLo, uint64_t pairHi, uint64_t pairTop, int feetPairs, uint64_t occ_, double rotC, double rotS, double rotAng, int rotValid_) {
   typedef Grp<EPW> G;
   constexpr int W = G::W, NROUNDS = (RC_NPAIR_ROUNDS * 64) / W;
   RcLds& L = G::tile();
-  const int it = G::uniform_i(it_), R = c.R;
+  const bool serial = G::uniform_i(serial_) != 0;
+  const int R = c.R;
   const uint64_t occ = G::uniform_u64(occ_);
   const bool isBody = lane == RC_BALL || lane < 2 * R;
   bool rotValid = rotValid_ != 0;
     // ---- sequential game logic (lane 0): processAction / tick per robot, then the ball (:465-475) ----------
-    rc_game_logic<EPW>(c, it, myActions, myHead, lane);
+    rc_game_logic_rest<EPW>(c, serial, lane);
     __syncthreads();
     // ---- cpBodyUpdatePosition + shape cache + AABB ------------------------------------------------------
     if (isBody) {
@@ -1718,7 +1737,7 @@ __device__ __noinline__ RcCommonRet rc_common_substep(RcCtx c, int it_, int lane
       float fcx, fcy, fhx, fhy;
       if (lane != RC_BALL) {
         if (nang != rotAng || !rotValid) {  // this lane's rotation cache (registers): invalid at kernel entry
-          const DevSC sc = dev_sincos(nang);
+          const DevSC sc = RC_COMMON_SINCOS(nang);
           rotC = sc.c; rotS = sc.s; rotAng = nang; rotValid = true;
         }
         L.cpx[lane] = npx; L.cpy[lane] = npy; L.crc[lane] = rotC; L.crs[lane] = rotS;
@@ -1839,7 +1858,14 @@ RC_PROF(if (lane < 12 && e < 4096) g_rcprof[e * 12 + lane] = 0ull; const unsigne
   for (int it = 0; it < 50; ++it) {
 RC_PROF(const unsigned long long A0 = __builtin_amdgcn_s_memtime();)
 #if RC_INVERT
-    const RcCommonRet cr = rc_common_substep<EPW>(c, it, lane, myActions, myHead, pairLo, pairHi, pairTop, feetPairs, occ, rotC, rotS, rotAng, rotValid ? 1 : 0);
+    // the game logic's sequential form (first substep: processAction; later: a cross-robot event) is the only call of the common
+    // part: it is made from here, the outermost frame, so that rc_common_substep itself contains no call at all
+    bool serial = it == 0;
+    if (!serial) serial = G::ballot(lane < R && rc_tick_has_event(L, lane)) != 0ull;
+    if (serial) {
+      if (lane == 0) rc_game_serial<EPW>(c, it, myActions, myHead);
+    }
+    const RcCommonRet cr = rc_common_substep<EPW>(c, serial ? 1 : 0, lane, pairLo, pairHi, pairTop, feetPairs, occ, rotC, rotS, rotAng, rotValid ? 1 : 0);
     rotC = cr.rotC; rotS = cr.rotS; rotAng = cr.rotAng; rotValid = (cr.bits & 2) != 0;
     const int cand = cr.cand;
     const bool quiet = G::uniform_i(cr.bits & 1) != 0;
@@ -1860,7 +1886,7 @@ RC_PROF(const unsigned long long A1 = __builtin_amdgcn_s_memtime();)
       float fcx, fcy, fhx, fhy;
       if (lane != RC_BALL) {
         if (nang != rotAng || !rotValid) {  // this lane's rotation cache (registers): invalid at kernel entry
-          const DevSC sc = dev_sincos(nang);
+          const DevSC sc = RC_COMMON_SINCOS(nang);
           rotC = sc.c; rotS = sc.s; rotAng = nang; rotValid = true;
         }
         L.cpx[lane] = npx; L.cpy[lane] = npy; L.crc[lane] = rotC; L.crs[lane] = rotS;
