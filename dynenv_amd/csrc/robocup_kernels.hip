@@ -1864,12 +1864,13 @@ RC_PROF(const unsigned long long A0 = __builtin_amdgcn_s_memtime();)
     if (!serial) serial = G::ballot(lane < R && rc_tick_has_event(L, lane)) != 0ull;
     if (serial) {
       if (lane == 0) rc_game_serial<EPW>(c, it, myActions, myHead);
+RC_PROF(tG += 1;)  // (profile build: "game logic" = substeps with the sequential form, "position" = cycles of the whole common part)
     }
     const RcCommonRet cr = rc_common_substep<EPW>(c, serial ? 1 : 0, lane, pairLo, pairHi, pairTop, feetPairs, occ, rotC, rotS, rotAng, rotValid ? 1 : 0);
     rotC = cr.rotC; rotS = cr.rotS; rotAng = cr.rotAng; rotValid = (cr.bits & 2) != 0;
     const int cand = cr.cand;
     const bool quiet = G::uniform_i(cr.bits & 1) != 0;
-RC_PROF(const unsigned long long A1 = A0, A2 = A0, A3 = A0;)
+RC_PROF(tP += __builtin_amdgcn_s_memtime() - A0;)
     if (quiet) {
 #else
     // ---- sequential game logic (lane 0): processAction / tick per robot, then the ball (:465-475) ----------
