@@ -883,6 +883,17 @@ int dynenv_obs_unpack_peers_ranks(const float* packed_dev, int64_t src_stride_fl
   const long long total = (long long)n_env_time * A * D;
   if (total == 0) return DYNENV_OK;
   const bool vec = (D % 4) == 0 && ((uintptr_t)obs_dev % 16) == 0;
+  if (vec && A <= PEER_ROWS_MAXA && D - (PEER_SELF + (A - 1) * PEER_COLS) <= 160) {
+    // row job (see obs_unpack_peers_rows_kernel)
+    int rowsPerBlock = (int)((n_env_time * (long long)n_ranks + 4095) / 4096);  // ~4096 blocks: the chip several times over
+    if (rowsPerBlock < 1) rowsPerBlock = 1;
+    if (rowsPerBlock > 32) rowsPerBlock = 32;
+    const dim3 rgrid((unsigned)((n_env_time + rowsPerBlock - 1) / rowsPerBlock), (unsigned)n_ranks);
+    hipLaunchKernelGGL(obs_unpack_peers_rows_kernel, rgrid, dim3(ARR_BLOCK), 0, (hipStream_t)stream, packed_dev, (long long)n_env_time, A, D,
+                       obs_dev, (long long)src_stride_floats, rowsPerBlock);
+    HIP_OK(hipGetLastError());
+    return DYNENV_OK;
+  }
   const long long threads = vec ? total / 4 : total;
   const dim3 grid((unsigned)((threads + ARR_BLOCK - 1) / ARR_BLOCK), (unsigned)n_ranks);
   if (vec)

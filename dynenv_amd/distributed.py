@@ -183,8 +183,13 @@ class StepGather(object):
         # high priority: its own hardware queue (a default-priority stream created after RCCL's can end up sharing the launch
         # stream's queue, which serialises the two), and the small transport kernels are dispatched ahead of the big step grid
         self.comm = torch.cuda.Stream(self.device, priority=-1) if self.device.type == "cuda" else None
+        # the expansion of step k (one kernel that writes the dense [G, E, T, A, D] tensor: 8x the bytes the collective moved at
+        # 8 ranks) runs on a second side stream, so that it overlaps the collective of step k + 1 instead of delaying it: the
+        # transport's throughput is max(collective, expansion) per step, not their sum
+        self.expand = torch.cuda.Stream(self.device, priority=-1) if self.device.type == "cuda" and any(s.packed for s in self.slabs) else None
         if self.comm is not None:
             self._ready = [torch.cuda.Event() for _ in self.slabs]
+            self._gathered = [torch.cuda.Event() for _ in self.slabs]
             self._done = [torch.cuda.Event() for _ in self.slabs]
 
     def __call__(self):
@@ -234,8 +239,16 @@ class StepGather(object):
                 sl.pack()
                 # a blocking-semantics collective is stream-ordered on the current (= side) stream; the host does not wait
                 self.dist.all_gather_into_tensor(self.gbufs[i], sl.buf, group=self.group)
-                views = sl.gathered_views(self.gbufs[i], self.world_size, self.dense[i])
-                self._done[i].record(self.comm)
+                if self.expand is None:
+                    views = sl.gathered_views(self.gbufs[i], self.world_size, self.dense[i])
+                    self._done[i].record(self.comm)
+                else:
+                    self._gathered[i].record(self.comm)
+            if self.expand is not None:
+                with t.cuda.stream(self.expand):
+                    self.expand.wait_event(self._gathered[i])
+                    views = sl.gathered_views(self.gbufs[i], self.world_size, self.dense[i])
+                    self._done[i].record(self.expand)
             h = StepGather._Handle(self, i, views=views, done=self._done[i])
         self._pending[i] = h
         return h
