@@ -22,11 +22,11 @@ for s in range(STEP):
     env.step_flat(a)
 env.debug_counters()
 d = np.loadtxt("gpurun_out/rcprof.txt")
-names = ["game logic", "position", "broadphase", "contacts+prestep", "joint prestep", "velocity", "warm start", "solver", "post-solve", "touched", "levels", "TOTAL"]
+names = ["sequential-logic substeps", "common part (logic+position+broadphase+quiet joints)", "-", "contacts+prestep", "joint prestep", "velocity", "warm start", "solver", "post-solve", "touched", "levels", "TOTAL"]
 print("per-env cycles of one step (50 substeps): mean / p99 / max")
 for k, n in enumerate(names):
     c = d[:, k]
-    print("  %-18s %10.0f %10.0f %10.0f" % (n, c.mean(), np.percentile(c, 99), c.max()))
+    print("  %-54s %10.0f %10.0f %10.0f" % (n, c.mean(), np.percentile(c, 99), c.max()))
 top = np.argsort(-d[:, 11])[:12]
 print("slowest environments: " + " | ".join(names))
 for k in top: print("  ", " ".join("%8d" % v for v in d[k]))
