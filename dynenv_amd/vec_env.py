@@ -741,6 +741,14 @@ class BatchedDynEnv(object):
     def render(self, *a, **k):
         return None
 
+    def get_images(self, *a, **k):
+        """base_vec_env.py:174-178: the rendered frames of the sub-environments.  Rendering (pygame) is outside the step path."""
+        raise NotImplementedError("rendering is not part of the batched step path (SURVEY.md section 2: out of scope)")
+
+    @property
+    def unwrapped(self):  # base_vec_env.py:203-208
+        return self
+
     def close(self):
         if not self.closed and self._h:
             self._lib.dynenv_destroy(self._h)
