@@ -228,6 +228,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     if args.rehearse_one_gpu:
         local_rank = 0
+    ndev = torch.cuda.device_count()
+    if ndev > 0 and local_rank >= ndev:  # a launcher that shows each rank only its own GPU (ROCR/HIP_VISIBLE_DEVICES)
+        local_rank %= ndev
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
