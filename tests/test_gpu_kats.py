@@ -129,3 +129,51 @@ def test_kat_resting_car_is_pushed_out_of_an_obstacle_geometrically(gpu, car_typ
         assert g.vx == 0.0 and g.vy == 0.0 and g.w == 0.0 and abs(g.angle) < 1e-6 and abs(g.py - cy) < 1e-6 and g.crashed == 1
     assert env.error_flags() == 0
     env.close()
+
+
+@pytest.mark.parametrize("car_type,speed", [(0, 40.0), (2, 25.0)])
+def test_kat_head_on_cars_conserve_momentum_and_mirror_each_other(gpu, car_type, speed):
+    """Two identical cars on one line, nose to nose, equal and opposite speeds (a mirror-symmetric scene about the contact plane):
+    whatever the solver does, (1) every impulse acts on both bodies with opposite sign, so the total momentum stays 0 up to
+    rounding; (2) the scene's mirror symmetry survives - v1 = -v2, the lateral velocity and the spin of a face-on two-point
+    manifold cancel; (3) the cars separate no faster than e = 0.05 * 0.05 times the approach speed allows (the velocity
+    function only ever slows them); (4) the begin callback crashed both.  And HIP == oracle bit for bit along the way."""
+    dynenv_amd = gpu
+    half_len = [10.0, 15.0, 20.0, 25.0][car_type]
+    env = dynenv_amd.BatchedDynEnv(dynenv_amd.DynEnvType.DRIVE, 1, 2, seed=8)
+    ora = ol.OracleEnv(env_type=1, num_envs=1, n_players=2, seed=8)
+    env.reset_flat()
+    ora.reset()
+    st = ora.get_state(0)
+    st.n_peds, st.n_obst = 0, 0
+    cy, gap = 445.0, 6.0   # the walkway strip (see the obstacle KAT); the noses are `gap` apart
+    x0 = 300.0
+    for k, sgn in ((0, +1.0), (1, -1.0)):
+        c = st.cars[k]
+        c.px, c.py = x0 - sgn * (half_len + gap / 2.0), cy
+        c.vx, c.vy, c.w, c.angle = sgn * speed, 0.0, 0.0, 0.0
+        c.dirx, c.diry = 1.0, 0.0
+        c.prevx, c.prevy, c.type, c.finished, c.crashed, c.fric, c.lane_pos = c.px, c.py, car_type, 0, 0, 0, 4
+    env.set_state(0, st)
+    ora.set_state(0, st)
+    a = np.ones((1, 2, 2), np.int32)  # coast: (acc, steer) = (0, 0) brakes towards rest, symmetrically
+    hit = False
+    for s in range(3):
+        env.step_flat(a)
+        ora.step(a)
+        g0, g1 = env.get_state(0).cars[0], env.get_state(0).cars[1]
+        r0, r1 = ora.get_state(0).cars[0], ora.get_state(0).cars[1]
+        for g, r in ((g0, r0), (g1, r1)):
+            assert [g.px, g.py, g.vx, g.vy, g.angle, g.w, g.crashed] == [r.px, r.py, r.vx, r.vy, r.angle, r.w, r.crashed], "HIP == oracle, step %d" % s
+        scale = max(abs(g0.vx), abs(g1.vx), 1e-3)
+        assert abs(g0.vx + g1.vx) <= 1e-9 * scale + 1e-12, "momentum along the line (equal masses)"
+        assert abs(g0.vy + g1.vy) <= 1e-9 and abs((g0.px - x0) + (g1.px - x0)) <= 1e-9, "mirror symmetry"
+        assert abs(g0.vy) <= 1e-9 and abs(g0.w) <= 1e-9 and abs(g0.angle) <= 1e-9, "a face-on two-point manifold neither deflects nor spins"
+        if g0.crashed:
+            hit = True
+            assert g1.crashed == 1
+            assert g0.vx <= 0.05 * 0.05 * speed + 1e-9, "separation speed bounded by e x approach speed"
+            assert (g1.px - g0.px) >= 2.0 * half_len - 2.0 * speed * 0.01 - 1e-9, "never deeper than one substep of approach"
+    assert hit, "the cars must have met within three steps"
+    assert env.error_flags() == 0
+    env.close()
