@@ -5,7 +5,7 @@ is what to optimise.  Usage (GPU box):  python tools/contact_profile.py [step]""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-PROF = os.path.join(ROOT, "dynenv_amd", "libdynenv_hip_prof.so")
+PROF = os.environ.get("PROFILE_LIB", os.path.join(ROOT, "dynenv_amd", "libdynenv_hip_prof.so"))
 os.environ["DYNENV_HIP_LIB"] = PROF  # read by dynenv_amd._capi at import
 from dynenv_amd import build as _b
 if not os.path.exists(PROF) or any(os.path.getmtime(d) > os.path.getmtime(PROF) for d in _b.DEPS if os.path.exists(d)):
@@ -15,14 +15,15 @@ os.chdir(ROOT)
 import torch, numpy as np
 from dynenv_amd import BatchedDynEnv, DynEnvType
 STEP = int(sys.argv[1]) if len(sys.argv) > 1 else 560
-env = BatchedDynEnv(DynEnvType.DRIVE, 4096, 10, seed=42)
+NE = int(os.environ.get("PROFILE_ENVS", "4096"))
+env = BatchedDynEnv(DynEnvType.DRIVE, NE, 10, seed=42)
 env.reset_flat()
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 for s in range(STEP):
-    a = torch.randint(0, 3, (4096, 10, 2), dtype=torch.int32, device="cuda", generator=g)
+    a = torch.randint(0, 3, (NE, 10, 2), dtype=torch.int32, device="cuda", generator=g)
     env.step_flat(a)
 print("substep path counters of the whole run:", env.debug_counters())
-d = np.loadtxt("gpurun_out/dbgw.txt")
+d = np.loadtxt("gpurun_out/dbgw.txt")[:NE]
 c = d[:, 0]
 print("cycles: mean %.0f  p50 %.0f p90 %.0f p99 %.0f max %.0f" % (c.mean(), *np.percentile(c, [50, 90, 99]), c.max()))
 for k in range(11):
@@ -34,7 +35,7 @@ m = d[:, 1] == 10
 for o in range(0, 25):
     mm = m & (d[:, 2] == o)
     if mm.any(): print("nContact=10 occ=%d n=%d mean %.0f" % (o, mm.sum(), c[mm].mean()))
-praw = np.loadtxt("gpurun_out/dbgp.txt", dtype=np.uint64)
+praw = np.loadtxt("gpurun_out/dbgp.txt", dtype=np.uint64)[:NE]
 p = praw.astype(float)
 lv = praw[:, 6]
 modes = np.stack([(lv >> np.uint64(12 * k)) & np.uint64(0xFFF) for k in range(1, 5)], 1)  # level passes (x10 iterations) per solver mode
