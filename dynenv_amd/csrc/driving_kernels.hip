@@ -824,6 +824,144 @@ __device__ __noinline__ DrvSplitIO drv_solve_multilevel_split(int lane, bool act
 }
 #endif
 
+#ifndef DRV_SOLVE_OOL
+#define DRV_SOLVE_OOL 1 /* prestep + velocity update + solve as a function of their own (fresh register allocation; the per-slot
+                           geometry comes from the mailbox in LDS, not through registers held since the slot update) */
+#endif
+#if DRV_SOLVE_OOL
+struct DrvSolveRet {
+  double jn[2], jBias[2];
+  int bits;  // 1: restIn, 2: bias[0] == 0 && bias[1] == 0
+};
+__device__ __noinline__ DrvSolveRet drv_prestep_solve(int lane, int roleBits, int active_, int bodyA, int bodyB, int a_count, int a_state, int myLevel,
+                                                     int maxLevel_, int anyActive_, double jn0, double jn1, double jt0, double jt1) {
+  DrvLds& L = g_L;
+  DrvMailbox& M = L.u.mb;
+  const bool isCar = (roleBits & 1) != 0, isPed = (roleBits & 2) != 0, active = active_ != 0;
+  const int maxLevel = uniform_i(maxLevel_);
+  const uint64_t activeMask = uniform_i(anyActive_) ? 1ull : 0ull;
+  double jn[2] = {jn0, jn1}, jt[2] = {jt0, jt1};
+  V2 n = v2(0.0, 0.0), r1[2], r2[2];
+  r1[0] = r1[1] = r2[0] = r2[1] = v2(0.0, 0.0);
+  // ---- prestep (cpArbiterPreStep) on velocities BEFORE the friction update -------------------------------
+  double nMass[2] = {0.0, 0.0}, tMass[2] = {0.0, 0.0}, bias[2] = {0.0, 0.0}, bounce[2] = {0.0, 0.0}, jBias[2] = {0.0, 0.0};
+  const double arb_e = 0.05 * 0.05, arb_u = 0.0 * 0.0;
+  bool restIn = false;  // both bodies exactly at rest when the arbiter was prestepped
+  if (active) {
+    BodyV a, b;
+    body_load(L, bodyA, a);
+    body_load(L, bodyB, b);
+    restIn = a.v.x == 0.0 && a.v.y == 0.0 && a.w == 0.0 && b.v.x == 0.0 && b.v.y == 0.0 && b.w == 0.0;
+    r1[0] = vsub(v2(M.p1x[lane][0], M.p1y[lane][0]), a.p);
+    r2[0] = vsub(v2(M.p2x[lane][0], M.p2y[lane][0]), b.p);
+    if (a_count > 1) {
+      r1[1] = vsub(v2(M.p1x[lane][1], M.p1y[lane][1]), a.p);
+      r2[1] = vsub(v2(M.p2x[lane][1], M.p2y[lane][1]), b.p);
+    }
+    n = v2(M.nx[lane], M.ny[lane]);
+    V2 body_delta = vsub(b.p, a.p);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      if (c < a_count) {
+        nMass[c] = 1.0 / (k_scalar_body(a, r1[c], n) + k_scalar_body(b, r2[c], n));
+        double dist = vdot(vadd(vsub(r2[c], r1[c]), body_delta), n);  // (tMass is not needed: see arb_apply_impulse)
+        bias[c] = -DE_CONTACT_BIAS_COEF * fmin_cp(0.0, dist + DE_COLLISION_SLOP) / DE_DT;
+        jBias[c] = 0.0;
+        bounce[c] = vdot(relative_velocity(a, b, r1[c], r2[c]), n) * arb_e;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- velocity update (velocity_func: friction_* or default) -------------------------------------------
+  velocity_update(L, lane, isCar, isPed);
+  if (activeMask && maxLevel == 0) {
+    // No two active arbiters share a dynamic body: each lane keeps its two bodies in registers through the warm start
+    // and all 10 iterations, with one LDS load and one store (same arithmetic, no LDS round trip per iteration).
+    __syncthreads();
+    if (active) {
+      BodyV a, b;
+      body_load(L, bodyA, a);
+      body_load(L, bodyB, b);
+      if (a_state != ARB_FIRST) arb_warm_start(a, b, n, r1, r2, jn, jt, a_count);
+      if (wave_ballot(!arb_is_bias_only(a, b, jn, jt, bounce, a_count)) == 0ull) {  // all resting contacts: bias half only
+#pragma unroll 1
+        for (int iter = 0; iter < 10; ++iter) arb_apply_bias_only(a, b, n, r1, r2, nMass, bias, jBias, a_count);
+      } else {
+#pragma unroll 1
+        for (int iter = 0; iter < 10; ++iter) arb_apply_impulse(a, b, n, r1, r2, nMass, tMass, bias, bounce, jBias, jn, jt, a_count, arb_u);
+      }
+      body_store_vel(L, bodyA, a);
+      body_store_vel(L, bodyB, b);
+    }
+    __syncthreads();
+  } else if (activeMask) {
+    __syncthreads();
+    // ---- warm start (cpArbiterApplyCachedImpulse; skipped on first contact), level by level ------------
+    for (int lv = 0; lv <= maxLevel; ++lv) {
+      if (active && myLevel == lv && a_state != ARB_FIRST) {
+        BodyV a, b;
+        body_load(L, bodyA, a);
+        body_load(L, bodyB, b);
+        arb_warm_start(a, b, n, r1, r2, jn, jt, a_count);
+        body_store_vel(L, bodyA, a);
+        body_store_vel(L, bodyB, b);
+      }
+      __syncthreads();
+    }
+    // ---- 10 sequential-impulse iterations (cpArbiterApplyImpulse) ---------------------------------------
+    BodyV a, b;
+    bool biasOnly = true;
+    if (active) {  // statics stay all-zero; p, minv, iinv are invariant
+      body_load(L, bodyA, a); body_load(L, bodyB, b);
+      biasOnly = arb_is_bias_only(a, b, jn, jt, bounce, a_count);
+    }
+    if (wave_ballot(!biasOnly) == 0ull) {
+      // every active arbiter is a resting contact being pushed out of penetration (the pile-ups that make up the launch's
+      // tail): only bias velocities move, through LDS, level by level
+      for (int iter = 0; iter < 10; ++iter) {
+        for (int lv = 0; lv <= maxLevel; ++lv) {
+          if (active && myLevel == lv) {
+            body_load_bias(L, bodyA, a);
+            body_load_bias(L, bodyB, b);
+            arb_apply_bias_only(a, b, n, r1, r2, nMass, bias, jBias, a_count);
+            body_store_bias(L, bodyA, a);
+            body_store_bias(L, bodyB, b);
+          }
+          __syncthreads();
+        }
+      }
+    } else {
+#if DRV_SPLIT_BIAS
+      {
+        DrvSplitIO io;
+        io.n = n; io.r1[0] = r1[0]; io.r1[1] = r1[1]; io.r2[0] = r2[0]; io.r2[1] = r2[1];
+        for (int c = 0; c < 2; ++c) { io.nMass[c] = nMass[c]; io.bias[c] = bias[c]; io.bounce[c] = bounce[c]; io.jn[c] = jn[c]; io.jt[c] = jt[c]; io.jBias[c] = jBias[c]; }
+        io = drv_solve_multilevel_split(lane, active, bodyA, bodyB, a_count, myLevel, maxLevel, io);
+        for (int c = 0; c < 2; ++c) { jn[c] = io.jn[c]; jBias[c] = io.jBias[c]; }
+      }
+#else
+      for (int iter = 0; iter < 10; ++iter) {
+        for (int lv = 0; lv <= maxLevel; ++lv) {
+          if (active && myLevel == lv) {
+            body_load_vel(L, bodyA, a);
+            body_load_vel(L, bodyB, b);
+            arb_apply_impulse(a, b, n, r1, r2, nMass, tMass, bias, bounce, jBias, jn, jt, a_count, arb_u);
+            body_store_vel(L, bodyA, a);
+            body_store_vel(L, bodyB, b);
+          }
+          __syncthreads();
+        }
+      }
+#endif
+    }
+  }
+  DrvSolveRet ret;
+  ret.jn[0] = jn[0]; ret.jn[1] = jn[1]; ret.jBias[0] = jBias[0]; ret.jBias[1] = jBias[1];
+  ret.bits = (restIn ? 1 : 0) | ((bias[0] == 0.0 && bias[1] == 0.0) ? 2 : 0);
+  return ret;
+}
+#endif
 struct ContactRet {
   uint64_t occ;
   double rew;
@@ -1082,6 +1220,16 @@ DRV_PROF(const unsigned long long T1 = __builtin_amdgcn_s_memtime();)
     maxLevel = lv > maxLevel ? lv : maxLevel;
   }
 
+#if DRV_SOLVE_OOL
+DRV_PROF(const unsigned long long T2 = __builtin_amdgcn_s_memtime();)
+  const DrvSolveRet sr = drv_prestep_solve(lane, (isCar ? 1 : 0) | (isPed ? 2 : 0), active ? 1 : 0, bodyA, bodyB, a_count, a_state, myLevel, maxLevel,
+                                           activeMask != 0ull ? 1 : 0, jn[0], jn[1], jt[0], jt[1]);
+  jn[0] = sr.jn[0]; jn[1] = sr.jn[1];
+  double jBias[2] = {sr.jBias[0], sr.jBias[1]}, bias[2];
+  bias[0] = bias[1] = (sr.bits & 2) ? 0.0 : 1.0;  // only "both zero" is asked of them below
+  const bool restIn = (sr.bits & 1) != 0;
+DRV_PROF(const unsigned long long T3 = T2, T4 = T2; const int profMode = 0;)
+#else
 DRV_PROF(const unsigned long long T2 = __builtin_amdgcn_s_memtime();)
   // ---- prestep (cpArbiterPreStep) on velocities BEFORE the friction update -------------------------------
   double nMass[2] = {0.0, 0.0}, tMass[2] = {0.0, 0.0}, bias[2] = {0.0, 0.0}, bounce[2] = {0.0, 0.0}, jBias[2] = {0.0, 0.0};
@@ -1197,6 +1345,7 @@ DRV_PROF(profMode = 4;)
 #endif
     }
   }
+#endif
   // arbiters that were active this step are NORMAL from the next step on (cpSpaceStep resets the state)
   const bool wasNormal = a_state == ARB_NORMAL;  // i.e. not a first contact in this substep
   if (active && a_state == ARB_FIRST) a_state = ARB_NORMAL;
