@@ -829,15 +829,16 @@ __device__ __noinline__ DrvSplitIO drv_solve_multilevel_split(int lane, bool act
                            geometry comes from the mailbox in LDS, not through registers held since the slot update) */
 #endif
 #if DRV_SOLVE_OOL
-struct DrvSolveRet {
-  double jn[2], jBias[2];
-  int bits;  // 1: restIn, 2: bias[0] == 0 && bias[1] == 0
-};
-__device__ __noinline__ DrvSolveRet drv_prestep_solve(int lane, int roleBits, int active_, int bodyA, int bodyB, int a_count, int a_state, int myLevel,
-                                                     int maxLevel_, int anyActive_, double jn0, double jn1, double jt0, double jt1) {
+// pk: a_state | a_count << 8 | a_age << 16 | touched << 24 | freeMe << 25 | hashSame << 26 | prevInert << 27 | skipped << 28 | slotOcc << 29 | active << 30
+__device__ __noinline__ int drv_prestep_solve(int lane, int roleBits, int pk, int a_pair, int bodyA, int bodyB, int myLevel,
+                                             int maxLevel_, int anyActive_, double jn0, double jn1, double jt0, double jt1) {
   DrvLds& L = g_L;
   DrvMailbox& M = L.u.mb;
-  const bool isCar = (roleBits & 1) != 0, isPed = (roleBits & 2) != 0, active = active_ != 0;
+  int a_state = pk & 0xFF;
+  const int a_count = (pk >> 8) & 0xFF, a_age = (pk >> 16) & 0xFF;
+  const bool touched = (pk >> 24) & 1, freeMe = (pk >> 25) & 1, hashSame = (pk >> 26) & 1, prevInert = (pk >> 27) & 1;
+  const bool skipped = (pk >> 28) & 1, slotOcc = (pk >> 29) & 1, active = (pk >> 30) & 1;
+  const bool isCar = (roleBits & 1) != 0, isPed = (roleBits & 2) != 0;
   const int maxLevel = uniform_i(maxLevel_);
   const uint64_t activeMask = uniform_i(anyActive_) ? 1ull : 0ull;
   double jn[2] = {jn0, jn1}, jt[2] = {jt0, jt1};
@@ -956,10 +957,42 @@ __device__ __noinline__ DrvSolveRet drv_prestep_solve(int lane, int roleBits, in
 #endif
     }
   }
-  DrvSolveRet ret;
-  ret.jn[0] = jn[0]; ret.jn[1] = jn[1]; ret.jBias[0] = jBias[0]; ret.jBias[1] = jBias[1];
-  ret.bits = (restIn ? 1 : 0) | ((bias[0] == 0.0 && bias[1] == 0.0) ? 2 : 0);
-  return ret;
+  // arbiters that were active this step are NORMAL from the next step on (cpSpaceStep resets the state)
+  const bool wasNormal = a_state == ARB_NORMAL;  // i.e. not a first contact in this substep
+  if (active && a_state == ARB_FIRST) a_state = ARB_NORMAL;
+  // steady: re-running this slot on identical inputs (same frozen positions, bodies at rest) reproduces this substep
+  // bit for bit: the slot record is unchanged (same contact ids, same accumulated impulses, NORMAL before and after, or
+  // ignored) and both bodies were at rest before the prestep and after the solve.  See DESIGN.md "steady replay".
+  bool steady = true;
+  if (slotOcc && !skipped) {
+    steady = touched && !freeMe && hashSame;
+    if (steady && a_state != ARB_IGNORE) {
+      steady = a_state == ARB_NORMAL && wasNormal && restIn && L.s_jn0[lane] == jn[0] && L.s_jt0[lane] == jt[0] &&
+               L.s_jn1[lane] == jn[1] && L.s_jt1[lane] == jt[1];
+      if (steady) {
+        const int i = a_pair >> 8, j = a_pair & 0xFF;
+        steady = L.vx[i] == 0.0 && L.vy[i] == 0.0 && L.w[i] == 0.0;
+        if (j < DRV_SLOT_OBST) steady = steady && L.vx[j] == 0.0 && L.vy[j] == 0.0 && L.w[j] == 0.0;
+      }
+    }
+  }
+  const bool allSteady = wave_ballot(!steady) == 0ull;
+  // inert: touched, not first contact, and (ignored | zero bias and zero accumulated impulses on every contact)
+  bool inert = true;
+  if (slotOcc && skipped) inert = prevInert;
+  else if (slotOcc) {
+    inert = touched && !freeMe &&
+            (a_state == ARB_IGNORE ||
+             (a_state == ARB_NORMAL && wasNormal && bias[0] == 0.0 && bias[1] == 0.0 && jn[0] == 0.0 && jt[0] == 0.0 &&
+              jn[1] == 0.0 && jt[1] == 0.0 && jBias[0] == 0.0 && jBias[1] == 0.0));
+  }
+  if (slotOcc) {
+    if (freeMe) L.s_pair[lane] = 0xFFFF;
+    L.s_meta[lane] = a_state | (a_count << 8) | (a_age << 16) | (steady ? (1 << 24) : 0) | (inert ? (1 << 25) : 0);
+    if (touched) { L.s_jn0[lane] = jn[0]; L.s_jt0[lane] = jt[0]; L.s_jn1[lane] = jn[1]; L.s_jt1[lane] = jt[1]; }
+  }
+  const bool allInert = wave_ballot(!inert) == 0ull;
+  return (allInert ? 2 : 0) | (allSteady ? 4 : 0);
 }
 #endif
 struct ContactRet {
@@ -1222,13 +1255,20 @@ DRV_PROF(const unsigned long long T1 = __builtin_amdgcn_s_memtime();)
 
 #if DRV_SOLVE_OOL
 DRV_PROF(const unsigned long long T2 = __builtin_amdgcn_s_memtime();)
-  const DrvSolveRet sr = drv_prestep_solve(lane, (isCar ? 1 : 0) | (isPed ? 2 : 0), active ? 1 : 0, bodyA, bodyB, a_count, a_state, myLevel, maxLevel,
-                                           activeMask != 0ull ? 1 : 0, jn[0], jn[1], jt[0], jt[1]);
-  jn[0] = sr.jn[0]; jn[1] = sr.jn[1];
-  double jBias[2] = {sr.jBias[0], sr.jBias[1]}, bias[2];
-  bias[0] = bias[1] = (sr.bits & 2) ? 0.0 : 1.0;  // only "both zero" is asked of them below
-  const bool restIn = (sr.bits & 1) != 0;
-DRV_PROF(const unsigned long long T3 = T2, T4 = T2; const int profMode = 0;)
+  // everything per-slot from here on - prestep, solve, the steady / inert verdicts and the slot record - happens inside the
+  // function: nothing of the contact cache stays live in this frame across the call
+  const int solveBits = drv_prestep_solve(lane, (isCar ? 1 : 0) | (isPed ? 2 : 0),
+                                          (a_state & 0xFF) | ((a_count & 0xFF) << 8) | ((a_age & 0xFF) << 16) | (touched ? 1 << 24 : 0) | (freeMe ? 1 << 25 : 0) |
+                                              (hashSame ? 1 << 26 : 0) | (prevInert ? 1 << 27 : 0) | (skipped ? 1 << 28 : 0) | (slotOcc ? 1 << 29 : 0) | (active ? 1 << 30 : 0),
+                                          a_pair, bodyA, bodyB, myLevel, maxLevel, activeMask != 0ull ? 1 : 0, jn[0], jn[1], jt[0], jt[1]);
+  occ &= ~freeMask;
+DRV_PROF(const unsigned long long T3 = T2, T4 = T2, T5 = __builtin_amdgcn_s_memtime(); const int profModeW = 0;)
+DRV_PROF(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* d = g_dbgp + blockIdx.x * 8; d[0] += T1 - T0; d[1] += T2 - T1; d[2] += T3 - T2; d[3] += T4 - T3; d[4] += T5 - T4; d[5] += 1ull + (light ? (1ull << 16) : 0ull); d[6] += (unsigned long long)(maxLevel + 1) + ((unsigned long long)(maxLevel + 1) << (12 * profModeW)); d[7] += (unsigned long long)nTouched + ((unsigned long long)profCand << 16); })
+  {
+    ContactRet ret;
+    ret.occ = occ; ret.rew = rew; ret.err = err | (uniform_i(solveBits) & 6);
+    return ret;
+  }
 #else
 DRV_PROF(const unsigned long long T2 = __builtin_amdgcn_s_memtime();)
   // ---- prestep (cpArbiterPreStep) on velocities BEFORE the friction update -------------------------------
@@ -1345,7 +1385,6 @@ DRV_PROF(profMode = 4;)
 #endif
     }
   }
-#endif
   // arbiters that were active this step are NORMAL from the next step on (cpSpaceStep resets the state)
   const bool wasNormal = a_state == ARB_NORMAL;  // i.e. not a first contact in this substep
   if (active && a_state == ARB_FIRST) a_state = ARB_NORMAL;
@@ -1395,6 +1434,7 @@ DRV_PROF(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* d = g_dbgp + 
   ContactRet ret;
   ret.occ = occ; ret.rew = rew; ret.err = err | (allInert ? 2 : 0) | (allSteady ? 4 : 0);
   return ret;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
