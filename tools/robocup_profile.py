@@ -3,7 +3,7 @@ Usage (GPU box):  python tools/robocup_profile.py [step]"""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-PROF = os.path.join(ROOT, "dynenv_amd", "libdynenv_hip_prof.so")
+PROF = os.environ.get("PROFILE_LIB", os.path.join(ROOT, "dynenv_amd", "libdynenv_hip_prof.so"))
 os.environ["DYNENV_HIP_LIB"] = PROF
 from dynenv_amd import build as _b
 if not os.path.exists(PROF) or any(os.path.getmtime(d) > os.path.getmtime(PROF) for d in _b.DEPS if os.path.exists(d)):
@@ -13,15 +13,16 @@ os.chdir(ROOT)
 import torch, numpy as np
 from dynenv_amd import BatchedDynEnv, DynEnvType
 STEP = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-env = BatchedDynEnv(DynEnvType.ROBO_CUP, 4096, 5, seed=42)
+NE = int(os.environ.get("PROFILE_ENVS", "4096"))
+env = BatchedDynEnv(DynEnvType.ROBO_CUP, NE, 5, seed=42)
 env.reset_flat()
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 hi = torch.tensor([5, 3, 3, 7], device="cuda")  # MultiDiscrete([5, 3, 3, 7]) RoboCupEnvironment.py:342
 for s in range(STEP):
-    a = (torch.rand((4096, 10, 4), device="cuda", generator=g) * hi).to(torch.int32)
+    a = (torch.rand((NE, 10, 4), device="cuda", generator=g) * hi).to(torch.int32)
     env.step_flat(a)
 env.debug_counters()
-d = np.loadtxt("gpurun_out/rcprof.txt")
+d = np.loadtxt("gpurun_out/rcprof.txt")[:NE]
 names = ["sequential-logic substeps", "common part (logic+position+broadphase+quiet joints)", "-", "contacts+prestep", "joint prestep", "velocity", "warm start", "solver", "post-solve", "touched", "levels", "TOTAL"]
 print("per-env cycles of one step (50 substeps): mean / p99 / max")
 for k, n in enumerate(names):
