@@ -108,14 +108,36 @@ WORKLOADS = {
 }
 
 
+def kernel_source_sha():
+    """sha256 over the kernel sources the shipped library is built from (dynenv_amd/csrc/* + include/*), first 16 hex digits:
+    stamps profiles/pmc_traffic.json, so that a traffic figure measured on other kernels is never reported for these."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in (os.path.join(ROOT, "dynenv_amd", "csrc"), os.path.join(ROOT, "include")):
+        for name in sorted(os.listdir(d)):
+            if name.endswith((".hip", ".h")):
+                with open(os.path.join(d, name), "rb") as f:
+                    h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes (profiles/pmc_traffic.json,
-    written by tools/pmc_traffic_all.sh on the GPU box; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)."""
+    written by tools/profile_round.sh on the GPU box; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  A PMC
+    pass cannot run inside this process, so the file is stamped with the hash of the kernel sources it was measured on: if
+    the sources have changed since, the figure is stale and null is reported.  -> (bytes or None, detail dict)"""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f).get(kernel + "_bytes_per_launch")
+            t = json.load(f)
     except (OSError, ValueError):
-        return None
+        return None, {"traffic_source": None}
+    sha = kernel_source_sha()
+    if t.get("kernel_source_sha16") != sha:
+        return None, {"traffic_source": "profiles/pmc_traffic.json is STALE (measured on kernel sources %s, these are %s): null"
+                                        % (t.get("kernel_source_sha16"), sha)}
+    d = t.get(kernel + "_detail", {})
+    return t.get(kernel + "_bytes_per_launch"), {"traffic_source": "profiles/pmc_traffic.json (kernel sources %s)" % sha,
+                                                 "traffic_whole_step": d.get("step_bytes_all_kernels")}
 
 
 def episode_leg(torch, device, workload, E, seed, n_players=None):
@@ -146,16 +168,76 @@ def episode_leg(torch, device, workload, E, seed, n_players=None):
     k1.record()
     torch.cuda.synchronize(device)
     ms = k0.elapsed_time(k1) / ep_steps
+    # the named kernel's OWN launch duration: a second pass over the same episode (same seed, same actions) with the library
+    # recording HIP events on the launch stream right before and after that kernel (dynenv_set_step_events), a fresh event
+    # triple per step and no host wait in between, so the launches stay back to back as in the pass above and the Partial
+    # paths' trailing kernels are not counted
+    import ctypes as C
+    evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(ep_steps)]
+    for tr in evs:
+        for ev in tr:
+            ev.record()  # creates the hipEvent_t
+    env.reset_flat()
+    torch.cuda.synchronize(device)
+    for i in range(ep_steps):
+        eb, em, ee = evs[i]
+        env._lib.dynenv_set_step_events(env._h, C.c_void_p(eb.cuda_event), C.c_void_p(em.cuda_event), C.c_void_p(ee.cuda_event))
+        env.step_flat(pool[i & 15], auto_reset=False)
+    env._lib.dynenv_set_step_events(env._h, None, None, None)
+    torch.cuda.synchronize(device)
+    kern_ms = sum(eb.elapsed_time(em) for eb, em, ee in evs) / ep_steps
+    step_ms = sum(eb.elapsed_time(ee) for eb, em, ee in evs) / ep_steps
     err = env.error_flags()
     env.close()
     out = {"workload": workload, "reference": ref, "envs": E, "n_agents": A, "steps": ep_steps, "ms_per_step": ms,
            "value": E * A / (ms * 1e-3), "unit": "agent-steps/s", "kernel_error_flags": err}
     if A == 10:
-        achieved = b_alg * E / (ms * 1e-3) / 1e9
+        achieved = b_alg * E / (kern_ms * 1e-3) / 1e9
+        traffic, tdetail = measured_traffic(kernel)
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": measured_traffic(kernel), "kernel": kernel, "launch_ms": ms, "alg_bytes_per_env_step": b_alg,
-                           "env_steps_per_launch": E}
+                           "traffic": traffic, "kernel": kernel, "launch_ms": kern_ms, "step_ms_all_kernels": step_ms,
+                           "step_ms_back_to_back": ms, "alg_bytes_per_env_step": b_alg, "env_steps_per_launch": E}
+        out["roofline"].update(tdetail)
     return out
+
+
+def batch_leg(torch, device, E, K, seed, steps=600):
+    """Throughput against batch size / sub-batches (never the headline): Driving nPlayers=10 Full over one whole episode with
+    E environments as K handles of E / K (env_id_offset = k E / K: the same global environments, results identical to one
+    handle - tools/split_batch_probe.py checks the digests) on K streams, stepped round-robin.  A launch lasts as long as its
+    slowest environment and 4096 environments are exactly one residency round of the chip (16 waves per CU), so a bigger
+    batch backfills the tail of a launch with later blocks; K > 1 overlaps the tails of the sub-batches."""
+    from dynenv_amd import BatchedDynEnv, DynEnvType
+    A, D, n = 10, 232, E // K
+    obs = torch.zeros((E, 1, A, D), dtype=torch.float32, device=device)
+    rew = torch.zeros((E, A), dtype=torch.float64, device=device)
+    don = torch.zeros((E,), dtype=torch.uint8, device=device)
+    envs = [BatchedDynEnv(DynEnvType.DRIVE, n, 10, seed=seed, device=device, env_id_offset=k * n,
+                          out_buffers=(obs[k * n:(k + 1) * n], rew[k * n:(k + 1) * n], don[k * n:(k + 1) * n])) for k in range(K)]
+    streams = [torch.cuda.Stream(device=device) for _ in range(K)] if K > 1 else [torch.cuda.current_stream(device)]
+    g = torch.Generator(device=device).manual_seed(4321)
+    pool = [torch.randint(0, 3, (E, A, 2), generator=g, device=device, dtype=torch.int32) for _ in range(16)]
+    sub = [[p[k * n:(k + 1) * n] for k in range(K)] for p in pool]
+
+    def episode():
+        for k in range(K):
+            with torch.cuda.stream(streams[k]):
+                envs[k].reset_flat()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            for k in range(K):
+                with torch.cuda.stream(streams[k]):
+                    envs[k].step_flat(sub[i & 15][k], auto_reset=False)
+        torch.cuda.synchronize(device)
+        return time.perf_counter() - t0
+    episode()
+    dt = episode()
+    for e in envs:
+        e.close()
+    del obs, rew, don, pool, sub
+    return {"envs": E, "handles_on_streams": K, "steps": steps, "ms_per_step": dt / steps * 1e3, "value": E * A * steps / dt,
+            "unit": "agent-steps/s"}
 
 
 def plumbing_leg(torch, device, seed):
@@ -360,6 +442,9 @@ def main():
         if world == 1 and not args.no_extra_legs and gather is None:
             env.close()
             out["other_configs"] = [episode_leg(torch, device, w, E, args.seed) for w in WORKLOADS if w != args.workload]
+            if args.workload == "driving":  # what the idle tail of a 4096-environment launch is worth (DESIGN.md "Batch size")
+                out["throughput_vs_batch"] = [batch_leg(torch, device, e_, k_, args.seed)
+                                              for e_, k_ in ((E, 2), (2 * E, 1), (4 * E, 1), (8 * E, 1))]
             out["plumbing_config0"] = plumbing_leg(torch, device, args.seed)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(E, n_players, A, args.seed, robocup, partial=partial)

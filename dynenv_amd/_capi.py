@@ -76,7 +76,8 @@ EXPORTS = ["dynenv_abi_version", "dynenv_last_error", "dynenv_create", "dynenv_d
            "dynenv_error_flags", "dynenv_debug_counters", "dynenv_arrange_scratch_ints", "dynenv_arrange_plan",
            "dynenv_arrange_gather", "dynenv_arrange_scatter", "dynenv_arrange_pad", "dynenv_checkpoint_size",
            "dynenv_checkpoint_save", "dynenv_checkpoint_load", "dynenv_obs_pack", "dynenv_obs_unpack", "dynenv_obs_unpack_ranks",
-           "dynenv_obs_pack_peers", "dynenv_obs_unpack_peers_ranks", "dynenv_step_head", "dynenv_full_obs", "dynenv_full_obs_dim"]
+           "dynenv_obs_pack_peers", "dynenv_obs_unpack_peers_ranks", "dynenv_step_head", "dynenv_full_obs", "dynenv_full_obs_dim",
+           "dynenv_global_state", "dynenv_global_state_dim", "dynenv_set_step_events"]
 
 ARR_MAX_TYPES = 4
 ARR_COUNT_CONST, ARR_COUNT_ENV, ARR_COUNT_ROW = 0, 1, 2
@@ -121,6 +122,9 @@ def load():
     lib.dynenv_step_head.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.dynenv_full_obs.argtypes = [vp, vp, vp]
     lib.dynenv_full_obs_dim.argtypes = [vp]
+    lib.dynenv_global_state.argtypes = [vp, vp, vp]
+    lib.dynenv_global_state_dim.argtypes = [vp]
+    lib.dynenv_set_step_events.argtypes = [vp, vp, vp, vp]
     i32 = C.c_int32
     lib.dynenv_arrange_scratch_ints.argtypes = [i32, i32, i32, i32]
     lib.dynenv_arrange_scratch_ints.restype = C.c_int64

@@ -7,7 +7,7 @@ ROOT = os.path.dirname(PKG)
 LIB = os.path.join(PKG, "libdynenv_hip.so")
 SRC = os.path.join(PKG, "csrc", "dynenv_capi.hip")
 DEPS = [os.path.join(PKG, "csrc", f) for f in
-        ("dynenv_capi.hip", "driving_kernels.hip", "driving_partial.hip", "robocup_kernels.hip", "robocup_rpl.hip", "robocup_partial.hip", "arranger_kernels.hip", "driving_dev.h",
+        ("dynenv_capi.hip", "driving_kernels.hip", "driving_partial.hip", "robocup_kernels.hip", "robocup_partial.hip", "arranger_kernels.hip", "driving_dev.h",
          "robocup_dev.h", "dev_common.h")] + \
        [os.path.join(ROOT, "include", f) for f in ("dynenv.h", "dynenv_math.h")]
 

@@ -712,123 +712,14 @@ DE_DEV void body_store_bias(DrvLds& L, int idx, const BodyV& b) {
 DRV_PROF(__device__ unsigned long long g_dbgw[4096 * 12];)
 DRV_PROF(__device__ unsigned long long g_dbgp[4096 * 8];)
 DRV_PROF(__device__ unsigned long long g_dbgr[16];)
-#ifndef DRV_SPLIT_BIAS
-#define DRV_SPLIT_BIAS 0 /* 1: multi-level solves with live velocities run an arbiter's bias impulses on lane slot + 32 beside its velocity
-                            impulses (what RC_SPLIT_BIAS does for RoboCup).  Bit-identical, and measured SLOWER here (0.252 against 0.245 ms per
-                            step, inline 0.262): the rare call costs drv_contact_path callee-saved registers on every one of its calls */
-#endif
 // Which half of a substep is out of line.  DRV_INVERT = 1 (default): the COMMON part (game logic, position update, broadphase:
 // drv_light_substep, 88 VGPRs, nothing to save) is the function and the contact path is inlined into the kernel, which as the
 // outermost frame never saves a register: the per-call save / restore of 47 callee-saved VGPRs that the round-1 layout
 // (DRV_INVERT = 0: contact path out of line) paid - 3/4 of that kernel's HBM traffic - is gone (236 -> 76 MB per launch).
-#ifndef DRV_INVERT
-#define DRV_INVERT 1
-#endif
 #ifndef DRV_CONTACT_INLINE
-#if DRV_INVERT
 #define DRV_CONTACT_INLINE __forceinline__
-#else
-#define DRV_CONTACT_INLINE __noinline__
-#endif
-#endif
-#if DRV_SPLIT_BIAS
-struct DrvSplitIO {
-  V2 n, r1[2], r2[2];
-  double nMass[2], bias[2], bounce[2], jn[2], jt[2], jBias[2];
-};
-// The 10 iterations of a multi-level solve with live velocities, out of line (its registers are only paid for when it runs).
-__device__ __noinline__ DrvSplitIO drv_solve_multilevel_split(int lane, bool active, int bodyA, int bodyB, int a_count, int myLevel, int maxLevel, DrvSplitIO io) {
-  DrvLds& L = g_L;
-  const V2 n = io.n;
-  V2 r1[2] = {io.r1[0], io.r1[1]}, r2[2] = {io.r2[0], io.r2[1]};
-  double nMass[2] = {io.nMass[0], io.nMass[1]}, bias[2] = {io.bias[0], io.bias[1]}, bounce[2] = {io.bounce[0], io.bounce[1]};
-  double jn[2] = {io.jn[0], io.jn[1]}, jt[2] = {io.jt[0], io.jt[1]}, jBias[2] = {io.jBias[0], io.jBias[1]};
-  BodyV a, b;
-  if (active) { body_load(L, bodyA, a); body_load(L, bodyB, b); }
-      // The two impulse chains of a contact - velocity (v, w, jn) and position correction (v_bias, w_bias, jBias) - touch
-      // disjoint fields and are the same instruction sequence up to the impulse vector.  A lone wave pays per instruction,
-      // not per lane: the bias chain of slot s runs on lane s + 32, which takes the arbiter's constants over the lanes.
-      static_assert(DRV_NS <= 32, "bias lanes are slot lanes + 32");
-      const bool biasCand = lane >= 32 && lane < 32 + DRV_NS;
-      const int srcLane = biasCand ? lane - 32 : lane;
-      const int code = __shfl(active ? (bodyA | (bodyB << 8) | (a_count << 16) | (myLevel << 24)) : -1, srcLane);
-      const bool biasLane = biasCand && code >= 0;
-      V2 sn = v2(__shfl(n.x, srcLane), __shfl(n.y, srcLane)), sr1[2], sr2[2];
-      double sMass[2], tgt[2], acc[2];
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        sr1[c] = v2(__shfl(r1[c].x, srcLane), __shfl(r1[c].y, srcLane));
-        sr2[c] = v2(__shfl(r2[c].x, srcLane), __shfl(r2[c].y, srcLane));
-        sMass[c] = __shfl(nMass[c], srcLane);
-        // jbn = (bias - vbn) nMass in the velocity chain's form -((-bias) + vbn) nMass: the two can only differ in the sign of
-        // a zero jbn, which jBias = max(jBias + jbn, 0) with jBias >= +0 absorbs
-        const double sb = __shfl(bias[c], srcLane);
-        tgt[c] = biasLane ? -sb : bounce[c];
-        acc[c] = biasLane ? 0.0 : jn[c];
-      }
-      int sA = bodyA, sB = bodyB, sCount = a_count, sLevel = myLevel;
-      if (biasLane) { sA = code & 0xFF; sB = (code >> 8) & 0xFF; sCount = (code >> 16) & 0xFF; sLevel = (code >> 24) & 0xFF; }
-      const bool solveMe = active || biasLane;
-      const bool aDyn = sA < DRV_SLOT_OBST, bDyn = sB < DRV_SLOT_OBST;
-      double* const fX = biasLane ? L.vbx : L.vx;
-      double* const fY = biasLane ? L.vby : L.vy;
-      double* const fW = biasLane ? L.wb : L.w;
-      if (biasLane) {
-        a.minv = aDyn ? L.minv[sA] : 0.0; a.iinv = aDyn ? L.iinv[sA] : 0.0;
-        b.minv = bDyn ? L.minv[sB] : 0.0; b.iinv = bDyn ? L.iinv[sB] : 0.0;
-        a.v = b.v = v2(0.0, 0.0); a.w = b.w = 0.0;
-      }
-      for (int iter = 0; iter < 10; ++iter) {
-        for (int lv = 0; lv <= maxLevel; ++lv) {
-          if (solveMe && sLevel == lv) {
-            if (aDyn) { a.v = v2(fX[sA], fY[sA]); a.w = fW[sA]; }
-            if (bDyn) { b.v = v2(fX[sB], fY[sB]); b.w = fW[sB]; }
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-              if (c < sCount) {
-                if (!biasLane) {  // the velocity half of a resting contact is an exact no-op (see arb_apply_impulse)
-                  const long long zbits = __double_as_longlong(a.v.x) | __double_as_longlong(a.v.y) | __double_as_longlong(a.w) |
-                                          __double_as_longlong(b.v.x) | __double_as_longlong(b.v.y) | __double_as_longlong(b.w) |
-                                          __double_as_longlong(acc[c]) | __double_as_longlong(jt[c]);
-                  if (zbits == 0ll && tgt[c] == 0.0) continue;
-                }
-                const V2 vr = relative_velocity(a, b, sr1[c], sr2[c]);
-                const double vrn = vdot(vr, sn);
-                const double jnn = -(tgt[c] + vrn) * sMass[c];
-                const double jnOld = acc[c];
-                acc[c] = fmax_cp(jnOld + jnn, 0.0);
-                const double dj = acc[c] - jnOld;
-                const V2 jr = vrotate(sn, v2(dj, 0.0));  // (friction: see arb_apply_impulse)
-                const V2 jl = vmul(sn, dj);
-                const V2 jj = biasLane ? jl : jr;
-                apply_impulse(a, vneg(jj), sr1[c]);
-                apply_impulse(b, jj, sr2[c]);
-              }
-            }
-            if (aDyn) { fX[sA] = a.v.x; fY[sA] = a.v.y; fW[sA] = a.w; }
-            if (bDyn) { fX[sB] = b.v.x; fY[sB] = b.v.y; fW[sB] = b.w; }
-          }
-          __syncthreads();
-        }
-      }
-      {  // accumulated impulses back to the slot lanes: jn from their own chain, jBias from lane + 32
-        const int back = lane < DRV_NS ? lane + 32 : lane;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const double other = __shfl(acc[c], back);
-          if (active) { jn[c] = acc[c]; jBias[c] = other; }
-        }
-      }
-  io.jn[0] = jn[0]; io.jn[1] = jn[1]; io.jBias[0] = jBias[0]; io.jBias[1] = jBias[1];
-  return io;
-}
 #endif
 
-#ifndef DRV_SOLVE_OOL
-#define DRV_SOLVE_OOL 1 /* prestep + velocity update + solve as a function of their own (fresh register allocation; the per-slot
-                           geometry comes from the mailbox in LDS, not through registers held since the slot update) */
-#endif
-#if DRV_SOLVE_OOL
 // pk: a_state | a_count << 8 | a_age << 16 | touched << 24 | freeMe << 25 | hashSame << 26 | prevInert << 27 | skipped << 28 | slotOcc << 29 | active << 30
 __device__ __noinline__ int drv_prestep_solve(int lane, int roleBits, int pk, int a_pair, int bodyA, int bodyB, int myLevel,
                                              int maxLevel_, int anyActive_, double jn0, double jn1, double jt0, double jt1) {
@@ -933,15 +824,6 @@ __device__ __noinline__ int drv_prestep_solve(int lane, int roleBits, int pk, in
         }
       }
     } else {
-#if DRV_SPLIT_BIAS
-      {
-        DrvSplitIO io;
-        io.n = n; io.r1[0] = r1[0]; io.r1[1] = r1[1]; io.r2[0] = r2[0]; io.r2[1] = r2[1];
-        for (int c = 0; c < 2; ++c) { io.nMass[c] = nMass[c]; io.bias[c] = bias[c]; io.bounce[c] = bounce[c]; io.jn[c] = jn[c]; io.jt[c] = jt[c]; io.jBias[c] = jBias[c]; }
-        io = drv_solve_multilevel_split(lane, active, bodyA, bodyB, a_count, myLevel, maxLevel, io);
-        for (int c = 0; c < 2; ++c) { jn[c] = io.jn[c]; jBias[c] = io.jBias[c]; }
-      }
-#else
       for (int iter = 0; iter < 10; ++iter) {
         for (int lv = 0; lv <= maxLevel; ++lv) {
           if (active && myLevel == lv) {
@@ -954,7 +836,6 @@ __device__ __noinline__ int drv_prestep_solve(int lane, int roleBits, int pk, in
           __syncthreads();
         }
       }
-#endif
     }
   }
   // arbiters that were active this step are NORMAL from the next step on (cpSpaceStep resets the state)
@@ -994,7 +875,6 @@ __device__ __noinline__ int drv_prestep_solve(int lane, int roleBits, int pk, in
   const bool allInert = wave_ballot(!inert) == 0ull;
   return (allInert ? 2 : 0) | (allSteady ? 4 : 0);
 }
-#endif
 struct ContactRet {
   uint64_t occ;
   double rew;
@@ -1253,7 +1133,6 @@ DRV_PROF(const unsigned long long T1 = __builtin_amdgcn_s_memtime();)
     maxLevel = lv > maxLevel ? lv : maxLevel;
   }
 
-#if DRV_SOLVE_OOL
 DRV_PROF(const unsigned long long T2 = __builtin_amdgcn_s_memtime();)
   // everything per-slot from here on - prestep, solve, the steady / inert verdicts and the slot record - happens inside the
   // function: nothing of the contact cache stays live in this frame across the call
@@ -1269,172 +1148,6 @@ DRV_PROF(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* d = g_dbgp + 
     ret.occ = occ; ret.rew = rew; ret.err = err | (uniform_i(solveBits) & 6);
     return ret;
   }
-#else
-DRV_PROF(const unsigned long long T2 = __builtin_amdgcn_s_memtime();)
-  // ---- prestep (cpArbiterPreStep) on velocities BEFORE the friction update -------------------------------
-  double nMass[2] = {0.0, 0.0}, tMass[2] = {0.0, 0.0}, bias[2] = {0.0, 0.0}, bounce[2] = {0.0, 0.0}, jBias[2] = {0.0, 0.0};
-  const double arb_e = 0.05 * 0.05, arb_u = 0.0 * 0.0;
-  bool restIn = false;  // both bodies exactly at rest when the arbiter was prestepped
-  if (active) {
-    BodyV a, b;
-    body_load(L, bodyA, a);
-    body_load(L, bodyB, b);
-    restIn = a.v.x == 0.0 && a.v.y == 0.0 && a.w == 0.0 && b.v.x == 0.0 && b.v.y == 0.0 && b.w == 0.0;
-    V2 body_delta = vsub(b.p, a.p);
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      if (c < a_count) {
-        nMass[c] = 1.0 / (k_scalar_body(a, r1[c], n) + k_scalar_body(b, r2[c], n));
-        double dist = vdot(vadd(vsub(r2[c], r1[c]), body_delta), n);  // (tMass is not needed: see arb_apply_impulse)
-        bias[c] = -DE_CONTACT_BIAS_COEF * fmin_cp(0.0, dist + DE_COLLISION_SLOP) / DE_DT;
-        jBias[c] = 0.0;
-        bounce[c] = vdot(relative_velocity(a, b, r1[c], r2[c]), n) * arb_e;
-      }
-    }
-  }
-  __syncthreads();
-
-DRV_PROF(const unsigned long long T3 = __builtin_amdgcn_s_memtime();)
-  // ---- velocity update (velocity_func: friction_* or default) -------------------------------------------
-  velocity_update(L, lane, isCar, isPed);
-DRV_PROF(unsigned long long T4 = __builtin_amdgcn_s_memtime(); int profMode = 0;)
-  if (activeMask && maxLevel == 0) {
-    // No two active arbiters share a dynamic body: each lane keeps its two bodies in registers through the warm start
-    // and all 10 iterations, with one LDS load and one store (same arithmetic, no LDS round trip per iteration).
-    __syncthreads();
-    if (active) {
-      BodyV a, b;
-      body_load(L, bodyA, a);
-      body_load(L, bodyB, b);
-      if (a_state != ARB_FIRST) arb_warm_start(a, b, n, r1, r2, jn, jt, a_count);
-DRV_PROF(T4 = __builtin_amdgcn_s_memtime();)
-      if (wave_ballot(!arb_is_bias_only(a, b, jn, jt, bounce, a_count)) == 0ull) {  // all resting contacts: bias half only
-DRV_PROF(profMode = 1;)
-#pragma unroll 1
-        for (int iter = 0; iter < 10; ++iter) arb_apply_bias_only(a, b, n, r1, r2, nMass, bias, jBias, a_count);
-      } else {
-DRV_PROF(profMode = 2;)
-#pragma unroll 1
-        for (int iter = 0; iter < 10; ++iter) arb_apply_impulse(a, b, n, r1, r2, nMass, tMass, bias, bounce, jBias, jn, jt, a_count, arb_u);
-      }
-      body_store_vel(L, bodyA, a);
-      body_store_vel(L, bodyB, b);
-    }
-    __syncthreads();
-  } else if (activeMask) {
-    __syncthreads();
-    // ---- warm start (cpArbiterApplyCachedImpulse; skipped on first contact), level by level ------------
-    for (int lv = 0; lv <= maxLevel; ++lv) {
-      if (active && myLevel == lv && a_state != ARB_FIRST) {
-        BodyV a, b;
-        body_load(L, bodyA, a);
-        body_load(L, bodyB, b);
-        arb_warm_start(a, b, n, r1, r2, jn, jt, a_count);
-        body_store_vel(L, bodyA, a);
-        body_store_vel(L, bodyB, b);
-      }
-      __syncthreads();
-    }
-DRV_PROF(T4 = __builtin_amdgcn_s_memtime();)
-    // ---- 10 sequential-impulse iterations (cpArbiterApplyImpulse) ---------------------------------------
-    BodyV a, b;
-    bool biasOnly = true;
-    if (active) {  // statics stay all-zero; p, minv, iinv are invariant
-      body_load(L, bodyA, a); body_load(L, bodyB, b);
-      biasOnly = arb_is_bias_only(a, b, jn, jt, bounce, a_count);
-    }
-    if (wave_ballot(!biasOnly) == 0ull) {
-      // every active arbiter is a resting contact being pushed out of penetration (the pile-ups that make up the launch's
-      // tail): only bias velocities move, through LDS, level by level
-DRV_PROF(profMode = 3;)
-      for (int iter = 0; iter < 10; ++iter) {
-        for (int lv = 0; lv <= maxLevel; ++lv) {
-          if (active && myLevel == lv) {
-            body_load_bias(L, bodyA, a);
-            body_load_bias(L, bodyB, b);
-            arb_apply_bias_only(a, b, n, r1, r2, nMass, bias, jBias, a_count);
-            body_store_bias(L, bodyA, a);
-            body_store_bias(L, bodyB, b);
-          }
-          __syncthreads();
-        }
-      }
-    } else {
-DRV_PROF(profMode = 4;)
-#if DRV_SPLIT_BIAS
-      {
-        DrvSplitIO io;
-        io.n = n; io.r1[0] = r1[0]; io.r1[1] = r1[1]; io.r2[0] = r2[0]; io.r2[1] = r2[1];
-        for (int c = 0; c < 2; ++c) { io.nMass[c] = nMass[c]; io.bias[c] = bias[c]; io.bounce[c] = bounce[c]; io.jn[c] = jn[c]; io.jt[c] = jt[c]; io.jBias[c] = jBias[c]; }
-        io = drv_solve_multilevel_split(lane, active, bodyA, bodyB, a_count, myLevel, maxLevel, io);
-        for (int c = 0; c < 2; ++c) { jn[c] = io.jn[c]; jBias[c] = io.jBias[c]; }
-      }
-#else
-      for (int iter = 0; iter < 10; ++iter) {
-        for (int lv = 0; lv <= maxLevel; ++lv) {
-          if (active && myLevel == lv) {
-            body_load_vel(L, bodyA, a);
-            body_load_vel(L, bodyB, b);
-            arb_apply_impulse(a, b, n, r1, r2, nMass, tMass, bias, bounce, jBias, jn, jt, a_count, arb_u);
-            body_store_vel(L, bodyA, a);
-            body_store_vel(L, bodyB, b);
-          }
-          __syncthreads();
-        }
-      }
-#endif
-    }
-  }
-  // arbiters that were active this step are NORMAL from the next step on (cpSpaceStep resets the state)
-  const bool wasNormal = a_state == ARB_NORMAL;  // i.e. not a first contact in this substep
-  if (active && a_state == ARB_FIRST) a_state = ARB_NORMAL;
-  // steady: re-running this slot on identical inputs (same frozen positions, bodies at rest) reproduces this substep
-  // bit for bit: the slot record is unchanged (same contact ids, same accumulated impulses, NORMAL before and after, or
-  // ignored) and both bodies were at rest before the prestep and after the solve.  See DESIGN.md "steady replay".
-  bool steady = true;
-  if (slotOcc && !skipped) {
-    steady = touched && !freeMe && hashSame;
-    if (steady && a_state != ARB_IGNORE) {
-      steady = a_state == ARB_NORMAL && wasNormal && restIn && L.s_jn0[lane] == jn[0] && L.s_jt0[lane] == jt[0] &&
-               L.s_jn1[lane] == jn[1] && L.s_jt1[lane] == jt[1];
-      if (steady) {
-        const int i = a_pair >> 8, j = a_pair & 0xFF;
-        steady = L.vx[i] == 0.0 && L.vy[i] == 0.0 && L.w[i] == 0.0;
-        if (j < DRV_SLOT_OBST) steady = steady && L.vx[j] == 0.0 && L.vy[j] == 0.0 && L.w[j] == 0.0;
-      }
-    }
-  }
-  const bool allSteady = wave_ballot(!steady) == 0ull;
-  // inert: touched, not first contact, and (ignored | zero bias and zero accumulated impulses on every contact)
-  bool inert = true;
-  if (slotOcc && skipped) inert = prevInert;
-  else if (slotOcc) {
-    inert = touched && !freeMe &&
-            (a_state == ARB_IGNORE ||
-             (a_state == ARB_NORMAL && wasNormal && bias[0] == 0.0 && bias[1] == 0.0 && jn[0] == 0.0 && jt[0] == 0.0 &&
-              jn[1] == 0.0 && jt[1] == 0.0 && jBias[0] == 0.0 && jBias[1] == 0.0));
-  }
-DRV_PROF(if (active) { const int pi = a_pair >> 8, pj = a_pair & 0xFF; const bool fz = (L.still[pi] & 2) && (pj >= DRV_SLOT_OBST || (L.still[pj] & 2));
-  atomicAdd(&g_dbgr[13], 1ull); if (fz && steady) atomicAdd(&g_dbgr[14], 1ull); if (maxLevel > 0) { atomicAdd(&g_dbgr[15], 1ull); if (fz && steady) atomicAdd(&g_dbgr[12], 1ull); } })
-DRV_PROF(if (slotOcc) { int why = 0; const int pi = a_pair >> 8, pj = a_pair & 0xFF;
-  if (steady) why = 0; else if (!touched) why = 1; else if (freeMe) why = 2; else if (!hashSame) why = 3; else if (a_state != ARB_NORMAL || !wasNormal) why = 4;
-  else if (!restIn) why = 5; else if (!(L.s_jn0[lane] == jn[0] && L.s_jt0[lane] == jt[0] && L.s_jn1[lane] == jn[1] && L.s_jt1[lane] == jt[1])) why = 6; else why = 7;
-  atomicAdd(&g_dbgr[why], 1ull);
-  if (why == 6) { if (L.s_jn0[lane] == 0.0 && L.s_jn1[lane] == 0.0) atomicAdd(&g_dbgr[8], 1ull); if (pj >= DRV_SLOT_PED && pj < DRV_SLOT_OBST) atomicAdd(&g_dbgr[9], 1ull); else if (pj < DRV_SLOT_PED) atomicAdd(&g_dbgr[10], 1ull); else atomicAdd(&g_dbgr[11], 1ull); } })
-  if (slotOcc) {
-    if (freeMe) L.s_pair[lane] = 0xFFFF;
-    L.s_meta[lane] = a_state | (a_count << 8) | (a_age << 16) | (steady ? (1 << 24) : 0) | (inert ? (1 << 25) : 0);
-    if (touched) { L.s_jn0[lane] = jn[0]; L.s_jt0[lane] = jt[0]; L.s_jn1[lane] = jn[1]; L.s_jt1[lane] = jt[1]; }
-  }
-  occ &= ~freeMask;
-  const bool allInert = wave_ballot(!inert) == 0ull;
-DRV_PROF(const unsigned long long T5 = __builtin_amdgcn_s_memtime();)
-DRV_PROF(const int profModeW = __ballot(profMode == 1) ? 1 : __ballot(profMode == 2) ? 2 : __ballot(profMode == 3) ? 3 : __ballot(profMode == 4) ? 4 : 0;)
-DRV_PROF(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* d = g_dbgp + blockIdx.x * 8; d[0] += T1 - T0; d[1] += T2 - T1; d[2] += T3 - T2; d[3] += T4 - T3; d[4] += T5 - T4; d[5] += 1ull + (light ? (1ull << 16) : 0ull); d[6] += (unsigned long long)(maxLevel + 1) + ((unsigned long long)(maxLevel + 1) << (12 * profModeW)); d[7] += (unsigned long long)nTouched + ((unsigned long long)profCand << 16); })
-  ContactRet ret;
-  ret.occ = occ; ret.rew = rew; ret.err = err | (allInert ? 2 : 0) | (allSteady ? 4 : 0);
-  return ret;
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1448,7 +1161,6 @@ __device__ __noinline__ void drv_partial_obs_fused(const DrvState& S, int e, int
 #ifndef DRV_FUSED_AGENTS
 #define DRV_FUSED_AGENTS 7 /* agent passes a light environment runs in the step launch */
 #endif
-#if DRV_INVERT
 struct DrvLightRet {
   double rew, posrew;
   int cand, dirty, bits;
@@ -1655,7 +1367,6 @@ __device__ __noinline__ DrvLightRet drv_light_substep(int it_, int lane, int A_,
   ret.rew = rew; ret.posrew = posrew; ret.cand = cand; ret.dirty = dirty; ret.bits = (candMoving ? 1 : 0) | (removed ? 2 : 0);
   return ret;
 }
-#endif
 template <bool PARTIAL>
 DE_DEV void drv_step_body(const DrvState& S, const int* __restrict__ actions, float* __restrict__ obs, double* __restrict__ rewards,
                           uint8_t* __restrict__ dones, float* __restrict__ pobs, int pvNoise, double pvMagn) {
@@ -1705,7 +1416,6 @@ DRV_PROF(const unsigned long long K0 = __builtin_amdgcn_s_memtime(); unsigned lo
   for (int it = 0; it < 10; ++it) {
 DRV_PROF(const unsigned long long A0 = __builtin_amdgcn_s_memtime();)
     // ======== phase 1a: car game logic (processAction at substep 0, tick) ===================================
-#if DRV_INVERT
     const DrvLightRet lr = drv_light_substep(it, lane, A, nPed, nObst, elapsed, act0, act1, lastCand, (uint32_t)S.seed, (uint32_t)(S.seed >> 32), genv, episode,
                                              (vbValid ? 1 : 0) | (aabbValid ? 2 : 0), rew, posrew);
     rew = lr.rew; posrew = lr.posrew;
@@ -1713,194 +1423,6 @@ DRV_PROF(const unsigned long long A0 = __builtin_amdgcn_s_memtime();)
     const bool candMoving = (lr.bits & 1) != 0, removed = (lr.bits & 2) != 0;
     aabbValid = true;
 DRV_PROF(const unsigned long long A1 = A0;)
-#else
-    bool turned = false;  // Car.turn rotated the body in place: geometry changed even if every velocity is zero
-    if (isCar) {
-      int f = L.flags[lane];
-      const double px = L.px[lane], py = L.py[lane];
-      double vx = L.vx[lane], vy = L.vy[lane];
-      if (it == 0) {  // processAction :357-373 -> Car.accelerate (Car.py:55-94), Car.turn (Car.py:97-108)
-        const int acc = act0 - 1, steer = (act1 - 1) * 2;
-        if (!CF_FIN(f)) {
-          double dirx = L.dirx[lane], diry = L.diry[lane];
-          double power = (double)acc;
-          double moveDir = vx * dirx + vy * diry;
-          bool skip = false;
-          if (acc < 0) power = (double)acc * 0.75;
-          if (acc == 0) power = (moveDir == 0.0) ? 0.0 : (moveDir > 0.0 ? -2.0 : 2.0);
-          else if (acc < 0 && moveDir > 0.0) skip = true;
-          else if (acc > 0 && moveDir < 0.0) skip = true;
-          if (!skip) {
-            const double cs = L.rc[lane], sn = L.rs[lane];  // = dm_sincos(ang): the cache is refreshed on every change
-            vx = vx + L.cpower[lane] * power * cs;
-            vy = vy + L.cpower[lane] * power * sn;
-            if (acc == 0 && (vx * dirx + vy * diry) * moveDir < 0.0) { vx = 0.0; vy = 0.0; }
-          }
-          if (steer != 0) {
-            const double rot = (double)steer * (DM_PI / 180.0);
-            const double ang = L.ang[lane] + rot;
-            const DevSC rsc = dev_sincos(rot);
-            const double sn = rsc.s, cs = rsc.c;
-            const double dx = dirx * cs - diry * sn, dy = dirx * sn + diry * cs;
-            L.dirx[lane] = dx; L.diry[lane] = dy;
-            const double nvx = vx * cs - vy * sn, nvy = vx * sn + vy * cs;
-            vx = nvx; vy = nvy;
-            L.ang[lane] = ang;
-            car_refresh_rot(L, lane, ang);
-            turned = true;
-          }
-        }
-      }
-      // tick :376-426
-      const V2 pos = v2(px, py);
-      int lp = LP_OffRoad;
-      {
-        int rp = road_pos<0>(pos, L.cosRel0[lane]);
-        if (rp < lp) lp = rp;
-        rp = road_pos<1>(pos, L.cosRel1[lane]);
-        if (rp < lp) lp = rp;
-      }
-      const double dnow = vlen(vsub(pos, v2(L.goalx[lane], L.goaly[lane])));
-      const double diff = L.dprev[lane] - dnow;
-      if (!CF_FIN(f)) { const double d50 = diff / 50.0; rew += d50; posrew += dm_max(0.0, d50); }
-      L.prevx[lane] = px; L.prevy[lane] = py; L.dprev[lane] = dnow;
-      if (lp >= LP_OverRoad) {
-        if (!CF_FIN(f)) {
-          if (lp == LP_OverRoad && dnow < 100.0) {
-            lp = LP_AtGoal;
-            f |= (1 << 4) | (1 << 6);  // finished, friction_car_crashed
-            rew += (double)(DRV_MAX_TIME - elapsed) / 100.0;
-            posrew += (double)(DRV_MAX_TIME - elapsed) / 100.0;
-          } else {
-            f |= CF_CRASH_BITS;
-            rew -= vlen(v2(vx, vy)) / 5.0;
-          }
-        }
-      } else if (lp == LP_InOpposingLane) {
-        if (!CF_FIN(f)) rew -= vlen(v2(vx, vy)) / 10000.0;
-      }
-      f = CF_SET_LP(f, lp);
-      if (px >= DRV_W + 50.0 || px <= -50.0 || py >= DRV_H + 50.0 || py <= -50.0) { vx = 0.0; vy = 0.0; }  // prevPos == pos here
-      L.flags[lane] = f;
-      L.vx[lane] = vx; L.vy[lane] = vy;
-    } else if (isPed) {
-      // ======== phase 1b: pedestrian FSM (move :429-506) ====================================================
-      const int f = L.flags[lane];
-      if (!PF_DEAD(f)) {
-        double vx = L.vx[lane], vy = L.vy[lane];
-        int moving = L.moving[lane];
-        int crossing = PF_CROSSING(f), beginc = PF_BEGIN(f), side = PF_SIDE(f);
-        const V2 pos = v2(L.px[lane], L.py[lane]);
-        const bool isOffRoad = drv_is_off_road(pos);
-        const bool isOut = drv_is_out(pos);
-        if (moving > 0) {
-          moving = (moving - DRV_TIME_DIFF > 0) ? moving - DRV_TIME_DIFF : 0;
-          if (crossing) {
-            if (!beginc && isOffRoad) { moving = 0; crossing = 0; vx = 0.0; vy = 0.0; }
-            else if (beginc && !isOffRoad) { beginc = 0; }
-          }
-          if (isOut) { moving = 0; vx = 0.0; vy = 0.0; }
-        } else {
-          if (!crossing) {
-            dm_u32x4 u = dm_env_rng(S.seed, genv, episode, DM_RNG_PED_MOVE, (uint32_t)(lane - DRV_SLOT_PED), (uint32_t)elapsed);
-            const bool r1 = PF_ROAD(f) != 0;
-            const V2 rdir = r1 ? v2(RoadK<1>::dirx, RoadK<1>::diry) : v2(RoadK<0>::dirx, RoadK<0>::diry);
-            const V2 rnrm = r1 ? v2(RoadK<1>::nx, RoadK<1>::ny) : v2(RoadK<0>::nx, RoadK<0>::ny);
-            V2 dir = rdir;
-            moving = dm_randint(u.v[0], 5000, 30000);
-            int speed = dm_randint(u.v[1], -2, 2);
-            if (!isOffRoad) {
-              crossing = 1; beginc = 0;
-              if (speed == 0) speed = 2;
-            } else if (isOut) {
-              dir = drv_is_out(vadd(pos, rdir)) ? vneg(rdir) : rdir;
-            } else if (dm_unit(u.v[2]) < 0.05) {
-              crossing = 1; beginc = 1;
-              dir = side ? rnrm : vneg(rnrm);
-              side = side ? 0 : 1;
-              speed = dm_randint(u.v[3], 1, 2);
-            }
-            const V2 nv = vmul(vmul(dir, (double)PF_SPEED(f)), (double)speed);
-            vx = nv.x; vy = nv.y;
-          } else if (isOffRoad) {
-            crossing = 0; beginc = 0;
-          }
-        }
-        L.moving[lane] = moving;
-        L.flags[lane] = PEDF_PACK(PF_ROAD(f), side, 0, crossing, beginc, PF_SPEED(f));
-        L.vx[lane] = vx; L.vy[lane] = vy;
-      }
-    }
-
-    // ======== phase 1c: cpBodyUpdatePosition for every body (one instance of the code for cars + pedestrians) ===
-    if (isBody) {
-      const double px = L.px[lane], py = L.py[lane], ang = L.ang[lane];
-      const double vx = L.vx[lane], vy = L.vy[lane], w = L.w[lane];
-      // bias velocities: L.vb* keep the output of the last contact solve (a replay needs it again); they count only if
-      // the previous substep solved or replayed contacts (vbValid), else cpBodyUpdatePosition saw zeros
-      const double vbx = vbValid ? L.vbx[lane] : 0.0, vby = vbValid ? L.vby[lane] : 0.0, wb = vbValid ? L.wb[lane] : 0.0;
-      const double npx = px + (vx + vbx) * DE_DT, npy = py + (vy + vby) * DE_DT, nang = ang + (w + wb) * DE_DT;
-      const bool still = !turned && vx == 0.0 && vy == 0.0 && w == 0.0 && vbx == 0.0 && vby == 0.0 && wb == 0.0;
-      L.px[lane] = npx; L.py[lane] = npy; L.ang[lane] = nang;
-      // frozen: at rest and the position update was absorbed by rounding (sub-ulp bias velocities of a resting contact)
-      const bool frozen = !turned && vx == 0.0 && vy == 0.0 && w == 0.0 && npx == px && npy == py && nang == ang;
-      L.still[lane] = (still ? 1 : 0) | (frozen ? 2 : 0);
-      if (isCar) {
-        if (nang != L.rotAng[lane]) car_refresh_rot(L, lane, nang);
-        if (!aabbValid || !frozen) {  // frozen: same position and rotation => same box
-          BoxW bw;
-          box_world(bw, v2(npx, npy), L.rc[lane], L.rs[lane], L.chx[lane], L.chy[lane]);
-          double l = INFINITY, r = -INFINITY, b = INFINITY, t = -INFINITY;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            l = fmin_cp(l, bw.v[k].x); r = fmax_cp(r, bw.v[k].x); b = fmin_cp(b, bw.v[k].y); t = fmax_cp(t, bw.v[k].y);
-          }
-          L.aabb[lane][0] = l - 0.0; L.aabb[lane][1] = b - 0.0; L.aabb[lane][2] = r + 0.0; L.aabb[lane][3] = t + 0.0;
-        }
-      }
-    }
-    aabbValid = true;
-    __syncthreads();
-
-DRV_PROF(const unsigned long long A1 = __builtin_amdgcn_s_memtime();)
-    // ======== phase 2: broadphase.  Lane = object j (slot id: cars, pedestrians, obstacles, buildings); the loop runs over
-    // the cars i < j whose box is broadcast from LDS.  cand bit i <=> cpBBIntersects(bb_i, bb_j) for the canonical pair
-    // (i, j); the pairs of one car are consecutive in canonical order and ascend with the lane.
-    int cand = 0;
-    bool candMoving = false, removed = false;
-    int dirty = 0;
-    {
-      double bl = 0.0, bb = 0.0, br = -1.0, bt = -1.0;
-      bool live = false;
-      int sj = 3;  // statics are always still and frozen
-      if (lane < DRV_SLOT_PED) {
-        live = isCar; sj = L.still[lane];
-        bl = L.aabb[lane][0]; bb = L.aabb[lane][1]; br = L.aabb[lane][2]; bt = L.aabb[lane][3];
-      } else if (lane < DRV_SLOT_OBST) {
-        live = isPed; sj = L.still[lane];
-        const double cx = L.px[lane], cy = L.py[lane];
-        bl = cx - 5.0; bb = cy - 5.0; br = cx + 5.0; bt = cy + 5.0;
-      } else if (lane < DRV_SLOT_BLD + 4) {
-        live = lane >= DRV_SLOT_BLD || (lane - DRV_SLOT_OBST) < nObst;
-        const V2 c = static_pos(L, lane);
-        const double ex = lane >= DRV_SLOT_BLD ? 400.0 : 10.0, ey = lane >= DRV_SLOT_BLD ? 225.0 : 10.0;
-        // static box AABB = min/max of (c +- e) exactly as cached by cpShapeCacheBB with rot = (1,0)
-        bl = -ex + c.x; br = ex + c.x; bb = -ey + c.y; bt = ey + c.y;
-      }
-      const int carStill = (int)(wave_ballot(isCar && (sj & 1)) & 0x3FFull);
-      const int carFrozen = (int)(wave_ballot(isCar && (sj & 2)) & 0x3FFull);
-#pragma unroll 5
-      for (int i = 0; i < DRV_MAXA; ++i) {  // rows >= A are never written but in bounds: the loads pipeline unconditionally
-        const double al = L.aabb[i][0], ab = L.aabb[i][1], ar = L.aabb[i][2], at = L.aabb[i][3];
-        if (live && i < A && lane > i && al <= br && bl <= ar && ab <= bt && bb <= at) cand |= (1 << i);
-      }
-      if (cand) candMoving = !(sj & 1) || (cand & ~carStill) != 0;
-      // clean pair: a candidate in the previous substep too, both bodies frozen since.  dirty: every other candidate.
-      const int clean = (lastCand >= 0 && (sj & 2)) ? (cand & lastCand & carFrozen) : 0;
-      dirty = cand & ~clean;
-      removed = lastCand < 0 || (lastCand & ~cand) != 0;
-    }
-#endif
     const uint64_t anyCand = wave_ballot(cand != 0);
     // Quiescent contact set: same candidate pairs as in the previous substep, every body in them exactly at rest and
     // every cached arbiter inert (zero bias, zero accumulated impulse, not first contact).  Then narrowphase, arbiter

@@ -49,6 +49,7 @@ struct dynenv {
   bool partial;
   std::vector<void*> allocs;
   std::vector<size_t> alloc_bytes;  // checkpoint = these arrays, in allocation order
+  hipEvent_t ev_begin = nullptr, ev_main = nullptr, ev_end = nullptr;  // dynenv_set_step_events (caller-owned)
 };
 
 // ---------------------------------------------------------------------------------------------- constants
@@ -161,7 +162,6 @@ static int rc_create(dynenv* h) {
   rc |= dev_alloc(h, &R.prew0, E * 16);
   rc |= dev_alloc(h, &R.seenPart, (size_t)E * 5 * 10 * RCP_SEEN_STRIDE);
   rc |= dev_alloc(h, &R.deferList, (size_t)E + 1);
-  rc |= dev_alloc(h, &R.sched, (size_t)2 * E + 1);
   rc |= dev_alloc(h, &R.s_pair, E * RC_NS);
   rc |= dev_alloc(h, &R.s_meta, E * RC_NS);
   rc |= dev_alloc(h, &R.s_hash, 2 * E * RC_NS);
@@ -500,6 +500,21 @@ int dynenv_full_obs(dynenv_t* h, float* full_dev, void* stream) {
   return DYNENV_OK;
 }
 
+int dynenv_global_state_dim(const dynenv_t* h) {
+  if (!h) return fail(DYNENV_ERR_ARG, "null handle");
+  return h->robocup ? h->R.R * 6 + 3 : 0;
+}
+
+int dynenv_global_state(dynenv_t* h, float* state_dev, void* stream) {
+  if (!h || !state_dev) return fail(DYNENV_ERR_ARG, "null argument");
+  if (!h->robocup)
+    return fail(DYNENV_ERR_UNSUPPORTED, "Driving: getFullState(None) is made of columns of dynenv_full_obs (every car's own self block); no separate emit");
+  ON_DEVICE(h);
+  hipLaunchKernelGGL(rc_global_state_kernel, dim3((h->R.E + 3) / 4), dim3(64), 0, (hipStream_t)stream, h->R, state_dev);
+  HIP_OK(hipGetLastError());
+  return DYNENV_OK;
+}
+
 int dynenv_step(dynenv_t* h, const int32_t* actions_dev, float* obs_dev, double* rewards_dev, uint8_t* dones_dev,
                 void* stream) {
   return dynenv_step_head(h, actions_dev, nullptr, obs_dev, rewards_dev, dones_dev, stream);
@@ -512,41 +527,55 @@ int dynenv_step_head(dynenv_t* h, const int32_t* actions_dev, const double* head
     return fail(DYNENV_ERR_ARG, "the continuous head channel exists for RoboCup with DYNENV_FLAG_ALLOW_HEAD_TURN only");
   ON_DEVICE(h);
   hipStream_t st = (hipStream_t)stream;
+  // measurement hook (dynenv_set_step_events): the step's dominant kernel bracketed by events on the launch stream
+  struct StepEvents {
+    dynenv* h; hipStream_t st;
+    void main_done() { if (h->ev_main) (void)hipEventRecord(h->ev_main, st); }
+    ~StepEvents() { if (h->ev_end) (void)hipEventRecord(h->ev_end, st); }
+  } sev{h, st};
   if (h->robocup) {
     if (h->R.obs_type == DYNENV_OBS_PARTIAL && obs_dev) {  // getAgentVision at the five snapshots + processSeens fused into the launch
       HIP_OK(hipMemsetAsync(h->R.deferList, 0, sizeof(int), st));
+      if (h->ev_begin) HIP_OK(hipEventRecord(h->ev_begin, st));
       hipLaunchKernelGGL(rc_step_partial_kernel, dim3(h->R.E), dim3(64), 0, st, h->R, (const int*)actions_dev, head_dev, obs_dev, rewards_dev, dones_dev);
+      sev.main_done();
       const int nb = h->R.E < RC_DEFER_BLOCKS ? h->R.E : RC_DEFER_BLOCKS;  // the deferred environments are few: blocks stride over their list
       hipLaunchKernelGGL(rc_partial_obs_deferred_kernel, dim3(nb, 5, h->R.R), dim3(64), 0, st, h->R, obs_dev);
       hipLaunchKernelGGL(rc_partial_finalize_kernel, dim3(nb), dim3(64), 0, st, h->R, rewards_dev);
     }
     else if (h->R.obs_type == DYNENV_OBS_PARTIAL)
       return fail(DYNENV_ERR_ARG, "RoboCup Partial: the observation buffer is required (the processSeens rewards come out of the same pass)");
-    else
-#if RC_SCHED
-    {  // heavy environments solo, the others two per wave (robocup_kernels.hip "the scheduled step"); the table is scratch
-      hipLaunchKernelGGL(rc_schedule_kernel, dim3(1), dim3(1024), 0, st, h->R, h->R.sched);
-      hipLaunchKernelGGL(rc_step_sched_kernel, dim3(h->R.E), dim3(64), 0, st, h->R, (const int*)h->R.sched, (const int*)actions_dev, head_dev, obs_dev, rewards_dev, dones_dev);
+    else {
+      if (h->ev_begin) HIP_OK(hipEventRecord(h->ev_begin, st));
+      hipLaunchKernelGGL(rc_step_kernel, dim3(h->R.E), dim3(64), 0, st, h->R, (const int*)actions_dev, head_dev, obs_dev, rewards_dev, dones_dev);
+      sev.main_done();
     }
-#else
-      hipLaunchKernelGGL(rc_step_kernel, dim3((h->R.E + RC_FULL_EPW - 1) / RC_FULL_EPW), dim3(64), 0, st, h->R, (const int*)actions_dev, head_dev, obs_dev, rewards_dev, dones_dev);
-#endif
     HIP_OK(hipGetLastError());
     return DYNENV_OK;
   }
+  if (h->ev_begin) HIP_OK(hipEventRecord(h->ev_begin, st));
   // Partial: getAgentVision for every agent (DrivingEnvironment.py:294) is fused into the step kernel - each wave writes its
   // environment's observation as soon as its step is done, which fills the launch's tail
   if (h->partial && obs_dev)
   {
     hipLaunchKernelGGL(drv_step_partial_kernel, dim3(h->S.E), dim3(64), 0, st, h->S, (const int*)actions_dev, rewards_dev, dones_dev, obs_dev,
                        (int)h->cfg.noise_type, (double)h->cfg.noise_magnitude);
+    sev.main_done();
     hipLaunchKernelGGL(drv_partial_obs_deferred_kernel, dim3(h->S.E, h->S.A), dim3(64), 0, st, h->S, (int)h->cfg.noise_type,
                        (double)h->cfg.noise_magnitude, obs_dev);
   }
-  else
+  else {
     hipLaunchKernelGGL(drv_step_kernel, dim3(h->S.E), dim3(64), 0, st, h->S, (const int*)actions_dev, h->partial ? (float*)nullptr : obs_dev,
                        rewards_dev, dones_dev);
+    sev.main_done();
+  }
   HIP_OK(hipGetLastError());
+  return DYNENV_OK;
+}
+
+int dynenv_set_step_events(dynenv_t* h, void* ev_begin, void* ev_main_done, void* ev_end) {
+  if (!h) return fail(DYNENV_ERR_ARG, "null handle");
+  h->ev_begin = (hipEvent_t)ev_begin; h->ev_main = (hipEvent_t)ev_main_done; h->ev_end = (hipEvent_t)ev_end;
   return DYNENV_OK;
 }
 

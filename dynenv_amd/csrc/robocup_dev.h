@@ -75,7 +75,6 @@ struct RcState {
   double* prew0; /* [E][16] positive part of the step's robot + team reward, before the observation reward (Partial) */
   int* seenPart; /* [E][5][120] per-snapshot seen counts of the environments whose vision runs in the deferred launch */
   int* deferList; /* [E + 1]: [0] = number of environments deferred in this step (zeroed before every step launch), then their ids */
-  int* sched;     /* [1 + 2 E] wave -> environment table of the scheduled Full-observation step (rc_schedule_kernel), rebuilt every step */
   int obs_type, noise_type;
   double noise_magn;
   int* s_pair;   /* [E][NS] */

@@ -20,34 +20,12 @@ __constant__ RcConst RC;
 #ifndef RC_WAVES_PER_SIMD
 #define RC_WAVES_PER_SIMD 4
 #endif
-#ifndef RC_FULL_EPW
-#define RC_FULL_EPW 1 /* environments per wave of rc_step_kernel (Full observations): 1 or 2, see Grp<> */
-#endif
-#ifndef RC_SCHED
-#define RC_SCHED 0 /* 1: dynenv_step launches rc_schedule_kernel + rc_step_sched_kernel for Full observations */
-#endif
-#ifndef RC_RPL
-#define RC_RPL (RC_FULL_EPW == 2) /* robocup_rpl.hip: one lane per robot, the common substep in registers (0: the foot-per-lane rc_step_body) */
-#endif
-#ifndef RC_SPLIT_BIAS
-#define RC_SPLIT_BIAS 1 /* general solve: an arbiter's position-correction (bias) impulses run on lane slot + 16 beside its velocity impulses */
-#endif
-// RC_INVERT = 1 (default for one environment per wave): the COMMON part of a substep (game logic, position update, broadphase,
+// The COMMON part of a substep (game logic, position update, broadphase,
 // the quiet substep's joints) is an out-of-line function of its own, rc_common_substep - 102 VGPRs, no call inside, nothing
 // saved, nothing spilled - instead of living inline in a kernel whose register allocation it shared with everything else
 // (87 spilled VGPRs, ~50 scratch instructions per substep and wave: 2.1 GB of HBM traffic per launch, now 0.6 GB, all of it
 // the general path's).  The one call the common part could make (the sequential game logic) is made by the kernel.
-#ifndef RC_INVERT
-#define RC_INVERT (RC_FULL_EPW == 1)
-#endif
-#if RC_INVERT
 #define RC_COMMON_SINCOS(x) dev_sincos_inl(x)
-#else
-#define RC_COMMON_SINCOS(x) dev_sincos(x)
-#endif
-#ifndef RC_QUIET_JOINTS_INLINE
-#define RC_QUIET_JOINTS_INLINE RC_INVERT /* the quiet substep's joint solve inlined into the step loop (EPW = 2 always inlines) */
-#endif
 
 
 #define ROBOT_VELOCITY 50.0
@@ -75,10 +53,6 @@ struct RcObsStage {
 struct RcPrefilter {
   float cx[RC_NB], cy[RC_NB], hx[RC_NB], hy[RC_NB];
 };
-struct RcRplExchange {  // robocup_rpl.hip: what crosses lanes in the register-resident substep
-  double q[16];                     // squared distance robot - ball (closest-robot searches)
-  float bx[16], by[16], br[16];     // robot / ball bounding boxes of the contact prefilter
-};
 struct __align__(16) RcLds {
   // bodies: feet 0..19, ball 20 (home location of the state); posts 21..24 are constants
   double px[RC_NB], py[RC_NB], vx[RC_NB], vy[RC_NB], ang[RC_NB], w[RC_NB], vbx[RC_NB], vby[RC_NB], wb[RC_NB];
@@ -101,19 +75,15 @@ struct __align__(16) RcLds {
     RcArbShare sh;
     RcObsStage ob;
     RcPrefilter pf;
-    RcRplExchange rq;
   } u;
 };
-// LDS tiles: the one-environment-per-wave kernels (Partial observations, the observation kernel after a reset) use g_R,
-// the two-environments-per-wave step kernel one tile per half wave.  A kernel only allocates what it references.
+// the LDS tile of a wave's environment
 __shared__ RcLds g_R;
-__shared__ RcLds g_R2[2];
 
-// Grp<EPW>: the lanes that serve ONE environment.  EPW = 1: the whole wave (cross-lane traffic through v_readlane with
-// wave-uniform indices, masks in SGPRs).  EPW = 2: a half wave (32 lanes: feet 0..19, ball 20, robots 0..9, contact
-// slots 0..15, the general solve's joints on 16..25); "uniform" then means uniform within the half, masks are the half's
-// 32 bits of the wave ballot and broadcasts go through ds_bpermute.  A launch of E environments needs E / 2 waves, which
-// fit the chip at two waves per SIMD with 256 VGPRs each - no scratch, nothing out of line in the hot loop.
+// Grp<EPW>: the lanes that serve ONE environment and how they talk to each other.  EPW = 1, the only layout shipped: the whole
+// wave (cross-lane traffic through v_readlane with wave-uniform indices, masks in SGPRs).  (Round 2 measured two further
+// layouts through this interface - two environments per wave, one lane per robot - 4x less HBM traffic, 23 % slower; they are
+// in the repository's history, profiles/r02_robocup_variants_final.txt, and not in the product.)
 template <int EPW> struct Grp;
 template <> struct Grp<1> {
   static constexpr int W = 64, JL0 = 32, OBS_BALL_LANE = 32;
@@ -127,49 +97,6 @@ template <> struct Grp<1> {
   DE_DEV static uint64_t uniform_u64(uint64_t v) { return ::uniform_u64(v); }
   DE_DEV static int uniform_i(int v) { return ::uniform_i(v); }
 };
-// Grp<3>: Grp<1>'s lane roles and wave-uniform cross-lane traffic for an environment that has a whole wave to itself inside the
-// two-tiles-per-wave kernel (rc_step_sched_kernel's "solo" mode): its tile is the wave's first one, nothing is out of line
-// (the kernel's budget is 256 VGPRs).
-template <> struct Grp<3> {
-  static constexpr int W = 64, JL0 = 32, OBS_BALL_LANE = 32;
-  DE_DEV static int lane() { return (int)threadIdx.x; }
-  DE_DEV static int id() { return 0; }
-  DE_DEV static RcLds& tile() { return g_R2[0]; }
-  DE_DEV static uint64_t ballot(bool p) { return __ballot(p); }
-  DE_DEV static uint64_t lt_mask() { return ::lanemask_lt(); }
-  DE_DEV static int bcast_i(int v, int src) { return ::bcast_i(v, src); }
-  DE_DEV static double bcast_d(double v, int src) { return ::bcast_d(v, src); }
-  DE_DEV static uint64_t uniform_u64(uint64_t v) { return ::uniform_u64(v); }
-  DE_DEV static int uniform_i(int v) { return ::uniform_i(v); }
-};
-template <> struct Grp<4> {  // Grp<3> on the wave's second tile
-  static constexpr int W = 64, JL0 = 32, OBS_BALL_LANE = 32;
-  DE_DEV static int lane() { return (int)threadIdx.x; }
-  DE_DEV static int id() { return 0; }
-  DE_DEV static RcLds& tile() { return g_R2[1]; }
-  DE_DEV static uint64_t ballot(bool p) { return __ballot(p); }
-  DE_DEV static uint64_t lt_mask() { return ::lanemask_lt(); }
-  DE_DEV static int bcast_i(int v, int src) { return ::bcast_i(v, src); }
-  DE_DEV static double bcast_d(double v, int src) { return ::bcast_d(v, src); }
-  DE_DEV static uint64_t uniform_u64(uint64_t v) { return ::uniform_u64(v); }
-  DE_DEV static int uniform_i(int v) { return ::uniform_i(v); }
-};
-template <> struct Grp<2> {
-  static constexpr int W = 32, JL0 = 16, OBS_BALL_LANE = 31;
-  DE_DEV static int lane() { return (int)threadIdx.x & 31; }
-  DE_DEV static int id() { return ((int)threadIdx.x >> 5) & 1; }
-  DE_DEV static RcLds& tile() { return g_R2[((int)threadIdx.x >> 5) & 1]; }
-  DE_DEV static uint64_t ballot(bool p) {
-    const uint64_t b = __ballot(p);
-    return (threadIdx.x & 32) ? (b >> 32) : (b & 0xFFFFFFFFull);
-  }
-  DE_DEV static uint64_t lt_mask() { return (1ull << ((int)threadIdx.x & 31)) - 1ull; }
-  DE_DEV static int bcast_i(int v, int src) { return __shfl(v, ((int)threadIdx.x & 32) | src, 64); }
-  DE_DEV static double bcast_d(double v, int src) { return __shfl(v, ((int)threadIdx.x & 32) | src, 64); }
-  DE_DEV static uint64_t uniform_u64(uint64_t v) { return v; }
-  DE_DEV static int uniform_i(int v) { return v; }
-};
-
 #define RC_MY_PAIR(t) ((int)((((t) < 4 ? pairLo : (t) < 8 ? pairHi : pairTop) >> (16 * ((t)&3))) & 0xFFFFull))
 
 DE_DEV double rc_minv(int b) { return b == RC_BALL ? 1.0 / 10.0 : (b < RC_BALL ? 1.0 / ROBOT_MASS : 0.0); }
@@ -1091,13 +1018,10 @@ DE_DEV void rc_joints_only_inl(int lane, int R) {
   }
 }
 
-// out of line at 128 VGPRs (one environment per wave: its own small register allocation), inlined where the budget is 256
+// out of line where it runs inside the general path's caller (its own small register allocation)
 __device__ __noinline__ void rc_joints_only_ool(int lane, int R) { rc_joints_only_inl<1>(lane, R); }
 template <int EPW>
-DE_DEV void rc_joints_only(int lane, int R) {
-  if (EPW == 1) rc_joints_only_ool(lane, R);
-  else rc_joints_only_inl<EPW>(lane, R);  // (2, 3: a 256-VGPR kernel)
-}
+DE_DEV void rc_joints_only(int lane, int R) { rc_joints_only_ool(lane, R); }
 
 #ifdef DRV_PROFILE
 #define RC_PROF(...) __VA_ARGS__
@@ -1117,7 +1041,7 @@ DE_DEV RcStepRet rc_physics_inl(RcCtx c, int lane, int cand, uint64_t pairLo, ui
   // SPLIT: the two impulse chains of an arbiter's contact - velocity (normal + tangent) and position correction (bias) -
   // read and write disjoint body fields (v, w against v_bias, w_bias) and run the same instruction sequence up to the
   // impulse vector; a lone wave pays per instruction, not per lane, so the bias chain moves to lane slot + 16.
-  constexpr bool SPLIT = RC_SPLIT_BIAS && W == 64 && RC_NS == 16 && G::JL0 == 32;
+  constexpr bool SPLIT = W == 64 && RC_NS == 16 && G::JL0 == 32;  // an arbiter's bias impulses on lane slot + 16 beside its velocity impulses
   RcLds& L = G::tile();
   RcMailbox& M = L.u.mb;
   int err = 0;
@@ -1545,22 +1469,9 @@ RC_PROF(if (lane == 0 && c.genv < 4096u) { unsigned long long* d = g_rcprof + c.
 __device__ RC_PHYS_INLINE RcStepRet rc_physics_ool(RcCtx c, int lane, int cand, uint64_t pairLo, uint64_t pairHi, uint64_t occ) {
   return rc_physics_inl<1>(c, lane, cand, pairLo, pairHi, 0ull, occ);
 }
-__device__ __noinline__ RcStepRet rc_physics_ool3(RcCtx c, int lane, int cand, uint64_t pairLo, uint64_t pairHi, uint64_t occ) {
-  return rc_physics_inl<3>(c, lane, cand, pairLo, pairHi, 0ull, occ);
-}
-__device__ __noinline__ RcStepRet rc_physics_ool2(RcCtx c, int lane, int cand, uint64_t pairLo, uint64_t pairHi, uint64_t pairTop, uint64_t occ) {
-  return rc_physics_inl<2>(c, lane, cand, pairLo, pairHi, pairTop, occ);
-}
 template <int EPW>
 DE_DEV RcStepRet rc_physics(RcCtx c, int lane, int cand, uint64_t pairLo, uint64_t pairHi, uint64_t pairTop, uint64_t occ) {
-  if (EPW == 1) return rc_physics_ool(c, lane, cand, pairLo, pairHi, occ);
-  if (EPW == 3) return rc_physics_ool3(c, lane, cand, pairLo, pairHi, occ);
-  if (EPW == 4) return rc_physics_inl<4>(c, lane, cand, pairLo, pairHi, 0ull, occ);  // (only ever called from the out-of-line rpl_general_physics<4>)
-#ifdef RC_PHYS2_OOL  /* analysis builds: keeps the general path out of the step kernel's listing */
-  return rc_physics_ool2(c, lane, cand, pairLo, pairHi, pairTop, occ);
-#else
-  return rc_physics_inl<EPW>(c, lane, cand, pairLo, pairHi, pairTop, occ);
-#endif
+  return rc_physics_ool(c, lane, cand, pairLo, pairHi, occ);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1708,7 +1619,6 @@ DE_DEV void rc_write_obs(RcLds& L, int lane, int R, int obs_dim, float* __restri
 #ifndef RC_DEFER_MIN_GENERAL
 #define RC_DEFER_MIN_GENERAL 25 /* rc_physics substeps (of 50) from which an environment defers its Partial observation */
 #endif
-#if RC_INVERT
 struct RcCommonRet {
   double rotC, rotS, rotAng;
   int cand, bits;  // bits: 1 quiet, 2 rotValid
@@ -1798,18 +1708,13 @@ __device__ __noinline__ RcCommonRet rc_common_substep(RcCtx c, int serial_, int 
     if (quiet) {
       if (isBody) rc_velocity_update(L, lane);
       __syncthreads();
-#if RC_QUIET_JOINTS_INLINE
       rc_joints_only_inl<EPW>(lane, R);
-#else
-      rc_joints_only<EPW>(lane, R);
-#endif
       __syncthreads();
     }
   RcCommonRet ret;
   ret.rotC = rotC; ret.rotS = rotS; ret.rotAng = rotAng; ret.cand = cand; ret.bits = (quiet ? 1 : 0) | (rotValid ? 2 : 0);
   return ret;
 }
-#endif
 template <bool PARTIAL, int EPW>
 DE_DEV void rc_step_body(const RcState& S, const int e, const int* __restrict__ actions, const double* __restrict__ headActions, float* __restrict__ obs,
                          double* __restrict__ rewards, uint8_t* __restrict__ dones) {
@@ -1857,7 +1762,6 @@ DE_DEV void rc_step_body(const RcState& S, const int e, const int* __restrict__ 
 RC_PROF(if (lane < 12 && e < 4096) g_rcprof[e * 12 + lane] = 0ull; const unsigned long long K0 = __builtin_amdgcn_s_memtime(); unsigned long long tG = 0, tP = 0, tB = 0;)
   for (int it = 0; it < 50; ++it) {
 RC_PROF(const unsigned long long A0 = __builtin_amdgcn_s_memtime();)
-#if RC_INVERT
     // the game logic's sequential form (first substep: processAction; later: a cross-robot event) is the only call of the common
     // part: it is made from here, the outermost frame, so that rc_common_substep itself contains no call at all
     bool serial = it == 0;
@@ -1872,91 +1776,6 @@ RC_PROF(tG += 1;)  // (profile build: "game logic" = substeps with the sequentia
     const bool quiet = G::uniform_i(cr.bits & 1) != 0;
 RC_PROF(tP += __builtin_amdgcn_s_memtime() - A0;)
     if (quiet) {
-#else
-    // ---- sequential game logic (lane 0): processAction / tick per robot, then the ball (:465-475) ----------
-    rc_game_logic<EPW>(c, it, myActions, myHead, lane);
-    __syncthreads();
-RC_PROF(const unsigned long long A1 = __builtin_amdgcn_s_memtime();)
-    // ---- cpBodyUpdatePosition + shape cache + AABB ------------------------------------------------------
-    if (isBody) {
-      const double npx = L.px[lane] + (L.vx[lane] + L.vbx[lane]) * DE_DT;
-      const double npy = L.py[lane] + (L.vy[lane] + L.vby[lane]) * DE_DT;
-      const double nang = L.ang[lane] + (L.w[lane] + L.wb[lane]) * DE_DT;
-      L.px[lane] = npx; L.py[lane] = npy; L.ang[lane] = nang;
-      L.vbx[lane] = 0.0; L.vby[lane] = 0.0; L.wb[lane] = 0.0;
-      float fcx, fcy, fhx, fhy;
-      if (lane != RC_BALL) {
-        if (nang != rotAng || !rotValid) {  // this lane's rotation cache (registers): invalid at kernel entry
-          const DevSC sc = RC_COMMON_SINCOS(nang);
-          rotC = sc.c; rotS = sc.s; rotAng = nang; rotValid = true;
-        }
-        L.cpx[lane] = npx; L.cpy[lane] = npy; L.crc[lane] = rotC; L.crs[lane] = rotS;
-        SegW s;
-        seg_world(L, lane, s);
-        double l, r, b, t;
-        if (s.ta.x < s.tb.x) { l = s.ta.x; r = s.tb.x; } else { l = s.tb.x; r = s.ta.x; }
-        if (s.ta.y < s.tb.y) { b = s.ta.y; t = s.tb.y; } else { b = s.tb.y; t = s.ta.y; }
-        L.aabb[lane][0] = l - FOOT_RADIUS; L.aabb[lane][1] = b - FOOT_RADIUS; L.aabb[lane][2] = r + FOOT_RADIUS; L.aabb[lane][3] = t + FOOT_RADIUS;
-      } else {
-        L.cpx[lane] = npx; L.cpy[lane] = npy;
-        L.aabb[lane][0] = npx - BALL_R; L.aabb[lane][1] = npy - BALL_R; L.aabb[lane][2] = npx + BALL_R; L.aabb[lane][3] = npy + BALL_R;
-      }
-      const double al = L.aabb[lane][0], ab = L.aabb[lane][1], ar = L.aabb[lane][2], at = L.aabb[lane][3];
-      fcx = (float)(0.5 * (al + ar)); fcy = (float)(0.5 * (ab + at));
-      fhx = (float)(0.5 * (ar - al)) + 1.0f; fhy = (float)(0.5 * (at - ab)) + 1.0f;
-      L.u.pf.cx[lane] = fcx; L.u.pf.cy[lane] = fcy; L.u.pf.hx[lane] = fhx; L.u.pf.hy[lane] = fhy;
-    }
-    __syncthreads();
-RC_PROF(const unsigned long long A2 = __builtin_amdgcn_s_memtime();)
-    // ---- broadphase ---------------------------------------------------------------------------------------
-    // The two feet of one robot overlap in every substep: they are candidates without a test (a candidate whose boxes
-    // do not overlap is harmless - shapes that touch have overlapping boxes, so the narrowphase finds nothing), which
-    // keeps the double-precision box test below for the rare real prefilter hits.
-    int cand = feetPairs, pre = 0;
-#pragma unroll
-    for (int t = 0; t < NROUNDS; ++t) {  // the fp32 prefilter of all my pairs first: their LDS reads are in flight together
-      const int pr = RC_MY_PAIR(t);
-      if (pr != 0xFFFF && !((feetPairs >> t) & 1)) {
-        const int i = pr >> 8, j = pr & 0xFF;
-        float bx, by, bhx, bhy;
-        if (j <= RC_BALL) { bx = L.u.pf.cx[j]; by = L.u.pf.cy[j]; bhx = L.u.pf.hx[j]; bhy = L.u.pf.hy[j]; }
-        else { const V2 pc = post_pos(j); bx = (float)pc.x; by = (float)pc.y; bhx = 11.0f; bhy = 11.0f; }
-        const float dx = L.u.pf.cx[i] - bx, dy = L.u.pf.cy[i] - by;
-        if (__builtin_fabsf(dx) <= L.u.pf.hx[i] + bhx && __builtin_fabsf(dy) <= L.u.pf.hy[i] + bhy) pre |= 1 << t;
-      }
-    }
-#pragma unroll 1
-    for (int mm = pre; mm; mm &= mm - 1) {  // the exact test (cpBBIntersects) of the pairs that passed (rare)
-      const int t = __builtin_ctz(mm);
-      const int pr = RC_MY_PAIR(t);
-      const int i = pr >> 8, j = pr & 0xFF;
-      const double al = L.aabb[i][0], ab = L.aabb[i][1], ar = L.aabb[i][2], at = L.aabb[i][3];
-      double bl, bb, br, bt;
-      if (j <= RC_BALL) { bl = L.aabb[j][0]; bb = L.aabb[j][1]; br = L.aabb[j][2]; bt = L.aabb[j][3]; }
-      else { const V2 pc = post_pos(j); bl = pc.x - POST_R; bb = pc.y - POST_R; br = pc.x + POST_R; bt = pc.y + POST_R; }
-      if (al <= br && bl <= ar && ab <= bt && bb <= at) cand |= (1 << t);
-    }
-    __syncthreads();
-RC_PROF(const unsigned long long A3 = __builtin_amdgcn_s_memtime(); tG += A1 - A0; tP += A2 - A1; tB += A3 - A2;)
-    // ---- contacts, joints, velocity update, solver, post-solve callbacks -----------------------------------------
-    // The common substep never enters rc_physics: no cached arbiter, the only candidates are the robots' own feet pairs, and
-    // the narrowphase's separating-axis early out rejects every one of them.  What rc_physics does then is exactly this:
-    // velocity update, then every robot's joints (prestep, warm start, 10 iterations) in registers.
-    bool quiet = occ == 0ull && G::ballot((cand & ~feetPairs) != 0) == 0ull;
-    if (quiet) {
-      const bool far = lane < R ? feet_far_apart(L, lane) : true;
-      quiet = G::ballot(!far) == 0ull;
-    }
-    if (quiet) {
-      if (isBody) rc_velocity_update(L, lane);
-      __syncthreads();
-#if RC_QUIET_JOINTS_INLINE
-      rc_joints_only_inl<EPW>(lane, R);
-#else
-      rc_joints_only<EPW>(lane, R);
-#endif
-      __syncthreads();
-#endif
     } else {
       __builtin_amdgcn_s_setprio(3);  // an environment with contact work is on the launch's critical path: issue it first
       ++nGeneral;
@@ -2012,73 +1831,11 @@ RC_PROF(if (lane == 0 && e < 4096) { unsigned long long* d = g_rcprof + e * 12; 
     if (obs && !deferObs) rc_partial_obs_fused(S, e, lane, obs, rewards);  // getAgentVision at the five snapshots + processSeens
   }
 }
-#include "robocup_rpl.hip"
-
-// Full observations.  RC_FULL_EPW = 2: two environments per wave, E / 2 waves at two per SIMD (256 VGPRs, everything inline,
-// no scratch); = 1: one environment per wave at four per SIMD (128 VGPRs, the general path out of line).
-extern "C" __global__ void __launch_bounds__(64, RC_FULL_EPW == 2 ? 2 : RC_WAVES_PER_SIMD)
+// Full observations: one environment per wave at four waves per SIMD (128 VGPRs, the general path out of line)
+extern "C" __global__ void __launch_bounds__(64, RC_WAVES_PER_SIMD)
 rc_step_kernel(RcState S, const int* __restrict__ actions, const double* __restrict__ headActions, float* __restrict__ obs,
                double* __restrict__ rewards, uint8_t* __restrict__ dones) {
-#if RC_RPL
-  rc_step_rpl_body<RC_FULL_EPW>(S, (int)blockIdx.x * RC_FULL_EPW + Grp<RC_FULL_EPW>::id(), actions, headActions, obs, rewards, dones);  // one lane per robot, the common substep in registers
-#else
-  rc_step_body<false, RC_FULL_EPW>(S, (int)blockIdx.x * RC_FULL_EPW + Grp<RC_FULL_EPW>::id(), actions, headActions, obs, rewards, dones);
-#endif
-}
-
-// ---- the scheduled step: who runs where is decided per step from the contact caches ------------------------------------------
-// An environment that enters the step with a cached arbiter (bodies in touch: it will spend the step in the general solve, and
-// contacts persist for many steps) gets a wave of its own and the foot-per-lane code with wave-uniform control flow
-// (rc_step_body<false, 3>); all others share waves two by two in the register-resident layout (rc_step_rpl_body<2>).  Waves
-// are numbered heavy environments first, so the long ones start first.  The table is rebuilt before every step launch by
-// rc_schedule_kernel (one block; a prefix sum over the E occupancy words - deterministic, unlike an atomic queue):
-// table[0] = number of waves with work, table[1 + 2 b], table[2 + 2 b] = the environments of wave b (-1: none; a solo wave
-// has -2 in the second place).
-extern "C" __global__ void __launch_bounds__(1024) rc_schedule_kernel(RcState S, int* __restrict__ table) {
-  __shared__ int waveHeavy[16], waveLight[16];
-  __shared__ int totHeavy;
-  const int tid = threadIdx.x, wave = tid >> 6, ln = tid & 63;
-  const int E = S.E, per = (E + 1023) / 1024;  // contiguous chunk of environments per thread keeps ids ascending
-  int nh = 0, nl = 0;
-  for (int k = 0; k < per; ++k) {
-    const int e = tid * per + k;
-    if (e < E) { if (S.envi[(size_t)e * RE_COUNT + RE_OCC] != 0) ++nh; else ++nl; }
-  }
-  // exclusive scan over the threads: inside the wave by shuffles, across the 16 waves through LDS
-  int ih = nh, il = nl;
-  for (int d = 1; d < 64; d <<= 1) {
-    const int th = __shfl_up(ih, d, 64), tl = __shfl_up(il, d, 64);
-    if (ln >= d) { ih += th; il += tl; }
-  }
-  if (ln == 63) { waveHeavy[wave] = ih; waveLight[wave] = il; }
-  __syncthreads();
-  int baseH = 0, baseL = 0, allH = 0;
-  for (int w = 0; w < 16; ++w) { if (w < wave) { baseH += waveHeavy[w]; baseL += waveLight[w]; } allH += waveHeavy[w]; }
-  if (tid == 0) totHeavy = allH;
-  __syncthreads();
-  int oh = baseH + ih - nh, ol = baseL + il - nl;  // my first heavy / light ordinal
-  for (int k = 0; k < per; ++k) {
-    const int e = tid * per + k;
-    if (e < E) {
-      if (S.envi[(size_t)e * RE_COUNT + RE_OCC] != 0) { table[1 + 2 * oh] = e; table[2 + 2 * oh] = -2; ++oh; }
-      else { table[1 + 2 * (allH + (ol >> 1)) + (ol & 1)] = e; ++ol; }
-    }
-  }
-  __syncthreads();
-  if (tid == 1023) {  // the last thread knows the totals
-    const int nLight = ol;
-    if (nLight & 1) table[2 + 2 * (totHeavy + (nLight >> 1))] = -2;  // an odd one out runs solo too (the paired layout wants both halves alive)
-    table[0] = totHeavy + ((nLight + 1) >> 1);
-  }
-}
-extern "C" __global__ void __launch_bounds__(64, 2)
-rc_step_sched_kernel(RcState S, const int* __restrict__ table, const int* __restrict__ actions, const double* __restrict__ headActions,
-                     float* __restrict__ obs, double* __restrict__ rewards, uint8_t* __restrict__ dones) {
-  const int b = blockIdx.x;
-  if (b >= table[0]) return;
-  const int e0 = table[1 + 2 * b], e1 = table[2 + 2 * b];
-  if (e1 == -2) rc_step_body<false, 3>(S, uniform_i(e0), actions, headActions, obs, rewards, dones);
-  else rc_step_rpl_body<2>(S, Grp<2>::id() ? e1 : e0, actions, headActions, obs, rewards, dones);
+  rc_step_body<false, 1>(S, (int)blockIdx.x, actions, headActions, obs, rewards, dones);
 }
 extern "C" __global__ void __launch_bounds__(64, RC_WAVES_PER_SIMD)
 rc_step_partial_kernel(RcState S, const int* __restrict__ actions, const double* __restrict__ headActions, float* __restrict__ obs,
@@ -2112,6 +1869,35 @@ extern "C" __global__ void __launch_bounds__(64) rc_obs_kernel(RcState S, float*
   }
   for (int t = 0; t < 5; ++t)  // environment_base.py:217-222: nTimeSteps copies of the initial observation
     rc_write_obs(L, lane, S.R, S.obs_dim, obs + ((size_t)e * 5 + t) * S.R * S.obs_dim);
+}
+
+// getFullState(agent=None) (RoboCupEnvironment.py:1149-1161), what step() stores as info['Full State'] (:511): per environment
+// robots [R][6] = (normalize(x, standardNorm, 0), normalize(y, ...), cos a, sin a, team, fallen | penalized) in FIELD coordinates
+// (no team flip, a different normalisation from the per-agent rows: ((pt * nf) - 0) * 2, cutils.py:318-323), then the ball
+// (normalize(bx), normalize(by), ballOwned): out float32 [E][R * 6 + 3].  One thread per (environment, robot) + one for the ball.
+extern "C" __global__ void __launch_bounds__(64) rc_global_state_kernel(RcState S, float* __restrict__ out) {
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 4), r = threadIdx.x & 15, R = S.R;
+  if (e >= S.E || r > R) return;
+  const size_t E = (size_t)S.E;
+  float* o = out + (size_t)e * (R * 6 + 3);
+  const double* px = S.body + ((size_t)RB_PX * E + e) * RC_NB;
+  const double* py = S.body + ((size_t)RB_PY * E + e) * RC_NB;
+  if (r == R) {
+    o[R * 6 + 0] = (float)(((px[RC_BALL] * RC_STD_NORM) - 0.0) * 2.0);
+    o[R * 6 + 1] = (float)(((py[RC_BALL] * RC_STD_NORM) - 0.0) * 2.0);
+    o[R * 6 + 2] = (float)S.envi[(size_t)e * RE_COUNT + RE_OWNED];
+    return;
+  }
+  const double* ang = S.body + ((size_t)RB_ANG * E + e) * RC_NB;
+  const double x = (px[2 * r] + px[2 * r + 1]) / 2.0, y = (py[2 * r] + py[2 * r + 1]) / 2.0;  // Robot.getPos
+  const DevSC a = dev_sincos((ang[2 * r] + ang[2 * r + 1]) / 2.0);                             // Robot.getAngle
+  const int f = S.robi[((size_t)RI_FLAGS * E + e) * 16 + r];
+  o[r * 6 + 0] = (float)(((x * RC_STD_NORM) - 0.0) * 2.0);
+  o[r * 6 + 1] = (float)(((y * RC_STD_NORM) - 0.0) * 2.0);
+  o[r * 6 + 2] = (float)a.c;
+  o[r * 6 + 3] = (float)a.s;
+  o[r * 6 + 4] = (f & RF_TEAMPOS) ? 1.0f : -1.0f;
+  o[r * 6 + 5] = (f & (RF_FALLEN | RF_PENAL)) ? 1.0f : 0.0f;
 }
 
 // ------------------------------------------------------------------------------------------------

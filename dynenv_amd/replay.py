@@ -27,17 +27,23 @@ class ReplayRecorder(object):
                          noise_type=int(c.noise_type), noise_magnitude=float(c.noise_magnitude), seed=int(c.seed),
                          env_id_offset=int(c.env_id_offset), flags=int(c.flags))
         self.checkpoint = env.checkpoint()
-        self.actions, self.digests = [], []
+        self.actions, self.heads, self.digests = [], [], []
 
     def step(self, actions, auto_reset=True):
+        # what the kernel is given: the discrete channels as int32 and, with allowHeadTurn, the continuous head action as
+        # float64 (RoboCupEnvironment.py:339-342) - recorded bit for bit, not truncated
+        a, head = self.env._stage_actions(actions)
         out = self.env.step_flat(actions, auto_reset=auto_reset)
-        self.actions.append(actions.detach().cpu().numpy().astype(np.int8))
+        self.actions.append(a.detach().cpu().numpy().astype(np.int8))
+        if head is not None:
+            self.heads.append(head.detach().cpu().numpy().astype(np.float64))
         self.digests.append(_reward_digest(out[1], out[2]))
         return out
 
     def save(self, path):
+        extra = {"heads": np.stack(self.heads)} if self.heads else {}
         np.savez_compressed(path, checkpoint=self.checkpoint, actions=np.stack(self.actions), digests=np.stack(self.digests),
-                            auto_reset=np.array(1, np.int8), **{"meta_" + k: np.array(v) for k, v in self.meta.items()})
+                            auto_reset=np.array(1, np.int8), **extra, **{"meta_" + k: np.array(v) for k, v in self.meta.items()})
 
 
 def replay(path, device=None, on_step=None):
@@ -50,8 +56,12 @@ def replay(path, device=None, on_step=None):
                         device=device, env_id_offset=m["env_id_offset"], flags=m["flags"])
     env.restore(z["checkpoint"])
     acts, digs = z["actions"], z["digests"]
+    heads = z["heads"] if "heads" in z.files else None
     for i in range(acts.shape[0]):
-        a = torch.tensor(acts[i].astype(np.int32), device=env.device)
+        if heads is not None:  # (discrete [E, A, 3], head [E, A] float64): the continuous head channel as recorded
+            a = (acts[i][..., :3].astype(np.int32), heads[i])
+        else:
+            a = torch.tensor(acts[i].astype(np.int32), device=env.device)
         out = env.step_flat(a)
         d = _reward_digest(out[1], out[2])
         assert np.array_equal(d, digs[i]), "replay diverged at step %d" % i

@@ -516,6 +516,16 @@ class BatchedDynEnv(object):
         _capi.check(self._lib.dynenv_full_obs(self._h, C.c_void_p(out.data_ptr()), self._stream()), "dynenv_full_obs")
         return out
 
+    def global_state(self):
+        """RoboCup: getFullState(agent=None) of the current state for every environment, float32 [E, 6 A + 3] on the device -
+        robots [A, 6] = (x, y, cos, sin, team, fallen | penalized) in field coordinates, then the ball (x, y, ballOwned) - the
+        content of info['Full State'] (RoboCupEnvironment.py:511, :1149-1161)."""
+        if self.env_type != DynEnvType.ROBO_CUP:
+            raise NotImplementedError("Driving's getFullState(None) is made of columns of full_state_obs()")
+        out = self._torch.empty((self.num_envs, 6 * self.n_agents + 3), dtype=self._torch.float32, device=self.device)
+        _capi.check(self._lib.dynenv_global_state(self._h, C.c_void_p(out.data_ptr()), self._stream()), "dynenv_global_state")
+        return out
+
     def refresh_obs(self):
         """Re-emit the observation of the current state into `self.obs` (after set_state / restore).  Full observations only:
         a Partial observation is a noisy draw keyed by the step that produced it."""
@@ -623,17 +633,19 @@ class BatchedDynEnv(object):
     def _wrap_obs(self, obs_np, counts):
         return self._compat_obs(obs_np, counts) if self.eager_compat else LazyObsArray(self, obs_np, counts)
 
-    def _full_states(self, full_np, counts, e):
+    def _full_states(self, full_np, counts, e, glob_np=None):
         """info['Full State'] / info['Recon States'] (DrivingEnvironment.py:306-307, RoboCupEnvironment.py:511-512) of env e from
-        the noise-free Full rows [E, A, full_obs_dim] of the state after the step (whatever the observation type)."""
+        the noise-free Full rows [E, A, full_obs_dim] of the state after the step (whatever the observation type) and, for
+        RoboCup, the rows of dynenv_global_state [E, 6 A + 3]."""
         A = self.n_agents
-        if self.env_type == DynEnvType.ROBO_CUP:  # getFullState(agent) = [ball, self, robots] (:1164-1188)
-            recon = []
+        if self.env_type == DynEnvType.ROBO_CUP:
+            recon = []  # getFullState(agent) = [ball, self, robots] (:1164-1188)
             for a in range(A):
                 r = full_np[e, a]
                 recon.append([r[0:4].reshape(1, 4).copy(), r[4:12].reshape(1, 8).copy(),
                               r[12:12 + (A - 1) * 6].reshape(A - 1, 6).copy()])
-            return recon[0], recon  # (the reference's agent=None variant is un-normalised; not reproduced)
+            g = glob_np[e]  # getFullState(None) = [robots [A, 6], ball [3]] (:1149-1161)
+            return [g[:6 * A].reshape(A, 6).copy(), g[6 * A:6 * A + 3].copy()], recon
         n_obst, n_ped = int(counts[e, 0]), int(counts[e, 1])
         o1 = 9 + (A - 1) * 7
         o2, o3 = o1 + 80, o1 + 120
@@ -663,6 +675,7 @@ class BatchedDynEnv(object):
         # the state behind info['Full State'] / info['Recon States']: with Full observations it is the step's last snapshot; with
         # Partial ones a noise-free Full row is emitted now (one short launch) and copied to the host only if somebody asks
         full_dev = self.full_state_obs() if self.observationType != ObservationType.FULL else None
+        glob_dev = self.global_state() if self.env_type == DynEnvType.ROBO_CUP else None  # 252 B per environment, one short launch
         rewards = self.rewards.cpu().numpy().copy()
         done = bool(self.last_done)
         dones = np.full((self.num_envs,), done, dtype=bool)
@@ -676,6 +689,13 @@ class BatchedDynEnv(object):
             if "full" not in cache:
                 cache["full"] = full_dev.cpu().numpy() if full_dev is not None else lazy_obs._dense[:, -1]
             return cache["full"]
+
+        def glob_np():
+            if glob_dev is None:
+                return None
+            if "glob" not in cache:
+                cache["glob"] = glob_dev.cpu().numpy()
+            return cache["glob"]
         stats = term = None
         if done:
             stats = [x.cpu().numpy() for x in self.episode_stats()]
@@ -689,7 +709,7 @@ class BatchedDynEnv(object):
                 eager["episode_o_r"] = stats[2][e].copy() if self.env_type == DynEnvType.ROBO_CUP else [0, ] * self.n_agents
                 eager["episode_g"] = [int(stats[3][e, 0]), int(stats[3][e, 1])]
                 eager["terminal_observation"] = [list(term[e, t]) for t in range(self.n_time_steps)]
-            return LazyInfo(lambda: self._full_states(full_np(), counts, e), eager)
+            return LazyInfo(lambda: self._full_states(full_np(), counts, e, glob_np()), eager)
         infos = LazyInfos(self.num_envs, make_info)
         if self.eager_compat:
             infos = tuple(infos)

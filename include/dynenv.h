@@ -167,6 +167,16 @@ int dynenv_step(dynenv_t* h, const int32_t* actions_dev, float* obs_dev, double*
 int dynenv_full_obs_dim(const dynenv_t* h);
 int dynenv_full_obs(dynenv_t* h, float* full_dev, void* stream);
 
+/* RoboCup's info['Full State'] = getFullState(agent=None) of the CURRENT state (RoboCupEnvironment.py:511, :1149-1161), which is
+ * NOT a per-agent row of dynenv_full_obs: robots float32 [A][6] = (normalize(x, standardNorm, 0), normalize(y, standardNorm, 0),
+ * cos a, sin a, team, fallen | penalized) in field coordinates (no team flip; normalize = cutils.py:318-323), then the ball
+ * [3] = (normalize(bx), normalize(by), ballOwned): state_dev float32 [E, dynenv_global_state_dim(h)] with dim = 6 A + 3.
+ * The reference's trainer reads the robots' last column from it (models/train.py:272).  Driving: dim 0 and
+ * DYNENV_ERR_UNSUPPORTED - its getFullState(None) (DrivingEnvironment.py:697-711) is columns {0..5, 8} of every car's own self
+ * block in dynenv_full_obs plus the shared obstacle / pedestrian / lane blocks, bit for bit. */
+int dynenv_global_state_dim(const dynenv_t* h);
+int dynenv_global_state(dynenv_t* h, float* state_dev, void* stream);
+
 /* dynenv_step with the reference's continuous head action: RoboCup built with allowHeadTurn (make_dyn_env's
  * use_continuous_actions, DynEnv/__init__.py:11) takes Tuple((MultiDiscrete([5, 3, 3]), Box(-3, 3, (1,))))
  * (RoboCupEnvironment.py:339-342); head_dev float64 [E, A] carries the Box channel (turnHead(head), Robot.py:136-138),
@@ -174,6 +184,13 @@ int dynenv_full_obs(dynenv_t* h, float* full_dev, void* stream);
  * does).  DYNENV_ERR_ARG unless the handle is RoboCup with DYNENV_FLAG_ALLOW_HEAD_TURN. */
 int dynenv_step_head(dynenv_t* h, const int32_t* actions_dev, const double* head_dev, float* obs_dev, double* rewards_dev,
                      uint8_t* dones_dev, void* stream);
+
+/* Measurement hook (bench.py's roofline leg): three caller-owned hipEvent_t (as void*; NULL = none, all NULL = off) that every
+ * following dynenv_step / dynenv_step_head records on ITS launch stream - before the step's dominant kernel (drv_step_kernel,
+ * rc_step_kernel, drv_step_partial_kernel, rc_step_partial_kernel), right after it, and after the step's last kernel (the
+ * deferred-observation / finalize launches of the Partial paths).  hipEventElapsedTime(begin, main_done) is that kernel's own
+ * launch duration.  The events are overwritten by the next step: synchronise on ev_end before stepping again. */
+int dynenv_set_step_events(dynenv_t* h, void* ev_begin, void* ev_main_done, void* ev_end);
 
 /* Per-env object counts of the current episode: int32 [E, 2] = (n_obstacles, n_pedestrians) (Driving). */
 int dynenv_counts(dynenv_t* h, int32_t* counts_dev, void* stream);

@@ -373,6 +373,7 @@ int oracle_rc_begin(oracle_t* o, int env, int slotA, int slotB, double* rew22) {
 }
 int oracle_rc_joint_count(oracle_t* o, int env) { return o->rc[env].space.n_constraints; }
 void oracle_rc_obs(oracle_t* o, int env, float* out) { rc_write_full_obs(&o->rc[env], out); }
+void oracle_rc_global_state(oracle_t* o, int env, float* out) { rc_write_global_state(&o->rc[env], out); }
 void oracle_rc_spots(const double* rnd18, double* out20) {
   cpv spots[2][5]; int t, i;
   rc_spots(rnd18, spots);

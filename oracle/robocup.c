@@ -666,6 +666,29 @@ void rc_write_full_obs(const RoboCupEnv* e, float* out) {
   }
 }
 
+/* getFullState(agent=None) :1149-1161 - what step() puts into info['Full State'] (:511): robots [R][6] = (normalize(x,
+ * standardNorm, 0), normalize(y, ...), cos a, sin a, team, fallen | penalized) in field coordinates (no team flip), then the
+ * ball [3] = (normalize(bx, ...), normalize(by, ...), ballOwned); normalize = cutils.py:318-323 */
+static inline double norm_plain(double pt, double nf) { return ((pt * nf) - 0.0) * 2.0 * 1.0; }
+void rc_write_global_state(const RoboCupEnv* e, float* out) {
+  int R = e->nRobots, a;
+  for (a = 0; a < R; ++a) {
+    const Robot* rb = &e->robots[a];
+    cpv p = rc_robot_pos(rb);
+    double s, c;
+    float* o = out + (size_t)a * 6;
+    o[0] = (float)norm_plain(p.x, RC_STD_NORM);
+    o[1] = (float)norm_plain(p.y, RC_STD_NORM);
+    dm_sincos(robot_angle(rb), &s, &c);
+    o[2] = (float)c; o[3] = (float)s;
+    o[4] = (float)rb->team;
+    o[5] = (float)(rb->fallen || rb->penalized);
+  }
+  out[R * 6 + 0] = (float)norm_plain(e->ballBody.p.x, RC_STD_NORM);
+  out[R * 6 + 1] = (float)norm_plain(e->ballBody.p.y, RC_STD_NORM);
+  out[R * 6 + 2] = (float)e->ballOwned;
+}
+
 /* ------------------------------------------------------------------ step :446-524 */
 /* processSeens (RoboCupEnvironment.py, `def processSeens`) for one robot: sums over the step's 5 snapshots of numLandMarks,
  * of each other robot's seen flag, and of ballsSeen -> the observation reward */

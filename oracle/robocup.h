@@ -62,6 +62,7 @@ int rc_obs_dim(int nPlayers);
 void rc_init(RoboCupEnv* e, int nPlayers, uint64_t seed, uint32_t genv, int flags);
 void rc_reset(RoboCupEnv* e);
 void rc_write_full_obs(const RoboCupEnv* e, float* out /* [2n][obs_dim] */);
+void rc_write_global_state(const RoboCupEnv* e, float* out /* [2n * 6 + 3] */);
 int rc_step(RoboCupEnv* e, const int32_t* actions /* [2n][4] */, float* obs /* [5][2n][obs_dim] or NULL */, double* rewards);
 
 double rc_process_seens(double lSum, const double* rSum, int nOthers, double bSum);

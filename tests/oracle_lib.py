@@ -177,6 +177,13 @@ class OracleEnv:
         rc = self.l.oracle_set_state(self.h, env, C.byref(st), C.sizeof(st))
         assert rc == 0
 
+    def global_state(self):
+        """RoboCup getFullState(agent=None) of every environment: float32 [E, 6 A + 3]"""
+        out = np.zeros((self.E, 6 * self.A + 3), np.float32)
+        for e in range(self.E):
+            self.l.oracle_rc_global_state(self.h, e, _p(out[e]))
+        return out
+
     def overflow(self):
         return self.l.oracle_overflow(self.h)
 

@@ -107,11 +107,126 @@ def test_full_state_with_partial_observations_is_the_oracles_true_state(gpu, kin
                 else:
                     np.testing.assert_array_equal(recon[ag][0], oc[e, -1, ag, 0:9].reshape(1, 9))
                     np.testing.assert_array_equal(recon[ag][1], oc[e, -1, ag, 9:9 + (A - 1) * 7].reshape(A - 1, 7))
-            assert infos[e]["Full State"] is not None
+            full = infos[e]["Full State"]
+            if robocup:  # getFullState(None): [robots [A, 6], ball [3]] (contents: test_robocup_full_state_is_getFullState_none)
+                assert len(full) == 2 and full[0].shape == (A, 6) and full[1].shape == (3,)
+            else:        # [cars [A, 7], obstacles, pedestrians, lanes]
+                assert len(full) == 4 and full[0].shape == (A, 7)
         locs = env.env_method("get_agent_locs", indices=[1])[0]   # the true poses, not the noisy self rows
         for ag in range(A):
             np.testing.assert_array_equal(locs[ag][0], oc[1, -1, ag, 4:10] if robocup else oc[1, -1, ag, 0:4])
     env.close()
+
+
+@pytest.mark.parametrize("obs", [None, "partial"])
+def test_robocup_full_state_is_getFullState_none(gpu, obs):
+    """info['Full State'] of RoboCup is getFullState(agent=None) (RoboCupEnvironment.py:511, :1149-1161): [robots [A, 6] in field
+    coordinates, ball [3]] - not an agent's 'Recon States' triple - bit-identical to the oracle (which the reference's own
+    method pins, tests/test_oracle_golden_robocup_r3.py), and the reference trainer's line over it (models/train.py:272) gives the
+    fallen | penalized flag of every robot."""
+    dynenv_amd, torch, _ = gpu
+    from dynenv_amd import DynEnvType, NoiseType, ObservationType
+    E, n = 12, 5
+    kw = dict(observationType=ObservationType.PARTIAL, noiseType=NoiseType.REALISTIC, noiseMagnitude=3) if obs else {}
+    flags = ol.ROBOCUP_DEFAULT_FLAGS
+    env = dynenv_amd.BatchedDynEnv(DynEnvType.ROBO_CUP, E, n, seed=17, flags=flags, **kw)
+    ora = ol.OracleEnv(env_type=0, num_envs=E, n_players=n, seed=17, flags=flags)
+    env.reset()
+    ora.reset()
+    rng = np.random.default_rng(4)
+    A = env.n_agents
+    assert int(env._lib.dynenv_global_state_dim(env._h)) == 6 * A + 3
+    downs = 0
+    for s in range(40):
+        a = _acts(rng, env)
+        new_obs, rew, dones, state = env.step(a)
+        ora.step(a)
+        if s % 4 and s < 36:
+            continue
+        g = ora.global_state()
+        np.testing.assert_array_equal(env.global_state().cpu().numpy(), g, err_msg="step %d" % s)
+        for e in (0, 5, E - 1):
+            full = state[e]["Full State"]
+            assert len(full) == 2 and full[0].shape == (A, 6) and full[1].shape == (3,) and full[0].dtype == np.float32
+            np.testing.assert_array_equal(full[0], g[e, :6 * A].reshape(A, 6))
+            np.testing.assert_array_equal(full[1], g[e, 6 * A:])
+            st = ora.get_state(e)
+            np.testing.assert_array_equal(full[0][:, 4], [st.robots[r].team for r in range(A)])
+            assert full[1][2] == st.ball_owned
+        # models/train.py:272, verbatim
+        agentFinished = torch.tensor([[agent[-1] for agent in s_['Full State'][0]] for s_ in state]).bool()
+        assert tuple(agentFinished.shape) == (E, A)
+        exp = [[bool(ora.get_state(e).robots[r].fallen or ora.get_state(e).robots[r].penalized) for r in range(A)] for e in range(E)]
+        assert agentFinished.tolist() == exp
+        downs += int(agentFinished.sum())
+        # models/train.py:270-271 on 'Recon States' keeps working beside it
+        fullStates = [[x[0::2] for x in s_['Recon States']] for s_ in state]
+        assert len(fullStates) == E and len(fullStates[0]) == A and len(fullStates[0][0]) == 2
+    assert downs > 0, "some robot must have fallen or been penalized in 40 steps with the fall dice on"
+    env.close()
+
+
+def test_driving_full_state_feeds_the_trainers_line(gpu):
+    """the same consumer line on Driving (DrivingEnvironment.py:306, :697-711: cars [A, 7] with `finished` last)"""
+    dynenv_amd, torch, _ = gpu
+    E, n = 6, 10
+    env = dynenv_amd.BatchedDynEnv(dynenv_amd.DynEnvType.DRIVE, E, n, seed=17)
+    ora = ol.OracleEnv(env_type=1, num_envs=E, n_players=n, seed=17)
+    env.reset()
+    ora.reset()
+    rng = np.random.default_rng(4)
+    for s in range(30):
+        a = _acts(rng, env)
+        new_obs, rew, dones, state = env.step(a)
+        oc, _, _ = ora.step(a)
+    agentFinished = torch.tensor([[agent[-1] for agent in s_['Full State'][0]] for s_ in state]).bool()
+    assert tuple(agentFinished.shape) == (E, n)
+    assert agentFinished.tolist() == [[bool(ora.get_state(e).cars[c].finished) for c in range(n)] for e in range(E)]
+    cars = state[2]["Full State"][0]
+    assert cars.shape == (n, 7)
+    np.testing.assert_array_equal(cars, oc[2, -1][:, [0, 1, 2, 3, 4, 5, 8]])
+    env.close()
+
+
+def test_replay_with_the_continuous_head_channel_across_an_episode_end(gpu, tmp_path):
+    """a use_continuous_actions=True RoboCup run (float head turns, RoboCupEnvironment.py:339-342) recorded to a replay file and
+    re-run on a fresh handle: the head channel travels as float64, so rewards and dones reproduce bit for bit - also after the
+    lock-step reset in the middle of the recording"""
+    dynenv_amd, torch, _ = gpu
+    from dynenv_amd import DynEnvType, NoiseType, ObservationType, make_dyn_env
+    from dynenv_amd.replay import ReplayRecorder, replay
+    E, n = 6, 5
+    venv, _ = make_dyn_env(DynEnvType.ROBO_CUP, E, n, False, ObservationType.FULL, NoiseType.REALISTIC, 0, True, seed=11)
+    venv.reset_flat()
+    rng = np.random.default_rng(8)
+    S = venv.steps_per_episode
+
+    def act():
+        a = _acts(rng, venv).astype(np.float64)
+        a[..., 3] = (rng.random((E, 2 * n)) - 0.5) * 5.9   # fractional head turns: an int8 recording would change the run
+        return a
+    for s in range(S - 5):
+        venv.step_flat(act())
+    rec = ReplayRecorder(venv)
+    seen_done = 0
+    for s in range(14):
+        rec.step(act())
+        seen_done += int(venv.last_done)
+    assert seen_done == 1
+    path = str(tmp_path / "head.npz")
+    rec.save(path)
+    z = np.load(path)
+    assert z["heads"].dtype == np.float64 and z["heads"].shape == (14, E, 2 * n) and np.abs(z["heads"] - np.round(z["heads"])).max() > 0.1
+    final = venv.rewards.cpu().numpy().copy()
+    env2, nsteps = replay(path)           # asserts the digest of every step
+    assert nsteps == 14 and env2.allow_head_turn
+    np.testing.assert_array_equal(env2.rewards.cpu().numpy(), final)
+    for e in range(E):
+        assert ol.rc_state_to_dict(env2.get_state(e)).keys() == ol.rc_state_to_dict(venv.get_state(e)).keys()
+        a, b = ol.rc_state_to_dict(env2.get_state(e)), ol.rc_state_to_dict(venv.get_state(e))
+        for k in a:
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    venv.close(); env2.close()
 
 
 @pytest.mark.parametrize("flags", [ol.FLAG_RANDOM_INIT | ol.FLAG_CAN_FALL, ol.FLAG_DETERMINISTIC_TURN | ol.FLAG_CAN_FALL,

@@ -4,6 +4,3 @@ set -e
 cd "$(dirname "$0")/.."
 python -c "from dynenv_amd import build; build.build(force=True)"
 python -c "from dynenv_amd import build as b; b.build(out='dynenv_amd/libdynenv_hip_prof.so', defines=('DRV_PROFILE',))"
-# the RoboCup build variants tools/robocup_variants.sh compares (register-resident robot-per-lane substep; + scheduler)
-python -c "from dynenv_amd import build as b; b.build(out='dynenv_amd/libdynenv_hip_rpl2.so', defines=('RC_FULL_EPW=2',))"
-python -c "from dynenv_amd import build as b; b.build(out='dynenv_amd/libdynenv_hip_sched.so', defines=('RC_FULL_EPW=2', 'RC_SCHED=1'))"

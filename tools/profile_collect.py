@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Collect what tools/profile_round.sh measured: gpurun_out/pmc_traffic.json (per kernel and per whole step, stamped with the
+kernel-source hash bench.py checks) and the SQ breakdowns.  Usage: python3 tools/profile_collect.py TAG workload..."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (kernel_source_sha, nothing else)
+
+STEP_KERNELS = {"driving": ["drv_step_kernel"], "robocup": ["rc_step_kernel"],
+                "driving_partial": ["drv_step_partial_kernel", "drv_partial_obs_deferred_kernel"],
+                "robocup_partial": ["rc_step_partial_kernel", "rc_partial_obs_deferred_kernel", "rc_partial_finalize_kernel"]}
+
+
+def counters(pattern):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(pattern):
+        for r in csv.DictReader(open(f)):
+            agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+
+def main():
+    tag, workloads = sys.argv[1], sys.argv[2:]
+    path = "gpurun_out/pmc_traffic.json"
+    out = {}
+    if os.path.exists(os.path.join(ROOT, "profiles", "pmc_traffic.json")):
+        old = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if old.get("kernel_source_sha16") == bench.kernel_source_sha():
+            out = old  # same kernels: keep the workloads not re-measured in this call
+    out["note"] = ("bytes per launch, mean over the launches of whole episodes at 4096 envs; rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in "
+                   "separate passes, FETCH_SIZE x 2 (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md) + WRITE_SIZE, both in KB; "
+                   "step_bytes_all_kernels adds the Partial paths' deferred / finalize launches; tools/profile_round.sh")
+    out["kernel_source_sha16"] = bench.kernel_source_sha()
+    out["tag"] = tag
+    for w in workloads:
+        f = counters("gpurun_out/%s_prof_%s_f/*/*counter_collection.csv" % (tag, w))
+        wr = counters("gpurun_out/%s_prof_%s_w/*/*counter_collection.csv" % (tag, w))
+        total = 0.0
+        per = {}
+        for k in STEP_KERNELS[w]:
+            if k not in f or k not in wr:
+                continue
+            fv, wv = f[k]["FETCH_SIZE"], wr[k]["WRITE_SIZE"]
+            fb, wb = sum(fv) / len(fv) * 1024 * 2, sum(wv) / len(wv) * 1024
+            per[k] = {"fetch_bytes_x2": fb, "write_bytes": wb, "launches": len(fv), "workload": w}
+            total += fb + wb
+        for k, d in per.items():
+            d["step_bytes_all_kernels"] = total
+            out[k + "_bytes_per_launch"] = d["fetch_bytes_x2"] + d["write_bytes"]
+            out[k + "_detail"] = d
+        lines = []
+        for p in ("s1", "s2"):
+            c = counters("gpurun_out/%s_prof_%s_%s/*/*counter_collection.csv" % (tag, w, p))
+            k = STEP_KERNELS[w][0]
+            for name in sorted(c.get(k, {})):
+                v = c[k][name]
+                lines.append("%-22s n=%d mean=%.5g  first50=%.5g last50=%.5g" % (name, len(v), sum(v) / len(v), sum(v[:50]) / 50, sum(v[-50:]) / 50))
+        if lines:
+            m = {ln.split()[0]: float(ln.split("mean=")[1].split()[0]) for ln in lines}
+            wc = m.get("SQ_WAVE_CYCLES")
+            if wc:
+                lines.append("")
+                lines.append("shares of a wave's lifetime (quad-cycles of SQ_WAVE_CYCLES): executing an instruction %.1f %% (VALU %.1f %%, scalar %.1f %%, LDS %.1f %%), "
+                             "parked in s_waitcnt / barrier (SQ_WAIT_ANY) %.1f %%, issue stalls (SQ_WAIT_INST_ANY) %.1f %%"
+                             % tuple(100 * m.get(x, 0) / wc for x in ("SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY")))
+                if "SQ_WAVES" in m and m["SQ_WAVES"]:
+                    lines.append("per wave and step: VALU %.0f, SALU %.0f, LDS %.0f, branches %.0f, VMEM rd %.0f / wr %.0f instructions"
+                                 % tuple(m.get(x, 0) / m["SQ_WAVES"] for x in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")))
+                if "SQ_BUSY_CYCLES" in m and m["SQ_BUSY_CYCLES"]:
+                    # 1024 SIMDs x launch cycles of quad-cycles were available; ACTIVE_INST_VALU / (BUSY_CYCLES summed over SQs) ~ VALU busy
+                    lines.append("SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES = %.3f (VALU-busy share of the time the SQs had waves)" % (m.get("SQ_ACTIVE_INST_VALU", 0) / m["SQ_BUSY_CYCLES"]))
+            open("gpurun_out/%s_sq_breakdown_%s.txt" % (tag, w), "w").write(
+                "%s, 4096 envs, one whole episode (kernel sources %s); rocprofv3 --pmc, per launch\n" % (STEP_KERNELS[w][0], bench.kernel_source_sha()) + "\n".join(lines) + "\n")
+    json.dump(out, open(path, "w"), indent=1)
+    print(json.dumps({k: v for k, v in out.items() if k.endswith("_bytes_per_launch") or k == "kernel_source_sha16"}, indent=1))
+
+
+if __name__ == "__main__":
+    main()

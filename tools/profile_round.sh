@@ -1,0 +1,32 @@
+#!/bin/bash
+# The judged profiling artifacts of a round, ONE workload per rocprofv3 run (no 1-env launches mixed in: --no-extra-legs):
+#   1. rocprofv3 --kernel-trace --stats        -> gpurun_out/<TAG>_kernel_stats_<workload>.csv   (+ the bench line printed under it)
+#   2. rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) for EVERY kernel of the step, the Partial paths' deferred /
+#      finalize launches included -> gpurun_out/pmc_traffic.json, stamped with the hash of the kernel sources (bench.py reports
+#      roofline.traffic from profiles/pmc_traffic.json only while that hash matches)
+#   3. SQ counters (two passes) of the Full step kernels -> gpurun_out/<TAG>_sq_breakdown_<workload>.txt
+# Every run is `bench.py --workload W --steps <one episode> --warmup 0`: all launches are whole-episode launches at 4096 envs.
+# Usage (GPU box): bash tools/profile_round.sh r03_a ["driving robocup driving_partial robocup_partial"]; then copy into profiles/.
+TAG=${1:-rXX}
+WORKLOADS=${2:-"driving robocup driving_partial robocup_partial"}
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+B="--warmup 0 --no-cpu-baseline --no-extra-legs"
+for W in $WORKLOADS; do
+  case $W in robocup*) STEPS=240;; *) STEPS=600;; esac
+  D=gpurun_out/${TAG}_prof_$W
+  rm -rf $D ${D}_f ${D}_w
+  rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 bench.py --workload $W --steps $STEPS $B > gpurun_out/${TAG}_bench_${W}_under_rocprof.json 2> $D.err || exit 1
+  cp "$(ls $D/*/*kernel_stats.csv | head -1)" gpurun_out/${TAG}_kernel_stats_$W.csv
+  echo "[profile_round] $W kernel stats done"
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d ${D}_f -- python3 bench.py --workload $W --steps $STEPS $B > /dev/null 2> ${D}_f.err || exit 1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d ${D}_w -- python3 bench.py --workload $W --steps $STEPS $B > /dev/null 2> ${D}_w.err || exit 1
+  echo "[profile_round] $W traffic passes done"
+  case $W in driving|robocup)
+    rm -rf ${D}_s1 ${D}_s2
+    rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS --output-format csv -d ${D}_s1 -- python3 bench.py --workload $W --steps $STEPS $B > /dev/null 2> ${D}_s1.err || exit 1
+    rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES --output-format csv -d ${D}_s2 -- python3 bench.py --workload $W --steps $STEPS $B > /dev/null 2> ${D}_s2.err || exit 1
+    echo "[profile_round] $W SQ passes done";;
+  esac
+done
+python3 tools/profile_collect.py $TAG $WORKLOADS
