@@ -170,23 +170,26 @@ def episode_leg(torch, device, workload, E, seed, n_players=None):
     ms = k0.elapsed_time(k1) / ep_steps
     # the named kernel's OWN launch duration: a second pass over the same episode (same seed, same actions) with the library
     # recording HIP events on the launch stream right before and after that kernel (dynenv_set_step_events), a fresh event
-    # triple per step and no host wait in between, so the launches stay back to back as in the pass above and the Partial
-    # paths' trailing kernels are not counted
+    # set per step and no host wait in between, so the launches stay back to back as in the pass above and the Partial
+    # paths' trailing kernels are not counted.  An interval between two events contains one event record (a barrier packet,
+    # ~5 us here): its cost is measured by a fourth event recorded right behind the third and subtracted
     import ctypes as C
-    evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(ep_steps)]
+    evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(ep_steps)]
     for tr in evs:
         for ev in tr:
             ev.record()  # creates the hipEvent_t
     env.reset_flat()
     torch.cuda.synchronize(device)
     for i in range(ep_steps):
-        eb, em, ee = evs[i]
+        eb, em, ee, ex = evs[i]
         env._lib.dynenv_set_step_events(env._h, C.c_void_p(eb.cuda_event), C.c_void_p(em.cuda_event), C.c_void_p(ee.cuda_event))
         env.step_flat(pool[i & 15], auto_reset=False)
+        ex.record()  # nothing between `ee` and `ex`: their distance is what an event record itself costs on this stream
     env._lib.dynenv_set_step_events(env._h, None, None, None)
     torch.cuda.synchronize(device)
-    kern_ms = sum(eb.elapsed_time(em) for eb, em, ee in evs) / ep_steps
-    step_ms = sum(eb.elapsed_time(ee) for eb, em, ee in evs) / ep_steps
+    ev_cost = sum(ee.elapsed_time(ex) for eb, em, ee, ex in evs) / ep_steps
+    kern_ms = sum(eb.elapsed_time(em) for eb, em, ee, ex in evs) / ep_steps - ev_cost
+    step_ms = sum(eb.elapsed_time(ee) for eb, em, ee, ex in evs) / ep_steps - ev_cost
     err = env.error_flags()
     env.close()
     out = {"workload": workload, "reference": ref, "envs": E, "n_agents": A, "steps": ep_steps, "ms_per_step": ms,
@@ -196,7 +199,8 @@ def episode_leg(torch, device, workload, E, seed, n_players=None):
         traffic, tdetail = measured_traffic(kernel)
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            "traffic": traffic, "kernel": kernel, "launch_ms": kern_ms, "step_ms_all_kernels": step_ms,
-                           "step_ms_back_to_back": ms, "alg_bytes_per_env_step": b_alg, "env_steps_per_launch": E}
+                           "step_ms_back_to_back": ms, "event_record_cost_ms": ev_cost, "alg_bytes_per_env_step": b_alg,
+                           "env_steps_per_launch": E}
         out["roofline"].update(tdetail)
     return out
 
@@ -399,11 +403,37 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     gpu_ms = ev0.elapsed_time(ev1)
+    per_rank = None
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        # every rank's own wall clock and GPU time of the timed region: the line is self-checking (value uses the MAX)
+        mine = torch.tensor([elapsed, gpu_ms / args.steps], dtype=torch.float64, device=device)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [[float(x[0]), float(x[1])] for x in allr]
+        elapsed = max(x[0] for x in per_rank)
     err = env.error_flags()
+
+    # the lock-step variant in the same line (N > 1): the global view of step k is awaited before step k + 1 is launched
+    sync_leg = None
+    if gather is not None and not args.sync_gather:
+        n_sync = min(args.steps, 100)
+        env.use_buffers(slab.obs, slab.rewards, slab.dones)
+        for i in range(3):
+            env.step_flat(pool[i & 63])
+            gather()
+        fence()
+        ts = time.perf_counter()
+        for i in range(n_sync):
+            env.step_flat(pool[i & 63])
+            gather()
+        fence()
+        dt = time.perf_counter() - ts
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        sync_leg = {"steps": n_sync, "ms_per_step": dt / n_sync * 1e3, "value": E * world * n_sync * A / dt,
+                    "note": "--sync-gather semantics: all-gather of step k completed before step k + 1 is launched"}
 
     # roofline leg: the dominant kernel over one WHOLE episode (no reset, no collective), HIP events on the launch stream
     roofline = None
@@ -433,6 +463,10 @@ def main():
                        "rccl_world_size": (dist.get_world_size() if dist is not None else None)},
             "env_steps_per_s": env_steps / elapsed,
             "gpu_ms_per_step_rank0": gpu_ms / args.steps,
+            "per_rank": (None if per_rank is None else {
+                "wall_ms_per_step": [x[0] / args.steps * 1e3 for x in per_rank], "gpu_ms_per_step": [x[1] for x in per_rank],
+                "slowest_over_fastest": max(x[0] for x in per_rank) / min(x[0] for x in per_rank)}),
+            "sync_gather": sync_leg,
             "kernel_error_flags": err,
             "roofline": roofline,
         }

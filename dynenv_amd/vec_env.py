@@ -130,6 +130,16 @@ def _robocup_spaces(obs_type, allow_head_turn):
     return observation_space, action_space, reco
 
 
+def _to_host(t):
+    """Device tensor -> numpy through a PINNED staging tensor: torch's caching host allocator hands the block of the previous
+    step back (no 38 MB of fresh page faults per step, ~20 ms at 4096 envs) and the copy runs at PCIe speed.  The numpy array
+    keeps the tensor alive; every step gets its own block, as the reference returns fresh arrays."""
+    import torch
+    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    h.copy_(t)
+    return h.numpy()
+
+
 class LazyInfo(dict):
     """The per-environment `info` dict of the reference (subproc_vec_env.py:17-23, DrivingEnvironment.py:306-316) whose two
     expensive entries - 'Full State' and 'Recon States', lists of per-agent arrays - are built from the step's single
@@ -207,7 +217,7 @@ class LazyObsArray(object):
     def _dense(self):
         d = self._box[0]
         if not isinstance(d, np.ndarray):
-            d = self._box[0] = d.cpu().numpy()
+            d = self._box[0] = _to_host(d)
         return d
 
     @property
@@ -255,8 +265,8 @@ class LazyObsArray(object):
     def materialize(self):
         """The eager object ndarray of this (sub-)array, element for element what the reference returns."""
         E, T, A, _ = self._dense.shape
-        if all(isinstance(x, range) and x == range(n) for x, n in zip(self._sel, (E, T, A, 3))) and hasattr(self._owner, "_compat_obs"):
-            return self._owner._compat_obs(self._dense, self._counts)  # the whole array: the batched builder
+        if all(isinstance(x, range) and x == range(n) for x, n in zip(self._sel, (E, T, A, 3))) and hasattr(self._owner, "_compat_obs_bulk"):
+            return self._owner._compat_obs_bulk(self._dense, self._counts)  # the whole array: the bulk builder
         axes = [([s] if isinstance(s, int) else list(s)) for s in self._sel]
         out = np.empty(tuple(len(a) for a in axes), dtype=object)
         for ie, e in enumerate(axes[0]):
@@ -599,6 +609,72 @@ class BatchedDynEnv(object):
                     out[e, t, a, 2] = ones
         return out
 
+    def _compat_obs_bulk(self, obs_t, counts):
+        """`_compat_obs` without a Python-level loop over (env, time, agent): the per-agent arrays of a type are made by iterating
+        the type's block once in C (`np.fromiter(iter(block), object)`: one view per row), ragged blocks grouped by their row
+        count, and the reference's nested lists by `zip`.  Element for element what `_compat_obs` builds (the test compares
+        them); ~1 us per agent instead of 2.6 (five ndarray objects and two lists per agent remain - the reference's format)."""
+        import gc
+        import itertools
+        o = obs_t if isinstance(obs_t, np.ndarray) else _to_host(obs_t.detach())
+        E, T, A, D = o.shape
+        N = E * T * A
+        gc_was_on = gc.isenabled()
+        gc.disable()  # ~8 N container objects are about to be allocated: every 700th would trigger a collection pass over them
+        try:
+            return self._compat_obs_bulk_build(o, counts, E, T, A, D, N)
+        finally:
+            if gc_was_on:
+                gc.enable()
+
+    def _compat_obs_bulk_build(self, o, counts, E, T, A, D, N):
+        import itertools
+        L = self.layout
+        off, rows, feat = list(L.block_offset), list(L.block_rows), list(L.block_feat)
+        flat = o.reshape(N, D)
+
+        def views(lo, cap, f, lens=None, dtype=None):
+            block = flat[:, lo:lo + cap * f].reshape(N, cap, f)
+            if dtype is not None:
+                block = block.astype(dtype)
+            if lens is None:
+                return np.fromiter(iter(block), dtype=object, count=N)
+            res = np.empty(N, dtype=object)
+            for n in np.unique(lens):
+                pos = np.nonzero(lens == n)[0]
+                res[pos] = np.fromiter(iter(block[pos, :int(n)]), dtype=object, count=len(pos))
+            return res
+
+        def lists(*cols):
+            return np.fromiter(map(list, zip(*cols)), dtype=object, count=N)
+        out = np.empty((N, 3), dtype=object)
+        ones = np.fromiter(itertools.repeat((1, 1, 1), N), dtype=object, count=N)
+        if self.env_type == DynEnvType.ROBO_CUP and self.observationType == ObservationType.PARTIAL:
+            tail = off[6]
+            n = flat[:, tail:tail + 6].astype(np.int64)
+            v = [views(off[k], rows[k], feat[k], n[:, k]) for k in range(6)]
+            seen = np.fromiter(iter(flat[:, tail + 8:tail + 8 + (A - 1)].astype("uint8")), dtype=object, count=N)
+            out[:, 0] = lists(v[0], v[1])
+            out[:, 1] = lists(v[2], v[3], v[4], v[5])
+            out[:, 2] = np.fromiter(zip(flat[:, tail + 6].astype(np.int64).tolist(), seen, (flat[:, tail + 7] != 0).tolist()),
+                                    dtype=object, count=N)
+        elif self.env_type == DynEnvType.ROBO_CUP:
+            out[:, 0] = lists(views(0, 1, 4), views(12, A - 1, 6))
+            out[:, 1] = lists(views(4, 1, 8))
+            out[:, 2] = ones
+        elif self.observationType == ObservationType.PARTIAL:
+            n = flat[:, D - 4:].astype(np.int64)
+            out[:, 0] = lists(views(off[1], rows[1], 7, n[:, 0]), views(off[2], rows[2], 6, n[:, 1]), views(off[3], rows[3], 2, n[:, 2]))
+            out[:, 1] = lists(views(0, 1, 9), views(off[4], rows[4], 4, n[:, 3]))
+            out[:, 2] = ones
+        else:
+            c = np.asarray(counts).astype(np.int64)
+            n_obst, n_ped = np.repeat(c[:, 0], T * A), np.repeat(c[:, 1], T * A)
+            out[:, 0] = lists(views(off[1], rows[1], 7), views(off[2], rows[2], 4, n_obst), views(off[3], rows[3], 2, n_ped))
+            out[:, 1] = lists(views(off[0], 1, 9), views(off[4], rows[4], 5))
+            out[:, 2] = ones
+        return out.reshape(E, T, A, 3)
+
     def _compat_element(self, o, counts, e, t, a):
         """One element [e, t, a] of the reference's observation array: [movable-object arrays, static / self arrays, seen info]
         (the same views / values `_compat_obs` assembles for the whole batch)."""
@@ -631,7 +707,7 @@ class BatchedDynEnv(object):
         return self._counts_np
 
     def _wrap_obs(self, obs_np, counts):
-        return self._compat_obs(obs_np, counts) if self.eager_compat else LazyObsArray(self, obs_np, counts)
+        return self._compat_obs_bulk(obs_np, counts) if self.eager_compat else LazyObsArray(self, obs_np, counts)
 
     def _full_states(self, full_np, counts, e, glob_np=None):
         """info['Full State'] / info['Recon States'] (DrivingEnvironment.py:306-307, RoboCupEnvironment.py:511-512) of env e from
@@ -718,7 +794,7 @@ class BatchedDynEnv(object):
             self.reset_flat()
             obs = self._wrap_obs(self.obs.clone() if not self.eager_compat else self.obs.cpu().numpy(), self._host_counts())
         else:
-            obs = self._compat_obs(lazy_obs._dense, counts) if self.eager_compat else lazy_obs
+            obs = self._compat_obs_bulk(lazy_obs._dense, counts) if self.eager_compat else lazy_obs
         return obs, rewards, dones, infos
 
     def step(self, actions):

@@ -91,6 +91,16 @@ int oracle_layout(const oracle_t* o, dynenv_layout_t* L) {
     L->block_offset[3] = L->block_offset[2] + DYNENV_MAX_OBST * 4; L->block_rows[3] = DYNENV_MAX_PEDS; L->block_feat[3] = 2;
     L->block_offset[4] = L->block_offset[3] + DYNENV_MAX_PEDS * 2; L->block_rows[4] = DYNENV_DRIVE_LANES; L->block_feat[4] = 5;
     L->steps_per_episode = DRV_MAX_TIME / DRV_STEP_ITER;
+  } else if (o->cfg.obs_type == DYNENV_OBS_PARTIAL) {
+    /* ((balls, robots), (goals, crosses, line crosses, lines), (numLandMarks, robotsSeen, ballsSeen)) of getAgentVision; block 6 =
+     * the tail: 6 list lengths, numLandMarks, ballsSeen, robotsSeen[9] (oracle/robocup_partial.h) */
+    const int off[7] = {RCP_OFF_BALL, RCP_OFF_ROB, RCP_OFF_GOAL, RCP_OFF_CROSS, RCP_OFF_FCROSS, RCP_OFF_LINE, RCP_OFF_TAIL};
+    const int rows[7] = {RCP_CAP_BALL, RCP_CAP_ROB, RCP_CAP_GOAL, RCP_CAP_CROSS, RCP_CAP_FCROSS, RCP_CAP_LINE, 1};
+    const int feat[7] = {5, 7, 6, 6, 8, 5, 17};
+    int i;
+    L->n_blocks = 7;
+    for (i = 0; i < 7; ++i) { L->block_offset[i] = off[i]; L->block_rows[i] = rows[i]; L->block_feat[i] = feat[i]; }
+    L->steps_per_episode = RC_MAX_TIME / RC_STEP_ITER;
   } else {
     L->n_blocks = 3; /* ((ball, robots), (self,)) of RoboCupEnvironment.py:440-443 */
     L->block_offset[0] = 0; L->block_rows[0] = 1; L->block_feat[0] = 4;

@@ -179,3 +179,130 @@ def test_kat_head_on_cars_conserve_momentum_and_mirror_each_other(gpu, car_type,
     assert hit, "the cars must have met within three steps"
     assert env.error_flags() == 0
     env.close()
+
+
+# ---- round 3: joints and the friction cone through rc_step_kernel -----------------------------------------------------------
+PIVOT_BIAS = 1.0 - 0.1 ** 0.01   # Robot.py:58 joint.error_bias = 0.1  ->  biasCoef = 1 - errorBias ** dt
+
+
+def _quiet_actions():
+    a = np.zeros((1, 10, 4), np.int32)
+    a[..., 3] = 3  # head action 3 = no head turn; nobody moves
+    return a
+
+
+def _same_robot(g, r):
+    names = ("lpx", "lpy", "lvx", "lvy", "la", "lw", "rpx", "rpy", "rvx", "rvy", "ra", "rw")
+    assert [getattr(g, n) for n in names] == [getattr(r, n) for n in names], "HIP == oracle, bit for bit"
+
+
+def test_kat_pivot_joint_error_decays_with_its_error_bias(gpu):
+    """A robot's feet are two bodies held together by PivotJoint(left, right, pos) with error_bias = 0.1 (Robot.py:57-58; both
+    anchors are the body centres).  Pull the right foot delta away along x, everything at rest: each substep the joint gives
+    the pair the relative velocity -biasCoef * error / dt (maxBias = inf; the velocity function has zeroed what was left from the
+    substep before: |v| < friction * m = 4), the next position update applies it, so  error_k = delta (1 - biasCoef)^k  with
+    biasCoef = 1 - 0.1^dt - after s env steps k = 50 s - 1 (the first position update still sees zero velocity).  Equal masses:
+    the midpoint does not move; centre anchors: no torque, the angles stay 0."""
+    env, ora = _robocup_pair(gpu)
+    st = ora.get_state(0)
+    r = st.robots[0]
+    delta = 2.0
+    r.rpx = r.lpx + delta
+    mid = (r.lpx + r.rpx) / 2.0
+    y0 = r.lpy
+    env.set_state(0, st)
+    ora.set_state(0, st)
+    a = _quiet_actions()
+    for s in range(1, 4):
+        env.step_flat(a)
+        ora.step(a)
+        g = env.get_state(0).robots[0]
+        _same_robot(g, ora.get_state(0).robots[0])
+        np.testing.assert_allclose(g.rpx - g.lpx, delta * (1.0 - PIVOT_BIAS) ** (50 * s - 1), rtol=1e-10)
+        # the relative velocity left by the last solve is the bias of the error before the last position update
+        np.testing.assert_allclose(g.lvx - g.rvx, PIVOT_BIAS * (g.rpx - g.lpx) / 0.01, rtol=1e-10)
+        assert abs((g.lpx + g.rpx) / 2.0 - mid) < 1e-9 and g.lpy == y0 and g.rpy == y0
+        assert g.la == 0.0 and g.ra == 0.0 and g.lw == 0.0 and g.rw == 0.0
+    assert env.error_flags() == 0
+    env.close()
+
+
+def test_kat_rotary_limit_joint_pulls_the_feet_back_to_its_limit(gpu):
+    """RotaryLimitJoint(left, right, 0, 0) (Robot.py:59): the right foot turned theta past the (zero-width) limit.  The joint's
+    bias is -biasCoef * pdist / dt with the DEFAULT error bias (1 - 0.1f)^60, i.e. biasCoef = BIAS, the collision constant; the
+    feet have the same moment of inertia, so each takes half and the mean angle stays theta / 2:
+    angle error_k = theta (1 - BIAS)^k, k = 50 s - 1.  (|w| < rotFriction * m = 40 is zeroed by the velocity function every
+    substep and put back by the warm start - the closed form holds only if the cached impulse is carried over correctly.)"""
+    env, ora = _robocup_pair(gpu)
+    st = ora.get_state(0)
+    r = st.robots[0]
+    theta = 0.05
+    r.ra = r.la + theta
+    x0, y0 = r.lpx, r.lpy
+    env.set_state(0, st)
+    ora.set_state(0, st)
+    a = _quiet_actions()
+    for s in range(1, 4):
+        env.step_flat(a)
+        ora.step(a)
+        g = env.get_state(0).robots[0]
+        _same_robot(g, ora.get_state(0).robots[0])
+        np.testing.assert_allclose(g.ra - g.la, theta * (1.0 - BIAS) ** (50 * s - 1), rtol=1e-9)
+        np.testing.assert_allclose(g.lw - g.rw, BIAS * (g.ra - g.la) / 0.01, rtol=1e-9)
+        np.testing.assert_allclose((g.la + g.ra) / 2.0, theta / 2.0, rtol=1e-12)
+        assert (g.lpx, g.lpy, g.rpx, g.rpy) == (x0, y0, x0, y0) and g.lvx == 0.0 and g.rvx == 0.0
+    assert env.error_flags() == 0
+    env.close()
+
+
+def test_kat_grazing_ball_slides_on_the_coulomb_cone(gpu):
+    """The ball (m = 10, r = 10, I = m r^2 / 2, friction 3.0) grazes the flat side of a foot capsule (friction 2.5: u = 7.5) at
+    (100, -2): far too fast tangentially for friction to stop the sliding within the cone (it would take jt = m vt / 3 against
+    u jn ~ 7.5 * 1.29 m |vn|), so every iteration leaves the accumulated tangent impulse clamped at u * jn.  The scene is timed
+    with the closed-form free flight so that the FIRST touch happens in the last substep of the env step: the state read back
+    is the state right after that one solve, and the ball's velocity before it is the closed form.  Then, exactly:
+      dp_t / dp_n = -u            (the clamp - only the arbiter touches the ball)
+      I dw = r x dp = 10 dp_x      (the impulse acts at the contact point, straight below the centre)
+      dp(ball) + dp(both feet) = 0 (the pivot between the feet is internal)
+    and jn ~ (1 + e) m |vn| with e = 0.98 * 0.3 up to the recoil of the 400x heavier foot."""
+    env, ora = _robocup_pair(gpu)
+    st = ora.get_state(0)
+    r = st.robots[0]
+    assert r.team == 1 and r.la == 0.0
+    thr = r.lpy + 10.0 + 17.5   # the left foot's axis is y = py + 10 for x in [px - 10, px + 10]; touch at centre distance 17.5
+
+    def flight(p0, v0, n):
+        p, v, w, traj = np.array(p0, float), np.array(v0, float), 0.0, []
+        for _ in range(n):
+            p = p + v * 0.01
+            traj.append((p.copy(), v.copy()))
+            vx, vy, w = ball_friction(v[0], v[1], w)
+            v = np.array([vx, vy])
+        return traj, v, w
+    v0 = (100.0, -2.0)
+    d50 = flight((0.0, 0.0), v0, 50)[0][49][0]
+    p0 = np.array([r.lpx - d50[0], thr - 0.01 - d50[1]])
+    traj, v_pre, w_pre = flight(p0, v0, 50)
+    assert traj[48][0][1] > thr > traj[49][0][1] and abs(traj[49][0][0] - r.lpx) < 1e-9, "first touch in substep 49, above the capsule's middle"
+    st.bpx, st.bpy, st.bvx, st.bvy, st.bw = p0[0], p0[1], v0[0], v0[1], 0.0
+    st.bprevx, st.bprevy = p0
+    env.set_state(0, st)
+    ora.set_state(0, st)
+    a = _quiet_actions()
+    env.step_flat(a)
+    ora.step(a)
+    sg, so = env.get_state(0), ora.get_state(0)
+    assert [sg.bpx, sg.bpy, sg.bvx, sg.bvy, sg.bw] == [so.bpx, so.bpy, so.bvx, so.bvy, so.bw], "HIP == oracle, bit for bit"
+    _same_robot(sg.robots[0], so.robots[0])
+    np.testing.assert_allclose([sg.bpx, sg.bpy], traj[49][0], rtol=0, atol=1e-9)   # nothing moved it before the touch
+    m, inertia = 10.0, 10.0 * 10.0 * 10.0 / 2.0
+    dp = m * (np.array([sg.bvx, sg.bvy]) - v_pre)
+    assert dp[1] > 0.0 and dp[0] < 0.0, "pushed away from the foot, slowed along it"
+    np.testing.assert_allclose(dp[0] / dp[1], -7.5, rtol=1e-12)
+    np.testing.assert_allclose(inertia * (sg.bw - w_pre), 10.0 * dp[0], rtol=1e-12)
+    g = sg.robots[0]
+    np.testing.assert_allclose(4000.0 * np.array([g.lvx + g.rvx, g.lvy + g.rvy]), -dp, rtol=1e-9)
+    np.testing.assert_allclose(dp[1], (1.0 + 0.98 * 0.3) * m * abs(traj[49][1][1]), rtol=1e-2)
+    assert sg.bvx > 0.5 * v_pre[0], "still sliding: the friction did not stop the ball"
+    assert env.error_flags() == 0
+    env.close()

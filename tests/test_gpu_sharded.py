@@ -49,6 +49,45 @@ def test_sharded_env_pipelined_gather_rccl_world1():
         pass  # the process group (RCCL, world_size 1) is shared by this module's tests
 
 
+def test_pipelined_gather_across_an_episode_end_with_auto_reset():
+    """the pipelined protocol (ring of 4 slabs, transport of step k beside the following kernels) for many times the ring length,
+    through the lock-step episode end: step 599 returns done and - auto-reset, SubprocVecEnv semantics - the FIRST observation of
+    the next episode, written into that step's slab by the reset kernels; every gathered view equals a plain BatchedDynEnv"""
+    import torch
+    from dynenv_amd import BatchedDynEnv, DynEnvType
+    from dynenv_amd.distributed import ShardedDynEnv
+    _rccl_world1()
+    E, A = 48, 10
+    sh = ShardedDynEnv(DynEnvType.DRIVE, E, A, gather=True, seed=5, device="cuda:0", ring=4)
+    ref = BatchedDynEnv(DynEnvType.DRIVE, E, A, seed=5, device="cuda:0")
+    S = ref.steps_per_episode
+    g_obs, _, _ = sh.reset()
+    assert torch.equal(g_obs[0], ref.reset_flat())
+    g = torch.Generator(device="cuda:0").manual_seed(3)
+    pool = [torch.randint(0, 3, (E, A, 2), generator=g, device="cuda:0", dtype=torch.int32) for _ in range(32)]
+    handles, want, dones = {}, {}, 0
+    lag = 2
+    for k in range(S + 40):
+        handles[k] = sh.step(pool[k & 31], wait=False)
+        o, r, d = ref.step_flat(pool[k & 31])          # auto_reset=True
+        if k >= S - 20:                                 # keep (and compare) the window around the episode end
+            want[k] = (o.clone(), r.clone(), d.clone())
+        if k - lag in want:
+            go, gr, gd = handles.pop(k - lag).wait()
+            w = want.pop(k - lag)
+            assert torch.equal(go[0], w[0]) and torch.equal(gr[0], w[1]) and torch.equal(gd[0], w[2]), "step %d" % (k - lag)
+            dones += int(w[2].all())
+        elif k - lag in handles and k - lag < S - 20:
+            handles.pop(k - lag).wait()                 # consumed, not compared: the slabs keep rotating
+    for k in sorted(want):
+        go, gr, gd = handles.pop(k).wait()
+        assert torch.equal(go[0], want[k][0]) and torch.equal(gr[0], want[k][1]), "step %d" % k
+    assert dones == 1, "exactly one episode end in the window"
+    assert sh.env._episode_step == 40 and ref._episode_step == 40
+    sh.gather.drain()
+    sh.env.close(); ref.close()
+
+
 def test_obs_pack_unpack_roundtrip():
     import ctypes as C
     import torch

@@ -16,3 +16,16 @@ pytestmark = pytest.mark.gpu
 def test_full_episode_full_batch_parity(oracle_built, cfg, E):
     import soak_parity
     soak_parity.run(cfg, E, 20261003)
+
+
+def test_rank7_shard_of_the_8_gpu_configuration(oracle_built):
+    """BASELINE configs[4] = 32768 Driving environments over 8 GPUs: rank 7 owns global environments [28672, 32768).  Its whole
+    shard, a whole episode, against the oracle run on the same global ids (RNG streams are keyed by global environment id, so
+    this is what that rank computes in the 8-GPU job) - and it is NOT the result of rank 0's ids."""
+    import numpy as np
+    import soak_parity
+    soak_parity.run("driving", 4096, 20261003, env_id_offset=28672)
+    import oracle_lib as ol
+    a = ol.OracleEnv(num_envs=4, n_players=10, seed=20261003, env_id_offset=28672)
+    b = ol.OracleEnv(num_envs=4, n_players=10, seed=20261003, env_id_offset=0)
+    assert not np.array_equal(a.reset(), b.reset())

@@ -242,3 +242,45 @@ def test_transport_layout_falls_back_to_dense_where_rows_are_not_redundant():
     for et, ob in ((DynEnvType.DRIVE, ObservationType.PARTIAL), (DynEnvType.ROBO_CUP, ObservationType.FULL),
                    (DynEnvType.ROBO_CUP, ObservationType.PARTIAL)):
         assert transport_layout(Probe(et, ob)) == {} and shared_tail_split(Probe(et, ob)) is None
+
+
+def _deep_same(a, b):
+    if isinstance(a, (list, tuple)):
+        assert type(a) is type(b) and len(a) == len(b), (type(a), type(b))
+        for x, y in zip(a, b):
+            _deep_same(x, y)
+    elif isinstance(a, np.ndarray):
+        assert a.shape == b.shape and a.dtype == b.dtype, (a.shape, b.shape, a.dtype, b.dtype)
+        np.testing.assert_array_equal(a, b)
+    else:
+        assert type(a) is type(b) and a == b, (a, b)
+
+
+@pytest.mark.parametrize("env_type,n,partial", [(1, 10, False), (1, 4, True), (0, 5, False), (0, 3, True)])
+def test_bulk_compat_builder_equals_the_loop_builder(oracle_built, env_type, n, partial):
+    """the reference's ragged object array [E, T, A, 3] built without a Python loop over agents (vec_env._compat_obs_bulk) is
+    element for element - container types, dtypes, shapes, values - what the plain triple loop (_compat_obs) builds, on real
+    observations of all four layouts (the oracle's: same dense layout as the library's)"""
+    import oracle_lib as ol
+    from dynenv_amd.enums import DynEnvType, ObservationType
+    from dynenv_amd.vec_env import BatchedDynEnv
+    E = 9
+    kw = dict(obs_type=1, noise_type=1, noise_magnitude=3.0) if partial else {}
+    ora = ol.OracleEnv(env_type=env_type, num_envs=E, n_players=n, seed=3, flags=ol.ROBOCUP_DEFAULT_FLAGS if env_type == 0 else 0, **kw)
+    ora.reset()
+    rng = np.random.default_rng(0)
+    hi = (5, 3, 3, 7) if env_type == 0 else (3, 3)
+    for _ in range(6):
+        obs, _, _ = ora.step(np.stack([rng.integers(0, k, (E, ora.A)) for k in hi], -1).astype(np.int32))
+    host = BatchedDynEnv.__new__(BatchedDynEnv)   # the builders only read the layout (no device, no handle)
+    host.layout, host.env_type = ora.layout, DynEnvType(env_type)
+    host.observationType = ObservationType.PARTIAL if partial else ObservationType.FULL
+    host.n_agents, host.obs_dim, host.closed = ora.A, ora.D, True
+    counts = ora.counts()
+    loop = host._compat_obs(obs.copy(), counts)
+    bulk = host._compat_obs_bulk(obs.copy(), counts)
+    assert bulk.shape == loop.shape == (E, ora.T, ora.A, 3) and bulk.dtype == object
+    for idx in np.ndindex(*loop.shape):
+        _deep_same(bulk[idx], loop[idx])
+    if not partial and env_type == 1:
+        assert len({bulk[e, 0, 0, 0][1].shape[0] for e in range(E)}) > 1, "ragged obstacle lists must differ between environments"

@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def run(cfg, E, seed, players=None):
+def run(cfg, E, seed, players=None, env_id_offset=0):
     import numpy as np
     import torch
     import oracle_lib as ol
@@ -26,8 +26,9 @@ def run(cfg, E, seed, players=None):
     if players is not None:
         n = players
     kw, okw = (part, opart) if cfg.endswith("partial") else ({}, {})
-    env = BatchedDynEnv(et, E, n, seed=seed, flags=flags, **kw)
-    ora = ol.OracleEnv(env_type=oet, num_envs=E, n_players=n, seed=seed, flags=flags, threads=16, **okw)
+    # env_id_offset: the shard of a bigger job (rank g of a sharded run owns global environments [g E, (g + 1) E): RNG streams are keyed by global id)
+    env = BatchedDynEnv(et, E, n, seed=seed, flags=flags, env_id_offset=env_id_offset, **kw)
+    ora = ol.OracleEnv(env_type=oet, num_envs=E, n_players=n, seed=seed, flags=flags, threads=16, env_id_offset=env_id_offset, **okw)
     assert np.array_equal(env.reset_flat().cpu().numpy(), ora.reset()), "reset"
     rng = np.random.default_rng(seed)
     t0 = time.time()
@@ -60,7 +61,7 @@ def run(cfg, E, seed, players=None):
         tot = c["fast"] + c["quiescent"] + c["contact"] + c["steady"]
         extra = " paths: fast %.3f quiescent %.3f replay %.3f (light %.3f) full %.3f" % (
             c["fast"] / tot, c["quiescent"] / tot, (c["steady"] + c["light"]) / tot, c["light"] / tot, (c["contact"] - c["light"]) / tot)
-    print("soak OK: %s nPlayers=%d, %d envs x %d steps bit-identical to the oracle (%.0f s)%s" % (cfg, n, E, steps, time.time() - t0, extra), flush=True)
+    print("soak OK: %s nPlayers=%d, %d envs (global ids from %d) x %d steps bit-identical to the oracle (%.0f s)%s" % (cfg, n, E, env_id_offset, steps, time.time() - t0, extra), flush=True)
     env.close(); ora.close()
 
 
