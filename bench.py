@@ -149,18 +149,22 @@ def episode_leg(torch, device, workload, E, seed, n_players=None):
     players = n_players if n_players is not None else players
     A = 2 * players if robocup else players
     kw = dict(observationType=ObservationType.PARTIAL, noiseType=NoiseType.REALISTIC, noiseMagnitude=3) if partial else {}
-    env = BatchedDynEnv(DynEnvType.ROBO_CUP if robocup else DynEnvType.DRIVE, E, players, seed=seed, device=device, **kw)
     g = torch.Generator(device=device).manual_seed(4321)
     if robocup:
         hi = torch.tensor([5, 3, 3, 7], device=device)
         pool = [(torch.rand((E, A, 4), generator=g, device=device) * hi).to(torch.int32) for _ in range(16)]
     else:
         pool = [torch.randint(0, 3, (E, A, 2), generator=g, device=device, dtype=torch.int32) for _ in range(16)]
-    env.reset_flat()
-    for i in range(10):  # untimed: first-touch of the buffers, then a fresh episode
-        env.step_flat(pool[i & 15], auto_reset=False)
-    env.reset_flat()
-    torch.cuda.synchronize(device)
+
+    def fresh_env():  # both passes below run the SAME episode (episode index 2 of a fresh handle: identical trajectories)
+        env = BatchedDynEnv(DynEnvType.ROBO_CUP if robocup else DynEnvType.DRIVE, E, players, seed=seed, device=device, **kw)
+        env.reset_flat()
+        for i in range(3):  # untimed: first-touch of the buffers, then a fresh episode
+            env.step_flat(pool[i & 15], auto_reset=False)
+        env.reset_flat()
+        torch.cuda.synchronize(device)
+        return env
+    env = fresh_env()
     k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     k0.record()
     for i in range(ep_steps):
@@ -168,6 +172,9 @@ def episode_leg(torch, device, workload, E, seed, n_players=None):
     k1.record()
     torch.cuda.synchronize(device)
     ms = k0.elapsed_time(k1) / ep_steps
+    assert env.error_flags() == 0
+    env.close()
+    env = fresh_env()
     # the named kernel's OWN launch duration: a second pass over the same episode (same seed, same actions) with the library
     # recording HIP events on the launch stream right before and after that kernel (dynenv_set_step_events), a fresh event
     # set per step and no host wait in between, so the launches stay back to back as in the pass above and the Partial
@@ -178,7 +185,6 @@ def episode_leg(torch, device, workload, E, seed, n_players=None):
     for tr in evs:
         for ev in tr:
             ev.record()  # creates the hipEvent_t
-    env.reset_flat()
     torch.cuda.synchronize(device)
     for i in range(ep_steps):
         eb, em, ee, ex = evs[i]
@@ -280,6 +286,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the whole-episode leg, the other BASELINE configurations and the configs[0] plumbing leg (N = 1 only)")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="profiling runs (tools/profile_round.sh): skip the warm-up and the timed window and run only the whole-episode "
+                         "roofline leg, so that every launch a profiler sees belongs to it; the line says so in `mode`")
     ap.add_argument("--no-gather", action="store_true", help="skip the end-of-step all-gather (data-parallel consumer)")
     ap.add_argument("--force-gather", action="store_true",
                     help="rehearsal on a one-GPU box: run the N > 1 code path (slab, pack, all-gather, unpack) with world_size 1")
@@ -381,6 +390,8 @@ def main():
             env.step_flat(pool[i & 63])
             gather.start(k)
 
+    if args.roofline_only:
+        args.steps, args.warmup, args.no_extra_legs, args.no_cpu_baseline = 1, 0, True, True
     env.reset_flat()
     for i in range(args.warmup):
         one_step(i)
@@ -454,6 +465,7 @@ def main():
                          % (what, E, WORKLOADS[args.workload][6], ep_steps, args.warmup, args.warmup + args.steps - 1, ep_steps, args.warmup))
         out = {
             "metric": "agent-steps/s", "value": value, "unit": "agent-steps/s", "n_gpus": world,
+            **({"mode": "roofline-only: `value` is ONE untimed-quality step; read roofline / ms_per_step_full_episode"} if args.roofline_only else {}),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload_text,

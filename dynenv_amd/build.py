@@ -20,14 +20,15 @@ def needs_build():
 
 
 def build(force=False, verbose=False, out=None, defines=()):
-    """hipcc --offload-arch=gfx950, FMA contraction off (bit-exact parity with the oracle).
+    """hipcc --offload-arch=gfx950, FMA contraction off (bit-exact parity with the oracle); -fno-optimize-sibling-calls: see
+    DE_OOL in csrc/dev_common.h (out-of-line device functions without callee-saved registers).
     `out` / `defines` build an instrumented variant next to the product library (e.g. -DDRV_PROFILE)."""
     if out is None and not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-fno-optimize-sibling-calls", "-fPIC", "-shared",
            "-std=c++17", "-Wno-unused-value", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc"),
            "-o", out or LIB, SRC] + ["-D" + d for d in defines]
     if verbose:

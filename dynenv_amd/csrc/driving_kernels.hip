@@ -721,7 +721,7 @@ DRV_PROF(__device__ unsigned long long g_dbgr[16];)
 #endif
 
 // pk: a_state | a_count << 8 | a_age << 16 | touched << 24 | freeMe << 25 | hashSame << 26 | prevInert << 27 | skipped << 28 | slotOcc << 29 | active << 30
-__device__ __noinline__ int drv_prestep_solve(int lane, int roleBits, int pk, int a_pair, int bodyA, int bodyB, int myLevel,
+DE_OOL int drv_prestep_solve(int lane, int roleBits, int pk, int a_pair, int bodyA, int bodyB, int myLevel,
                                              int maxLevel_, int anyActive_, double jn0, double jn1, double jt0, double jt1) {
   DrvLds& L = g_L;
   DrvMailbox& M = L.u.mb;
@@ -1153,7 +1153,7 @@ DRV_PROF(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* d = g_dbgp + 
 // ------------------------------------------------------------------------------------------------
 // THE step kernel: grid = E blocks of one wavefront
 // ------------------------------------------------------------------------------------------------
-__device__ __noinline__ void drv_partial_obs_fused(const DrvState& S, int e, int lane, int nPed, int nObst, int elapsed, uint32_t episode,
+DE_OOL void drv_partial_obs_fused(const DrvState& S, int e, int lane, int nPed, int nObst, int elapsed, uint32_t episode,
                                                    PvIn in, int noiseType, double magn, float* __restrict__ obs, int nAgents);  // driving_partial.hip
 #ifndef DRV_DEFER_MIN_CONTACT
 #define DRV_DEFER_MIN_CONTACT 5 /* contact-path substeps (of 10) from which an environment defers its Partial observation */
@@ -1166,7 +1166,7 @@ struct DrvLightRet {
   int cand, dirty, bits;
 };
 struct DrvSeedOnly { uint64_t seed; };
-__device__ __noinline__ DrvLightRet drv_light_substep(int it_, int lane, int A_, int nPed_, int nObst_, int elapsed_, int act0, int act1, int lastCand,
+DE_OOL DrvLightRet drv_light_substep(int it_, int lane, int A_, int nPed_, int nObst_, int elapsed_, int act0, int act1, int lastCand,
                                                       uint32_t seedLo, uint32_t seedHi, uint32_t genv_, uint32_t episode_, int stateBits, double rew, double posrew) {
   DrvLds& L = g_L;
   const int it = uniform_i(it_), A = uniform_i(A_), nPed = uniform_i(nPed_), nObst = uniform_i(nObst_), elapsed = uniform_i(elapsed_);

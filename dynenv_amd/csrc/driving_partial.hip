@@ -513,7 +513,7 @@ drv_partial_obs_kernel(DrvState S, int noiseType, double magn, float* __restrict
 // stepping - the observation work of the light environments fills the launch's tail instead of a second launch.  The
 // scratch tile aliases the step kernel's (no longer needed) LDS tile.
 static_assert(sizeof(PvLds) <= sizeof(DrvLds), "the Partial observation tile must fit in the step kernel's LDS tile");
-__device__ __noinline__ void drv_partial_obs_fused(const DrvState& S, int e, int lane, int nPed, int nObst, int elapsed, uint32_t episode,
+DE_OOL void drv_partial_obs_fused(const DrvState& S, int e, int lane, int nPed, int nObst, int elapsed, uint32_t episode,
                                                    PvIn in, int noiseType, double magn, float* __restrict__ obs, int nAgents) {
   __syncthreads();  // every lane has taken what it needs out of the step tile
   pv_env(S, *reinterpret_cast<PvLds*>(&g_L), e, lane, nPed, nObst, elapsed, episode, in, noiseType, magn, obs, 0, nAgents);

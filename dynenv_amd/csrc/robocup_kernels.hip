@@ -9,11 +9,8 @@
 
 __constant__ RcConst RC;
 
-// A/B switches for the two per-substep stages.  Measured on MI355X (4096 envs): both out of line 3.93 ms/step,
+// The two per-substep stages are out-of-line functions.  Measured on MI355X (4096 envs, round 1): both out of line 3.93 ms/step,
 // physics inlined 4.29, both inlined 4.45 -> out of line wins (smaller live ranges beat the call overhead)
-#ifndef RC_PHYS_INLINE
-#define RC_PHYS_INLINE __noinline__
-#endif
 #ifndef RC_LOGIC_INLINE
 #define RC_LOGIC_INLINE __forceinline__
 #endif
@@ -208,7 +205,7 @@ DE_DEV void free_penalty_spot(const RcCtx& c, const RcLds& L, int r, V2& spot, d
 }
 
 template <int EPW>
-__device__ __noinline__ void rc_penalize(const RcCtx& c, int r) {  // :824-859
+DE_OOL void rc_penalize(const RcCtx& c, int r) {  // :824-859
   RcLds& L = Grp<EPW>::tile();
   const int teamIdx = robot_team(L, r) > 0 ? 0 : 1;
   int f = L.rflags[r];
@@ -247,7 +244,7 @@ DE_DEV double shape_point_dist(const RcLds& L, int s, V2 p) {
 }
 
 template <int EPW>
-__device__ __noinline__ void rc_fall(const RcCtx& c, int r, int punish) {  // :735-791
+DE_OOL void rc_fall(const RcCtx& c, int r, int punish) {  // :735-791
   RcLds& L = Grp<EPW>::tile();
   const V2 pos = robot_pos(L, r);
   if (punish) L.rrew[r] -= 2.0;
@@ -563,7 +560,7 @@ DE_DEV bool rc_tick_has_event(const RcLds& L, int r) {
 // The sequential form (first substep, or a cross-robot event) is out of line; the common lane-parallel form is inlined
 // into the step kernel's loop so that it costs no call (callee-saved registers travel through scratch on every call).
 template <int EPW>
-__device__ __noinline__ void rc_game_serial(RcCtx c, int it, const int* __restrict__ actions, const double* __restrict__ headAct) {
+DE_OOL void rc_game_serial(RcCtx c, int it, const int* __restrict__ actions, const double* __restrict__ headAct) {
   RcLds& L = Grp<EPW>::tile();
   for (int r = 0; r < c.R; ++r) {
     if (it == 0) {
@@ -1019,7 +1016,7 @@ DE_DEV void rc_joints_only_inl(int lane, int R) {
 }
 
 // out of line where it runs inside the general path's caller (its own small register allocation)
-__device__ __noinline__ void rc_joints_only_ool(int lane, int R) { rc_joints_only_inl<1>(lane, R); }
+DE_OOL void rc_joints_only_ool(int lane, int R) { rc_joints_only_inl<1>(lane, R); }
 template <int EPW>
 DE_DEV void rc_joints_only(int lane, int R) { rc_joints_only_ool(lane, R); }
 
@@ -1466,7 +1463,7 @@ RC_PROF(if (lane == 0 && c.genv < 4096u) { unsigned long long* d = g_rcprof + c.
   return ret;
 }
 
-__device__ RC_PHYS_INLINE RcStepRet rc_physics_ool(RcCtx c, int lane, int cand, uint64_t pairLo, uint64_t pairHi, uint64_t occ) {
+DE_OOL RcStepRet rc_physics_ool(RcCtx c, int lane, int cand, uint64_t pairLo, uint64_t pairHi, uint64_t occ) {
   return rc_physics_inl<1>(c, lane, cand, pairLo, pairHi, 0ull, occ);
 }
 template <int EPW>
@@ -1624,7 +1621,7 @@ struct RcCommonRet {
   int cand, bits;  // bits: 1 quiet, 2 rotValid
 };
 template <int EPW>
-__device__ __noinline__ RcCommonRet rc_common_substep(RcCtx c, int serial_, int lane,
+DE_OOL RcCommonRet rc_common_substep(RcCtx c, int serial_, int lane,
                                                       uint64_t pairLo, uint64_t pairHi, uint64_t pairTop, int feetPairs, uint64_t occ_, double rotC, double rotS, double rotAng, int rotValid_) {
   typedef Grp<EPW> G;
   constexpr int W = G::W, NROUNDS = (RC_NPAIR_ROUNDS * 64) / W;

@@ -471,7 +471,7 @@ rc_partial_obs_kernel(RcState S, float* __restrict__ obs, double* __restrict__ r
 // of a RoboCup launch are such a tail).  The tile aliases the step kernel's LDS tile, which is no longer needed; the
 // snapshots, rewards and prew0 this wave wrote to HBM are read back after a device-scope fence.
 static_assert(sizeof(RvLds) <= sizeof(RcLds), "the vision tile must fit in the step kernel's LDS tile");
-__device__ __noinline__ void rc_partial_obs_fused(const RcState& S, int e, int lane, float* __restrict__ obs, double* __restrict__ rewards) {
+DE_OOL void rc_partial_obs_fused(const RcState& S, int e, int lane, float* __restrict__ obs, double* __restrict__ rewards) {
   __threadfence();
   __syncthreads();
   rv_env(S, *reinterpret_cast<RvLds*>(&g_R), e, lane, obs, rewards);
