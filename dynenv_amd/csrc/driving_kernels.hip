@@ -1523,7 +1523,10 @@ DRV_PROF(const unsigned long long K1 = __builtin_amdgcn_s_memtime();)
     }
     if (lane < nObst) { in.ox = L.ox[lane]; in.oy = L.oy[lane]; }
     if (lane < A) { in.gx = L.goalx[lane]; in.gy = L.goaly[lane]; }
-    drv_partial_obs_fused(S, e, lane, nPed, nObst, elapsed, episode, in, pvNoise, pvMagn, pobs, fusedAgents);
+    // (a copy: the out-of-line function takes the state by reference, and an address-taken S would live in scratch for the
+    //  whole kernel - every S.field of the step a scratch load instead of a kernel-argument SGPR)
+    const DrvState Scopy = S;
+    drv_partial_obs_fused(Scopy, e, lane, nPed, nObst, elapsed, episode, in, pvNoise, pvMagn, pobs, fusedAgents);
   }
 DRV_PROF(if (lane == 0 && e < 4096) { unsigned long long* d = g_dbgw + e * 12; const unsigned long long KE = __builtin_amdgcn_s_memtime(); d[0] = KE - KS; d[1] = nContact; d[2] = __popcll(occ); d[3] = nSteady + nQuiet; d[4] = K0 - KS; d[5] = tPh1; d[6] = tBroad; d[7] = tFast; d[8] = tCont; d[9] = (K1 - K0) - tPh1 - tBroad - tFast - tCont; d[10] = KE - K1; d[11] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned long long)__builtin_amdgcn_s_getreg(63492); })
 }

@@ -113,8 +113,9 @@ DE_DEV void pv_env(const DrvState& S, PvLds& L, const int e, const int lane, con
     double dc = 0.0, ds = 0.0, dw = 0.0, dh = 0.0;
     int dfin = 0;
     bool hasCorners = false;
-    V2 cor[4];
-    cor[0] = cor[1] = cor[2] = cor[3] = v2(0.0, 0.0);
+    // the four corners as scalars, not an array: an array written by a (later unrolled) loop and read through index selects
+    // ends up in scratch memory - the selects of loads become loads through a selected pointer before the loop is unrolled
+    V2 cor0 = v2(0.0, 0.0), cor1 = cor0, cor2 = cor0, cor3 = cor0;
     const bool isSelf = isCarLane && lane == a;
     // one sincos call serves every lane of this pass: self -> its heading, the other objects -> heading relative to the
     // agent, lane rows -> road direction relative to the agent, and lane 63 -> the rotation by -ang that every object's
@@ -149,9 +150,7 @@ DE_DEV void pv_env(const DrvState& S, PvLds& L, const int e, const int lane, con
     if (isObjLane) {
       if (isSelf) {  // selfDet :755-756: absolute position, own corners, never filtered
         seen = SIGHT_NORMAL; pos = P; dc = sc1.c; ds = sc1.s;
-        const double lx[4] = {hx, -hx, -hx, hx}, ly[4] = {hy, hy, -hy, -hy};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) cor[i] = vadd(v2(lx[i], ly[i]), P);
+        cor0 = vadd(v2(hx, hy), P); cor1 = vadd(v2(-hx, hy), P); cor2 = vadd(v2(-hx, -hy), P); cor3 = vadd(v2(hx, -hy), P);
       } else {
         const V2 trPt = vsub(point, P);
         const double dist = pv_lensq(trPt);
@@ -159,9 +158,9 @@ DE_DEV void pv_env(const DrvState& S, PvLds& L, const int e, const int lane, con
           seen = SIGHT_NORMAL;  // Distant is unreachable: maxDist < distantDist (quirk C17)
           if (!(dist <= distD)) seen = 2;
           if (hasCorners) {
-            const double lx[4] = {hx, -hx, -hx, hx}, ly[4] = {hy, hy, -hy, -hy};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) cor[i] = vadd(vsub(vadd(v2(lx[i], ly[i]), point), point), trPt);
+#define PV_COR(X, Y) vadd(vsub(vadd(v2((X), (Y)), point), point), trPt)
+            cor0 = PV_COR(hx, hy); cor1 = PV_COR(-hx, hy); cor2 = PV_COR(-hx, -hy); cor3 = PV_COR(hx, -hy);
+#undef PV_COR
           }
           pos = v2(trPt.x * rotC - trPt.y * rotS, trPt.x * rotS + trPt.y * rotC);  // trPt.rotated(-ang)
           dc = sc1.c; ds = sc1.s;
@@ -194,22 +193,23 @@ DE_DEV void pv_env(const DrvState& S, PvLds& L, const int e, const int lane, con
       b.seen = seen; b.posx = pos.x; b.posy = pos.y; b.angle2 = angle1;
       b.minA = b.maxA = 0.0; b.p1x = b.p1y = b.p2x = b.p2y = b.pmx = b.pmy = 0.0; b.extreme = 0;
       if (seen != SIGHT_NONE) {
-        double angs[4], dsts[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { angs[i] = dev_atan2(cor[i].y, cor[i].x) - angle1; dsts[i] = pv_lensq(cor[i]); }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) if (angs[i] > DM_PI) angs[i] -= DM_TWO_PI;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) if (angs[i] < -DM_PI) angs[i] += DM_TWO_PI;
+        double ang0 = dev_atan2(cor0.y, cor0.x) - angle1, ang1 = dev_atan2(cor1.y, cor1.x) - angle1;
+        double ang2 = dev_atan2(cor2.y, cor2.x) - angle1, ang3 = dev_atan2(cor3.y, cor3.x) - angle1;
+        const double dst0 = pv_lensq(cor0), dst1 = pv_lensq(cor1), dst2 = pv_lensq(cor2), dst3 = pv_lensq(cor3);
+#define PV_WRAP(A) do { if ((A) > DM_PI) (A) -= DM_TWO_PI; } while (0)
+        PV_WRAP(ang0); PV_WRAP(ang1); PV_WRAP(ang2); PV_WRAP(ang3);
+#undef PV_WRAP
+#define PV_WRAP(A) do { if ((A) < -DM_PI) (A) += DM_TWO_PI; } while (0)
+        PV_WRAP(ang0); PV_WRAP(ang1); PV_WRAP(ang2); PV_WRAP(ang3);
+#undef PV_WRAP
         int mn = 0, mx = 0, ci = 0;
-        double amin = angs[0], amax = angs[0], dmin = dsts[0];
-#pragma unroll
-        for (int i = 1; i < 4; ++i) {
-          if (angs[i] < amin) { amin = angs[i]; mn = i; }
-          if (angs[i] > amax) { amax = angs[i]; mx = i; }
-          if (dsts[i] < dmin) { dmin = dsts[i]; ci = i; }
-        }
-        const V2 p1 = sel4(cor, mn), p2 = sel4(cor, mx), pm = sel4(cor, ci);
+        double amin = ang0, amax = ang0, dmin = dst0;
+#define PV_STEP(I, A, D) do { if ((A) < amin) { amin = (A); mn = (I); } if ((A) > amax) { amax = (A); mx = (I); } if ((D) < dmin) { dmin = (D); ci = (I); } } while (0)
+        PV_STEP(1, ang1, dst1); PV_STEP(2, ang2, dst2); PV_STEP(3, ang3, dst3);
+#undef PV_STEP
+#define PV_SEL(I) ((I) == 3 ? cor3 : ((I) == 2 ? cor2 : ((I) == 1 ? cor1 : cor0)))
+        const V2 p1 = PV_SEL(mn), p2 = PV_SEL(mx), pm = PV_SEL(ci);
+#undef PV_SEL
         b.minA = amin; b.maxA = amax; b.p1x = p1.x; b.p1y = p1.y; b.p2x = p2.x; b.p2y = p2.y; b.pmx = pm.x; b.pmy = pm.y;
         b.extreme = (ci == mn || ci == mx) ? 1 : 0;
       }

@@ -1825,7 +1825,10 @@ RC_PROF(if (lane == 0 && e < 4096) { unsigned long long* d = g_rcprof + e * 12; 
   __syncthreads();
   rc_store_env(S, L, e, lane, occ, W);
   if constexpr (PARTIAL) {
-    if (obs && !deferObs) rc_partial_obs_fused(S, e, lane, obs, rewards);  // getAgentVision at the five snapshots + processSeens
+    if (obs && !deferObs) {  // getAgentVision at the five snapshots + processSeens
+      const RcState Scopy = S;  // (a copy: see drv_step_body - an address-taken S would live in scratch for the whole kernel)
+      rc_partial_obs_fused(Scopy, e, lane, obs, rewards);
+    }
   }
 }
 // Full observations: one environment per wave at four waves per SIMD (128 VGPRs, the general path out of line)
