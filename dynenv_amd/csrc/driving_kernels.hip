@@ -1352,10 +1352,18 @@ DE_OOL DrvLightRet drv_light_substep(int it_, int lane, int A_, int nPed_, int n
       }
       const int carStill = (int)(wave_ballot(isCar && (sj & 1)) & 0x3FFull);
       const int carFrozen = (int)(wave_ballot(isCar && (sj & 2)) & 0x3FFull);
-#pragma unroll 5
+      // cpBBIntersects(a, b) = a.l <= b.r && b.l <= a.r && a.b <= b.t && b.b <= a.t, branch-free: four compares into scalar masks,
+      // three s_and, one select per car.  Pairs that do not exist (i >= A, i >= lane, a lane without an object) are masked out
+      // afterwards, whatever their rows held.
+#pragma unroll
       for (int i = 0; i < DRV_MAXA; ++i) {  // rows >= A are never written but in bounds: the loads pipeline unconditionally
         const double al = L.aabb[i][0], ab = L.aabb[i][1], ar = L.aabb[i][2], at = L.aabb[i][3];
-        if (live && i < A && lane > i && al <= br && bl <= ar && ab <= bt && bb <= at) cand |= (1 << i);
+        const bool hit = (al <= br) & (bl <= ar) & (ab <= bt) & (bb <= at);
+        cand |= hit ? (1 << i) : 0;
+      }
+      {
+        const int lim = lane < A ? lane : A;  // pair (i, lane) exists for i < min(lane, A)
+        cand &= live ? ((1 << lim) - 1) : 0;
       }
       if (cand) candMoving = !(sj & 1) || (cand & ~carStill) != 0;
       // clean pair: a candidate in the previous substep too, both bodies frozen since.  dirty: every other candidate.

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Whole-episode mean step time of one workload at 4096 envs for the library DYNENV_HIP_LIB selects (A/B of build variants).
-Usage (GPU box): DYNENV_HIP_LIB=dynenv_amd/libdynenv_hip_x.so python tools/episode_time.py driving [repeats]"""
+Usage (GPU box): DYNENV_HIP_LIB=dynenv_amd/libdynenv_hip_x.so [ET_ENVS=256 ET_STEPS=100] python tools/episode_time.py driving [repeats]
+(256 environments = one wave per CU: the time of a lone wave)"""
 import os
 import sys
 
@@ -12,7 +13,7 @@ from dynenv_amd import BatchedDynEnv, DynEnvType, NoiseType, ObservationType  # 
 w = sys.argv[1] if len(sys.argv) > 1 else "driving"
 rep = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 robocup, partial = w.startswith("robocup"), w.endswith("partial")
-E, A = 4096, 10
+E, A = int(os.environ.get("ET_ENVS", "4096")), 10
 kw = dict(observationType=ObservationType.PARTIAL, noiseType=NoiseType.REALISTIC, noiseMagnitude=3) if partial else {}
 env = BatchedDynEnv(DynEnvType.ROBO_CUP if robocup else DynEnvType.DRIVE, E, 5 if robocup else 10, seed=42, **kw)
 g = torch.Generator(device="cuda").manual_seed(4321)
@@ -21,7 +22,7 @@ if robocup:
     pool = [(torch.rand((E, A, 4), generator=g, device="cuda") * hi).to(torch.int32) for _ in range(16)]
 else:
     pool = [torch.randint(0, 3, (E, A, 2), generator=g, device="cuda", dtype=torch.int32) for _ in range(16)]
-steps = 240 if robocup else 600
+steps = int(os.environ.get("ET_STEPS", "240" if robocup else "600"))
 out = []
 for r in range(rep + 1):
     env.reset_flat()
