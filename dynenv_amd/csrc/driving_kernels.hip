@@ -730,7 +730,7 @@ DE_OOL int drv_prestep_solve(int lane, int roleBits, int pk, int a_pair, int bod
   const bool touched = (pk >> 24) & 1, freeMe = (pk >> 25) & 1, hashSame = (pk >> 26) & 1, prevInert = (pk >> 27) & 1;
   const bool skipped = (pk >> 28) & 1, slotOcc = (pk >> 29) & 1, active = (pk >> 30) & 1;
   const bool isCar = (roleBits & 1) != 0, isPed = (roleBits & 2) != 0;
-  const int maxLevel = uniform_i(maxLevel_);
+  const int maxLevel = (int)(signed char)(uniform_i(maxLevel_) & 0xFF), period = uniform_i(maxLevel_) >> 8;
   const uint64_t activeMask = uniform_i(anyActive_) ? 1ull : 0ull;
   double jn[2] = {jn0, jn1}, jt[2] = {jt0, jt1};
   V2 n = v2(0.0, 0.0), r1[2], r2[2];
@@ -808,33 +808,39 @@ DE_OOL int drv_prestep_solve(int lane, int roleBits, int pk, int a_pair, int bod
       body_load(L, bodyA, a); body_load(L, bodyB, b);
       biasOnly = arb_is_bias_only(a, b, jn, jt, bounce, a_count);
     }
+    // PIPELINED SWEEPS.  Chipmunk runs 10 sweeps over the arbiters in order; sweep k + 1 of an arbiter only depends on sweep k of
+    // the arbiters it shares a body with.  Pass (arbiter a, sweep k) runs at time step  level(a) + period * k  with
+    // period = 1 + the largest level difference between two arbiters sharing a dynamic body: then for two such arbiters, a before
+    // b in canonical order,  (a, k) < (b, k) < (a, k + 1)  holds in time exactly as in the sequential sweep (level(a) <
+    // level(b) < level(a) + period), passes of one time step never share a body, and everything else commutes - the result is
+    // bit for bit the sequential one.  A chain of L resting cars (period 2) needs L + 18 time steps instead of 10 L.
+    const int nSteps = maxLevel + 1 + period * 9;
+    int due = myLevel, passes = 0;
     if (wave_ballot(!biasOnly) == 0ull) {
       // every active arbiter is a resting contact being pushed out of penetration (the pile-ups that make up the launch's
-      // tail): only bias velocities move, through LDS, level by level
-      for (int iter = 0; iter < 10; ++iter) {
-        for (int lv = 0; lv <= maxLevel; ++lv) {
-          if (active && myLevel == lv) {
-            body_load_bias(L, bodyA, a);
-            body_load_bias(L, bodyB, b);
-            arb_apply_bias_only(a, b, n, r1, r2, nMass, bias, jBias, a_count);
-            body_store_bias(L, bodyA, a);
-            body_store_bias(L, bodyB, b);
-          }
-          __syncthreads();
+      // tail): only bias velocities move, through LDS
+      for (int t = 0; t < nSteps; ++t) {
+        if (active && t == due && passes < 10) {
+          body_load_bias(L, bodyA, a);
+          body_load_bias(L, bodyB, b);
+          arb_apply_bias_only(a, b, n, r1, r2, nMass, bias, jBias, a_count);
+          body_store_bias(L, bodyA, a);
+          body_store_bias(L, bodyB, b);
+          due += period; ++passes;
         }
+        __syncthreads();
       }
     } else {
-      for (int iter = 0; iter < 10; ++iter) {
-        for (int lv = 0; lv <= maxLevel; ++lv) {
-          if (active && myLevel == lv) {
-            body_load_vel(L, bodyA, a);
-            body_load_vel(L, bodyB, b);
-            arb_apply_impulse(a, b, n, r1, r2, nMass, tMass, bias, bounce, jBias, jn, jt, a_count, arb_u);
-            body_store_vel(L, bodyA, a);
-            body_store_vel(L, bodyB, b);
-          }
-          __syncthreads();
+      for (int t = 0; t < nSteps; ++t) {
+        if (active && t == due && passes < 10) {
+          body_load_vel(L, bodyA, a);
+          body_load_vel(L, bodyB, b);
+          arb_apply_impulse(a, b, n, r1, r2, nMass, tMass, bias, bounce, jBias, jn, jt, a_count, arb_u);
+          body_store_vel(L, bodyA, a);
+          body_store_vel(L, bodyB, b);
+          due += period; ++passes;
         }
+        __syncthreads();
       }
     }
   }
@@ -1119,7 +1125,10 @@ DRV_PROF(const unsigned long long T1 = __builtin_amdgcn_s_memtime();)
   // ---- active arbiters: levels (arbiters sharing a dynamic body keep their canonical sequential order) --
   const bool active = solvable && !skipped;
   const uint64_t activeMask = wave_ballot(active);
-  int myLevel = 0, maxLevel = -1, blvl = 0;
+  // `period` (pipelined sweeps, see drv_prestep_solve): 1 + the largest level difference between two arbiters that share a
+  // dynamic body.  The first arbiter on a body has the lowest level of all arbiters on it (levels ascend along a body's
+  // arbiters), so the difference to that one (bfirst) is the largest difference this arbiter has with any earlier one.
+  int myLevel = 0, maxLevel = -1, blvl = 0, bfirst = -1, period = 1;
   for (int k = 0; k < nTouched; ++k) {
     uint64_t who = wave_ballot(active && rank == k);
     if (who == 0ull) continue;
@@ -1128,8 +1137,11 @@ DRV_PROF(const unsigned long long T1 = __builtin_amdgcn_s_memtime();)
     int la = ba < DRV_SLOT_OBST ? bcast_i(blvl, ba) : 0;
     int lb = bb2 < DRV_SLOT_OBST ? bcast_i(blvl, bb2) : 0;
     int lv = la > lb ? la : lb;
+    const int fa = ba < DRV_SLOT_OBST ? bcast_i(bfirst, ba) : -1, fb = bb2 < DRV_SLOT_OBST ? bcast_i(bfirst, bb2) : -1;
+    const int lo = fa < 0 ? fb : (fb < 0 ? fa : (fa < fb ? fa : fb));  // lowest level of an earlier arbiter sharing a body (-1: none)
+    if (lo >= 0 && lv - lo + 1 > period) period = lv - lo + 1;
     if (lane == b) myLevel = lv;
-    if (lane == ba || lane == bb2) blvl = lv + 1;  // static indices (>= 30) never equal a body lane (< 30)
+    if (lane == ba || lane == bb2) { blvl = lv + 1; if (bfirst < 0) bfirst = lv; }  // static indices (>= 30) never equal a body lane (< 30)
     maxLevel = lv > maxLevel ? lv : maxLevel;
   }
 
@@ -1139,7 +1151,7 @@ DRV_PROF(const unsigned long long T2 = __builtin_amdgcn_s_memtime();)
   const int solveBits = drv_prestep_solve(lane, (isCar ? 1 : 0) | (isPed ? 2 : 0),
                                           (a_state & 0xFF) | ((a_count & 0xFF) << 8) | ((a_age & 0xFF) << 16) | (touched ? 1 << 24 : 0) | (freeMe ? 1 << 25 : 0) |
                                               (hashSame ? 1 << 26 : 0) | (prevInert ? 1 << 27 : 0) | (skipped ? 1 << 28 : 0) | (slotOcc ? 1 << 29 : 0) | (active ? 1 << 30 : 0),
-                                          a_pair, bodyA, bodyB, myLevel, maxLevel, activeMask != 0ull ? 1 : 0, jn[0], jn[1], jt[0], jt[1]);
+                                          a_pair, bodyA, bodyB, myLevel, (maxLevel & 0xFF) | (period << 8), activeMask != 0ull ? 1 : 0, jn[0], jn[1], jt[0], jt[1]);
   occ &= ~freeMask;
 DRV_PROF(const unsigned long long T3 = T2, T4 = T2, T5 = __builtin_amdgcn_s_memtime(); const int profModeW = 0;)
 DRV_PROF(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* d = g_dbgp + blockIdx.x * 8; d[0] += T1 - T0; d[1] += T2 - T1; d[2] += T3 - T2; d[3] += T4 - T3; d[4] += T5 - T4; d[5] += 1ull + (light ? (1ull << 16) : 0ull); d[6] += (unsigned long long)(maxLevel + 1) + ((unsigned long long)(maxLevel + 1) << (12 * profModeW)); d[7] += (unsigned long long)nTouched + ((unsigned long long)profCand << 16); })
