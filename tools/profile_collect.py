@@ -72,9 +72,13 @@ def main():
                 if "SQ_WAVES" in m and m["SQ_WAVES"]:
                     lines.append("per wave and step: VALU %.0f, SALU %.0f, LDS %.0f, branches %.0f, VMEM rd %.0f / wr %.0f instructions"
                                  % tuple(m.get(x, 0) / m["SQ_WAVES"] for x in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")))
-                if "SQ_BUSY_CYCLES" in m and m["SQ_BUSY_CYCLES"]:
-                    # 1024 SIMDs x launch cycles of quad-cycles were available; ACTIVE_INST_VALU / (BUSY_CYCLES summed over SQs) ~ VALU busy
-                    lines.append("SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES = %.3f (VALU-busy share of the time the SQs had waves)" % (m.get("SQ_ACTIVE_INST_VALU", 0) / m["SQ_BUSY_CYCLES"]))
+                try:  # VALU issue-slot utilisation over the launch: a wave64 VALU instruction occupies its SIMD for >= 4 cycles
+                    rows = list(csv.DictReader(open("gpurun_out/%s_kernel_stats_%s.csv" % (tag, w))))
+                    avg_ns = [float(r["AverageNs"]) for r in rows if r["Name"].split("(")[0] == STEP_KERNELS[w][0]][0]
+                    lines.append("SIMD VALU busy >= %.1f %% of the launch (SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x %.1f us x 2.4 GHz); fp64 instructions hold the "
+                                 "SIMD longer than 4 cycles, so this is a lower bound)" % (100 * m.get("SQ_INSTS_VALU", 0) * 4 / (1024 * avg_ns * 2.4), avg_ns / 1e3))
+                except (OSError, IndexError, KeyError, ValueError):
+                    pass
             open("gpurun_out/%s_sq_breakdown_%s.txt" % (tag, w), "w").write(
                 "%s, 4096 envs, one whole episode (kernel sources %s); rocprofv3 --pmc, per launch\n" % (STEP_KERNELS[w][0], bench.kernel_source_sha()) + "\n".join(lines) + "\n")
     json.dump(out, open(path, "w"), indent=1)
