@@ -162,11 +162,15 @@ DE_DEV void velocity_update(DrvLds& L, int lane, bool isCar, bool isPed) {
 }
 
 // refresh the cached rotation of car `lane` (cpBodySetAngle -> cpvforangle) and the two road-relative cosines
+// INL: the inline form for drv_light_substep, which must stay a LEAF function - a function that calls saves its return
+// address through a VGPR that it stores to and reloads from scratch on every call (256 B per wave and substep, and the
+// reload sits right in front of the return).
+template <bool INL = false>
 DE_DEV void car_refresh_rot(DrvLds& L, int lane, double ang) {
-  const DevSC sc = dev_sincos(ang);
+  const DevSC sc = INL ? dev_sincos_inl(ang) : dev_sincos(ang);
   L.rc[lane] = sc.c; L.rs[lane] = sc.s; L.rotAng[lane] = ang;
-  L.cosRel0[lane] = dev_cos(RoadK<0>::dirAngle - ang);
-  L.cosRel1[lane] = dev_cos(RoadK<1>::dirAngle - ang);
+  L.cosRel0[lane] = INL ? dev_sincos_inl(RoadK<0>::dirAngle - ang).c : dev_cos(RoadK<0>::dirAngle - ang);
+  L.cosRel1[lane] = INL ? dev_sincos_inl(RoadK<1>::dirAngle - ang).c : dev_cos(RoadK<1>::dirAngle - ang);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1215,14 +1219,14 @@ DE_OOL DrvLightRet drv_light_substep(int it_, int lane, int A_, int nPed_, int n
           if (steer != 0) {
             const double rot = (double)steer * (DM_PI / 180.0);
             const double ang = L.ang[lane] + rot;
-            const DevSC rsc = dev_sincos(rot);
+            const DevSC rsc = dev_sincos_inl(rot);
             const double sn = rsc.s, cs = rsc.c;
             const double dx = dirx * cs - diry * sn, dy = dirx * sn + diry * cs;
             L.dirx[lane] = dx; L.diry[lane] = dy;
             const double nvx = vx * cs - vy * sn, nvy = vx * sn + vy * cs;
             vx = nvx; vy = nvy;
             L.ang[lane] = ang;
-            car_refresh_rot(L, lane, ang);
+            car_refresh_rot<true>(L, lane, ang);
             turned = true;
           }
         }
@@ -1322,7 +1326,7 @@ DE_OOL DrvLightRet drv_light_substep(int it_, int lane, int A_, int nPed_, int n
       const bool frozen = !turned && vx == 0.0 && vy == 0.0 && w == 0.0 && npx == px && npy == py && nang == ang;
       L.still[lane] = (still ? 1 : 0) | (frozen ? 2 : 0);
       if (isCar) {
-        if (nang != L.rotAng[lane]) car_refresh_rot(L, lane, nang);
+        if (nang != L.rotAng[lane]) car_refresh_rot<true>(L, lane, nang);
         if (!aabbValid || !frozen) {  // frozen: same position and rotation => same box
           BoxW bw;
           box_world(bw, v2(npx, npy), L.rc[lane], L.rs[lane], L.chx[lane], L.chy[lane]);
