@@ -100,6 +100,17 @@ struct RoadK<1> {  // Road(1, 35, [(0,500),(1750,500)])
   static constexpr double dirAngle = 0.0, cosDir0 = 1.0, nx = DRV_COS_PI_2, ny = 1.0;
 };
 
+// Car.py:9-12 (masses, lengths = half extent x, widths = half extent y, powers) and cpMomentForPoly of the car's box, as
+// literals; Pedestrian.py:11-14.  dynenv_create compares them with the table build_consts computes (car_literals_ok).
+struct CarK {
+  static constexpr double carMass0 = 1200.0, carMass1 = 1800.0, carMass2 = 3500.0, carMass3 = 5000.0;
+  static constexpr double carHx0 = 10.0, carHx1 = 15.0, carHx2 = 20.0, carHx3 = 25.0;
+  static constexpr double carHy0 = 5.0, carHy1 = 6.0, carHy2 = 7.0, carHy3 = 8.0;
+  static constexpr double carPower0 = 3.0, carPower1 = 4.0, carPower2 = 3.0, carPower3 = 4.0;
+  static constexpr double carInertia0 = 50000.0, carInertia1 = 156600.0, carInertia2 = 0x1.ff8e555555555p+18, carInertia3 = 0x1.185ad55555555p+20;
+  static constexpr double pedMass = 90.0, pedInertia = 90.0 * (0.5 * (0.0 * 0.0 + 5.0 * 5.0) + 0.0);
+};
+
 // Road.isPointOnRoad (Road.py:74-97) with cos(road.dirAngle - angle) supplied by the caller (cached)
 template <int R>
 DE_DEV int road_pos(V2 point, double cosRel) {
@@ -491,48 +502,71 @@ DE_DEV void write_full_obs(DrvLds& L, int lane, int A, int nPed, int nObst, int 
 // ------------------------------------------------------------------------------------------------
 // HBM <-> LDS (field-major rows: each field of one env is one coalesced 256-byte segment)
 // ------------------------------------------------------------------------------------------------
+// Every global load of an environment is ISSUED before the first one is waited for (addresses are clamped into the arrays, the
+// values of lanes without that object are replaced by the defaults afterwards): two memory round trips per launch - the
+// environment's scalars, then everything else - instead of one per `if` of the straightforward form (13, ~1.2 k cycles each).
+// The four car types' constants are wave-uniform (scalar loads) and selected by the type bits instead of indexed per lane.
 DE_DEV void load_env(const DrvState& S, DrvLds& L, int e, int lane, int A, int nPed, int nObst, uint64_t occ) {
   const size_t E = (size_t)S.E;
+  const int bl = lane & (DRV_NB - 1), cl = lane & 15, ol = lane < DRV_MAXO ? lane : DRV_MAXO - 1, sl = lane < DRV_NS ? lane : DRV_NS - 1;
+  const double* b = S.body + (size_t)e * DRV_NB + bl;
+  const double g_px = b[BF_PX * E * DRV_NB], g_py = b[BF_PY * E * DRV_NB], g_vx = b[BF_VX * E * DRV_NB], g_vy = b[BF_VY * E * DRV_NB];
+  const double g_ang = b[BF_ANG * E * DRV_NB], g_w = b[BF_W * E * DRV_NB];
+  const double g_vbx = b[BF_VBX * E * DRV_NB], g_vby = b[BF_VBY * E * DRV_NB], g_wb = b[BF_WB * E * DRV_NB];
+  const int g_f = S.flags[(size_t)e * DRV_NB + bl], g_aux = S.aux[(size_t)e * DRV_NB + bl];
+  const double* c = S.carx + (size_t)e * 16 + cl;
+  const double g_prevx = c[CF_PREVX * E * 16], g_prevy = c[CF_PREVY * E * 16], g_gx = c[CF_GOALX * E * 16], g_gy = c[CF_GOALY * E * 16];
+  const double g_dirx = c[CF_DIRX * E * 16], g_diry = c[CF_DIRY * E * 16];
+  const double g_ox = S.obst[(size_t)e * DRV_MAXO + ol], g_oy = S.obst[E * DRV_MAXO + (size_t)e * DRV_MAXO + ol];
+  int g_pair = 0xFFFF, g_meta = 0, g_h0 = 0, g_h1 = 0;
+  double g_jn0 = 0.0, g_jt0 = 0.0, g_jn1 = 0.0, g_jt1 = 0.0;
+  if (occ != 0ull) {  // (wave-uniform: most environments have an empty contact cache and skip these eight loads)
+    const size_t o = (size_t)e * DRV_NS + sl;
+    g_pair = S.s_pair[o]; g_meta = S.s_meta[o];
+    g_h0 = (int)S.s_hash[o]; g_h1 = (int)S.s_hash[E * DRV_NS + o];
+    g_jn0 = S.s_imp[o]; g_jt0 = S.s_imp[E * DRV_NS + o]; g_jn1 = S.s_imp[2 * E * DRV_NS + o]; g_jt1 = S.s_imp[3 * E * DRV_NS + o];
+  }
   if (lane < DRV_NB) {
     const bool used = lane < A || (lane >= DRV_SLOT_PED && lane < DRV_SLOT_PED + nPed);
-    const double* b = S.body + (size_t)e * DRV_NB + lane;
-    L.px[lane] = used ? b[BF_PX * E * DRV_NB] : 0.0; L.py[lane] = used ? b[BF_PY * E * DRV_NB] : 0.0;
-    L.vx[lane] = used ? b[BF_VX * E * DRV_NB] : 0.0; L.vy[lane] = used ? b[BF_VY * E * DRV_NB] : 0.0;
-    double ang = used ? b[BF_ANG * E * DRV_NB] : 0.0;
-    L.ang[lane] = ang; L.w[lane] = used ? b[BF_W * E * DRV_NB] : 0.0;
-    L.vbx[lane] = used ? b[BF_VBX * E * DRV_NB] : 0.0; L.vby[lane] = used ? b[BF_VBY * E * DRV_NB] : 0.0;
-    L.wb[lane] = used ? b[BF_WB * E * DRV_NB] : 0.0;
-    int f = used ? S.flags[(size_t)e * DRV_NB + lane] : 0;
+    L.px[lane] = used ? g_px : 0.0; L.py[lane] = used ? g_py : 0.0;
+    L.vx[lane] = used ? g_vx : 0.0; L.vy[lane] = used ? g_vy : 0.0;
+    const double ang = used ? g_ang : 0.0;
+    L.ang[lane] = ang; L.w[lane] = used ? g_w : 0.0;
+    L.vbx[lane] = used ? g_vbx : 0.0; L.vby[lane] = used ? g_vby : 0.0;
+    L.wb[lane] = used ? g_wb : 0.0;
+    const int f = used ? g_f : 0;
     L.flags[lane] = f;
-    L.moving[lane] = used ? S.aux[(size_t)e * DRV_NB + lane] : 0;
+    L.moving[lane] = used ? g_aux : 0;
+    const int ty = f & 3;
+    // the four car types' constants (Car.py:9-12 and cpMomentForPoly of the box) as literals selected by the type bits: no
+    // memory access that depends on the flag word just loaded (dynenv_create checks them against the computed table, CarK)
+#define DRV_BY_TYPE(ARR) (ty == 3 ? CarK::ARR##3 : (ty == 2 ? CarK::ARR##2 : (ty == 1 ? CarK::ARR##1 : CarK::ARR##0)))
     double minv = 0.0, iinv = 0.0;
-    if (lane < A) { minv = 1.0 / C.carMass[f & 3]; iinv = 1.0 / C.carInertia[f & 3]; }
-    else if (used) { minv = 1.0 / C.pedMass; iinv = 1.0 / C.pedInertia; }
+    if (lane < A) { minv = 1.0 / DRV_BY_TYPE(carMass); iinv = 1.0 / DRV_BY_TYPE(carInertia); }
+    else if (used) { minv = 1.0 / CarK::pedMass; iinv = 1.0 / CarK::pedInertia; }
     L.minv[lane] = minv; L.iinv[lane] = iinv;
     L.rc[lane] = 1.0; L.rs[lane] = 0.0; L.rotAng[lane] = 0.0;
     if (lane < A) {
-      const double* c = S.carx + (size_t)e * 16 + lane;
-      double prevx = c[CF_PREVX * E * 16], prevy = c[CF_PREVY * E * 16], gx = c[CF_GOALX * E * 16], gy = c[CF_GOALY * E * 16];
-      L.dirx[lane] = c[CF_DIRX * E * 16]; L.diry[lane] = c[CF_DIRY * E * 16];
-      L.prevx[lane] = prevx; L.prevy[lane] = prevy; L.goalx[lane] = gx; L.goaly[lane] = gy;
-      L.dprev[lane] = vlen(vsub(v2(prevx, prevy), v2(gx, gy)));
-      L.cmass[lane] = C.carMass[f & 3]; L.cpower[lane] = C.carPower[f & 3];
-      L.chx[lane] = C.carHx[f & 3]; L.chy[lane] = C.carHy[f & 3];
+      L.dirx[lane] = g_dirx; L.diry[lane] = g_diry;
+      L.prevx[lane] = g_prevx; L.prevy[lane] = g_prevy; L.goalx[lane] = g_gx; L.goaly[lane] = g_gy;
+      L.dprev[lane] = vlen(vsub(v2(g_prevx, g_prevy), v2(g_gx, g_gy)));
+      L.cmass[lane] = DRV_BY_TYPE(carMass); L.cpower[lane] = DRV_BY_TYPE(carPower);
+      L.chx[lane] = DRV_BY_TYPE(carHx); L.chy[lane] = DRV_BY_TYPE(carHy);
       car_refresh_rot(L, lane, ang);
     }
+#undef DRV_BY_TYPE
   }
   if (lane < DRV_MAXO) {
-    L.ox[lane] = lane < nObst ? S.obst[(size_t)e * DRV_MAXO + lane] : 0.0;
-    L.oy[lane] = lane < nObst ? S.obst[E * DRV_MAXO + (size_t)e * DRV_MAXO + lane] : 0.0;
+    L.ox[lane] = lane < nObst ? g_ox : 0.0;
+    L.oy[lane] = lane < nObst ? g_oy : 0.0;
   }
   if (lane < DRV_NS) {
     const bool on = (occ >> lane) & 1ull;
-    size_t o = (size_t)e * DRV_NS + lane;
-    L.s_pair[lane] = on ? S.s_pair[o] : 0xFFFF;
-    L.s_meta[lane] = on ? S.s_meta[o] : 0;
-    L.s_hash0[lane] = on ? (int)S.s_hash[o] : 0; L.s_hash1[lane] = on ? (int)S.s_hash[E * DRV_NS + o] : 0;
-    L.s_jn0[lane] = on ? S.s_imp[o] : 0.0; L.s_jt0[lane] = on ? S.s_imp[E * DRV_NS + o] : 0.0;
-    L.s_jn1[lane] = on ? S.s_imp[2 * E * DRV_NS + o] : 0.0; L.s_jt1[lane] = on ? S.s_imp[3 * E * DRV_NS + o] : 0.0;
+    L.s_pair[lane] = on ? g_pair : 0xFFFF;
+    L.s_meta[lane] = on ? g_meta : 0;
+    L.s_hash0[lane] = on ? g_h0 : 0; L.s_hash1[lane] = on ? g_h1 : 0;
+    L.s_jn0[lane] = on ? g_jn0 : 0.0; L.s_jt0[lane] = on ? g_jt0 : 0.0;
+    L.s_jn1[lane] = on ? g_jn1 : 0.0; L.s_jt1[lane] = on ? g_jt1 : 0.0;
   }
 }
 
@@ -1416,10 +1450,12 @@ DRV_PROF(if (lane < 8 && e < 4096) g_dbgp[e * 8 + lane] = 0ull;)
   const bool isCar = lane < A;
   const bool isPed = lane >= DRV_SLOT_PED && lane < DRV_SLOT_PED + nPed;
   const bool isBody = isCar || isPed;
+  // (the action and candidate-mask loads are issued with load_env's batch, not after it)
+  const int g_act0 = actions[((size_t)e * A + (isCar ? lane : 0)) * 2 + 0], g_act1 = actions[((size_t)e * A + (isCar ? lane : 0)) * 2 + 1];
+  const int g_lastCand = S.lastcand[(size_t)e * 64 + lane];
   load_env(S, L, e, lane, A, nPed, nObst, occ);
 
-  int act0 = 1, act1 = 1;
-  if (isCar) { act0 = actions[((size_t)e * A + lane) * 2 + 0]; act1 = actions[((size_t)e * A + lane) * 2 + 1]; }
+  int act0 = isCar ? g_act0 : 1, act1 = isCar ? g_act1 : 1;
   // action_space is MultiDiscrete([3, 3]) (:170-174); the reference raises on a malformed action (:365-368), here the car
   // coasts (acc = steer = 0) and the environment's error flag (bit 1, dynenv_error_flags) records it
   if ((unsigned)act0 > 2u || (unsigned)act1 > 2u) { act0 = 1; act1 = 1; err |= 2; }
@@ -1427,7 +1463,7 @@ DRV_PROF(if (lane < 8 && e < 4096) g_dbgp[e * 8 + lane] = 0ull;)
   bool aabbValid = false;
   // quiescent-shortcut state carried across launches: candidate mask of the previous substep (-1: unknown) and
   // whether every cached arbiter was inert when the contact path last ran
-  int lastCand = S.lastcand[(size_t)e * 64 + lane];
+  int lastCand = g_lastCand;
   bool inertAll = (uniform_i(envi[EI_PAD]) & 1) != 0;
   // steady-replay state: the contact path ran (or was replayed) in the previous substep and reported every slot steady
   bool steadyAll = (uniform_i(envi[EI_PAD]) & 2) != 0;

@@ -120,6 +120,16 @@ static bool road_literals_ok(const DrvRoad& r) {
          r.normal.y == RoadK<R>::ny;
 }
 
+// ... and so are the car-type constants (CarK)
+static bool car_literals_ok(const DrvConst& c) {
+  const double m[4] = {CarK::carMass0, CarK::carMass1, CarK::carMass2, CarK::carMass3}, hx[4] = {CarK::carHx0, CarK::carHx1, CarK::carHx2, CarK::carHx3};
+  const double hy[4] = {CarK::carHy0, CarK::carHy1, CarK::carHy2, CarK::carHy3}, pw[4] = {CarK::carPower0, CarK::carPower1, CarK::carPower2, CarK::carPower3};
+  const double in[4] = {CarK::carInertia0, CarK::carInertia1, CarK::carInertia2, CarK::carInertia3};
+  for (int t = 0; t < 4; ++t)
+    if (c.carMass[t] != m[t] || c.carHx[t] != hx[t] || c.carHy[t] != hy[t] || c.carPower[t] != pw[t] || c.carInertia[t] != in[t]) return false;
+  return c.pedMass == CarK::pedMass && c.pedInertia == CarK::pedInertia;
+}
+
 // ---------------------------------------------------------------------------------------------- helpers
 template <typename T>
 static int dev_alloc(dynenv* h, T** out, size_t count) {
@@ -389,9 +399,9 @@ int dynenv_create(const dynenv_cfg_t* cfg, dynenv_t** out) {
   if (rc) { dynenv_destroy(h); return DYNENV_ERR_HIP; }
   DrvConst c;
   build_consts(c);
-  if (!road_literals_ok<0>(c.roads[0]) || !road_literals_ok<1>(c.roads[1])) {
+  if (!road_literals_ok<0>(c.roads[0]) || !road_literals_ok<1>(c.roads[1]) || !car_literals_ok(c)) {
     dynenv_destroy(h);
-    return fail(DYNENV_ERR_HIP, "internal: RoadK literals differ from the computed road constants");
+    return fail(DYNENV_ERR_HIP, "internal: RoadK / CarK literals differ from the computed constants");
   }
   hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(C), &c, sizeof(c));
   if (e != hipSuccess) { dynenv_destroy(h); return fail(DYNENV_ERR_HIP, hipGetErrorString(e)); }
