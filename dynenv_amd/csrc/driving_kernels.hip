@@ -1548,28 +1548,39 @@ DRV_PROF(const unsigned long long A3 = __builtin_amdgcn_s_memtime(); tPh1 += A1 
 
 DRV_PROF(const unsigned long long K1 = __builtin_amdgcn_s_memtime();)
   // ---------------- end of env step :300-322 ----------------------------------------------------------------
+  // The read-modify-writes of the epilogue (episode sums, diagnostic counters) are split: their loads are issued here, the
+  // state and the observation are written meanwhile, the sums are stored last - one memory round trip hidden behind the
+  // observation instead of two in front of it.
+  double* er = S.epr + (size_t)e * 16 + (isCar ? lane : 0);
+  double* ep = S.epr + (size_t)S.E * 16 + (size_t)e * 16 + (isCar ? lane : 0);
+  const double g_er = *er, g_ep = *ep;
+  const int cl = lane < 9 ? lane : 0;  // lanes 0..8: one diagnostic counter each (EI_N_FAST .. EI_N_LIGHT are consecutive)
+  const int g_cnt = envi[EI_N_FAST + cl];
+  const int g_err = envi[EI_ERR];
   if (isCar) {
     rew += teamReward;
     posrew += dm_max(0.0, teamReward);
-    double* er = S.epr + (size_t)e * 16 + lane;
-    double* ep = S.epr + (size_t)S.E * 16 + (size_t)e * 16 + lane;
-    *er = *er + rew;
-    *ep = *ep + posrew;
     rewards[(size_t)e * A + lane] = rew;
   }
   if (lane == 0) {
     dones[e] = (uint8_t)(elapsed >= DRV_MAX_TIME);
     envi[EI_ELAPSED] = elapsed; envi[EI_ALLFIN] = allFinished; envi[EI_OCC] = (int)(uint32_t)occ;
     envi[EI_PAD] = (inertAll ? 1 : 0) | (steadyAll ? 2 : 0) | (vbValid ? 4 : 0);
-    envi[EI_N_STEADY] += nSteady; envi[EI_N_LIGHT] += nLight;
-    envi[EI_N_WHY_CAND] += nWhyCand; envi[EI_N_WHY_MOVING] += nWhyMoving; envi[EI_N_WHY_INERT] += nWhyInert;
-    envi[EI_N_FAST] += nFast; envi[EI_N_QUIET] += nQuiet; envi[EI_N_CONTACT] += nContact; envi[EI_N_SLOTS] += nSlots;
   }
   const int errBits = (wave_ballot((err & 1) != 0) ? 1 : 0) | (wave_ballot((err & 2) != 0) ? 2 : 0);
-  if (errBits && lane == 0) envi[EI_ERR] = envi[EI_ERR] | errBits;
   S.lastcand[(size_t)e * 64 + lane] = lastCand;
   store_env(S, L, e, lane, A, nPed, occ);
   if (obs) write_full_obs(L, lane, A, nPed, nObst, S.obs_dim, obs + (size_t)e * A * S.obs_dim);
+  if (isCar) { *er = g_er + rew; *ep = g_ep + posrew; }
+  {
+    static_assert(EI_N_QUIET == EI_N_FAST + 1 && EI_N_CONTACT == EI_N_FAST + 2 && EI_N_SLOTS == EI_N_FAST + 3 && EI_N_WHY_CAND == EI_N_FAST + 4 &&
+                  EI_N_WHY_MOVING == EI_N_FAST + 5 && EI_N_WHY_INERT == EI_N_FAST + 6 && EI_N_STEADY == EI_N_FAST + 7 && EI_N_LIGHT == EI_N_FAST + 8,
+                  "the diagnostic counters are consecutive");
+    const int add = lane == 0 ? nFast : lane == 1 ? nQuiet : lane == 2 ? nContact : lane == 3 ? nSlots : lane == 4 ? nWhyCand : lane == 5 ? nWhyMoving :
+                    lane == 6 ? nWhyInert : lane == 7 ? nSteady : nLight;
+    if (lane < 9) envi[EI_N_FAST + lane] = g_cnt + add;
+  }
+  if (errBits && lane == 0) envi[EI_ERR] = g_err | errBits;
   // Partial observation of this environment, fused (see drv_partial_obs_fused): the first `fusedAgents` agent passes run
   // here, the rest is left to the deferred launch.  An environment that spent the step on the contact path is among the
   // last to finish and defers everything; a light one keeps as many passes as fit before the heavy ones are done.
