@@ -53,6 +53,8 @@ struct __align__(16) DrvLds {
   // contact cache slots (lane s = slot s)
   int s_pair[DRV_NS], s_meta[DRV_NS], s_hash0[DRV_NS], s_hash1[DRV_NS];
   double s_jn0[DRV_NS], s_jt0[DRV_NS], s_jn1[DRV_NS], s_jt1[DRV_NS];
+  double rewAcc[16], posAcc[16];  // the step's reward / positive-reward accumulators of the cars (:252-254): in LDS, not carried
+                                  // through the substep loop in registers (two doubles less to save around every call)
   int still[DRV_NB];  // bit0: body had exactly zero v, w, v_bias, w_bias when positions were integrated; bit1: frozen
   unsigned short clist[DRV_CLIST];  // contact path: dense list of candidate pair ids in canonical order
   union {
@@ -603,7 +605,7 @@ DE_DEV void store_env(const DrvState& S, const DrvLds& L, int e, int lane, int A
 // (DrivingEnvironment.py:587-683: carCrash / pedHit / carHit).  Returns false => arbiter ignored until separation.
 // `rew` is the per-step reward accumulator held by the car's own lane.
 // ------------------------------------------------------------------------------------------------
-DE_DEV bool cb_begin(DrvLds& L, int i, int j, int lane, double& rew) {
+DE_DEV bool cb_begin(DrvLds& L, int i, int j, int lane) {
   // i = car, j = partner slot (car / pedestrian lane, or static >= 30); all arguments are wave-uniform
   const double v1x = L.vx[i], v1y = L.vy[i];
   const int f1 = L.flags[i];
@@ -613,7 +615,7 @@ DE_DEV bool cb_begin(DrvLds& L, int i, int j, int lane, double& rew) {
     const int crashed1 = CF_CRASHED(f1), crashed2 = CF_CRASHED(f2), pos1 = CF_LP(f1), pos2 = CF_LP(f2);
     const double v1len = vlen(v2(v1x, v1y)), v2len = vlen(v2(v2x, v2y));
     const double v1l = v1len / 5.0, v2l = v2len / 5.0;
-    double r1 = bcast_d(rew, i), r2 = bcast_d(rew, j);
+    double r1 = L.rewAcc[i], r2 = L.rewAcc[j];
     if (!crashed1) r1 -= v1l;
     if (!crashed2) r2 -= v2l;
     if (pos1 != LP_InRightLane && !crashed1) r1 -= v1l;
@@ -624,8 +626,8 @@ DE_DEV bool cb_begin(DrvLds& L, int i, int j, int lane, double& rew) {
       if (v1len > 1.0 && dev_cos(adp - dev_atan2(v1y, v1x)) < -0.4 && !crashed1) r1 -= v1l;
       if (v2len > 1.0 && dev_cos(adp - dev_atan2(v2y, v2x)) > 0.4 && !crashed2) r2 -= v2l;
     }
-    if (lane == i) { rew = r1; L.flags[i] = f1 | CF_CRASH_BITS; }
-    if (lane == j) { rew = r2; L.flags[j] = f2 | CF_CRASH_BITS; }
+    if (lane == i) { L.rewAcc[i] = r1; L.flags[i] = f1 | CF_CRASH_BITS; }
+    if (lane == j) { L.rewAcc[j] = r2; L.flags[j] = f2 | CF_CRASH_BITS; }
     return true;
   } else if (j < DRV_SLOT_OBST) {  // pedHit :640-667
     const double v1l = vlen(v2(v1x, v1y));
@@ -635,14 +637,14 @@ DE_DEV bool cb_begin(DrvLds& L, int i, int j, int lane, double& rew) {
         L.moving[j] = 0; L.vx[j] = 0.0; L.vy[j] = 0.0; L.flags[j] = L.flags[j] | (1 << 2);
       }
       if (dev_cos(dev_atan2(dp.y, dp.x) - dev_atan2(v1y, v1x)) < -0.4 && !CF_FIN(f1)) {
-        if (lane == i) { L.flags[i] = f1 | CF_CRASH_BITS; rew -= v1l / 5.0; }
+        if (lane == i) { L.flags[i] = f1 | CF_CRASH_BITS; L.rewAcc[i] = L.rewAcc[i] - v1l / 5.0; }
       }
       return true;
     }
     return false;
   } else {  // carHit :670-683
     if (lane == i) {
-      if (!CF_FIN(f1)) rew -= vlen(v2(v1x, v1y)) / 5.0;
+      if (!CF_FIN(f1)) L.rewAcc[i] = L.rewAcc[i] - vlen(v2(v1x, v1y)) / 5.0;
       L.flags[i] = f1 | CF_CRASH_BITS;
     }
     return true;
@@ -924,12 +926,11 @@ DE_OOL int drv_prestep_solve(int lane, int roleBits, int pk, int a_pair, int bod
 }
 struct ContactRet {
   uint64_t occ;
-  double rew;
   int err;
 };
 
 __device__ DRV_CONTACT_INLINE ContactRet drv_contact_path(int lane, int cand, int dirty, int light, int A, uint64_t occ,
-                                                    double rew, bool isCar, bool isPed) {
+                                                    bool isCar, bool isPed) {
   DrvLds& L = g_L;
   int err = 0;
   // ---------- slow path: narrowphase -> arbiter cache -> callbacks -> prestep -> friction -> solver -------
@@ -1038,7 +1039,7 @@ DRV_PROF(profCand += nCand;)
   }
   if (lightOk) {
     ContactRet ret;
-    ret.occ = occ; ret.rew = rew; ret.err = err | 8;
+    ret.occ = occ; ret.err = err | 8;
     return ret;
   }
 
@@ -1109,7 +1110,7 @@ DRV_PROF(const unsigned long long T1 = __builtin_amdgcn_s_memtime();)
     int st = bcast_i(a_state, b);
     if (st != ARB_FIRST) continue;
     int pk = bcast_i(a_pair, b);
-    bool keep = cb_begin(L, pk >> 8, pk & 0xFF, lane, rew);
+    bool keep = cb_begin(L, pk >> 8, pk & 0xFF, lane);
     if (!keep && lane == b) a_state = ARB_IGNORE;
     __syncthreads();
   }
@@ -1198,7 +1199,7 @@ DRV_PROF(const unsigned long long T3 = T2, T4 = T2, T5 = __builtin_amdgcn_s_memt
 DRV_PROF(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* d = g_dbgp + blockIdx.x * 8; d[0] += T1 - T0; d[1] += T2 - T1; d[2] += T3 - T2; d[3] += T4 - T3; d[4] += T5 - T4; d[5] += 1ull + (light ? (1ull << 16) : 0ull); d[6] += (unsigned long long)(maxLevel + 1) + ((unsigned long long)(maxLevel + 1) << (12 * profModeW)); d[7] += (unsigned long long)nTouched + ((unsigned long long)profCand << 16); })
   {
     ContactRet ret;
-    ret.occ = occ; ret.rew = rew; ret.err = err | (uniform_i(solveBits) & 6);
+    ret.occ = occ; ret.err = err | (uniform_i(solveBits) & 6);
     return ret;
   }
 }
@@ -1215,12 +1216,11 @@ DE_OOL void drv_partial_obs_fused(const DrvState& S, int e, int lane, int nPed, 
 #define DRV_FUSED_AGENTS 7 /* agent passes a light environment runs in the step launch */
 #endif
 struct DrvLightRet {
-  double rew, posrew;
   int cand, dirty, bits;
 };
 struct DrvSeedOnly { uint64_t seed; };
 DE_OOL DrvLightRet drv_light_substep(int it_, int lane, int A_, int nPed_, int nObst_, int elapsed_, int act0, int act1, int lastCand,
-                                                      uint32_t seedLo, uint32_t seedHi, uint32_t genv_, uint32_t episode_, int stateBits, double rew, double posrew) {
+                                                      uint32_t seedLo, uint32_t seedHi, uint32_t genv_, uint32_t episode_, int stateBits) {
   DrvLds& L = g_L;
   const int it = uniform_i(it_), A = uniform_i(A_), nPed = uniform_i(nPed_), nObst = uniform_i(nObst_), elapsed = uniform_i(elapsed_);
   const uint32_t genv = (uint32_t)uniform_i((int)genv_), episode = (uint32_t)uniform_i((int)episode_);
@@ -1269,6 +1269,7 @@ DE_OOL DrvLightRet drv_light_substep(int it_, int lane, int A_, int nPed_, int n
         }
       }
       // tick :376-426
+      double rew = L.rewAcc[lane], posrew = L.posAcc[lane];
       const V2 pos = v2(px, py);
       int lp = LP_OffRoad;
       {
@@ -1300,6 +1301,7 @@ DE_OOL DrvLightRet drv_light_substep(int it_, int lane, int A_, int nPed_, int n
       if (px >= DRV_W + 50.0 || px <= -50.0 || py >= DRV_H + 50.0 || py <= -50.0) { vx = 0.0; vy = 0.0; }  // prevPos == pos here
       L.flags[lane] = f;
       L.vx[lane] = vx; L.vy[lane] = vy;
+      L.rewAcc[lane] = rew; L.posAcc[lane] = posrew;
     } else if (isPed) {
       // ======== phase 1b: pedestrian FSM (move :429-506) ====================================================
       const int f = L.flags[lane];
@@ -1425,7 +1427,7 @@ DE_OOL DrvLightRet drv_light_substep(int it_, int lane, int A_, int nPed_, int n
       removed = lastCand < 0 || (lastCand & ~cand) != 0;
     }
   DrvLightRet ret;
-  ret.rew = rew; ret.posrew = posrew; ret.cand = cand; ret.dirty = dirty; ret.bits = (candMoving ? 1 : 0) | (removed ? 2 : 0);
+  ret.cand = cand; ret.dirty = dirty; ret.bits = (candMoving ? 1 : 0) | (removed ? 2 : 0);
   return ret;
 }
 template <bool PARTIAL>
@@ -1462,7 +1464,8 @@ DRV_PROF(if (lane < 8 && e < 4096) g_dbgp[e * 8 + lane] = 0ull;)
   // action_space is MultiDiscrete([3, 3]) (:170-174); the reference raises on a malformed action (:365-368), here the car
   // coasts (acc = steer = 0) and the environment's error flag (bit 1, dynenv_error_flags) records it
   if ((unsigned)act0 > 2u || (unsigned)act1 > 2u) { act0 = 1; act1 = 1; err |= 2; }
-  double rew = 0.0, posrew = 0.0, teamReward = 0.0;  // :252-254
+  double teamReward = 0.0;  // :252-254
+  if (lane < 16) { L.rewAcc[lane] = 0.0; L.posAcc[lane] = 0.0; }
   bool aabbValid = false;
   // quiescent-shortcut state carried across launches: candidate mask of the previous substep (-1: unknown) and
   // whether every cached arbiter was inert when the contact path last ran
@@ -1480,8 +1483,7 @@ DRV_PROF(const unsigned long long K0 = __builtin_amdgcn_s_memtime(); unsigned lo
 DRV_PROF(const unsigned long long A0 = __builtin_amdgcn_s_memtime();)
     // ======== phase 1a: car game logic (processAction at substep 0, tick) ===================================
     const DrvLightRet lr = drv_light_substep(it, lane, A, nPed, nObst, elapsed, act0, act1, lastCand, (uint32_t)S.seed, (uint32_t)(S.seed >> 32), genv, episode,
-                                             (vbValid ? 1 : 0) | (aabbValid ? 2 : 0), rew, posrew);
-    rew = lr.rew; posrew = lr.posrew;
+                                             (vbValid ? 1 : 0) | (aabbValid ? 2 : 0));
     const int cand = lr.cand, dirty = lr.dirty;
     const bool candMoving = (lr.bits & 1) != 0, removed = (lr.bits & 2) != 0;
     aabbValid = true;
@@ -1519,13 +1521,13 @@ DRV_PROF(const unsigned long long A2 = __builtin_amdgcn_s_memtime(); bool tookCo
       // ---------- contact path (out of line): narrowphase -> contact cache -> callbacks -> prestep -> friction -> solver
 DRV_PROF(tookContact = true;)
       __builtin_amdgcn_s_setprio(3);  // an environment on the contact path is on the launch's critical path: issue it first
-      ContactRet cr = drv_contact_path(lane, cand, dirty, light ? 1 : 0, A, occ, rew, isCar, isPed);
+      ContactRet cr = drv_contact_path(lane, cand, dirty, light ? 1 : 0, A, occ, isCar, isPed);
       err |= cr.err & 1;
       if (light && !(uniform_i(cr.err >> 3) & 1)) lightOff = true;
       if (uniform_i(cr.err >> 3) & 1) {  // light mode: no dirty pair touches => replay
         replay = true; nLight++;
       } else {
-        occ = uniform_u64(cr.occ); rew = cr.rew;
+        occ = uniform_u64(cr.occ);
         inertAll = (uniform_i(cr.err >> 1) & 1) != 0;
         steadyAll = (uniform_i(cr.err >> 2) & 1) != 0;
         vbValid = true;
@@ -1560,9 +1562,10 @@ DRV_PROF(const unsigned long long K1 = __builtin_amdgcn_s_memtime();)
   const int cl = lane < 9 ? lane : 0;  // lanes 0..8: one diagnostic counter each (EI_N_FAST .. EI_N_LIGHT are consecutive)
   const int g_cnt = envi[EI_N_FAST + cl];
   const int g_err = envi[EI_ERR];
+  double rew = 0.0, posrew = 0.0;
   if (isCar) {
-    rew += teamReward;
-    posrew += dm_max(0.0, teamReward);
+    rew = L.rewAcc[lane] + teamReward;
+    posrew = L.posAcc[lane] + dm_max(0.0, teamReward);
     rewards[(size_t)e * A + lane] = rew;
   }
   if (lane == 0) {
