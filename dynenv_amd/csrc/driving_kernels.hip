@@ -933,6 +933,10 @@ __device__ DRV_CONTACT_INLINE ContactRet drv_contact_path(int lane, int cand, in
                                                     bool isCar, bool isPed) {
   DrvLds& L = g_L;
   int err = 0;
+  // The lane id is made opaque here: everything this (inlined) function derives from it - quad roles, lane masks, slot
+  // predicates - is then recomputed per call (a few integer instructions) instead of being hoisted out of the kernel's substep
+  // loop and kept alive, i.e. saved to and reloaded from scratch, across every call the loop makes.
+  asm volatile("" : "+v"(lane));
   // ---------- slow path: narrowphase -> arbiter cache -> callbacks -> prestep -> friction -> solver -------
 DRV_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
   DrvMailbox& M = L.u.mb;
@@ -957,7 +961,7 @@ DRV_PROF(int profCand = 0;)
     const uint64_t m = wave_ballot(c);
     if (m == 0ull) continue;
     if (c) {
-      const int idx = nCand + __popcll(m & lanemask_lt());
+      const int idx = nCand + __popcll(m & ((1ull << lane) - 1ull));
       if (idx < DRV_CLIST) L.clist[idx] = (unsigned short)((i << 8) | lane); else err |= 1;  // overflow is reported
     }
     nCand += __popcll(m);
@@ -1010,7 +1014,7 @@ DRV_PROF(profCand += nCand;)
     const uint64_t newMask = wave_ballot(needNew);
     if (newMask) {
       const uint64_t slotBits = (1ull << DRV_NS) - 1ull;
-      int rank = __popcll(newMask & lanemask_lt());
+      int rank = __popcll(newMask & ((1ull << lane) - 1ull));
       uint64_t fm = (~occ) & slotBits;
       if (needNew) {
         for (int r = 0; r < rank; ++r) fm &= fm - 1;
@@ -1436,7 +1440,7 @@ DE_DEV void drv_step_body(const DrvState& S, const int* __restrict__ actions, fl
 DRV_PROF(const unsigned long long KS = __builtin_amdgcn_s_memtime();)
   DrvLds& L = g_L;
   const int e = blockIdx.x;
-  const int lane = threadIdx.x;
+  int lane = threadIdx.x;
 DRV_PROF(if (lane < 8 && e < 4096) g_dbgp[e * 8 + lane] = 0ull;)
   const int A = S.A;
   int* envi = S.envi + (size_t)e * EI_COUNT;
@@ -1480,6 +1484,8 @@ DRV_PROF(if (lane < 8 && e < 4096) g_dbgp[e * 8 + lane] = 0ull;)
 DRV_PROF(const unsigned long long K0 = __builtin_amdgcn_s_memtime(); unsigned long long tPh1 = 0, tBroad = 0, tFast = 0, tCont = 0, tBook = 0;)
   bool lightOff = false;
   for (int it = 0; it < 10; ++it) {
+    asm volatile("" : "+v"(lane));  // opaque per iteration: nothing derived from the lane id is hoisted out of the loop and kept
+                                      // alive (= spilled and reloaded) across the calls of every substep
 DRV_PROF(const unsigned long long A0 = __builtin_amdgcn_s_memtime();)
     // ======== phase 1a: car game logic (processAction at substep 0, tick) ===================================
     const DrvLightRet lr = drv_light_substep(it, lane, A, nPed, nObst, elapsed, act0, act1, lastCand, (uint32_t)S.seed, (uint32_t)(S.seed >> 32), genv, episode,
