@@ -1557,7 +1557,10 @@ DE_DEV void rc_store_env(const RcState& S, const RcLds& L, int e, int lane, uint
 #define RC_STD_NORM (2.0 / RC_W)
 DE_DEV double norm_after_scale(double pt, double nf, double mean) { return (pt - mean) * nf; }  // x team applied as a sign
 
-DE_DEV void rc_write_obs(RcLds& L, int lane, int R, int obs_dim, float* __restrict__ out, int W = 64) {
+// out of line with inline trigonometry (a leaf, its own register allocation: no spill reloads between its stores)
+DE_OOL void rc_write_obs_ool(int lane, int R, int obs_dim, float* __restrict__ out) {
+  RcLds& L = g_R;
+  constexpr int W = 64;
   RcObsStage& O = L.u.ob;
   __syncthreads();
   if (lane < R) {
@@ -1566,11 +1569,11 @@ DE_DEV void rc_write_obs(RcLds& L, int lane, int R, int obs_dim, float* __restri
     const int f = L.rflags[lane];
     O.rx[lane] = (float)norm_after_scale(p.x, RC_STD_NORM, RC_W / 2.0);
     O.ry[lane] = (float)norm_after_scale(p.y, RC_STD_NORM, RC_H / 2.0);
-    const DevSC a = dev_sincos(ang);
+    const DevSC a = dev_sincos_inl(ang);
     O.rcs[lane] = (float)a.c; O.rsn[lane] = (float)a.s;
-    const DevSC ah = dev_sincos(ang + L.head[lane]);
+    const DevSC ah = dev_sincos_inl(ang + L.head[lane]);
     O.ahc[lane] = (float)ah.c; O.ahs[lane] = (float)ah.s;
-    const DevSC h = dev_sincos(L.head[lane]);
+    const DevSC h = dev_sincos_inl(L.head[lane]);
     O.hc[lane] = (float)h.c; O.hs[lane] = (float)h.s;
     O.team[lane] = (f & RF_TEAMPOS) ? 1.0f : -1.0f;
     O.down[lane] = (f & (RF_FALLEN | RF_PENAL)) ? 1.0f : 0.0f;
@@ -1718,7 +1721,8 @@ DE_DEV void rc_step_body(const RcState& S, const int e, const int* __restrict__ 
   typedef Grp<EPW> G;
   constexpr int W = G::W, NROUNDS = (RC_NPAIR_ROUNDS * 64) / W;
   static_assert(!PARTIAL || EPW == 1, "the fused Partial observation works on one environment per wave");
-  const int lane = G::lane(), R = S.R;
+  int lane = G::lane();
+  const int R = S.R;
   if (e < 0 || e >= S.E) return;  // (two environments per wave: a half without an environment; its lanes are off from here on)
   RcLds& L = G::tile();
   uint64_t occ = (uint64_t)(uint32_t)G::uniform_i(S.envi[(size_t)e * RE_COUNT + RE_OCC]);
@@ -1758,6 +1762,7 @@ DE_DEV void rc_step_body(const RcState& S, const int e, const int* __restrict__ 
 
 RC_PROF(if (lane < 12 && e < 4096) g_rcprof[e * 12 + lane] = 0ull; const unsigned long long K0 = __builtin_amdgcn_s_memtime(); unsigned long long tG = 0, tP = 0, tB = 0;)
   for (int it = 0; it < 50; ++it) {
+    asm volatile("" : "+v"(lane));  // opaque per substep: nothing derived from the lane id is hoisted out of the loop and spilled around its calls
 RC_PROF(const unsigned long long A0 = __builtin_amdgcn_s_memtime();)
     // the game logic's sequential form (first substep: processAction; later: a cross-robot event) is the only call of the common
     // part: it is made from here, the outermost frame, so that rc_common_substep itself contains no call at all
@@ -1788,7 +1793,7 @@ RC_PROF(tP += __builtin_amdgcn_s_memtime() - A0;)
         if (lane < 20) sn.ang[lane] = L.ang[lane];
         if (lane < 10) { sn.head[lane] = L.head[lane]; sn.rflags[lane] = L.rflags[lane]; }
         if (lane == 0) { sn.owned = L.envi[RE_OWNED]; sn.close0 = L.envi[RE_CLOSE0]; sn.close1 = L.envi[RE_CLOSE1]; sn.tkey = L.envi[RE_ELAPSED]; }
-      } else if (obs) rc_write_obs(L, lane, R, S.obs_dim, obs + ((size_t)e * 5 + snap) * R * S.obs_dim, W);
+      } else if (obs) rc_write_obs_ool(lane, R, S.obs_dim, obs + ((size_t)e * 5 + snap) * R * S.obs_dim);
       ++snap;
     }
   }
@@ -1852,7 +1857,7 @@ extern "C" __global__ void __launch_bounds__(64) rc_obs_kernel(RcState S, float*
   rc_load_env(S, L, e, lane, 0ull);
   __syncthreads();
   if (fullOnce) {
-    rc_write_obs(L, lane, S.R, 4 + 8 + (S.R - 1) * 6, obs + (size_t)e * S.R * (4 + 8 + (S.R - 1) * 6));
+    rc_write_obs_ool(lane, S.R, 4 + 8 + (S.R - 1) * 6, obs + (size_t)e * S.R * (4 + 8 + (S.R - 1) * 6));
     return;
   }
   if (S.obs_type == DYNENV_OBS_PARTIAL) {
@@ -1868,7 +1873,7 @@ extern "C" __global__ void __launch_bounds__(64) rc_obs_kernel(RcState S, float*
     return;
   }
   for (int t = 0; t < 5; ++t)  // environment_base.py:217-222: nTimeSteps copies of the initial observation
-    rc_write_obs(L, lane, S.R, S.obs_dim, obs + ((size_t)e * 5 + t) * S.R * S.obs_dim);
+    rc_write_obs_ool(lane, S.R, S.obs_dim, obs + ((size_t)e * 5 + t) * S.R * S.obs_dim);
 }
 
 // getFullState(agent=None) (RoboCupEnvironment.py:1149-1161), what step() stores as info['Full State'] (:511): per environment
