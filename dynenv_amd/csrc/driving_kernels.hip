@@ -755,6 +755,7 @@ DE_DEV void body_store_bias(DrvLds& L, int idx, const BodyV& b) {
 DRV_PROF(__device__ unsigned long long g_dbgw[4096 * 12];)
 DRV_PROF(__device__ unsigned long long g_dbgp[4096 * 8];)
 DRV_PROF(__device__ unsigned long long g_dbgr[16];)
+DRV_PROF(DE_DEV int prof_any(int v) { const uint64_t m = wave_ballot(v != 0); return m ? bcast_i(v, __builtin_ctzll(m)) : 0; })
 // Which half of a substep is out of line.  DRV_INVERT = 1 (default): the COMMON part (game logic, position update, broadphase:
 // drv_light_substep, 88 VGPRs, nothing to save) is the function and the contact path is inlined into the kernel, which as the
 // outermost frame never saves a register: the per-call save / restore of 47 callee-saved VGPRs that the round-1 layout
@@ -810,6 +811,7 @@ DE_OOL int drv_prestep_solve(int lane, int roleBits, int pk, int a_pair, int bod
 
   // ---- velocity update (velocity_func: friction_* or default) -------------------------------------------
   velocity_update(L, lane, isCar, isPed);
+DRV_PROF(int profMode = 0;)
   if (activeMask && maxLevel == 0) {
     // No two active arbiters share a dynamic body: each lane keeps its two bodies in registers through the warm start
     // and all 10 iterations, with one LDS load and one store (same arithmetic, no LDS round trip per iteration).
@@ -820,9 +822,11 @@ DE_OOL int drv_prestep_solve(int lane, int roleBits, int pk, int a_pair, int bod
       body_load(L, bodyB, b);
       if (a_state != ARB_FIRST) arb_warm_start(a, b, n, r1, r2, jn, jt, a_count);
       if (wave_ballot(!arb_is_bias_only(a, b, jn, jt, bounce, a_count)) == 0ull) {  // all resting contacts: bias half only
+DRV_PROF(profMode = 1;)
 #pragma unroll 1
         for (int iter = 0; iter < 10; ++iter) arb_apply_bias_only(a, b, n, r1, r2, nMass, bias, jBias, a_count);
       } else {
+DRV_PROF(profMode = 2;)
 #pragma unroll 1
         for (int iter = 0; iter < 10; ++iter) arb_apply_impulse(a, b, n, r1, r2, nMass, tMass, bias, bounce, jBias, jn, jt, a_count, arb_u);
       }
@@ -859,6 +863,7 @@ DE_OOL int drv_prestep_solve(int lane, int roleBits, int pk, int a_pair, int bod
     // bit for bit the sequential one.  A chain of L resting cars (period 2) needs L + 18 time steps instead of 10 L.
     const int nSteps = maxLevel + 1 + period * 9;
     int due = myLevel, passes = 0;
+DRV_PROF(profMode = wave_ballot(!biasOnly) == 0ull ? 3 : 4;)
     if (wave_ballot(!biasOnly) == 0ull) {
       // every active arbiter is a resting contact being pushed out of penetration (the pile-ups that make up the launch's
       // tail): only bias velocities move, through LDS
@@ -922,7 +927,7 @@ DE_OOL int drv_prestep_solve(int lane, int roleBits, int pk, int a_pair, int bod
     if (touched) { L.s_jn0[lane] = jn[0]; L.s_jt0[lane] = jt[0]; L.s_jn1[lane] = jn[1]; L.s_jt1[lane] = jt[1]; }
   }
   const bool allInert = wave_ballot(!inert) == 0ull;
-  return (allInert ? 2 : 0) | (allSteady ? 4 : 0);
+  return (allInert ? 2 : 0) | (allSteady ? 4 : 0) DRV_PROF(| (prof_any(profMode) << 4));
 }
 struct ContactRet {
   uint64_t occ;
@@ -1199,7 +1204,7 @@ DRV_PROF(const unsigned long long T2 = __builtin_amdgcn_s_memtime();)
                                               (hashSame ? 1 << 26 : 0) | (prevInert ? 1 << 27 : 0) | (skipped ? 1 << 28 : 0) | (slotOcc ? 1 << 29 : 0) | (active ? 1 << 30 : 0),
                                           a_pair, bodyA, bodyB, myLevel, (maxLevel & 0xFF) | (period << 8), activeMask != 0ull ? 1 : 0, jn[0], jn[1], jt[0], jt[1]);
   occ &= ~freeMask;
-DRV_PROF(const unsigned long long T3 = T2, T4 = T2, T5 = __builtin_amdgcn_s_memtime(); const int profModeW = 0;)
+DRV_PROF(const unsigned long long T3 = T2, T4 = T2, T5 = __builtin_amdgcn_s_memtime(); const int profModeW = (uniform_i(solveBits) >> 4) & 7;)
 DRV_PROF(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* d = g_dbgp + blockIdx.x * 8; d[0] += T1 - T0; d[1] += T2 - T1; d[2] += T3 - T2; d[3] += T4 - T3; d[4] += T5 - T4; d[5] += 1ull + (light ? (1ull << 16) : 0ull); d[6] += (unsigned long long)(maxLevel + 1) + ((unsigned long long)(maxLevel + 1) << (12 * profModeW)); d[7] += (unsigned long long)nTouched + ((unsigned long long)profCand << 16); })
   {
     ContactRet ret;
