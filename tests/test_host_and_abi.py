@@ -284,3 +284,30 @@ def test_bulk_compat_builder_equals_the_loop_builder(oracle_built, env_type, n, 
         _deep_same(bulk[idx], loop[idx])
     if not partial and env_type == 1:
         assert len({bulk[e, 0, 0, 0][1].shape[0] for e in range(E)}) > 1, "ragged obstacle lists must differ between environments"
+
+
+def test_bench_reports_traffic_only_for_the_kernels_it_was_measured_on(tmp_path, monkeypatch):
+    """roofline.traffic comes from profiles/pmc_traffic.json (a PMC pass cannot run inside bench.py): the file is stamped with the
+    sha256 of the kernel sources it was measured on, and a figure measured on other sources is reported as null with the reason"""
+    import importlib
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    sha = bench.kernel_source_sha()
+    assert len(sha) == 16 and int(sha, 16) >= 0
+    committed = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    assert "kernel_source_sha16" in committed and "drv_step_kernel_bytes_per_launch" in committed
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_source_sha", lambda: sha)
+    (prof / "pmc_traffic.json").write_text(json.dumps({"kernel_source_sha16": sha, "drv_step_kernel_bytes_per_launch": 123.0,
+                                                        "drv_step_kernel_detail": {"step_bytes_all_kernels": 456.0}}))
+    t, d = bench.measured_traffic("drv_step_kernel")
+    assert t == 123.0 and d["traffic_whole_step"] == 456.0 and sha in d["traffic_source"]
+    (prof / "pmc_traffic.json").write_text(json.dumps({"kernel_source_sha16": "0" * 16, "drv_step_kernel_bytes_per_launch": 123.0}))
+    t, d = bench.measured_traffic("drv_step_kernel")
+    assert t is None and "STALE" in d["traffic_source"]
+    (prof / "pmc_traffic.json").unlink()
+    assert bench.measured_traffic("drv_step_kernel") == (None, {"traffic_source": None})
