@@ -1241,10 +1241,14 @@ DE_OOL DrvLightRet drv_light_substep(int it_, int lane, int A_, int nPed_, int n
   const bool vbValid = (uniform_i(stateBits) & 1) != 0;
   bool aabbValid = (uniform_i(stateBits) & 2) != 0;
     bool turned = false;  // Car.turn rotated the body in place: geometry changed even if every velocity is zero
+    // ---- common prefix of cars and pedestrians, ONE instruction stream for both (the two roles sit on different lanes of the
+    //      wave: what each does on its own is executed one after the other): state loads and, after processAction, the lane
+    //      classification of the position - min over the two roads of Road.isPointOnRoad - with the car's cached
+    //      cos(road - angle) or, for a pedestrian (isOffRoad, angle 0), the road's constant
+    int f = 0;
+    double px = 0.0, py = 0.0, vx = 0.0, vy = 0.0;
+    if (isBody) { f = L.flags[lane]; px = L.px[lane]; py = L.py[lane]; vx = L.vx[lane]; vy = L.vy[lane]; }
     if (isCar) {
-      int f = L.flags[lane];
-      const double px = L.px[lane], py = L.py[lane];
-      double vx = L.vx[lane], vy = L.vy[lane];
       if (it == 0) {  // processAction :357-373 -> Car.accelerate (Car.py:55-94), Car.turn (Car.py:97-108)
         const int acc = act0 - 1, steer = (act1 - 1) * 2;
         if (!CF_FIN(f)) {
@@ -1277,16 +1281,18 @@ DE_OOL DrvLightRet drv_light_substep(int it_, int lane, int A_, int nPed_, int n
           }
         }
       }
+    }
+    const V2 pos = v2(px, py);
+    int lp = LP_OffRoad;
+    if (isBody) {
+      int rp = road_pos<0>(pos, isCar ? L.cosRel0[lane] : RoadK<0>::cosDir0);
+      if (rp < lp) lp = rp;
+      rp = road_pos<1>(pos, isCar ? L.cosRel1[lane] : RoadK<1>::cosDir0);
+      if (rp < lp) lp = rp;
+    }
+    if (isCar) {
       // tick :376-426
       double rew = L.rewAcc[lane], posrew = L.posAcc[lane];
-      const V2 pos = v2(px, py);
-      int lp = LP_OffRoad;
-      {
-        int rp = road_pos<0>(pos, L.cosRel0[lane]);
-        if (rp < lp) lp = rp;
-        rp = road_pos<1>(pos, L.cosRel1[lane]);
-        if (rp < lp) lp = rp;
-      }
       const double dnow = vlen(vsub(pos, v2(L.goalx[lane], L.goaly[lane])));
       const double diff = L.dprev[lane] - dnow;
       if (!CF_FIN(f)) { const double d50 = diff / 50.0; rew += d50; posrew += dm_max(0.0, d50); }
@@ -1313,13 +1319,10 @@ DE_OOL DrvLightRet drv_light_substep(int it_, int lane, int A_, int nPed_, int n
       L.rewAcc[lane] = rew; L.posAcc[lane] = posrew;
     } else if (isPed) {
       // ======== phase 1b: pedestrian FSM (move :429-506) ====================================================
-      const int f = L.flags[lane];
       if (!PF_DEAD(f)) {
-        double vx = L.vx[lane], vy = L.vy[lane];
         int moving = L.moving[lane];
         int crossing = PF_CROSSING(f), beginc = PF_BEGIN(f), side = PF_SIDE(f);
-        const V2 pos = v2(L.px[lane], L.py[lane]);
-        const bool isOffRoad = drv_is_off_road(pos);
+        const bool isOffRoad = lp >= LP_OverRoad;  // drv_is_off_road(pos)
         const bool isOut = drv_is_out(pos);
         if (moving > 0) {
           moving = (moving - DRV_TIME_DIFF > 0) ? moving - DRV_TIME_DIFF : 0;
