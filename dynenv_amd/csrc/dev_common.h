@@ -44,7 +44,16 @@ DE_HD double fclamp01_cp(double f) { return fmax_cp(0.0, fmin_cp(f, 1.0)); }
 
 // ---- wave64 cross-lane helpers -------------------------------------------------------------
 DE_DEV uint64_t wave_ballot(bool p) { return __ballot(p); }
-DE_DEV int lane_id() { return (int)(threadIdx.x & 63); }
+// (not threadIdx.x & 63: a function that reads the work-item id makes every caller keep v31, the ABI's packed id, alive for it)
+DE_DEV int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// The lane id computed afresh (two instructions, no input): a value the compiler cannot tie to an earlier copy, so a kernel that
+// calls it after every call of a 128-VGPR function keeps nothing lane-derived alive - and spilled - across that call.
+// (workgroup = one wave: the id within the wave is threadIdx.x)
+DE_DEV int fresh_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
 DE_DEV uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
 // broadcast from a wave-uniform lane index (v_readlane_b32 pairs for doubles)
@@ -63,6 +72,9 @@ DE_DEV uint64_t uniform_u64(uint64_t v) {
   uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
   return ((uint64_t)hi << 32) | lo;
 }
+template <typename T>
+DE_DEV T* uniform_ptr(T* p) { return (T*)uniform_u64((uint64_t)p); }
+DE_DEV double uniform_d(double v) { return __longlong_as_double((long long)uniform_u64((uint64_t)__double_as_longlong(v))); }
 
 // Out-of-line transcendental wrappers for device code.  sincos/atan2 are only needed when a car's angle changes or a
 // collision callback fires; inlining their polynomial constants into the substep loop makes the compiler hoist dozens

@@ -1216,8 +1216,8 @@ DRV_PROF(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* d = g_dbgp + 
 // ------------------------------------------------------------------------------------------------
 // THE step kernel: grid = E blocks of one wavefront
 // ------------------------------------------------------------------------------------------------
-DE_OOL void drv_partial_obs_fused(const DrvState& S, int e, int lane, int nPed, int nObst, int elapsed, uint32_t episode,
-                                                   PvIn in, int noiseType, double magn, float* __restrict__ obs, int nAgents);  // driving_partial.hip
+DE_OOL void drv_partial_obs_fused(PvIn in, uint64_t seed, int A, int* envi, int env_id_offset, int e, int nPedObst, int elapsed,
+                                  uint32_t episode, int noiseType, double magn, float* __restrict__ obs, int nAgents);  // driving_partial.hip
 #ifndef DRV_DEFER_MIN_CONTACT
 #define DRV_DEFER_MIN_CONTACT 5 /* contact-path substeps (of 10) from which an environment defers its Partial observation */
 #endif
@@ -1614,10 +1614,7 @@ DRV_PROF(const unsigned long long K1 = __builtin_amdgcn_s_memtime();)
     }
     if (lane < nObst) { in.ox = L.ox[lane]; in.oy = L.oy[lane]; }
     if (lane < A) { in.gx = L.goalx[lane]; in.gy = L.goaly[lane]; }
-    // (a copy: the out-of-line function takes the state by reference, and an address-taken S would live in scratch for the
-    //  whole kernel - every S.field of the step a scratch load instead of a kernel-argument SGPR)
-    const DrvState Scopy = S;
-    drv_partial_obs_fused(Scopy, e, lane, nPed, nObst, elapsed, episode, in, pvNoise, pvMagn, pobs, fusedAgents);
+    drv_partial_obs_fused(in, S.seed, S.A, S.envi, S.env_id_offset, e, nPed | (nObst << 8), elapsed, episode, pvNoise, pvMagn, pobs, fusedAgents);
   }
 DRV_PROF(if (lane == 0 && e < 4096) { unsigned long long* d = g_dbgw + e * 12; const unsigned long long KE = __builtin_amdgcn_s_memtime(); d[0] = KE - KS; d[1] = nContact; d[2] = __popcll(occ); d[3] = nSteady + nQuiet; d[4] = K0 - KS; d[5] = tPh1; d[6] = tBroad; d[7] = tFast; d[8] = tCont; d[9] = (K1 - K0) - tPh1 - tBroad - tFast - tCont; d[10] = KE - K1; d[11] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned long long)__builtin_amdgcn_s_getreg(63492); })
 }

@@ -513,10 +513,17 @@ drv_partial_obs_kernel(DrvState S, int noiseType, double magn, float* __restrict
 // stepping - the observation work of the light environments fills the launch's tail instead of a second launch.  The
 // scratch tile aliases the step kernel's (no longer needed) LDS tile.
 static_assert(sizeof(PvLds) <= sizeof(DrvLds), "the Partial observation tile must fit in the step kernel's LDS tile");
-DE_OOL void drv_partial_obs_fused(const DrvState& S, int e, int lane, int nPed, int nObst, int elapsed, uint32_t episode,
-                                                   PvIn in, int noiseType, double magn, float* __restrict__ obs, int nAgents) {
+// The per-lane inputs come first in the argument list (an aggregate is passed in registers only while the function has 16 argument
+// registers left, else through scratch), and of the state the function receives the four fields it reads, as scalars, not a
+// reference to the struct (which the caller would first have to write to scratch, all of it, in every lane).
+DE_OOL void drv_partial_obs_fused(PvIn in, uint64_t seed, int A, int* envi, int env_id_offset, int e, int nPedObst, int elapsed,
+                                  uint32_t episode, int noiseType, double magn, float* __restrict__ obs, int nAgents) {
+  const int nPed = nPedObst & 0xFF, nObst = nPedObst >> 8;  // (one register: with v31 reserved there are 31 for arguments)
+  DrvState S = DrvState();  // (a local that never leaves registers: pv_env is inlined)
+  S.seed = uniform_u64(seed); S.A = uniform_i(A); S.envi = uniform_ptr(envi); S.env_id_offset = uniform_i(env_id_offset);
   __syncthreads();  // every lane has taken what it needs out of the step tile
-  pv_env(S, *reinterpret_cast<PvLds*>(&g_L), e, lane, nPed, nObst, elapsed, episode, in, noiseType, magn, obs, 0, nAgents);
+  pv_env(S, *reinterpret_cast<PvLds*>(&g_L), uniform_i(e), lane_id(), uniform_i(nPed), uniform_i(nObst), uniform_i(elapsed),
+         (uint32_t)uniform_i((int)episode), in, uniform_i(noiseType), uniform_d(magn), uniform_ptr(obs), 0, uniform_i(nAgents));
 }
 
 // The agent passes the step launch left over (EI_DEFER_OBS = first agent not done there): all of them for the environments

@@ -176,7 +176,10 @@ static int rc_create(dynenv* h) {
   rc |= dev_alloc(h, &R.s_meta, E * RC_NS);
   rc |= dev_alloc(h, &R.s_hash, 2 * E * RC_NS);
   rc |= dev_alloc(h, &R.s_imp, 4 * E * RC_NS);
+  uint64_t* pairTab = nullptr;
+  rc |= dev_alloc(h, &pairTab, 64 * 2);
   if (rc) return DYNENV_ERR_HIP;
+  R.pairTab = pairTab;
   RcConst c;
   memset(&c, 0, sizeof(c));
   c.footInertia = moment_for_segment_host(4000.0, v2(-10.0, 10.0), v2(10.0, 10.0), 7.5);  // Robot.py:34
@@ -224,6 +227,25 @@ static int rc_create(dynenv* h) {
   for (; p < RC_NPAIR_ROUNDS * 64; ++p) c.pairs[p] = 0xFFFF;
   hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(RC), &c, sizeof(c));
   if (e != hipSuccess) return fail(DYNENV_ERR_HIP, hipGetErrorString(e));
+  {  // the pairs of each lane (lane l tests pairs l, 64 + l, ...), packed, without those of feet this handle's robots do not have
+    static_assert(RC_NPAIR_ROUNDS == 5, "pairTab packs four rounds into the first word and the fifth into the second");
+    uint64_t tab[64][2];
+    for (int lane = 0; lane < 64; ++lane) {
+      uint64_t lo = 0ull, hi = 0ull, feet = 0ull;
+      for (int t = 0; t < RC_NPAIR_ROUNDS; ++t) {
+        const int pr = c.pairs[t * 64 + lane], i = pr >> 8, j = pr & 0xFF;
+        bool ok = pr != 0xFFFF;
+        if (ok && i < RC_BALL) ok = i < 2 * R.R;  // feet 2r, 2r + 1 of robot r < R.R
+        if (ok && j < RC_BALL) ok = j < 2 * R.R;
+        const uint64_t v = (uint64_t)(ok ? pr : 0xFFFF);
+        if (t < 4) lo |= v << (16 * t); else hi |= v;
+        if (ok && j < RC_BALL && j == i + 1 && !(i & 1)) feet |= 1ull << t;
+      }
+      tab[lane][0] = lo; tab[lane][1] = hi | (feet << 32);
+    }
+    e = hipMemcpy(pairTab, tab, sizeof(tab), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return fail(DYNENV_ERR_HIP, hipGetErrorString(e));
+  }
   return 0;
 }
 

@@ -81,4 +81,6 @@ struct RcState {
   int* s_meta;
   uint32_t* s_hash; /* [2][E][NS] */
   double* s_imp;    /* [4][E][NS] */
+  const uint64_t* pairTab; /* [64][2] per lane: {pair codes of rounds 0..3 (16 bits each), pair code of round 4 | feet-pair bits << 32},
+                              filtered for this handle's R (a pair with an absent foot reads 0xFFFF); read-only after create */
 };

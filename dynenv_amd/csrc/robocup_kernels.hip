@@ -56,6 +56,7 @@ struct __align__(16) RcLds {
   double fx[RC_NB], fy[RC_NB], tq[RC_NB];
   // shape cache as of the last position integration (what pymunk's spatial queries and the narrowphase see)
   double cpx[RC_NB], cpy[RC_NB], crc[RC_NB], crs[RC_NB];
+  double rotAng[RC_BALL];  // the angle (crc, crs) are the cosine and sine of; NaN at kernel entry (the angle is not part of the saved state)
   double aabb[21][4];
   // robots
   double head[16], headmov[16], prevx[16], prevy[16], initx[16], inity[16], penalT[16], fallT[16], moveT[16];
@@ -142,6 +143,15 @@ struct RcCtx {
   int n, R, canFall, allowHead, detTurn;
 };
 
+// The context is the same in every lane; an out-of-line function receives it in vector registers (the calling convention has no
+// uniform arguments) and says so here, first thing: its fields then live in scalar registers instead of nine VGPRs that would be
+// spilled across the solver.
+DE_DEV RcCtx rc_ctx_uniform(const RcCtx& v) {
+  RcCtx c;
+  c.seed = uniform_u64(v.seed); c.genv = (uint32_t)uniform_i((int)v.genv); c.episode = (uint32_t)uniform_i((int)v.episode);
+  c.n = uniform_i(v.n); c.R = uniform_i(v.R); c.canFall = uniform_i(v.canFall); c.allowHead = uniform_i(v.allowHead); c.detTurn = uniform_i(v.detTurn);
+  return c;
+}
 DE_DEV dm_u32x4 rc_rng(const RcCtx& c, const RcLds& L, uint32_t entity) {
   return dm_env_rng(c.seed, c.genv, c.episode, DM_RNG_ROBO_STEP, entity, (uint32_t)L.envi[RE_ELAPSED]);
 }
@@ -205,7 +215,8 @@ DE_DEV void free_penalty_spot(const RcCtx& c, const RcLds& L, int r, V2& spot, d
 }
 
 template <int EPW>
-DE_OOL void rc_penalize(const RcCtx& c, int r) {  // :824-859
+DE_OOL void rc_penalize(const RcCtx c_, int r) {  // :824-859
+  const RcCtx c = rc_ctx_uniform(c_);
   RcLds& L = Grp<EPW>::tile();
   const int teamIdx = robot_team(L, r) > 0 ? 0 : 1;
   int f = L.rflags[r];
@@ -244,7 +255,8 @@ DE_DEV double shape_point_dist(const RcLds& L, int s, V2 p) {
 }
 
 template <int EPW>
-DE_OOL void rc_fall(const RcCtx& c, int r, int punish) {  // :735-791
+DE_OOL void rc_fall(const RcCtx c_, int r, int punish) {  // :735-791
+  const RcCtx c = rc_ctx_uniform(c_);
   RcLds& L = Grp<EPW>::tile();
   const V2 pos = robot_pos(L, r);
   if (punish) L.rrew[r] -= 2.0;
@@ -560,7 +572,8 @@ DE_DEV bool rc_tick_has_event(const RcLds& L, int r) {
 // The sequential form (first substep, or a cross-robot event) is out of line; the common lane-parallel form is inlined
 // into the step kernel's loop so that it costs no call (callee-saved registers travel through scratch on every call).
 template <int EPW>
-DE_OOL void rc_game_serial(RcCtx c, int it, const int* __restrict__ actions, const double* __restrict__ headAct) {
+DE_OOL void rc_game_serial(RcCtx c_, int it, const int* __restrict__ actions, const double* __restrict__ headAct) {
+  const RcCtx c = rc_ctx_uniform(c_);
   RcLds& L = Grp<EPW>::tile();
   for (int r = 0; r < c.R; ++r) {
     if (it == 0) {
@@ -1463,7 +1476,8 @@ RC_PROF(if (lane == 0 && c.genv < 4096u) { unsigned long long* d = g_rcprof + c.
   return ret;
 }
 
-DE_OOL RcStepRet rc_physics_ool(RcCtx c, int lane, int cand, uint64_t pairLo, uint64_t pairHi, uint64_t occ) {
+DE_OOL RcStepRet rc_physics_ool(RcCtx c_, int lane, int cand, uint64_t pairLo, uint64_t pairHi, uint64_t occ) {
+  const RcCtx c = rc_ctx_uniform(c_);
   return rc_physics_inl<1>(c, lane, cand, pairLo, pairHi, 0ull, occ);
 }
 template <int EPW>
@@ -1489,6 +1503,7 @@ DE_DEV void rc_load_env(const RcState& S, RcLds& L, int e, int lane, uint64_t oc
     // shape cache (position / rotation at the last integration) is stored in the 4 spare body fields
     L.cpx[lane] = used ? b[(RB_COUNT + 0) * E * RC_NB] : 0.0; L.cpy[lane] = used ? b[(RB_COUNT + 1) * E * RC_NB] : 0.0;
     L.crc[lane] = used ? b[(RB_COUNT + 2) * E * RC_NB] : 1.0; L.crs[lane] = used ? b[(RB_COUNT + 3) * E * RC_NB] : 0.0;
+    if (lane < RC_BALL) L.rotAng[lane] = __builtin_nan("");
   }
   if (lane < 16) {
     const bool used = lane < S.R;
@@ -1620,12 +1635,12 @@ DE_OOL void rc_write_obs_ool(int lane, int R, int obs_dim, float* __restrict__ o
 #define RC_DEFER_MIN_GENERAL 25 /* rc_physics substeps (of 50) from which an environment defers its Partial observation */
 #endif
 struct RcCommonRet {
-  double rotC, rotS, rotAng;
-  int cand, bits;  // bits: 1 quiet, 2 rotValid
+  uint64_t pairLo, pairHi;  // this lane's pair codes, for rc_physics (S.pairTab)
+  int cand, bits;           // bits: 1 quiet
 };
 template <int EPW>
-DE_OOL RcCommonRet rc_common_substep(RcCtx c, int serial_, int lane,
-                                                      uint64_t pairLo, uint64_t pairHi, uint64_t pairTop, int feetPairs, uint64_t occ_, double rotC, double rotS, double rotAng, int rotValid_) {
+DE_OOL RcCommonRet rc_common_substep(RcCtx c_, int serial_, int lane, const uint64_t* __restrict__ pairTab, uint64_t occ_) {
+  const RcCtx c = rc_ctx_uniform(c_);
   typedef Grp<EPW> G;
   constexpr int W = G::W, NROUNDS = (RC_NPAIR_ROUNDS * 64) / W;
   RcLds& L = G::tile();
@@ -1633,7 +1648,12 @@ DE_OOL RcCommonRet rc_common_substep(RcCtx c, int serial_, int lane,
   const int R = c.R;
   const uint64_t occ = G::uniform_u64(occ_);
   const bool isBody = lane == RC_BALL || lane < 2 * R;
-  bool rotValid = rotValid_ != 0;
+  // my pairs: loaded here, first used by the broadphase - the latency is hidden behind the game logic and the position update.
+  // They are NOT kept in registers across substeps: whatever the kernel holds across the call of rc_physics (128 VGPRs) is
+  // spilled around it, 4 bytes x 64 lanes a register and call - that was most of this kernel's HBM writes.
+  const uint64_t pairLo = pairTab[2 * lane], pairHiFeet = pairTab[2 * lane + 1];
+  const uint64_t pairHi = pairHiFeet & 0xFFFFull, pairTop = 0ull;
+  const int feetPairs = (int)(pairHiFeet >> 32);  // bit t: my pair of round t is the two feet of one robot
     // ---- sequential game logic (lane 0): processAction / tick per robot, then the ball (:465-475) ----------
     rc_game_logic_rest<EPW>(c, serial, lane);
     __syncthreads();
@@ -1646,11 +1666,11 @@ DE_OOL RcCommonRet rc_common_substep(RcCtx c, int serial_, int lane,
       L.vbx[lane] = 0.0; L.vby[lane] = 0.0; L.wb[lane] = 0.0;
       float fcx, fcy, fhx, fhy;
       if (lane != RC_BALL) {
-        if (nang != rotAng || !rotValid) {  // this lane's rotation cache (registers): invalid at kernel entry
+        if (!(nang == L.rotAng[lane])) {  // the shape cache's rotation is that of another angle (or, NaN, of an earlier launch)
           const DevSC sc = RC_COMMON_SINCOS(nang);
-          rotC = sc.c; rotS = sc.s; rotAng = nang; rotValid = true;
+          L.crc[lane] = sc.c; L.crs[lane] = sc.s; L.rotAng[lane] = nang;
         }
-        L.cpx[lane] = npx; L.cpy[lane] = npy; L.crc[lane] = rotC; L.crs[lane] = rotS;
+        L.cpx[lane] = npx; L.cpy[lane] = npy;
         SegW s;
         seg_world(L, lane, s);
         double l, r, b, t;
@@ -1712,7 +1732,7 @@ DE_OOL RcCommonRet rc_common_substep(RcCtx c, int serial_, int lane,
       __syncthreads();
     }
   RcCommonRet ret;
-  ret.rotC = rotC; ret.rotS = rotS; ret.rotAng = rotAng; ret.cand = cand; ret.bits = (quiet ? 1 : 0) | (rotValid ? 2 : 0);
+  ret.pairLo = pairLo; ret.pairHi = pairHi; ret.cand = cand; ret.bits = quiet ? 1 : 0;
   return ret;
 }
 template <bool PARTIAL, int EPW>
@@ -1734,22 +1754,8 @@ DE_DEV void rc_step_body(const RcState& S, const int e, const int* __restrict__ 
   c.seed = S.seed; c.genv = (uint32_t)(S.env_id_offset + e); c.n = S.n; c.R = R;
   c.canFall = (S.flags & DYNENV_FLAG_CAN_FALL) != 0; c.allowHead = (S.flags & DYNENV_FLAG_ALLOW_HEAD_TURN) != 0;
   c.detTurn = (S.flags & DYNENV_FLAG_DETERMINISTIC_TURN) != 0;
-  int err = 0;
-  uint64_t pairLo = 0ull, pairHi = 0ull, pairTop = 0ull;
-  int feetPairs = 0;  // bit t: my pair of round t is the two feet of one robot
-#pragma unroll
-  for (int t = 0; t < NROUNDS; ++t) {
-    int pr = RC.pairs[t * W + lane];
-    int i = pr >> 8, j = pr & 0xFF;
-    bool ok = pr != 0xFFFF;
-    if (ok && i < RC_BALL) ok = i < 2 * R;
-    if (ok && j < RC_BALL) ok = j < 2 * R;
-    uint64_t v = (uint64_t)(ok ? pr : 0xFFFF);
-    if (t < 4) pairLo |= v << (16 * t); else if (t < 8) pairHi |= v << (16 * (t - 4)); else pairTop |= v << (16 * (t - 8));
-    if (ok && j < RC_BALL && j == i + 1 && !(i & 1)) feetPairs |= 1 << t;
-  }
   __syncthreads();
-  c.episode = (uint32_t)L.envi[RE_EPISODE];
+  c.episode = (uint32_t)G::uniform_i(L.envi[RE_EPISODE]);  // (an LDS read is a vector value until told otherwise: it would be spilled around every call)
   if (lane == 0) refresh_pivot_first(L);
   __syncthreads();
   const bool partial = PARTIAL;
@@ -1757,12 +1763,10 @@ DE_DEV void rc_step_body(const RcState& S, const int e, const int* __restrict__ 
   const int* myActions = actions + (size_t)e * R * 4;
   const double* myHead = headActions ? headActions + (size_t)e * R : nullptr;
   int snap = 0, nGeneral = 0;  // substeps that went through rc_physics
-  double rotC = 1.0, rotS = 0.0, rotAng = 0.0;  // (cos, sin) of my body's angle as of rotAng
-  bool rotValid = false;
 
 RC_PROF(if (lane < 12 && e < 4096) g_rcprof[e * 12 + lane] = 0ull; const unsigned long long K0 = __builtin_amdgcn_s_memtime(); unsigned long long tG = 0, tP = 0, tB = 0;)
   for (int it = 0; it < 50; ++it) {
-    asm volatile("" : "+v"(lane));  // opaque per substep: nothing derived from the lane id is hoisted out of the loop and spilled around its calls
+    lane = fresh_lane();  // per substep: nothing derived from the lane id is hoisted out of the loop, and the id itself is not kept across the calls
 RC_PROF(const unsigned long long A0 = __builtin_amdgcn_s_memtime();)
     // the game logic's sequential form (first substep: processAction; later: a cross-robot event) is the only call of the common
     // part: it is made from here, the outermost frame, so that rc_common_substep itself contains no call at all
@@ -1772,8 +1776,7 @@ RC_PROF(const unsigned long long A0 = __builtin_amdgcn_s_memtime();)
       if (lane == 0) rc_game_serial<EPW>(c, it, myActions, myHead);
 RC_PROF(tG += 1;)  // (profile build: "game logic" = substeps with the sequential form, "position" = cycles of the whole common part)
     }
-    const RcCommonRet cr = rc_common_substep<EPW>(c, serial ? 1 : 0, lane, pairLo, pairHi, pairTop, feetPairs, occ, rotC, rotS, rotAng, rotValid ? 1 : 0);
-    rotC = cr.rotC; rotS = cr.rotS; rotAng = cr.rotAng; rotValid = (cr.bits & 2) != 0;
+    const RcCommonRet cr = rc_common_substep<EPW>(c, serial ? 1 : 0, lane, S.pairTab, occ);
     const int cand = cr.cand;
     const bool quiet = G::uniform_i(cr.bits & 1) != 0;
 RC_PROF(tP += __builtin_amdgcn_s_memtime() - A0;)
@@ -1781,9 +1784,12 @@ RC_PROF(tP += __builtin_amdgcn_s_memtime() - A0;)
     } else {
       __builtin_amdgcn_s_setprio(3);  // an environment with contact work is on the launch's critical path: issue it first
       ++nGeneral;
-      const RcStepRet sr = rc_physics<EPW>(c, lane, cand, pairLo, pairHi, pairTop, occ);
-      occ = G::uniform_u64(sr.occ); err |= sr.err;
+      const RcStepRet sr = rc_physics<EPW>(c, fresh_lane(), cand, cr.pairLo, cr.pairHi, 0ull, occ);
+      occ = G::uniform_u64(sr.occ);
+      lane = fresh_lane();
+      if (G::ballot(sr.err != 0) != 0ull && lane == 0) L.envi[RE_ERR] |= 1;  // (a full slot table / candidate list: reported, never silent)
     }
+    lane = fresh_lane();
     if (lane == 0) L.envi[RE_ELAPSED] += 1;
     __syncthreads();
     if (it % 10 == 9) {
@@ -1824,15 +1830,13 @@ RC_PROF(if (lane == 0 && e < 4096) { unsigned long long* d = g_rcprof + e * 12; 
   if (lane == 0) {
     dones[e] = (uint8_t)(L.envi[RE_ELAPSED] >= RC_MAX_TIME);
     L.envi[RE_OCC] = (int)(uint32_t)occ;
-    if (err) L.envi[RE_ERR] |= 1;
     if (deferObs) S.deferList[1 + atomicAdd(&S.deferList[0], 1)] = e;
   }
   __syncthreads();
   rc_store_env(S, L, e, lane, occ, W);
   if constexpr (PARTIAL) {
     if (obs && !deferObs) {  // getAgentVision at the five snapshots + processSeens
-      const RcState Scopy = S;  // (a copy: see drv_step_body - an address-taken S would live in scratch for the whole kernel)
-      rc_partial_obs_fused(Scopy, e, lane, obs, rewards);
+      rc_partial_obs_fused(S.seed, S.env_id_offset, S.envi, S.n, S.R, S.noise_type, S.noise_magn, S.snap, S.flags, S.prew0, S.epr, S.E, S.epo, e, obs, rewards);
     }
   }
 }

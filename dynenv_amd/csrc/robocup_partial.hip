@@ -471,10 +471,18 @@ rc_partial_obs_kernel(RcState S, float* __restrict__ obs, double* __restrict__ r
 // of a RoboCup launch are such a tail).  The tile aliases the step kernel's LDS tile, which is no longer needed; the
 // snapshots, rewards and prew0 this wave wrote to HBM are read back after a device-scope fence.
 static_assert(sizeof(RvLds) <= sizeof(RcLds), "the vision tile must fit in the step kernel's LDS tile");
-DE_OOL void rc_partial_obs_fused(const RcState& S, int e, int lane, float* __restrict__ obs, double* __restrict__ rewards) {
+// What it needs of the state arrives as scalar arguments (25 registers), not as a reference to the struct: a by-reference struct
+// has to exist in memory, i.e. the caller would write all 200-odd bytes of it to scratch in every lane before the call.
+DE_OOL void rc_partial_obs_fused(uint64_t seed, int env_id_offset, int* envi, int n, int R, int noise_type, double noise_magn, RvSnap* snap,
+                                 int flags, double* prew0, double* epr, int E, double* epo, int e, float* __restrict__ obs,
+                                 double* __restrict__ rewards) {
+  RcState S = RcState();  // (a local that never leaves registers: everything below is inlined)
+  S.seed = uniform_u64(seed); S.env_id_offset = uniform_i(env_id_offset); S.envi = uniform_ptr(envi); S.n = uniform_i(n); S.R = uniform_i(R);
+  S.noise_type = uniform_i(noise_type); S.noise_magn = uniform_d(noise_magn); S.snap = uniform_ptr(snap); S.flags = uniform_i(flags);
+  S.prew0 = uniform_ptr(prew0); S.epr = uniform_ptr(epr); S.E = uniform_i(E); S.epo = uniform_ptr(epo);
   __threadfence();
   __syncthreads();
-  rv_env(S, *reinterpret_cast<RvLds*>(&g_R), e, lane, obs, rewards);
+  rv_env(S, *reinterpret_cast<RvLds*>(&g_R), uniform_i(e), lane_id(), uniform_ptr(obs), uniform_ptr(rewards));
 }
 
 // The environments that held a contact through the step finish last; their 50 agent passes run by one lone, latency-bound
