@@ -41,7 +41,7 @@ struct __align__(16) DrvLds {
   // dynamic bodies (lane l = body l): home location of the state
   double px[DRV_NB], py[DRV_NB], vx[DRV_NB], vy[DRV_NB], ang[DRV_NB], w[DRV_NB], vbx[DRV_NB], vby[DRV_NB], wb[DRV_NB];
   double minv[DRV_NB], iinv[DRV_NB];
-  double rc[DRV_NB], rs[DRV_NB], rotAng[DRV_NB];  // cos/sin of rotAng (recomputed only when the angle changes)
+  double rc[16], rs[16], rotAng[16];  // cars: cos/sin of rotAng (recomputed only when the angle changes)
   // cars
   double dirx[16], diry[16], prevx[16], prevy[16], goalx[16], goaly[16];
   double cosRel0[16], cosRel1[16];  // dm_cos(road.dirAngle - rotAng), cached with rc/rs
@@ -55,6 +55,11 @@ struct __align__(16) DrvLds {
   double s_jn0[DRV_NS], s_jt0[DRV_NS], s_jn1[DRV_NS], s_jt1[DRV_NS];
   double rewAcc[16], posAcc[16];  // the step's reward / positive-reward accumulators of the cars (:252-254): in LDS, not carried
                                   // through the substep loop in registers (two doubles less to save around every call)
+  // Per-lane values the step carries from substep to substep live HERE, not in the kernel's registers: whatever the kernel holds in
+  // VGPRs across the call of the solver (124 VGPRs) is spilled around it, 256 B of scratch per register and call.
+  int lastCand[64];        // candidate mask of the previous substep (-1: unknown), persisted in S.lastcand
+  int stepErr;             // error bits of this step (1: candidate list / contact cache overflow, 2: malformed action)
+  unsigned char act[16];   // cars: acc | steer << 2 (each 0..2), consumed by the first substep
   int still[DRV_NB];  // bit0: body had exactly zero v, w, v_bias, w_bias when positions were integrated; bit1: frozen
   unsigned short clist[DRV_CLIST];  // contact path: dense list of candidate pair ids in canonical order
   union {
@@ -172,6 +177,12 @@ DE_DEV void velocity_update(DrvLds& L, int lane, bool isCar, bool isPed) {
   if (dflt) { vx = vx * 1.0 + (0.0 + 0.0) * DE_DT; vy = vy * 1.0 + (0.0 + 0.0) * DE_DT; w = w * 1.0 + 0.0; }
   else apply_friction(vx, vy, w, m, fr, rfr, 0.0);
   L.vx[lane] = vx; L.vy[lane] = vy; L.w[lane] = w;
+}
+// The same as a leaf function, for the substeps without a solve (fast path, replay): inlined into the kernel's substep loop, its
+// friction coefficients - 64-bit literals - are hoisted out of the loop into registers that are then saved around every call.
+DE_OOL void velocity_update_ool(int nCarPed) {
+  const int lane = lane_id(), A = uniform_i(nCarPed) & 0xFF, nPed = uniform_i(nCarPed) >> 8;
+  velocity_update(g_L, lane, lane < A, lane >= DRV_SLOT_PED && lane < DRV_SLOT_PED + nPed);
 }
 
 // refresh the cached rotation of car `lane` (cpBodySetAngle -> cpvforangle) and the two road-relative cosines
@@ -550,7 +561,7 @@ DE_DEV void load_env(const DrvState& S, DrvLds& L, int e, int lane, int A, int n
     if (lane < A) { minv = 1.0 / DRV_BY_TYPE(carMass); iinv = 1.0 / DRV_BY_TYPE(carInertia); }
     else if (used) { minv = 1.0 / CarK::pedMass; iinv = 1.0 / CarK::pedInertia; }
     L.minv[lane] = minv; L.iinv[lane] = iinv;
-    L.rc[lane] = 1.0; L.rs[lane] = 0.0; L.rotAng[lane] = 0.0;
+    if (lane < 16) { L.rc[lane] = 1.0; L.rs[lane] = 0.0; L.rotAng[lane] = 0.0; }
     if (lane < A) {
       L.dirx[lane] = g_dirx; L.diry[lane] = g_diry;
       L.prevx[lane] = g_prevx; L.prevy[lane] = g_prevy; L.goalx[lane] = g_gx; L.goaly[lane] = g_gy;
@@ -765,7 +776,7 @@ DRV_PROF(DE_DEV int prof_any(int v) { const uint64_t m = wave_ballot(v != 0); re
 #endif
 
 // pk: a_state | a_count << 8 | a_age << 16 | touched << 24 | freeMe << 25 | hashSame << 26 | prevInert << 27 | skipped << 28 | slotOcc << 29 | active << 30
-DE_OOL int drv_prestep_solve(int lane, int roleBits, int pk, int a_pair, int bodyA, int bodyB, int myLevel,
+DE_OOL int drv_prestep_solve(int lane, int nCarPed, int pk, int a_pair, int bodyA, int bodyB, int myLevel,
                                              int maxLevel_, int anyActive_, double jn0, double jn1, double jt0, double jt1) {
   DrvLds& L = g_L;
   DrvMailbox& M = L.u.mb;
@@ -773,7 +784,7 @@ DE_OOL int drv_prestep_solve(int lane, int roleBits, int pk, int a_pair, int bod
   const int a_count = (pk >> 8) & 0xFF, a_age = (pk >> 16) & 0xFF;
   const bool touched = (pk >> 24) & 1, freeMe = (pk >> 25) & 1, hashSame = (pk >> 26) & 1, prevInert = (pk >> 27) & 1;
   const bool skipped = (pk >> 28) & 1, slotOcc = (pk >> 29) & 1, active = (pk >> 30) & 1;
-  const bool isCar = (roleBits & 1) != 0, isPed = (roleBits & 2) != 0;
+  const bool isCar = lane < (uniform_i(nCarPed) & 0xFF), isPed = lane >= DRV_SLOT_PED && lane < DRV_SLOT_PED + (uniform_i(nCarPed) >> 8);
   const int maxLevel = (int)(signed char)(uniform_i(maxLevel_) & 0xFF), period = uniform_i(maxLevel_) >> 8;
   const uint64_t activeMask = uniform_i(anyActive_) ? 1ull : 0ull;
   double jn[2] = {jn0, jn1}, jt[2] = {jt0, jt1};
@@ -934,8 +945,8 @@ struct ContactRet {
   int err;
 };
 
-__device__ DRV_CONTACT_INLINE ContactRet drv_contact_path(int lane, int cand, int dirty, int light, int A, uint64_t occ,
-                                                    bool isCar, bool isPed) {
+__device__ DRV_CONTACT_INLINE ContactRet drv_contact_path(int lane, int cand, int dirty, int light, int A, int nCarPed, uint64_t occ) {
+  const bool isCar = lane < A, isPed = lane >= DRV_SLOT_PED && lane < DRV_SLOT_PED + (nCarPed >> 8);
   DrvLds& L = g_L;
   int err = 0;
   // The lane id is made opaque here: everything this (inlined) function derives from it - quad roles, lane masks, slot
@@ -1199,7 +1210,7 @@ DRV_PROF(const unsigned long long T1 = __builtin_amdgcn_s_memtime();)
 DRV_PROF(const unsigned long long T2 = __builtin_amdgcn_s_memtime();)
   // everything per-slot from here on - prestep, solve, the steady / inert verdicts and the slot record - happens inside the
   // function: nothing of the contact cache stays live in this frame across the call
-  const int solveBits = drv_prestep_solve(lane, (isCar ? 1 : 0) | (isPed ? 2 : 0),
+  const int solveBits = drv_prestep_solve(lane, nCarPed,
                                           (a_state & 0xFF) | ((a_count & 0xFF) << 8) | ((a_age & 0xFF) << 16) | (touched ? 1 << 24 : 0) | (freeMe ? 1 << 25 : 0) |
                                               (hashSame ? 1 << 26 : 0) | (prevInert ? 1 << 27 : 0) | (skipped ? 1 << 28 : 0) | (slotOcc ? 1 << 29 : 0) | (active ? 1 << 30 : 0),
                                           a_pair, bodyA, bodyB, myLevel, (maxLevel & 0xFF) | (period << 8), activeMask != 0ull ? 1 : 0, jn[0], jn[1], jt[0], jt[1]);
@@ -1228,9 +1239,10 @@ struct DrvLightRet {
   int cand, dirty, bits;
 };
 struct DrvSeedOnly { uint64_t seed; };
-DE_OOL DrvLightRet drv_light_substep(int it_, int lane, int A_, int nPed_, int nObst_, int elapsed_, int act0, int act1, int lastCand,
+DE_OOL DrvLightRet drv_light_substep(int it_, int lane, int A_, int nPed_, int nObst_, int elapsed_,
                                                       uint32_t seedLo, uint32_t seedHi, uint32_t genv_, uint32_t episode_, int stateBits) {
   DrvLds& L = g_L;
+  const int lastCand = L.lastCand[lane];
   const int it = uniform_i(it_), A = uniform_i(A_), nPed = uniform_i(nPed_), nObst = uniform_i(nObst_), elapsed = uniform_i(elapsed_);
   const uint32_t genv = (uint32_t)uniform_i((int)genv_), episode = (uint32_t)uniform_i((int)episode_);
   DrvSeedOnly S;
@@ -1250,7 +1262,8 @@ DE_OOL DrvLightRet drv_light_substep(int it_, int lane, int A_, int nPed_, int n
     if (isBody) { f = L.flags[lane]; px = L.px[lane]; py = L.py[lane]; vx = L.vx[lane]; vy = L.vy[lane]; }
     if (isCar) {
       if (it == 0) {  // processAction :357-373 -> Car.accelerate (Car.py:55-94), Car.turn (Car.py:97-108)
-        const int acc = act0 - 1, steer = (act1 - 1) * 2;
+        const int actPk = (int)L.act[lane];
+        const int acc = (actPk & 3) - 1, steer = ((actPk >> 2) - 1) * 2;
         if (!CF_FIN(f)) {
           double dirx = L.dirx[lane], diry = L.diry[lane];
           double power = (double)acc;
@@ -1438,8 +1451,9 @@ DE_OOL DrvLightRet drv_light_substep(int it_, int lane, int A_, int nPed_, int n
       dirty = cand & ~clean;
       removed = lastCand < 0 || (lastCand & ~cand) != 0;
     }
+  L.lastCand[lane] = cand;
   DrvLightRet ret;
-  ret.cand = cand; ret.dirty = dirty; ret.bits = (candMoving ? 1 : 0) | (removed ? 2 : 0);
+  ret.cand = cand; ret.dirty = dirty; ret.bits = (candMoving ? 1 : 0) | (removed ? 2 : 0) | (cand != lastCand ? 4 : 0);
   return ret;
 }
 template <bool PARTIAL>
@@ -1461,7 +1475,6 @@ DRV_PROF(if (lane < 8 && e < 4096) g_dbgp[e * 8 + lane] = 0ull;)
   // Environments with live contacts are the long ones and the launch ends with the slowest: their waves get issue priority
   // over the (three) lighter waves they share a SIMD with, from the first instruction on.
   if (occ != 0ull) __builtin_amdgcn_s_setprio(3);
-  int err = 0;
   const uint32_t genv = (uint32_t)(S.env_id_offset + e);
 
   const bool isCar = lane < A;
@@ -1472,16 +1485,22 @@ DRV_PROF(if (lane < 8 && e < 4096) g_dbgp[e * 8 + lane] = 0ull;)
   const int g_lastCand = S.lastcand[(size_t)e * 64 + lane];
   load_env(S, L, e, lane, A, nPed, nObst, occ);
 
-  int act0 = isCar ? g_act0 : 1, act1 = isCar ? g_act1 : 1;
-  // action_space is MultiDiscrete([3, 3]) (:170-174); the reference raises on a malformed action (:365-368), here the car
-  // coasts (acc = steer = 0) and the environment's error flag (bit 1, dynenv_error_flags) records it
-  if ((unsigned)act0 > 2u || (unsigned)act1 > 2u) { act0 = 1; act1 = 1; err |= 2; }
-  double teamReward = 0.0;  // :252-254
+  {
+    int act0 = isCar ? g_act0 : 1, act1 = isCar ? g_act1 : 1;
+    // action_space is MultiDiscrete([3, 3]) (:170-174); the reference raises on a malformed action (:365-368), here the car
+    // coasts (acc = steer = 0) and the environment's error flag (bit 1, dynenv_error_flags) records it
+    const bool bad = (unsigned)act0 > 2u || (unsigned)act1 > 2u;
+    if (bad) { act0 = 1; act1 = 1; }
+    if (lane < 16) L.act[lane] = (unsigned char)(act0 | (act1 << 2));
+    const bool anyBad = wave_ballot(bad) != 0ull;
+    if (lane == 0) L.stepErr = anyBad ? 2 : 0;
+  }
+  int finishedAt = -1;  // elapsed time at which the last car finished in this step: the team reward (:252-254) follows from it
   if (lane < 16) { L.rewAcc[lane] = 0.0; L.posAcc[lane] = 0.0; }
   bool aabbValid = false;
   // quiescent-shortcut state carried across launches: candidate mask of the previous substep (-1: unknown) and
   // whether every cached arbiter was inert when the contact path last ran
-  int lastCand = g_lastCand;
+  L.lastCand[lane] = g_lastCand;
   bool inertAll = (uniform_i(envi[EI_PAD]) & 1) != 0;
   // steady-replay state: the contact path ran (or was replayed) in the previous substep and reported every slot steady
   bool steadyAll = (uniform_i(envi[EI_PAD]) & 2) != 0;
@@ -1492,11 +1511,11 @@ DRV_PROF(if (lane < 8 && e < 4096) g_dbgp[e * 8 + lane] = 0ull;)
 DRV_PROF(const unsigned long long K0 = __builtin_amdgcn_s_memtime(); unsigned long long tPh1 = 0, tBroad = 0, tFast = 0, tCont = 0, tBook = 0;)
   bool lightOff = false;
   for (int it = 0; it < 10; ++it) {
-    asm volatile("" : "+v"(lane));  // opaque per iteration: nothing derived from the lane id is hoisted out of the loop and kept
-                                      // alive (= spilled and reloaded) across the calls of every substep
+    lane = fresh_lane();  // per substep: nothing derived from the lane id is hoisted out of the loop and kept alive (= spilled and
+                          // reloaded) across the calls of every substep, and the id itself is recomputed after them
 DRV_PROF(const unsigned long long A0 = __builtin_amdgcn_s_memtime();)
     // ======== phase 1a: car game logic (processAction at substep 0, tick) ===================================
-    const DrvLightRet lr = drv_light_substep(it, lane, A, nPed, nObst, elapsed, act0, act1, lastCand, (uint32_t)S.seed, (uint32_t)(S.seed >> 32), genv, episode,
+    const DrvLightRet lr = drv_light_substep(it, lane, A, nPed, nObst, elapsed, (uint32_t)S.seed, (uint32_t)(S.seed >> 32), genv, episode,
                                              (vbValid ? 1 : 0) | (aabbValid ? 2 : 0));
     const int cand = lr.cand, dirty = lr.dirty;
     const bool candMoving = (lr.bits & 1) != 0, removed = (lr.bits & 2) != 0;
@@ -1507,7 +1526,7 @@ DRV_PROF(const unsigned long long A1 = A0;)
     // every cached arbiter inert (zero bias, zero accumulated impulse, not first contact).  Then narrowphase, arbiter
     // update, warm start and all 10 solver iterations are exact no-ops (DESIGN.md "quiescent shortcut") and only the
     // velocity update remains.
-    const bool candChanged = wave_ballot(cand != lastCand) != 0ull, anyMoving = wave_ballot(candMoving) != 0ull;
+    const bool candChanged = wave_ballot((lr.bits & 4) != 0) != 0ull, anyMoving = wave_ballot(candMoving) != 0ull;
     const bool quiescent = inertAll && !candChanged && !anyMoving;
     // Steady replay: the contact path of the previous substep reported every slot steady, the candidate set is the
     // same and every body in it is frozen => this substep's contact path would read the same inputs and reproduce the
@@ -1521,22 +1540,22 @@ DRV_PROF(const unsigned long long A1 = A0;)
     // resting pile - persists: after a failure the rest of the step goes straight to the full path.  Both give the same result.)
     const bool light = steadyOk && anyDirty && !lightOff;
     if (!(anyCand == 0ull && occ == 0ull) && !quiescent && !replay) { if (candChanged) nWhyCand++; else if (anyMoving) nWhyMoving++; else nWhyInert++; }
-    lastCand = cand;
 
 DRV_PROF(const unsigned long long A2 = __builtin_amdgcn_s_memtime(); bool tookContact = false;)
     if (anyCand == 0ull && occ == 0ull) nFast++; else if (quiescent) nQuiet++; else if (replay) nSteady++; else nContact++;
     nSlots += __popcll(occ);
     if ((anyCand == 0ull && occ == 0ull) || quiescent) {
       // ---------- fast path: nothing touches and the contact cache is empty (or quiescent): velocity update only
-      velocity_update(L, lane, isCar, isPed);
+      velocity_update_ool(A | (nPed << 8));
       if (anyCand == 0ull && occ == 0ull) steadyAll = false;
       vbValid = false;  // nothing was solved: the next position update sees zero bias velocities
     } else if (!replay) {
       // ---------- contact path (out of line): narrowphase -> contact cache -> callbacks -> prestep -> friction -> solver
 DRV_PROF(tookContact = true;)
       __builtin_amdgcn_s_setprio(3);  // an environment on the contact path is on the launch's critical path: issue it first
-      ContactRet cr = drv_contact_path(lane, cand, dirty, light ? 1 : 0, A, occ, isCar, isPed);
-      err |= cr.err & 1;
+      ContactRet cr = drv_contact_path(lane, cand, dirty, light ? 1 : 0, A, A | (nPed << 8), occ);
+      lane = fresh_lane();
+      if (wave_ballot((cr.err & 1) != 0) != 0ull && lane == 0) L.stepErr |= 1;
       if (light && !(uniform_i(cr.err >> 3) & 1)) lightOff = true;
       if (uniform_i(cr.err >> 3) & 1) {  // light mode: no dirty pair touches => replay
         replay = true; nLight++;
@@ -1548,7 +1567,7 @@ DRV_PROF(tookContact = true;)
       }
     }
     if (replay) {  // L.vb* still hold the bias velocities of the solve being replayed
-      velocity_update(L, lane, isCar, isPed);
+      velocity_update_ool(A | (nPed << 8));
       vbValid = true;
     }
     __syncthreads();
@@ -1561,9 +1580,11 @@ DRV_PROF(const unsigned long long A3 = __builtin_amdgcn_s_memtime(); tPh1 += A1 
     const bool allFin = wave_ballot(notDone) == 0ull;
     if (!allFinished && allFin) {
       allFinished = 1;
-      teamReward += (double)(DRV_MAX_TIME - elapsed) / 100.0;
+      finishedAt = elapsed;
     }
   }
+  lane = fresh_lane();
+  const double teamReward = finishedAt >= 0 ? 0.0 + (double)(DRV_MAX_TIME - finishedAt) / 100.0 : 0.0;
 
 DRV_PROF(const unsigned long long K1 = __builtin_amdgcn_s_memtime();)
   // ---------------- end of env step :300-322 ----------------------------------------------------------------
@@ -1587,8 +1608,8 @@ DRV_PROF(const unsigned long long K1 = __builtin_amdgcn_s_memtime();)
     envi[EI_ELAPSED] = elapsed; envi[EI_ALLFIN] = allFinished; envi[EI_OCC] = (int)(uint32_t)occ;
     envi[EI_PAD] = (inertAll ? 1 : 0) | (steadyAll ? 2 : 0) | (vbValid ? 4 : 0);
   }
-  const int errBits = (wave_ballot((err & 1) != 0) ? 1 : 0) | (wave_ballot((err & 2) != 0) ? 2 : 0);
-  S.lastcand[(size_t)e * 64 + lane] = lastCand;
+  const int errBits = uniform_i(L.stepErr);
+  S.lastcand[(size_t)e * 64 + lane] = L.lastCand[lane];
   store_env(S, L, e, lane, A, nPed, occ);
   if (obs) write_full_obs_ool(lane, A, nPed, nObst, S.obs_dim, obs + (size_t)e * A * S.obs_dim);
   if (isCar) { *er = g_er + rew; *ep = g_ep + posrew; }
