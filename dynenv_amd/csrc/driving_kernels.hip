@@ -766,6 +766,7 @@ DE_DEV void body_store_bias(DrvLds& L, int idx, const BodyV& b) {
 DRV_PROF(__device__ unsigned long long g_dbgw[4096 * 12];)
 DRV_PROF(__device__ unsigned long long g_dbgp[4096 * 8];)
 DRV_PROF(__device__ unsigned long long g_dbgr[16];)
+DRV_PROF(__device__ unsigned long long g_dbgl[4096 * 8];)  // stages of drv_light_substep, summed over the step's substeps
 DRV_PROF(DE_DEV int prof_any(int v) { const uint64_t m = wave_ballot(v != 0); return m ? bcast_i(v, __builtin_ctzll(m)) : 0; })
 // Which half of a substep is out of line.  DRV_INVERT = 1 (default): the COMMON part (game logic, position update, broadphase:
 // drv_light_substep, 88 VGPRs, nothing to save) is the function and the contact path is inlined into the kernel, which as the
@@ -787,6 +788,7 @@ DE_OOL int drv_prestep_solve(int lane, int nCarPed, int pk, int a_pair, int body
   const bool isCar = lane < (uniform_i(nCarPed) & 0xFF), isPed = lane >= DRV_SLOT_PED && lane < DRV_SLOT_PED + (uniform_i(nCarPed) >> 8);
   const int maxLevel = (int)(signed char)(uniform_i(maxLevel_) & 0xFF), period = uniform_i(maxLevel_) >> 8;
   const uint64_t activeMask = uniform_i(anyActive_) ? 1ull : 0ull;
+DRV_PROF(const unsigned long long P0 = __builtin_amdgcn_s_memtime();)
   double jn[2] = {jn0, jn1}, jt[2] = {jt0, jt1};
   V2 n = v2(0.0, 0.0), r1[2], r2[2];
   r1[0] = r1[1] = r2[0] = r2[1] = v2(0.0, 0.0);
@@ -819,10 +821,11 @@ DE_OOL int drv_prestep_solve(int lane, int nCarPed, int pk, int a_pair, int body
     }
   }
   __syncthreads();
+DRV_PROF(const unsigned long long P1 = __builtin_amdgcn_s_memtime();)
 
   // ---- velocity update (velocity_func: friction_* or default) -------------------------------------------
   velocity_update(L, lane, isCar, isPed);
-DRV_PROF(int profMode = 0;)
+DRV_PROF(int profMode = 0; const unsigned long long P2 = __builtin_amdgcn_s_memtime();)
   if (activeMask && maxLevel == 0) {
     // No two active arbiters share a dynamic body: each lane keeps its two bodies in registers through the warm start
     // and all 10 iterations, with one LDS load and one store (same arithmetic, no LDS round trip per iteration).
@@ -903,6 +906,7 @@ DRV_PROF(profMode = wave_ballot(!biasOnly) == 0ull ? 3 : 4;)
       }
     }
   }
+DRV_PROF(const unsigned long long P3 = __builtin_amdgcn_s_memtime();)
   // arbiters that were active this step are NORMAL from the next step on (cpSpaceStep resets the state)
   const bool wasNormal = a_state == ARB_NORMAL;  // i.e. not a first contact in this substep
   if (active && a_state == ARB_FIRST) a_state = ARB_NORMAL;
@@ -938,6 +942,7 @@ DRV_PROF(profMode = wave_ballot(!biasOnly) == 0ull ? 3 : 4;)
     if (touched) { L.s_jn0[lane] = jn[0]; L.s_jt0[lane] = jt[0]; L.s_jn1[lane] = jn[1]; L.s_jt1[lane] = jt[1]; }
   }
   const bool allInert = wave_ballot(!inert) == 0ull;
+DRV_PROF(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* d = g_dbgp + blockIdx.x * 8; const unsigned long long P4 = __builtin_amdgcn_s_memtime(); d[2] += (P1 - P0) + ((P4 - P3) << 32); d[3] += (P2 - P1) + ((P3 - P2) << 32); })
   return (allInert ? 2 : 0) | (allSteady ? 4 : 0) DRV_PROF(| (prof_any(profMode) << 4));
 }
 struct ContactRet {
@@ -1242,6 +1247,7 @@ struct DrvSeedOnly { uint64_t seed; };
 DE_OOL DrvLightRet drv_light_substep(int it_, int lane, int A_, int nPed_, int nObst_, int elapsed_,
                                                       uint32_t seedLo, uint32_t seedHi, uint32_t genv_, uint32_t episode_, int stateBits) {
   DrvLds& L = g_L;
+DRV_PROF(const unsigned long long Q0 = __builtin_amdgcn_s_memtime();)
   const int lastCand = L.lastCand[lane];
   const int it = uniform_i(it_), A = uniform_i(A_), nPed = uniform_i(nPed_), nObst = uniform_i(nObst_), elapsed = uniform_i(elapsed_);
   const uint32_t genv = (uint32_t)uniform_i((int)genv_), episode = (uint32_t)uniform_i((int)episode_);
@@ -1295,6 +1301,7 @@ DE_OOL DrvLightRet drv_light_substep(int it_, int lane, int A_, int nPed_, int n
         }
       }
     }
+DRV_PROF(const unsigned long long Q1 = __builtin_amdgcn_s_memtime();)
     const V2 pos = v2(px, py);
     int lp = LP_OffRoad;
     if (isBody) {
@@ -1303,6 +1310,7 @@ DE_OOL DrvLightRet drv_light_substep(int it_, int lane, int A_, int nPed_, int n
       rp = road_pos<1>(pos, isCar ? L.cosRel1[lane] : RoadK<1>::cosDir0);
       if (rp < lp) lp = rp;
     }
+DRV_PROF(const unsigned long long Q2 = __builtin_amdgcn_s_memtime();)
     if (isCar) {
       // tick :376-426
       double rew = L.rewAcc[lane], posrew = L.posAcc[lane];
@@ -1330,6 +1338,7 @@ DE_OOL DrvLightRet drv_light_substep(int it_, int lane, int A_, int nPed_, int n
       L.flags[lane] = f;
       L.vx[lane] = vx; L.vy[lane] = vy;
       L.rewAcc[lane] = rew; L.posAcc[lane] = posrew;
+DRV_PROF(asm volatile("" ::: "memory");)
     } else if (isPed) {
       // ======== phase 1b: pedestrian FSM (move :429-506) ====================================================
       if (!PF_DEAD(f)) {
@@ -1376,6 +1385,7 @@ DE_OOL DrvLightRet drv_light_substep(int it_, int lane, int A_, int nPed_, int n
       }
     }
 
+DRV_PROF(const unsigned long long Q3 = __builtin_amdgcn_s_memtime();)
     // ======== phase 1c: cpBodyUpdatePosition for every body (one instance of the code for cars + pedestrians) ===
     if (isBody) {
       const double px = L.px[lane], py = L.py[lane], ang = L.ang[lane];
@@ -1405,6 +1415,7 @@ DE_OOL DrvLightRet drv_light_substep(int it_, int lane, int A_, int nPed_, int n
     }
     aabbValid = true;
     __syncthreads();
+DRV_PROF(const unsigned long long Q4 = __builtin_amdgcn_s_memtime();)
 
     // ======== phase 2: broadphase.  Lane = object j (slot id: cars, pedestrians, obstacles, buildings); the loop runs over
     // the cars i < j whose box is broadcast from LDS.  cand bit i <=> cpBBIntersects(bb_i, bb_j) for the canonical pair
@@ -1452,6 +1463,7 @@ DE_OOL DrvLightRet drv_light_substep(int it_, int lane, int A_, int nPed_, int n
       removed = lastCand < 0 || (lastCand & ~cand) != 0;
     }
   L.lastCand[lane] = cand;
+DRV_PROF(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* d = g_dbgl + blockIdx.x * 8; const unsigned long long Q5 = __builtin_amdgcn_s_memtime(); if (it == 0) { for (int k = 0; k < 8; ++k) d[k] = 0ull; } d[0] += Q1 - Q0; d[1] += Q2 - Q1; d[2] += Q3 - Q2; d[3] += Q4 - Q3; d[4] += Q5 - Q4; d[5] += Q5 - Q0; })
   DrvLightRet ret;
   ret.cand = cand; ret.dirty = dirty; ret.bits = (candMoving ? 1 : 0) | (removed ? 2 : 0) | (cand != lastCand ? 4 : 0);
   return ret;

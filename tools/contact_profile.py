@@ -31,6 +31,10 @@ for k in range(11):
     if m.any(): print("nContact=%d: n=%d mean cycles %.0f max %.0f, mean occ %.2f" % (k, m.sum(), c[m].mean(), c[m].max(), d[m, 2].mean()))
 top = np.argsort(-c)[:15]
 print(d[top])
+ql = np.loadtxt("gpurun_out/dbgl.txt")[:NE]
+print("light substep, cycles per step (10 substeps): loads+processAction | lane classification | tick / pedestrian FSM | position update+rotation+box | broadphase | whole function")
+print("   top envs:"); [print("     ", ql[k, :6].astype(int)) for k in top[:8]]
+print("   mean over all envs:", ql[:, :6].mean(0).astype(int), " mean over envs without contact substeps:", ql[d[:, 1] == 0, :6].mean(0).astype(int))
 m = d[:, 1] == 10
 for o in range(0, 25):
     mm = m & (d[:, 2] == o)
@@ -49,6 +53,11 @@ print("narrowphase candidates per contact-path call, top envs:", [round(ncand[k]
 print("solver level passes by mode [single bias-only, single general, multi bias-only, multi general] of the top envs:")
 for k in top[:10]: print("  ", int(c[k]), modes[k])
 print("all envs:", modes.sum(0))
+# (the solve function reports its own stages: prestep | verdicts + slot record in d[2], velocity update | warm start + iterations in d[3])
+tail = (praw[:, 2] >> np.uint64(32)).astype(float); p[:, 2] = (praw[:, 2] & np.uint64(0xFFFFFFFF)).astype(float)
+iters = (praw[:, 3] >> np.uint64(32)).astype(float); p[:, 3] = (praw[:, 3] & np.uint64(0xFFFFFFFF)).astype(float)
+print("solve function of the top envs: prestep | velocity update | warm start + iterations | verdicts + slot record | call, arguments, rest")
+for k in top[:10]: print("  ", int(p[k, 2]), int(p[k, 3]), int(iters[k]), int(tail[k]), int(p[k, 4] - p[k, 2] - p[k, 3] - iters[k] - tail[k]))
 print("top envs: total | load phase1 broad fast contact book store+obs | narrow slots prestep velupd solver | calls levels touched")
 for k in top[:10]: print(int(c[k]), d[k, 4:11].astype(int), p[k].astype(int))
 m = d[:, 1] == 10
