@@ -44,7 +44,8 @@ struct __align__(16) DrvLds {
   double rc[16], rs[16], rotAng[16];  // cars: cos/sin of rotAng (recomputed only when the angle changes)
   // cars
   double dirx[16], diry[16], prevx[16], prevy[16], goalx[16], goaly[16];
-  double cosRel0[16], cosRel1[16];  // dm_cos(road.dirAngle - rotAng), cached with rc/rs
+  double cosRel0[16];  // dm_cos(road0.dirAngle - rotAng), cached with rc/rs.  (Road 1 has dirAngle 0: dm_cos(0 - a) is dm_cos(a) = rc bit for
+                       // bit - dm_sincos negates fn and r exactly with its argument, the cosine kernel is even and the quadrant cases pair up)
   double dprev[16];                 // |prevPos - goal|
   double cmass[16], cpower[16], chx[16], chy[16];  // per-car constants (Car.py:9-12) copied out of constant memory
   double aabb[DRV_MAXA][4];
@@ -194,7 +195,7 @@ DE_DEV void car_refresh_rot(DrvLds& L, int lane, double ang) {
   const DevSC sc = INL ? dev_sincos_inl(ang) : dev_sincos(ang);
   L.rc[lane] = sc.c; L.rs[lane] = sc.s; L.rotAng[lane] = ang;
   L.cosRel0[lane] = INL ? dev_sincos_inl(RoadK<0>::dirAngle - ang).c : dev_cos(RoadK<0>::dirAngle - ang);
-  L.cosRel1[lane] = INL ? dev_sincos_inl(RoadK<1>::dirAngle - ang).c : dev_cos(RoadK<1>::dirAngle - ang);
+  static_assert(RoadK<1>::dirAngle == 0.0, "cos(road1.dirAngle - angle) is read from rc");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1307,7 +1308,7 @@ DRV_PROF(const unsigned long long Q1 = __builtin_amdgcn_s_memtime();)
     if (isBody) {
       int rp = road_pos<0>(pos, isCar ? L.cosRel0[lane] : RoadK<0>::cosDir0);
       if (rp < lp) lp = rp;
-      rp = road_pos<1>(pos, isCar ? L.cosRel1[lane] : RoadK<1>::cosDir0);
+      rp = road_pos<1>(pos, isCar ? L.rc[lane] : RoadK<1>::cosDir0);
       if (rp < lp) lp = rp;
     }
 DRV_PROF(const unsigned long long Q2 = __builtin_amdgcn_s_memtime();)
@@ -1387,6 +1388,11 @@ DRV_PROF(asm volatile("" ::: "memory");)
 
 DRV_PROF(const unsigned long long Q3 = __builtin_amdgcn_s_memtime();)
     // ======== phase 1c: cpBodyUpdatePosition for every body (one instance of the code for cars + pedestrians) ===
+    // Every lane leaves this phase with the box of ITS object (bl, bb, br, bt), `live` and the still / frozen bits in registers:
+    // the broadphase below reads only the ten car rows from LDS.  (Lane = object j: cars, pedestrians, obstacles, buildings.)
+    double bl = 0.0, bb = 0.0, br = -1.0, bt = -1.0;
+    bool live = false;
+    int sj = 3;  // statics are always still and frozen
     if (isBody) {
       const double px = L.px[lane], py = L.py[lane], ang = L.ang[lane];
       const double vx = L.vx[lane], vy = L.vy[lane], w = L.w[lane];
@@ -1398,7 +1404,9 @@ DRV_PROF(const unsigned long long Q3 = __builtin_amdgcn_s_memtime();)
       L.px[lane] = npx; L.py[lane] = npy; L.ang[lane] = nang;
       // frozen: at rest and the position update was absorbed by rounding (sub-ulp bias velocities of a resting contact)
       const bool frozen = !turned && vx == 0.0 && vy == 0.0 && w == 0.0 && npx == px && npy == py && nang == ang;
-      L.still[lane] = (still ? 1 : 0) | (frozen ? 2 : 0);
+      sj = (still ? 1 : 0) | (frozen ? 2 : 0);
+      L.still[lane] = sj;
+      live = true;
       if (isCar) {
         if (nang != L.rotAng[lane]) car_refresh_rot<true>(L, lane, nang);
         if (!aabbValid || !frozen) {  // frozen: same position and rotation => same box
@@ -1409,38 +1417,32 @@ DRV_PROF(const unsigned long long Q3 = __builtin_amdgcn_s_memtime();)
           for (int k = 0; k < 4; ++k) {
             l = fmin_cp(l, bw.v[k].x); r = fmax_cp(r, bw.v[k].x); b = fmin_cp(b, bw.v[k].y); t = fmax_cp(t, bw.v[k].y);
           }
-          L.aabb[lane][0] = l - 0.0; L.aabb[lane][1] = b - 0.0; L.aabb[lane][2] = r + 0.0; L.aabb[lane][3] = t + 0.0;
+          bl = l - 0.0; bb = b - 0.0; br = r + 0.0; bt = t + 0.0;
+          L.aabb[lane][0] = bl; L.aabb[lane][1] = bb; L.aabb[lane][2] = br; L.aabb[lane][3] = bt;
+        } else {
+          bl = L.aabb[lane][0]; bb = L.aabb[lane][1]; br = L.aabb[lane][2]; bt = L.aabb[lane][3];
         }
+      } else {  // pedestrian: a circle of radius 5 at the new position
+        bl = npx - 5.0; bb = npy - 5.0; br = npx + 5.0; bt = npy + 5.0;
       }
+    } else if (lane >= DRV_SLOT_OBST && lane < DRV_SLOT_BLD + 4) {
+      live = lane >= DRV_SLOT_BLD || (lane - DRV_SLOT_OBST) < nObst;
+      const V2 c = static_pos(L, lane);
+      const double ex = lane >= DRV_SLOT_BLD ? 400.0 : 10.0, ey = lane >= DRV_SLOT_BLD ? 225.0 : 10.0;
+      // static box AABB = min/max of (c +- e) exactly as cached by cpShapeCacheBB with rot = (1,0)
+      bl = -ex + c.x; br = ex + c.x; bb = -ey + c.y; bt = ey + c.y;
     }
     aabbValid = true;
     __syncthreads();
 DRV_PROF(const unsigned long long Q4 = __builtin_amdgcn_s_memtime();)
 
-    // ======== phase 2: broadphase.  Lane = object j (slot id: cars, pedestrians, obstacles, buildings); the loop runs over
-    // the cars i < j whose box is broadcast from LDS.  cand bit i <=> cpBBIntersects(bb_i, bb_j) for the canonical pair
-    // (i, j); the pairs of one car are consecutive in canonical order and ascend with the lane.
+    // ======== phase 2: broadphase.  The loop runs over the cars i < j whose box is broadcast from LDS.  cand bit i <=>
+    // cpBBIntersects(bb_i, bb_j) for the canonical pair (i, j); the pairs of one car are consecutive in canonical order and
+    // ascend with the lane.
     int cand = 0;
     bool candMoving = false, removed = false;
     int dirty = 0;
     {
-      double bl = 0.0, bb = 0.0, br = -1.0, bt = -1.0;
-      bool live = false;
-      int sj = 3;  // statics are always still and frozen
-      if (lane < DRV_SLOT_PED) {
-        live = isCar; sj = L.still[lane];
-        bl = L.aabb[lane][0]; bb = L.aabb[lane][1]; br = L.aabb[lane][2]; bt = L.aabb[lane][3];
-      } else if (lane < DRV_SLOT_OBST) {
-        live = isPed; sj = L.still[lane];
-        const double cx = L.px[lane], cy = L.py[lane];
-        bl = cx - 5.0; bb = cy - 5.0; br = cx + 5.0; bt = cy + 5.0;
-      } else if (lane < DRV_SLOT_BLD + 4) {
-        live = lane >= DRV_SLOT_BLD || (lane - DRV_SLOT_OBST) < nObst;
-        const V2 c = static_pos(L, lane);
-        const double ex = lane >= DRV_SLOT_BLD ? 400.0 : 10.0, ey = lane >= DRV_SLOT_BLD ? 225.0 : 10.0;
-        // static box AABB = min/max of (c +- e) exactly as cached by cpShapeCacheBB with rot = (1,0)
-        bl = -ex + c.x; br = ex + c.x; bb = -ey + c.y; bt = ey + c.y;
-      }
       const int carStill = (int)(wave_ballot(isCar && (sj & 1)) & 0x3FFull);
       const int carFrozen = (int)(wave_ballot(isCar && (sj & 2)) & 0x3FFull);
       // cpBBIntersects(a, b) = a.l <= b.r && b.l <= a.r && a.b <= b.t && b.b <= a.t, branch-free: four compares into scalar masks,
