@@ -190,12 +190,16 @@ DE_OOL void velocity_update_ool(int nCarPed) {
 // INL: the inline form for drv_light_substep, which must stay a LEAF function - a function that calls saves its return
 // address through a VGPR that it stores to and reloads from scratch on every call (256 B per wave and substep, and the
 // reload sits right in front of the return).
+struct CarRot { double c, s, cosRel0; };
 template <bool INL = false>
-DE_DEV void car_refresh_rot(DrvLds& L, int lane, double ang) {
+DE_DEV CarRot car_refresh_rot(DrvLds& L, int lane, double ang) {
   const DevSC sc = INL ? dev_sincos_inl(ang) : dev_sincos(ang);
-  L.rc[lane] = sc.c; L.rs[lane] = sc.s; L.rotAng[lane] = ang;
-  L.cosRel0[lane] = INL ? dev_sincos_inl(RoadK<0>::dirAngle - ang).c : dev_cos(RoadK<0>::dirAngle - ang);
+  CarRot r;
+  r.c = sc.c; r.s = sc.s;
+  r.cosRel0 = INL ? dev_sincos_inl(RoadK<0>::dirAngle - ang).c : dev_cos(RoadK<0>::dirAngle - ang);
+  L.rc[lane] = r.c; L.rs[lane] = r.s; L.rotAng[lane] = ang; L.cosRel0[lane] = r.cosRel0;
   static_assert(RoadK<1>::dirAngle == 0.0, "cos(road1.dirAngle - angle) is read from rc");
+  return r;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1260,13 +1264,24 @@ DRV_PROF(const unsigned long long Q0 = __builtin_amdgcn_s_memtime();)
   const bool vbValid = (uniform_i(stateBits) & 1) != 0;
   bool aabbValid = (uniform_i(stateBits) & 2) != 0;
     bool turned = false;  // Car.turn rotated the body in place: geometry changed even if every velocity is zero
+    // ---- ONE batch of LDS loads: everything the lane's role reads below, issued before the first use (a lone wave cannot hide an
+    //      LDS round trip, ~110 cycles, and the phases below would otherwise make a dozen of them one after the other).  Indices are
+    //      clamped into the arrays, the values of lanes without the role are never used.  What this function changes before a later
+    //      use (velocity, angle, rotation cache) is tracked in these registers.
+    const int bi = lane & (DRV_NB - 1), ci = lane & 15;
+    int f = L.flags[bi];
+    double px = L.px[bi], py = L.py[bi], vx = L.vx[bi], vy = L.vy[bi], ang = L.ang[bi];
+    const double w = L.w[bi];
+    const double vbx = vbValid ? L.vbx[bi] : 0.0, vby = vbValid ? L.vby[bi] : 0.0, wb = vbValid ? L.wb[bi] : 0.0;
+    double rcv = L.rc[ci], rsv = L.rs[ci], rotAngv = L.rotAng[ci], cosRel0v = L.cosRel0[ci];
+    const double goalx = L.goalx[ci], goaly = L.goaly[ci], dprev = L.dprev[ci], chx = L.chx[ci], chy = L.chy[ci];
+    double rew = L.rewAcc[ci], posrew = L.posAcc[ci];
+    int moving = L.moving[bi];
+    if (!isBody) { f = 0; px = 0.0; py = 0.0; vx = 0.0; vy = 0.0; }
     // ---- common prefix of cars and pedestrians, ONE instruction stream for both (the two roles sit on different lanes of the
-    //      wave: what each does on its own is executed one after the other): state loads and, after processAction, the lane
-    //      classification of the position - min over the two roads of Road.isPointOnRoad - with the car's cached
-    //      cos(road - angle) or, for a pedestrian (isOffRoad, angle 0), the road's constant
-    int f = 0;
-    double px = 0.0, py = 0.0, vx = 0.0, vy = 0.0;
-    if (isBody) { f = L.flags[lane]; px = L.px[lane]; py = L.py[lane]; vx = L.vx[lane]; vy = L.vy[lane]; }
+    //      wave: what each does on its own is executed one after the other): after processAction, the lane classification of the
+    //      position - min over the two roads of Road.isPointOnRoad - with the car's cached cos(road - angle) or, for a pedestrian
+    //      (isOffRoad, angle 0), the road's constant
     if (isCar) {
       if (it == 0) {  // processAction :357-373 -> Car.accelerate (Car.py:55-94), Car.turn (Car.py:97-108)
         const int actPk = (int)L.act[lane];
@@ -1281,14 +1296,15 @@ DRV_PROF(const unsigned long long Q0 = __builtin_amdgcn_s_memtime();)
           else if (acc < 0 && moveDir > 0.0) skip = true;
           else if (acc > 0 && moveDir < 0.0) skip = true;
           if (!skip) {
-            const double cs = L.rc[lane], sn = L.rs[lane];  // = dm_sincos(ang): the cache is refreshed on every change
-            vx = vx + L.cpower[lane] * power * cs;
-            vy = vy + L.cpower[lane] * power * sn;
+            const double cs = rcv, sn = rsv;  // = dm_sincos(ang): the cache is refreshed on every change
+            const double cpower = L.cpower[lane];
+            vx = vx + cpower * power * cs;
+            vy = vy + cpower * power * sn;
             if (acc == 0 && (vx * dirx + vy * diry) * moveDir < 0.0) { vx = 0.0; vy = 0.0; }
           }
           if (steer != 0) {
             const double rot = (double)steer * (DM_PI / 180.0);
-            const double ang = L.ang[lane] + rot;
+            ang = ang + rot;
             const DevSC rsc = dev_sincos_inl(rot);
             const double sn = rsc.s, cs = rsc.c;
             const double dx = dirx * cs - diry * sn, dy = dirx * sn + diry * cs;
@@ -1296,7 +1312,8 @@ DRV_PROF(const unsigned long long Q0 = __builtin_amdgcn_s_memtime();)
             const double nvx = vx * cs - vy * sn, nvy = vx * sn + vy * cs;
             vx = nvx; vy = nvy;
             L.ang[lane] = ang;
-            car_refresh_rot<true>(L, lane, ang);
+            const CarRot cr = car_refresh_rot<true>(L, lane, ang);
+            rcv = cr.c; rsv = cr.s; rotAngv = ang; cosRel0v = cr.cosRel0;
             turned = true;
           }
         }
@@ -1306,17 +1323,16 @@ DRV_PROF(const unsigned long long Q1 = __builtin_amdgcn_s_memtime();)
     const V2 pos = v2(px, py);
     int lp = LP_OffRoad;
     if (isBody) {
-      int rp = road_pos<0>(pos, isCar ? L.cosRel0[lane] : RoadK<0>::cosDir0);
+      int rp = road_pos<0>(pos, isCar ? cosRel0v : RoadK<0>::cosDir0);
       if (rp < lp) lp = rp;
-      rp = road_pos<1>(pos, isCar ? L.rc[lane] : RoadK<1>::cosDir0);
+      rp = road_pos<1>(pos, isCar ? rcv : RoadK<1>::cosDir0);
       if (rp < lp) lp = rp;
     }
 DRV_PROF(const unsigned long long Q2 = __builtin_amdgcn_s_memtime();)
     if (isCar) {
       // tick :376-426
-      double rew = L.rewAcc[lane], posrew = L.posAcc[lane];
-      const double dnow = vlen(vsub(pos, v2(L.goalx[lane], L.goaly[lane])));
-      const double diff = L.dprev[lane] - dnow;
+      const double dnow = vlen(vsub(pos, v2(goalx, goaly)));
+      const double diff = dprev - dnow;
       if (!CF_FIN(f)) { const double d50 = diff / 50.0; rew += d50; posrew += dm_max(0.0, d50); }
       L.prevx[lane] = px; L.prevy[lane] = py; L.dprev[lane] = dnow;
       if (lp >= LP_OverRoad) {
@@ -1343,7 +1359,6 @@ DRV_PROF(asm volatile("" ::: "memory");)
     } else if (isPed) {
       // ======== phase 1b: pedestrian FSM (move :429-506) ====================================================
       if (!PF_DEAD(f)) {
-        int moving = L.moving[lane];
         int crossing = PF_CROSSING(f), beginc = PF_BEGIN(f), side = PF_SIDE(f);
         const bool isOffRoad = lp >= LP_OverRoad;  // drv_is_off_road(pos)
         const bool isOut = drv_is_out(pos);
@@ -1394,11 +1409,8 @@ DRV_PROF(const unsigned long long Q3 = __builtin_amdgcn_s_memtime();)
     bool live = false;
     int sj = 3;  // statics are always still and frozen
     if (isBody) {
-      const double px = L.px[lane], py = L.py[lane], ang = L.ang[lane];
-      const double vx = L.vx[lane], vy = L.vy[lane], w = L.w[lane];
       // bias velocities: L.vb* keep the output of the last contact solve (a replay needs it again); they count only if
       // the previous substep solved or replayed contacts (vbValid), else cpBodyUpdatePosition saw zeros
-      const double vbx = vbValid ? L.vbx[lane] : 0.0, vby = vbValid ? L.vby[lane] : 0.0, wb = vbValid ? L.wb[lane] : 0.0;
       const double npx = px + (vx + vbx) * DE_DT, npy = py + (vy + vby) * DE_DT, nang = ang + (w + wb) * DE_DT;
       const bool still = !turned && vx == 0.0 && vy == 0.0 && w == 0.0 && vbx == 0.0 && vby == 0.0 && wb == 0.0;
       L.px[lane] = npx; L.py[lane] = npy; L.ang[lane] = nang;
@@ -1408,10 +1420,10 @@ DRV_PROF(const unsigned long long Q3 = __builtin_amdgcn_s_memtime();)
       L.still[lane] = sj;
       live = true;
       if (isCar) {
-        if (nang != L.rotAng[lane]) car_refresh_rot<true>(L, lane, nang);
+        if (nang != rotAngv) { const CarRot cr = car_refresh_rot<true>(L, lane, nang); rcv = cr.c; rsv = cr.s; }
         if (!aabbValid || !frozen) {  // frozen: same position and rotation => same box
           BoxW bw;
-          box_world(bw, v2(npx, npy), L.rc[lane], L.rs[lane], L.chx[lane], L.chy[lane]);
+          box_world(bw, v2(npx, npy), rcv, rsv, chx, chy);
           double l = INFINITY, r = -INFINITY, b = INFINITY, t = -INFINITY;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
