@@ -66,6 +66,15 @@ DE_DEV double bcast_d(double v, int src) {
   u.i[1] = __builtin_amdgcn_readlane(u.i[1], src);
   return u.d;
 }
+// value of `v` in lane `src` (any lane, per-lane index; source lanes must be active): ds_bpermute_b32, no LDS storage involved
+DE_DEV int lane_read_i(int v, int src) { return __builtin_amdgcn_ds_bpermute(src << 2, v); }
+DE_DEV double lane_read_d(double v, int src) {
+  union { double d; int i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_ds_bpermute(src << 2, u.i[0]);
+  u.i[1] = __builtin_amdgcn_ds_bpermute(src << 2, u.i[1]);
+  return u.d;
+}
 DE_DEV int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 DE_DEV uint64_t uniform_u64(uint64_t v) {
   uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);

@@ -768,6 +768,95 @@ DE_DEV void body_store_bias(DrvLds& L, int idx, const BodyV& b) {
   if (idx < DRV_SLOT_OBST) { L.vbx[idx] = b.vb.x; L.vby[idx] = b.vb.y; L.wb[idx] = b.wb; }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The sweeps of a GENERAL multi-level solve (some arbiter with moving bodies or accumulated impulses, arbiters sharing bodies:
+// a car pushing into a pile - the slowest environments of a launch), as a function of its own.  An arbiter's two impulse chains -
+// velocity (v, w, jn) and position correction (v_bias, w_bias, jBias) - read and write disjoint body fields and run the same
+// instruction sequence:  j += clamp((c -+ rel.n) * nMass),  impulse along n,  two body updates.  A lone wave pays per
+// instruction, not per lane, so the bias chain of slot s runs on lane s + 32 beside the velocity chain on lane s: 63 instead of
+// 95 fp64 instructions per contact and pass.  Same operations on the same operands in the same order as arb_apply_impulse,
+// chain by chain (the two only meet in memory, in different fields): bit-identical.  The mirror lanes fetch their arbiter's
+// scalars from the slot lane (ds_bpermute) and rebuild r1, r2, n from the mailbox exactly as the prestep did.
+// (Inside drv_prestep_solve this form needs more registers than the function has: 16 spills on every call, measured.  Here only
+// the solves that take this path pay for what their caller keeps across the call.)
+// ------------------------------------------------------------------------------------------------
+struct DrvSplitRet { double jn0, jn1, jb0, jb1, jt0, jt1; int pk, pair, bits; };
+DE_OOL DrvSplitRet drv_solve_general_split(int lane, int myLevel_, int bodyAB, int lvl_, double nMass0, double nMass1, double bias0, double bias1,
+                                           double bounce0, double bounce1, double jn0, double jn1, double jt0, double jt1, int pk, int pair,
+                                           int bits3) {
+  DrvLds& L = g_L;
+  DrvMailbox& M = L.u.mb;
+  int code = ((pk >> 30) & 1) | (((pk >> 8) & 0xFF) << 1) | (myLevel_ << 8);  // active | contact count << 1 | level << 8
+  const int maxLevel = (int)(signed char)(uniform_i(lvl_) & 0xFF), period = uniform_i(lvl_) >> 8;
+  const bool biasLane = lane >= 32;
+  const int sl = lane & 31;  // the slot this lane works for
+  code = lane_read_i(code, sl); bodyAB = lane_read_i(bodyAB, sl);
+  nMass0 = lane_read_d(nMass0, sl); nMass1 = lane_read_d(nMass1, sl);
+  bias0 = lane_read_d(bias0, sl); bias1 = lane_read_d(bias1, sl);
+  const bool active = (code & 1) != 0 && sl < DRV_NS;
+  const int count = (code >> 1) & 3, myLevel = code >> 8;
+  const int bodyA = bodyAB & 0xFF, bodyB = bodyAB >> 8;
+  const double nM[2] = {nMass0, nMass1};
+  const double cq[2] = {biasLane ? bias0 : bounce0, biasLane ? bias1 : bounce1};
+  double acc[2] = {biasLane ? 0.0 : jn0, biasLane ? 0.0 : jn1};  // jBias starts every solve at zero, jn at the warm-started value
+  V2 n = v2(0.0, 0.0), r1[2], r2[2];
+  r1[0] = r1[1] = r2[0] = r2[1] = v2(0.0, 0.0);
+  BodyV a, b;
+  a.p = b.p = a.v = b.v = a.vb = b.vb = v2(0.0, 0.0); a.w = b.w = a.wb = b.wb = a.minv = b.minv = a.iinv = b.iinv = 0.0;
+  if (active) {
+    body_load(L, bodyA, a);
+    body_load(L, bodyB, b);
+    r1[0] = vsub(v2(M.p1x[sl][0], M.p1y[sl][0]), a.p);
+    r2[0] = vsub(v2(M.p2x[sl][0], M.p2y[sl][0]), b.p);
+    if (count > 1) {
+      r1[1] = vsub(v2(M.p1x[sl][1], M.p1y[sl][1]), a.p);
+      r2[1] = vsub(v2(M.p2x[sl][1], M.p2y[sl][1]), b.p);
+    }
+    n = v2(M.nx[sl], M.ny[sl]);
+  }
+  // this lane's chain works on (v, w) - the velocity fields on a slot lane, the bias fields on its mirror lane
+  double* const fX = biasLane ? L.vbx : L.vx;
+  double* const fY = biasLane ? L.vby : L.vy;
+  double* const fW = biasLane ? L.wb : L.w;
+  const bool aDyn = bodyA < DRV_SLOT_OBST, bDyn = bodyB < DRV_SLOT_OBST;
+  a.v = b.v = v2(0.0, 0.0); a.w = b.w = 0.0;  // statics: all-zero and never stored
+  const int nSteps = maxLevel + 1 + period * 9;  // pipelined sweeps, see drv_prestep_solve
+  int due = myLevel, passes = 0;
+  for (int t = 0; t < nSteps; ++t) {
+    if (active && t == due && passes < 10) {
+      if (aDyn) { a.v = v2(fX[bodyA], fY[bodyA]); a.w = fW[bodyA]; }
+      if (bDyn) { b.v = v2(fX[bodyB], fY[bodyB]); b.w = fW[bodyB]; }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if (q < count) {
+          const V2 vr = relative_velocity(a, b, r1[q], r2[q]);
+          const double vn = vdot(vr, n);
+          // velocity: jnn = -(bounce + vrn) * nMass;  bias: jbn = (bias - vbn) * nMass  (x - y is x + (-y), negation is exact)
+          const double t0 = cq[q] + (biasLane ? -vn : vn);
+          const double jq = (biasLane ? t0 : -t0) * nM[q];
+          const double old = acc[q];
+          acc[q] = fmax_cp(old + jq, 0.0);
+          const double dj = acc[q] - old;
+          const V2 jr = vrotate(n, v2(dj, 0.0));  // velocity: normal + (zero) tangent impulse through cpvrotate, as in the reference
+          const V2 jl = vmul(n, dj);              // bias: no tangent term, not even a zero one (sign of zero)
+          const V2 jj = biasLane ? jl : jr;
+          apply_impulse(a, vneg(jj), r1[q]);
+          apply_impulse(b, jj, r2[q]);
+        }
+      }
+      if (aDyn) { fX[bodyA] = a.v.x; fY[bodyA] = a.v.y; fW[bodyA] = a.w; }
+      if (bDyn) { fX[bodyB] = b.v.x; fY[bodyB] = b.v.y; fW[bodyB] = b.w; }
+      due += period; ++passes;
+    }
+    __syncthreads();
+  }
+  DrvSplitRet r;
+  r.jt0 = jt0; r.jt1 = jt1; r.pk = pk; r.pair = pair; r.bits = bits3;  // the caller's own values, handed back
+  r.jn0 = acc[0]; r.jn1 = acc[1];
+  r.jb0 = lane_read_d(acc[0], (lane + 32) & 63); r.jb1 = lane_read_d(acc[1], (lane + 32) & 63);  // a slot lane reads its mirror lane's jBias
+  return r;
+}
+
 DRV_PROF(__device__ unsigned long long g_dbgw[4096 * 12];)
 DRV_PROF(__device__ unsigned long long g_dbgp[4096 * 8];)
 DRV_PROF(__device__ unsigned long long g_dbgr[16];)
@@ -787,9 +876,9 @@ DE_OOL int drv_prestep_solve(int lane, int nCarPed, int pk, int a_pair, int body
   DrvLds& L = g_L;
   DrvMailbox& M = L.u.mb;
   int a_state = pk & 0xFF;
-  const int a_count = (pk >> 8) & 0xFF, a_age = (pk >> 16) & 0xFF;
-  const bool touched = (pk >> 24) & 1, freeMe = (pk >> 25) & 1, hashSame = (pk >> 26) & 1, prevInert = (pk >> 27) & 1;
-  const bool skipped = (pk >> 28) & 1, slotOcc = (pk >> 29) & 1, active = (pk >> 30) & 1;
+  int a_count = (pk >> 8) & 0xFF, a_age = (pk >> 16) & 0xFF;
+  bool touched = (pk >> 24) & 1, freeMe = (pk >> 25) & 1, hashSame = (pk >> 26) & 1, prevInert = (pk >> 27) & 1;
+  bool skipped = (pk >> 28) & 1, slotOcc = (pk >> 29) & 1, active = (pk >> 30) & 1;
   const bool isCar = lane < (uniform_i(nCarPed) & 0xFF), isPed = lane >= DRV_SLOT_PED && lane < DRV_SLOT_PED + (uniform_i(nCarPed) >> 8);
   const int maxLevel = (int)(signed char)(uniform_i(maxLevel_) & 0xFF), period = uniform_i(maxLevel_) >> 8;
   const uint64_t activeMask = uniform_i(anyActive_) ? 1ull : 0ull;
@@ -897,18 +986,22 @@ DRV_PROF(profMode = wave_ballot(!biasOnly) == 0ull ? 3 : 4;)
         }
         __syncthreads();
       }
-    } else {
-      for (int t = 0; t < nSteps; ++t) {
-        if (active && t == due && passes < 10) {
-          body_load_vel(L, bodyA, a);
-          body_load_vel(L, bodyB, b);
-          arb_apply_impulse(a, b, n, r1, r2, nMass, tMass, bias, bounce, jBias, jn, jt, a_count, arb_u);
-          body_store_vel(L, bodyA, a);
-          body_store_vel(L, bodyB, b);
-          due += period; ++passes;
-        }
-        __syncthreads();
-      }
+    } else [[unlikely]] {
+      // the general sweeps are a function of their own (drv_solve_general_split).  NOTHING of this frame lives across the call:
+      // what the verdicts below need - the packed slot state, the pair, the tangent impulses, three predicates - travels through
+      // the callee's registers and comes back in its return value (a value kept across the call would be spilled, and the
+      // allocator then spills it across the whole function, the bias-only loops that every pile-up runs included: measured)
+      const int bits3 = (restIn ? 1 : 0) | (bias[0] == 0.0 ? 2 : 0) | (bias[1] == 0.0 ? 4 : 0);
+      const DrvSplitRet sr = drv_solve_general_split(lane, myLevel, bodyA | (bodyB << 8), maxLevel_, nMass[0], nMass[1], bias[0], bias[1], bounce[0],
+                                                     bounce[1], jn[0], jn[1], jt[0], jt[1], pk, a_pair, bits3);
+      lane = fresh_lane();
+      pk = sr.pk; a_pair = sr.pair;
+      a_state = pk & 0xFF; a_count = (pk >> 8) & 0xFF; a_age = (pk >> 16) & 0xFF;
+      touched = (pk >> 24) & 1; freeMe = (pk >> 25) & 1; hashSame = (pk >> 26) & 1; prevInert = (pk >> 27) & 1;
+      skipped = (pk >> 28) & 1; slotOcc = (pk >> 29) & 1; active = (pk >> 30) & 1;
+      restIn = (sr.bits & 1) != 0;
+      bias[0] = (sr.bits & 2) ? 0.0 : 1.0; bias[1] = (sr.bits & 4) ? 0.0 : 1.0;  // (only compared with zero from here on)
+      jn[0] = sr.jn0; jn[1] = sr.jn1; jBias[0] = sr.jb0; jBias[1] = sr.jb1; jt[0] = sr.jt0; jt[1] = sr.jt1;
     }
   }
 DRV_PROF(const unsigned long long P3 = __builtin_amdgcn_s_memtime();)
