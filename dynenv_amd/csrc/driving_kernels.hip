@@ -1074,13 +1074,13 @@ DRV_PROF(int profCand = 0;)
   // ---- compact the pairs (bit i of lane j = pair (i, j)) into one dense list in canonical order, so that the
   //      narrowphase runs once over up to 64 pairs
   int nCand = 0;
-#pragma unroll 1
-  for (int i = 0; i < A; ++i) {
+  // (straight-line over the ten car bits - `bits` has none at or above A: ten ballots and masked stores, no loop-carried wait)
+#pragma unroll
+  for (int i = 0; i < DRV_MAXA; ++i) {
     const bool c = (bits >> i) & 1;
     const uint64_t m = wave_ballot(c);
-    if (m == 0ull) continue;
     if (c) {
-      const int idx = nCand + __popcll(m & ((1ull << lane) - 1ull));
+      const int idx = nCand + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
       if (idx < DRV_CLIST) L.clist[idx] = (unsigned short)((i << 8) | lane); else err |= 1;  // overflow is reported
     }
     nCand += __popcll(m);
@@ -1088,6 +1088,7 @@ DRV_PROF(int profCand = 0;)
   if (nCand > DRV_CLIST) nCand = DRV_CLIST;
 DRV_PROF(profCand += nCand;)
   __syncthreads();
+DRV_PROF(const unsigned long long N1 = __builtin_amdgcn_s_memtime(); unsigned long long nMath = 0ull;)
   if (mode == 0) {  // a dirty pair that owns a slot rules the light mode out before any narrowphase work is spent on it
     bool owns = false;
     for (int k = lane; k < nCand; k += 64) {
@@ -1098,6 +1099,7 @@ DRV_PROF(profCand += nCand;)
   }
 #pragma unroll 1
   for (int pass = 0; pass * 16 < nCand; ++pass) {  // 16 pairs per pass, one DPP quad of lanes each
+DRV_PROF(nMath -= __builtin_amdgcn_s_memtime();)
     const int q = lane & 3;
     const bool isCand = pass * 16 + (lane >> 2) < nCand;
     Contacts ct;
@@ -1117,6 +1119,7 @@ DRV_PROF(profCand += nCand;)
         poly_to_poly(b1, i, b2, j, q, ct);
       }
     }
+DRV_PROF(nMath += __builtin_amdgcn_s_memtime();)
     const bool touch = isCand && q == 0 && ct.count > 0;  // lane 0 of the quad speaks for the pair
     // find my slot among the occupied ones
     int slot = -1;
@@ -1158,6 +1161,7 @@ DRV_PROF(profCand += nCand;)
     __syncthreads();
   }
   __syncthreads();
+DRV_PROF(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* d = g_dbgl + blockIdx.x * 8; d[6] += (N1 - T0) + (nMath << 32); d[7] += __builtin_amdgcn_s_memtime() - N1 - nMath; })
   if (mode == 0 && wave_ballot(lightBad) == 0ull) { lightOk = true; break; }
   }
   if (lightOk) {

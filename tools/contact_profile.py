@@ -35,6 +35,9 @@ ql = np.loadtxt("gpurun_out/dbgl.txt")[:NE]
 print("light substep, cycles per step (10 substeps): loads+processAction | lane classification | tick / pedestrian FSM | position update+rotation+box | broadphase | whole function")
 print("   top envs:"); [print("     ", ql[k, :6].astype(int)) for k in top[:8]]
 print("   mean over all envs:", ql[:, :6].mean(0).astype(int), " mean over envs without contact substeps:", ql[d[:, 1] == 0, :6].mean(0).astype(int))
+qraw = np.loadtxt("gpurun_out/dbgl.txt", dtype=np.uint64)[:NE]
+print("narrowphase of the top envs, cycles per step: flag clear + candidate list | the pair tests (SAT, clipping) | slot matching, mailbox, barriers")
+for k in top[:10]: print("     ", int(qraw[k, 6] & np.uint64(0xFFFFFFFF)), int(qraw[k, 6] >> np.uint64(32)), int(qraw[k, 7]))
 m = d[:, 1] == 10
 for o in range(0, 25):
     mm = m & (d[:, 2] == o)
