@@ -994,10 +994,17 @@ DE_DEV void joints_solve(const RcJoint& J, RcFeet& f, double& jx, double& jy, do
   pivot_warm_start<CLEAN>(J, f, jx, jy);
   if (pf) rotary_warm_start(J, f, jr);
   if (!pf) rotary_iterate(J, f, jr);
+  // CLEAN: fixed-point exit.  An iteration (pivot, rotary) that leaves the three accumulated impulses where they were has applied
+  // impulses jNew - jOld = 0 to the feet: x + (+-0) is x bit for bit since no velocity is -0 (the CLEAN invariant), so the
+  // iteration changed nothing - and every later one, a function of the same state, changes nothing either (also the last one
+  // of a rotary-first robot, which lacks its rotary half).  All robots of the wave must have got there: the lanes share the loop.
+  // A walking robot's pivot is solved exactly by its first pass up to rounding; the second or third pass adds zero.
 #pragma unroll 1
   for (int iter = 0; iter < 10; ++iter) {
+    const double jx0 = jx, jy0 = jy, jr0 = jr;
     pivot_iterate<CLEAN>(J, f, jx, jy);
     if (pf || iter < 9) rotary_iterate(J, f, jr);
+    if (CLEAN && __ballot(!(jx == jx0 && jy == jy0 && jr == jr0)) == 0ull) break;
   }
 }
 template <int EPW>
