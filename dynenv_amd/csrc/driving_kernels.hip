@@ -735,8 +735,9 @@ DE_DEV void arb_apply_impulse(BodyV& a, BodyV& b, V2 n, const V2* r1, const V2* 
 // The bias half of cpArbiterApplyImpulse alone (exactly the bias-only branch above), for solves in which EVERY active
 // arbiter is bias-only.  Nothing in such a solve writes v, w, jn or jt, so the condition - evaluated once, after the warm
 // start - holds for all 10 iterations and the loop needs neither the per-pass test nor the velocities themselves.
-DE_DEV void arb_apply_bias_only(BodyV& a, BodyV& b, V2 n, const V2* r1, const V2* r2, const double* nMass, const double* bias,
+DE_DEV bool arb_apply_bias_only(BodyV& a, BodyV& b, V2 n, const V2* r1, const V2* r2, const double* nMass, const double* bias,
                                 double* jBias, int count) {
+  bool changed = false;
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     if (c < count) {
@@ -746,11 +747,13 @@ DE_DEV void arb_apply_bias_only(BodyV& a, BodyV& b, V2 n, const V2* r1, const V2
       double jbn = (bias[c] - vbn) * nMass[c];
       double jbnOld = jBias[c];
       jBias[c] = fmax_cp(jbnOld + jbn, 0.0);
+      changed |= jBias[c] != jbnOld;
       V2 jb = vmul(n, jBias[c] - jbnOld);
       apply_bias_impulse(a, vneg(jb), r1[c]);
       apply_bias_impulse(b, jb, r2[c]);
     }
   }
+  return changed;
 }
 DE_DEV bool arb_is_bias_only(const BodyV& a, const BodyV& b, const double* jn, const double* jt, const double* bounce, int count) {
   long long z = __double_as_longlong(a.v.x) | __double_as_longlong(a.v.y) | __double_as_longlong(a.w) |
@@ -932,7 +935,10 @@ DRV_PROF(int profMode = 0; const unsigned long long P2 = __builtin_amdgcn_s_memt
       if (wave_ballot(!arb_is_bias_only(a, b, jn, jt, bounce, a_count)) == 0ull) {  // all resting contacts: bias half only
 DRV_PROF(profMode = 1;)
 #pragma unroll 1
-        for (int iter = 0; iter < 10; ++iter) arb_apply_bias_only(a, b, n, r1, r2, nMass, bias, jBias, a_count);
+        // (fixed-point exit: a sweep in which no accumulated bias impulse moved added +-0 to bias velocities that start at +0 and
+        //  can never be -0 - it changed nothing, and neither will any later sweep)
+        for (int iter = 0; iter < 10; ++iter)
+          if (wave_ballot(arb_apply_bias_only(a, b, n, r1, r2, nMass, bias, jBias, a_count)) == 0ull) break;
       } else {
 DRV_PROF(profMode = 2;)
 #pragma unroll 1
