@@ -32,6 +32,7 @@ enum { CF_DIRX = 0, CF_DIRY, CF_PREVX, CF_PREVY, CF_GOALX, CF_GOALY, CF_COUNT };
 enum { EI_ELAPSED = 0, EI_ALLFIN, EI_NPED, EI_NOBST, EI_EPISODE, EI_OCC, EI_ERR, EI_PAD,
        EI_N_FAST, EI_N_QUIET, EI_N_CONTACT, EI_N_SLOTS, /* diagnostics: substeps per path, sum of live slots */
        EI_N_WHY_CAND, EI_N_WHY_MOVING, EI_N_WHY_INERT, EI_N_STEADY, EI_N_LIGHT, /* why the quiescent shortcut was not taken */
+       EI_N_SPLIT, /* contact-path substeps whose sweeps ran in drv_solve_general_split (general multi-level solves) */
        EI_DEFER_OBS, /* Partial: first agent whose observation is left to drv_partial_obs_deferred_kernel (A = none) */
        EI_COUNT };
 // arbiter states (Chipmunk cpArbiterState)

@@ -923,6 +923,7 @@ DRV_PROF(const unsigned long long P1 = __builtin_amdgcn_s_memtime();)
   // ---- velocity update (velocity_func: friction_* or default) -------------------------------------------
   velocity_update(L, lane, isCar, isPed);
 DRV_PROF(int profMode = 0; const unsigned long long P2 = __builtin_amdgcn_s_memtime();)
+  bool tookSplit = false;  // (wave-uniform) the sweeps ran in drv_solve_general_split: counted in EI_N_SPLIT
   if (activeMask && maxLevel == 0) {
     // No two active arbiters share a dynamic body: each lane keeps its two bodies in registers through the warm start
     // and all 10 iterations, with one LDS load and one store (same arithmetic, no LDS round trip per iteration).
@@ -1008,6 +1009,7 @@ DRV_PROF(profMode = wave_ballot(!biasOnly) == 0ull ? 3 : 4;)
       restIn = (sr.bits & 1) != 0;
       bias[0] = (sr.bits & 2) ? 0.0 : 1.0; bias[1] = (sr.bits & 4) ? 0.0 : 1.0;  // (only compared with zero from here on)
       jn[0] = sr.jn0; jn[1] = sr.jn1; jBias[0] = sr.jb0; jBias[1] = sr.jb1; jt[0] = sr.jt0; jt[1] = sr.jt1;
+      tookSplit = true;
     }
   }
 DRV_PROF(const unsigned long long P3 = __builtin_amdgcn_s_memtime();)
@@ -1047,7 +1049,7 @@ DRV_PROF(const unsigned long long P3 = __builtin_amdgcn_s_memtime();)
   }
   const bool allInert = wave_ballot(!inert) == 0ull;
 DRV_PROF(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* d = g_dbgp + blockIdx.x * 8; const unsigned long long P4 = __builtin_amdgcn_s_memtime(); d[2] += (P1 - P0) + ((P4 - P3) << 32); d[3] += (P2 - P1) + ((P3 - P2) << 32); })
-  return (allInert ? 2 : 0) | (allSteady ? 4 : 0) DRV_PROF(| (prof_any(profMode) << 4));
+  return (allInert ? 2 : 0) | (allSteady ? 4 : 0) | (tookSplit ? 8 : 0) DRV_PROF(| (prof_any(profMode) << 4));
 }
 struct ContactRet {
   uint64_t occ;
@@ -1332,7 +1334,7 @@ DRV_PROF(const unsigned long long T3 = T2, T4 = T2, T5 = __builtin_amdgcn_s_memt
 DRV_PROF(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* d = g_dbgp + blockIdx.x * 8; d[0] += T1 - T0; d[1] += T2 - T1; d[2] += T3 - T2; d[3] += T4 - T3; d[4] += T5 - T4; d[5] += 1ull + (light ? (1ull << 16) : 0ull); d[6] += (unsigned long long)(maxLevel + 1) + ((unsigned long long)(maxLevel + 1) << (12 * profModeW)); d[7] += (unsigned long long)nTouched + ((unsigned long long)profCand << 16); })
   {
     ContactRet ret;
-    ret.occ = occ; ret.err = err | (uniform_i(solveBits) & 6);
+    ret.occ = occ; ret.err = err | (uniform_i(solveBits) & 6) | ((uniform_i(solveBits) & 8) << 1);  // bit 4: split-lane sweeps
     return ret;
   }
 }
@@ -1634,7 +1636,7 @@ DRV_PROF(if (lane < 8 && e < 4096) g_dbgp[e * 8 + lane] = 0ull;)
   // steady-replay state: the contact path ran (or was replayed) in the previous substep and reported every slot steady
   bool steadyAll = (uniform_i(envi[EI_PAD]) & 2) != 0;
   bool vbValid = (uniform_i(envi[EI_PAD]) & 4) != 0;
-  int nFast = 0, nQuiet = 0, nContact = 0, nSlots = 0, nWhyCand = 0, nWhyMoving = 0, nWhyInert = 0, nSteady = 0, nLight = 0;  // diagnostics
+  int nFast = 0, nQuiet = 0, nContact = 0, nSlots = 0, nWhyCand = 0, nWhyMoving = 0, nWhyInert = 0, nSteady = 0, nLight = 0, nSplit = 0;  // diagnostics
   __syncthreads();
 
 DRV_PROF(const unsigned long long K0 = __builtin_amdgcn_s_memtime(); unsigned long long tPh1 = 0, tBroad = 0, tFast = 0, tCont = 0, tBook = 0;)
@@ -1689,6 +1691,7 @@ DRV_PROF(tookContact = true;)
       if (uniform_i(cr.err >> 3) & 1) {  // light mode: no dirty pair touches => replay
         replay = true; nLight++;
       } else {
+        nSplit += uniform_i(cr.err >> 4) & 1;
         occ = uniform_u64(cr.occ);
         inertAll = (uniform_i(cr.err >> 1) & 1) != 0;
         steadyAll = (uniform_i(cr.err >> 2) & 1) != 0;
@@ -1723,7 +1726,7 @@ DRV_PROF(const unsigned long long K1 = __builtin_amdgcn_s_memtime();)
   double* er = S.epr + (size_t)e * 16 + (isCar ? lane : 0);
   double* ep = S.epr + (size_t)S.E * 16 + (size_t)e * 16 + (isCar ? lane : 0);
   const double g_er = *er, g_ep = *ep;
-  const int cl = lane < 9 ? lane : 0;  // lanes 0..8: one diagnostic counter each (EI_N_FAST .. EI_N_LIGHT are consecutive)
+  const int cl = lane < 10 ? lane : 0;  // lanes 0..9: one diagnostic counter each (EI_N_FAST .. EI_N_SPLIT are consecutive)
   const int g_cnt = envi[EI_N_FAST + cl];
   const int g_err = envi[EI_ERR];
   double rew = 0.0, posrew = 0.0;
@@ -1744,11 +1747,11 @@ DRV_PROF(const unsigned long long K1 = __builtin_amdgcn_s_memtime();)
   if (isCar) { *er = g_er + rew; *ep = g_ep + posrew; }
   {
     static_assert(EI_N_QUIET == EI_N_FAST + 1 && EI_N_CONTACT == EI_N_FAST + 2 && EI_N_SLOTS == EI_N_FAST + 3 && EI_N_WHY_CAND == EI_N_FAST + 4 &&
-                  EI_N_WHY_MOVING == EI_N_FAST + 5 && EI_N_WHY_INERT == EI_N_FAST + 6 && EI_N_STEADY == EI_N_FAST + 7 && EI_N_LIGHT == EI_N_FAST + 8,
+                  EI_N_WHY_MOVING == EI_N_FAST + 5 && EI_N_WHY_INERT == EI_N_FAST + 6 && EI_N_STEADY == EI_N_FAST + 7 && EI_N_LIGHT == EI_N_FAST + 8 && EI_N_SPLIT == EI_N_FAST + 9,
                   "the diagnostic counters are consecutive");
     const int add = lane == 0 ? nFast : lane == 1 ? nQuiet : lane == 2 ? nContact : lane == 3 ? nSlots : lane == 4 ? nWhyCand : lane == 5 ? nWhyMoving :
-                    lane == 6 ? nWhyInert : lane == 7 ? nSteady : nLight;
-    if (lane < 9) envi[EI_N_FAST + lane] = g_cnt + add;
+                    lane == 6 ? nWhyInert : lane == 7 ? nSteady : lane == 8 ? nLight : nSplit;
+    if (lane < 10) envi[EI_N_FAST + lane] = g_cnt + add;
   }
   if (errBits && lane == 0) envi[EI_ERR] = g_err | errBits;
   // Partial observation of this environment, fused (see drv_partial_obs_fused): the first `fusedAgents` agent passes run
@@ -1889,7 +1892,7 @@ extern "C" __global__ void __launch_bounds__(64) drv_reset_kernel(DrvState S) {
   envi[EI_ELAPSED] = 0; envi[EI_ALLFIN] = 0; envi[EI_NPED] = nPed; envi[EI_NOBST] = nObst;
   envi[EI_EPISODE] = (int)(ep + 1); envi[EI_OCC] = 0; envi[EI_ERR] = 0;
   envi[EI_N_FAST] = 0; envi[EI_N_QUIET] = 0; envi[EI_N_CONTACT] = 0; envi[EI_N_SLOTS] = 0; envi[EI_PAD] = 0;
-  envi[EI_N_STEADY] = 0; envi[EI_N_LIGHT] = 0;
+  envi[EI_N_STEADY] = 0; envi[EI_N_LIGHT] = 0; envi[EI_N_SPLIT] = 0;
   envi[EI_N_WHY_CAND] = 0; envi[EI_N_WHY_MOVING] = 0; envi[EI_N_WHY_INERT] = 0;
   for (int k = 0; k < 64; ++k) S.lastcand[(size_t)e * 64 + k] = -1;
 }

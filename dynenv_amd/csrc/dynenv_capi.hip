@@ -686,7 +686,7 @@ int dynenv_debug_counters(dynenv_t* h, int64_t* out4) {
   HIP_OK(hipMemcpy(envi.data(), h->S.envi, envi.size() * sizeof(int), hipMemcpyDeviceToHost));
   for (int k = 0; k < 12; ++k) out4[k] = 0;
   for (int e = 0; e < h->S.E; ++e)
-    for (int k = 0; k < 9; ++k) out4[k] += envi[(size_t)e * EI_COUNT + EI_N_FAST + k];
+    for (int k = 0; k < 10; ++k) out4[k] += envi[(size_t)e * EI_COUNT + EI_N_FAST + k];
 #ifdef DRV_PROFILE
   { unsigned long long d[16]; HIP_OK(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_dbgr), sizeof(d))); FILE* f = fopen("gpurun_out/dbgr.txt", "w"); for (int k = 0; k < 16; ++k) fprintf(f, "%llu\n", d[k]); fclose(f); }
   { static unsigned long long d[4096 * 12]; HIP_OK(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_dbgw), sizeof(d))); FILE* f = fopen("gpurun_out/dbgw.txt", "w"); for (int k = 0; k < 4096; ++k) { for (int q = 0; q < 12; ++q) fprintf(f, "%llu ", d[12*k+q]); fprintf(f, "\n"); } fclose(f); }

@@ -214,7 +214,8 @@ int dynenv_error_flags(dynenv_t* h, int32_t* out);
 
 /* Diagnostics (Driving), summed over environments since the last reset: out12 = {substeps on the no-contact fast path,
  * on the quiescent shortcut, on the full contact path, sum of live contact-cache slots, contact-path substeps caused by
- * a changed candidate set / a moving body / a non-inert arbiter, substeps served by a steady replay, 0, 0, 0, 0}.
+ * a changed candidate set / a moving body / a non-inert arbiter, substeps served by a steady replay, by the light mode,
+ * contact-path substeps whose sweeps ran as split-lane general multi-level solves, 0, 0}.
  * Synchronises the device. */
 int dynenv_debug_counters(dynenv_t* h, int64_t* out12);
 

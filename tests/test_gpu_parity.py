@@ -175,6 +175,8 @@ def test_collision_scenarios(gpu, kind):
         _assert_state_equal(env.get_state(0), ora.get_state(0), "%s step %d" % (kind, s))
     if kind != "ped_slow":
         assert touched > 0, "scenario %s never produced an active contact" % kind
+    if kind == "pileup":  # chained arbiters with moving bodies: the split-lane sweeps (drv_solve_general_split) must have run here
+        assert env.debug_counters()["split"] > 0, "the pile-up never took the general multi-level solver"
     assert env.error_flags() == 0
     env.close()
 
