@@ -1046,6 +1046,7 @@ DE_DEV void rc_joints_only(int lane, int R) { rc_joints_only_ool(lane, R); }
 #define RC_PROF(...)
 #endif
 RC_PROF(__device__ unsigned long long g_rcprof[4096 * 12];)
+RC_PROF(__device__ unsigned long long g_rcprof2[4096 * 8];)  // stages of "contacts + prestep", summed over the step's rc_physics calls
 struct RcStepRet {
   uint64_t occ;
   int err;
@@ -1064,7 +1065,7 @@ DE_DEV RcStepRet rc_physics_inl(RcCtx c, int lane, int cand, uint64_t pairLo, ui
   int err = 0;
   bool biasLane = false;
   const bool anyContactWork = G::ballot(cand != 0) != 0ull || occ != 0ull;
-RC_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
+RC_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime(); unsigned long long C0 = T0, C1 = T0, C2 = T0, C3 = T0, C4 = T0;)
   // --- contact detection / cache -------------------------------------------------------------------------
   bool touched = false, slotOcc = false, freeMe = false, active = false;
   int bodyA = 0, bodyB = 0, a_pair = 0xFFFF, a_state = ARB_FIRST_, a_count = 0, a_age = 0, rank = 0, nTouched = 0;
@@ -1082,13 +1083,13 @@ RC_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
     // is not live yet: every lane takes its entries into registers before the mailbox flags are cleared.
     unsigned short* cl = L.candList;
     int nCand = 0;
-#pragma unroll 1
+    // (straight-line over the five rounds: five ballots, v_mbcnt, masked stores - no loop-carried wait, no branch per round)
+#pragma unroll
     for (int t = 0; t < NROUNDS; ++t) {
       const bool cbit = (cand >> t) & 1;
       const uint64_t m = G::ballot(cbit);
-      if (m == 0ull) continue;
       if (cbit) {
-        const int idx = nCand + __popcll(m & G::lt_mask());
+        const int idx = nCand + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
         if (idx < 128) cl[idx] = (unsigned short)RC_MY_PAIR(t); else err |= 1;  // overflow is reported through RE_ERR
       }
       nCand += __popcll(m);
@@ -1096,6 +1097,7 @@ RC_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
     if (nCand > 128) nCand = 128;
     if (lane < RC_NS) M.flag[lane] = 0;
     __syncthreads();
+RC_PROF(C0 = __builtin_amdgcn_s_memtime();)
 #pragma unroll 1
     for (int pass = 0; pass * W < nCand; ++pass) {
       const int pr = pass * W + lane < nCand ? (int)cl[pass * W + lane] : 0xFFFF;
@@ -1141,6 +1143,7 @@ RC_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
       __syncthreads();
     }
     __syncthreads();
+RC_PROF(C1 = __builtin_amdgcn_s_memtime();)
     // slot lanes: load the cached arbiter, match hashes (cpArbiterUpdate without the r1/r2 part, see below)
     slotOcc = lane < RC_NS && ((occ >> lane) & 1ull);
     int cnt = 0;
@@ -1173,6 +1176,7 @@ RC_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
         a_age = 0;
       }
     }
+RC_PROF(C2 = __builtin_amdgcn_s_memtime();)
     touchedMask = G::ballot(touched);
     nTouched = __popcll(touchedMask);
     for (uint64_t mm = touchedMask; mm; mm &= mm - 1) {
@@ -1182,10 +1186,13 @@ RC_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
     }
     // canonical order: r1/r2 relative to the bodies' CURRENT positions (an earlier begin callback may have teleported
     // a robot: ballCollision -> penalize), then the begin callback of first contacts (scalar, lane 0)
-    for (int k = 0; k < nTouched; ++k) {
+    // (no first contact among the touched arbiters - the usual case - means no begin callback, nothing moves a body in between,
+    //  and every touched lane takes its r1 / r2 at once instead of one lane after the other with an LDS round trip each)
+    const bool anyFirst = G::ballot(touched && a_state == ARB_FIRST_) != 0ull;
+    for (int k = 0; k < (anyFirst ? nTouched : (nTouched ? 1 : 0)); ++k) {
       const uint64_t who = G::ballot(touched && rank == k);
       const int b = __builtin_ctzll(who);
-      if (lane == b) {
+      if (anyFirst ? lane == b : touched) {
         const V2 pa = bodyA <= RC_BALL ? v2(L.px[bodyA], L.py[bodyA]) : post_pos(bodyA);
         const V2 pb = bodyB <= RC_BALL ? v2(L.px[bodyB], L.py[bodyB]) : post_pos(bodyB);
         r1[0] = vsub(v2(M.p1x[lane][0], M.p1y[lane][0]), pa);
@@ -1195,6 +1202,7 @@ RC_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
           r2[1] = vsub(v2(M.p2x[lane][1], M.p2y[lane][1]), pb);
         }
       }
+      if (!anyFirst) break;
       const int st = G::bcast_i(a_state, b);
       if (st != ARB_FIRST_) continue;
       const int pk = G::bcast_i(a_pair, b);
@@ -1227,6 +1235,7 @@ RC_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
       }
       if (sepMe) a_state = ARB_CACHED_;
     }
+RC_PROF(C3 = __builtin_amdgcn_s_memtime();)
     // levels of the active arbiters
     active = touched && a_state != ARB_IGNORE_;
     activeMask = G::ballot(active);
@@ -1243,6 +1252,7 @@ RC_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
       if (lane == ba || lane == bb2) blvl = lv + 1;
       maxLevel = lv > maxLevel ? lv : maxLevel;
     }
+RC_PROF(C4 = __builtin_amdgcn_s_memtime();)
     // arbiter prestep
     if (active) {
       RBody a, b;
@@ -1477,7 +1487,8 @@ RC_PROF(const unsigned long long T5 = __builtin_amdgcn_s_memtime();)
     occ &= ~G::ballot(freeMe);
   }
   __syncthreads();
-RC_PROF(if (lane == 0 && c.genv < 4096u) { unsigned long long* d = g_rcprof + c.genv * 12;  /* (profile runs: env_id_offset 0) */ const unsigned long long T6 = __builtin_amdgcn_s_memtime(); d[3] += T1 - T0; d[4] += T2 - T1; d[5] += T3 - T2; d[6] += T4 - T3; d[7] += T5 - T4; d[8] += T6 - T5; d[9] += (unsigned long long)nTouched; d[10] += (unsigned long long)(maxLevel + 1); })
+RC_PROF(if (lane == 0 && c.genv < 4096u) { unsigned long long* d = g_rcprof + c.genv * 12;  /* (profile runs: env_id_offset 0) */ const unsigned long long T6 = __builtin_amdgcn_s_memtime(); d[3] += T1 - T0; d[4] += T2 - T1; d[5] += T3 - T2; d[6] += T4 - T3; d[7] += T5 - T4; d[8] += T6 - T5; d[9] += (unsigned long long)nTouched; d[10] += (unsigned long long)(maxLevel + 1);
+  if (anyContactWork) { unsigned long long* q = g_rcprof2 + c.genv * 8; q[0] += C0 - T0; q[1] += C1 - C0; q[2] += C2 - C1; q[3] += C3 - C2; q[4] += C4 - C3; q[5] += T1 - C4; q[6] += 1ull; } })
   RcStepRet ret;
   ret.occ = occ; ret.err = err;
   return ret;
@@ -1771,6 +1782,7 @@ DE_DEV void rc_step_body(const RcState& S, const int e, const int* __restrict__ 
   const double* myHead = headActions ? headActions + (size_t)e * R : nullptr;
   int snap = 0, nGeneral = 0;  // substeps that went through rc_physics
 
+RC_PROF(if (lane < 8 && e < 4096) g_rcprof2[e * 8 + lane] = 0ull;)
 RC_PROF(if (lane < 12 && e < 4096) g_rcprof[e * 12 + lane] = 0ull; const unsigned long long K0 = __builtin_amdgcn_s_memtime(); unsigned long long tG = 0, tP = 0, tB = 0;)
   for (int it = 0; it < 50; ++it) {
     lane = fresh_lane();  // per substep: nothing derived from the lane id is hoisted out of the loop, and the id itself is not kept across the calls

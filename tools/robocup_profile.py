@@ -31,3 +31,6 @@ for k, n in enumerate(names):
 top = np.argsort(-d[:, 11])[:12]
 print("slowest environments: " + " | ".join(names))
 for k in top: print("  ", " ".join("%8d" % v for v in d[k]))
+q = np.loadtxt("gpurun_out/rcprof2.txt")[:NE]
+print("contacts + prestep of the slowest environments, cycles per step: candidate list | narrowphase passes | slot record | callbacks, expiry | levels | prestep + bias-lane share | rc_physics calls with contact work")
+for k in top: print("  ", " ".join("%8d" % v for v in q[k, :7]))
