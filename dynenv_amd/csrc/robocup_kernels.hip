@@ -340,10 +340,9 @@ DE_DEV void rc_process_action(const RcCtx& c, RcLds& L, int r, const int* action
   }
 }
 
-// NOEV: the caller has established !rc_tick_has_event(L, r) on the state before the tick.  The branches that only an event
-// reaches (kick end, getting up, end of a penalty, the defender set, leaving the field - everything that calls rc_fall /
-// rc_penalize or touches shared state) are then dead and compiled out: the lane-parallel tick contains no call.
-template <int EPW, bool NOEV = false>
+// The reference's tick, every branch: used by the sequential form (rc_game_serial).  The common substep runs the event-free
+// subset one robot per lane on registers (rc_game_logic_batched below).
+template <int EPW>
 DE_DEV void rc_tick(const RcCtx& c, RcLds& L, int r) {  // :862-1007
   const double time = RC_TIME;
   if (L.moveT[r] > 0.0) {
@@ -357,16 +356,16 @@ DE_DEV void rc_tick(const RcCtx& c, RcLds& L, int r) {  // :862-1007
       const int fb = 2 * r + ((f & RF_FOOT) ? 1 : 0);
       const double mt = L.moveT[r];
       if (mt + time > 500.0 && mt <= 500.0) {
-        if (!NOEV && !(f & RF_JREM)) { con_remove(L, 2 * r); f |= RF_JREM; }
-        const DevSC sc = NOEV ? RC_COMMON_SINCOS(L.ang[fb]) : dev_sincos(L.ang[fb]);
+        if (!(f & RF_JREM)) { con_remove(L, 2 * r); f |= RF_JREM; }
+        const DevSC sc = dev_sincos(L.ang[fb]);
         const double vxl = ROBOT_VELOCITY * 3.0;
         L.vx[fb] = vxl * sc.c - 0.0 * sc.s; L.vy[fb] = vxl * sc.s + 0.0 * sc.c;
       }
       if (mt + time > 400.0 && mt <= 400.0) {
-        const DevSC sc = NOEV ? RC_COMMON_SINCOS(L.ang[fb]) : dev_sincos(L.ang[fb]);
+        const DevSC sc = dev_sincos(L.ang[fb]);
         const double vxl = ROBOT_VELOCITY * 2.5;
         L.vx[fb] = -(vxl * sc.c - 0.0 * sc.s); L.vy[fb] = -(vxl * sc.s + 0.0 * sc.c);
-      } else if (!NOEV && mt <= 300.0) {
+      } else if (mt <= 300.0) {
         L.vx[fb] = 0.0; L.vy[fb] = 0.0;
         f &= ~RF_KICK;
         L.px[fb] = L.initx[r]; L.py[fb] = L.inity[r];
@@ -382,7 +381,7 @@ DE_DEV void rc_tick(const RcCtx& c, RcLds& L, int r) {  // :862-1007
   }
   if (L.rflags[r] & RF_FALLEN) {
     L.fallT[r] -= time;
-    if (!NOEV && L.fallT[r] < 0.0) {
+    if (L.fallT[r] < 0.0) {
       const dm_u32x4 u = rc_rng(c, L, (uint32_t)r | (1u << 8));
       const double rr = dm_unit(u.v[0]);
       if (rr > 0.9 && !(L.rflags[r] & RF_PENAL) && c.canFall) { rc_fall<EPW>(c, r, 0); return; }
@@ -392,7 +391,7 @@ DE_DEV void rc_tick(const RcCtx& c, RcLds& L, int r) {  // :862-1007
   }
   if (L.rflags[r] & RF_PENAL) {
     L.penalT[r] -= time;
-    if (!NOEV && L.penalT[r] <= 0.0) {
+    if (L.penalT[r] <= 0.0) {
       L.penalT[r] = 0.0;
       L.rflags[r] &= ~(RF_PENAL | RF_FALLEN);
       L.fallc[r] = 0;
@@ -400,7 +399,7 @@ DE_DEV void rc_tick(const RcCtx& c, RcLds& L, int r) {  // :862-1007
       free_penalty_spot(c, L, r, p, angle);
       for (int k = 0; k < 2; ++k) { L.px[2 * r + k] = p.x; L.py[2 * r + k] = p.y; set_body_angle(L, 2 * r + k, angle); }
     }
-  } else if (!NOEV) {  // (no event: in the penalty area exactly if already a defender - nothing to do)
+  } else {
     const int teamIdx = robot_team(L, r) > 0 ? 0 : 1;
     const V2 p = robot_pos(L, r);
     const double robX = teamIdx ? RC_W - p.x : p.x;
@@ -417,7 +416,7 @@ DE_DEV void rc_tick(const RcCtx& c, RcLds& L, int r) {  // :862-1007
     }
   }
   const V2 pos = robot_pos(L, r);
-  if (!NOEV && (pos.y < 0.0 || pos.x < 0.0 || pos.y > RC_H || pos.x > RC_W)) rc_penalize<EPW>(c, r);
+  if (pos.y < 0.0 || pos.x < 0.0 || pos.y > RC_H || pos.x > RC_W) rc_penalize<EPW>(c, r);
   if (pos.x != L.prevx[r] || pos.y != L.prevy[r]) {
     if ((r == L.envi[RE_CLOSE0] || r == L.envi[RE_CLOSE1]) && !(L.rflags[r] & RF_PENAL)) {
       const V2 ballPos = v2(L.px[RC_BALL], L.py[RC_BALL]);
@@ -429,40 +428,120 @@ DE_DEV void rc_tick(const RcCtx& c, RcLds& L, int r) {  // :862-1007
   }
 }
 
-DE_DEV void ball_free_kick_process(RcLds& L, int team) {  // :600-619
-  if (team == 0) {
-    if (L.envd[RD_GRACE] > 0.0) {
-      L.envd[RD_GRACE] -= RC_TIME;
-      if (L.envd[RD_GRACE] < 0.0) { L.envd[RD_GRACE] = 0.0; L.envd[RD_FREECNT] = 9999.0; }
-    } else if (L.envd[RD_FREECNT] > 0.0) {
-      L.envd[RD_FREECNT] -= RC_TIME;
-      if (L.envd[RD_FREECNT] < 0.0) { L.envd[RD_FREECNT] = 0.0; L.envi[RE_OWNED] = 0; }
-    }
-  } else {
-    L.envi[RE_OWNED] = team;
-    L.envd[RD_GRACE] = 14999.0;
-    L.envd[RD_FREECNT] = 0.0;
-  }
-}
-
-// isBallOutOfField :622-732, by the whole wave: the scalar decisions are computed redundantly (uniform) by every lane and
-// written by lane 0; the per-robot reward terms run one robot per lane; the two "closest robot" searches replay the
-// reference's ascending strict-< loop over the per-lane distances.
+// ------------------------------------------------------------------------------------------------
+// The lane-parallel game logic of the common substep on REGISTERS: one batch of LDS loads, then
+//   (1) would robot r's tick touch anything another robot's tick reads or writes?  Events: the kick taking the pivot joint out of
+//       / back into the constraint list (and the foot snapping back), a getting-up roll, the end of a penalty, entering or leaving
+//       the defender set, leaving the field.  Conservative; evaluated without side effects from the state before the tick.  With
+//       an event in any lane the function returns false with NOTHING stored and the kernel runs the sequential form (rc_game_serial).
+//   (2) the event-free tick (rc_tick with the branches only an event reaches removed), one robot per lane: without an event a tick
+//       reads shared state only and writes its own robot's fields, so the ticks of all robots commute;
+//   (3) isBallOutOfField + ballFreeKickProcess (:600-732) by the whole wave: the scalar decisions are computed redundantly by every
+//       lane and written by lane 0, the per-robot reward terms run one robot per lane, the two "closest robot" searches replay the
+//       reference's ascending strict-< loop over the per-lane distances.
+// On loaded values because a lone wave cannot hide an LDS round trip (~110 cycles): the plain form made some forty of them per
+// substep, one after the other.
+// ------------------------------------------------------------------------------------------------
 template <int EPW>
-DE_DEV void rc_ball_logic(const RcCtx& c, RcLds& L, int lane) {
+DE_DEV bool rc_game_logic_batched(const RcCtx& c, RcLds& L, int lane, bool withTick) {
+  const int R = c.R, n = c.n;
+  const bool isRobot = lane < R;
+  const int r = isRobot ? lane : 0;
+  const double time = RC_TIME;
+  // ---- loads ----
+  double moveT = L.moveT[r], headmov = L.headmov[r], head = L.head[r], fallT = L.fallT[r], penalT = L.penalT[r];
+  const int f = L.rflags[r];
+  const double pxa = L.px[2 * r], pxb = L.px[2 * r + 1], pya = L.py[2 * r], pyb = L.py[2 * r + 1];
+  double prevx = L.prevx[r], prevy = L.prevy[r];
+  double rrew = L.rrew[r], rposrew = L.rposrew[r];
+  const int close0 = L.envi[RE_CLOSE0], close1 = L.envi[RE_CLOSE1], def0 = L.envi[RE_DEF0], def1 = L.envi[RE_DEF1];
+  const int nlk = L.envi[RE_NLK], lk0 = L.envi[RE_LK0], lk1 = L.envi[RE_LK0 + 1], lk2 = L.envi[RE_LK0 + 2], lk3 = L.envi[RE_LK0 + 3];
+  const V2 bpos = v2(L.px[RC_BALL], L.py[RC_BALL]);
+  const double bprevx = L.envd[RD_BPREVX];
+  // (lane 0's end-of-logic updates read these)
+  double grace = L.envd[RD_GRACE], freecnt = L.envd[RD_FREECNT];
+  int owned = L.envi[RE_OWNED];
+  const int g_goal0 = L.envi[RE_GOAL0], g_goal1 = L.envi[RE_GOAL1];
+  const double g_tr0 = L.teamRew[0], g_tr1 = L.teamRew[1];
+  const V2 rpos = v2((pxa + pxb) / 2.0, (pya + pyb) / 2.0);  // Robot.getPos (robot_pos)
+  if (withTick) {
+    // ---- (1) events ----
+    bool ev = false;
+    if (isRobot) {
+      if (moveT > 0.0 && (f & RF_KICK)) {
+        const double mt = moveT - time;
+        if ((mt + time > 500.0 && mt <= 500.0 && !(f & RF_JREM)) || mt <= 300.0) ev = true;
+      }
+      if ((f & RF_FALLEN) && fallT - time < 0.0) ev = true;
+      if (f & RF_PENAL) {
+        if (penalT - time <= 0.0) ev = true;
+      } else {
+        const int teamIdx = (f & RF_TEAMPOS) ? 0 : 1;
+        const double robX = teamIdx ? RC_W - rpos.x : rpos.x;
+        const double penX = RC_SIDE + 60.0 + 5.0 / 2.0;
+        const bool isDef = ((teamIdx ? def1 : def0) & (1 << r)) != 0;
+        const bool inArea = robX < penX && rpos.y > (RC_H / 2.0 - 110.0) && rpos.y < (RC_H / 2.0 + 110.0);
+        if (inArea != isDef) ev = true;
+      }
+      if (rpos.y < 0.0 || rpos.x < 0.0 || rpos.y > RC_H || rpos.x > RC_W) ev = true;
+    }
+    if (Grp<EPW>::ballot(ev) != 0ull) return false;
+    // ---- (2) the event-free tick (:862-1007) ----
+    if (isRobot) {
+      if (moveT > 0.0) {
+        moveT -= time;
+        if (headmov != 0.0) {
+          const double h = head + headmov;
+          head = dm_max(-ROBOT_HEAD_MAX, dm_min(ROBOT_HEAD_MAX, h));
+          L.head[r] = head;
+        }
+        if (f & RF_KICK) {
+          const int fb = 2 * r + ((f & RF_FOOT) ? 1 : 0);
+          const double mt = moveT;
+          if (mt + time > 500.0 && mt <= 500.0) {
+            const DevSC sc = RC_COMMON_SINCOS(L.ang[fb]);
+            const double vxl = ROBOT_VELOCITY * 3.0;
+            L.vx[fb] = vxl * sc.c - 0.0 * sc.s; L.vy[fb] = vxl * sc.s + 0.0 * sc.c;
+          }
+          if (mt + time > 400.0 && mt <= 400.0) {
+            const DevSC sc = RC_COMMON_SINCOS(L.ang[fb]);
+            const double vxl = ROBOT_VELOCITY * 2.5;
+            L.vx[fb] = -(vxl * sc.c - 0.0 * sc.s); L.vy[fb] = -(vxl * sc.s + 0.0 * sc.c);
+          }
+        }
+        if (moveT <= 0.0) {
+          moveT = 0.0;
+          L.headmov[r] = 0.0;
+          L.vx[2 * r] = 0.0; L.vy[2 * r] = 0.0; L.w[2 * r] = 0.0;
+          L.vx[2 * r + 1] = 0.0; L.vy[2 * r + 1] = 0.0; L.w[2 * r + 1] = 0.0;
+        }
+        L.moveT[r] = moveT;
+      }
+      if (f & RF_FALLEN) L.fallT[r] = fallT - time;
+      if (f & RF_PENAL) L.penalT[r] = penalT - time;
+      if (rpos.x != prevx || rpos.y != prevy) {
+        if ((r == close0 || r == close1) && !(f & RF_PENAL)) {
+          const double diff = vlen(vsub(rpos, bpos)) - vlen(vsub(v2(prevx, prevy), bpos));
+          rrew -= diff * 0.05;
+          rposrew += dm_max(0.0, -diff * 0.05);
+        }
+        prevx = rpos.x; prevy = rpos.y;
+        L.prevx[r] = prevx; L.prevy[r] = prevy;
+      }
+    }
+  }
+  // ---- (3) the ball (:622-732) ----
   bool finished = false, moved = false;
   int team = 0;
-  const int n = c.n;
-  const V2 pos = v2(L.px[RC_BALL], L.py[RC_BALL]);
+  const V2 pos = bpos;
   double cr0 = 0.0, cr1 = 0.0;
   double x = pos.x, y = pos.y;
   int goal0 = 0, goal1 = 0;
   const double outMin = RC_SIDE - 5.0, outMaxX = RC_W - RC_SIDE + 5.0, outMaxY = RC_H - RC_SIDE + 5.0;
-  const int nlk = L.envi[RE_NLK];
   if (pos.y < outMin || pos.x < outMin || pos.y > outMaxY || pos.x > outMaxX) {
     moved = true;
     x = RC_W / 2.0; y = RC_H / 2.0;
-    team = nlk ? robot_team(L, L.envi[RE_LK0]) : 1;
+    team = nlk ? robot_team(L, lk0) : 1;
     if (pos.y < outMin || pos.y > outMaxY) {
       x = team < 0 ? pos.x + 50.0 : pos.x - 50.0;
       y = pos.y < outMin ? outMin + 5.0 : outMaxY - 5.0;
@@ -483,35 +562,34 @@ DE_DEV void rc_ball_logic(const RcCtx& c, RcLds& L, int lane) {
     }
   }
   if (!finished) {
-    const double dx = x - L.envd[RD_BPREVX];
+    const double dx = x - bprevx;
     const double d = dx == 0.0 ? dx : dx / 20.0;  // +-0 / 20 is that same zero: a resting ball skips the division
     cr0 += d;
     cr1 -= d;
   }
-  // per-robot terms (one robot per lane); a robot is either in lastKicked (discounted share) or not (penalty share).
-  // With both team terms zero every per-robot term is +-0, and adding +-0 cannot change rrew / rposrew: they start each
-  // step as +0 and are only ever updated by += / -=, which never yields -0 from a non-(-0) accumulator.
   bool inLk = false;
   const bool anyTeamTerm = !(cr0 == 0.0 && cr1 == 0.0);
-  if (anyTeamTerm && lane < c.R) {
+  if (anyTeamTerm && isRobot) {
     double disc = 1.0;
     for (int i = 0; i < nlk; ++i) {
-      if (L.envi[RE_LK0 + i] == lane) {
+      const int lki = i == 0 ? lk0 : i == 1 ? lk1 : i == 2 ? lk2 : lk3;
+      if (lki == lane) {
         inLk = true;
         const double rew = (lane < n ? cr0 : cr1) * disc;
-        L.rrew[lane] += rew;
-        L.rposrew[lane] += dm_max(0.0, rew);
+        rrew += rew;
+        rposrew += dm_max(0.0, rew);
       }
       disc *= 0.5;
     }
-    const bool cond1 = (lane == L.envi[RE_CLOSE0] || lane == L.envi[RE_CLOSE1]);
-    const bool cond2 = vlen(vsub(robot_pos(L, lane), pos)) < 150.0;
-    if ((cond1 || cond2) && !inLk) L.rrew[lane] += dm_min(0.0, (lane < n ? cr0 : cr1) * 0.5);
+    const bool cond1 = (lane == close0 || lane == close1);
+    const bool cond2 = vlen(vsub(rpos, pos)) < 150.0;
+    if ((cond1 || cond2) && !inLk) rrew += dm_min(0.0, (lane < n ? cr0 : cr1) * 0.5);
   }
+  if (isRobot) { L.rrew[r] = rrew; L.rposrew[r] = rposrew; }
   // closest robot of each team to the (possibly reset) ball
   double q = INFINITY;
-  if (lane < c.R) {
-    const V2 d = vsub(v2(x, y), robot_pos(L, lane));
+  if (isRobot) {
+    const V2 d = vsub(v2(x, y), rpos);
     q = d.x * d.x + d.y * d.y;
   }
   int best0 = 0, best1 = 0;
@@ -527,45 +605,29 @@ DE_DEV void rc_ball_logic(const RcCtx& c, RcLds& L, int lane) {
   __syncthreads();  // every lane has read the shared scalars it needs
   if (lane == 0) {
     if (moved) { L.px[RC_BALL] = x; L.py[RC_BALL] = y; L.vx[RC_BALL] = 0.0; L.vy[RC_BALL] = 0.0; L.w[RC_BALL] = 0.0; }
-    L.envi[RE_GOAL0] += goal0; L.envi[RE_GOAL1] += goal1;
-    ball_free_kick_process(L, -team);
+    L.envi[RE_GOAL0] = g_goal0 + goal0; L.envi[RE_GOAL1] = g_goal1 + goal1;
+    {  // ballFreeKickProcess(-team) :600-619
+      const int tm = -team;
+      if (tm == 0) {
+        if (grace > 0.0) {
+          grace -= RC_TIME;
+          if (grace < 0.0) { grace = 0.0; freecnt = 9999.0; }
+        } else if (freecnt > 0.0) {
+          freecnt -= RC_TIME;
+          if (freecnt < 0.0) { freecnt = 0.0; owned = 0; }
+        }
+      } else {
+        owned = tm; grace = 14999.0; freecnt = 0.0;
+      }
+      L.envd[RD_GRACE] = grace; L.envd[RD_FREECNT] = freecnt; L.envi[RE_OWNED] = owned;
+    }
     L.envd[RD_BPREVX] = x; L.envd[RD_BPREVY] = y;
-    L.teamRew[0] += cr0 * 0.1;
-    L.teamRew[1] += cr1 * 0.1;
+    L.teamRew[0] = g_tr0 + cr0 * 0.1;
+    L.teamRew[1] = g_tr1 + cr1 * 0.1;
     L.envi[RE_CLOSE0] = best0;
     L.envi[RE_CLOSE1] = n + best1;
   }
-}
-
-// Would robot r's tick touch anything another robot's tick reads or writes?  Events: the kick taking the pivot joint out
-// of / back into the constraint list (and the foot snapping back), a getting-up roll, the end of a penalty, entering or
-// leaving the defender set, leaving the field.  Conservative (may report an event where rc_tick finds none); evaluated
-// without side effects from the state before the tick.  Without an event rc_tick(r) reads shared state only and writes
-// robot r's own fields, so the ticks of all robots commute and run one per lane.
-DE_DEV bool rc_tick_has_event(const RcLds& L, int r) {
-  const double time = RC_TIME;
-  const int f = L.rflags[r];
-  bool ev = false;
-  const double moveT = L.moveT[r];
-  if (moveT > 0.0 && (f & RF_KICK)) {
-    const double mt = moveT - time;
-    if ((mt + time > 500.0 && mt <= 500.0 && !(f & RF_JREM)) || mt <= 300.0) ev = true;
-  }
-  if ((f & RF_FALLEN) && L.fallT[r] - time < 0.0) ev = true;
-  if (f & RF_PENAL) {
-    if (L.penalT[r] - time <= 0.0) ev = true;
-  } else {
-    const int teamIdx = (f & RF_TEAMPOS) ? 0 : 1;
-    const V2 p = robot_pos(L, r);
-    const double robX = teamIdx ? RC_W - p.x : p.x;
-    const double penX = RC_SIDE + 60.0 + 5.0 / 2.0;
-    const bool isDef = (L.envi[RE_DEF0 + teamIdx] & (1 << r)) != 0;
-    const bool inArea = robX < penX && p.y > (RC_H / 2.0 - 110.0) && p.y < (RC_H / 2.0 + 110.0);
-    if (inArea != isDef) ev = true;
-  }
-  const V2 pos = robot_pos(L, r);
-  if (pos.y < 0.0 || pos.x < 0.0 || pos.y > RC_H || pos.x > RC_W) ev = true;
-  return ev;
+  return true;
 }
 
 // the per-substep game logic: for robot in agents: [processAction]; tick; then the ball.  Called by the whole wave.
@@ -583,28 +645,6 @@ DE_OOL void rc_game_serial(RcCtx c_, int it, const int* __restrict__ actions, co
     rc_tick<EPW>(c, L, r);
   }
 }
-// RC_INVERT: the kernel has already decided `serial` and, if so, run rc_game_serial (the only call of the game logic)
-template <int EPW>
-DE_DEV void rc_game_logic_rest(RcCtx c, bool serial, int lane) {
-  RcLds& L = Grp<EPW>::tile();
-  if (!serial && lane < c.R) rc_tick<EPW, true>(c, L, lane);
-  __syncthreads();
-  rc_ball_logic<EPW>(c, L, lane);
-}
-template <int EPW>
-__device__ RC_LOGIC_INLINE void rc_game_logic(RcCtx c, int it, const int* __restrict__ actions, const double* __restrict__ headAct, int lane) {
-  RcLds& L = Grp<EPW>::tile();
-  bool serial = it == 0;  // processAction draws the fall dice and may knock other robots over: keep the reference order
-  if (!serial) serial = Grp<EPW>::ballot(lane < c.R && rc_tick_has_event(L, lane)) != 0ull;
-  if (!serial) {
-    if (lane < c.R) rc_tick<EPW, true>(c, L, lane);
-  } else if (lane == 0) {
-    rc_game_serial<EPW>(c, it, actions, headAct);
-  }
-  __syncthreads();
-  rc_ball_logic<EPW>(c, L, lane);
-}
-
 // ------------------------------------------------------------------------------------------------
 // collision callbacks (lane 0), RoboCupEnvironment.py:1010-1146
 // ------------------------------------------------------------------------------------------------
@@ -1662,7 +1702,7 @@ DE_OOL RcCommonRet rc_common_substep(RcCtx c_, int serial_, int lane, const uint
   typedef Grp<EPW> G;
   constexpr int W = G::W, NROUNDS = (RC_NPAIR_ROUNDS * 64) / W;
   RcLds& L = G::tile();
-  const bool serial = G::uniform_i(serial_) != 0;
+  const bool serial = G::uniform_i(serial_) != 0;  // the sequential game logic has run already: no tick here
   const int R = c.R;
   const uint64_t occ = G::uniform_u64(occ_);
   const bool isBody = lane == RC_BALL || lane < 2 * R;
@@ -1672,8 +1712,12 @@ DE_OOL RcCommonRet rc_common_substep(RcCtx c_, int serial_, int lane, const uint
   const uint64_t pairLo = pairTab[2 * lane], pairHiFeet = pairTab[2 * lane + 1];
   const uint64_t pairHi = pairHiFeet & 0xFFFFull, pairTop = 0ull;
   const int feetPairs = (int)(pairHiFeet >> 32);  // bit t: my pair of round t is the two feet of one robot
-    // ---- sequential game logic (lane 0): processAction / tick per robot, then the ball (:465-475) ----------
-    rc_game_logic_rest<EPW>(c, serial, lane);
+    // ---- game logic: tick per robot (one robot per lane, unless the sequential form has run), then the ball (:465-475) ----
+    if (!rc_game_logic_batched<EPW>(c, L, lane, !serial)) {
+      RcCommonRet ret;  // a robot's tick has a cross-robot event: nothing has been changed, the kernel runs the sequential form
+      ret.pairLo = 0ull; ret.pairHi = 0ull; ret.cand = 0; ret.bits = 4;
+      return ret;
+    }
     __syncthreads();
     // ---- cpBodyUpdatePosition + shape cache + AABB ------------------------------------------------------
     if (isBody) {
@@ -1789,13 +1833,21 @@ RC_PROF(if (lane < 12 && e < 4096) g_rcprof[e * 12 + lane] = 0ull; const unsigne
 RC_PROF(const unsigned long long A0 = __builtin_amdgcn_s_memtime();)
     // the game logic's sequential form (first substep: processAction; later: a cross-robot event) is the only call of the common
     // part: it is made from here, the outermost frame, so that rc_common_substep itself contains no call at all
+    // (the first substep is always sequential: processAction; later ones when the common part's lane-parallel tick reports an
+    //  event - it then returns without having changed anything and is called again after the sequential form)
     bool serial = it == 0;
-    if (!serial) serial = G::ballot(lane < R && rc_tick_has_event(L, lane)) != 0ull;
     if (serial) {
       if (lane == 0) rc_game_serial<EPW>(c, it, myActions, myHead);
 RC_PROF(tG += 1;)  // (profile build: "game logic" = substeps with the sequential form, "position" = cycles of the whole common part)
     }
-    const RcCommonRet cr = rc_common_substep<EPW>(c, serial ? 1 : 0, lane, S.pairTab, occ);
+    RcCommonRet cr = rc_common_substep<EPW>(c, serial ? 1 : 0, lane, S.pairTab, occ);
+    if (G::uniform_i(cr.bits & 4) != 0) {
+      lane = fresh_lane();
+      if (lane == 0) rc_game_serial<EPW>(c, it, myActions, myHead);
+RC_PROF(tG += 1;)
+      lane = fresh_lane();
+      cr = rc_common_substep<EPW>(c, 1, lane, S.pairTab, occ);
+    }
     const int cand = cr.cand;
     const bool quiet = G::uniform_i(cr.bits & 1) != 0;
 RC_PROF(tP += __builtin_amdgcn_s_memtime() - A0;)
