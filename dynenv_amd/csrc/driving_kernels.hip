@@ -668,9 +668,9 @@ DE_DEV bool cb_begin(DrvLds& L, int i, int j, int lane) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// contact path of one substep, OUT OF LINE on purpose: narrowphase + contact cache + callbacks + solver need far
-// more registers than the common no-contact path; as a separate function its spills and saves are only paid
-// when something actually touches.  Operates on the LDS tile; returns the few scalars it changes.
+// The contact path of one substep (drv_contact_path below): narrowphase -> contact cache -> callbacks -> prestep, velocity
+// update and solve (drv_prestep_solve, out of line; the sweeps of a general multi-level solve in drv_solve_general_split).
+// Operates on the LDS tile; returns the few scalars it changes.  First the solver's building blocks.
 // ------------------------------------------------------------------------------------------------
 // cpArbiterApplyCachedImpulse for the (up to two) contacts of one arbiter
 DE_DEV void arb_warm_start(BodyV& a, BodyV& b, V2 n, const V2* r1, const V2* r2, const double* jn, const double* jt,
@@ -865,10 +865,10 @@ DRV_PROF(__device__ unsigned long long g_dbgp[4096 * 8];)
 DRV_PROF(__device__ unsigned long long g_dbgr[16];)
 DRV_PROF(__device__ unsigned long long g_dbgl[4096 * 8];)  // stages of drv_light_substep, summed over the step's substeps
 DRV_PROF(DE_DEV int prof_any(int v) { const uint64_t m = wave_ballot(v != 0); return m ? bcast_i(v, __builtin_ctzll(m)) : 0; })
-// Which half of a substep is out of line.  DRV_INVERT = 1 (default): the COMMON part (game logic, position update, broadphase:
-// drv_light_substep, 88 VGPRs, nothing to save) is the function and the contact path is inlined into the kernel, which as the
-// outermost frame never saves a register: the per-call save / restore of 47 callee-saved VGPRs that the round-1 layout
-// (DRV_INVERT = 0: contact path out of line) paid - 3/4 of that kernel's HBM traffic - is gone (236 -> 76 MB per launch).
+// Which half of a substep is out of line: the COMMON part (game logic, position update, broadphase: drv_light_substep, a leaf
+// with nothing to save) is a function; the contact path is inlined into the kernel, which as the outermost frame never saves a
+// register (round 1 had it the other way round and paid the save / restore of 47 callee-saved VGPRs per call: 3/4 of that
+// kernel's HBM traffic).  Its solver is a function again (drv_prestep_solve), entered with nothing of the contact cache live.
 #ifndef DRV_CONTACT_INLINE
 #define DRV_CONTACT_INLINE __forceinline__
 #endif
@@ -1681,7 +1681,7 @@ DRV_PROF(const unsigned long long A2 = __builtin_amdgcn_s_memtime(); bool tookCo
       if (anyCand == 0ull && occ == 0ull) steadyAll = false;
       vbValid = false;  // nothing was solved: the next position update sees zero bias velocities
     } else if (!replay) {
-      // ---------- contact path (out of line): narrowphase -> contact cache -> callbacks -> prestep -> friction -> solver
+      // ---------- contact path: narrowphase -> contact cache -> callbacks -> prestep -> friction -> solver
 DRV_PROF(tookContact = true;)
       __builtin_amdgcn_s_setprio(3);  // an environment on the contact path is on the launch's critical path: issue it first
       ContactRet cr = drv_contact_path(lane, cand, dirty, light ? 1 : 0, A, A | (nPed << 8), occ);
