@@ -9,19 +9,17 @@
 
 __constant__ RcConst RC;
 
-// The two per-substep stages are out-of-line functions.  Measured on MI355X (4096 envs, round 1): both out of line 3.93 ms/step,
-// physics inlined 4.29, both inlined 4.45 -> out of line wins (smaller live ranges beat the call overhead)
-#ifndef RC_LOGIC_INLINE
-#define RC_LOGIC_INLINE __forceinline__
-#endif
+// The per-substep stages are out-of-line functions (DE_OOL: no callee-saved registers, dev_common.h).  Measured on MI355X (4096
+// envs, round 1): both out of line 3.93 ms/step, physics inlined 4.29, both inlined 4.45 -> out of line wins (smaller live ranges
+// beat the call overhead)
 #ifndef RC_WAVES_PER_SIMD
 #define RC_WAVES_PER_SIMD 4
 #endif
 // The COMMON part of a substep (game logic, position update, broadphase,
 // the quiet substep's joints) is an out-of-line function of its own, rc_common_substep - 102 VGPRs, no call inside, nothing
 // saved, nothing spilled - instead of living inline in a kernel whose register allocation it shared with everything else
-// (87 spilled VGPRs, ~50 scratch instructions per substep and wave: 2.1 GB of HBM traffic per launch, now 0.6 GB, all of it
-// the general path's).  The one call the common part could make (the sequential game logic) is made by the kernel.
+// (round 1: 87 spilled VGPRs, ~50 scratch instructions per substep and wave, 2.1 GB of HBM traffic per launch; 0.11 GB now).
+// The one call the common part could make (the sequential game logic) is made by the kernel.
 #define RC_COMMON_SINCOS(x) dev_sincos_inl(x)
 
 
@@ -630,9 +628,9 @@ DE_DEV bool rc_game_logic_batched(const RcCtx& c, RcLds& L, int lane, bool withT
   return true;
 }
 
-// the per-substep game logic: for robot in agents: [processAction]; tick; then the ball.  Called by the whole wave.
-// The sequential form (first substep, or a cross-robot event) is out of line; the common lane-parallel form is inlined
-// into the step kernel's loop so that it costs no call (callee-saved registers travel through scratch on every call).
+// The sequential form of the robots' game logic - for robot in agents: [processAction]; tick - for the first substep and for
+// substeps with a cross-robot event; out of line, called by lane 0 from the kernel.  (The ball's part follows in
+// rc_game_logic_batched, which the common substep then runs without its tick.)
 template <int EPW>
 DE_OOL void rc_game_serial(RcCtx c_, int it, const int* __restrict__ actions, const double* __restrict__ headAct) {
   const RcCtx c = rc_ctx_uniform(c_);
