@@ -681,10 +681,17 @@ DE_DEV bool rc_dice_exceeds(double rr, double base, double xOver, int n) {
   if (rr <= 1.0 - (double)n * xOver - 1e-6) return false;
   return rr > dm_powi(base, n);
 }
-template <int EPW>
-DE_DEV void rc_cb_post_solve(const RcCtx& c, RcLds& L, int i, int j) {
-  if (!c.canFall) return;
+// The dice of the post_solve handlers (robotCollision / goalpostCollision) of pair (i, j): two uniforms in [0, 1), a pure
+// function of the pair and the time.  Every active arbiter's lane draws its own (one instance of the Philox code for all of
+// them) before the handlers run one after the other on lane 0.
+DE_DEV void rc_post_solve_dice(const RcCtx& c, const RcLds& L, int i, int j, double& d0, double& d1) {
   const uint32_t key = (uint32_t)(i * 32 + j);
+  const dm_u32x4 u = rc_rng(c, L, key | ((j < RC_BALL ? 2u : 3u) << 16));
+  d0 = dm_unit(u.v[0]); d1 = dm_unit(u.v[1]);
+}
+template <int EPW>
+DE_DEV void rc_cb_post_solve(const RcCtx& c, RcLds& L, int i, int j, double dice0, double dice1) {
+  if (!c.canFall) return;
   if (j < RC_BALL) {  // robotCollision :1039-1088
     const int r1 = i >> 1, r2 = j >> 1;
     if (r1 == r2) return;
@@ -694,13 +701,12 @@ DE_DEV void rc_cb_post_solve(const RcCtx& c, RcLds& L, int i, int j) {
     if (!(f1 & (RF_FALLEN | RF_PENAL))) t1 += 1;
     if (!(f2 & (RF_FALLEN | RF_PENAL))) t2 += 1;
     L.touchc[r1] = t1; L.touchc[r2] = t2;
-    const dm_u32x4 u = rc_rng(c, L, key | (2u << 16));
     const bool p1 = f1 & RF_PUSH, p2 = f2 & RF_PUSH;
-    if (!(f1 & RF_FALLEN) && rc_dice_exceeds(dm_unit(u.v[0]), p1 ? 0.99995 : 0.9999, p1 ? 5.0001e-5 : 1.0001e-4, t1)) {
+    if (!(f1 & RF_FALLEN) && rc_dice_exceeds(dice0, p1 ? 0.99995 : 0.9999, p1 ? 5.0001e-5 : 1.0001e-4, t1)) {
       rc_fall<EPW>(c, r1, p1 ? 1 : 0);
       L.touchc[r1] = 0;
     }
-    if (!(f2 & RF_FALLEN) && rc_dice_exceeds(dm_unit(u.v[1]), p2 ? 0.99995 : 0.9999, p2 ? 5.0001e-5 : 1.0001e-4, t2)) {
+    if (!(f2 & RF_FALLEN) && rc_dice_exceeds(dice1, p2 ? 0.99995 : 0.9999, p2 ? 5.0001e-5 : 1.0001e-4, t2)) {
       rc_fall<EPW>(c, r2, p2 ? 1 : 0);
       L.touchc[r2] = 0;
     }
@@ -716,8 +722,7 @@ DE_DEV void rc_cb_post_solve(const RcCtx& c, RcLds& L, int i, int j) {
     if (!(f & RF_TOUCH)) { L.rflags[r] = f | RF_TOUCH; t = 0; }
     t += 1;
     L.touchc[r] = t;
-    const dm_u32x4 u = rc_rng(c, L, key | (3u << 16));
-    if (rc_dice_exceeds(dm_unit(u.v[0]), 0.9998, 2.0001e-4, t)) rc_fall<EPW>(c, r, 1);
+    if (rc_dice_exceeds(dice0, 0.9998, 2.0001e-4, t)) rc_fall<EPW>(c, r, 1);
   }
 }
 
@@ -1508,12 +1513,15 @@ RC_PROF(const unsigned long long T5 = __builtin_amdgcn_s_memtime();)
 #undef RC_JOINT_VIEW
   // --- post-solve callbacks of the active arbiters, canonical order (scalar, lane 0) -------------------------
   if (anyContactWork) {
+    double dice0 = 0.0, dice1 = 0.0;
+    if (active && c.canFall) rc_post_solve_dice(c, L, a_pair >> 8, a_pair & 0xFF, dice0, dice1);
     for (int k = 0; k < nTouched; ++k) {
       const uint64_t who = G::ballot(active && rank == k);
       if (who == 0ull) continue;
       const int b = __builtin_ctzll(who);
       const int pk = G::bcast_i(a_pair, b);
-      if (lane == 0) rc_cb_post_solve<EPW>(c, L, pk >> 8, pk & 0xFF);
+      const double d0 = G::bcast_d(dice0, b), d1 = G::bcast_d(dice1, b);
+      if (lane == 0) rc_cb_post_solve<EPW>(c, L, pk >> 8, pk & 0xFF, d0, d1);
       __syncthreads();
     }
     if (active && a_state == ARB_FIRST_) a_state = ARB_NORMAL_;
