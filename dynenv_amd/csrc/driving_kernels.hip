@@ -496,20 +496,22 @@ DE_OOL void write_full_obs_ool(int lane, int A, int nPed, int nObst, int obs_dim
   const int carsEnd = 9 + (A - 1) * 7;
   if (((carsEnd | obs_dim) & 3) == 0) {
     // vector path (A in {2,6,10}): one float4 per lane; the 160-float tail is identical for every agent of the env
-    const int nvec = obs_dim >> 2;
-    for (int q = lane; q < nvec; q += DE_WAVE) {
-      int f = q << 2;
-      if (f >= carsEnd) {
-        float4 v = *reinterpret_cast<const float4*>(&O.shared[f - carsEnd]);
-        for (int a = 0; a < A; ++a) *reinterpret_cast<float4*>(out + (size_t)a * obs_dim + f) = v;
-      } else {
-        for (int a = 0; a < A; ++a) {
-          float4 v;
-          v.x = obs_self_or_car(O, A, a, f + 0); v.y = obs_self_or_car(O, A, a, f + 1);
-          v.z = obs_self_or_car(O, A, a, f + 2); v.w = obs_self_or_car(O, A, a, f + 3);
-          *reinterpret_cast<float4*>(out + (size_t)a * obs_dim + f) = v;
-        }
+    // the per-agent part (own row, then the other cars in order): lane = float index, which fixes the source column and - but for
+    // the skip of the agent itself - the source car; one LDS read and one 4-byte store per agent (a wave's stores are 256 contiguous
+    // bytes), instead of assembling float4s through four index computations (a division by 7 each) per agent
+    for (int f = lane; f < carsEnd; f += DE_WAVE) {
+      const bool own = f < 9;
+      const int p = own ? 0 : (f - 9) / 7, col = own ? (f < 6 ? f : (f == 8 ? 6 : f - 6)) : (f - 9) - p * 7;
+      const bool fromGoal = f == 6 || f == 7;
+      for (int a = 0; a < A; ++a) {
+        const int k = own ? a : p + (p >= a ? 1 : 0);
+        out[(size_t)a * obs_dim + f] = fromGoal ? O.goal[a][col] : O.carRow[k][col];
       }
+    }
+    const int nvec = (obs_dim - carsEnd) >> 2;
+    for (int q = lane; q < nvec; q += DE_WAVE) {
+      const float4 v = *reinterpret_cast<const float4*>(&O.shared[q << 2]);
+      for (int a = 0; a < A; ++a) *reinterpret_cast<float4*>(out + (size_t)a * obs_dim + carsEnd + (q << 2)) = v;
     }
   } else {
     for (int idx = lane; idx < A * obs_dim; idx += DE_WAVE) {
