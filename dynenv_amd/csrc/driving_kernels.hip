@@ -1589,13 +1589,93 @@ DRV_PROF(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* d = g_dbgl + 
   ret.cand = cand; ret.dirty = dirty; ret.bits = (candMoving ? 1 : 0) | (removed ? 2 : 0) | (cand != lastCand ? 4 : 0);
   return ret;
 }
+// ------------------------------------------------------------------------------------------------
+// SIMD isolation of the slow environments.  A launch lasts as long as its slowest environment, and that environment's wave
+// shares its SIMD with three others: their instructions delay it by ~10 % (measured: 458 k cycles alone, 502 k with neighbours).
+// Which block steps which environment is free - results do not depend on it - so: the K environments that were slowest in the
+// previous step (list built by that step's epilogue) take blocks 0..K-1, the first wave slot of SIMD groups 0..K-1 (blocks b,
+// b + 1024, b + 2048, b + 3072 share a SIMD); the other three blocks of those groups run no environment - they sleep until
+// "their" slow environment has finished and hold the slots meanwhile - and the 3 K environments that would have sat there run
+// in the spare blocks behind the regular grid, which the dispatcher starts as soon as the first light environments finish.
+// Every environment that is not in the list is the r-th of them in id order for exactly one block r: a bijection whatever the
+// list holds.  Returns the environment of this block, or -1 for a block without one (after the placeholder's wait).
+// ------------------------------------------------------------------------------------------------
+DE_DEV int drv_iso_assign(const DrvState& S, int lane) {
+  const int b = blockIdx.x, E = S.E;
+  if (!S.iso_on) return b;
+  const int buf = S.tick % 3;
+  if (b == 0 && lane == 0) { const int nn = (S.tick + 2) % 3; S.iso[nn] = 0; S.iso[3 + nn] = 0; }  // the buffer the NEXT step fills
+  int K = uniform_i(S.iso[buf]);
+  K = K < DRV_ISO_MAX ? K : DRV_ISO_MAX;
+  if (K == 0) return b < E ? b : -1;
+  const int* H = S.iso + 8 + buf * DRV_ISO_MAX;
+  int r;
+  if (b >= E) {
+    const int d = b - E;
+    if (d >= 3 * K) return -1;
+    r = (E - 4 * K) + d;
+  } else {
+    const int g = b & (DRV_ISO_GROUPS - 1), pos = b / DRV_ISO_GROUPS;
+    if (g < K) {
+      const int h = uniform_i(H[g]);
+      if (pos == 0) return h;
+      // placeholder: hold this wave slot idle while the slow environment of this SIMD runs (bounded wait, then exit)
+      int i = 0;
+      for (; i < 96; ++i) {
+        if (uniform_i(__atomic_load_n(&S.iso_done[h], __ATOMIC_RELAXED)) == S.tick) break;
+        __builtin_amdgcn_s_sleep(127);
+      }
+      if (i >= 96 && lane == 0) atomicAdd(&S.iso[7], 1);  // (diagnostic: a placeholder that gave up waiting; dynenv_debug_counters)
+      return -1;
+    }
+    r = pos * (DRV_ISO_GROUPS - K) + (g - K);
+  }
+  // the r-th environment id that is not in the list: least x with x = r + #{h in H : h <= x}
+  int h0 = 0x7FFFFFFF, h1 = h0, h2 = h0, h3 = h0;
+  if (lane < K) h0 = H[lane];
+  if (lane + 64 < K) h1 = H[lane + 64];
+  if (lane + 128 < K) h2 = H[lane + 128];
+  if (lane + 192 < K) h3 = H[lane + 192];
+  int x = r;
+  for (int it = 0; it <= DRV_ISO_MAX; ++it) {
+    const int c = __popcll(wave_ballot(h0 <= x)) + __popcll(wave_ballot(h1 <= x)) + __popcll(wave_ballot(h2 <= x)) + __popcll(wave_ballot(h3 <= x));
+    const int nx = r + c;
+    if (nx == x) break;
+    x = nx;
+  }
+  return x < E ? x : -1;
+}
+// the step's epilogue: this environment's cycles -> the list of the next step (those above 0.7 of the previous step's slowest, once
+// that is long enough for isolation to matter), and the tick its placeholders are waiting for
+#ifndef DRV_ISO_MIN
+#define DRV_ISO_MIN 300000 /* isolation starts when the slowest environment of a step needed this many cycles */
+#endif
+#ifndef DRV_ISO_TENTHS
+#define DRV_ISO_TENTHS 8 /* ... for the environments above this many tenths of it */
+#endif
+DE_DEV void drv_iso_report(const DrvState& S, int e, int lane, unsigned long long t0) {
+  if (!S.iso_on || lane != 0) return;
+  const int cycles = (int)(__builtin_amdgcn_s_memtime() - t0);
+  const int buf = S.tick % 3, nxt = (S.tick + 1) % 3;
+  const int slowest = S.iso[3 + buf];
+  // (only the few environments above the floor touch the shared words: 4096 atomics on one address serialise - 0.12 ms, measured)
+  if (cycles > DRV_ISO_MIN) atomicMax(&S.iso[3 + nxt], cycles);
+  if (slowest > DRV_ISO_MIN && cycles > (slowest / 10) * DRV_ISO_TENTHS) {
+    const int k = atomicAdd(&S.iso[nxt], 1);
+    if (k < DRV_ISO_MAX) S.iso[8 + nxt * DRV_ISO_MAX + k] = e;
+  }
+  __atomic_store_n(&S.iso_done[e], S.tick, __ATOMIC_RELAXED);
+}
+
 template <bool PARTIAL>
 DE_DEV void drv_step_body(const DrvState& S, const int* __restrict__ actions, float* __restrict__ obs, double* __restrict__ rewards,
                           uint8_t* __restrict__ dones, float* __restrict__ pobs, int pvNoise, double pvMagn) {
-DRV_PROF(const unsigned long long KS = __builtin_amdgcn_s_memtime();)
+  const unsigned long long isoT0 = __builtin_amdgcn_s_memtime();
+DRV_PROF(const unsigned long long KS = isoT0;)
   DrvLds& L = g_L;
-  const int e = blockIdx.x;
   int lane = threadIdx.x;
+  const int e = drv_iso_assign(S, lane);  // (= blockIdx.x unless the slow environments of the previous step are being isolated)
+  if (e < 0) return;
 DRV_PROF(if (lane < 8 && e < 4096) g_dbgp[e * 8 + lane] = 0ull;)
   const int A = S.A;
   int* envi = S.envi + (size_t)e * EI_COUNT;
@@ -1761,6 +1841,7 @@ DRV_PROF(const unsigned long long K1 = __builtin_amdgcn_s_memtime();)
   // last to finish and defers everything; a light one keeps as many passes as fit before the heavy ones are done.
   const int fusedAgents = !(PARTIAL && pobs) ? 0 : nContact >= DRV_DEFER_MIN_CONTACT ? 0 : (A < DRV_FUSED_AGENTS ? A : DRV_FUSED_AGENTS);
   if (PARTIAL && lane == 0) envi[EI_DEFER_OBS] = fusedAgents;  // first agent the deferred launch has to do
+  drv_iso_report(S, e, fresh_lane(), isoT0);
   if (PARTIAL && fusedAgents > 0) {
     PvIn in;
     in.px = in.py = in.ang = in.ox = in.oy = in.gx = in.gy = 0.0; in.flags = 0;

@@ -215,7 +215,8 @@ int dynenv_error_flags(dynenv_t* h, int32_t* out);
 /* Diagnostics (Driving), summed over environments since the last reset: out12 = {substeps on the no-contact fast path,
  * on the quiescent shortcut, on the full contact path, sum of live contact-cache slots, contact-path substeps caused by
  * a changed candidate set / a moving body / a non-inert arbiter, substeps served by a steady replay, by the light mode,
- * contact-path substeps whose sweeps ran as split-lane general multi-level solves, 0, 0}.
+ * contact-path substeps whose sweeps ran as split-lane general multi-level solves, the number of environments the next step
+ * gives a SIMD of their own (-1: isolation off for this handle), isolation placeholders that gave up waiting (stays 0)}.
  * Synchronises the device. */
 int dynenv_debug_counters(dynenv_t* h, int64_t* out12);
 

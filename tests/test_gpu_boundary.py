@@ -356,3 +356,36 @@ def test_refresh_obs_and_device_guard(gpu):
     with pytest.raises(dynenv_amd._capi.DynEnvError):
         dynenv_amd.BatchedDynEnv(dynenv_amd.DynEnvType.ROBO_CUP, 4, 5, flags=64)   # unknown bit
     env.close()
+
+
+def test_simd_isolation_changes_the_schedule_and_nothing_else(gpu, monkeypatch):
+    """4096 Driving environments on a 256-CU device: the environments that were slowest in the previous step get a SIMD of their
+    own (which block steps which environment).  A handle created with DYNENV_NO_ISOLATION=1 must produce the same
+    observations, rewards, dones and states, bit for bit, and no placeholder may ever give up waiting."""
+    dynenv_amd, torch, _ = gpu
+    E, A, steps = 4096, 10, 420
+    iso = dynenv_amd.BatchedDynEnv(dynenv_amd.DynEnvType.DRIVE, E, A, seed=11)
+    monkeypatch.setenv("DYNENV_NO_ISOLATION", "1")
+    ref = dynenv_amd.BatchedDynEnv(dynenv_amd.DynEnvType.DRIVE, E, A, seed=11)
+    monkeypatch.delenv("DYNENV_NO_ISOLATION")
+    assert ref.debug_counters()["isolated_next"] == -1
+    on = iso.debug_counters()["isolated_next"] >= 0
+    if not on:
+        pytest.skip("isolation is only switched on for 4096 environments on a 256-CU device")
+    iso.reset_flat(); ref.reset_flat()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    seen = 0
+    for s in range(steps):
+        a = torch.randint(0, 3, (E, A, 2), generator=g, device="cuda", dtype=torch.int32)
+        o1, r1, d1 = iso.step_flat(a, auto_reset=False)
+        o2, r2, d2 = ref.step_flat(a, auto_reset=False)
+        if s % 20 == 19 or s == steps - 1:
+            assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2), "step %d" % s
+            seen = max(seen, iso.debug_counters()["isolated_next"])
+    assert seen > 0, "no environment was ever isolated in %d steps" % steps
+    assert iso.debug_counters()["isolation_timeouts"] == 0
+    for e in (0, 1, 1023, 1024, 2048, 4095):
+        s1, s2 = iso.get_state(e), ref.get_state(e)
+        assert bytes(s1) == bytes(s2), "state of environment %d" % e
+    assert iso.error_flags() == 0 and ref.error_flags() == 0
+    iso.close(); ref.close()

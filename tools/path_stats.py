@@ -12,7 +12,7 @@ for s in range(600):
     env.step_flat(a, auto_reset=False)
     if s % 100 == 99:
         c = env.debug_counters()
-        d = {k: c[k] - prev[k] for k in c}
+        d = {k: c[k] - prev[k] for k in prev}
         tot = d["fast"] + d["quiescent"] + d["contact"] + d["steady"]
-        print("steps %3d-%3d: fast %.3f quiescent %.3f contact %.3f (cand-changed %.3f moving %.3f not-inert %.3f) steady-replay %.3f (+%.3f of contact via light mode), split-lane general sweeps in %.4f  avg live slots %.2f" % (s - 99, s, d["fast"] / tot, d["quiescent"] / tot, d["contact"] / tot, d["why_cand"] / tot, d["why_moving"] / tot, d["why_inert"] / tot, d["steady"] / tot, d["light"] / tot, d["split"] / tot, d["slot_sum"] / tot))
+        print("steps %3d-%3d: fast %.3f quiescent %.3f contact %.3f (cand-changed %.3f moving %.3f not-inert %.3f) steady-replay %.3f (+%.3f of contact via light mode), split-lane general sweeps in %.4f  avg live slots %.2f; isolated next step %d, isolation timeouts %d" % (s - 99, s, d["fast"] / tot, d["quiescent"] / tot, d["contact"] / tot, d["why_cand"] / tot, d["why_moving"] / tot, d["why_inert"] / tot, d["steady"] / tot, d["light"] / tot, d["split"] / tot, d["slot_sum"] / tot, c["isolated_next"], c["isolation_timeouts"]))
         prev = c
