@@ -607,7 +607,7 @@ int dynenv_step_head(dynenv_t* h, const int32_t* actions_dev, const double* head
   // (with isolation on, 3 x DRV_ISO_MAX spare blocks behind the E regular ones: the environments displaced from a slow
   //  environment's SIMD run there - or nothing, and the block ends at once)
   const unsigned stepGrid = (unsigned)h->S.E + (h->S.iso_on ? 3u * DRV_ISO_MAX : 0u);
-  h->S.tick = (h->S.tick + 1) & 0x3FFFFFFF;
+  h->S.tick = (h->S.tick + 1) % (3 * (1 << 28));  // (wraps at a multiple of 3: the three isolation lists keep rotating in order)
   if (h->partial && obs_dev)
   {
     hipLaunchKernelGGL(drv_step_partial_kernel, dim3(stepGrid), dim3(64), 0, st, h->S, (const int*)actions_dev, rewards_dev, dones_dev, obs_dev,
