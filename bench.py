@@ -197,6 +197,10 @@ def episode_leg(torch, device, workload, E, seed, n_players=None):
     kern_ms = sum(eb.elapsed_time(em) for eb, em, ee, ex in evs) / ep_steps - ev_cost
     step_ms = sum(eb.elapsed_time(ee) for eb, em, ee, ex in evs) / ep_steps - ev_cost
     err = env.error_flags()
+    iso = None
+    if not robocup:  # Driving: did the library isolate its slow environments on SIMDs of their own (scheduling only)?
+        dc = env.debug_counters()
+        iso = {"on": dc["isolated_next"] >= 0, "isolated_in_last_step": max(int(dc["isolated_next"]), 0), "placeholder_timeouts": int(dc["isolation_timeouts"])}
     env.close()
     out = {"workload": workload, "reference": ref, "envs": E, "n_agents": A, "steps": ep_steps, "ms_per_step": ms,
            "value": E * A / (ms * 1e-3), "unit": "agent-steps/s", "kernel_error_flags": err}
@@ -208,6 +212,8 @@ def episode_leg(torch, device, workload, E, seed, n_players=None):
                            "step_ms_back_to_back": ms, "event_record_cost_ms": ev_cost, "alg_bytes_per_env_step": b_alg,
                            "env_steps_per_launch": E}
         out["roofline"].update(tdetail)
+    if iso is not None:
+        out["simd_isolation"] = iso
     return out
 
 
@@ -484,6 +490,8 @@ def main():
         }
         if full is not None:  # the same kernel over one whole episode: the mean a training run sees
             out["ms_per_step_full_episode"] = full["ms_per_step"]  # (N > 1: rank 0's kernel alone, no transport)
+            if "simd_isolation" in full:
+                out["simd_isolation"] = full["simd_isolation"]
             out["value_full_episode"] = full["value"] if world == 1 else None
         if world == 1 and not args.no_extra_legs and gather is None:
             env.close()
