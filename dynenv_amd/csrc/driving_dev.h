@@ -90,13 +90,14 @@ struct DrvState {
   double* s_imp;  /* [4][E][NS] jn0 jt0 jn1 jt1 */
   int* lastcand;  /* [E][64] per-lane candidate mask of the last substep (-1 = unknown); envi[EI_PAD] = inert | steady<<1 | vbValid<<2 */
   /* SIMD isolation of the slow environments (scheduling only - which block steps which environment; see drv_iso_assign):
-     iso[0..2] = list lengths, iso[3..5] = slowest environment's cycles, iso[8 + buf * DRV_ISO_MAX + k] = ids, three buffers used
+     iso[0..2] = list lengths, iso[3..5] = slowest environment's cycles, iso[8 + buf * DRV_ISO_LIST + k] = ids, three buffers used
      in rotation (step t reads buffer t % 3, fills (t + 1) % 3, clears (t + 2) % 3); iso_done[e] = tick of e's last finished step */
   int* iso;
   int* iso_done;
-  int tick, iso_on;
+  int tick, iso_on;  /* iso_on: 0 off, 1 isolation (E = one residency round), 2 slow environments first (E larger) */
 };
 #ifndef DRV_ISO_MAX
-#define DRV_ISO_MAX 64   /* at most this many environments get a SIMD of their own */
+#define DRV_ISO_MAX 64   /* at most this many environments get a SIMD of their own (iso_on = 1) */
 #endif
+#define DRV_ISO_LIST 256 /* capacity of a list; iso_on = 2 (more environments than fit at once) starts up to this many slow ones first */
 #define DRV_ISO_GROUPS 1024 /* SIMDs of an MI355X: blocks b, b + 1024, b + 2048, b + 3072 of a launch share one (measured) */

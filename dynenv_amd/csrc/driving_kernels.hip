@@ -1606,11 +1606,17 @@ DE_DEV int drv_iso_assign(const DrvState& S, int lane) {
   const int buf = S.tick % 3;
   if (b == 0 && lane == 0) { const int nn = (S.tick + 2) % 3; S.iso[nn] = 0; S.iso[3 + nn] = 0; }  // the buffer the NEXT step fills
   int K = uniform_i(S.iso[buf]);
-  K = K < DRV_ISO_MAX ? K : DRV_ISO_MAX;
+  const int cap = S.iso_on == 1 ? DRV_ISO_MAX : DRV_ISO_LIST;
+  K = K < cap ? K : cap;
   if (K == 0) return b < E ? b : -1;
-  const int* H = S.iso + 8 + buf * DRV_ISO_MAX;
+  const int* H = S.iso + 8 + buf * DRV_ISO_LIST;
   int r;
-  if (b >= E) {
+  if (S.iso_on == 2) {
+    // more environments than fit at once: the listed (slow) ones take the first blocks - they start with the launch instead of
+    // wherever their id falls in the later residency rounds -, every other environment follows in id order
+    if (b < K) return uniform_i(H[b]);
+    r = b - K;
+  } else if (b >= E) {
     const int d = b - E;
     if (d >= 3 * K) return -1;
     r = (E - 4 * K) + d;
@@ -1637,7 +1643,7 @@ DE_DEV int drv_iso_assign(const DrvState& S, int lane) {
   if (lane + 128 < K) h2 = H[lane + 128];
   if (lane + 192 < K) h3 = H[lane + 192];
   int x = r;
-  for (int it = 0; it <= DRV_ISO_MAX; ++it) {
+  for (int it = 0; it <= DRV_ISO_LIST; ++it) {
     const int c = __popcll(wave_ballot(h0 <= x)) + __popcll(wave_ballot(h1 <= x)) + __popcll(wave_ballot(h2 <= x)) + __popcll(wave_ballot(h3 <= x));
     const int nx = r + c;
     if (nx == x) break;
@@ -1659,10 +1665,10 @@ DE_DEV void drv_iso_report(const DrvState& S, int e, int lane, unsigned long lon
   const int buf = S.tick % 3, nxt = (S.tick + 1) % 3;
   const int slowest = S.iso[3 + buf];
   // (only the few environments above the floor touch the shared words: 4096 atomics on one address serialise - 0.12 ms, measured)
-  if (cycles > DRV_ISO_MIN) atomicMax(&S.iso[3 + nxt], cycles);
+  if (cycles > DRV_ISO_MIN && cycles > (slowest / 10) * DRV_ISO_TENTHS) atomicMax(&S.iso[3 + nxt], cycles);
   if (slowest > DRV_ISO_MIN && cycles > (slowest / 10) * DRV_ISO_TENTHS) {
     const int k = atomicAdd(&S.iso[nxt], 1);
-    if (k < DRV_ISO_MAX) S.iso[8 + nxt * DRV_ISO_MAX + k] = e;
+    if (k < DRV_ISO_LIST) S.iso[8 + nxt * DRV_ISO_LIST + k] = e;
   }
   __atomic_store_n(&S.iso_done[e], S.tick, __ATOMIC_RELAXED);
 }

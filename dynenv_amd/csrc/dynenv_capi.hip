@@ -418,7 +418,7 @@ int dynenv_create(const dynenv_cfg_t* cfg, dynenv_t** out) {
   rc |= dev_alloc(h, &S.s_hash, 2 * E * DRV_NS);
   rc |= dev_alloc(h, &S.s_imp, 4 * E * DRV_NS);
   rc |= dev_alloc(h, &S.lastcand, E * 64);
-  rc |= dev_alloc(h, &S.iso, 8 + 3 * DRV_ISO_MAX);
+  rc |= dev_alloc(h, &S.iso, 8 + 3 * DRV_ISO_LIST);
   rc |= dev_alloc(h, &S.iso_done, E);
   if (rc) { dynenv_destroy(h); return DYNENV_ERR_HIP; }
   {
@@ -427,10 +427,14 @@ int dynenv_create(const dynenv_cfg_t* cfg, dynenv_t** out) {
     hipDeviceProp_t prop;
     S.iso_on = 0;
     if (hipGetDeviceProperties(&prop, cfg->device_id) == hipSuccess)
-      S.iso_on = (E == 4 * DRV_ISO_GROUPS && prop.multiProcessorCount * 4 == DRV_ISO_GROUPS && !h->partial &&  // (Partial: the fused
-                  !getenv("DYNENV_NO_ISOLATION")) ? 1 : 0;  // observation makes the displaced environments too long for the second round: +1.4 %)
+    {
+      const bool dev256 = prop.multiProcessorCount * 4 == DRV_ISO_GROUPS, off = getenv("DYNENV_NO_ISOLATION") != nullptr;
+      // 1: isolation - one residency round, Full observations (Partial: the fused observation makes the displaced environments
+      //    too long for the second round: +1.4 %);  2: more environments than fit at once - the slow ones simply start first
+      S.iso_on = off || !dev256 ? 0 : (E == 4 * DRV_ISO_GROUPS ? (h->partial ? 0 : 1) : (E > 4 * DRV_ISO_GROUPS ? 2 : 0));
+    }
     S.tick = 0;
-    if (hipMemset(S.iso, 0, sizeof(int) * (8 + 3 * DRV_ISO_MAX)) != hipSuccess || hipMemset(S.iso_done, 0xFF, sizeof(int) * E) != hipSuccess) {
+    if (hipMemset(S.iso, 0, sizeof(int) * (8 + 3 * DRV_ISO_LIST)) != hipSuccess || hipMemset(S.iso_done, 0xFF, sizeof(int) * E) != hipSuccess) {
       dynenv_destroy(h);
       return fail(DYNENV_ERR_HIP, "hipMemset");
     }
@@ -606,7 +610,7 @@ int dynenv_step_head(dynenv_t* h, const int32_t* actions_dev, const double* head
   // environment's observation as soon as its step is done, which fills the launch's tail
   // (with isolation on, 3 x DRV_ISO_MAX spare blocks behind the E regular ones: the environments displaced from a slow
   //  environment's SIMD run there - or nothing, and the block ends at once)
-  const unsigned stepGrid = (unsigned)h->S.E + (h->S.iso_on ? 3u * DRV_ISO_MAX : 0u);
+  const unsigned stepGrid = (unsigned)h->S.E + (h->S.iso_on == 1 ? 3u * DRV_ISO_MAX : 0u);
   h->S.tick = (h->S.tick + 1) % (3 * (1 << 28));  // (wraps at a multiple of 3: the three isolation lists keep rotating in order)
   if (h->partial && obs_dev)
   {
@@ -712,7 +716,8 @@ int dynenv_debug_counters(dynenv_t* h, int64_t* out4) {
     int iso[8];
     HIP_OK(hipMemcpy(iso, h->S.iso, sizeof(iso), hipMemcpyDeviceToHost));
     const int k = iso[(h->S.tick + 1) % 3];
-    out4[10] = h->S.iso_on ? (k < DRV_ISO_MAX ? k : DRV_ISO_MAX) : -1; out4[11] = iso[7];
+    const int cap = h->S.iso_on == 1 ? DRV_ISO_MAX : DRV_ISO_LIST;
+    out4[10] = h->S.iso_on ? (k < cap ? k : cap) : -1; out4[11] = iso[7];
   }
 #ifdef DRV_PROFILE
   { unsigned long long d[16]; HIP_OK(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_dbgr), sizeof(d))); FILE* f = fopen("gpurun_out/dbgr.txt", "w"); for (int k = 0; k < 16; ++k) fprintf(f, "%llu\n", d[k]); fclose(f); }

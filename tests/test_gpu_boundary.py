@@ -358,12 +358,13 @@ def test_refresh_obs_and_device_guard(gpu):
     env.close()
 
 
-def test_simd_isolation_changes_the_schedule_and_nothing_else(gpu, monkeypatch):
-    """4096 Driving environments on a 256-CU device: the environments that were slowest in the previous step get a SIMD of their
-    own (which block steps which environment).  A handle created with DYNENV_NO_ISOLATION=1 must produce the same
-    observations, rewards, dones and states, bit for bit, and no placeholder may ever give up waiting."""
+@pytest.mark.parametrize("E,steps", [(4096, 420), (8192, 300)])
+def test_simd_isolation_changes_the_schedule_and_nothing_else(gpu, monkeypatch, E, steps):
+    """Driving on a 256-CU device.  4096 environments: those that were slowest in the previous step get a SIMD of their own;
+    8192: they start first (which block steps which environment).  A handle created with DYNENV_NO_ISOLATION=1
+    must produce the same observations, rewards, dones and states, bit for bit, and no placeholder may ever give up waiting."""
     dynenv_amd, torch, _ = gpu
-    E, A, steps = 4096, 10, 420
+    A = 10
     iso = dynenv_amd.BatchedDynEnv(dynenv_amd.DynEnvType.DRIVE, E, A, seed=11)
     monkeypatch.setenv("DYNENV_NO_ISOLATION", "1")
     ref = dynenv_amd.BatchedDynEnv(dynenv_amd.DynEnvType.DRIVE, E, A, seed=11)
@@ -371,7 +372,7 @@ def test_simd_isolation_changes_the_schedule_and_nothing_else(gpu, monkeypatch):
     assert ref.debug_counters()["isolated_next"] == -1
     on = iso.debug_counters()["isolated_next"] >= 0
     if not on:
-        pytest.skip("isolation is only switched on for 4096 environments on a 256-CU device")
+        pytest.skip("the scheduling is only switched on for 4096 or more environments on a 256-CU device")
     iso.reset_flat(); ref.reset_flat()
     g = torch.Generator(device="cuda").manual_seed(5)
     seen = 0
@@ -384,7 +385,7 @@ def test_simd_isolation_changes_the_schedule_and_nothing_else(gpu, monkeypatch):
             seen = max(seen, iso.debug_counters()["isolated_next"])
     assert seen > 0, "no environment was ever isolated in %d steps" % steps
     assert iso.debug_counters()["isolation_timeouts"] == 0
-    for e in (0, 1, 1023, 1024, 2048, 4095):
+    for e in (0, 1, 1023, 1024, 2048, 4095, E - 1):
         s1, s2 = iso.get_state(e), ref.get_state(e)
         assert bytes(s1) == bytes(s2), "state of environment %d" % e
     assert iso.error_flags() == 0 and ref.error_flags() == 0
