@@ -140,7 +140,7 @@ def measured_traffic(kernel):
                                                  "traffic_whole_step": d.get("step_bytes_all_kernels")}
 
 
-def episode_leg(torch, device, workload, E, seed, n_players=None):
+def episode_leg(torch, device, workload, E, seed, n_players=None, env_id_offset=0):
     """One whole episode of `workload` (every step of it, the lock-step reset excluded), timed with HIP events on the launch
     stream: the episode mean is what a training run sees - a window at the start of an episode flatters Driving, whose
     contact work grows over the episode."""
@@ -157,7 +157,8 @@ def episode_leg(torch, device, workload, E, seed, n_players=None):
         pool = [torch.randint(0, 3, (E, A, 2), generator=g, device=device, dtype=torch.int32) for _ in range(16)]
 
     def fresh_env():  # both passes below run the SAME episode (episode index 2 of a fresh handle: identical trajectories)
-        env = BatchedDynEnv(DynEnvType.ROBO_CUP if robocup else DynEnvType.DRIVE, E, players, seed=seed, device=device, **kw)
+        env = BatchedDynEnv(DynEnvType.ROBO_CUP if robocup else DynEnvType.DRIVE, E, players, seed=seed, device=device,
+                            env_id_offset=env_id_offset, **kw)
         env.reset_flat()
         for i in range(3):  # untimed: first-touch of the buffers, then a fresh episode
             env.step_flat(pool[i & 15], auto_reset=False)
@@ -205,10 +206,16 @@ def episode_leg(torch, device, workload, E, seed, n_players=None):
     out = {"workload": workload, "reference": ref, "envs": E, "n_agents": A, "steps": ep_steps, "ms_per_step": ms,
            "value": E * A / (ms * 1e-3), "unit": "agent-steps/s", "kernel_error_flags": err}
     if A == 10:
-        achieved = b_alg * E / (kern_ms * 1e-3) / 1e9
+        # the algorithmic bytes are those of the WHOLE step: where a step is more than one launch (Partial observations: the
+        # deferred / finalize kernels do part of the work) they are divided by the time of all of its kernels
+        basis_ms = step_ms if partial else kern_ms
+        achieved = b_alg * E / (basis_ms * 1e-3) / 1e9
         traffic, tdetail = measured_traffic(kernel)
+        if partial and tdetail.get("traffic_whole_step") is not None:
+            traffic = tdetail["traffic_whole_step"]
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                            "traffic": traffic, "kernel": kernel, "launch_ms": kern_ms, "step_ms_all_kernels": step_ms,
+                           "achieved_over": "step_ms_all_kernels" if partial else "launch_ms",
                            "step_ms_back_to_back": ms, "event_record_cost_ms": ev_cost, "alg_bytes_per_env_step": b_alg,
                            "env_steps_per_launch": E}
         out["roofline"].update(tdetail)
@@ -397,7 +404,7 @@ def main():
             gather.start(k)
 
     if args.roofline_only:
-        args.steps, args.warmup, args.no_extra_legs, args.no_cpu_baseline = 1, 0, True, True
+        args.steps, args.warmup, args.no_extra_legs, args.no_cpu_baseline = 0, 0, True, True
     env.reset_flat()
     for i in range(args.warmup):
         one_step(i)
@@ -410,20 +417,83 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    # ---- the timed region: EXACTLY args.steps steps, chosen so that they weigh an episode the way a training run does.
+    # A Driving step costs 0.10 ms at the start of an episode and 0.25 ms at its end (contacts accumulate), so K consecutive
+    # steps right after the warm-up measure the cheap end only.  Instead: K // L whole episodes run back to back (L = steps per
+    # episode; lock-step resets inside the timed region), and the remaining K % L steps are spread EVENLY over one
+    # further episode (stratified sample: timed step j sits at position (j + 1/2) L / (K % L)), the steps between them advance
+    # the same handle untimed.  N = 1: every timed step is bracketed by HIP events on the launch stream (nothing subtracted:
+    # the interval holds the kernel(s) and one event record).  N > 1: the spread steps are grouped into a few contiguous blocks,
+    # each bracketed by barrier + synchronize on both sides (the pipelined transport overlaps inside a block).
+    L_ep = WORKLOADS[args.workload][3]
+    n_full, n_spread = divmod(args.steps, L_ep)
+    if args.roofline_only:  # no timed region at all: every launch of the process belongs to the whole-episode leg
+        n_full = n_spread = 0
+    pos = [0]  # position inside the current episode (auto-reset at L_ep)
+
+    def advance(n):  # (the handle resets itself every L_ep steps: pos follows its position inside the episode)
+        for _ in range(n):
+            one_step(pos[0])
+            pos[0] = (pos[0] + 1) % L_ep
+    pos[0] = args.warmup % L_ep
+    untimed_advance = 0
+    elapsed, gpu_ms, timed_at = 0.0, 0.0, []
     fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for i in range(args.steps):
-        one_step(i)
-    ev1.record()
-    fence()
-    elapsed = time.perf_counter() - t0
-    gpu_ms = ev0.elapsed_time(ev1)
+    if n_full:
+        if pos[0]:  # start whole episodes at an episode boundary
+            untimed_advance += L_ep - pos[0]
+            advance(L_ep - pos[0])
+            fence()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        advance(n_full * L_ep)
+        ev1.record()
+        fence()
+        elapsed += time.perf_counter() - t0
+        gpu_ms += ev0.elapsed_time(ev1)
+        timed_at.append("%d whole episode(s) of %d steps, back to back, resets included" % (n_full, L_ep))
+    if n_spread:
+        if pos[0]:
+            untimed_advance += L_ep - pos[0]
+            advance(L_ep - pos[0])
+        at = [min(L_ep - 1, int((j + 0.5) * L_ep / n_spread)) for j in range(n_spread)]
+        if dist is None:
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in at]
+            fence()
+            for j, p_ in enumerate(at):
+                untimed_advance += p_ - pos[0]
+                advance(p_ - pos[0])
+                evs[j][0].record()
+                advance(1)
+                evs[j][1].record()
+            fence()
+            dt_ms = sum(a.elapsed_time(b) for a, b in evs)
+            elapsed += dt_ms * 1e-3
+            gpu_ms += dt_ms
+            timed_at.append("%d single steps at positions %s of one episode, HIP events around each" % (n_spread, at))
+        else:
+            n_blocks = min(4, n_spread)
+            sizes = [n_spread // n_blocks + (1 if b < n_spread % n_blocks else 0) for b in range(n_blocks)]
+            starts = [max(0, min(L_ep - sizes[b], int((b + 0.5) * L_ep / n_blocks) - sizes[b] // 2)) for b in range(n_blocks)]
+            for b in range(n_blocks):
+                untimed_advance += starts[b] - pos[0]
+                advance(starts[b] - pos[0])
+                fence()
+                eb0, eb1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0 = time.perf_counter()
+                eb0.record()
+                advance(sizes[b])
+                eb1.record()
+                fence()
+                elapsed += time.perf_counter() - t0
+                gpu_ms += eb0.elapsed_time(eb1)
+            timed_at.append("%d steps as %d blocks %s of one episode, barrier + synchronize around each block"
+                            % (n_spread, n_blocks, [(a, a + n - 1) for a, n in zip(starts, sizes)]))
     per_rank = None
     if dist is not None:
         # every rank's own wall clock and GPU time of the timed region: the line is self-checking (value uses the MAX)
-        mine = torch.tensor([elapsed, gpu_ms / args.steps], dtype=torch.float64, device=device)
+        mine = torch.tensor([elapsed, gpu_ms / max(args.steps, 1)], dtype=torch.float64, device=device)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = [[float(x[0]), float(x[1])] for x in allr]
@@ -452,38 +522,56 @@ def main():
         sync_leg = {"steps": n_sync, "ms_per_step": dt / n_sync * 1e3, "value": E * world * n_sync * A / dt,
                     "note": "--sync-gather semantics: all-gather of step k completed before step k + 1 is launched"}
 
-    # roofline leg: the dominant kernel over one WHOLE episode (no reset, no collective), HIP events on the launch stream
+    # roofline leg: the dominant kernel over one WHOLE episode (no reset, no collective), HIP events on the launch stream.
+    # N > 1: every rank runs it on its own shard's environment ids (kernel alone, no transport), so that a SCALE record can be
+    # cross-checked against the N = 1 BENCH record rank by rank without trusting the timed window
     roofline = None
     full = None
     ep_steps = WORKLOADS[args.workload][3]
-    if rank == 0:
-        full = episode_leg(torch, device, args.workload, E, args.seed, n_players=n_players)
+    shard_check = None
+    if rank == 0 or dist is not None:
+        full = episode_leg(torch, device, args.workload, E, args.seed, n_players=n_players, env_id_offset=rank * E)
         roofline = full.get("roofline")
+    if dist is not None:
+        mine = torch.tensor([float(env.cfg.env_id_offset), full["value"], full["ms_per_step"], float(env.num_envs)], dtype=torch.float64, device=device)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        offs = [int(x[0]) for x in allr]
+        shard_check = {"rccl_world_size": dist.get_world_size(), "backend": dist.get_backend(), "n_gpus_flag": args.gpus,
+                       "env_id_offset_per_rank": offs, "envs_per_rank": [int(x[3]) for x in allr],
+                       "value_full_episode_per_rank": [float(x[1]) for x in allr],
+                       "ms_per_step_full_episode_per_rank": [float(x[2]) for x in allr],
+                       "note": "per rank: the N = 1-equivalent whole-episode figure of that rank's shard (kernel alone, no transport)"}
+        # a line that claims N GPUs must have been produced by N RCCL ranks, each owning its own slice of the global environment ids
+        assert dist.get_world_size() == args.gpus or args.force_gather, "bench.py --gpus %d ran with world size %d" % (args.gpus, dist.get_world_size())
+        assert offs == [r * E for r in range(world)], "environment id offsets %s are not rank * %d" % (offs, E)
 
     if rank == 0:
         env_steps = E * world * args.steps
-        value = env_steps * A / elapsed
+        value = env_steps * A / elapsed if elapsed > 0 else None
         what = ("RoboCupEnvironment nPlayers=%d %s, 50 substeps/step" % (n_players, "Partial obs + Realistic noise magnitude 3" if partial else "Full obs")
                 if robocup else
                 "DrivingEnvironment nPlayers=%d %s, 10 substeps/step" % (A, "Partial obs + Realistic noise magnitude 3" if partial else "Full obs, noise=0"))
-        workload_text = ("%s, %d envs per GPU (%s), lock-step resets every %d steps; timed: steps %d..%d of the %d-step episodes "
-                         "(after %d warm-up steps) - the whole-episode mean is in ms_per_step_full_episode"
-                         % (what, E, WORKLOADS[args.workload][6], ep_steps, args.warmup, args.warmup + args.steps - 1, ep_steps, args.warmup))
+        workload_text = ("%s, %d envs per GPU (%s), lock-step resets every %d steps; timed after %d warm-up steps: %s"
+                         % (what, E, WORKLOADS[args.workload][6], ep_steps, args.warmup, "; ".join(timed_at)))
         out = {
             "metric": "agent-steps/s", "value": value, "unit": "agent-steps/s", "n_gpus": world,
-            **({"mode": "roofline-only: `value` is ONE untimed-quality step; read roofline / ms_per_step_full_episode"} if args.roofline_only else {}),
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            **({"mode": "roofline-only: no timed region (value null); read roofline / ms_per_step_full_episode"} if args.roofline_only else {}),
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": (elapsed / args.steps * 1e3 if elapsed > 0 else None),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload_text,
                        "envs_per_gpu": E, "n_players": n_players, "n_agents": A, "obs": "partial" if partial else "full", "gather": (False if gather is None else "sync" if args.sync_gather else "overlapped (transport of step k on a side stream beside the next kernels, ring of %d slabs)" % args.ring),
                        "gather_bytes_per_rank": (None if slab is None else slab.nbytes),
                        "parallelism": "env-shard x%d" % world + (" (REHEARSAL: all ranks on one GPU, gloo)" if args.rehearse_one_gpu else ""),
                        "rccl_world_size": (dist.get_world_size() if dist is not None else None)},
-            "env_steps_per_s": env_steps / elapsed,
-            "gpu_ms_per_step_rank0": gpu_ms / args.steps,
+            "timed_region": {"steps": args.steps, "whole_episodes": n_full, "spread_over_one_episode": n_spread,
+                             "untimed_steps_between": untimed_advance, "clock": "HIP events per timed step" if (dist is None and not n_full) else "wall clock between barrier + synchronize" if n_spread == 0 or dist is not None else "wall clock (whole episodes) + HIP events (spread steps)"},
+            "env_steps_per_s": (env_steps / elapsed if elapsed > 0 else None),
+            "gpu_ms_per_step_rank0": gpu_ms / max(args.steps, 1),
+            "shard_check": shard_check,
             "per_rank": (None if per_rank is None else {
-                "wall_ms_per_step": [x[0] / args.steps * 1e3 for x in per_rank], "gpu_ms_per_step": [x[1] for x in per_rank],
-                "slowest_over_fastest": max(x[0] for x in per_rank) / min(x[0] for x in per_rank)}),
+                "wall_ms_per_step": [x[0] / max(args.steps, 1) * 1e3 for x in per_rank], "gpu_ms_per_step": [x[1] for x in per_rank],
+                "slowest_over_fastest": max(x[0] for x in per_rank) / max(min(x[0] for x in per_rank), 1e-12)}),
             "sync_gather": sync_leg,
             "kernel_error_flags": err,
             "roofline": roofline,

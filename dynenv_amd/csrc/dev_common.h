@@ -107,7 +107,7 @@ DE_DEV double dev_cos(double x) { return dev_sincos(x).c; }
 
 #define DE_DBL_MIN 2.2250738585072014e-308
 // Chipmunk space defaults reached through pymunk.Space() (environment_base.py:126-128); values pinned against
-// libm pow() by tests/test_constants.py
+// libm pow() by tests/test_oracle_physics.py::test_bias_constants_match_device_header
 #define DE_COLLISION_SLOP 0.1
 #define DE_CONTACT_BIAS_COEF 0.061259621561307376 /* 1 - pow(pow(1-0.1f,60), 0.01) */
 #define DE_PIVOT_BIAS_COEF 0.022762779044189331   /* 1 - pow(0.1, 0.01)  (Robot.py:59 error_bias=0.1) */

@@ -90,14 +90,21 @@ struct DrvState {
   double* s_imp;  /* [4][E][NS] jn0 jt0 jn1 jt1 */
   int* lastcand;  /* [E][64] per-lane candidate mask of the last substep (-1 = unknown); envi[EI_PAD] = inert | steady<<1 | vbValid<<2 */
   /* SIMD isolation of the slow environments (scheduling only - which block steps which environment; see drv_iso_assign):
-     iso[0..2] = list lengths, iso[3..5] = slowest environment's cycles, iso[8 + buf * DRV_ISO_LIST + k] = ids, three buffers used
-     in rotation (step t reads buffer t % 3, fills (t + 1) % 3, clears (t + 2) % 3); iso_done[e] = tick of e's last finished step */
+     iso[0..2] = list lengths, iso[3..5] = slowest environment's cycles, iso[7] = placeholders that gave up waiting,
+     iso[8..10] = "the block -> SIMD placement isolation relies on was observed" (written by the launch before the one that
+     reads it), iso[11] = launches in which it was not, iso[DRV_ISO_HDR + buf * DRV_ISO_LIST + k] = ids; three buffers used in
+     rotation (step t reads buffer t % 3, fills (t + 1) % 3, clears (t + 2) % 3); iso_done[e] = tick of e's last finished step;
+     iso_hw[t & 1][b] = hardware id (XCC | SE | SH | CU | SIMD) block b of step t ran on.  None of this is simulation state:
+     it is allocated outside the checkpointed arrays and starts over at dynenv_checkpoint_load. */
   int* iso;
   int* iso_done;
+  unsigned* iso_hw;
   int tick, iso_on;  /* iso_on: 0 off, 1 isolation (E = one residency round), 2 slow environments first (E larger) */
 };
 #ifndef DRV_ISO_MAX
 #define DRV_ISO_MAX 64   /* at most this many environments get a SIMD of their own (iso_on = 1) */
 #endif
 #define DRV_ISO_LIST 256 /* capacity of a list; iso_on = 2 (more environments than fit at once) starts up to this many slow ones first */
+#define DRV_ISO_HDR 16    /* header words of DrvState.iso in front of the three lists */
+#define DRV_ISO_WORDS (DRV_ISO_HDR + 3 * DRV_ISO_LIST)
 #define DRV_ISO_GROUPS 1024 /* SIMDs of an MI355X: blocks b, b + 1024, b + 2048, b + 3072 of a launch share one (measured) */

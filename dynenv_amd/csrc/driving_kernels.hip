@@ -1600,6 +1600,11 @@ DRV_PROF(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* d = g_dbgl + 
 // Every environment that is not in the list is the r-th of them in id order for exactly one block r: a bijection whatever the
 // list holds.  Returns the environment of this block, or -1 for a block without one (after the placeholder's wait).
 // ------------------------------------------------------------------------------------------------
+// hardware placement of this wave: XCC id, shader engine / array, CU and SIMD (HW_ID bits 15:8 and 5:4; wave slot and pipe dropped)
+DE_DEV unsigned drv_hw_simd_key() {
+  const unsigned hw = (unsigned)__builtin_amdgcn_s_getreg(63492) /* HW_REG_HW_ID, 32 bits */, xcc = (unsigned)__builtin_amdgcn_s_getreg(63508) /* XCC_ID */;
+  return ((xcc & 0xFu) << 16) | (hw & 0xFF30u);
+}
 DE_DEV int drv_iso_assign(const DrvState& S, int lane) {
   const int b = blockIdx.x, E = S.E;
   if (!S.iso_on) return b;
@@ -1608,8 +1613,28 @@ DE_DEV int drv_iso_assign(const DrvState& S, int lane) {
   int K = uniform_i(S.iso[buf]);
   const int cap = S.iso_on == 1 ? DRV_ISO_MAX : DRV_ISO_LIST;
   K = K < cap ? K : cap;
+  if (S.iso_on == 1) {
+    // Self-validation of the placement isolation relies on (blocks g, g + 1024, g + 2048, g + 3072 of the regular grid on one
+    // SIMD): every regular block records where it runs; the LAST spare block of the launch (it steps no environment) checks the
+    // record of the previous launch and publishes the verdict for the next one.  Wherever the pattern does not hold - another
+    // kernel sharing the device, a partitioned device, a different dispatcher - isolation stays off (K = 0): same results,
+    // same bijection, no placeholders holding wave slots for nothing.
+    if (b < E) { if (lane == 0) S.iso_hw[(size_t)(S.tick & 1) * (4 * DRV_ISO_GROUPS) + b] = drv_hw_simd_key(); }
+    else if (b == E + 3 * DRV_ISO_MAX - 1) {
+      const unsigned* hw = S.iso_hw + (size_t)((S.tick + 1) & 1) * (4 * DRV_ISO_GROUPS);
+      bool bad = false;
+      for (int g = lane; g < DRV_ISO_GROUPS; g += 64) {
+        const unsigned k0 = hw[g], k1 = hw[g + DRV_ISO_GROUPS], k2 = hw[g + 2 * DRV_ISO_GROUPS], k3 = hw[g + 3 * DRV_ISO_GROUPS];
+        bad |= k0 == 0xFFFFFFFFu || k0 != k1 || k0 != k2 || k0 != k3;
+      }
+      const bool ok = wave_ballot(bad) == 0ull;
+      if (lane == 0) { S.iso[8 + (S.tick + 1) % 3] = ok ? 1 : 0; if (!ok && S.tick > 1) atomicAdd(&S.iso[11], 1); }
+      return -1;
+    }
+    if (uniform_i(S.iso[8 + buf]) != 1) K = 0;
+  }
   if (K == 0) return b < E ? b : -1;
-  const int* H = S.iso + 8 + buf * DRV_ISO_LIST;
+  const int* H = S.iso + DRV_ISO_HDR + buf * DRV_ISO_LIST;
   int r;
   if (S.iso_on == 2) {
     // more environments than fit at once: the listed (slow) ones take the first blocks - they start with the launch instead of
@@ -1668,7 +1693,7 @@ DE_DEV void drv_iso_report(const DrvState& S, int e, int lane, unsigned long lon
   if (cycles > DRV_ISO_MIN && cycles > (slowest / 10) * DRV_ISO_TENTHS) atomicMax(&S.iso[3 + nxt], cycles);
   if (slowest > DRV_ISO_MIN && cycles > (slowest / 10) * DRV_ISO_TENTHS) {
     const int k = atomicAdd(&S.iso[nxt], 1);
-    if (k < DRV_ISO_LIST) S.iso[8 + nxt * DRV_ISO_LIST + k] = e;
+    if (k < DRV_ISO_LIST) S.iso[DRV_ISO_HDR + nxt * DRV_ISO_LIST + k] = e;
   }
   __atomic_store_n(&S.iso_done[e], S.tick, __ATOMIC_RELAXED);
 }

@@ -49,6 +49,7 @@ struct dynenv {
   bool partial;
   std::vector<void*> allocs;
   std::vector<size_t> alloc_bytes;  // checkpoint = these arrays, in allocation order
+  std::vector<void*> scratch;       // scheduling scratch (SIMD-isolation lists): NOT simulation state, never checkpointed
   hipEvent_t ev_begin = nullptr, ev_main = nullptr, ev_end = nullptr;  // dynenv_set_step_events (caller-owned)
 };
 
@@ -139,6 +140,26 @@ static int dev_alloc(dynenv* h, T** out, size_t count) {
   h->allocs.push_back(p);
   h->alloc_bytes.push_back(count * sizeof(T));
   *out = (T*)p;
+  return 0;
+}
+
+// device memory that is not part of the simulation state (never saved / restored by dynenv_checkpoint_*)
+template <typename T>
+static int dev_alloc_scratch(dynenv* h, T** out, size_t count) {
+  void* p = nullptr;
+  HIP_OK(hipMalloc(&p, count * sizeof(T)));
+  HIP_OK(hipMemset(p, 0, count * sizeof(T)));
+  h->scratch.push_back(p);
+  *out = (T*)p;
+  return 0;
+}
+// the SIMD-isolation scheduler starts from scratch: empty lists, placement "not validated yet", no environment "done"
+static int iso_reset(dynenv* h) {
+  DrvState& S = h->S;
+  S.tick = 0;
+  HIP_OK(hipMemset(S.iso, 0, sizeof(int) * DRV_ISO_WORDS));
+  HIP_OK(hipMemset(S.iso_done, 0xFF, sizeof(int) * (size_t)S.E));
+  HIP_OK(hipMemset(S.iso_hw, 0xFF, sizeof(unsigned) * 2 * 4 * DRV_ISO_GROUPS));
   return 0;
 }
 
@@ -418,8 +439,9 @@ int dynenv_create(const dynenv_cfg_t* cfg, dynenv_t** out) {
   rc |= dev_alloc(h, &S.s_hash, 2 * E * DRV_NS);
   rc |= dev_alloc(h, &S.s_imp, 4 * E * DRV_NS);
   rc |= dev_alloc(h, &S.lastcand, E * 64);
-  rc |= dev_alloc(h, &S.iso, 8 + 3 * DRV_ISO_LIST);
-  rc |= dev_alloc(h, &S.iso_done, E);
+  rc |= dev_alloc_scratch(h, &S.iso, DRV_ISO_WORDS);
+  rc |= dev_alloc_scratch(h, &S.iso_done, E);
+  rc |= dev_alloc_scratch(h, &S.iso_hw, 2 * 4 * DRV_ISO_GROUPS);
   if (rc) { dynenv_destroy(h); return DYNENV_ERR_HIP; }
   {
     // The slowest environments of the previous step get a SIMD to themselves (drv_iso_assign): only where the block -> SIMD
@@ -433,11 +455,7 @@ int dynenv_create(const dynenv_cfg_t* cfg, dynenv_t** out) {
       //    too long for the second round: +1.4 %);  2: more environments than fit at once - the slow ones simply start first
       S.iso_on = off || !dev256 ? 0 : (E == 4 * DRV_ISO_GROUPS ? (h->partial ? 0 : 1) : (E > 4 * DRV_ISO_GROUPS ? 2 : 0));
     }
-    S.tick = 0;
-    if (hipMemset(S.iso, 0, sizeof(int) * (8 + 3 * DRV_ISO_LIST)) != hipSuccess || hipMemset(S.iso_done, 0xFF, sizeof(int) * E) != hipSuccess) {
-      dynenv_destroy(h);
-      return fail(DYNENV_ERR_HIP, "hipMemset");
-    }
+    if (iso_reset(h)) { dynenv_destroy(h); return DYNENV_ERR_HIP; }
   }
   DrvConst c;
   build_consts(c);
@@ -455,6 +473,7 @@ void dynenv_destroy(dynenv_t* h) {
   if (!h) return;
   DeviceGuard guard_(h->cfg.device_id);
   for (void* p : h->allocs) hipFree(p);
+  for (void* p : h->scratch) hipFree(p);
   delete h;
 }
 
@@ -698,7 +717,7 @@ int dynenv_debug_counters(dynenv_t* h, int64_t* out4) {
   if (!h || !out4) return fail(DYNENV_ERR_ARG, "null argument");
   ON_DEVICE(h);
   if (h->robocup) {
-    for (int k = 0; k < 12; ++k) out4[k] = 0;
+    for (int k = 0; k < 16; ++k) out4[k] = 0;
 #ifdef DRV_PROFILE
     HIP_OK(hipDeviceSynchronize());
     { static unsigned long long d[4096 * 12]; HIP_OK(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_rcprof), sizeof(d))); FILE* f = fopen("gpurun_out/rcprof.txt", "w"); for (int k = 0; k < 4096; ++k) { for (int q = 0; q < 12; ++q) fprintf(f, "%llu ", d[12*k+q]); fprintf(f, "\n"); } fclose(f); }
@@ -709,15 +728,18 @@ int dynenv_debug_counters(dynenv_t* h, int64_t* out4) {
   HIP_OK(hipDeviceSynchronize());
   std::vector<int> envi((size_t)h->S.E * EI_COUNT);
   HIP_OK(hipMemcpy(envi.data(), h->S.envi, envi.size() * sizeof(int), hipMemcpyDeviceToHost));
-  for (int k = 0; k < 12; ++k) out4[k] = 0;
+  for (int k = 0; k < 16; ++k) out4[k] = 0;
   for (int e = 0; e < h->S.E; ++e)
     for (int k = 0; k < 10; ++k) out4[k] += envi[(size_t)e * EI_COUNT + EI_N_FAST + k];
   {  // SIMD isolation: how many environments the next step isolates, placeholders that gave up waiting (should stay 0)
-    int iso[8];
+    int iso[DRV_ISO_HDR];
     HIP_OK(hipMemcpy(iso, h->S.iso, sizeof(iso), hipMemcpyDeviceToHost));
-    const int k = iso[(h->S.tick + 1) % 3];
+    const int nxt = (h->S.tick + 1) % 3, k = iso[nxt];
     const int cap = h->S.iso_on == 1 ? DRV_ISO_MAX : DRV_ISO_LIST;
     out4[10] = h->S.iso_on ? (k < cap ? k : cap) : -1; out4[11] = iso[7];
+    // out[12]: isolation mode (0 off, 1 SIMD isolation, 2 slow environments first); out[13]: 1 = the next step found the block ->
+    // SIMD placement validated (mode 1 only; 0 = isolation is holding off); out[14]: launches whose placement did not validate
+    out4[12] = h->S.iso_on; out4[13] = h->S.iso_on == 1 ? iso[8 + nxt] : -1; out4[14] = iso[11]; out4[15] = 0;
   }
 #ifdef DRV_PROFILE
   { unsigned long long d[16]; HIP_OK(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_dbgr), sizeof(d))); FILE* f = fopen("gpurun_out/dbgr.txt", "w"); for (int k = 0; k < 16; ++k) fprintf(f, "%llu\n", d[k]); fclose(f); }
@@ -1004,7 +1026,7 @@ int dynenv_obs_unpack_peers_ranks(const float* packed_dev, int64_t src_stride_fl
 // exact checkpoint: every device array of the handle, bit for bit
 // ------------------------------------------------------------------------------------------------
 struct CkptHeader {
-  char magic[8];  // "DYNCKPT1"
+  char magic[8];  // "DYNCKPT2"
   int32_t abi_version, n_arrays;
   dynenv_cfg_t cfg;
   uint64_t payload_bytes;
@@ -1023,7 +1045,7 @@ int dynenv_checkpoint_save(dynenv_t* h, void* buf_host, size_t nbytes) {
   HIP_OK(hipDeviceSynchronize());
   CkptHeader hd;
   memset(&hd, 0, sizeof(hd));
-  memcpy(hd.magic, "DYNCKPT1", 8);
+  memcpy(hd.magic, "DYNCKPT2", 8);
   hd.abi_version = DYNENV_ABI_VERSION; hd.n_arrays = (int32_t)h->allocs.size(); hd.cfg = h->cfg;
   hd.cfg.seed = h->robocup ? h->R.seed : h->S.seed;
   hd.payload_bytes = ckpt_payload(h);
@@ -1043,7 +1065,7 @@ int dynenv_checkpoint_load(dynenv_t* h, const void* buf_host, size_t nbytes) {
   if (nbytes < sizeof(CkptHeader)) return fail(DYNENV_ERR_ARG, "not a checkpoint");
   CkptHeader hd;
   memcpy(&hd, buf_host, sizeof(hd));
-  if (memcmp(hd.magic, "DYNCKPT1", 8) != 0 || hd.abi_version != DYNENV_ABI_VERSION) return fail(DYNENV_ERR_ARG, "not a checkpoint of this ABI version");
+  if (memcmp(hd.magic, "DYNCKPT2", 8) != 0 || hd.abi_version != DYNENV_ABI_VERSION) return fail(DYNENV_ERR_ARG, "not a checkpoint of this ABI version");
   const dynenv_cfg_t& a = hd.cfg; const dynenv_cfg_t& b = h->cfg;
   if (a.env_type != b.env_type || a.num_envs != b.num_envs || a.n_players != b.n_players || a.obs_type != b.obs_type ||
       a.noise_type != b.noise_type || a.noise_magnitude != b.noise_magnitude || a.env_id_offset != b.env_id_offset || a.flags != b.flags)
@@ -1058,6 +1080,9 @@ int dynenv_checkpoint_load(dynenv_t* h, const void* buf_host, size_t nbytes) {
   }
   h->cfg.seed = a.seed;
   if (h->robocup) h->R.seed = a.seed; else h->S.seed = a.seed;
+  // the scheduler's lists describe the timing of the steps this handle ran, not the state just restored: start them over
+  // (a list that keeps ids from before the restore could be appended to without having been cleared - ADVICE r3)
+  if (!h->robocup && iso_reset(h)) return DYNENV_ERR_HIP;
   return DYNENV_OK;
 }
 

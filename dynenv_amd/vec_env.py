@@ -484,10 +484,11 @@ class BatchedDynEnv(object):
         return f.value
 
     def debug_counters(self):
-        out = (C.c_int64 * 12)()
+        out = (C.c_int64 * 16)()
         _capi.check(self._lib.dynenv_debug_counters(self._h, out), "dynenv_debug_counters")
         return dict(fast=out[0], quiescent=out[1], contact=out[2], slot_sum=out[3], why_cand=out[4], why_moving=out[5],
-                    why_inert=out[6], steady=out[7], light=out[8], split=out[9], isolated_next=out[10], isolation_timeouts=out[11])
+                    why_inert=out[6], steady=out[7], light=out[8], split=out[9], isolated_next=out[10], isolation_timeouts=out[11],
+                    isolation_mode=out[12], placement_validated=out[13], placement_invalid_launches=out[14])
 
     def get_state(self, env=0):
         st = _capi.DrivingState() if self.env_type == DynEnvType.DRIVE else _capi.RoboCupState()

@@ -17,7 +17,8 @@
  *
  * All functions return 0 on success, <0 on error (dynenv_last_error() gives the text).  Pointers named *_dev are
  * DEVICE pointers (HBM) owned by the caller; `stream` is a hipStream_t passed as void* (NULL = default stream).
- * No torch types cross this boundary.  A handle is single-threaded; distinct handles are independent.
+ * No torch types cross this boundary.  A handle is single-threaded; distinct handles are independent (dynenv_last_error() is
+ * per calling thread).
  * There is NO CPU fallback: every entry fails with DYNENV_ERR_NO_DEVICE when no gfx950 device is usable.
  */
 #ifndef DYNENV_H
@@ -30,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DYNENV_ABI_VERSION 1
+#define DYNENV_ABI_VERSION 2 /* 2: dynenv_debug_counters writes 16 words; checkpoints hold simulation state only */
 
 /* DynEnvType / ObservationType / NoiseType values are the reference's (cutils.py:10-51) */
 #define DYNENV_ROBO_CUP 0
@@ -212,13 +213,16 @@ int dynenv_sync(dynenv_t* h, void* stream);
  * Synchronises the device. */
 int dynenv_error_flags(dynenv_t* h, int32_t* out);
 
-/* Diagnostics (Driving), summed over environments since the last reset: out12 = {substeps on the no-contact fast path,
+/* Diagnostics (Driving), summed over environments since the last reset: out16 = {substeps on the no-contact fast path,
  * on the quiescent shortcut, on the full contact path, sum of live contact-cache slots, contact-path substeps caused by
  * a changed candidate set / a moving body / a non-inert arbiter, substeps served by a steady replay, by the light mode,
  * contact-path substeps whose sweeps ran as split-lane general multi-level solves, the number of environments the next step
- * gives a SIMD of their own (-1: isolation off for this handle), isolation placeholders that gave up waiting (stays 0)}.
+ * gives a SIMD of their own (-1: isolation off for this handle), isolation placeholders that gave up waiting (stays 0),
+ * the handle's scheduling mode (0 none, 1 SIMD isolation, 2 slow environments first), whether the block -> SIMD placement
+ * isolation relies on validated for the next step (mode 1; it is re-checked on the device every launch and isolation holds
+ * off while it does not validate), launches whose placement did not validate, 0}.
  * Synchronises the device. */
-int dynenv_debug_counters(dynenv_t* h, int64_t* out12);
+int dynenv_debug_counters(dynenv_t* h, int64_t* out16);
 
 /* ---- de-duplicated transport format for the multi-GPU all-gather.  Where every agent row of an (env, time) ends in the
  * same tail (Driving Full: obstacles, pedestrians, lane rows = 160 of 232 floats), the packed form holds the A prefixes

@@ -306,3 +306,8 @@ def test_bench_launched_like_the_driver_with_two_ranks_on_this_gpu():
     assert d["config"]["rccl_world_size"] == 2 and "REHEARSAL" in d["config"]["parallelism"]
     assert abs(d["env_steps_per_s"] - 2 * 256 * 8 / (d["ms_per_step"] * 8e-3)) < 1e-6 * d["env_steps_per_s"]
     assert d["roofline"]["frac"] > 0 and d["cpu_baseline"] is None
+    # the line proves its own sharding and carries every rank's N = 1-equivalent whole-episode figure
+    sc = d["shard_check"]
+    assert sc["rccl_world_size"] == 2 and sc["env_id_offset_per_rank"] == [0, 256] and sc["envs_per_rank"] == [256, 256]
+    assert len(sc["value_full_episode_per_rank"]) == 2 and min(sc["value_full_episode_per_rank"]) > 0
+    assert d["timed_region"]["spread_over_one_episode"] == 8 and d["timed_region"]["whole_episodes"] == 0

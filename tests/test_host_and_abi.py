@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(capi):
     for n in names:
         assert hasattr(lib, n), "libdynenv_hip.so does not export %s declared in include/dynenv.h" % n
     assert set(names) <= set(capi.EXPORTS) | {"dynenv_abi_version", "dynenv_last_error"}
-    assert lib.dynenv_abi_version() == 1
+    assert lib.dynenv_abi_version() == capi.DYNENV_ABI_VERSION == 2
 
 
 def test_struct_sizes_match_the_header(capi):
@@ -52,7 +52,7 @@ def test_no_gpu_means_loud_failure_not_fallback(capi):
     if torch.cuda.is_available():
         pytest.skip("this check is for the CPU-only container")
     lib = capi.load()
-    cfg = capi.Cfg(1, 1, 4, 10, 0, 1, 0.0, 42, 0, 0, 0, 0)
+    cfg = capi.Cfg(capi.DYNENV_ABI_VERSION, 1, 4, 10, 0, 1, 0.0, 42, 0, 0, 0, 0)
     h = C.c_void_p()
     rc = lib.dynenv_create(C.byref(cfg), C.byref(h))
     assert rc == capi.ERR_NO_DEVICE and not h
@@ -70,9 +70,9 @@ def test_argument_validation(capi):
     h = C.c_void_p()
     bad = capi.Cfg(99, 1, 4, 10, 0, 1, 0.0, 42, 0, 0, 0, 0)
     assert lib.dynenv_create(C.byref(bad), C.byref(h)) == -1 and b"ABI" in lib.dynenv_last_error()
-    bad = capi.Cfg(1, 1, 0, 10, 0, 1, 0.0, 42, 0, 0, 0, 0)
+    bad = capi.Cfg(capi.DYNENV_ABI_VERSION, 1, 0, 10, 0, 1, 0.0, 42, 0, 0, 0, 0)
     assert lib.dynenv_create(C.byref(bad), C.byref(h)) == -1
-    bad = capi.Cfg(1, 1, 4, 10, 0, 1, 7.0, 42, 0, 0, 0, 0)  # environment_base.py:162-164
+    bad = capi.Cfg(capi.DYNENV_ABI_VERSION, 1, 4, 10, 0, 1, 7.0, 42, 0, 0, 0, 0)  # environment_base.py:162-164
     assert lib.dynenv_create(C.byref(bad), C.byref(h)) == -1 and b"noise magnitude" in lib.dynenv_last_error()
 
 
