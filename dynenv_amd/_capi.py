@@ -73,7 +73,7 @@ FLAG_RANDOM_INIT, FLAG_DETERMINISTIC_TURN, FLAG_CAN_FALL, FLAG_USE_OBS_REWARDS, 
 EXPORTS = ["dynenv_abi_version", "dynenv_last_error", "dynenv_create", "dynenv_destroy", "dynenv_layout",
            "dynenv_seed", "dynenv_reset", "dynenv_step", "dynenv_counts", "dynenv_episode_stats",
            "dynenv_state_size", "dynenv_get_state", "dynenv_set_state", "dynenv_sync", "dynenv_math_selftest",
-           "dynenv_error_flags", "dynenv_debug_counters", "dynenv_arrange_scratch_ints", "dynenv_arrange_plan",
+           "dynenv_error_flags", "dynenv_debug_counters", "dynenv_debug_placement", "dynenv_arrange_scratch_ints", "dynenv_arrange_plan",
            "dynenv_arrange_gather", "dynenv_arrange_scatter", "dynenv_arrange_pad", "dynenv_checkpoint_size",
            "dynenv_checkpoint_save", "dynenv_checkpoint_load", "dynenv_obs_pack", "dynenv_obs_unpack", "dynenv_obs_unpack_ranks",
            "dynenv_obs_pack_peers", "dynenv_obs_unpack_peers_ranks", "dynenv_step_head", "dynenv_full_obs", "dynenv_full_obs_dim",
@@ -152,6 +152,7 @@ def load():
     lib.dynenv_math_selftest.argtypes = [vp, vp, C.c_int32, vp, C.c_int32]
     lib.dynenv_error_flags.argtypes = [vp, C.POINTER(C.c_int32)]
     lib.dynenv_debug_counters.argtypes = [vp, C.POINTER(C.c_int64)]
+    lib.dynenv_debug_placement.argtypes = [vp, vp, C.c_int32]
     if lib.dynenv_abi_version() != DYNENV_ABI_VERSION:
         raise DynEnvError("ABI version mismatch between dynenv_amd and libdynenv_hip.so")
     _lib = lib

@@ -107,4 +107,6 @@ struct DrvState {
 #define DRV_ISO_LIST 256 /* capacity of a list; iso_on = 2 (more environments than fit at once) starts up to this many slow ones first */
 #define DRV_ISO_HDR 16    /* header words of DrvState.iso in front of the three lists */
 #define DRV_ISO_WORDS (DRV_ISO_HDR + 3 * DRV_ISO_LIST)
+#define DRV_ISO_G0 256     /* first SIMD group isolation uses: groups 256..511 are the ones whose four blocks always share a SIMD */
+#define DRV_ISO_GSPAN 256  /* ... and how many of them the device-side validation checks (DRV_ISO_MAX <= GSPAN) */
 #define DRV_ISO_GROUPS 1024 /* SIMDs of an MI355X: blocks b, b + 1024, b + 2048, b + 3072 of a launch share one (measured) */

@@ -1593,8 +1593,11 @@ DRV_PROF(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* d = g_dbgl + 
 // SIMD isolation of the slow environments.  A launch lasts as long as its slowest environment, and that environment's wave
 // shares its SIMD with three others: their instructions delay it by ~10 % (measured: 458 k cycles alone, 502 k with neighbours).
 // Which block steps which environment is free - results do not depend on it - so: the K environments that were slowest in the
-// previous step (list built by that step's epilogue) take blocks 0..K-1, the first wave slot of SIMD groups 0..K-1 (blocks b,
-// b + 1024, b + 2048, b + 3072 share a SIMD); the other three blocks of those groups run no environment - they sleep until
+// previous step (list built by that step's epilogue) take blocks G0..G0+K-1, the first wave slot of SIMD groups G0..G0+K-1 (blocks
+// b, b + 1024, b + 2048, b + 3072 share a SIMD for b in 256..511 in every launch looked at - tools/placement_probe.py: a CU receives
+// blocks c, c + 256, c + 512, ... in turn; its very first block (groups 0..255) and its very last (group c + 768, sometimes c + 512)
+// trade SIMDs in 3-35 % of the launches, the second block of every round never does -, G0 = 256); the
+// other three blocks of those groups run no environment - they sleep until
 // "their" slow environment has finished and hold the slots meanwhile - and the 3 K environments that would have sat there run
 // in the spare blocks behind the regular grid, which the dispatcher starts as soon as the first light environments finish.
 // Every environment that is not in the list is the r-th of them in id order for exactly one block r: a bijection whatever the
@@ -1615,15 +1618,15 @@ DE_DEV int drv_iso_assign(const DrvState& S, int lane) {
   K = K < cap ? K : cap;
   if (S.iso_on == 1) {
     // Self-validation of the placement isolation relies on (blocks g, g + 1024, g + 2048, g + 3072 of the regular grid on one
-    // SIMD): every regular block records where it runs; the LAST spare block of the launch (it steps no environment) checks the
+    // SIMD, for the groups G0 <= g < G0 + GSPAN it may use): every regular block records where it runs; the LAST spare block of the launch (it steps no environment) checks the
     // record of the previous launch and publishes the verdict for the next one.  Wherever the pattern does not hold - another
     // kernel sharing the device, a partitioned device, a different dispatcher - isolation stays off (K = 0): same results,
     // same bijection, no placeholders holding wave slots for nothing.
     if (b < E) { if (lane == 0) S.iso_hw[(size_t)(S.tick & 1) * (4 * DRV_ISO_GROUPS) + b] = drv_hw_simd_key(); }
-    else if (b == E + 3 * DRV_ISO_MAX - 1) {
+    else if (b == E + 3 * DRV_ISO_MAX) {  // (one block behind the spares, for this alone)
       const unsigned* hw = S.iso_hw + (size_t)((S.tick + 1) & 1) * (4 * DRV_ISO_GROUPS);
       bool bad = false;
-      for (int g = lane; g < DRV_ISO_GROUPS; g += 64) {
+      for (int g = DRV_ISO_G0 + lane; g < DRV_ISO_G0 + DRV_ISO_GSPAN; g += 64) {
         const unsigned k0 = hw[g], k1 = hw[g + DRV_ISO_GROUPS], k2 = hw[g + 2 * DRV_ISO_GROUPS], k3 = hw[g + 3 * DRV_ISO_GROUPS];
         bad |= k0 == 0xFFFFFFFFu || k0 != k1 || k0 != k2 || k0 != k3;
       }
@@ -1647,8 +1650,8 @@ DE_DEV int drv_iso_assign(const DrvState& S, int lane) {
     r = (E - 4 * K) + d;
   } else {
     const int g = b & (DRV_ISO_GROUPS - 1), pos = b / DRV_ISO_GROUPS;
-    if (g < K) {
-      const int h = uniform_i(H[g]);
+    if ((unsigned)(g - DRV_ISO_G0) < (unsigned)K) {
+      const int h = uniform_i(H[g - DRV_ISO_G0]);
       if (pos == 0) return h;
       // placeholder: hold this wave slot idle while the slow environment of this SIMD runs (bounded wait, then exit)
       int i = 0;
@@ -1659,7 +1662,7 @@ DE_DEV int drv_iso_assign(const DrvState& S, int lane) {
       if (i >= 96 && lane == 0) atomicAdd(&S.iso[7], 1);  // (diagnostic: a placeholder that gave up waiting; dynenv_debug_counters)
       return -1;
     }
-    r = pos * (DRV_ISO_GROUPS - K) + (g - K);
+    r = pos * (DRV_ISO_GROUPS - K) + (g < DRV_ISO_G0 ? g : g - K);
   }
   // the r-th environment id that is not in the list: least x with x = r + #{h in H : h <= x}
   int h0 = 0x7FFFFFFF, h1 = h0, h2 = h0, h3 = h0;

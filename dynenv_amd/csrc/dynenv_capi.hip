@@ -629,7 +629,7 @@ int dynenv_step_head(dynenv_t* h, const int32_t* actions_dev, const double* head
   // environment's observation as soon as its step is done, which fills the launch's tail
   // (with isolation on, 3 x DRV_ISO_MAX spare blocks behind the E regular ones: the environments displaced from a slow
   //  environment's SIMD run there - or nothing, and the block ends at once)
-  const unsigned stepGrid = (unsigned)h->S.E + (h->S.iso_on == 1 ? 3u * DRV_ISO_MAX : 0u);
+  const unsigned stepGrid = (unsigned)h->S.E + (h->S.iso_on == 1 ? 3u * DRV_ISO_MAX + 1u /* the placement validator */ : 0u);
   h->S.tick = (h->S.tick + 1) % (3 * (1 << 28));  // (wraps at a multiple of 3: the three isolation lists keep rotating in order)
   if (h->partial && obs_dev)
   {
@@ -748,6 +748,18 @@ int dynenv_debug_counters(dynenv_t* h, int64_t* out4) {
   { static unsigned long long d[4096 * 8]; HIP_OK(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_dbgl), sizeof(d))); FILE* f = fopen("gpurun_out/dbgl.txt", "w"); for (int k = 0; k < 4096; ++k) { for (int q = 0; q < 8; ++q) fprintf(f, "%llu ", d[8*k+q]); fprintf(f, "\n"); } fclose(f); }
 #endif
   return DYNENV_OK;
+}
+
+// diagnostics: where the blocks of the last Driving step ran (XCC << 16 | HW_ID bits: SE 15:13, SH 12, CU 11:8, SIMD 5:4), one
+// word per regular block; only recorded by handles in isolation mode 1.  Returns the number of words written (<= n), < 0 on error.
+int dynenv_debug_placement(dynenv_t* h, uint32_t* out, int32_t n) {
+  if (!h || !out || n < 0) return fail(DYNENV_ERR_ARG, "bad argument");
+  if (h->robocup || h->S.iso_on != 1) return 0;
+  ON_DEVICE(h);
+  HIP_OK(hipDeviceSynchronize());
+  const int m = n < 4 * DRV_ISO_GROUPS ? n : 4 * DRV_ISO_GROUPS;
+  HIP_OK(hipMemcpy(out, h->S.iso_hw + (size_t)(h->S.tick & 1) * (4 * DRV_ISO_GROUPS), sizeof(uint32_t) * m, hipMemcpyDeviceToHost));
+  return m;
 }
 
 int dynenv_get_state(dynenv_t* h, int32_t env, void* blob, size_t nbytes) {

@@ -490,6 +490,15 @@ class BatchedDynEnv(object):
                     why_inert=out[6], steady=out[7], light=out[8], split=out[9], isolated_next=out[10], isolation_timeouts=out[11],
                     isolation_mode=out[12], placement_validated=out[13], placement_invalid_launches=out[14])
 
+    def debug_placement(self):
+        """uint32 [4096]: XCC << 16 | SE, SH, CU, SIMD bits of HW_ID of every regular block of the last step (mode 1 handles), else empty"""
+        import numpy as np
+        out = np.zeros((4096,), np.uint32)
+        n = self._lib.dynenv_debug_placement(self._h, C.c_void_p(out.ctypes.data), out.size)
+        if n < 0:
+            _capi.check(n, "dynenv_debug_placement")
+        return out[:n]
+
     def get_state(self, env=0):
         st = _capi.DrivingState() if self.env_type == DynEnvType.DRIVE else _capi.RoboCupState()
         _capi.check(self._lib.dynenv_get_state(self._h, env, C.byref(st), C.sizeof(st)), "dynenv_get_state")

@@ -223,6 +223,10 @@ int dynenv_error_flags(dynenv_t* h, int32_t* out);
  * off while it does not validate), launches whose placement did not validate, 0}.
  * Synchronises the device. */
 int dynenv_debug_counters(dynenv_t* h, int64_t* out16);
+/* Diagnostics: where the regular blocks of the last Driving step ran - out[b] = XCC id << 16 | HW_ID bits (SE 15:13, SH 12,
+ * CU 11:8, SIMD 5:4) of block b; recorded only by handles in scheduling mode 1 (it is what the self-validation of the SIMD
+ * isolation reads).  Returns the number of words written (0: not recorded), < 0 on error.  Synchronises the device. */
+int dynenv_debug_placement(dynenv_t* h, uint32_t* out, int32_t n);
 
 /* ---- de-duplicated transport format for the multi-GPU all-gather.  Where every agent row of an (env, time) ends in the
  * same tail (Driving Full: obstacles, pedestrians, lane rows = 160 of 232 floats), the packed form holds the A prefixes
