@@ -306,3 +306,99 @@ def test_kat_grazing_ball_slides_on_the_coulomb_cone(gpu):
     assert sg.bvx > 0.5 * v_pre[0], "still sliding: the friction did not stop the ball"
     assert env.error_flags() == 0
     env.close()
+
+
+# ---- round 4: Chipmunk-specific behaviours through the C ABI (scenes and expected values: tests/kat_scenes_r4.py) --------------
+import kat_scenes_r4 as ks  # noqa: E402
+
+
+def _drv_pair(dynenv_amd, n_players, seed):
+    env = dynenv_amd.BatchedDynEnv(dynenv_amd.DynEnvType.DRIVE, 1, n_players, seed=seed)
+    ora = ol.OracleEnv(env_type=1, num_envs=1, n_players=n_players, seed=seed)
+    env.reset_flat()
+    ora.reset()
+    return env, ora
+
+
+def _car_tuple(c):
+    return [c.px, c.py, c.vx, c.vy, c.angle, c.w, c.crashed, c.finished]
+
+
+def test_kat_r4_offset_face_contact_two_point_manifold(gpu):
+    """K1: ContactPoints puts the contacts of an offset box-box face contact at the ends of the OVERLAP (here +2 and +5 above the
+    car's centre), and the inner one alone stops the car: v_x' = v_f - jn / m, w' = 2 jn / I, jn = (e v_pre + v_f) / (1/m + 4/I)."""
+    env, ora = _drv_pair(gpu, 2, 5)
+    g, want, chain_car = ks.k1_offset_face_contact(ks.Sim(env), 2)
+    o, _, _ = ks.k1_offset_face_contact(ks.Sim(ora), 2)
+    assert _car_tuple(g) == _car_tuple(o), "HIP == oracle, bit for bit"
+    assert g.crashed == 1 and g.vy == 0.0 and g.py == ks.CY and g.angle == 0.0
+    np.testing.assert_allclose([g.px, g.vx, g.w], [want["px"], want["vx"], want["w"]], rtol=1e-12)
+    np.testing.assert_allclose([g.px, g.vx, g.w], [chain_car["x"], chain_car["vx"], chain_car["w"]], rtol=1e-12)
+    assert g.w > 1.0, "an impulse 2 above the centre of mass spins the car counter-clockwise; corner contacts (+-5) would not"
+    assert env.error_flags() == 0
+    env.close()
+
+
+@pytest.mark.parametrize("target", [48, 49, 50, 51])
+def test_kat_r4_separate_fires_in_the_substep_the_shapes_part(gpu, target):
+    """K2: two robots slide past each other foot against foot, inside the slop (no impulse: closed-form slide); `touching` (set by
+    robotPushingDet at begin, cleared by RoboCupEnvironment.separate) must drop in the very substep the capsules part: parted
+    in substep 48 / 49 -> clear after env step 1; in 50 / 51 -> still set after step 1, clear after step 2."""
+    dynenv_amd = gpu
+    env, ora = _robocup_pair(dynenv_amd)
+    out = ks.k2_separate_in_substep(ks.Sim(env), target)
+    assert out == ks.k2_separate_in_substep(ks.Sim(ora), target), "HIP == oracle"
+    _same_robot(env.get_state(0).robots[0], ora.get_state(0).robots[0])
+    _same_robot(env.get_state(0).robots[1], ora.get_state(0).robots[1])
+    (ta1, tb1, _, _, dev1), (ta2, tb2, _, _, dev2) = out
+    assert dev1 < 1e-9 and dev2 < 1e-9, "the slide must stay the closed form"
+    assert (ta1, tb1) == ((0, 0) if target < 50 else (1, 1)) and (ta2, tb2) == (0, 0)
+    assert env.error_flags() == 0
+    env.close()
+
+
+def test_kat_r4_begin_returning_false_hides_the_pair_until_it_separates(gpu):
+    """K3: pedHit returns False for a car at |v| <= 1 (DrivingEnvironment.py:649, 664-665): Chipmunk then ignores the pair until the
+    shapes separate.  The car accelerates THROUGH the pedestrian (24 px/s while inside it): it moves and is rewarded exactly as if
+    the pedestrian were not there, the pedestrian exactly as if the car were not there, nobody dies, nobody crashes."""
+    dynenv_amd = gpu
+    runs = {}
+    for variant in ("with", "no_ped", "no_car"):
+        env, ora = _drv_pair(dynenv_amd, 10, 3)
+        runs[variant] = ks.k3_run(ks.Sim(env), variant)
+        if variant == "with":
+            assert runs[variant] == ks.k3_run(ks.Sim(ora), variant), "HIP == oracle, every step"
+        assert env.error_flags() == 0
+        env.close()
+    a, no_ped, no_car = runs["with"], runs["no_ped"], runs["no_car"]
+    assert a[0][0][2] == 0.0
+    assert [x[0] for x in a] == [x[0] for x in no_ped] and [x[2] for x in a] == [x[2] for x in no_ped]
+    assert [x[1] for x in a] == [x[1] for x in no_car]
+    assert all(x[1][4] == 0 for x in a) and all(x[0][6] == 0 for x in a)
+    v = [x[0][2] for x in a]
+    np.testing.assert_allclose(v[1:], [2.4 * k for k in range(1, len(v))], rtol=1e-5)
+    assert v[10] > 20.0 and a[10][0][0] + 10.0 > 691.0 and a[10][0][0] - 10.0 < 701.0, "the car is inside the pedestrian at 24 px/s"
+    assert a[-1][0][0] - 10.0 > 701.0
+
+
+@pytest.mark.parametrize("arrive", [9, 8])
+def test_kat_r4_unconverged_chain_order_levers_and_warm_start(gpu, arrive):
+    """K4: three cars and a wall, six coupled contacts that ten iterations leave far from converged: arbiter order, contact order,
+    lever arms and - arrive = 8 - cached impulses re-applied and carried over by hash decide the outcome; tests/kat_chain.py says
+    what it is (1e-11 for one solve; 1 % when a second, slightly rotated substep follows).  Leaving the cached impulses out would
+    change car 0's speed by 90 %, the other contact order flips the sign of its spin (tests/test_oracle_kats_r4.py)."""
+    env, ora = _drv_pair(gpu, 3, 5)
+    cars, want = ks.k4_chain_against_a_wall(ks.Sim(env), arrive)
+    ocars, _ = ks.k4_chain_against_a_wall(ks.Sim(ora), arrive)
+    for c, o in zip(cars, ocars):
+        assert _car_tuple(c) == _car_tuple(o), "HIP == oracle, bit for bit"
+    got = np.array([[c.px, c.vx, c.w] for c in cars])
+    exp = np.array([[b["x"], b["vx"], b["w"]] for b in want])
+    if arrive == 9:
+        np.testing.assert_allclose(got, exp, rtol=1e-11)
+    else:
+        np.testing.assert_allclose(got[:, 0], exp[:, 0], rtol=1e-9)
+        np.testing.assert_allclose(got[:2, 1], exp[:2, 1], rtol=1e-2)
+    assert abs(got[0, 2]) > 1e-3, "ten iterations must not have converged"
+    assert env.error_flags() == 0
+    env.close()
