@@ -786,7 +786,7 @@ DE_DEV void body_store_bias(DrvLds& L, int idx, const BodyV& b) {
 // the solves that take this path pay for what their caller keeps across the call.)
 // ------------------------------------------------------------------------------------------------
 struct DrvSplitRet { double jn0, jn1, jb0, jb1, jt0, jt1; int pk, pair, bits; };
-DE_DEV DrvSplitRet drv_solve_general_split(int lane, int myLevel_, int bodyAB, int lvl_, double nMass0, double nMass1, double bias0, double bias1,
+DE_OOL DrvSplitRet drv_solve_general_split(int lane, int myLevel_, int bodyAB, int lvl_, double nMass0, double nMass1, double bias0, double bias1,
                                            double bounce0, double bounce1, double jn0, double jn1, double jt0, double jt1, int pk, int pair,
                                            int bits3) {
   DrvLds& L = g_L;
@@ -862,126 +862,6 @@ DE_DEV DrvSplitRet drv_solve_general_split(int lane, int myLevel_, int bodyAB, i
   return r;
 }
 
-// ------------------------------------------------------------------------------------------------
-// A two-level solve of resting contacts (every active arbiter bias-only) whose contact graph falls into components of at most
-// TWO arbiters - a car leaning on a car that leans on a wall: the environments a launch ends with.  Through LDS (the pipelined
-// sweeps of drv_prestep_solve) such a solve takes 20 time steps of one pass each, and every time step pays an LDS store, a barrier
-// and an LDS load on top of the pass's ~76 dependent fp64 instructions (800 cycles against 494, measured).  Here the lane of the
-// component's FIRST arbiter (level 0) adopts the second one (its constants come over with ds_bpermute, once) and runs all ten
-// sweeps - X, then Y, then X again ... - on registers; the body the two share is handed from one arbiter's view to the other's with
-// a few selects.  Same passes, same operands, same order as the sequential sweep restricted to the component; components do not
-// interact.  Arbiters without a partner are components of one: the same code with the Y half masked off.
-// ------------------------------------------------------------------------------------------------
-struct DrvPairRet { double jb0, jb1, jn0, jn1, jt0, jt1; int pk, pair, bits; };
-DE_DEV DrvPairRet drv_solve_bias_multi(int lane, int myLevel_, int bodyAB, int peer, int lvl_, double nMass0, double nMass1, double bias0, double bias1,
-                                       double jn0, double jn1, double jt0, double jt1, int pk, int pair, int bits3) {
-  DrvLds& L = g_L;
-  DrvMailbox& M = L.u.mb;
-  const bool active = ((pk >> 30) & 1) != 0;
-  const int sl = lane < DRV_NS ? lane : 0;
-  const int xCount = active ? (pk >> 8) & 0xFF : 0;
-  const int xA = bodyAB & 0xFF, xB = bodyAB >> 8;
-  const int maxLevel = (int)(signed char)(uniform_i(lvl_) & 0xFF), period = (uniform_i(lvl_) >> 8) & 0xFF;
-  if (!(uniform_i(lvl_) >> 16)) {
-    // components of three or more arbiters, or three or more levels: the pipelined sweeps through LDS (see drv_prestep_solve:
-    // pass (arbiter a, sweep k) runs at time step level(a) + period * k)
-    BodyV a, b;
-    a.p = b.p = a.v = b.v = a.vb = b.vb = v2(0.0, 0.0); a.w = b.w = a.wb = b.wb = a.minv = b.minv = a.iinv = b.iinv = 0.0;
-    V2 n = v2(0.0, 0.0), r1[2], r2[2];
-    r1[0] = r1[1] = r2[0] = r2[1] = v2(0.0, 0.0);
-    if (active) {
-      body_load(L, xA, a);
-      body_load(L, xB, b);
-      r1[0] = vsub(v2(M.p1x[sl][0], M.p1y[sl][0]), a.p);
-      r2[0] = vsub(v2(M.p2x[sl][0], M.p2y[sl][0]), b.p);
-      if (xCount > 1) {
-        r1[1] = vsub(v2(M.p1x[sl][1], M.p1y[sl][1]), a.p);
-        r2[1] = vsub(v2(M.p2x[sl][1], M.p2y[sl][1]), b.p);
-      }
-      n = v2(M.nx[sl], M.ny[sl]);
-    }
-    const double nM[2] = {nMass0, nMass1}, bs[2] = {bias0, bias1};
-    double jb[2] = {0.0, 0.0};
-    const int nSteps = maxLevel + 1 + period * 9;
-    int due = myLevel_, passes = 0;
-    for (int t = 0; t < nSteps; ++t) {
-      if (active && t == due && passes < 10) {
-        body_load_bias(L, xA, a);
-        body_load_bias(L, xB, b);
-        arb_apply_bias_only(a, b, n, r1, r2, nM, bs, jb, xCount);
-        body_store_bias(L, xA, a);
-        body_store_bias(L, xB, b);
-        due += period; ++passes;
-      }
-      __syncthreads();
-    }
-    DrvPairRet r;
-    r.jn0 = jn0; r.jn1 = jn1; r.jt0 = jt0; r.jt1 = jt1; r.pk = pk; r.pair = pair; r.bits = bits3;
-    r.jb0 = jb[0]; r.jb1 = jb[1];
-    return r;
-  }
-  BodyV xa, xb;
-  xa.p = xb.p = xa.v = xb.v = xa.vb = xb.vb = v2(0.0, 0.0); xa.w = xb.w = xa.wb = xb.wb = xa.minv = xb.minv = xa.iinv = xb.iinv = 0.0;
-  V2 xn = v2(0.0, 0.0), xr1[2], xr2[2];
-  xr1[0] = xr1[1] = xr2[0] = xr2[1] = v2(0.0, 0.0);
-  if (active) {  // r1, r2, n rebuilt from the mailbox exactly as the prestep did
-    body_load(L, xA, xa);
-    body_load(L, xB, xb);
-    xr1[0] = vsub(v2(M.p1x[sl][0], M.p1y[sl][0]), xa.p);
-    xr2[0] = vsub(v2(M.p2x[sl][0], M.p2y[sl][0]), xb.p);
-    if (xCount > 1) {
-      xr1[1] = vsub(v2(M.p1x[sl][1], M.p1y[sl][1]), xa.p);
-      xr2[1] = vsub(v2(M.p2x[sl][1], M.p2y[sl][1]), xb.p);
-    }
-    xn = v2(M.nx[sl], M.ny[sl]);
-  }
-  const double xnM[2] = {nMass0, nMass1}, xbias[2] = {bias0, bias1};
-  const bool worker = active && myLevel_ == 0;
-  const bool hasY = worker && peer >= 0;
-  const int src = peer >= 0 ? peer : lane;  // (every lane takes part in the exchange; lanes without a partner read themselves)
-  V2 yn, yr1[2], yr2[2];
-  yn = v2(lane_read_d(xn.x, src), lane_read_d(xn.y, src));
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    yr1[q] = v2(lane_read_d(xr1[q].x, src), lane_read_d(xr1[q].y, src));
-    yr2[q] = v2(lane_read_d(xr2[q].x, src), lane_read_d(xr2[q].y, src));
-  }
-  const double ynM[2] = {lane_read_d(nMass0, src), lane_read_d(nMass1, src)}, ybias[2] = {lane_read_d(bias0, src), lane_read_d(bias1, src)};
-  const int yCount = hasY ? lane_read_i(xCount, src) : (lane_read_i(xCount, src), 0);
-  const int yAB = lane_read_i(bodyAB, src), yA = yAB & 0xFF, yB = yAB >> 8;
-  BodyV ya, yb;
-  ya.p = yb.p = ya.v = yb.v = ya.vb = yb.vb = v2(0.0, 0.0); ya.w = yb.w = ya.wb = yb.wb = ya.minv = yb.minv = ya.iinv = yb.iinv = 0.0;
-  if (hasY) { body_load(L, yA, ya); body_load(L, yB, yb); }
-  // which side of each arbiter the shared body is on (it is dynamic; the other three sides may be static)
-  const bool yaShared = yA == xA || yA == xB, xaShared = xA == yA || xA == yB;
-  double xjb[2] = {0.0, 0.0}, yjb[2] = {0.0, 0.0};
-#pragma unroll 1
-  for (int iter = 0; iter < 10; ++iter) {
-    if (worker) arb_apply_bias_only(xa, xb, xn, xr1, xr2, xnM, xbias, xjb, xCount);
-    if (hasY) {
-      // (the operands of these selects are made opaque first: a select of two loads from local objects is otherwise turned into a
-      //  load through a selected pointer, which pins the four BodyV in scratch for good - DESIGN.md section 3b)
-#define DRV_PICK(c, A, B) ([&] { double pa_ = (A), pb_ = (B); asm volatile("" : "+v"(pa_)); asm volatile("" : "+v"(pb_)); return (c) ? pa_ : pb_; }())
-      double sx = DRV_PICK(xaShared, xa.vb.x, xb.vb.x), sy = DRV_PICK(xaShared, xa.vb.y, xb.vb.y), sw = DRV_PICK(xaShared, xa.wb, xb.wb);
-      ya.vb.x = yaShared ? sx : ya.vb.x; ya.vb.y = yaShared ? sy : ya.vb.y; ya.wb = yaShared ? sw : ya.wb;
-      yb.vb.x = yaShared ? yb.vb.x : sx; yb.vb.y = yaShared ? yb.vb.y : sy; yb.wb = yaShared ? yb.wb : sw;
-      arb_apply_bias_only(ya, yb, yn, yr1, yr2, ynM, ybias, yjb, yCount);
-      sx = DRV_PICK(yaShared, ya.vb.x, yb.vb.x); sy = DRV_PICK(yaShared, ya.vb.y, yb.vb.y); sw = DRV_PICK(yaShared, ya.wb, yb.wb);
-      xa.vb.x = xaShared ? sx : xa.vb.x; xa.vb.y = xaShared ? sy : xa.vb.y; xa.wb = xaShared ? sw : xa.wb;
-      xb.vb.x = xaShared ? xb.vb.x : sx; xb.vb.y = xaShared ? xb.vb.y : sy; xb.wb = xaShared ? xb.wb : sw;
-#undef DRV_PICK
-    }
-  }
-  if (worker) { body_store_bias(L, xA, xa); body_store_bias(L, xB, xb); }
-  if (hasY) { if (yaShared) body_store_bias(L, yB, yb); else body_store_bias(L, yA, ya); }
-  __syncthreads();
-  DrvPairRet r;
-  r.jn0 = jn0; r.jn1 = jn1; r.jt0 = jt0; r.jt1 = jt1; r.pk = pk; r.pair = pair; r.bits = bits3;  // the caller's own values, handed back
-  const double f0 = lane_read_d(yjb[0], src), f1 = lane_read_d(yjb[1], src);  // an adopted arbiter's lane fetches its jBias from the worker
-  r.jb0 = worker ? xjb[0] : f0; r.jb1 = worker ? xjb[1] : f1;
-  return r;
-}
-
 DRV_PROF(__device__ unsigned long long g_dbgw[4096 * 12];)
 DRV_PROF(__device__ unsigned long long g_dbgp[4096 * 8];)
 DRV_PROF(__device__ unsigned long long g_dbgr[16];)
@@ -994,73 +874,6 @@ DRV_PROF(DE_DEV int prof_any(int v) { const uint64_t m = wave_ballot(v != 0); re
 #ifndef DRV_CONTACT_INLINE
 #define DRV_CONTACT_INLINE __forceinline__
 #endif
-
-// The single-level solve (no two active arbiters share a dynamic body - the commonest contact solve): each lane keeps its two bodies
-// in registers through the warm start and all 10 iterations, with one LDS load and one store (same arithmetic, no LDS round trip
-// per iteration).  A function of its own like the two multi-level solves: inlined into drv_prestep_solve, its operands were kept
-// alive - saved and reloaded through scratch, 45 registers - across the calls of the OTHER two (measured in the ISA, round 4).
-DE_DEV DrvSplitRet drv_solve_single(int lane, int bodyAB, double nMass0, double nMass1, double bias0, double bias1, double bounce0, double bounce1,
-                                    double jn0, double jn1, double jt0, double jt1, int pk, int pair, int bits3) {
-  DrvLds& L = g_L;
-  DrvMailbox& M = L.u.mb;
-  const bool active = ((pk >> 30) & 1) != 0;
-  const int sl = lane < DRV_NS ? lane : 0;
-  const int a_state = pk & 0xFF, a_count = (pk >> 8) & 0xFF;
-  const int bodyA = bodyAB & 0xFF, bodyB = bodyAB >> 8;
-  double jn[2] = {jn0, jn1}, jt[2] = {jt0, jt1}, jBias[2] = {0.0, 0.0};
-  const double nMass[2] = {nMass0, nMass1}, tMass[2] = {0.0, 0.0}, bias[2] = {bias0, bias1}, bounce[2] = {bounce0, bounce1};
-  const double arb_u = 0.0 * 0.0;
-  __syncthreads();
-  if (active) {
-    BodyV a, b;
-    body_load(L, bodyA, a);
-    body_load(L, bodyB, b);
-    V2 r1[2], r2[2];
-    r1[1] = r2[1] = v2(0.0, 0.0);
-    r1[0] = vsub(v2(M.p1x[sl][0], M.p1y[sl][0]), a.p);  // r1, r2, n rebuilt from the mailbox exactly as the prestep did
-    r2[0] = vsub(v2(M.p2x[sl][0], M.p2y[sl][0]), b.p);
-    if (a_count > 1) {
-      r1[1] = vsub(v2(M.p1x[sl][1], M.p1y[sl][1]), a.p);
-      r2[1] = vsub(v2(M.p2x[sl][1], M.p2y[sl][1]), b.p);
-    }
-    const V2 n = v2(M.nx[sl], M.ny[sl]);
-    if (a_state != ARB_FIRST) arb_warm_start(a, b, n, r1, r2, jn, jt, a_count);
-    if (wave_ballot(!arb_is_bias_only(a, b, jn, jt, bounce, a_count)) == 0ull) {  // all resting contacts: bias half only
-#pragma unroll 1
-      // (fixed-point exit: a sweep in which no accumulated bias impulse moved added +-0 to bias velocities that start at +0 and
-      //  can never be -0 - it changed nothing, and neither will any later sweep)
-      for (int iter = 0; iter < 10; ++iter)
-        if (wave_ballot(arb_apply_bias_only(a, b, n, r1, r2, nMass, bias, jBias, a_count)) == 0ull) break;
-    } else {
-#pragma unroll 1
-      for (int iter = 0; iter < 10; ++iter) arb_apply_impulse(a, b, n, r1, r2, nMass, tMass, bias, bounce, jBias, jn, jt, a_count, arb_u);
-    }
-    body_store_vel(L, bodyA, a);
-    body_store_vel(L, bodyB, b);
-  }
-  __syncthreads();
-  DrvSplitRet r;
-  r.jn0 = jn[0]; r.jn1 = jn[1]; r.jb0 = jBias[0]; r.jb1 = jBias[1]; r.jt0 = jt[0]; r.jt1 = jt[1];
-  r.pk = pk; r.pair = pair; r.bits = bits3;  // the caller's own values, handed back
-  return r;
-}
-
-// ONE out-of-line entry for the three solves.  With three call sites in drv_prestep_solve the operands of each arm were kept alive -
-// 21 to 45 registers through scratch - across the calls of the other arms (the machine CFG has edges between the arms that the
-// source does not); with one call site there are no other arms.  `mode` (wave-uniform): 0 single level, 1 multi-level resting
-// contacts (lvl bit 16: components of at most two arbiters -> one lane per component), 2 multi-level general (split lanes).
-DE_OOL DrvSplitRet drv_solve(int mode_, int lane, int myLevel, int bodyAB, int peer, int lvl, double nMass0, double nMass1, double bias0, double bias1,
-                             double bounce0, double bounce1, double jn0, double jn1, double jt0, double jt1, int pk, int pair, int bits3) {
-  const int mode = uniform_i(mode_);
-  if (mode == 0) return drv_solve_single(lane, bodyAB, nMass0, nMass1, bias0, bias1, bounce0, bounce1, jn0, jn1, jt0, jt1, pk, pair, bits3);
-  if (mode == 1) {
-    const DrvPairRet p = drv_solve_bias_multi(lane, myLevel, bodyAB, peer, lvl, nMass0, nMass1, bias0, bias1, jn0, jn1, jt0, jt1, pk, pair, bits3);
-    DrvSplitRet r;
-    r.jn0 = p.jn0; r.jn1 = p.jn1; r.jb0 = p.jb0; r.jb1 = p.jb1; r.jt0 = p.jt0; r.jt1 = p.jt1; r.pk = p.pk; r.pair = p.pair; r.bits = p.bits;
-    return r;
-  }
-  return drv_solve_general_split(lane, myLevel, bodyAB, lvl & 0xFFFF, nMass0, nMass1, bias0, bias1, bounce0, bounce1, jn0, jn1, jt0, jt1, pk, pair, bits3);
-}
 
 // pk: a_state | a_count << 8 | a_age << 16 | touched << 24 | freeMe << 25 | hashSame << 26 | prevInert << 27 | skipped << 28 | slotOcc << 29 | active << 30
 DE_OOL int drv_prestep_solve(int lane, int nCarPed, int pk, int a_pair, int bodyA, int bodyB, int myLevel,
@@ -1113,65 +926,93 @@ DRV_PROF(const unsigned long long P1 = __builtin_amdgcn_s_memtime();)
   velocity_update(L, lane, isCar, isPed);
 DRV_PROF(int profMode = 0; const unsigned long long P2 = __builtin_amdgcn_s_memtime();)
   bool tookSplit = false;  // (wave-uniform) the sweeps ran in drv_solve_general_split: counted in EI_N_SPLIT
-  if (activeMask) {
-    int mode = 0, peer = -1, pairsOk = 0;
-    if (maxLevel > 0) {
+  if (activeMask && maxLevel == 0) {
+    // No two active arbiters share a dynamic body: each lane keeps its two bodies in registers through the warm start
+    // and all 10 iterations, with one LDS load and one store (same arithmetic, no LDS round trip per iteration).
+    __syncthreads();
+    if (active) {
+      BodyV a, b;
+      body_load(L, bodyA, a);
+      body_load(L, bodyB, b);
+      if (a_state != ARB_FIRST) arb_warm_start(a, b, n, r1, r2, jn, jt, a_count);
+      if (wave_ballot(!arb_is_bias_only(a, b, jn, jt, bounce, a_count)) == 0ull) {  // all resting contacts: bias half only
+DRV_PROF(profMode = 1;)
+#pragma unroll 1
+        // (fixed-point exit: a sweep in which no accumulated bias impulse moved added +-0 to bias velocities that start at +0 and
+        //  can never be -0 - it changed nothing, and neither will any later sweep)
+        for (int iter = 0; iter < 10; ++iter)
+          if (wave_ballot(arb_apply_bias_only(a, b, n, r1, r2, nMass, bias, jBias, a_count)) == 0ull) break;
+      } else {
+DRV_PROF(profMode = 2;)
+#pragma unroll 1
+        for (int iter = 0; iter < 10; ++iter) arb_apply_impulse(a, b, n, r1, r2, nMass, tMass, bias, bounce, jBias, jn, jt, a_count, arb_u);
+      }
+      body_store_vel(L, bodyA, a);
+      body_store_vel(L, bodyB, b);
+    }
+    __syncthreads();
+  } else if (activeMask) {
+    __syncthreads();
+    // ---- warm start (cpArbiterApplyCachedImpulse; skipped on first contact), level by level ------------
+    for (int lv = 0; lv <= maxLevel; ++lv) {
+      if (active && myLevel == lv && a_state != ARB_FIRST) {
+        BodyV a, b;
+        body_load(L, bodyA, a);
+        body_load(L, bodyB, b);
+        arb_warm_start(a, b, n, r1, r2, jn, jt, a_count);
+        body_store_vel(L, bodyA, a);
+        body_store_vel(L, bodyB, b);
+      }
       __syncthreads();
-      // ---- warm start (cpArbiterApplyCachedImpulse; skipped on first contact), level by level ------------
-      for (int lv = 0; lv <= maxLevel; ++lv) {
-        if (active && myLevel == lv && a_state != ARB_FIRST) {
-          BodyV a, b;
-          body_load(L, bodyA, a);
-          body_load(L, bodyB, b);
-          arb_warm_start(a, b, n, r1, r2, jn, jt, a_count);
-          body_store_vel(L, bodyA, a);
-          body_store_vel(L, bodyB, b);
+    }
+    // ---- 10 sequential-impulse iterations (cpArbiterApplyImpulse) ---------------------------------------
+    BodyV a, b;
+    bool biasOnly = true;
+    if (active) {  // statics stay all-zero; p, minv, iinv are invariant
+      body_load(L, bodyA, a); body_load(L, bodyB, b);
+      biasOnly = arb_is_bias_only(a, b, jn, jt, bounce, a_count);
+    }
+    // PIPELINED SWEEPS.  Chipmunk runs 10 sweeps over the arbiters in order; sweep k + 1 of an arbiter only depends on sweep k of
+    // the arbiters it shares a body with.  Pass (arbiter a, sweep k) runs at time step  level(a) + period * k  with
+    // period = 1 + the largest level difference between two arbiters sharing a dynamic body: then for two such arbiters, a before
+    // b in canonical order,  (a, k) < (b, k) < (a, k + 1)  holds in time exactly as in the sequential sweep (level(a) <
+    // level(b) < level(a) + period), passes of one time step never share a body, and everything else commutes - the result is
+    // bit for bit the sequential one.  A chain of L resting cars (period 2) needs L + 18 time steps instead of 10 L.
+    const int nSteps = maxLevel + 1 + period * 9;
+    int due = myLevel, passes = 0;
+DRV_PROF(profMode = wave_ballot(!biasOnly) == 0ull ? 3 : 4;)
+    if (wave_ballot(!biasOnly) == 0ull) {
+      // every active arbiter is a resting contact being pushed out of penetration (the pile-ups that make up the launch's
+      // tail): only bias velocities move, through LDS
+      for (int t = 0; t < nSteps; ++t) {
+        if (active && t == due && passes < 10) {
+          body_load_bias(L, bodyA, a);
+          body_load_bias(L, bodyB, b);
+          arb_apply_bias_only(a, b, n, r1, r2, nMass, bias, jBias, a_count);
+          body_store_bias(L, bodyA, a);
+          body_store_bias(L, bodyB, b);
+          due += period; ++passes;
         }
         __syncthreads();
       }
-      // ---- 10 sequential-impulse iterations (cpArbiterApplyImpulse) ---------------------------------------
-      // PIPELINED SWEEPS (modes 1 without pairs, 2).  Chipmunk runs 10 sweeps over the arbiters in order; sweep k + 1 of an arbiter only
-      // depends on sweep k of the arbiters it shares a body with.  Pass (arbiter a, sweep k) runs at time step  level(a) + period * k
-      // with period = 1 + the largest level difference between two arbiters sharing a dynamic body: then for two such arbiters, a
-      // before b in canonical order,  (a, k) < (b, k) < (a, k + 1)  holds in time exactly as in the sequential sweep (level(a) <
-      // level(b) < level(a) + period), passes of one time step never share a body, and everything else commutes - the result is
-      // bit for bit the sequential one.  A chain of L resting cars (period 2) needs L + 18 time steps instead of 10 L.
-      bool biasOnly = true;
-      if (active) {
-        BodyV a, b;
-        body_load(L, bodyA, a); body_load(L, bodyB, b);
-        biasOnly = arb_is_bias_only(a, b, jn, jt, bounce, a_count);
-      }
-      // partners: the active arbiters this one shares a dynamic body with
-      int nPeers = 0;
-      for (uint64_t mm = wave_ballot(active); mm; mm &= mm - 1) {
-        const int s = __builtin_ctzll(mm);
-        const int ab = bcast_i(bodyA | (bodyB << 8), s), oa = ab & 0xFF, ob = ab >> 8;
-        const bool sh = active && s != lane && ((bodyA < DRV_SLOT_OBST && (bodyA == oa || bodyA == ob)) || (bodyB < DRV_SLOT_OBST && (bodyB == oa || bodyB == ob)));
-        if (sh) { peer = s; ++nPeers; }
-      }
-      // mode 1: every active arbiter is a resting contact being pushed out of penetration (the pile-ups that make up the launch's
-      // tail) - only bias velocities move; two levels in components of at most two arbiters -> one lane per component, on registers
-      // (drv_solve_bias_multi), anything else -> pipelined sweeps through LDS.  mode 2: the general sweeps on split lanes.
-      mode = wave_ballot(!biasOnly) == 0ull ? 1 : 2;
-      pairsOk = (mode == 1 && maxLevel == 1 && wave_ballot(nPeers > 1) == 0ull) ? 1 : 0;
-DRV_PROF(profMode = mode == 1 ? 3 : 4;)
+    } else [[unlikely]] {
+      // the general sweeps are a function of their own (drv_solve_general_split).  NOTHING of this frame lives across the call:
+      // what the verdicts below need - the packed slot state, the pair, the tangent impulses, three predicates - travels through
+      // the callee's registers and comes back in its return value (a value kept across the call would be spilled, and the
+      // allocator then spills it across the whole function, the bias-only loops that every pile-up runs included: measured)
+      const int bits3 = (restIn ? 1 : 0) | (bias[0] == 0.0 ? 2 : 0) | (bias[1] == 0.0 ? 4 : 0);
+      const DrvSplitRet sr = drv_solve_general_split(lane, myLevel, bodyA | (bodyB << 8), maxLevel_, nMass[0], nMass[1], bias[0], bias[1], bounce[0],
+                                                     bounce[1], jn[0], jn[1], jt[0], jt[1], pk, a_pair, bits3);
+      lane = fresh_lane();
+      pk = sr.pk; a_pair = sr.pair;
+      a_state = pk & 0xFF; a_count = (pk >> 8) & 0xFF; a_age = (pk >> 16) & 0xFF;
+      touched = (pk >> 24) & 1; freeMe = (pk >> 25) & 1; hashSame = (pk >> 26) & 1; prevInert = (pk >> 27) & 1;
+      skipped = (pk >> 28) & 1; slotOcc = (pk >> 29) & 1; active = (pk >> 30) & 1;
+      restIn = (sr.bits & 1) != 0;
+      bias[0] = (sr.bits & 2) ? 0.0 : 1.0; bias[1] = (sr.bits & 4) ? 0.0 : 1.0;  // (only compared with zero from here on)
+      jn[0] = sr.jn0; jn[1] = sr.jn1; jBias[0] = sr.jb0; jBias[1] = sr.jb1; jt[0] = sr.jt0; jt[1] = sr.jt1;
+      tookSplit = true;
     }
-    // ONE call for all three solves; NOTHING of this frame lives across it: what the verdicts below need - the packed slot state,
-    // the pair, the tangent impulses, three predicates - travels through the callee's registers and comes back in its return value
-    // (a value kept across the call would be spilled, and the allocator then spills it across the whole function: measured)
-    const int bits3 = (restIn ? 1 : 0) | (bias[0] == 0.0 ? 2 : 0) | (bias[1] == 0.0 ? 4 : 0);
-    const DrvSplitRet sr = drv_solve(mode, lane, myLevel, bodyA | (bodyB << 8), peer, (maxLevel & 0xFF) | (period << 8) | (pairsOk << 16), nMass[0], nMass[1],
-                                     bias[0], bias[1], bounce[0], bounce[1], jn[0], jn[1], jt[0], jt[1], pk, a_pair, bits3);
-    lane = fresh_lane();
-    pk = sr.pk; a_pair = sr.pair;
-    a_state = pk & 0xFF; a_count = (pk >> 8) & 0xFF; a_age = (pk >> 16) & 0xFF;
-    touched = (pk >> 24) & 1; freeMe = (pk >> 25) & 1; hashSame = (pk >> 26) & 1; prevInert = (pk >> 27) & 1;
-    skipped = (pk >> 28) & 1; slotOcc = (pk >> 29) & 1; active = (pk >> 30) & 1;
-    restIn = (sr.bits & 1) != 0;
-    bias[0] = (sr.bits & 2) ? 0.0 : 1.0; bias[1] = (sr.bits & 4) ? 0.0 : 1.0;  // (only compared with zero from here on)
-    jn[0] = sr.jn0; jn[1] = sr.jn1; jBias[0] = sr.jb0; jBias[1] = sr.jb1; jt[0] = sr.jt0; jt[1] = sr.jt1;
-    tookSplit = uniform_i(mode) == 2;
   }
 DRV_PROF(const unsigned long long P3 = __builtin_amdgcn_s_memtime();)
   // arbiters that were active this step are NORMAL from the next step on (cpSpaceStep resets the state)

@@ -378,3 +378,62 @@ def test_robocup_partial_parity(gpu, n, E, seed, noise, magn, steps):
     obs_r = env.episode_stats()[2].cpu().numpy()
     assert (obs_r > 0).any(), "observation rewards should have been paid"
     env.close()
+
+
+def _resting_chain_scene(st, rng):
+    """2..4 crashed cars in a row (random types, lateral offsets, overlaps above and below the collision slop), optionally a dead
+    pedestrian wedged in and an obstacle at the end: resting contacts that share bodies - the two- and three-level solves a launch's
+    slowest environments run (drv_solve_bias_multi / drv_solve_general_split), in every arrangement of who is shape a and shape b."""
+    import kat_scenes_r4 as ks
+    n = int(rng.integers(2, 5))
+    st.n_peds, st.n_obst = 0, 0
+    x, cy = 300.0 + float(rng.uniform(0, 50)), ks.CY
+    order = list(rng.permutation(n))         # which car index stands where: canonical pair order != spatial order
+    prev_hx = None
+    for pos, k in enumerate(order):
+        t = int(rng.integers(0, 4))
+        hx = [10.0, 15.0, 20.0, 25.0][t]
+        if prev_hx is not None:
+            x += prev_hx + hx - float(rng.choice([0.03, 0.5, 1.5, 3.0]))
+        ks._place_crashed_car(st.cars[k], t, x, cy + float(rng.uniform(-3.0, 3.0)), float(rng.choice([0.0, 0.0, 0.0, 2.0])) if pos == 0 else 0.0)
+        prev_hx = hx
+    for k in range(n, st.n_cars):
+        ks._place_crashed_car(st.cars[k], 0, 1500.0, 480.0 + 45.0 * k, 0.0)
+    if rng.random() < 0.6:
+        st.n_obst = 1
+        st.obst_x[0], st.obst_y[0] = x + prev_hx + 10.0 - float(rng.choice([0.03, 0.8, 2.0])), cy + float(rng.uniform(-6.0, 6.0))
+    if rng.random() < 0.3:   # a dead pedestrian (a circle, dynamic, shape a of its pair) leaning on the first car
+        st.n_peds = 1
+        p = st.peds[0]
+        c = st.cars[order[0]]
+        p.px, p.py, p.vx, p.vy = c.px - [10.0, 15.0, 20.0, 25.0][c.type] - 5.0 + float(rng.choice([0.05, 0.7])), c.py, 0.0, 0.0
+        p.road, p.side, p.dead, p.moving, p.speed, p.crossing, p.begin_crossing = 1, 0, 1, 0, 4, 0, 0
+
+
+def test_resting_chains_parity(gpu):
+    dynenv_amd, _, _ = gpu
+    E, A = 96, 5
+    env = dynenv_amd.BatchedDynEnv(dynenv_amd.DynEnvType.DRIVE, E, A, seed=9)
+    ora = ol.OracleEnv(num_envs=E, n_players=A, seed=9, threads=8)
+    env.reset_flat()
+    ora.reset()
+    rng = np.random.default_rng(2024)
+    for e in range(E):
+        st = ora.get_state(e)
+        _resting_chain_scene(st, rng)
+        env.set_state(e, st)
+        ora.set_state(e, st)
+    acts = np.ones((E, A, 2), np.int32)
+    multi = 0
+    for s in range(12):
+        og, rg, dg = env.step_flat(acts, auto_reset=False)
+        oc, rc, dc = ora.step(acts)
+        np.testing.assert_array_equal(rg.cpu().numpy(), rc, err_msg="rewards step %d" % s)
+        bad = np.argwhere(og.cpu().numpy() != oc)
+        assert len(bad) == 0, "observations differ at step %d, first (env, t, agent, column) = %s" % (s, bad[0])
+        for e in range(E):
+            _assert_state_equal(env.get_state(e), ora.get_state(e), "step %d env %d" % (s, e))
+        multi += sum(ora.active_contacts(e) >= 2 for e in range(E))
+    assert multi > 200, "the scenes must keep several arbiters active at once (%d)" % multi
+    assert env.error_flags() == 0 and ora.overflow() == 0
+    env.close()
