@@ -422,22 +422,29 @@ DE_DEV void body_store_vel(DrvLds& L, int idx, const BodyV& b) {
     L.vx[idx] = b.v.x; L.vy[idx] = b.v.y; L.w[idx] = b.w; L.vbx[idx] = b.vb.x; L.vby[idx] = b.vb.y; L.wb[idx] = b.wb;
   }
 }
-DE_DEV double k_scalar_body(const BodyV& b, V2 r, V2 n) {
-  double rcn = vcross(r, n);
-  return b.minv + b.iinv * rcn * rcn;
-}
+// The arbiter solver's arithmetic with its multiply-adds FUSED: the dms_* functions of include/dynenv_math.h, the same ones
+// oracle/cp_lite.c calls (k_scalar_body_f, relative_velocity_f, apply_impulse_f ...).
+DE_DEV double k_scalar_body(const BodyV& b, V2 r, V2 n) { return dms_k_scalar(b.minv, b.iinv, r.x, r.y, n.x, n.y); }
 DE_DEV V2 relative_velocity(const BodyV& a, const BodyV& b, V2 r1, V2 r2) {
-  V2 v1 = vadd(a.v, vmul(vperp(r1), a.w));
-  V2 v2s = vadd(b.v, vmul(vperp(r2), b.w));
+  V2 v1 = v2(dms_point_vx(a.v.x, r1.y, a.w), dms_point_vy(a.v.y, r1.x, a.w));
+  V2 v2s = v2(dms_point_vx(b.v.x, r2.y, b.w), dms_point_vy(b.v.y, r2.x, b.w));
   return vsub(v2s, v1);
 }
+DE_DEV V2 vrotate_f(V2 n, V2 j) { return v2(dms_rotate_x(n.x, n.y, j.x, j.y), dms_rotate_y(n.x, n.y, j.x, j.y)); }
+DE_DEV double vdot_f(V2 a, V2 b) { return dms_dot(a.x, a.y, b.x, b.y); }
 DE_DEV void apply_impulse(BodyV& b, V2 j, V2 r) {
-  b.v = vadd(b.v, vmul(j, b.minv));
-  b.w += b.iinv * vcross(r, j);
+  b.v = v2(dm_fma(j.x, b.minv, b.v.x), dm_fma(j.y, b.minv, b.v.y));
+  b.w = dm_fma(b.iinv, dms_cross(r.x, r.y, j.x, j.y), b.w);
 }
 DE_DEV void apply_bias_impulse(BodyV& b, V2 j, V2 r) {
-  b.vb = vadd(b.vb, vmul(j, b.minv));
-  b.wb += b.iinv * vcross(r, j);
+  b.vb = v2(dm_fma(j.x, b.minv, b.vb.x), dm_fma(j.y, b.minv, b.vb.y));
+  b.wb = dm_fma(b.iinv, dms_cross(r.x, r.y, j.x, j.y), b.wb);
+}
+// v_bias + perp(r) w_bias of the two bodies at their contact points, as the difference along n (vbn of cpArbiterApplyImpulse)
+DE_DEV double bias_rel_n(const BodyV& a, const BodyV& b, V2 r1, V2 r2, V2 n) {
+  const V2 vb1 = v2(dms_point_vx(a.vb.x, r1.y, a.wb), dms_point_vy(a.vb.y, r1.x, a.wb));
+  const V2 vb2 = v2(dms_point_vx(b.vb.x, r2.y, b.wb), dms_point_vy(b.vb.y, r2.x, b.wb));
+  return vdot_f(vsub(vb2, vb1), n);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -680,7 +687,7 @@ DE_DEV void arb_warm_start(BodyV& a, BodyV& b, V2 n, const V2* r1, const V2* r2,
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     if (c < count) {
-      V2 j = vrotate(n, v2(jn[c], jt[c]));
+      V2 j = vrotate_f(n, v2(jn[c], jt[c]));
       j = vmul(j, 1.0);  // dt_coef = dt/prev_dt = 1
       apply_impulse(a, vneg(j), r1[c]);
       apply_impulse(b, j, r2[c]);
@@ -694,9 +701,7 @@ DE_DEV void arb_apply_impulse(BodyV& a, BodyV& b, V2 n, const V2* r1, const V2* 
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     if (c < count) {
-      V2 vb1 = vadd(a.vb, vmul(vperp(r1[c]), a.wb));
-      V2 vb2 = vadd(b.vb, vmul(vperp(r2[c]), b.wb));
-      double vbn = vdot(vsub(vb2, vb1), n);
+      double vbn = bias_rel_n(a, b, r1[c], r2[c], n);
       // Bias-only contact (a resting contact that is still being pushed out of penetration): both bodies have all-zero
       // (+0) velocities, no accumulated impulse and no bounce.  Then vr = +-0, jn and jt come out as +0 again and the
       // velocity impulse is +-0, which leaves +0 velocities at +0: the velocity half of the pass is an exact no-op.
@@ -704,22 +709,19 @@ DE_DEV void arb_apply_impulse(BodyV& a, BodyV& b, V2 n, const V2* r1, const V2* 
                               __double_as_longlong(b.v.x) | __double_as_longlong(b.v.y) | __double_as_longlong(b.w) |
                               __double_as_longlong(jn[c]) | __double_as_longlong(jt[c]);
       if (zbits == 0ll && bounce[c] == 0.0) {
-        double jbn = (bias[c] - vbn) * nMass[c];
         double jbnOld = jBias[c];
-        jBias[c] = fmax_cp(jbnOld + jbn, 0.0);
+        jBias[c] = dms_acc_clamp0(bias[c] - vbn, nMass[c], jbnOld);
         V2 jb = vmul(n, jBias[c] - jbnOld);
         apply_bias_impulse(a, vneg(jb), r1[c]);
         apply_bias_impulse(b, jb, r2[c]);
         continue;
       }
       V2 vr = relative_velocity(a, b, r1[c], r2[c]);
-      double vrn = vdot(vr, n);
-      double jbn = (bias[c] - vbn) * nMass[c];
+      double vrn = vdot_f(vr, n);
       double jbnOld = jBias[c];
-      jBias[c] = fmax_cp(jbnOld + jbn, 0.0);
-      double jnn = -(bounce[c] + vrn) * nMass[c];
+      jBias[c] = dms_acc_clamp0(bias[c] - vbn, nMass[c], jbnOld);
       double jnOld = jn[c];
-      jn[c] = fmax_cp(jnOld + jnn, 0.0);
+      jn[c] = dms_acc_clamp0(-(bounce[c] + vrn), nMass[c], jnOld);
       // Friction: no Driving shape sets one (Chipmunk default u = 0), so arb.u = 0 * 0 = +0 and jtMax = u * jn = +0.
       // cpfclamp(x, -0, +0) = cpfmin(cpfmax(x, -0), +0) is +0 for EVERY x (also inf / NaN): jt stays +0 and its increment
       // is +0 - +0 = +0.  The tangent speed, tMass and the clamp are therefore not evaluated; the +0 increment still goes
@@ -727,7 +729,7 @@ DE_DEV void arb_apply_impulse(BodyV& a, BodyV& b, V2 n, const V2* r1, const V2* 
       V2 jb = vmul(n, jBias[c] - jbnOld);
       apply_bias_impulse(a, vneg(jb), r1[c]);
       apply_bias_impulse(b, jb, r2[c]);
-      V2 jj = vrotate(n, v2(jn[c] - jnOld, 0.0));
+      V2 jj = vrotate_f(n, v2(jn[c] - jnOld, 0.0));
       apply_impulse(a, vneg(jj), r1[c]);
       apply_impulse(b, jj, r2[c]);
     }
@@ -743,12 +745,9 @@ DE_DEV bool arb_apply_bias_only(BodyV& a, BodyV& b, V2 n, const V2* r1, const V2
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     if (c < count) {
-      V2 vb1 = vadd(a.vb, vmul(vperp(r1[c]), a.wb));
-      V2 vb2 = vadd(b.vb, vmul(vperp(r2[c]), b.wb));
-      double vbn = vdot(vsub(vb2, vb1), n);
-      double jbn = (bias[c] - vbn) * nMass[c];
+      double vbn = bias_rel_n(a, b, r1[c], r2[c], n);
       double jbnOld = jBias[c];
-      jBias[c] = fmax_cp(jbnOld + jbn, 0.0);
+      jBias[c] = dms_acc_clamp0(bias[c] - vbn, nMass[c], jbnOld);
       changed |= jBias[c] != jbnOld;
       V2 jb = vmul(n, jBias[c] - jbnOld);
       apply_bias_impulse(a, vneg(jb), r1[c]);
@@ -835,14 +834,14 @@ DE_OOL DrvSplitRet drv_solve_general_split(int lane, int myLevel_, int bodyAB, i
       for (int q = 0; q < 2; ++q) {
         if (q < count) {
           const V2 vr = relative_velocity(a, b, r1[q], r2[q]);
-          const double vn = vdot(vr, n);
-          // velocity: jnn = -(bounce + vrn) * nMass;  bias: jbn = (bias - vbn) * nMass  (x - y is x + (-y), negation is exact)
+          const double vn = vdot_f(vr, n);
+          // velocity: jn = max(jn - (bounce + vrn) * nMass, 0);  bias: jBias = max(jBias + (bias - vbn) * nMass, 0), each one fma
+          // (x - y is x + (-y), negation is exact)
           const double t0 = cq[q] + (biasLane ? -vn : vn);
-          const double jq = (biasLane ? t0 : -t0) * nM[q];
           const double old = acc[q];
-          acc[q] = fmax_cp(old + jq, 0.0);
+          acc[q] = dms_acc_clamp0(biasLane ? t0 : -t0, nM[q], old);
           const double dj = acc[q] - old;
-          const V2 jr = vrotate(n, v2(dj, 0.0));  // velocity: normal + (zero) tangent impulse through cpvrotate, as in the reference
+          const V2 jr = vrotate_f(n, v2(dj, 0.0));  // velocity: normal + (zero) tangent impulse through cpvrotate, as in the reference
           const V2 jl = vmul(n, dj);              // bias: no tangent term, not even a zero one (sign of zero)
           const V2 jj = biasLane ? jl : jr;
           apply_impulse(a, vneg(jj), r1[q]);
@@ -912,10 +911,10 @@ DRV_PROF(const unsigned long long P0 = __builtin_amdgcn_s_memtime();)
     for (int c = 0; c < 2; ++c) {
       if (c < a_count) {
         nMass[c] = 1.0 / (k_scalar_body(a, r1[c], n) + k_scalar_body(b, r2[c], n));
-        double dist = vdot(vadd(vsub(r2[c], r1[c]), body_delta), n);  // (tMass is not needed: see arb_apply_impulse)
+        double dist = vdot_f(vadd(vsub(r2[c], r1[c]), body_delta), n);  // (tMass is not needed: see arb_apply_impulse)
         bias[c] = -DE_CONTACT_BIAS_COEF * fmin_cp(0.0, dist + DE_COLLISION_SLOP) / DE_DT;
         jBias[c] = 0.0;
-        bounce[c] = vdot(relative_velocity(a, b, r1[c], r2[c]), n) * arb_e;
+        bounce[c] = vdot_f(relative_velocity(a, b, r1[c], r2[c]), n) * arb_e;
       }
     }
   }

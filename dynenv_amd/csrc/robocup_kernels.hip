@@ -888,22 +888,21 @@ DE_DEV void rbody_store_vel(RcLds& L, int idx, const RBody& b) {
     L.vx[idx] = b.v.x; L.vy[idx] = b.v.y; L.w[idx] = b.w; L.vbx[idx] = b.vb.x; L.vby[idx] = b.vb.y; L.wb[idx] = b.wb;
   }
 }
-DE_DEV double rk_scalar_body(const RBody& b, V2 r, V2 n) {
-  double rcn = vcross(r, n);
-  return b.minv + b.iinv * rcn * rcn;
-}
+// The arbiter solver's arithmetic with its multiply-adds FUSED: the dms_* functions of include/dynenv_math.h, the same ones
+// oracle/cp_lite.c calls (k_scalar_body_f, relative_velocity_f, apply_impulse_f ...).  (vrotate_f / vdot_f: driving_kernels.hip)
+DE_DEV double rk_scalar_body(const RBody& b, V2 r, V2 n) { return dms_k_scalar(b.minv, b.iinv, r.x, r.y, n.x, n.y); }
 DE_DEV V2 rrelative_velocity(const RBody& a, const RBody& b, V2 r1, V2 r2) {
-  V2 v1 = vadd(a.v, vmul(vperp(r1), a.w));
-  V2 v2s = vadd(b.v, vmul(vperp(r2), b.w));
+  V2 v1 = v2(dms_point_vx(a.v.x, r1.y, a.w), dms_point_vy(a.v.y, r1.x, a.w));
+  V2 v2s = v2(dms_point_vx(b.v.x, r2.y, b.w), dms_point_vy(b.v.y, r2.x, b.w));
   return vsub(v2s, v1);
 }
 DE_DEV void rapply_impulse(RBody& b, V2 j, V2 r) {
-  b.v = vadd(b.v, vmul(j, b.minv));
-  b.w += b.iinv * vcross(r, j);
+  b.v = v2(dm_fma(j.x, b.minv, b.v.x), dm_fma(j.y, b.minv, b.v.y));
+  b.w = dm_fma(b.iinv, dms_cross(r.x, r.y, j.x, j.y), b.w);
 }
 DE_DEV void rapply_bias_impulse(RBody& b, V2 j, V2 r) {
-  b.vb = vadd(b.vb, vmul(j, b.minv));
-  b.wb += b.iinv * vcross(r, j);
+  b.vb = v2(dm_fma(j.x, b.minv, b.vb.x), dm_fma(j.y, b.minv, b.vb.y));
+  b.wb = dm_fma(b.iinv, dms_cross(r.x, r.y, j.x, j.y), b.wb);
 }
 // arbiter material: e = e_a * e_b, u = u_a * u_b in narrowphase order (a = circle / lower slot)
 DE_DEV void pair_material(int i, int j, double& e, double& u) {
@@ -1307,10 +1306,10 @@ RC_PROF(C4 = __builtin_amdgcn_s_memtime();)
         if (q < a_count) {
           nMass[q] = 1.0 / (rk_scalar_body(a, r1[q], n) + rk_scalar_body(b, r2[q], n));
           tMass[q] = 1.0 / (rk_scalar_body(a, r1[q], vperp(n)) + rk_scalar_body(b, r2[q], vperp(n)));
-          const double dist = vdot(vadd(vsub(r2[q], r1[q]), body_delta), n);
+          const double dist = vdot_f(vadd(vsub(r2[q], r1[q]), body_delta), n);
           bias[q] = -DE_CONTACT_BIAS_COEF * fmin_cp(0.0, dist + DE_COLLISION_SLOP) / DE_DT;
           jBias[q] = 0.0;
-          bounce[q] = vdot(rrelative_velocity(a, b, r1[q], r2[q]), n) * arb_e;
+          bounce[q] = vdot_f(rrelative_velocity(a, b, r1[q], r2[q]), n) * arb_e;
         }
       }
     }
@@ -1385,7 +1384,7 @@ RC_PROF(T4 = __builtin_amdgcn_s_memtime();)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           if (q < a_count) {
-            V2 j = vrotate(n, v2(jn[q], jt[q]));
+            V2 j = vrotate_f(n, v2(jn[q], jt[q]));
             j = vmul(j, 1.0);
             rapply_impulse(a, vneg(j), r1[q]);
             rapply_impulse(b, j, r2[q]);
@@ -1429,17 +1428,15 @@ RC_PROF(T4 = __builtin_amdgcn_s_memtime();)
             for (int q = 0; q < 2; ++q) {
               if (q < a_count) {
                 const V2 vr = rrelative_velocity(a, b, r1[q], r2[q]);
-                const double vrn = vdot(vr, n);
-                const double vrt = vdot(vr, vperp(n));
-                const double jnn = -(bounce[q] + vrn) * nMass[q];
+                const double vrn = vdot_f(vr, n);
+                const double vrt = vdot_f(vr, vperp(n));
                 const double jnOld = jn[q];
-                jn[q] = fmax_cp(jnOld + jnn, 0.0);
+                jn[q] = dms_acc_clamp0(-(bounce[q] + vrn), nMass[q], jnOld);
                 const double jtMax = arb_u * jn[q];
-                const double jtt = -vrt * tMass[q];
                 const double jtOld = jt[q];
-                jt[q] = fclamp_cp(jtOld + jtt, -jtMax, jtMax);
+                jt[q] = fclamp_cp(dm_fma(-vrt, tMass[q], jtOld), -jtMax, jtMax);
                 const double dj = jn[q] - jnOld;
-                const V2 jr = vrotate(n, v2(dj, jt[q] - jtOld));
+                const V2 jr = vrotate_f(n, v2(dj, jt[q] - jtOld));
                 const V2 jl = vmul(n, dj);  // the bias impulse has no tangent term: not even a zero one (sign of zero)
                 const V2 jj = biasLane ? jl : jr;
                 rapply_impulse(a, vneg(jj), r1[q]);
@@ -1469,26 +1466,23 @@ RC_PROF(T4 = __builtin_amdgcn_s_memtime();)
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
             if (q < a_count) {
-              const V2 vb1 = vadd(a.vb, vmul(vperp(r1[q]), a.wb));
-              const V2 vb2 = vadd(b.vb, vmul(vperp(r2[q]), b.wb));
+              const V2 vb1 = v2(dms_point_vx(a.vb.x, r1[q].y, a.wb), dms_point_vy(a.vb.y, r1[q].x, a.wb));
+              const V2 vb2 = v2(dms_point_vx(b.vb.x, r2[q].y, b.wb), dms_point_vy(b.vb.y, r2[q].x, b.wb));
               const V2 vr = rrelative_velocity(a, b, r1[q], r2[q]);
-              const double vbn = vdot(vsub(vb2, vb1), n);
-              const double vrn = vdot(vr, n);
-              const double vrt = vdot(vr, vperp(n));
-              const double jbn = (bias[q] - vbn) * nMass[q];
+              const double vbn = vdot_f(vsub(vb2, vb1), n);
+              const double vrn = vdot_f(vr, n);
+              const double vrt = vdot_f(vr, vperp(n));
               const double jbnOld = jBias[q];
-              jBias[q] = fmax_cp(jbnOld + jbn, 0.0);
-              const double jnn = -(bounce[q] + vrn) * nMass[q];
+              jBias[q] = dms_acc_clamp0(bias[q] - vbn, nMass[q], jbnOld);
               const double jnOld = jn[q];
-              jn[q] = fmax_cp(jnOld + jnn, 0.0);
+              jn[q] = dms_acc_clamp0(-(bounce[q] + vrn), nMass[q], jnOld);
               const double jtMax = arb_u * jn[q];
-              const double jtt = -vrt * tMass[q];
               const double jtOld = jt[q];
-              jt[q] = fclamp_cp(jtOld + jtt, -jtMax, jtMax);
+              jt[q] = fclamp_cp(dm_fma(-vrt, tMass[q], jtOld), -jtMax, jtMax);
               const V2 jb = vmul(n, jBias[q] - jbnOld);
               rapply_bias_impulse(a, vneg(jb), r1[q]);
               rapply_bias_impulse(b, jb, r2[q]);
-              const V2 jj = vrotate(n, v2(jn[q] - jnOld, jt[q] - jtOld));
+              const V2 jj = vrotate_f(n, v2(jn[q] - jnOld, jt[q] - jtOld));
               rapply_impulse(a, vneg(jj), r1[q]);
               rapply_impulse(b, jj, r2[q]);
             }

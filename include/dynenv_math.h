@@ -21,7 +21,9 @@
 
 #if defined(__HIPCC__)
 #define DM_FN __host__ __device__ __forceinline__
+#ifndef DM_EXPERIMENT_CONTRACT_FAST /* (timing experiments only: what contraction everywhere would buy; never a product build) */
 #pragma clang fp contract(off)
+#endif
 #else
 #define DM_FN static inline
 #if defined(__GNUC__) && !defined(__clang__)
@@ -210,6 +212,36 @@ DM_FN int32_t dm_randint(uint32_t u, int32_t lo, int32_t hi) {
 }
 /* uniform double in [0,1) with 32-bit resolution (exact conversion) */
 DM_FN double dm_unit(uint32_t u) { return (double)u * 2.3283064365386962890625e-10; }
+
+/* ---- fused multiply-add, and the contact / joint solver's arithmetic built on it (round 4) -----------------------------------
+ * fma(a, b, c) = a * b + c with ONE rounding is an IEEE-754 operation, correctly rounded on gfx950 (v_fma_f64) and on the host
+ * (vfmadd with -mfma, libm's fma() otherwise): explicit calls give bit-identical results on both sides, which compiler
+ * contraction (-ffp-contract=fast) would not.  The sequential-impulse solver is the dependent fp64 instruction stream a launch's
+ * slowest environment spends its time in; with its multiply-adds fused it needs 23 instead of 38 instructions per contact for
+ * the position-correction half of cpArbiterApplyImpulse.  The fused forms below ARE the arithmetic contract of `Space.step`'s
+ * solver in this repository: oracle/cp_lite.c and the kernels call the same functions.  Against the unfused evaluation the
+ * results differ in the last place of single operations - inside what the reference itself leaves open (pymunk ships Chipmunk
+ * built with GCC in GNU C mode, whose default -ffp-contract=fast fuses exactly such expressions wherever the target has an
+ * FMA, e.g. on aarch64) and far inside north_star's 1e-4. */
+DM_FN double dm_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+DM_FN double dms_dot(double ax, double ay, double bx, double by) { return dm_fma(ax, bx, ay * by); }      /* a.x b.x + a.y b.y */
+DM_FN double dms_cross(double ax, double ay, double bx, double by) { return dm_fma(ax, by, -(ay * bx)); } /* a.x b.y - a.y b.x */
+/* velocity of the point r of a body: v + perp(r) w, perp(r) = (-r.y, r.x) */
+DM_FN double dms_point_vx(double vx, double ry, double w) { return dm_fma(-ry, w, vx); }
+DM_FN double dms_point_vy(double vy, double rx, double w) { return dm_fma(rx, w, vy); }
+/* cpvrotate(n, j) = (n.x j.x - n.y j.y, n.x j.y + n.y j.x) */
+DM_FN double dms_rotate_x(double nx, double ny, double jx, double jy) { return dm_fma(nx, jx, -(ny * jy)); }
+DM_FN double dms_rotate_y(double nx, double ny, double jx, double jy) { return dm_fma(nx, jy, ny * jx); }
+/* k_scalar_body: m_inv + i_inv (r x n)^2 */
+DM_FN double dms_k_scalar(double m_inv, double i_inv, double rx, double ry, double nx, double ny) {
+  const double rcn = dms_cross(rx, ry, nx, ny);
+  return dm_fma(i_inv * rcn, rcn, m_inv);
+}
+/* accumulate-and-clamp of cpArbiterApplyImpulse: max(acc + c * nMass, 0) */
+DM_FN double dms_acc_clamp0(double c, double nMass, double acc) {
+  const double s = dm_fma(c, nMass, acc);
+  return (s > 0.0) ? s : 0.0;
+}
 
 /* b ** n for small non-negative integer n by square-and-multiply (deterministic on host and device; the reference's
  * `0.9999 ** touchCntr` dice thresholds, RoboCupEnvironment.py:1065,1069,1117) */

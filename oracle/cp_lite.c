@@ -499,6 +499,29 @@ static inline void apply_bias_impulse(cpBody* b, cpv j, cpv r) {
   b->w_bias += b->i_inv * cpvcross(r, j);
 }
 
+/* The ARBITER solver's arithmetic with its multiply-adds fused (include/dynenv_math.h, "fused multiply-add ..."): the same dms_*
+ * functions the kernels call.  Operation order is Chipmunk's (cpArbiterPreStep, cpArbiterApplyCachedImpulse,
+ * cpArbiterApplyImpulse); only the rounding of a * b + c differs from the unfused helpers above, which the joints keep. */
+static inline double k_scalar_body_f(const cpBody* b, cpv r, cpv n) { return dms_k_scalar(b->m_inv, b->i_inv, r.x, r.y, n.x, n.y); }
+static inline cpv relative_velocity_f(const cpBody* a, const cpBody* b, cpv r1, cpv r2) {
+  cpv v1_sum = cpv_(dms_point_vx(a->v.x, r1.y, a->w), dms_point_vy(a->v.y, r1.x, a->w));
+  cpv v2_sum = cpv_(dms_point_vx(b->v.x, r2.y, b->w), dms_point_vy(b->v.y, r2.x, b->w));
+  return cpvsub(v2_sum, v1_sum);
+}
+static inline void apply_impulse_f(cpBody* b, cpv j, cpv r) {
+  b->v = cpv_(dm_fma(j.x, b->m_inv, b->v.x), dm_fma(j.y, b->m_inv, b->v.y));
+  b->w = dm_fma(b->i_inv, dms_cross(r.x, r.y, j.x, j.y), b->w);
+}
+static inline void apply_impulses_f(cpBody* a, cpBody* b, cpv r1, cpv r2, cpv j) {
+  apply_impulse_f(a, cpvneg(j), r1);
+  apply_impulse_f(b, j, r2);
+}
+static inline void apply_bias_impulse_f(cpBody* b, cpv j, cpv r) {
+  b->v_bias = cpv_(dm_fma(j.x, b->m_inv, b->v_bias.x), dm_fma(j.y, b->m_inv, b->v_bias.y));
+  b->w_bias = dm_fma(b->i_inv, dms_cross(r.x, r.y, j.x, j.y), b->w_bias);
+}
+static inline cpv cpvrotate_f(cpv n, cpv j) { return cpv_(dms_rotate_x(n.x, n.y, j.x, j.y), dms_rotate_y(n.x, n.y, j.x, j.y)); }
+
 static void arbiter_prestep(cpArbiter* arb, double dt, double slop, double bias) {
   cpBody *a = arb->body_a, *b = arb->body_b;
   cpv n = arb->n;
@@ -507,12 +530,15 @@ static void arbiter_prestep(cpArbiter* arb, double dt, double slop, double bias)
   for (i = 0; i < arb->count; ++i) {
     cpContact* con = &arb->contacts[i];
     double dist;
-    con->nMass = 1.0 / (k_scalar_body(a, con->r1, n) + k_scalar_body(b, con->r2, n));
-    con->tMass = 1.0 / (k_scalar_body(a, con->r1, cpvperp(n)) + k_scalar_body(b, con->r2, cpvperp(n)));
-    dist = cpvdot(cpvadd(cpvsub(con->r2, con->r1), body_delta), n);
+    cpv d, vr;
+    con->nMass = 1.0 / (k_scalar_body_f(a, con->r1, n) + k_scalar_body_f(b, con->r2, n));
+    con->tMass = 1.0 / (k_scalar_body_f(a, con->r1, cpvperp(n)) + k_scalar_body_f(b, con->r2, cpvperp(n)));
+    d = cpvadd(cpvsub(con->r2, con->r1), body_delta);
+    dist = dms_dot(d.x, d.y, n.x, n.y);
     con->bias = -bias * cpfmin(0.0, dist + slop) / dt;
     con->jBias = 0.0;
-    con->bounce = cpvdot(relative_velocity(a, b, con->r1, con->r2), n) * arb->e;
+    vr = relative_velocity_f(a, b, con->r1, con->r2);
+    con->bounce = dms_dot(vr.x, vr.y, n.x, n.y) * arb->e;
   }
 }
 
@@ -521,8 +547,8 @@ static void arbiter_apply_cached(cpArbiter* arb, double dt_coef) {
   if (arb->state == CP_ARB_FIRST) return;
   for (i = 0; i < arb->count; ++i) {
     cpContact* con = &arb->contacts[i];
-    cpv j = cpvrotate(arb->n, cpv_(con->jnAcc, con->jtAcc));
-    apply_impulses(arb->body_a, arb->body_b, con->r1, con->r2, cpvmult(j, dt_coef));
+    cpv j = cpvrotate_f(arb->n, cpv_(con->jnAcc, con->jtAcc));
+    apply_impulses_f(arb->body_a, arb->body_b, con->r1, con->r2, cpvmult(j, dt_coef));
   }
 }
 
@@ -535,29 +561,27 @@ static void arbiter_apply_impulse(cpArbiter* arb) {
     cpContact* con = &arb->contacts[i];
     double nMass = con->nMass;
     cpv r1 = con->r1, r2 = con->r2;
-    cpv vb1 = cpvadd(a->v_bias, cpvmult(cpvperp(r1), a->w_bias));
-    cpv vb2 = cpvadd(b->v_bias, cpvmult(cpvperp(r2), b->w_bias));
-    cpv vr = relative_velocity(a, b, r1, r2); /* surface_vr = 0 */
-    double vbn = cpvdot(cpvsub(vb2, vb1), n);
-    double vrn = cpvdot(vr, n);
-    double vrt = cpvdot(vr, cpvperp(n));
-    double jbn = (con->bias - vbn) * nMass;
+    cpv vb1 = cpv_(dms_point_vx(a->v_bias.x, r1.y, a->w_bias), dms_point_vy(a->v_bias.y, r1.x, a->w_bias));
+    cpv vb2 = cpv_(dms_point_vx(b->v_bias.x, r2.y, b->w_bias), dms_point_vy(b->v_bias.y, r2.x, b->w_bias));
+    cpv vr = relative_velocity_f(a, b, r1, r2); /* surface_vr = 0 */
+    cpv dvb = cpvsub(vb2, vb1);
+    double vbn = dms_dot(dvb.x, dvb.y, n.x, n.y);
+    double vrn = dms_dot(vr.x, vr.y, n.x, n.y);
+    double vrt = dms_dot(vr.x, vr.y, -n.y, n.x); /* vr . perp(n) */
     double jbnOld = con->jBias;
-    double jn, jnOld, jtMax, jt, jtOld;
-    con->jBias = cpfmax(jbnOld + jbn, 0.0);
-    jn = -(con->bounce + vrn) * nMass;
+    double jnOld, jtMax, jtOld;
+    con->jBias = dms_acc_clamp0(con->bias - vbn, nMass, jbnOld);
     jnOld = con->jnAcc;
-    con->jnAcc = cpfmax(jnOld + jn, 0.0);
+    con->jnAcc = dms_acc_clamp0(-(con->bounce + vrn), nMass, jnOld);
     jtMax = friction * con->jnAcc;
-    jt = -vrt * con->tMass;
     jtOld = con->jtAcc;
-    con->jtAcc = cpfclamp(jtOld + jt, -jtMax, jtMax);
+    con->jtAcc = cpfclamp(dm_fma(-vrt, con->tMass, jtOld), -jtMax, jtMax);
     {
       cpv jb = cpvmult(n, con->jBias - jbnOld);
-      apply_bias_impulse(a, cpvneg(jb), r1);
-      apply_bias_impulse(b, jb, r2);
+      apply_bias_impulse_f(a, cpvneg(jb), r1);
+      apply_bias_impulse_f(b, jb, r2);
     }
-    apply_impulses(a, b, r1, r2, cpvrotate(n, cpv_(con->jnAcc - jnOld, con->jtAcc - jtOld)));
+    apply_impulses_f(a, b, r1, r2, cpvrotate_f(n, cpv_(con->jnAcc - jnOld, con->jtAcc - jtOld)));
   }
 }
 
