@@ -942,44 +942,44 @@ template <bool CLEAN>
 DE_DEV void pivot_warm_start(const RcJoint& J, RcFeet& f, double jx, double jy) {
   if (J.hasPivot) {
     const V2 j = vmul(v2(jx, jy), 1.0);
-    f.vx0 = f.vx0 + (-j.x) * J.m; f.vy0 = f.vy0 + (-j.y) * J.m;
-    if (!CLEAN) f.w0 += J.i * vcross(v2(0.0, 0.0), vneg(j));
-    f.vx1 = f.vx1 + j.x * J.m; f.vy1 = f.vy1 + j.y * J.m;
-    if (!CLEAN) f.w1 += J.i * vcross(v2(0.0, 0.0), j);
+    f.vx0 = dm_fma(-j.x, J.m, f.vx0); f.vy0 = dm_fma(-j.y, J.m, f.vy0);
+    if (!CLEAN) f.w0 = dm_fma(J.i, dms_cross(0.0, 0.0, -j.x, -j.y), f.w0);
+    f.vx1 = dm_fma(j.x, J.m, f.vx1); f.vy1 = dm_fma(j.y, J.m, f.vy1);
+    if (!CLEAN) f.w1 = dm_fma(J.i, dms_cross(0.0, 0.0, j.x, j.y), f.w1);
   }
 }
 DE_DEV void rotary_warm_start(const RcJoint& J, RcFeet& f, double jr) {
   const double j = jr * 1.0;
-  f.w0 -= j * J.i;
-  f.w1 += j * J.i;
+  f.w0 = dm_fma(-j, J.i, f.w0);
+  f.w1 = dm_fma(j, J.i, f.w1);
 }
 template <bool CLEAN>
 DE_DEV void pivot_iterate(const RcJoint& J, RcFeet& f, double& jx, double& jy) {
   if (J.hasPivot) {
     // relative_velocity with r1 = r2 = 0
-    const V2 v1s = CLEAN ? v2(f.vx0, f.vy0) : vadd(v2(f.vx0, f.vy0), vmul(vperp(v2(0.0, 0.0)), f.w0));
-    const V2 v2s = CLEAN ? v2(f.vx1, f.vy1) : vadd(v2(f.vx1, f.vy1), vmul(vperp(v2(0.0, 0.0)), f.w1));
+    const V2 v1s = CLEAN ? v2(f.vx0, f.vy0) : v2(dms_point_vx(f.vx0, 0.0, f.w0), dms_point_vy(f.vy0, 0.0, f.w0));
+    const V2 v2s = CLEAN ? v2(f.vx1, f.vy1) : v2(dms_point_vx(f.vx1, 0.0, f.w1), dms_point_vy(f.vy1, 0.0, f.w1));
     const V2 vr = vsub(v2s, v1s);
     const V2 d = vsub(v2(J.pbx, J.pby), vr);
-    V2 j = v2(d.x * J.kk0 + d.y * J.kk1, d.x * J.kk2 + d.y * J.kk3);
+    V2 j = v2(dm_fma(d.x, J.kk0, d.y * J.kk1), dm_fma(d.x, J.kk2, d.y * J.kk3));
     const V2 jOld = v2(jx, jy);
     jx = jx + j.x; jy = jy + j.y;
     j = vsub(v2(jx, jy), jOld);
-    f.vx0 = f.vx0 + (-j.x) * J.m; f.vy0 = f.vy0 + (-j.y) * J.m;
-    if (!CLEAN) f.w0 += J.i * vcross(v2(0.0, 0.0), vneg(j));
-    f.vx1 = f.vx1 + j.x * J.m; f.vy1 = f.vy1 + j.y * J.m;
-    if (!CLEAN) f.w1 += J.i * vcross(v2(0.0, 0.0), j);
+    f.vx0 = dm_fma(-j.x, J.m, f.vx0); f.vy0 = dm_fma(-j.y, J.m, f.vy0);
+    if (!CLEAN) f.w0 = dm_fma(J.i, dms_cross(0.0, 0.0, -j.x, -j.y), f.w0);
+    f.vx1 = dm_fma(j.x, J.m, f.vx1); f.vy1 = dm_fma(j.y, J.m, f.vy1);
+    if (!CLEAN) f.w1 = dm_fma(J.i, dms_cross(0.0, 0.0, j.x, j.y), f.w1);
   }
 }
 DE_DEV void rotary_iterate(const RcJoint& J, RcFeet& f, double& jr) {
   if (J.rbias != 0.0) {
     const double wr = f.w1 - f.w0;
-    double j = -(J.rbias + wr) * J.iSum;
     const double jOld = jr;
-    if (J.rbias < 0.0) jr = fmax_cp(jOld + j, 0.0); else jr = fmin_cp(jOld + j, 0.0);
-    j = jr - jOld;
-    f.w0 -= j * J.i;
-    f.w1 += j * J.i;
+    const double s = dm_fma(-(J.rbias + wr), J.iSum, jOld);
+    if (J.rbias < 0.0) jr = fmax_cp(s, 0.0); else jr = fmin_cp(s, 0.0);
+    const double j = jr - jOld;
+    f.w0 = dm_fma(-j, J.i, f.w0);
+    f.w1 = dm_fma(j, J.i, f.w1);
   }
 }
 // general path: both constraints of this robot in the space's constraint order.  The pivot block is issued once for all

@@ -641,13 +641,15 @@ static void constraint_prestep(cpConstraint* c, double dt) {
   }
 }
 
+/* warm start and iteration of the two joints with their multiply-adds fused, like the arbiters' (dynenv_math.h); the prestep
+ * (K tensor, biases) is unfused: it runs once per substep, and the kernels take the pivot's K^-1 as a host-computed constant */
 static void constraint_apply_cached(cpConstraint* c, double dt_coef) {
   if (c->type == CP_JOINT_PIVOT) {
-    apply_impulses(c->a, c->b, c->r1, c->r2, cpvmult(c->jAcc2, dt_coef));
+    apply_impulses_f(c->a, c->b, c->r1, c->r2, cpvmult(c->jAcc2, dt_coef));
   } else {
     double j = c->jAcc * dt_coef;
-    c->a->w -= j * c->a->i_inv;
-    c->b->w += j * c->b->i_inv;
+    c->a->w = dm_fma(-j, c->a->i_inv, c->a->w);
+    c->b->w = dm_fma(j, c->b->i_inv, c->b->w);
   }
 }
 
@@ -655,23 +657,23 @@ static void constraint_apply_impulse(cpConstraint* c, double dt) {
   cpBody *a = c->a, *b = c->b;
   (void)dt;
   if (c->type == CP_JOINT_PIVOT) {
-    cpv vr = relative_velocity(a, b, c->r1, c->r2);
+    cpv vr = relative_velocity_f(a, b, c->r1, c->r2);
     cpv d = cpvsub(c->bias2, vr);
-    cpv j = cpv_(d.x * c->k[0] + d.y * c->k[1], d.x * c->k[2] + d.y * c->k[3]);
+    cpv j = cpv_(dm_fma(d.x, c->k[0], d.y * c->k[1]), dm_fma(d.x, c->k[2], d.y * c->k[3]));
     cpv jOld = c->jAcc2;
     c->jAcc2 = cpvadd(c->jAcc2, j); /* maxForce = INFINITY: no clamp */
     j = cpvsub(c->jAcc2, jOld);
-    apply_impulses(a, b, c->r1, c->r2, j);
+    apply_impulses_f(a, b, c->r1, c->r2, j);
   } else {
-    double wr, j, jOld;
+    double wr, s, j, jOld;
     if (c->bias == 0.0) return;
     wr = b->w - a->w;
-    j = -(c->bias + wr) * c->iSum;
     jOld = c->jAcc;
-    if (c->bias < 0.0) c->jAcc = cpfmax(jOld + j, 0.0); else c->jAcc = cpfmin(jOld + j, 0.0);
+    s = dm_fma(-(c->bias + wr), c->iSum, jOld);
+    if (c->bias < 0.0) c->jAcc = cpfmax(s, 0.0); else c->jAcc = cpfmin(s, 0.0);
     j = c->jAcc - jOld;
-    a->w -= j * a->i_inv;
-    b->w += j * b->i_inv;
+    a->w = dm_fma(-j, a->i_inv, a->w);
+    b->w = dm_fma(j, b->i_inv, b->w);
   }
 }
 
