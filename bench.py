@@ -459,7 +459,10 @@ def main():
             advance(L_ep - pos[0])
         at = [min(L_ep - 1, int((j + 0.5) * L_ep / n_spread)) for j in range(n_spread)]
         if dist is None:
-            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in at]
+            # an interval between two events holds the step's kernel(s) and ONE event record (a barrier packet, ~5 us on this stream),
+            # which a step in a run of steps does not contain: a third event right behind the second measures what a record costs,
+            # and that is subtracted (the whole-episode leg below does the same for its per-kernel figures)
+            evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in at]
             fence()
             for j, p_ in enumerate(at):
                 untimed_advance += p_ - pos[0]
@@ -467,11 +470,14 @@ def main():
                 evs[j][0].record()
                 advance(1)
                 evs[j][1].record()
+                evs[j][2].record()
             fence()
-            dt_ms = sum(a.elapsed_time(b) for a, b in evs)
+            ev_cost_ms = sum(b.elapsed_time(c) for a, b, c in evs)
+            dt_ms = sum(a.elapsed_time(b) for a, b, c in evs) - ev_cost_ms
             elapsed += dt_ms * 1e-3
             gpu_ms += dt_ms
-            timed_at.append("%d single steps at positions %s of one episode, HIP events around each" % (n_spread, at))
+            timed_at.append("%d single steps at positions %s of one episode, HIP events around each (minus the %.1f us one event record costs)"
+                            % (n_spread, at, ev_cost_ms / n_spread * 1e3))
         else:
             n_blocks = min(4, n_spread)
             sizes = [n_spread // n_blocks + (1 if b < n_spread % n_blocks else 0) for b in range(n_blocks)]
