@@ -201,7 +201,9 @@ def episode_leg(torch, device, workload, E, seed, n_players=None, env_id_offset=
     iso = None
     if not robocup:  # Driving: did the library isolate its slow environments on SIMDs of their own (scheduling only)?
         dc = env.debug_counters()
-        iso = {"on": dc["isolated_next"] >= 0, "isolated_in_last_step": max(int(dc["isolated_next"]), 0), "placeholder_timeouts": int(dc["isolation_timeouts"])}
+        iso = {"on": dc["isolated_next"] >= 0, "mode": int(dc["isolation_mode"]), "isolated_in_last_step": max(int(dc["isolated_next"]), 0),
+               "placeholder_timeouts": int(dc["isolation_timeouts"]), "placement_validated": int(dc["placement_validated"]),
+               "launches_whose_placement_did_not_validate": int(dc["placement_invalid_launches"])}
     env.close()
     out = {"workload": workload, "reference": ref, "envs": E, "n_agents": A, "steps": ep_steps, "ms_per_step": ms,
            "value": E * A / (ms * 1e-3), "unit": "agent-steps/s", "kernel_error_flags": err}
