@@ -108,6 +108,20 @@ WORKLOADS = {
 }
 
 
+def spread_positions(n, episode_len):
+    """positions inside one episode of the n timed steps that do not fill a whole episode: stratified, step j in the middle of the
+    j-th of n equal slices (so that the sample weighs the cheap start and the expensive end of an episode like the episode does)"""
+    return [min(episode_len - 1, int((j + 0.5) * episode_len / n)) for j in range(n)]
+
+
+def spread_blocks(n, episode_len, max_blocks=4):
+    """N > 1: the same n steps as up to `max_blocks` contiguous blocks (the pipelined transport overlaps inside a block), centred in
+    equal slices of the episode -> [(first step, number of steps)]"""
+    nb = min(max_blocks, n)
+    sizes = [n // nb + (1 if b < n % nb else 0) for b in range(nb)]
+    return [(max(0, min(episode_len - sizes[b], int((b + 0.5) * episode_len / nb) - sizes[b] // 2)), sizes[b]) for b in range(nb)]
+
+
 def kernel_source_sha():
     """sha256 over the kernel sources the shipped library is built from (dynenv_amd/csrc/* + include/*), first 16 hex digits:
     stamps profiles/pmc_traffic.json, so that a traffic figure measured on other kernels is never reported for these."""
@@ -459,7 +473,7 @@ def main():
         if pos[0]:
             untimed_advance += L_ep - pos[0]
             advance(L_ep - pos[0])
-        at = [min(L_ep - 1, int((j + 0.5) * L_ep / n_spread)) for j in range(n_spread)]
+        at = spread_positions(n_spread, L_ep)
         if dist is None:
             # an interval between two events holds the step's kernel(s) and ONE event record (a barrier packet, ~5 us on this stream),
             # which a step in a run of steps does not contain: a third event right behind the second measures what a record costs,
@@ -481,9 +495,8 @@ def main():
             timed_at.append("%d single steps at positions %s of one episode, HIP events around each (minus the %.1f us one event record costs)"
                             % (n_spread, at, ev_cost_ms / n_spread * 1e3))
         else:
-            n_blocks = min(4, n_spread)
-            sizes = [n_spread // n_blocks + (1 if b < n_spread % n_blocks else 0) for b in range(n_blocks)]
-            starts = [max(0, min(L_ep - sizes[b], int((b + 0.5) * L_ep / n_blocks) - sizes[b] // 2)) for b in range(n_blocks)]
+            blocks = spread_blocks(n_spread, L_ep)
+            n_blocks, starts, sizes = len(blocks), [b_[0] for b_ in blocks], [b_[1] for b_ in blocks]
             for b in range(n_blocks):
                 untimed_advance += starts[b] - pos[0]
                 advance(starts[b] - pos[0])

@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -311,3 +312,19 @@ def test_bench_reports_traffic_only_for_the_kernels_it_was_measured_on(tmp_path,
     assert t is None and "STALE" in d["traffic_source"]
     (prof / "pmc_traffic.json").unlink()
     assert bench.measured_traffic("drv_step_kernel") == (None, {"traffic_source": None})
+
+
+def test_bench_timed_steps_weigh_an_episode():
+    """the K timed steps of bench.py are a stratified sample of an episode (or whole episodes), never its cheap start"""
+    sys.path.insert(0, ROOT)
+    import bench
+    for n, L in ((20, 600), (1, 600), (7, 240), (599, 600), (600, 600)):
+        at = bench.spread_positions(n, L)
+        assert len(at) == n and all(0 <= p < L for p in at) and at == sorted(at) and len(set(at)) == n
+        # every one of the n equal slices of the episode holds exactly one timed step
+        assert [int(p * n / L) for p in at] == list(range(n))
+    assert bench.spread_positions(20, 600)[:3] == [15, 45, 75]
+    for n, L in ((20, 600), (3, 600), (8, 240), (1, 600)):
+        blocks = bench.spread_blocks(n, L)
+        assert sum(k for _, k in blocks) == n and all(0 <= a and a + k <= L for a, k in blocks)
+        assert all(blocks[i][0] + blocks[i][1] <= blocks[i + 1][0] for i in range(len(blocks) - 1))
