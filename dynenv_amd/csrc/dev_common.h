@@ -29,6 +29,9 @@ DE_HD double vdot(V2 a, V2 b) { return a.x * b.x + a.y * b.y; }
 DE_HD double vcross(V2 a, V2 b) { return a.x * b.y - a.y * b.x; }
 DE_HD V2 vperp(V2 a) { return v2(-a.y, a.x); }
 DE_HD V2 vrotate(V2 a, V2 b) { return v2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// fused forms (include/dynenv_math.h "fused multiply-add": the solver's and the polygon narrowphase's arithmetic)
+DE_HD double vdot_f(V2 a, V2 b) { return dms_dot(a.x, a.y, b.x, b.y); }
+DE_HD V2 vrotate_f(V2 n, V2 j) { return v2(dms_rotate_x(n.x, n.y, j.x, j.y), dms_rotate_y(n.x, n.y, j.x, j.y)); }
 DE_HD double vlensq(V2 a) { return vdot(a, a); }
 DE_HD V2 vlerp(V2 a, V2 b, double t) { return vadd(vmul(a, 1.0 - t), vmul(b, t)); }
 DE_HD double vlen(V2 v) { return dm_sqrt(v.x * v.x + v.y * v.y); }  // Vec2d.length

@@ -213,7 +213,7 @@ DE_DEV void box_world(BoxW& b, V2 p, double rc, double rs, double hx, double hy)
   const double nx[4] = {-1.0, 0.0, 1.0, 0.0}, ny[4] = {0.0, -1.0, 0.0, 1.0};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    b.v[i] = v2(rc * lx[i] - rs * ly[i] + p.x, rs * lx[i] + rc * ly[i] + p.y);
+    b.v[i] = v2(dms_xform_x(rc, rs, lx[i], ly[i], p.x), dms_xform_y(rc, rs, lx[i], ly[i], p.y));  // as cpShapeCacheBB in oracle/cp_lite.c
     b.n[i] = v2(rc * nx[i] - rs * ny[i], rs * nx[i] + rc * ny[i]);
   }
 }
@@ -247,7 +247,7 @@ struct BoxP {
 DE_DEV V2 boxp_vertex(const BoxP& b, int i) {
   const double lx = (i == 1 || i == 2) ? b.hx : -b.hx;
   const double ly = (i >= 2) ? b.hy : -b.hy;
-  return v2(b.c * lx - b.s * ly + b.p.x, b.s * lx + b.c * ly + b.p.y);
+  return v2(dms_xform_x(b.c, b.s, lx, ly, b.p.x), dms_xform_y(b.c, b.s, lx, ly, b.p.y));
 }
 DE_DEV V2 boxp_normal(const BoxP& b, int i) {
   const double nx = (i == 0) ? -1.0 : ((i == 2) ? 1.0 : 0.0);
@@ -278,7 +278,7 @@ DE_DEV void quad_argmax_first(double v, double& best, int& idx) {
 DE_DEV int poly_support_index(const BoxP& p, V2 n, int q) {
   double mx;
   int index;
-  quad_argmax_first(vdot(boxp_vertex(p, q), n), mx, index);
+  quad_argmax_first(vdot_f(boxp_vertex(p, q), n), mx, index);
   return index;
 }
 
@@ -328,11 +328,11 @@ DE_DEV void contact_points(const EdgeW& e1, const EdgeW& e2, V2 n, Contacts& out
 
 DE_DEV double sat_max_sep(const BoxP& a, const BoxP& b, int q, int& best) {
   const V2 n = boxp_normal(a, q);
-  const double d0 = vdot(n, boxp_vertex(a, q));
+  const double d0 = vdot_f(n, boxp_vertex(a, q));
   double minv = INFINITY;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    double d = vdot(n, boxp_vertex(b, j)) - d0;
+    double d = vdot_f(n, boxp_vertex(b, j)) - d0;
     if (d < minv) minv = d;
   }
   double maxsep;
@@ -430,8 +430,6 @@ DE_DEV V2 relative_velocity(const BodyV& a, const BodyV& b, V2 r1, V2 r2) {
   V2 v2s = v2(dms_point_vx(b.v.x, r2.y, b.w), dms_point_vy(b.v.y, r2.x, b.w));
   return vsub(v2s, v1);
 }
-DE_DEV V2 vrotate_f(V2 n, V2 j) { return v2(dms_rotate_x(n.x, n.y, j.x, j.y), dms_rotate_y(n.x, n.y, j.x, j.y)); }
-DE_DEV double vdot_f(V2 a, V2 b) { return dms_dot(a.x, a.y, b.x, b.y); }
 DE_DEV void apply_impulse(BodyV& b, V2 j, V2 r) {
   b.v = v2(dm_fma(j.x, b.minv, b.v.x), dm_fma(j.y, b.minv, b.v.y));
   b.w = dm_fma(b.iinv, dms_cross(r.x, r.y, j.x, j.y), b.w);

@@ -232,6 +232,9 @@ DM_FN double dms_point_vy(double vy, double rx, double w) { return dm_fma(rx, w,
 /* cpvrotate(n, j) = (n.x j.x - n.y j.y, n.x j.y + n.y j.x) */
 DM_FN double dms_rotate_x(double nx, double ny, double jx, double jy) { return dm_fma(nx, jx, -(ny * jy)); }
 DM_FN double dms_rotate_y(double nx, double ny, double jx, double jy) { return dm_fma(nx, jy, ny * jx); }
+/* a polygon vertex in world coordinates, cpTransformPoint: (c x - s y) + px, (s x + c y) + py, both multiply-adds fused */
+DM_FN double dms_xform_x(double c, double s, double x, double y, double px) { return dm_fma(c, x, dm_fma(-s, y, px)); }
+DM_FN double dms_xform_y(double c, double s, double x, double y, double py) { return dm_fma(s, x, dm_fma(c, y, py)); }
 /* k_scalar_body: m_inv + i_inv (r x n)^2 */
 DM_FN double dms_k_scalar(double m_inv, double i_inv, double rx, double ry, double nx, double ny) {
   const double rcn = dms_cross(rx, ry, nx, ny);

@@ -89,7 +89,9 @@ void cpShapeCacheBB(cpShape* s) {
     double l = INFINITY, r = -INFINITY, bt = INFINITY, t = -INFINITY;
     int i;
     for (i = 0; i < s->count; ++i) {
-      cpv v = xform_point(b, s->local[i].v0);
+      /* polygon vertices: both multiply-adds fused (dms_xform_x/y, dynenv_math.h), as the kernels' boxp_vertex / box_world */
+      cpv v = cpv_(dms_xform_x(b->rot.x, b->rot.y, s->local[i].v0.x, s->local[i].v0.y, b->p.x),
+                   dms_xform_y(b->rot.x, b->rot.y, s->local[i].v0.x, s->local[i].v0.y, b->p.y));
       s->world[i].v0 = v;
       s->world[i].n = xform_vect(b, s->local[i].n);
       l = cpfmin(l, v.x); r = cpfmax(r, v.x); bt = cpfmin(bt, v.y); t = cpfmax(t, v.y);
@@ -222,7 +224,7 @@ typedef struct { cpEdgePoint a, b; double r; cpv n; } cpEdge;
 static int poly_support_index(const cpShape* p, cpv n) {
   double max = -INFINITY; int index = 0, i;
   for (i = 0; i < p->count; ++i) {
-    double d = cpvdot(p->world[i].v0, n);
+    double d = dms_dot(p->world[i].v0.x, p->world[i].v0.y, n.x, n.y);
     if (d > max) { max = d; index = i; }
   }
   return index;
@@ -289,10 +291,10 @@ static double sat_max_sep(const cpShape* a, const cpShape* b, int* best) {
   *best = 0;
   for (i = 0; i < a->count; ++i) {
     cpv n = a->world[i].n;
-    double d0 = cpvdot(n, a->world[i].v0);
+    double d0 = dms_dot(n.x, n.y, a->world[i].v0.x, a->world[i].v0.y);
     double minv = INFINITY;
     for (j = 0; j < b->count; ++j) {
-      double d = cpvdot(n, b->world[j].v0) - d0;
+      double d = dms_dot(n.x, n.y, b->world[j].v0.x, b->world[j].v0.y) - d0;
       if (d < minv) minv = d;
     }
     if (minv > maxsep) { maxsep = minv; *best = i; }
