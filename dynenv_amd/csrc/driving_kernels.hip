@@ -863,6 +863,7 @@ DRV_PROF(__device__ unsigned long long g_dbgw[4096 * 12];)
 DRV_PROF(__device__ unsigned long long g_dbgp[4096 * 8];)
 DRV_PROF(__device__ unsigned long long g_dbgr[16];)
 DRV_PROF(__device__ unsigned long long g_dbgl[4096 * 8];)  // stages of drv_light_substep, summed over the step's substeps
+DRV_PROF(__device__ unsigned long long g_dbgs[4096 * 8];)  // stages of the slot update (between narrowphase and prestep), summed over the step's calls
 DRV_PROF(DE_DEV int prof_any(int v) { const uint64_t m = wave_ballot(v != 0); return m ? bcast_i(v, __builtin_ctzll(m)) : 0; })
 // Which half of a substep is out of line: the COMMON part (game logic, position update, broadphase: drv_light_substep, a leaf
 // with nothing to save) is a function; the contact path is inlined into the kernel, which as the outermost frame never saves a
@@ -1227,28 +1228,33 @@ DRV_PROF(const unsigned long long T1 = __builtin_amdgcn_s_memtime();)
     }
   }
 
+DRV_PROF(const unsigned long long U1 = __builtin_amdgcn_s_memtime();)
   // ---- rank touched slots by canonical pair order ------------------------------------------------------
   const uint64_t touchedMask = wave_ballot(touched);
   const int nTouched = __popcll(touchedMask);
   int rank = 0;
-  for (uint64_t mm = touchedMask; mm; mm &= mm - 1) {
-    int b = __builtin_ctzll(mm);
-    int pk = bcast_i(a_pair, b);
-    rank += (pk < a_pair) ? 1 : 0;
-  }
+  if (nTouched > 1)  // (a lone touched slot has rank 0)
+    for (uint64_t mm = touchedMask; mm; mm &= mm - 1) {
+      int b = __builtin_ctzll(mm);
+      int pk = bcast_i(a_pair, b);
+      rank += (pk < a_pair) ? 1 : 0;
+    }
 
+DRV_PROF(const unsigned long long U2 = __builtin_amdgcn_s_memtime();)
   // ---- begin callbacks in canonical order (first contact only) ------------------------------------------
-  for (int k = 0; k < nTouched; ++k) {
-    uint64_t who = wave_ballot(touched && rank == k);
-    int b = __builtin_ctzll(who);
-    int st = bcast_i(a_state, b);
-    if (st != ARB_FIRST) continue;
-    int pk = bcast_i(a_pair, b);
-    bool keep = cb_begin(L, pk >> 8, pk & 0xFF, lane);
-    if (!keep && lane == b) a_state = ARB_IGNORE;
-    __syncthreads();
-  }
+  if (wave_ballot(touched && a_state == ARB_FIRST) != 0ull)  // (most calls have no first contact: the loop would only skip)
+    for (int k = 0; k < nTouched; ++k) {
+      uint64_t who = wave_ballot(touched && rank == k);
+      int b = __builtin_ctzll(who);
+      int st = bcast_i(a_state, b);
+      if (st != ARB_FIRST) continue;
+      int pk = bcast_i(a_pair, b);
+      bool keep = cb_begin(L, pk >> 8, pk & 0xFF, lane);
+      if (!keep && lane == b) a_state = ARB_IGNORE;
+      __syncthreads();
+    }
 
+DRV_PROF(const unsigned long long U3 = __builtin_amdgcn_s_memtime();)
   // ---- expiry of untouched slots (cpSpaceArbiterSetFilter; no `separate` handlers in Driving) -----------
   bool freeMe = false;
   if (slotOcc && !touched) {
@@ -1280,13 +1286,14 @@ DRV_PROF(const unsigned long long T1 = __builtin_amdgcn_s_memtime();)
     bool slotDirty = slotOcc && !cleanSlot && !(touched && a_state == ARB_IGNORE);
     for (int round = 0; round < DRV_NS; ++round) {
       int m = 0;
-      for (uint64_t mm = occLanes; mm; mm &= mm - 1) {
-        const int b = __builtin_ctzll(mm);
-        m |= bcast_i(slotDirty ? myBodies : 0, b);
-      }
+      for (uint64_t mm = occLanes & wave_ballot(slotDirty); mm; mm &= mm - 1) m |= bcast_i(myBodies, __builtin_ctzll(mm));  // (dirty slots only)
       if (m == dirtyBodies) break;
       dirtyBodies = m;
-      slotDirty = slotDirty || (cleanSlot && (myBodies & dirtyBodies) != 0);
+      // (if no clean slot touches a dirty body, nothing spreads: the next round would find the same set - the usual case, a
+      //  frozen pair somewhere else in the scene beside the pile that is being relaxed)
+      const bool spreads = cleanSlot && !slotDirty && (myBodies & dirtyBodies) != 0;
+      if (wave_ballot(spreads) == 0ull) break;
+      slotDirty = slotDirty || spreads;
     }
     cleanSlot = cleanSlot && (myBodies & dirtyBodies) == 0;
   }
@@ -1298,30 +1305,40 @@ DRV_PROF(const unsigned long long T1 = __builtin_amdgcn_s_memtime();)
     if ((isCar || isPed) && !((keep >> lane) & 1)) { L.vbx[lane] = 0.0; L.vby[lane] = 0.0; L.wb[lane] = 0.0; }
   }
 
+DRV_PROF(const unsigned long long U4 = __builtin_amdgcn_s_memtime();)
   // ---- active arbiters: levels (arbiters sharing a dynamic body keep their canonical sequential order) --
   const bool active = solvable && !skipped;
   const uint64_t activeMask = wave_ballot(active);
   // `period` (pipelined sweeps, see drv_prestep_solve): 1 + the largest level difference between two arbiters that share a
   // dynamic body.  The first arbiter on a body has the lowest level of all arbiters on it (levels ascend along a body's
   // arbiters), so the difference to that one (bfirst) is the largest difference this arbiter has with any earlier one.
-  int myLevel = 0, maxLevel = -1, blvl = 0, bfirst = -1, period = 1;
-  for (int k = 0; k < nTouched; ++k) {
-    uint64_t who = wave_ballot(active && rank == k);
-    if (who == 0ull) continue;
-    int b = __builtin_ctzll(who);
-    int ba = bcast_i(bodyA, b), bb2 = bcast_i(bodyB, b);
-    int la = ba < DRV_SLOT_OBST ? bcast_i(blvl, ba) : 0;
-    int lb = bb2 < DRV_SLOT_OBST ? bcast_i(blvl, bb2) : 0;
-    int lv = la > lb ? la : lb;
-    const int fa = ba < DRV_SLOT_OBST ? bcast_i(bfirst, ba) : -1, fb = bb2 < DRV_SLOT_OBST ? bcast_i(bfirst, bb2) : -1;
-    const int lo = fa < 0 ? fb : (fb < 0 ? fa : (fa < fb ? fa : fb));  // lowest level of an earlier arbiter sharing a body (-1: none)
-    if (lo >= 0 && lv - lo + 1 > period) period = lv - lo + 1;
-    if (lane == b) myLevel = lv;
-    if (lane == ba || lane == bb2) { blvl = lv + 1; if (bfirst < 0) bfirst = lv; }  // static indices (>= 30) never equal a body lane (< 30)
-    maxLevel = lv > maxLevel ? lv : maxLevel;
+  int myLevel = 0, maxLevel = -1, period = 1;
+  const int nActive = __popcll(activeMask);
+  if (nActive == 1) maxLevel = 0;  // a lone active arbiter: level 0, nothing shared
+  else if (nActive > 1) {
+    // per body lane: level the next arbiter on this body gets | (level of the first arbiter on it + 1) << 8 (0: none yet) - one
+    // v_readlane per body instead of two, and the arbiter's two bodies come over in one
+    int bl = 0;
+    const int bodyAB = bodyA | (bodyB << 8);
+    for (int k = 0; k < nTouched; ++k) {
+      uint64_t who = wave_ballot(active && rank == k);
+      if (who == 0ull) continue;
+      int b = __builtin_ctzll(who);
+      const int ab = bcast_i(bodyAB, b), ba = ab & 0xFF, bb2 = ab >> 8;
+      const int pa = ba < DRV_SLOT_OBST ? bcast_i(bl, ba) : 0, pb = bb2 < DRV_SLOT_OBST ? bcast_i(bl, bb2) : 0;
+      const int la = pa & 0xFF, lb = pb & 0xFF;
+      int lv = la > lb ? la : lb;
+      const int fa = (pa >> 8) - 1, fb = (pb >> 8) - 1;
+      const int lo = fa < 0 ? fb : (fb < 0 ? fa : (fa < fb ? fa : fb));  // lowest level of an earlier arbiter sharing a body (-1: none)
+      if (lo >= 0 && lv - lo + 1 > period) period = lv - lo + 1;
+      if (lane == b) myLevel = lv;
+      if (lane == ba || lane == bb2) bl = (lv + 1) | (((bl >> 8) ? (bl >> 8) : lv + 1) << 8);  // static indices (>= 30) never equal a body lane (< 30)
+      maxLevel = lv > maxLevel ? lv : maxLevel;
+    }
   }
 
 DRV_PROF(const unsigned long long T2 = __builtin_amdgcn_s_memtime();)
+DRV_PROF(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* d = g_dbgs + blockIdx.x * 8; d[0] += U1 - T1; d[1] += U2 - U1; d[2] += U3 - U2; d[3] += U4 - U3; d[4] += T2 - U4; })
   // everything per-slot from here on - prestep, solve, the steady / inert verdicts and the slot record - happens inside the
   // function: nothing of the contact cache stays live in this frame across the call
   const int solveBits = drv_prestep_solve(lane, nCarPed,
@@ -1707,7 +1724,7 @@ DRV_PROF(const unsigned long long KS = isoT0;)
   int lane = threadIdx.x;
   const int e = drv_iso_assign(S, lane);  // (= blockIdx.x unless the slow environments of the previous step are being isolated)
   if (e < 0) return;
-DRV_PROF(if (lane < 8 && e < 4096) g_dbgp[e * 8 + lane] = 0ull;)
+DRV_PROF(if (lane < 8 && e < 4096) { g_dbgp[e * 8 + lane] = 0ull; g_dbgs[e * 8 + lane] = 0ull; })
   const int A = S.A;
   int* envi = S.envi + (size_t)e * EI_COUNT;
   int elapsed = uniform_i(envi[EI_ELAPSED]);

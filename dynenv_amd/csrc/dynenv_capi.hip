@@ -745,6 +745,7 @@ int dynenv_debug_counters(dynenv_t* h, int64_t* out4) {
   { unsigned long long d[16]; HIP_OK(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_dbgr), sizeof(d))); FILE* f = fopen("gpurun_out/dbgr.txt", "w"); for (int k = 0; k < 16; ++k) fprintf(f, "%llu\n", d[k]); fclose(f); }
   { static unsigned long long d[4096 * 12]; HIP_OK(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_dbgw), sizeof(d))); FILE* f = fopen("gpurun_out/dbgw.txt", "w"); for (int k = 0; k < 4096; ++k) { for (int q = 0; q < 12; ++q) fprintf(f, "%llu ", d[12*k+q]); fprintf(f, "\n"); } fclose(f); }
   { static unsigned long long d[4096 * 8]; HIP_OK(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_dbgp), sizeof(d))); FILE* f = fopen("gpurun_out/dbgp.txt", "w"); for (int k = 0; k < 4096; ++k) { for (int q = 0; q < 8; ++q) fprintf(f, "%llu ", d[8*k+q]); fprintf(f, "\n"); } fclose(f); }
+  { static unsigned long long d[4096 * 8]; HIP_OK(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_dbgs), sizeof(d))); FILE* f = fopen("gpurun_out/dbgs.txt", "w"); for (int k = 0; k < 4096; ++k) { for (int q = 0; q < 8; ++q) fprintf(f, "%llu ", d[8*k+q]); fprintf(f, "\n"); } fclose(f); }
   { static unsigned long long d[4096 * 8]; HIP_OK(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_dbgl), sizeof(d))); FILE* f = fopen("gpurun_out/dbgl.txt", "w"); for (int k = 0; k < 4096; ++k) { for (int q = 0; q < 8; ++q) fprintf(f, "%llu ", d[8*k+q]); fprintf(f, "\n"); } fclose(f); }
 #endif
   return DYNENV_OK;

@@ -74,3 +74,8 @@ names = ["steady", "untouched", "freed", "contact ids changed", "first contact /
          "... of which frozen + steady", "active arbiters in multi-level calls"]
 print("slot outcomes over the whole run (per slot per contact-path call):")
 for n, v in zip(names, r): print("  %-34s %d" % (n, v))
+
+# stages of the slot update (between the narrowphase and the prestep) of the last step
+sraw = np.loadtxt("gpurun_out/dbgs.txt")[:NE]
+print("slot update of the top envs, cycles per step: cpArbiterUpdate on the slot lanes | rank | begin callbacks | expiry + component closure + bias reset | levels")
+for k in top[:10]: print("     ", sraw[k, :5].astype(int))
