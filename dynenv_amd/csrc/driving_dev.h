@@ -92,7 +92,7 @@ struct DrvState {
   /* SIMD isolation of the slow environments (scheduling only - which block steps which environment; see drv_iso_assign):
      iso[0..2] = list lengths, iso[3..5] = slowest environment's cycles, iso[7] = placeholders that gave up waiting,
      iso[8..10] = "the block -> SIMD placement isolation relies on was observed" (written by the launch before the one that
-     reads it), iso[11] = launches in which it was not, iso[DRV_ISO_HDR + buf * DRV_ISO_LIST + k] = ids; three buffers used in
+     reads it), iso[11] = launches in which it was not, iso[12] = cool-down counter of the validation, iso[DRV_ISO_HDR + buf * DRV_ISO_LIST + k] = ids; three buffers used in
      rotation (step t reads buffer t % 3, fills (t + 1) % 3, clears (t + 2) % 3); iso_done[e] = tick of e's last finished step;
      iso_hw[t & 1][b] = hardware id (XCC | SE | SH | CU | SIMD) block b of step t ran on.  None of this is simulation state:
      it is allocated outside the checkpointed arrays and starts over at dynenv_checkpoint_load. */
@@ -107,6 +107,7 @@ struct DrvState {
 #define DRV_ISO_LIST 256 /* capacity of a list; iso_on = 2 (more environments than fit at once) starts up to this many slow ones first */
 #define DRV_ISO_HDR 16    /* header words of DrvState.iso in front of the three lists */
 #define DRV_ISO_WORDS (DRV_ISO_HDR + 3 * DRV_ISO_LIST)
+#define DRV_ISO_COOLDOWN 64 /* validated launches isolation stays off for after one that did not validate */
 #define DRV_ISO_G0 256     /* first SIMD group isolation uses: groups 256..511 are the ones whose four blocks always share a SIMD */
 #define DRV_ISO_GSPAN 256  /* ... and how many of them the device-side validation checks (DRV_ISO_MAX <= GSPAN) */
 #define DRV_ISO_GROUPS 1024 /* SIMDs of an MI355X: blocks b, b + 1024, b + 2048, b + 3072 of a launch share one (measured) */

@@ -1645,7 +1645,16 @@ DE_DEV int drv_iso_assign(const DrvState& S, int lane) {
         bad |= k0 == 0xFFFFFFFFu || k0 != k1 || k0 != k2 || k0 != k3;
       }
       const bool ok = wave_ballot(bad) == 0ull;
-      if (lane == 0) { S.iso[8 + (S.tick + 1) % 3] = ok ? 1 : 0; if (!ok && S.tick > 1) atomicAdd(&S.iso[11], 1); }
+      if (lane == 0) {
+        // hysteresis: one launch that did not validate keeps isolation off for the next DRV_ISO_COOLDOWN validated ones as well - a
+        // device shared with another kernel validates now and then by chance, and placeholders parked on such a launch's verdict
+        // hold wave slots the other kernel could use (two 4096-environment handles on two streams: 7 % slower without this)
+        int cd = S.iso[12];
+        if (!ok) cd = DRV_ISO_COOLDOWN; else if (cd > 0) cd -= 1;
+        S.iso[12] = cd;
+        S.iso[8 + (S.tick + 1) % 3] = (ok && cd == 0) ? 1 : 0;
+        if (!ok && S.tick > 1) atomicAdd(&S.iso[11], 1);
+      }
       return -1;
     }
     if (uniform_i(S.iso[8 + buf]) != 1) K = 0;

@@ -51,7 +51,14 @@ struct dynenv {
   std::vector<size_t> alloc_bytes;  // checkpoint = these arrays, in allocation order
   std::vector<void*> scratch;       // scheduling scratch (SIMD-isolation lists): NOT simulation state, never checkpointed
   hipEvent_t ev_begin = nullptr, ev_main = nullptr, ev_end = nullptr;  // dynenv_set_step_events (caller-owned)
+  // SIMD isolation, host side: iso_cfg = the mode the handle was created with (S.iso_on may be 0 while isolation is paused);
+  // iso_seen = pinned word the device's count of launches whose placement did not validate is copied into now and then
+  int iso_cfg = 0, iso_last_invalid = 0, iso_paused_until = 0, iso_pauses = 0;
+  long long steps = 0;
+  int* iso_seen = nullptr;
 };
+#define ISO_PROBE_EVERY 64     /* steps between two looks at the device's validation counter (an asynchronous 4-byte copy) */
+#define ISO_PAUSE_STEPS 2048   /* steps without isolation after a probe window in which more than half of the launches did not validate */
 
 // ---------------------------------------------------------------------------------------------- constants
 static void road_init_host(DrvRoad& r, int nLanes, double width, V2 p0, V2 p1) {  // Road.py:11-33
@@ -160,6 +167,15 @@ static int iso_reset(dynenv* h) {
   HIP_OK(hipMemset(S.iso, 0, sizeof(int) * DRV_ISO_WORDS));
   HIP_OK(hipMemset(S.iso_done, 0xFF, sizeof(int) * (size_t)S.E));
   HIP_OK(hipMemset(S.iso_hw, 0xFF, sizeof(unsigned) * 2 * 4 * DRV_ISO_GROUPS));
+  return 0;
+}
+
+static int iso_reset_async(dynenv* h, hipStream_t st) {  // the same, stream-ordered (resuming isolation between two steps)
+  DrvState& S = h->S;
+  S.tick = 0;
+  HIP_OK(hipMemsetAsync(S.iso, 0, sizeof(int) * DRV_ISO_WORDS, st));
+  HIP_OK(hipMemsetAsync(S.iso_done, 0xFF, sizeof(int) * (size_t)S.E, st));
+  HIP_OK(hipMemsetAsync(S.iso_hw, 0xFF, sizeof(unsigned) * 2 * 4 * DRV_ISO_GROUPS, st));
   return 0;
 }
 
@@ -456,6 +472,11 @@ int dynenv_create(const dynenv_cfg_t* cfg, dynenv_t** out) {
       S.iso_on = off || !dev256 ? 0 : (E == 4 * DRV_ISO_GROUPS ? (h->partial ? 0 : 1) : (E > 4 * DRV_ISO_GROUPS ? 2 : 0));
     }
     if (iso_reset(h)) { dynenv_destroy(h); return DYNENV_ERR_HIP; }
+    h->iso_cfg = S.iso_on;
+    if (S.iso_on == 1) {
+      if (hipHostMalloc((void**)&h->iso_seen, sizeof(int), hipHostMallocDefault) != hipSuccess) { dynenv_destroy(h); return fail(DYNENV_ERR_HIP, "hipHostMalloc"); }
+      *h->iso_seen = 0;
+    }
   }
   DrvConst c;
   build_consts(c);
@@ -474,6 +495,7 @@ void dynenv_destroy(dynenv_t* h) {
   DeviceGuard guard_(h->cfg.device_id);
   for (void* p : h->allocs) hipFree(p);
   for (void* p : h->scratch) hipFree(p);
+  if (h->iso_seen) (void)hipHostFree(h->iso_seen);
   delete h;
 }
 
@@ -629,6 +651,27 @@ int dynenv_step_head(dynenv_t* h, const int32_t* actions_dev, const double* head
   // environment's observation as soon as its step is done, which fills the launch's tail
   // (with isolation on, 3 x DRV_ISO_MAX spare blocks behind the E regular ones: the environments displaced from a slow
   //  environment's SIMD run there - or nothing, and the block ends at once)
+  // A device this handle does not have to itself (another handle stepping on another stream, another kernel): the placement
+  // does not validate, isolation holds off on the device - and what is left of it (the spare blocks, the placement record, the
+  // per-environment report) still costs 7 % of a step once the device is saturated.  So the host looks at the device's count of
+  // launches that did not validate every ISO_PROBE_EVERY steps - an asynchronous 4-byte copy, read one window later, never
+  // waited for - and when more than half of a window's launches did not validate it drops to the plain launch (mode 0: exactly
+  // what DYNENV_NO_ISOLATION=1 gives) for ISO_PAUSE_STEPS steps, then starts isolation over.  Scheduling only, as ever.
+  if (h->iso_cfg == 1) {
+    h->steps += 1;
+    if (h->S.iso_on == 0 && h->steps >= h->iso_paused_until) {
+      if (iso_reset_async(h, st)) return DYNENV_ERR_HIP;
+      h->S.iso_on = 1; h->iso_last_invalid = 0; *h->iso_seen = 0;
+    } else if (h->S.iso_on == 1 && h->steps % ISO_PROBE_EVERY == 0) {
+      const int seen = *(volatile int*)h->iso_seen;  // the copy issued one window ago (stale at worst)
+      if (seen - h->iso_last_invalid > ISO_PROBE_EVERY / 2) {
+        h->S.iso_on = 0; h->iso_paused_until = (int)(h->steps + ISO_PAUSE_STEPS); h->iso_pauses += 1;
+      } else {
+        h->iso_last_invalid = seen;
+        HIP_OK(hipMemcpyAsync(h->iso_seen, h->S.iso + 11, sizeof(int), hipMemcpyDeviceToHost, st));
+      }
+    }
+  }
   const unsigned stepGrid = (unsigned)h->S.E + (h->S.iso_on == 1 ? 3u * DRV_ISO_MAX + 1u /* the placement validator */ : 0u);
   h->S.tick = (h->S.tick + 1) % (3 * (1 << 28));  // (wraps at a multiple of 3: the three isolation lists keep rotating in order)
   if (h->partial && obs_dev)
@@ -739,7 +782,8 @@ int dynenv_debug_counters(dynenv_t* h, int64_t* out4) {
     out4[10] = h->S.iso_on ? (k < cap ? k : cap) : -1; out4[11] = iso[7];
     // out[12]: isolation mode (0 off, 1 SIMD isolation, 2 slow environments first); out[13]: 1 = the next step found the block ->
     // SIMD placement validated (mode 1 only; 0 = isolation is holding off); out[14]: launches whose placement did not validate
-    out4[12] = h->S.iso_on; out4[13] = h->S.iso_on == 1 ? iso[8 + nxt] : -1; out4[14] = iso[11]; out4[15] = 0;
+    out4[12] = h->iso_cfg; out4[13] = h->S.iso_on == 1 ? iso[8 + nxt] : (h->iso_cfg == 1 ? 0 : -1); out4[14] = iso[11];
+    out4[15] = h->iso_pauses;  // times the host dropped to the plain launch because the placement kept failing to validate
   }
 #ifdef DRV_PROFILE
   { unsigned long long d[16]; HIP_OK(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_dbgr), sizeof(d))); FILE* f = fopen("gpurun_out/dbgr.txt", "w"); for (int k = 0; k < 16; ++k) fprintf(f, "%llu\n", d[k]); fclose(f); }
@@ -1095,7 +1139,11 @@ int dynenv_checkpoint_load(dynenv_t* h, const void* buf_host, size_t nbytes) {
   if (h->robocup) h->R.seed = a.seed; else h->S.seed = a.seed;
   // the scheduler's lists describe the timing of the steps this handle ran, not the state just restored: start them over
   // (a list that keeps ids from before the restore could be appended to without having been cleared - ADVICE r3)
-  if (!h->robocup && iso_reset(h)) return DYNENV_ERR_HIP;
+  if (!h->robocup) {
+    if (iso_reset(h)) return DYNENV_ERR_HIP;
+    h->S.iso_on = h->iso_cfg; h->iso_last_invalid = 0; h->iso_paused_until = 0; h->steps = 0;
+    if (h->iso_seen) *h->iso_seen = 0;
+  }
   return DYNENV_OK;
 }
 

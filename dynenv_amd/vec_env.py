@@ -488,7 +488,7 @@ class BatchedDynEnv(object):
         _capi.check(self._lib.dynenv_debug_counters(self._h, out), "dynenv_debug_counters")
         return dict(fast=out[0], quiescent=out[1], contact=out[2], slot_sum=out[3], why_cand=out[4], why_moving=out[5],
                     why_inert=out[6], steady=out[7], light=out[8], split=out[9], isolated_next=out[10], isolation_timeouts=out[11],
-                    isolation_mode=out[12], placement_validated=out[13], placement_invalid_launches=out[14])
+                    isolation_mode=out[12], placement_validated=out[13], placement_invalid_launches=out[14], isolation_pauses=out[15])
 
     def debug_placement(self):
         """uint32 [4096]: XCC << 16 | SE, SH, CU, SIMD bits of HW_ID of every regular block of the last step (mode 1 handles), else empty"""

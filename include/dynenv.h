@@ -220,7 +220,9 @@ int dynenv_error_flags(dynenv_t* h, int32_t* out);
  * gives a SIMD of their own (-1: isolation off for this handle), isolation placeholders that gave up waiting (stays 0),
  * the handle's scheduling mode (0 none, 1 SIMD isolation, 2 slow environments first), whether the block -> SIMD placement
  * isolation relies on validated for the next step (mode 1; it is re-checked on the device every launch and isolation holds
- * off while it does not validate), launches whose placement did not validate, 0}.
+ * off while it does not validate), launches whose placement did not validate (since isolation was last started), the number
+ * of times the host paused isolation - plain launches for 2048 steps - because more than half of the launches of a 64-step
+ * window did not validate: a device shared with another handle or kernel}.
  * Synchronises the device. */
 int dynenv_debug_counters(dynenv_t* h, int64_t* out16);
 /* Diagnostics: where the regular blocks of the last Driving step ran - out[b] = XCC id << 16 | HW_ID bits (SE 15:13, SH 12,

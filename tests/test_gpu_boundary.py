@@ -399,7 +399,9 @@ def test_two_handles_on_two_streams_isolation_validates_itself(gpu, monkeypatch)
     """Two 4096-environment Driving handles stepped concurrently on two streams: the block -> SIMD placement that isolation
     assumes (one launch owning the device) no longer holds.  Every launch records where its blocks ran and the next ones only
     isolate while the record checks out, so: results are bit-identical to a DYNENV_NO_ISOLATION pair, no placeholder ever gives up
-    waiting, and the pair is not slower than the pair without isolation (a stale placement guess would park wave slots)."""
+    waiting, and the pair is not slower than the pair without isolation (a stale placement guess would park wave slots).  The host
+    side watches the device's count of launches that did not validate and drops to the plain launch while they keep failing
+    (isolation_pauses), so the second pass runs the very launch DYNENV_NO_ISOLATION gives."""
     import time
     dynenv_amd, torch, _ = gpu
     E, A, steps = 4096, 10, 300
@@ -429,14 +431,18 @@ def test_two_handles_on_two_streams_isolation_validates_itself(gpu, monkeypatch)
     monkeypatch.setenv("DYNENV_NO_ISOLATION", "1")
     ref = [mk(11), mk(12)]
     monkeypatch.delenv("DYNENV_NO_ISOLATION")
-    t_iso = min(run(iso), run(iso))      # (second pass: same episode again from a reset; the scheduler state carries over)
-    t_ref = min(run(ref), run(ref))
+    # alternating passes (the device's clocks drift by several per cent over the first seconds of load: whichever pair ran
+    # first looked 6 % slower); every pass is the same episode again from a reset, the scheduler state carries over
+    t = [(run(iso), run(ref)) for _ in range(3)]
+    t_iso, t_ref = min(x for x, _ in t), min(y for _, y in t)
     for a, b in zip(iso, ref):
         assert torch.equal(a.obs, b.obs) and torch.equal(a.rewards, b.rewards)
         for e in (0, 1024, 4095):
             assert bytes(a.get_state(e)) == bytes(b.get_state(e))
         c = a.debug_counters()
         assert c["isolation_timeouts"] == 0, c
+        # either the launches really overlapped and the host paused isolation, or (a host too slow to overlap them) they validated
+        assert c["isolation_pauses"] >= 1 or c["placement_invalid_launches"] < steps // 4, c
         assert a.error_flags() == 0 and b.error_flags() == 0
     assert t_iso <= 1.10 * t_ref, "two concurrent handles: %.1f ms with isolation, %.1f ms without" % (t_iso * 1e3, t_ref * 1e3)
     print("two handles x 4096 on two streams: %.3f ms per step pair with isolation (%s), %.3f without" %
