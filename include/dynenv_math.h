@@ -104,7 +104,13 @@ DM_FN void dm_sincos(double x, double* s, double* c) {
 DM_FN double dm_sin(double x) { double s, c; dm_sincos(x, &s, &c); return s; }
 DM_FN double dm_cos(double x) { double s, c; dm_sincos(x, &s, &c); return c; }
 
-DM_FN double dm_atan(double x) {
+/* atan of ax >= 0 (fdlibm's __atan: five ranges, odd minimax polynomial).  Written without branches: the ranges only differ in
+ * the quotient they reduce to and in the (hi, lo) they add back, so numerator, denominator, hi and lo are SELECTED and there is
+ * one division - on a 64-lane wavefront whose lanes fall into all five ranges the branching form executes every arm, four
+ * divisions of ~12 instructions each and fifteen exec-mask regions.  Operation for operation the same arithmetic per range (the
+ * first range's ax / 1.0 is exact, and so are its hi = lo = 0 in the last line), so the results are bit-identical to the
+ * branching form; tests/test_detmath.py holds a numpy restatement of the branching form and compares bit patterns. */
+DM_FN double dm_atan_pos(double ax) {
   const double atanhi0 = 4.63647609000806093515e-01, atanhi1 = 7.85398163397448278999e-01,
                atanhi2 = 9.82793723247329054082e-01, atanhi3 = 1.57079632679489655800e+00;
   const double atanlo0 = 2.26987774529616870924e-17, atanlo1 = 3.06161699786838301793e-17,
@@ -115,36 +121,32 @@ DM_FN double dm_atan(double x) {
                aT6 = 6.66107313738753120669e-02, aT7 = -5.83357013379057348645e-02,
                aT8 = 4.97687799461593236017e-02, aT9 = -3.65315727442169155270e-02,
                aT10 = 1.62858201153657823623e-02;
-  int neg = x < 0.0;
-  double ax = neg ? -x : x;
-  int id;
-  double hi = 0.0, lo = 0.0;
-  if (ax >= 1.0e300) { /* huge (incl. inf) */
-    double r = atanhi3 + atanlo3;
-    return neg ? -r : r;
-  }
-  if (ax < 0.4375) {
-    id = -1;
-    if (ax < 3.7252902984619140625e-09) return x; /* |x| < 2^-28 */
-  } else if (ax < 1.1875) {
-    if (ax < 0.6875) { id = 0; ax = (2.0 * ax - 1.0) / (2.0 + ax); hi = atanhi0; lo = atanlo0; }
-    else             { id = 1; ax = (ax - 1.0) / (ax + 1.0);       hi = atanhi1; lo = atanlo1; }
-  } else {
-    if (ax < 2.4375) { id = 2; ax = (ax - 1.5) / (1.0 + 1.5 * ax); hi = atanhi2; lo = atanlo2; }
-    else             { id = 3; ax = -1.0 / ax;                     hi = atanhi3; lo = atanlo3; }
-  }
-  double z = ax * ax;
-  double w = z * z;
-  double s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
-  double s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
-  if (id < 0) {
-    double r = ax - ax * (s1 + s2);
-    return neg ? -r : r;
-  }
-  {
-    double r = hi - ((ax * (s1 + s2) - lo) - ax);
-    return neg ? -r : r;
-  }
+  const int r0 = ax < 0.4375, r1 = ax < 0.6875, r2 = ax < 1.1875, r3 = ax < 2.4375;
+  /* the quotient's two halves as ax * A + B with selected A, B (products by 0, 1, 2 are exact; 1.5 ax is the one rounded
+   * product of the branching form), so that no arm is left for the compiler to branch around:
+   *                       [0, .4375)  [.4375, .6875)  [.6875, 1.1875)  [1.1875, 2.4375)  [2.4375, inf)
+   *   numerator           ax          2 ax - 1        ax - 1           ax - 1.5          -1
+   *   denominator         1           2 + ax          ax + 1           1 + 1.5 ax        ax                      */
+  const double nA = r0 ? 1.0 : (r1 ? 2.0     : (r2 ? 1.0     : (r3 ? 1.0     : 0.0)));
+  const double nB = r0 ? 0.0 : (r1 ? -1.0    : (r2 ? -1.0    : (r3 ? -1.5    : -1.0)));
+  const double dA = r0 ? 0.0 : (r1 ? 1.0     : (r2 ? 1.0     : (r3 ? 1.5     : 1.0)));
+  const double dB = r0 ? 1.0 : (r1 ? 2.0     : (r2 ? 1.0     : (r3 ? 1.0     : 0.0)));
+  const double hi = r0 ? 0.0 : (r1 ? atanhi0 : (r2 ? atanhi1 : (r3 ? atanhi2 : atanhi3)));
+  const double lo = r0 ? 0.0 : (r1 ? atanlo0 : (r2 ? atanlo1 : (r3 ? atanlo2 : atanlo3)));
+  const double num = ax * nA + nB, den = ax * dA + dB; /* (ax = inf: 0 * inf, discarded by the last select below) */
+  const double t = num / den;
+  const double z = t * t;
+  const double w = z * z;
+  const double s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+  const double s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+  double r = hi - ((t * (s1 + s2) - lo) - t);      /* first range: 0 - ((t s - 0) - t) = t - t s, exactly */
+  if (ax < 3.7252902984619140625e-09) r = ax;      /* |x| < 2^-28 */
+  if (ax >= 1.0e300) r = atanhi3 + atanlo3;        /* huge (incl. inf) */
+  return r;
+}
+DM_FN double dm_atan(double x) {
+  const double r = dm_atan_pos(__builtin_fabs(x));
+  return x < 0.0 ? -r : r;
 }
 
 /* math.atan2 semantics incl. signed zeros (Road.py:315 spotDir.angle relies on atan2(-0.0,-90) == -pi) */
@@ -154,25 +156,20 @@ DM_FN int dm_signbit(double x) {
   return (int)(q.u >> 63);
 }
 
+/* Branch-free as well: the quadrant logic is two selects, and so are the zero operands (0 / 0 would be a NaN, and for x = -0 the
+ * general expression pi - (pi/2 - pi_lo) lands one ulp above pi/2).  A NaN operand propagates through the division.  One corner
+ * differs from the branching form this replaces: a quotient that underflows to -0 (or x = +-inf with y < 0) now gives the -0 / -pi
+ * of math.atan2, where the old form - whose |q| kept the sign of a zero - gave +0 / +pi. */
 DM_FN double dm_atan2(double y, double x) {
   const double pi = 3.1415926535897931160e+00, pi_lo = 1.2246467991473531772e-16;
-  if (x != x || y != y) return x + y;
-  if (y == 0.0) {
-    if (dm_signbit(x)) return dm_signbit(y) ? -pi : pi; /* atan2(+-0, -anything) = +-pi */
-    return y;                                           /* atan2(+-0, +anything) = +-0 */
-  }
-  if (x == 0.0) return dm_signbit(y) ? -DM_PI_2 : DM_PI_2;
+  const double aq = __builtin_fabs(y / x);
+  double z = dm_atan_pos(aq);                      /* aq >= 1e300: atanhi3 + atanlo3 == pi/2 */
+  if (x < 0.0 && aq < 1.0e-300) z = 0.0;
   {
-    double z;
-    double q = y / x;
-    double aq = dm_abs(q);
-    if (aq > 1.0e300) z = DM_PI_2;
-    else if (x < 0.0 && aq < 1.0e-300) z = 0.0;
-    else z = dm_atan(aq);
-    if (!dm_signbit(x)) return dm_signbit(y) ? -z : z;
-    /* x < 0 */
-    if (!dm_signbit(y)) return pi - (z - pi_lo);
-    return (z - pi_lo) - pi;
+    double r = dm_signbit(x) ? pi - (z - pi_lo) : z; /* (z - pi_lo) - pi == -(pi - (z - pi_lo)) exactly */
+    if (x == 0.0) r = DM_PI_2;
+    if (y == 0.0) r = dm_signbit(x) ? pi : 0.0;
+    return dm_signbit(y) ? -r : r;
   }
 }
 
