@@ -35,7 +35,7 @@ struct PvPedSlot {  // phase 4: a visible pedestrian's inputs and running maxima
   int seen, carPed, obsPed;
 };
 static_assert(sizeof(PvPedSlot) <= sizeof(PvBlocker), "pedestrian slot must fit a blocker entry");
-static_assert(10 * sizeof(PvBlocker) >= 61 * sizeof(int), "index lists must fit the entries of lanes 54..63");
+static_assert(10 * sizeof(PvBlocker) >= (64 + 34) * sizeof(int), "index lists (ints 0..60) and the corner pool (64..97) must fit the entries of lanes 54..63");
 struct PvLds {
   double px[DRV_NB], py[DRV_NB], ang[DRV_NB];
   double ox[DRV_MAXO], oy[DRV_MAXO];
@@ -56,23 +56,23 @@ DE_DEV V2 pv_rotated(V2 v, double a) {
 }
 DE_DEV double pv_lensq(V2 v) { return v.x * v.x + v.y * v.y; }
 
-// cutils.doesInteractPoly :643-696 with the blocker's interval precomputed (getViewBlockAngle :626-640)
+// cutils.doesInteractPoly :643-696 with the blocker's interval precomputed (getViewBlockAngle :626-640).  Straight-line: every
+// comparison is evaluated and the verdict selected - the lanes of a wave disagree on all of these conditions, so a branching form
+// executes every arm anyway, behind an exec-mask region each (4 calls were 445 instructions and 34 branches).
 DE_DEV int pv_interact(int seen1, V2 point1, double angle1, const PvBlocker& b, double radius) {
-  int ret = INTER_NONE;
-  if (seen1 == SIGHT_NONE || b.seen == SIGHT_NONE) return ret;
+  const bool valid = seen1 != SIGHT_NONE && b.seen != SIGHT_NONE;
   const V2 point2 = v2(b.posx, b.posy);
-  if (radius > 0.0 && pv_lensq(vsub(point2, point1)) < radius) ret = INTER_NEARBY;
+  const bool nearby = radius > 0.0 && pv_lensq(vsub(point2, point1)) < radius;
   double pAngle = angle1 - b.angle2;
-  if (pAngle > DM_PI) pAngle -= DM_TWO_PI; else if (pAngle < -DM_PI) pAngle += DM_TWO_PI;
-  if (pAngle > b.minA && pAngle < b.maxA) {
-    const V2 p1 = v2(b.p1x, b.p1y), p2 = v2(b.p2x, b.p2y), pm = v2(b.pmx, b.pmy);
-    if (b.extreme) {
-      if (vcross(vsub(p2, p1), vsub(point1, p1)) < 0.0) ret = INTER_OCCLUDE;
-    } else if (vcross(vsub(p2, pm), vsub(point1, pm)) < 0.0 && vcross(vsub(pm, p1), vsub(point1, p1)) < 0.0) {
-      ret = INTER_OCCLUDE;
-    }
-  }
-  return ret;
+  const double up = pAngle - DM_TWO_PI, down = pAngle + DM_TWO_PI;
+  pAngle = pAngle > DM_PI ? up : (pAngle < -DM_PI ? down : pAngle);
+  const bool inside = pAngle > b.minA && pAngle < b.maxA;
+  const V2 p1 = v2(b.p1x, b.p1y), p2 = v2(b.p2x, b.p2y), pm = v2(b.pmx, b.pmy);
+  const V2 d1 = vsub(point1, p1), dm = vsub(point1, pm);
+  const bool c21 = vcross(vsub(p2, p1), d1) < 0.0;
+  const bool c2m = vcross(vsub(p2, pm), dm) < 0.0, cm1 = vcross(vsub(pm, p1), d1) < 0.0;
+  const bool occl = inside && (b.extreme ? c21 : (c2m && cm1));
+  return !valid ? INTER_NONE : (occl ? INTER_OCCLUDE : (nearby ? INTER_NEARBY : INTER_NONE));
 }
 
 // The observation of every agent of environment e.  `in` carries the per-lane state (from HBM in the stand-alone kernel,
@@ -187,15 +187,40 @@ DE_DEV void pv_env(const DrvState& S, PvLds& L, const int e, const int lane, con
       }
     }
     // ---- phase 2: publish blockers (cars other than self, obstacles, buildings) ------------------------------
+    // The four corner angles of every visible blocker: 4 n evaluations of atan2 for n blockers, pooled over the whole wave (item =
+    // 4 j + corner) instead of four calls with only the blocker lanes busy - n is ~10 of 64 lanes, so one call replaces four.  The
+    // corners travel through the blocker's own table entry (not yet written) and come back as (angle, squared length) in place.
     const double angle1 = (seen != SIGHT_NONE && !isSelf && (isCarLane || isPedLane || isObsLane || isBldLane)) ? dev_atan2(pos.y, pos.x) : 0.0;
-    if ((isCarLane && !isSelf) || isObsLane || isBldLane) {
+    const bool isBlk = (isCarLane && !isSelf) || isObsLane || isBldLane;
+    const bool blkSeen = isBlk && seen != SIGHT_NONE;
+    const uint64_t blkMask = wave_ballot(blkSeen);
+    const uint64_t below = lanemask_lt();
+    if (blkMask) {
+      int* pool = reinterpret_cast<int*>(&L.blk[54]) + 64;  // (the lists of phase 4 use ints 0..60 of these entries)
+      double* slot = reinterpret_cast<double*>(&L.blk[lane]);
+      if (blkSeen) {
+        pool[__popcll(blkMask & below)] = lane;
+        slot[0] = cor0.x; slot[1] = cor0.y; slot[2] = cor1.x; slot[3] = cor1.y;
+        slot[4] = cor2.x; slot[5] = cor2.y; slot[6] = cor3.x; slot[7] = cor3.y;
+      }
+      __syncthreads();
+      const int nItems = 4 * __popcll(blkMask);
+      for (int it = lane; it < nItems; it += DE_WAVE) {
+        double* c = reinterpret_cast<double*>(&L.blk[pool[it >> 2]]) + 2 * (it & 3);
+        const V2 cor = v2(c[0], c[1]);
+        c[0] = dev_atan2(cor.y, cor.x);
+        c[1] = pv_lensq(cor);
+      }
+      __syncthreads();
+    }
+    if (isBlk) {
       PvBlocker b;
       b.seen = seen; b.posx = pos.x; b.posy = pos.y; b.angle2 = angle1;
       b.minA = b.maxA = 0.0; b.p1x = b.p1y = b.p2x = b.p2y = b.pmx = b.pmy = 0.0; b.extreme = 0;
       if (seen != SIGHT_NONE) {
-        double ang0 = dev_atan2(cor0.y, cor0.x) - angle1, ang1 = dev_atan2(cor1.y, cor1.x) - angle1;
-        double ang2 = dev_atan2(cor2.y, cor2.x) - angle1, ang3 = dev_atan2(cor3.y, cor3.x) - angle1;
-        const double dst0 = pv_lensq(cor0), dst1 = pv_lensq(cor1), dst2 = pv_lensq(cor2), dst3 = pv_lensq(cor3);
+        const double* slot = reinterpret_cast<const double*>(&L.blk[lane]);
+        double ang0 = slot[0] - angle1, ang1 = slot[2] - angle1, ang2 = slot[4] - angle1, ang3 = slot[6] - angle1;
+        const double dst0 = slot[1], dst1 = slot[3], dst2 = slot[5], dst3 = slot[7];
 #define PV_WRAP(A) do { if ((A) > DM_PI) (A) -= DM_TWO_PI; } while (0)
         PV_WRAP(ang0); PV_WRAP(ang1); PV_WRAP(ang2); PV_WRAP(ang3);
 #undef PV_WRAP
@@ -232,7 +257,6 @@ DE_DEV void pv_env(const DrvState& S, PvLds& L, const int e, const int lane, con
     const uint64_t laneAlive = wave_ballot(isLaneRow && lseen != SIGHT_NONE);
     const int nCars0 = __popcll(carMask), nObst0 = __popcll(obsMask), nPeds0 = __popcll(pedMask);
     const int nLanes0 = __popcll(laneAlive);
-    const uint64_t below = lanemask_lt();
     int listIdx = 0;
     if (alive) listIdx = isCarLane ? __popcll(carMask & below) : (isPedLane ? __popcll(pedMask & below) : __popcll(obsMask & below));
     if (isLaneRow) listIdx = __popcll(laneAlive & below);

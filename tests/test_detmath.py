@@ -58,3 +58,57 @@ def test_philox4x32_10_known_answers():
         o = np.zeros(4, np.uint32)
         l.oracle_philox(key[0], key[1], c.ctypes.data_as(C.c_void_p), o.ctypes.data_as(C.c_void_p))
         assert tuple(int(v) for v in o) == exp
+
+
+def _fdlibm_atan_pos(ax):
+    """fdlibm __atan for ax >= 0 in its branching form (one arm per range, evaluated here with numpy: IEEE double, no FMA)"""
+    hi_t = np.array([4.63647609000806093515e-01, 7.85398163397448278999e-01, 9.82793723247329054082e-01, 1.57079632679489655800e+00])
+    lo_t = np.array([2.26987774529616870924e-17, 3.06161699786838301793e-17, 1.39033110312309984516e-17, 6.12323399573676603587e-17])
+    aT = [3.33333333333329318027e-01, -1.99999999998764832476e-01, 1.42857142725034663711e-01, -1.11111104054623557880e-01,
+          9.09088713343650656196e-02, -7.69187620504482999495e-02, 6.66107313738753120669e-02, -5.83357013379057348645e-02,
+          4.97687799461593236017e-02, -3.65315727442169155270e-02, 1.62858201153657823623e-02]
+    idx = np.where(ax < 0.4375, -1, np.where(ax < 0.6875, 0, np.where(ax < 1.1875, 1, np.where(ax < 2.4375, 2, 3))))
+    t = np.where(idx == -1, ax, np.where(idx == 0, (2.0 * ax - 1.0) / (2.0 + ax), np.where(idx == 1, (ax - 1.0) / (ax + 1.0),
+                 np.where(idx == 2, (ax - 1.5) / (1.0 + 1.5 * ax), -1.0 / ax))))
+    z = t * t
+    w = z * z
+    s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))))
+    s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))))
+    hi, lo = hi_t[np.maximum(idx, 0)], lo_t[np.maximum(idx, 0)]
+    r = np.where(idx < 0, t - t * (s1 + s2), hi - ((t * (s1 + s2) - lo) - t))
+    r = np.where(ax < 3.7252902984619140625e-09, ax, r)
+    return np.where(ax >= 1.0e300, hi_t[3] + lo_t[3], r)
+
+
+def _fdlibm_atan2(y, x):
+    pi, pi_lo = 3.1415926535897931160e+00, 1.2246467991473531772e-16
+    aq = np.abs(y / x)
+    z = np.where(aq > 1.0e300, 1.5707963267948966, np.where((x < 0.0) & (aq < 1.0e-300), 0.0, _fdlibm_atan_pos(aq)))
+    sx, sy = np.signbit(x), np.signbit(y)
+    r = np.where(~sx, np.where(sy, -z, z), np.where(~sy, pi - (z - pi_lo), (z - pi_lo) - pi))
+    r = np.where(x == 0.0, np.where(sy, -1.5707963267948966, 1.5707963267948966), r)
+    return np.where(y == 0.0, np.where(sx, np.where(sy, -pi, pi), y), r)
+
+
+def test_atan2_is_the_branching_fdlibm_evaluation_bit_for_bit():
+    """dm_atan2 selects numerator, denominator, hi and lo instead of branching over the five ranges (one division instead of
+    five arms on a diverging wavefront); it must stay the same arithmetic: bit patterns against the branching form, over the
+    simulators' ranges, the range boundaries +- a few ulp, extreme magnitudes, zeros and infinities."""
+    rng = np.random.default_rng(5)
+    n = 300000
+    sp = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, 1e300, -1e300, 1e-300, -1e-300, 5e-324, -5e-324, 1e-310, 0.4375, 0.6875,
+                   1.1875, 2.4375, 3.7252902984619140625e-09, 2.0 ** -28, 1e308, 90.0, -90.0, 1e-9, 1e150, 1e-150])
+    gx, gy = np.meshgrid(sp, sp)
+    sgn = lambda: rng.choice([-1.0, 1.0], n)
+    bx = (rng.random(n) + 0.5) * sgn()
+    by = rng.choice([0.4375, 0.6875, 1.1875, 2.4375], n) * (1 + rng.integers(-3, 4, n) * 2.2e-16) * bx * sgn()
+    x = np.concatenate([gx.ravel(), (rng.random(n) - 0.5) * 2000.0, (rng.random(n) - 0.5) * 8.0, np.exp((rng.random(n) - 0.5) * 1400) * sgn(), rng.choice(sp, n), bx])
+    y = np.concatenate([gy.ravel(), (rng.random(n) - 0.5) * 2000.0, (rng.random(n) - 0.5) * 1e-3, np.exp((rng.random(n) - 0.5) * 1400) * sgn(), (rng.random(n) - 0.5) * 8.0, by])
+    x, y = np.ascontiguousarray(x), np.ascontiguousarray(y)
+    out = np.zeros((len(x), 5))
+    ol.lib().oracle_math(x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), len(x), out.ctypes.data_as(C.c_void_p))
+    with np.errstate(all="ignore"):
+        ref = _fdlibm_atan2(y, x)
+    got = out[:, 2]
+    same = (got.view(np.uint64) == ref.view(np.uint64)) | (np.isnan(got) & np.isnan(ref))
+    assert same.all(), [(y[i], x[i], got[i], ref[i]) for i in np.flatnonzero(~same)[:5]]
