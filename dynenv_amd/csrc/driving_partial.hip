@@ -4,7 +4,7 @@
 // doesInteractPoly / addNoiseRect / addNoiseLane and Road.getCarLaneDistances) for all agents of all environments.
 // One wavefront per environment, looping over the env's agents; for one agent the lanes are the OBJECTS it might see:
 //   lanes 0..9 cars (the agent's own lane builds the self row), 10..29 pedestrians, 30..49 obstacles, 50..53 buildings,
-//   54..59 the six lane rows; the ten random false-positive trials are evaluated by lanes 0..9 in a later phase.
+//   54..59 the six lane rows; the ten random false-positive trials are evaluated in a later phase, by lanes that are idle there.
 // Row positions inside the ragged lists (which also index the noise streams) come from wave ballots + popcounts.
 // Mirrors oracle/driving_partial.c operation by operation (bit-identical output); see that file for the RNG keying.
 #include "driving_dev.h"
@@ -305,19 +305,35 @@ DE_DEV void pv_env(const DrvState& S, PvLds& L, const int e, const int lane, con
       if (alive && isPedLane && pedInter == INTER_OCCLUDE) seen = SIGHT_NONE;  // filterOcclude (row stays in the list)
     }
     // ---- phase 5: noise (addNoiseRect :479-542 on self / cars / pedestrians / obstacles; addNoiseLane :382-413) ---
-    // Objects and lane rows live on disjoint lanes: one pair of Philox blocks, one atan2 and one sincos serve both.
+    // Objects and lane rows live on disjoint lanes: one pair of Philox blocks, one atan2 and one sincos serve both.  The ten
+    // random-FP trials of phase 6 need a pair of blocks each as well: a Philox block costs the wave the same whatever the number
+    // of lanes that want one, so the trials ride on the first ten lanes that have no noise to draw here (the buildings' lanes and
+    // lanes 60..63 never have: at least eight; every invisible or absent object adds one) - trial t on the t-th such lane, so lane
+    // order is trial order.  Fewer than ten (a crowded view): the trials stay on lanes 0..9 with a pair of blocks of their own.
+    int trial = -1;
+    dm_u32x4 fu, fu1;
+    fu.v[0] = fu.v[1] = fu.v[2] = fu.v[3] = 0u; fu1 = fu;
+    bool trialsPooled;
     {
       const bool objNoise = (alive || isSelf) && seen != SIGHT_NONE, laneNoise = isLaneRow && lseen != SIGHT_NONE;
-      const int kind = isLaneRow ? 4 : (isSelf ? 0 : (isCarLane ? 1 : (isPedLane ? 2 : 3)));
-      const int idx = isSelf ? 0 : listIdx;
+      const bool noisy = objNoise || laneNoise;
+      const uint64_t idleMask = ~wave_ballot(noisy);
+      const int idleRank = __popcll(idleMask & below);
+      trialsPooled = __popcll(idleMask) >= 10;
+      if (trialsPooled) { if (!noisy && idleRank < 10) trial = idleRank; }
+      else if (lane < 10) trial = lane;
+      const bool trialHere = trialsPooled && trial >= 0;
+      const int kind = trialHere ? 5 : (isLaneRow ? 4 : (isSelf ? 0 : (isCarLane ? 1 : (isPedLane ? 2 : 3))));
+      const int idx = trialHere ? trial : (isSelf ? 0 : listIdx);
       dm_u32x4 u, u1;
       u.v[0] = u.v[1] = u.v[2] = u.v[3] = 0u; u1 = u;
       double base = 0.0;
-      if (objNoise || laneNoise) {
+      if (noisy || trialHere) {
         u = pv_rng(S, genv, episode, elapsed, a, kind, idx, 0);
         u1 = pv_rng(S, genv, episode, elapsed, a, kind, idx, 1);
-        base = dev_atan2(objNoise ? ds : ls, objNoise ? dc : lc);
       }
+      if (trialHere) { fu = u; fu1 = u1; }
+      if (noisy) base = dev_atan2(objNoise ? ds : ls, objNoise ? dc : lc);
       double angArg = base;
       bool applyAngle = false;
       V2 newPos = pos;
@@ -369,12 +385,16 @@ DE_DEV void pv_env(const DrvState& S, PvLds& L, const int e, const int lane, con
         if (laneNoise) { lc = sc.c; ls = sc.s; }
       }
     }
-    // ---- phase 6: random false positives :824-874, evaluated by lanes 0..9 (trial = lane) ---------------------
+    // ---- phase 6: random false positives :824-874, one trial per lane (see phase 5 for which lanes) -------------
     int fpClass = -1;
     V2 fpPos = v2(0.0, 0.0);
     double fpc = 0.0, fps = 0.0, fpw = 0.0, fph = 0.0, fpLaneDist = 0.0, fpLaneType = 0.0;
-    if (lane < 10) {
-      const dm_u32x4 u = pv_rng(S, genv, episode, elapsed, a, 5, lane, 0), u1 = pv_rng(S, genv, episode, elapsed, a, 5, lane, 1);
+    if (!trialsPooled && trial >= 0) {
+      fu = pv_rng(S, genv, episode, elapsed, a, 5, trial, 0);
+      fu1 = pv_rng(S, genv, episode, elapsed, a, 5, trial, 1);
+    }
+    if (trial >= 0) {
+      const dm_u32x4 u = fu, u1 = fu1;
       if (dm_unit(u.v[0]) < randBase) {
         fpClass = dm_randint(u.v[1], 0, 5);
         const double d = dm_unit(u.v[2]) * maxVis1;
@@ -392,7 +412,7 @@ DE_DEV void pv_env(const DrvState& S, PvLds& L, const int e, const int lane, con
       }
     }
     // ---- phase 7: list assembly (misclassification swap :816-821, FP pedestrians near cars :877-882, final filter) ---
-    // A lane can hold a real object AND a random-FP trial (lanes 0..9): the two are handled by independent code paths.
+    // A lane can hold a real object AND a random-FP trial (lanes 0..9, in a crowded view): two independent code paths.
     const bool realCar = alive && isCarLane, realObs = alive && isObsLane, realPed = alive && isPedLane;
     const uint64_t misCarMask = wave_ballot(realCar && seen == SIGHT_MISCLASS);   // cars -> appended to obstacles
     const uint64_t misObsMask = wave_ballot(realObs && seen == SIGHT_MISCLASS);   // obstacles -> appended to cars
@@ -432,58 +452,67 @@ DE_DEV void pv_env(const DrvState& S, PvLds& L, const int e, const int lane, con
     const int nOutPeds = __popcll(outPedReal) + __popcll(fpPedMask) + __popcll(genReal) + __popcll(genMis) + __popcll(genFp);
     const int nOutLanes = __popcll(outLaneReal) + __popcll(fpLaneMask);
     __syncthreads();  // row buffer zero-filled
-#define PV_PUT_CAR(P_, q_, c_, s_, w_, h_, fin_)                                                                         \
-  do {                                                                                                                  \
-    if ((P_) < PV_CAP_CARS) {                                                                                           \
-      float* o = row + PV_OFF_CARS + (P_)*7;                                                                            \
-      o[0] = (float)pv_normalize((q_).x, (5.0 * 2.0 / DRV_W), 0.0); o[1] = (float)pv_normalize((q_).y, (5.0 * 2.0 / DRV_H), 0.0);     \
-      o[2] = (float)(c_); o[3] = (float)(s_);                                                                           \
-      o[4] = (float)pv_normalize((w_), 1.0 / 7.5, 0.5); o[5] = (float)pv_normalize((h_), 1.0 / 15.0, 0.5); o[6] = (fin_); \
-    } else overflow = 1;                                                                                                \
-  } while (0)
-#define PV_PUT_OBS(P_, q_, c_, s_, w_, h_)                                                                               \
-  do {                                                                                                                  \
-    if ((P_) < PV_CAP_OBST) {                                                                                           \
-      float* o = row + PV_OFF_OBST + (P_)*6;                                                                            \
-      o[0] = (float)pv_normalize((q_).x, (5.0 * 2.0 / DRV_W), 0.0); o[1] = (float)pv_normalize((q_).y, (5.0 * 2.0 / DRV_H), 0.0);     \
-      o[2] = (float)(c_); o[3] = (float)(s_);                                                                           \
-      o[4] = (float)pv_normalize((w_), 1.0 / 7.5, 0.5); o[5] = (float)pv_normalize((h_), 1.0 / 15.0, 0.5);              \
-    } else overflow = 1;                                                                                                \
-  } while (0)
-#define PV_PUT_PED(P_, q_)                                                                                               \
-  do {                                                                                                                  \
-    if ((P_) < PV_CAP_PEDS) {                                                                                           \
-      float* o = row + PV_OFF_PEDS + (P_)*2;                                                                            \
-      o[0] = (float)pv_normalize((q_).x, (5.0 * 2.0 / DRV_W), 0.0); o[1] = (float)pv_normalize((q_).y, (5.0 * 2.0 / DRV_H), 0.0);     \
-    } else overflow = 1;                                                                                                \
-  } while (0)
-    // --- cars block: surviving real cars, misclassified obstacles, random-FP cars
-    if (realCar && seen == SIGHT_NORMAL) { const int p = __popcll(outCarReal & below); PV_PUT_CAR(p, pos, dc, ds, dw, dh, (float)dfin); }
-    if (realObs && seen == SIGHT_MISCLASS) { const int p = __popcll(outCarReal) + __popcll(misObsMask & below); PV_PUT_CAR(p, pos, dc, ds, dw, dh, 0.0f); }
-    if (fpClass == 0) { const int p = __popcll(outCarReal) + __popcll(misObsMask) + __popcll(fpCarMask & below); PV_PUT_CAR(p, fpPos, fpc, fps, fpw, fph, 0.0f); }
-    // --- obstacles block: surviving real obstacles, misclassified cars, random-FP obstacles
-    if (realObs && seen == SIGHT_NORMAL) { const int p = __popcll(outObsReal & below); PV_PUT_OBS(p, pos, dc, ds, dw, dh); }
-    if (realCar && seen == SIGHT_MISCLASS) { const int p = __popcll(outObsReal) + __popcll(misCarMask & below); PV_PUT_OBS(p, pos, dc, ds, dw, dh); }
-    if (fpClass == 1) { const int p = __popcll(outObsReal) + __popcll(misCarMask) + __popcll(fpObsMask & below); PV_PUT_OBS(p, fpPos, fpc, fps, fpw, fph); }
-    // --- pedestrians block: real, random FP (class 2), then the FP pedestrians near cars in car-list order
-    if (realPed && seen != SIGHT_NONE) { const int p = __popcll(outPedReal & below); PV_PUT_PED(p, pos); }
-    if (fpClass == 2) { const int p = __popcll(outPedReal) + __popcll(fpPedMask & below); PV_PUT_PED(p, fpPos); }
+    // A lane holds at most one real object and one random-FP trial, and each of them goes to exactly one of the row's blocks: one
+    // store sequence per kind with the block, the position in it and the values selected, instead of one per (kind, block) pair
+    // behind an exec-mask region each (13 of them).
     {
-      const int base = __popcll(outPedReal) + __popcll(fpPedMask);
-      if (genA) {
-        const int g = realCar ? __popcll(genReal & below) : __popcll(genReal) + __popcll(genMis & below);
-        PV_PUT_PED(base + g, genPosA);
+      // --- rectangles (cars / obstacles block): the real object ...
+      //   cars block: surviving real cars, misclassified obstacles, random-FP cars; obstacles block: the mirror image
+      const bool rCar = (realCar && seen == SIGHT_NORMAL) || (realObs && seen == SIGHT_MISCLASS);
+      const bool rObs = (realObs && seen == SIGHT_NORMAL) || (realCar && seen == SIGHT_MISCLASS);
+      const bool fCar = fpClass == 0, fObs = fpClass == 1;
+      const int pReal = realCar ? (seen == SIGHT_NORMAL ? __popcll(outCarReal & below) : __popcll(outObsReal) + __popcll(misCarMask & below))
+                                : (seen == SIGHT_NORMAL ? __popcll(outObsReal & below) : __popcll(outCarReal) + __popcll(misObsMask & below));
+      const int pFp = fCar ? __popcll(outCarReal) + __popcll(misObsMask) + __popcll(fpCarMask & below)
+                           : __popcll(outObsReal) + __popcll(misCarMask) + __popcll(fpObsMask & below);
+#define PV_PUT_RECT(on_, car_, P_, q_, c_, s_, w_, h_, fin_)                                                               \
+  do {                                                                                                                    \
+    if (on_) {                                                                                                            \
+      if ((P_) < ((car_) ? PV_CAP_CARS : PV_CAP_OBST)) {                                                                  \
+        float* o = row + ((car_) ? PV_OFF_CARS + (P_)*7 : PV_OFF_OBST + (P_)*6);                                          \
+        o[0] = (float)pv_normalize((q_).x, (5.0 * 2.0 / DRV_W), 0.0); o[1] = (float)pv_normalize((q_).y, (5.0 * 2.0 / DRV_H), 0.0); \
+        o[2] = (float)(c_); o[3] = (float)(s_);                                                                           \
+        o[4] = (float)pv_normalize((w_), 1.0 / 7.5, 0.5); o[5] = (float)pv_normalize((h_), 1.0 / 15.0, 0.5);              \
+        if (car_) o[6] = (fin_);                                                                                          \
+      } else overflow = 1;                                                                                                \
+    }                                                                                                                     \
+  } while (0)
+      PV_PUT_RECT(rCar || rObs, rCar, pReal, pos, dc, ds, dw, dh, realCar ? (float)dfin : 0.0f);
+      // ... and the random-FP trial
+      PV_PUT_RECT(fCar || fObs, fCar, pFp, fpPos, fpc, fps, fpw, fph, 0.0f);
+#undef PV_PUT_RECT
+      // --- pedestrians block: real, random FP (class 2), then the FP pedestrians near cars in car-list order.  From the real object:
+      //   a surviving pedestrian or the pedestrian generated near my car / misclassified obstacle; from the trial: a class-2 FP
+      //   or the pedestrian generated near my FP car.
+      const int pedBase = __popcll(outPedReal) + __popcll(fpPedMask);
+      const bool pedReal = realPed && seen != SIGHT_NONE;
+      const int pA = pedReal ? __popcll(outPedReal & below)
+                             : pedBase + (realCar ? __popcll(genReal & below) : __popcll(genReal) + __popcll(genMis & below));
+      const int pB = fpClass == 2 ? __popcll(outPedReal) + __popcll(fpPedMask & below)
+                                  : pedBase + __popcll(genReal) + __popcll(genMis) + __popcll(genFp & below);
+      const V2 qA = pedReal ? pos : genPosA, qB = fpClass == 2 ? fpPos : genPosB;
+#define PV_PUT_PED(on_, P_, q_)                                                                                            \
+  do {                                                                                                                    \
+    if (on_) {                                                                                                            \
+      if ((P_) < PV_CAP_PEDS) {                                                                                           \
+        float* o = row + PV_OFF_PEDS + (P_)*2;                                                                            \
+        o[0] = (float)pv_normalize((q_).x, (5.0 * 2.0 / DRV_W), 0.0); o[1] = (float)pv_normalize((q_).y, (5.0 * 2.0 / DRV_H), 0.0); \
+      } else overflow = 1;                                                                                                \
+    }                                                                                                                     \
+  } while (0)
+      PV_PUT_PED(pedReal || genA, pA, qA);
+      PV_PUT_PED(fpClass == 2 || genB, pB, qB);
+#undef PV_PUT_PED
+      // --- lanes block: a visible lane row draws noise, so it never carries a trial (phase 5): one store sequence for both
+      const bool lReal = isLaneRow && lseen != SIGHT_NONE, lFp = fpClass == 3;
+      if (lReal || lFp) {
+        const int p = lReal ? __popcll(outLaneReal & below) : __popcll(outLaneReal) + __popcll(fpLaneMask & below);
+        if (p < PV_CAP_LANES) {
+          float* o = row + PV_OFF_LANES + p * 4;
+          o[0] = (float)(lReal ? ldist : fpLaneDist); o[1] = (float)(lReal ? lc : fpc); o[2] = (float)(lReal ? ls : fps);
+          o[3] = (float)(lReal ? ltype : fpLaneType);
+        } else overflow = 1;
       }
-      if (genB) { const int g = __popcll(genReal) + __popcll(genMis) + __popcll(genFp & below); PV_PUT_PED(base + g, genPosB); }
-    }
-    // --- lanes block
-    if (isLaneRow && lseen != SIGHT_NONE) {
-      const int p = __popcll(outLaneReal & below);
-      if (p < PV_CAP_LANES) { float* o = row + PV_OFF_LANES + p * 4; o[0] = (float)ldist; o[1] = (float)lc; o[2] = (float)ls; o[3] = (float)ltype; } else overflow = 1;
-    }
-    if (fpClass == 3) {
-      const int p = __popcll(outLaneReal) + __popcll(fpLaneMask & below);
-      if (p < PV_CAP_LANES) { float* o = row + PV_OFF_LANES + p * 4; o[0] = (float)fpLaneDist; o[1] = (float)fpc; o[2] = (float)fps; o[3] = (float)fpLaneType; } else overflow = 1;
     }
     // --- self row + counts
     if (isSelf) {

@@ -513,7 +513,11 @@ int drv_env_obs_dim(const DrivingEnv* e) { return e->obsType == DYNENV_OBS_PARTI
 void drv_write_obs(DrivingEnv* e, float* out) { /* :290-294 and environment_base.py:217-222 */
   if (e->obsType == DYNENV_OBS_PARTIAL) {
     int a, dim = drv_partial_obs_dim();
-    for (a = 0; a < e->nPlayers; ++a) e->obsOverflow |= drv_agent_vision(e, a, e->noiseType, e->noiseMagnitude, out + (size_t)a * dim);
+    for (a = 0; a < e->nPlayers; ++a) {
+      const int r = drv_agent_vision(e, a, e->noiseType, e->noiseMagnitude, out + (size_t)a * dim);
+      e->obsOverflow |= r & 0xFF;
+      if ((r >> 8) > e->obsNoiseDrawsMax) e->obsNoiseDrawsMax = r >> 8;
+    }
   } else {
     drv_write_full_obs(e, out);
   }

@@ -58,6 +58,7 @@ typedef struct DrivingEnv {
   int obsType, noiseType; /* ObservationType / NoiseType (cutils.py:29-51) */
   double noiseMagnitude;
   int obsOverflow;
+  int obsNoiseDrawsMax; /* most rows that drew noise in one agent's vision pass so far (test instrumentation) */
 } DrivingEnv;
 
 #define DRV_W 1700.0

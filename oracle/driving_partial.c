@@ -222,6 +222,7 @@ static inline double normalize(double pt, double nf, double mean) { return ((pt 
 #define P_NORM_H (1.0 / 15.0)
 
 /* returns 1 if a row cap overflowed (rows beyond the cap are dropped) */
+/* returns the overflow flag in bit 0 and, above bit 8, the number of rows that drew noise (test instrumentation) */
 int drv_agent_vision(const DrivingEnv* e, int agentIdx, int noiseType, double magn, float* out) {
   static const cpv BUILDINGS[4] = {{365.0, 200.0}, {365.0, 800.0}, {1385.0, 200.0}, {1385.0, 800.0}};
   const double randBase = 0.01 * magn;                       /* environment_base.py:170 */
@@ -234,6 +235,7 @@ int drv_agent_vision(const DrivingEnv* e, int agentIdx, int noiseType, double ma
   LaneDet lanes[PCAP_LANES + 16];
   int nCars = 0, nObst = 0, nPeds = 0, nLanes = 0, i, j, k, overflow = 0;
   int pedInter[PCAP_PEDS + 16];
+  int noiseDraws = 0;
   double s, c;
   cpv corners[4];
   /* self detection :755-756 */
@@ -345,6 +347,11 @@ int drv_agent_vision(const DrivingEnv* e, int agentIdx, int noiseType, double ma
         }
       }
       /* noise :804-813 */
+      noiseDraws = 1; /* test instrumentation: how many rows draw noise in this pass (the HIP path pools other work on the rest) */
+      for (i = 0; i < nCars; ++i) noiseDraws += cars[i].seen != SIGHT_NONE;
+      for (i = 0; i < nPeds; ++i) noiseDraws += peds[i].seen != SIGHT_NONE;
+      for (i = 0; i < nObst; ++i) noiseDraws += obst[i].seen != SIGHT_NONE;
+      for (i = 0; i < nLanes; ++i) noiseDraws += lanes[i].seen != SIGHT_NONE;
       add_noise_rect(e, &self, noiseType, INTER_NONE, magn, randBase, maxVis1, 0, agentIdx, 0, 0);
       /* noise streams are indexed by the row's position in its (filtered) list = the order of the reference's calls */
       for (i = 0; i < nCars; ++i) add_noise_rect(e, &cars[i], noiseType, INTER_NONE, magn, randBase, maxVis1, 1, agentIdx, 1, i);
@@ -470,5 +477,5 @@ int drv_agent_vision(const DrivingEnv* e, int agentIdx, int noiseType, double ma
     }
     out[dim - 1] = (float)cnt;
   }
-  return overflow;
+  return overflow | (noiseDraws << 8);
 }

@@ -213,9 +213,14 @@ int oracle_obs_overflow(oracle_t* o) {
   if (o->drv) for (e = 0; e < o->cfg.num_envs; ++e) f |= o->drv[e].obsOverflow;
   return f;
 }
+int oracle_obs_noise_draws_max(oracle_t* o) { /* most rows that drew noise in one Driving Partial vision pass so far */
+  int e, m = 0;
+  if (o->drv) for (e = 0; e < o->cfg.num_envs; ++e) if (o->drv[e].obsNoiseDrawsMax > m) m = o->drv[e].obsNoiseDrawsMax;
+  return m;
+}
 void oracle_drv_vision(oracle_t* o, int env, int agent, float* out) {
   DrivingEnv* d = &o->drv[env];
-  d->obsOverflow |= drv_agent_vision(d, agent, d->noiseType, d->noiseMagnitude, out);
+  d->obsOverflow |= drv_agent_vision(d, agent, d->noiseType, d->noiseMagnitude, out) & 0xFF;
 }
 int oracle_active_contacts(oracle_t* o, int32_t env) { return o->drv ? o->drv[env].space.n_active : o->rc[env].space.n_active; }
 

@@ -333,6 +333,61 @@ def test_driving_partial_obs_parity(gpu, noise_type, magn, E, steps):
     env.close()
 
 
+def _crowded_view_scene(st, rng):
+    """Everything within sight of car 0 at the road crossing and nothing hidden: twenty pedestrians in a ring around it, twenty
+    obstacles in a wider ring, the other nine cars (crashed, standing) along the two roads behind those - a pedestrian is only
+    occluded by something nearer than itself."""
+    import kat_scenes_r4 as ks
+    cx, cy = 875.0 + float(rng.uniform(-20, 20)), 500.0 + float(rng.uniform(-20, 20))
+    ks._place_crashed_car(st.cars[0], 0, cx, cy, 0.0)
+    st.n_peds, st.n_obst = 20, 20
+    for i in range(20):
+        a, r = 2 * np.pi * (i + float(rng.uniform(0, 0.5))) / 20, float(rng.uniform(40.0, 70.0))
+        p = st.peds[i]
+        p.px, p.py, p.vx, p.vy = cx + r * np.cos(a), cy + r * np.sin(a), 0.0, 0.0
+        p.road, p.side, p.dead, p.moving, p.speed, p.crossing, p.begin_crossing = i & 1, 0, 1, 0, 4, 0, 0
+        a, r = 2 * np.pi * (i + 0.5 + float(rng.uniform(0, 0.4))) / 20, float(rng.uniform(100.0, 150.0))
+        st.obst_x[i], st.obst_y[i] = cx + r * np.cos(a), cy + r * np.sin(a)
+    spots = [(cx + d, cy) for d in (-420.0, -330.0, -240.0, 240.0, 330.0, 420.0)] + [(cx, cy + d) for d in (-330.0, -240.0, 240.0)]
+    for k in range(1, st.n_cars):
+        x, y = spots[k - 1]
+        ks._place_crashed_car(st.cars[k], int(rng.integers(0, 4)), x + float(rng.uniform(-5, 5)), y + float(rng.uniform(-5, 5)), 0.0)
+
+
+@pytest.mark.parametrize("noise_type", [1, 0])
+def test_driving_partial_crowded_view_parity(gpu, noise_type):
+    """A view with 55+ of the 56 possible rows drawing noise: the HIP pass then has fewer than ten lanes left to carry the
+    random-false-positive trials' Philox blocks and falls back to drawing them separately (driving_partial.hip, phase 5) - a
+    path random scenes never take (the oracle's instrumentation confirms it was taken here)."""
+    dynenv_amd, _, _ = gpu
+    from dynenv_amd import NoiseType, ObservationType
+    E, A = 48, 10
+    env = dynenv_amd.BatchedDynEnv(dynenv_amd.DynEnvType.DRIVE, E, A, observationType=ObservationType.PARTIAL,
+                                   noiseType=NoiseType(noise_type), noiseMagnitude=3.0, seed=77)
+    ora = ol.OracleEnv(env_type=1, num_envs=E, n_players=A, obs_type=1, noise_type=noise_type, noise_magnitude=3.0, seed=77, threads=8)
+    env.reset_flat()
+    ora.reset()
+    rng = np.random.default_rng(31)
+    for e in range(E):
+        st = ora.get_state(e)
+        _crowded_view_scene(st, rng)
+        env.set_state(e, st)
+        ora.set_state(e, st)
+    acts = np.ones((E, A, 2), np.int32)
+    fp_rows = 0
+    for s in range(6):
+        og, rg, dg = env.step_flat(acts, auto_reset=False)
+        oc, rc, dc = ora.step(acts)
+        og = og.cpu().numpy()
+        bad = np.argwhere(og != oc)
+        assert len(bad) == 0, "obs step %d first mismatch at %s: %r vs %r" % (s, bad[0], og[tuple(bad[0])], oc[tuple(bad[0])])
+        np.testing.assert_array_equal(rg.cpu().numpy(), rc)
+    ora.l.oracle_obs_noise_draws_max.restype = C.c_int
+    assert ora.l.oracle_obs_noise_draws_max(ora.h) >= 55, ora.l.oracle_obs_noise_draws_max(ora.h)
+    assert env.error_flags() == 0 and ora.l.oracle_obs_overflow(ora.h) == 0
+    env.close()
+
+
 def test_partial_compat_view(gpu):
     dynenv_amd, _, _ = gpu
     from dynenv_amd import DynEnvType, NoiseType, ObservationType, make_dyn_env
