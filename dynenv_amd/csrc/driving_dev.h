@@ -99,6 +99,11 @@ struct DrvState {
   int* iso;
   int* iso_done;
   unsigned* iso_hw;
+  /* Partial observation: the environments whose agent passes the step launch left to the deferred one (scheduling scratch as
+     well): pvq[16 p] = length, pvq[32 + p E + k] = ids of the list of parity p = pv_par (the host flips it every step; the deferred
+     launch of a step clears the other parity's length for the next one). */
+  int* pvq;
+  int pv_par;
   int tick, iso_on;  /* iso_on: 0 off, 1 isolation (E = one residency round), 2 slow environments first (E larger) */
 };
 #ifndef DRV_ISO_MAX

@@ -1364,7 +1364,7 @@ DE_OOL void drv_partial_obs_fused(PvIn in, uint64_t seed, int A, int* envi, int 
 #define DRV_DEFER_MIN_CONTACT 5 /* contact-path substeps (of 10) from which an environment defers its Partial observation */
 #endif
 #ifndef DRV_FUSED_AGENTS
-#define DRV_FUSED_AGENTS 7 /* agent passes a light environment runs in the step launch */
+#define DRV_FUSED_AGENTS 10 /* agent passes a light environment runs in the step launch */
 #endif
 struct DrvLightRet {
   int cand, dirty, bits;
@@ -1897,7 +1897,10 @@ DRV_PROF(const unsigned long long K1 = __builtin_amdgcn_s_memtime();)
   // here, the rest is left to the deferred launch.  An environment that spent the step on the contact path is among the
   // last to finish and defers everything; a light one keeps as many passes as fit before the heavy ones are done.
   const int fusedAgents = !(PARTIAL && pobs) ? 0 : nContact >= DRV_DEFER_MIN_CONTACT ? 0 : (A < DRV_FUSED_AGENTS ? A : DRV_FUSED_AGENTS);
-  if (PARTIAL && lane == 0) envi[EI_DEFER_OBS] = fusedAgents;  // first agent the deferred launch has to do
+  if (PARTIAL && lane == 0) {
+    envi[EI_DEFER_OBS] = fusedAgents;  // first agent the deferred launch has to do
+    if (pobs && fusedAgents < A) S.pvq[32 + S.pv_par * S.E + atomicAdd(&S.pvq[16 * S.pv_par], 1)] = e;  // ... and this environment on its list
+  }
   drv_iso_report(S, e, fresh_lane(), isoT0);
   if (PARTIAL && fusedAgents > 0) {
     PvIn in;

@@ -582,14 +582,25 @@ DE_OOL void drv_partial_obs_fused(PvIn in, uint64_t seed, int A, int* envi, int 
 // The agent passes the step launch left over (EI_DEFER_OBS = first agent not done there): all of them for the environments
 // that spent the step on the contact path and finish last - ten passes run by their one wave would sit on the launch's
 // critical path, a lone wave being latency bound at ~50 k cycles per pass - and the last few of the light ones.  One
-// wave per (environment, agent) spreads them over the whole chip.
+// wave per (environment, agent) spreads them over the whole chip; the step launch leaves the list of the environments concerned
+// (S.pvq), so the grid is one residency round of blocks that take the items in turn - a grid of E x A blocks, most of which
+// found nothing to do, took 9 us to dispatch.
 extern "C" __global__ void __launch_bounds__(64, 4)
 drv_partial_obs_deferred_kernel(DrvState S, int noiseType, double magn, float* __restrict__ obs) {
-  const int e = blockIdx.x, a = blockIdx.y, lane = threadIdx.x;
-  const int* envi = S.envi + (size_t)e * EI_COUNT;
-  if (a < uniform_i(envi[EI_DEFER_OBS])) return;  // done in the step launch
-  const int nPed = uniform_i(envi[EI_NPED]), nObst = uniform_i(envi[EI_NOBST]), elapsed = uniform_i(envi[EI_ELAPSED]);
-  const uint32_t episode = (uint32_t)uniform_i(envi[EI_EPISODE]);
-  const PvIn in = pv_load_inputs(S, e, lane, nPed, nObst);
-  pv_env(S, g_P, e, lane, nPed, nObst, elapsed, episode, in, noiseType, magn, obs, a, a + 1);
+  const int lane = threadIdx.x, A = S.A;
+  const int* list = S.pvq + 32 + S.pv_par * S.E;
+  const int n = uniform_i(S.pvq[16 * S.pv_par]);
+  if (blockIdx.x == 0 && lane == 0) S.pvq[16 * (S.pv_par ^ 1)] = 0;  // the next step's list starts empty (nobody reads or fills it now)
+  // item j = (agent j / n, listed environment j % n): neighbouring blocks work on different environments
+#pragma unroll 1
+  for (int j = blockIdx.x; j < n * A; j += gridDim.x) {
+    const int a = j / n, e = uniform_i(list[j - a * n]);
+    const int* envi = S.envi + (size_t)e * EI_COUNT;
+    if (a < uniform_i(envi[EI_DEFER_OBS])) continue;  // done in the step launch
+    const int nPed = uniform_i(envi[EI_NPED]), nObst = uniform_i(envi[EI_NOBST]), elapsed = uniform_i(envi[EI_ELAPSED]);
+    const uint32_t episode = (uint32_t)uniform_i(envi[EI_EPISODE]);
+    const PvIn in = pv_load_inputs(S, e, lane, nPed, nObst);
+    pv_env(S, g_P, e, lane, nPed, nObst, elapsed, episode, in, noiseType, magn, obs, a, a + 1);
+    __syncthreads();
+  }
 }

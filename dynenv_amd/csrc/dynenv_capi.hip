@@ -167,6 +167,8 @@ static int iso_reset(dynenv* h) {
   HIP_OK(hipMemset(S.iso, 0, sizeof(int) * DRV_ISO_WORDS));
   HIP_OK(hipMemset(S.iso_done, 0xFF, sizeof(int) * (size_t)S.E));
   HIP_OK(hipMemset(S.iso_hw, 0xFF, sizeof(unsigned) * 2 * 4 * DRV_ISO_GROUPS));
+  HIP_OK(hipMemset(S.pvq, 0, sizeof(int) * 32));  // both deferred-observation lists empty
+  S.pv_par = 0;
   return 0;
 }
 
@@ -458,6 +460,7 @@ int dynenv_create(const dynenv_cfg_t* cfg, dynenv_t** out) {
   rc |= dev_alloc_scratch(h, &S.iso, DRV_ISO_WORDS);
   rc |= dev_alloc_scratch(h, &S.iso_done, E);
   rc |= dev_alloc_scratch(h, &S.iso_hw, 2 * 4 * DRV_ISO_GROUPS);
+  rc |= dev_alloc_scratch(h, &S.pvq, 32 + 2 * (size_t)S.E);
   if (rc) { dynenv_destroy(h); return DYNENV_ERR_HIP; }
   {
     // The slowest environments of the previous step get a SIMD to themselves (drv_iso_assign): only where the block -> SIMD
@@ -676,11 +679,14 @@ int dynenv_step_head(dynenv_t* h, const int32_t* actions_dev, const double* head
   h->S.tick = (h->S.tick + 1) % (3 * (1 << 28));  // (wraps at a multiple of 3: the three isolation lists keep rotating in order)
   if (h->partial && obs_dev)
   {
+    h->S.pv_par ^= 1;
     hipLaunchKernelGGL(drv_step_partial_kernel, dim3(stepGrid), dim3(64), 0, st, h->S, (const int*)actions_dev, rewards_dev, dones_dev, obs_dev,
                        (int)h->cfg.noise_type, (double)h->cfg.noise_magnitude);
     sev.main_done();
-    hipLaunchKernelGGL(drv_partial_obs_deferred_kernel, dim3(h->S.E, h->S.A), dim3(64), 0, st, h->S, (int)h->cfg.noise_type,
-                       (double)h->cfg.noise_magnitude, obs_dev);
+    // one block per (listed environment, agent) in turn, over a grid that fits the device at once: the step launch left a list
+    const long long items = (long long)h->S.E * h->S.A;
+    hipLaunchKernelGGL(drv_partial_obs_deferred_kernel, dim3((unsigned)(items < 4096 ? items : 4096)), dim3(64), 0, st, h->S,
+                       (int)h->cfg.noise_type, (double)h->cfg.noise_magnitude, obs_dev);
   }
   else {
     hipLaunchKernelGGL(drv_step_kernel, dim3(stepGrid), dim3(64), 0, st, h->S, (const int*)actions_dev, h->partial ? (float*)nullptr : obs_dev,

@@ -15,7 +15,7 @@ rep = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 robocup, partial = w.startswith("robocup"), w.endswith("partial")
 E, A = int(os.environ.get("ET_ENVS", "4096")), 10
 kw = dict(observationType=ObservationType.PARTIAL, noiseType=NoiseType.REALISTIC, noiseMagnitude=3) if partial else {}
-env = BatchedDynEnv(DynEnvType.ROBO_CUP if robocup else DynEnvType.DRIVE, E, 5 if robocup else 10, seed=42, **kw)
+env = BatchedDynEnv(DynEnvType.ROBO_CUP if robocup else DynEnvType.DRIVE, E, 5 if robocup else 10, seed=int(os.environ.get("ET_SEED", "42")), **kw)
 g = torch.Generator(device="cuda").manual_seed(4321)
 if robocup:
     hi = torch.tensor([5, 3, 3, 7], device="cuda")
