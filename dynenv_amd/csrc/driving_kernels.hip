@@ -1903,6 +1903,7 @@ DRV_PROF(const unsigned long long K1 = __builtin_amdgcn_s_memtime();)
   }
   drv_iso_report(S, e, fresh_lane(), isoT0);
   if (PARTIAL && fusedAgents > 0) {
+    __builtin_amdgcn_s_setprio(0);  // (an environment that touched the contact path raised it: the vision passes are nobody's critical path)
     PvIn in;
     in.px = in.py = in.ang = in.ox = in.oy = in.gx = in.gy = 0.0; in.flags = 0;
     if (lane < DRV_NB && (lane < A || (lane >= DRV_SLOT_PED && lane < DRV_SLOT_PED + nPed))) {
