@@ -1745,6 +1745,7 @@ DRV_PROF(if (lane < 8 && e < 4096) { g_dbgp[e * 8 + lane] = 0ull; g_dbgs[e * 8 +
   // Environments with live contacts are the long ones and the launch ends with the slowest: their waves get issue priority
   // over the (three) lighter waves they share a SIMD with, from the first instruction on.
   if (occ != 0ull) __builtin_amdgcn_s_setprio(3);
+  else if (PARTIAL) __builtin_amdgcn_s_setprio(1);  // any physics goes before the neighbours' vision passes (priority 0)
   const uint32_t genv = (uint32_t)(S.env_id_offset + e);
 
   const bool isCar = lane < A;
