@@ -1811,6 +1811,7 @@ DE_DEV void rc_step_body(const RcState& S, const int e, const int* __restrict__ 
   // Environments with live contacts are the long ones and the launch ends with the slowest: their waves get issue priority
   // over the lighter waves they share a SIMD with, from the first instruction on.
   if (occ != 0ull) __builtin_amdgcn_s_setprio(3);
+  else if (PARTIAL) __builtin_amdgcn_s_setprio(1);
   rc_load_env(S, L, e, lane, occ, W);
   RcCtx c;
   c.seed = S.seed; c.genv = (uint32_t)(S.env_id_offset + e); c.n = S.n; c.R = R;
@@ -1907,6 +1908,7 @@ RC_PROF(if (lane == 0 && e < 4096) { unsigned long long* d = g_rcprof + e * 12; 
   rc_store_env(S, L, e, lane, occ, W);
   if constexpr (PARTIAL) {
     if (obs && !deferObs) {  // getAgentVision at the five snapshots + processSeens
+      __builtin_amdgcn_s_setprio(0);  // vision is nobody's critical path: behind every neighbour's physics (priority >= 1)
       rc_partial_obs_fused(S.seed, S.env_id_offset, S.envi, S.n, S.R, S.noise_type, S.noise_magn, S.snap, S.flags, S.prew0, S.epr, S.E, S.epo, e, obs, rewards);
     }
   }
