@@ -1900,7 +1900,11 @@ DRV_PROF(const unsigned long long K1 = __builtin_amdgcn_s_memtime();)
   const int fusedAgents = !(PARTIAL && pobs) ? 0 : nContact >= DRV_DEFER_MIN_CONTACT ? 0 : (A < DRV_FUSED_AGENTS ? A : DRV_FUSED_AGENTS);
   if (PARTIAL && lane == 0) {
     envi[EI_DEFER_OBS] = fusedAgents;  // first agent the deferred launch has to do
-    if (pobs && fusedAgents < A) S.pvq[32 + S.pv_par * S.E + atomicAdd(&S.pvq[16 * S.pv_par], 1)] = e;  // ... and this environment on its list
+    if (pobs && fusedAgents < A) {  // ... and this environment on its list
+      const int k = atomicAdd(&S.pvq[16 * S.pv_par], 1);
+      if (k < S.E) S.pvq[32 + S.pv_par * S.E + k] = e;
+      else envi[EI_ERR] = envi[EI_ERR] | 4;  // only a host that replays a captured launch (frozen pv_par: the length is never cleared) gets here
+    }
   }
   drv_iso_report(S, e, fresh_lane(), isoT0);
   if (PARTIAL && fusedAgents > 0) {

@@ -209,7 +209,10 @@ int dynenv_sync(dynenv_t* h, void* stream);
 
 /* OR over all environments of the kernels' error flags (bit 0: contact cache overflow, a pair was dropped; bit 1: an action
  * outside the action space was seen - the reference raises there, DrivingEnvironment.py:365-368 / RoboCupEnvironment.py:543-550;
- * here that agent's action is ignored for the step and the flag stays up until the next reset).
+ * here that agent's action is ignored for the step and the flag stays up until the next reset - also: a Partial observation row
+ * list longer than its capacity, rows dropped; bit 2: Driving Partial, the list of environments left to the deferred
+ * observation launch is full - it is cleared between steps by launches that alternate a host-chosen parity, so only a host that
+ * replays a captured dynenv_step gets here).
  * Synchronises the device. */
 int dynenv_error_flags(dynenv_t* h, int32_t* out);
 
