@@ -1363,6 +1363,9 @@ DE_OOL void drv_partial_obs_fused(PvIn in, uint64_t seed, int A, int* envi, int 
 #ifndef DRV_DEFER_MIN_CONTACT
 #define DRV_DEFER_MIN_CONTACT 5 /* contact-path substeps (of 10) from which an environment defers its Partial observation */
 #endif
+#ifndef DRV_PV_PASS_CYCLES
+#define DRV_PV_PASS_CYCLES 40000 /* what an environment on the contact path allows for one of its own vision passes (it shares its SIMD) */
+#endif
 #ifndef DRV_FUSED_AGENTS
 #define DRV_FUSED_AGENTS 10 /* agent passes a light environment runs in the step launch */
 #endif
@@ -1627,6 +1630,7 @@ DE_DEV int drv_iso_assign(const DrvState& S, int lane) {
   if (!S.iso_on) return b;
   const int buf = S.tick % 3;
   if (b == 0 && lane == 0) { const int nn = (S.tick + 2) % 3; S.iso[nn] = 0; S.iso[3 + nn] = 0; }  // the buffer the NEXT step fills
+  if (S.iso_on == 3) return b;  // timing only (Partial observations): see drv_iso_report and the fused passes in drv_step_body
   int K = uniform_i(S.iso[buf]);
   const int cap = S.iso_on == 1 ? DRV_ISO_MAX : DRV_ISO_LIST;
   K = K < cap ? K : cap;
@@ -1717,6 +1721,7 @@ DE_DEV void drv_iso_report(const DrvState& S, int e, int lane, unsigned long lon
   const int slowest = S.iso[3 + buf];
   // (only the few environments above the floor touch the shared words: 4096 atomics on one address serialise - 0.12 ms, measured)
   if (cycles > DRV_ISO_MIN && cycles > (slowest / 10) * DRV_ISO_TENTHS) atomicMax(&S.iso[3 + nxt], cycles);
+  if (S.iso_on == 3) return;
   if (slowest > DRV_ISO_MIN && cycles > (slowest / 10) * DRV_ISO_TENTHS) {
     const int k = atomicAdd(&S.iso[nxt], 1);
     if (k < DRV_ISO_LIST) S.iso[DRV_ISO_HDR + nxt * DRV_ISO_LIST + k] = e;
@@ -1897,7 +1902,15 @@ DRV_PROF(const unsigned long long K1 = __builtin_amdgcn_s_memtime();)
   // Partial observation of this environment, fused (see drv_partial_obs_fused): the first `fusedAgents` agent passes run
   // here, the rest is left to the deferred launch.  An environment that spent the step on the contact path is among the
   // last to finish and defers everything; a light one keeps as many passes as fit before the heavy ones are done.
-  const int fusedAgents = !(PARTIAL && pobs) ? 0 : nContact >= DRV_DEFER_MIN_CONTACT ? 0 : (A < DRV_FUSED_AGENTS ? A : DRV_FUSED_AGENTS);
+  int fusedAgents = !(PARTIAL && pobs) ? 0 : nContact >= DRV_DEFER_MIN_CONTACT ? 0 : (A < DRV_FUSED_AGENTS ? A : DRV_FUSED_AGENTS);
+  if (PARTIAL && pobs && nContact >= DRV_DEFER_MIN_CONTACT && S.iso_on >= 2) {
+    // ... but most environments on the contact path are done long before the slowest one (258 k cycles on average against 490 k):
+    // until then the launch has idle SIMD time that the deferred launch would have to find again.  The previous step's slowest
+    // environment is the forecast (drv_iso_report keeps it); this one runs as many of its passes as fit into what is left.
+    const int left = uniform_i(S.iso[3 + S.tick % 3]) - (int)(__builtin_amdgcn_s_memtime() - isoT0);
+    const int k = left / DRV_PV_PASS_CYCLES;
+    fusedAgents = k <= 0 ? 0 : (k < A ? k : A);
+  }
   if (PARTIAL && lane == 0) {
     envi[EI_DEFER_OBS] = fusedAgents;  // first agent the deferred launch has to do
     if (pobs && fusedAgents < A) {  // ... and this environment on its list

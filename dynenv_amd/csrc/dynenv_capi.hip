@@ -471,8 +471,11 @@ int dynenv_create(const dynenv_cfg_t* cfg, dynenv_t** out) {
     {
       const bool dev256 = prop.multiProcessorCount * 4 == DRV_ISO_GROUPS, off = getenv("DYNENV_NO_ISOLATION") != nullptr;
       // 1: isolation - one residency round, Full observations (Partial: the fused observation makes the displaced environments
-      //    too long for the second round: +1.4 %);  2: more environments than fit at once - the slow ones simply start first
+      //    too long for the second round: +1.4 %);  2: more environments than fit at once - the slow ones simply start first;
+      // 3: Partial observations - nothing is rescheduled, the step's slowest environment is timed all the same: an environment on
+      //    the contact path runs as many of its own vision passes as fit before that one is done (drv_step_body)
       S.iso_on = off || !dev256 ? 0 : (E == 4 * DRV_ISO_GROUPS ? (h->partial ? 0 : 1) : (E > 4 * DRV_ISO_GROUPS ? 2 : 0));
+      if (!off && S.iso_on == 0 && h->partial) S.iso_on = 3;
     }
     if (iso_reset(h)) { dynenv_destroy(h); return DYNENV_ERR_HIP; }
     h->iso_cfg = S.iso_on;
@@ -786,7 +789,7 @@ int dynenv_debug_counters(dynenv_t* h, int64_t* out4) {
     const int nxt = (h->S.tick + 1) % 3, k = iso[nxt];
     const int cap = h->S.iso_on == 1 ? DRV_ISO_MAX : DRV_ISO_LIST;
     out4[10] = h->S.iso_on ? (k < cap ? k : cap) : -1; out4[11] = iso[7];
-    // out[12]: isolation mode (0 off, 1 SIMD isolation, 2 slow environments first); out[13]: 1 = the next step found the block ->
+    // out[12]: scheduling mode (0 off, 1 SIMD isolation, 2 slow environments first, 3 timing only: Partial); out[13]: 1 = the next step found the block ->
     // SIMD placement validated (mode 1 only; 0 = isolation is holding off); out[14]: launches whose placement did not validate
     out4[12] = h->iso_cfg; out4[13] = h->S.iso_on == 1 ? iso[8 + nxt] : (h->iso_cfg == 1 ? 0 : -1); out4[14] = iso[11];
     out4[15] = h->iso_pauses;  // times the host dropped to the plain launch because the placement kept failing to validate
