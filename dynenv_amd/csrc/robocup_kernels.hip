@@ -1689,8 +1689,12 @@ DE_OOL void rc_write_obs_ool(int lane, int R, int obs_dim, float* __restrict__ o
 // ------------------------------------------------------------------------------------------------
 #include "robocup_partial.hip"
 
+#ifndef RC_PV_PASS_CYCLES
+#define RC_PV_PASS_CYCLES 40000 /* what a contact-path environment allows for one of its own vision passes (it shares its SIMD) */
+#endif
+#define RC_SCHED_MIN 1800000    /* cycles from which an environment may be the step's slowest (a light one needs 1.4 M) */
 #ifndef RC_DEFER_MIN_GENERAL
-#define RC_DEFER_MIN_GENERAL 25 /* rc_physics substeps (of 50) from which an environment defers its Partial observation */
+#define RC_DEFER_MIN_GENERAL 15 /* rc_physics substeps (of 50) from which an environment defers its Partial observation */
 #endif
 struct RcCommonRet {
   uint64_t pairLo, pairHi;  // this lane's pair codes, for rc_physics (S.pairTab)
@@ -1812,6 +1816,8 @@ DE_DEV void rc_step_body(const RcState& S, const int e, const int* __restrict__ 
   // over the lighter waves they share a SIMD with, from the first instruction on.
   if (occ != 0ull) __builtin_amdgcn_s_setprio(3);
   else if (PARTIAL) __builtin_amdgcn_s_setprio(1);
+  const unsigned long long schedT0 = __builtin_amdgcn_s_memtime();
+  if (PARTIAL && e == 0 && lane == 0) S.sched[(S.tick + 2) % 3] = 0;  // the word the NEXT step measures into
   rc_load_env(S, L, e, lane, occ, W);
   RcCtx c;
   c.seed = S.seed; c.genv = (uint32_t)(S.env_id_offset + e); c.n = S.n; c.R = R;
@@ -1898,18 +1904,34 @@ RC_PROF(if (lane == 0 && e < 4096) { unsigned long long* d = g_rcprof + e * 12; 
   __syncthreads();
   // Partial: an environment that spent much of the step in rc_physics is among the last to finish and leaves its vision
   // to the deferred launch (five waves per environment) instead of appending 50 agent passes to the critical path
-  const bool deferObs = PARTIAL && obs && nGeneral >= RC_DEFER_MIN_GENERAL;
+  bool deferObs = PARTIAL && obs && nGeneral >= RC_DEFER_MIN_GENERAL;
+  // ... but most of those are done long before the step's slowest one: until then the launch has idle SIMD time the deferred
+  // launch would have to find again.  The previous step's slowest environment is the forecast (S.sched); an environment runs the
+  // first `ownPasses` of its 5 R passes itself - as many as fit into what is left - and defers the rest.
+  int ownPasses = 0;
+  if (PARTIAL && obs) {
+    const int slowest = G::uniform_i(S.sched[S.tick % 3]);
+    const int cycles = (int)(__builtin_amdgcn_s_memtime() - schedT0);
+    if (deferObs) {
+      const int k = (slowest - cycles) / RC_PV_PASS_CYCLES;
+      ownPasses = k <= 0 ? 0 : (k < 5 * R ? k : 5 * R);
+      if (ownPasses == 5 * R) deferObs = false;
+    }
+    // (only the few environments near the top touch the shared word: thousands of atomics on one address serialise)
+    if (lane == 0 && cycles > RC_SCHED_MIN && cycles > (slowest / 10) * 8) atomicMax(&S.sched[(S.tick + 1) % 3], cycles);
+  }
   if (lane == 0) {
     dones[e] = (uint8_t)(L.envi[RE_ELAPSED] >= RC_MAX_TIME);
     L.envi[RE_OCC] = (int)(uint32_t)occ;
-    if (deferObs) S.deferList[1 + atomicAdd(&S.deferList[0], 1)] = e;
+    if (deferObs) S.deferList[1 + atomicAdd(&S.deferList[0], 1)] = e | (ownPasses << 20);
   }
   __syncthreads();
   rc_store_env(S, L, e, lane, occ, W);
   if constexpr (PARTIAL) {
-    if (obs && !deferObs) {  // getAgentVision at the five snapshots + processSeens
+    if (obs && (!deferObs || ownPasses > 0)) {  // getAgentVision at the five snapshots + processSeens (or the first ownPasses passes)
       __builtin_amdgcn_s_setprio(0);  // vision is nobody's critical path: behind every neighbour's physics (priority >= 1)
-      rc_partial_obs_fused(S.seed, S.env_id_offset, S.envi, S.n, S.R, S.noise_type, S.noise_magn, S.snap, S.flags, S.prew0, S.epr, S.E, S.epo, e, obs, rewards);
+      rc_partial_obs_fused(S.seed, S.env_id_offset, S.envi, S.n, S.R, S.noise_type, S.noise_magn, S.snap, S.flags, S.prew0, S.epr, S.E, S.epo, e, obs, rewards,
+                           S.seenPart, deferObs ? ownPasses : -1);
     }
   }
 }

@@ -475,14 +475,32 @@ static_assert(sizeof(RvLds) <= sizeof(RcLds), "the vision tile must fit in the s
 // has to exist in memory, i.e. the caller would write all 200-odd bytes of it to scratch in every lane before the call.
 DE_OOL void rc_partial_obs_fused(uint64_t seed, int env_id_offset, int* envi, int n, int R, int noise_type, double noise_magn, RvSnap* snap,
                                  int flags, double* prew0, double* epr, int E, double* epo, int e, float* __restrict__ obs,
-                                 double* __restrict__ rewards) {
+                                 double* __restrict__ rewards, int* seenPart, int nPasses) {
   RcState S = RcState();  // (a local that never leaves registers: everything below is inlined)
   S.seed = uniform_u64(seed); S.env_id_offset = uniform_i(env_id_offset); S.envi = uniform_ptr(envi); S.n = uniform_i(n); S.R = uniform_i(R);
   S.noise_type = uniform_i(noise_type); S.noise_magn = uniform_d(noise_magn); S.snap = uniform_ptr(snap); S.flags = uniform_i(flags);
   S.prew0 = uniform_ptr(prew0); S.epr = uniform_ptr(epr); S.E = uniform_i(E); S.epo = uniform_ptr(epo);
   __threadfence();
   __syncthreads();
-  rv_env(S, *reinterpret_cast<RvLds*>(&g_R), uniform_i(e), lane_id(), uniform_ptr(obs), uniform_ptr(rewards));
+  nPasses = uniform_i(nPasses);
+  if (nPasses < 0) { rv_env(S, *reinterpret_cast<RvLds*>(&g_R), uniform_i(e), lane_id(), uniform_ptr(obs), uniform_ptr(rewards)); return; }
+  // the first nPasses passes (pass = snapshot * R + agent) of an environment that leaves the rest to the deferred launch: the seen
+  // counts go where that launch puts its own, rc_partial_finalize_kernel adds the parts up
+  RvLds& V = *reinterpret_cast<RvLds*>(&g_R);
+  const int lane = lane_id();
+  e = uniform_i(e);
+  const RvArgs va = rv_args(S, e);
+  int ov = 0;
+#pragma unroll 1
+  for (int t = 0; t * S.R < nPasses; ++t) {
+    const int aEnd = nPasses - t * S.R < S.R ? nPasses - t * S.R : S.R;
+    for (int i = lane; i < 10 * RCP_SEEN_STRIDE; i += DE_WAVE) V.seen[i] = 0;
+    ov |= rv_snapshot(S, V, va, e, lane, t, uniform_ptr(obs), true, 0, aEnd);
+    int* part = uniform_ptr(seenPart) + ((size_t)e * 5 + t) * 10 * RCP_SEEN_STRIDE;
+    for (int i = lane; i < aEnd * RCP_SEEN_STRIDE; i += DE_WAVE) part[i] = V.seen[i];
+    __syncthreads();
+  }
+  if (ov && lane == 0) S.envi[(size_t)e * RE_COUNT + RE_ERR] |= 2;
 }
 
 // The environments that held a contact through the step finish last; their 50 agent passes run by one lone, latency-bound
@@ -498,7 +516,8 @@ rc_partial_obs_deferred_kernel(RcState S, float* __restrict__ obs) {
   const int count = uniform_i(S.deferList[0]);
   RvLds& V = g_V;
   for (int k = blockIdx.x; k < count; k += gridDim.x) {
-    const int e = uniform_i(S.deferList[1 + k]);
+    const int entry = uniform_i(S.deferList[1 + k]), e = entry & 0xFFFFF;
+    if (t * S.R + a < (entry >> 20)) continue;  // done in the step launch
     for (int i = lane; i < 10 * RCP_SEEN_STRIDE; i += DE_WAVE) V.seen[i] = 0;
     const int ov = rv_snapshot(S, V, rv_args(S, e), e, lane, t, obs, true, a, a + 1);
     if (ov && lane == 0) atomicOr(&S.envi[(size_t)e * RE_COUNT + RE_ERR], 2);
@@ -513,7 +532,7 @@ rc_partial_finalize_kernel(RcState S, double* __restrict__ rewards) {
   const int count = uniform_i(S.deferList[0]);
   RvLds& V = g_V;
   for (int k = blockIdx.x; k < count; k += gridDim.x) {
-    const int e = uniform_i(S.deferList[1 + k]);
+    const int e = uniform_i(S.deferList[1 + k]) & 0xFFFFF;
     const int* part = S.seenPart + (size_t)e * 5 * 10 * RCP_SEEN_STRIDE;
     for (int i = lane; i < 10 * RCP_SEEN_STRIDE; i += DE_WAVE) {
       int s = 0;
