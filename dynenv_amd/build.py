@@ -19,7 +19,7 @@ def needs_build():
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in DEPS)
 
 
-def build(force=False, verbose=False, out=None, defines=()):
+def build(force=False, verbose=False, out=None, defines=(), extra=()):
     """hipcc --offload-arch=gfx950, FMA contraction off (bit-exact parity with the oracle); -fno-optimize-sibling-calls: see
     DE_OOL in csrc/dev_common.h (out-of-line device functions without callee-saved registers).
     `out` / `defines` build an instrumented variant next to the product library (e.g. -DDRV_PROFILE)."""
@@ -30,7 +30,7 @@ def build(force=False, verbose=False, out=None, defines=()):
         hipcc = "hipcc"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-fno-optimize-sibling-calls", "-fPIC", "-shared",
            "-std=c++17", "-Wno-unused-value", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc"),
-           "-o", out or LIB, SRC] + ["-D" + d for d in defines]
+           "-o", out or LIB, SRC] + ["-D" + d for d in defines] + list(extra)
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -210,9 +210,7 @@ static int rc_create(dynenv* h) {
   rc |= dev_alloc(h, &R.snap, E * 5);
   rc |= dev_alloc(h, &R.prew0, E * 16);
   rc |= dev_alloc(h, &R.seenPart, (size_t)E * 5 * 10 * RCP_SEEN_STRIDE);
-  rc |= dev_alloc(h, &R.deferList, (size_t)E + 1);
-  rc |= dev_alloc_scratch(h, &R.sched, 8);
-  R.tick = 0;
+  rc |= dev_alloc(h, &R.deferList, (size_t)E + 1 + 8);
   rc |= dev_alloc(h, &R.s_pair, E * RC_NS);
   rc |= dev_alloc(h, &R.s_meta, E * RC_NS);
   rc |= dev_alloc(h, &R.s_hash, 2 * E * RC_NS);
@@ -637,7 +635,6 @@ int dynenv_step_head(dynenv_t* h, const int32_t* actions_dev, const double* head
   if (h->robocup) {
     if (h->R.obs_type == DYNENV_OBS_PARTIAL && obs_dev) {  // getAgentVision at the five snapshots + processSeens fused into the launch
       HIP_OK(hipMemsetAsync(h->R.deferList, 0, sizeof(int), st));
-      h->R.tick = (h->R.tick + 1) % (3 * (1 << 28));
       if (h->ev_begin) HIP_OK(hipEventRecord(h->ev_begin, st));
       hipLaunchKernelGGL(rc_step_partial_kernel, dim3(h->R.E), dim3(64), 0, st, h->R, (const int*)actions_dev, head_dev, obs_dev, rewards_dev, dones_dev);
       sev.main_done();
@@ -1151,7 +1148,6 @@ int dynenv_checkpoint_load(dynenv_t* h, const void* buf_host, size_t nbytes) {
   if (h->robocup) h->R.seed = a.seed; else h->S.seed = a.seed;
   // the scheduler's lists describe the timing of the steps this handle ran, not the state just restored: start them over
   // (a list that keeps ids from before the restore could be appended to without having been cleared - ADVICE r3)
-  if (h->robocup) { HIP_OK(hipMemset(h->R.sched, 0, sizeof(int) * 8)); h->R.tick = 0; }  // (scheduling scratch, like the lists below)
   if (!h->robocup) {
     if (iso_reset(h)) return DYNENV_ERR_HIP;
     h->S.iso_on = h->iso_cfg; h->iso_last_invalid = 0; h->iso_paused_until = 0; h->steps = 0;

@@ -74,12 +74,12 @@ struct RcState {
   struct RvSnap* snap; /* [E][5] what getAgentVision reads, exported at the step's five snapshots (Partial observation) */
   double* prew0; /* [E][16] positive part of the step's robot + team reward, before the observation reward (Partial) */
   int* seenPart; /* [E][5][120] per-snapshot seen counts of the environments whose vision runs in the deferred launch */
-  int* deferList; /* [E + 1]: [0] = number of environments deferred in this step (zeroed before every step launch), then
-                     id | first deferred pass << 20 (pass = snapshot * R + agent; the passes before it ran in the step launch) */
-  int* sched;     /* [8] scheduling scratch (never checkpointed): [tick % 3] = cycles of the previous step's slowest environment
-                     (the forecast the contact-path environments budget their own vision passes against), [(tick + 1) % 3] is being
-                     measured, [(tick + 2) % 3] cleared */
-  int tick;
+  int* deferList; /* [E + 1 + 8]: [0] = number of environments deferred in this step (zeroed before every step launch), then
+                     id | first deferred pass << 20 (pass = snapshot * R + agent; the passes before it ran in the step launch);
+                     [E + 1] = RC_SCHED: the forecast of the step's slowest environment, in cycles - the running maximum of the
+                     environments' own times, shrunk by 1/64 at the start of every step (contact-path environments budget their own
+                     vision passes against it).  Kept here, not in a field of its own: this struct is a kernel argument and
+                     rc_step_kernel ran 1 % slower with it 16 bytes larger - same instructions, measured three times */
   int obs_type, noise_type;
   double noise_magn;
   int* s_pair;   /* [E][NS] */

@@ -6,6 +6,16 @@
 // environment (lane roles in robocup_dev.h).  Mirrors oracle/robocup.c + oracle/cp_lite.c operation by operation
 // (fp64, FMA contraction off) so results are bit-identical to the CPU oracle.
 #include "robocup_dev.h"
+// Where the RoboCup code starts in the code object.  rc_step_kernel and the out-of-line functions it calls are ~110 KB of
+// instructions, more than the 64 KB instruction cache, and the launch's time moves by ~1 % with their addresses: the same
+// instructions ran 1.418 ms per step in one build and 1.430 in the next, in which only code in FRONT of them had grown (three same-box
+// A/Bs; padding them back to the old addresses modulo 32 KB recovered it).  This function pins the phase: it pads to a 32 KB boundary
+// and on to the offset the 1.418 ms build happened to have, so edits elsewhere (the Driving code in front, the vision code - which
+// is emitted behind the step kernels for the same reason, see the end of this file) no longer move RoboCup's time.
+#ifndef RC_LAYOUT_PAD_WORDS
+#define RC_LAYOUT_PAD_WORDS 6103
+#endif
+extern "C" __device__ __attribute__((used, noinline)) void rc_layout_pad() { asm volatile(".p2align 15\n.fill %0, 4, 0xbf800000" ::"i"(RC_LAYOUT_PAD_WORDS)); }
 
 __constant__ RcConst RC;
 
@@ -1816,8 +1826,9 @@ DE_DEV void rc_step_body(const RcState& S, const int e, const int* __restrict__ 
   // over the lighter waves they share a SIMD with, from the first instruction on.
   if (occ != 0ull) __builtin_amdgcn_s_setprio(3);
   else if (PARTIAL) __builtin_amdgcn_s_setprio(1);
-  const unsigned long long schedT0 = __builtin_amdgcn_s_memtime();
-  if (PARTIAL && e == 0 && lane == 0) S.sched[(S.tick + 2) % 3] = 0;  // the word the NEXT step measures into
+  unsigned long long schedT0 = 0ull;
+  if constexpr (PARTIAL) schedT0 = __builtin_amdgcn_s_memtime();
+  if (PARTIAL && e == 0 && lane == 0) { int* sc = S.deferList + S.E + 1; sc[0] = sc[0] - (sc[0] >> 6); }  // the forecast forgets slowly
   rc_load_env(S, L, e, lane, occ, W);
   RcCtx c;
   c.seed = S.seed; c.genv = (uint32_t)(S.env_id_offset + e); c.n = S.n; c.R = R;
@@ -1906,19 +1917,20 @@ RC_PROF(if (lane == 0 && e < 4096) { unsigned long long* d = g_rcprof + e * 12; 
   // to the deferred launch (five waves per environment) instead of appending 50 agent passes to the critical path
   bool deferObs = PARTIAL && obs && nGeneral >= RC_DEFER_MIN_GENERAL;
   // ... but most of those are done long before the step's slowest one: until then the launch has idle SIMD time the deferred
-  // launch would have to find again.  The previous step's slowest environment is the forecast (S.sched); an environment runs the
+  // launch would have to find again.  The slowest environment of the steps so far is the forecast (RcState.deferList); an environment runs the
   // first `ownPasses` of its 5 R passes itself - as many as fit into what is left - and defers the rest.
   int ownPasses = 0;
   if (PARTIAL && obs) {
-    const int slowest = G::uniform_i(S.sched[S.tick % 3]);
+    int* sc = S.deferList + S.E + 1;
+    const int slowest = G::uniform_i(__atomic_load_n(sc, __ATOMIC_RELAXED));
     const int cycles = (int)(__builtin_amdgcn_s_memtime() - schedT0);
     if (deferObs) {
       const int k = (slowest - cycles) / RC_PV_PASS_CYCLES;
       ownPasses = k <= 0 ? 0 : (k < 5 * R ? k : 5 * R);
       if (ownPasses == 5 * R) deferObs = false;
     }
-    // (only the few environments near the top touch the shared word: thousands of atomics on one address serialise)
-    if (lane == 0 && cycles > RC_SCHED_MIN && cycles > (slowest / 10) * 8) atomicMax(&S.sched[(S.tick + 1) % 3], cycles);
+    // (only an environment slower than everything so far touches the shared word: thousands of atomics on one address serialise)
+    if (lane == 0 && cycles > RC_SCHED_MIN && cycles > slowest) atomicMax(sc, cycles);
   }
   if (lane == 0) {
     dones[e] = (uint8_t)(L.envi[RE_ELAPSED] >= RC_MAX_TIME);
@@ -2124,3 +2136,6 @@ extern "C" __global__ void rc_stats_kernel(RcState S, double* ep_r, double* ep_p
   }
   if (goals) { goals[2 * e] = S.envi[(size_t)e * RE_COUNT + RE_GOAL0]; goals[2 * e + 1] = S.envi[(size_t)e * RE_COUNT + RE_GOAL1]; }
 }
+
+#define RC_PARTIAL_FUNCTIONS
+#include "robocup_partial.hip"

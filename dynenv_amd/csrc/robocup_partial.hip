@@ -38,6 +38,7 @@
 #define RV_STD_NORM (2.0 / RC_W)
 #define RV_SIZE_NORM (10.0 / 5.0)
 
+#ifndef RC_PARTIAL_FUNCTIONS
 struct RvDetTable {  // detections every lane may need (rotPt, `is not None`)
   double px[48], py[48];
   int has[48];
@@ -48,6 +49,14 @@ struct RvSnap {
   int rflags[10], owned, close0, close1, tkey;
   int pad[2];
 };
+// (included twice by robocup_kernels.hip: the definitions above where the step kernel needs them, the functions below - with
+//  RC_PARTIAL_FUNCTIONS - behind the step kernels, so that the distance between rc_step_kernel and the out-of-line functions it
+//  calls does not change with the size of the vision code: the launch's instruction working set is larger than the 64 KB
+//  instruction cache and its time moves by 1-2 % with that distance)
+DE_OOL void rc_partial_obs_fused(uint64_t seed, int env_id_offset, int* envi, int n, int R, int noise_type, double noise_magn, RvSnap* snap,
+                                 int flags, double* prew0, double* epr, int E, double* epo, int e, float* __restrict__ obs,
+                                 double* __restrict__ rewards, int* seenPart, int nPasses);
+#else
 struct RvLds {  // LDS of the observation kernel (2.7 KB: every environment of a 4096-env launch is resident)
   double px[RC_NB], py[RC_NB], ang[RC_NB], head[16];
   int rflags[16], owned, close0, close1, tkey;
@@ -544,3 +553,4 @@ rc_partial_finalize_kernel(RcState S, double* __restrict__ rewards) {
     __syncthreads();
   }
 }
+#endif  // RC_PARTIAL_FUNCTIONS
