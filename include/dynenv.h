@@ -221,7 +221,7 @@ int dynenv_error_flags(dynenv_t* h, int32_t* out);
  * a changed candidate set / a moving body / a non-inert arbiter, substeps served by a steady replay, by the light mode,
  * contact-path substeps whose sweeps ran as split-lane general multi-level solves, the number of environments the next step
  * gives a SIMD of their own (-1: isolation off for this handle), isolation placeholders that gave up waiting (stays 0),
- * the handle's scheduling mode (0 none, 1 SIMD isolation, 2 slow environments first), whether the block -> SIMD placement
+ * the handle's scheduling mode (0 none, 1 SIMD isolation, 2 slow environments first, 3 timing only: Partial observations), whether the block -> SIMD placement
  * isolation relies on validated for the next step (mode 1; it is re-checked on the device every launch and isolation holds
  * off while it does not validate), launches whose placement did not validate (since isolation was last started), the number
  * of times the host paused isolation - plain launches for 2048 steps - because more than half of the launches of a 64-step
