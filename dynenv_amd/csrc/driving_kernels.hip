@@ -1358,13 +1358,13 @@ DRV_PROF(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* d = g_dbgp + 
 // ------------------------------------------------------------------------------------------------
 // THE step kernel: grid = E blocks of one wavefront
 // ------------------------------------------------------------------------------------------------
-DE_OOL void drv_partial_obs_fused(PvIn in, uint64_t seed, int A, int* envi, int env_id_offset, int e, int nPedObst, int elapsed,
-                                  uint32_t episode, int noiseType, double magn, float* __restrict__ obs, int nAgents);  // driving_partial.hip
+DE_OOL int drv_partial_obs_fused(PvIn in, uint64_t seed, int A, int* envi, int env_id_offset, int e, int nPedObst, int elapsed,
+                                 uint32_t episode, int noiseTypeAgents, double magn, float* __restrict__ obs, int budgetCycles);  // driving_partial.hip
 #ifndef DRV_DEFER_MIN_CONTACT
 #define DRV_DEFER_MIN_CONTACT 5 /* contact-path substeps (of 10) from which an environment defers its Partial observation */
 #endif
-#ifndef DRV_PV_PASS_CYCLES
-#define DRV_PV_PASS_CYCLES 40000 /* what an environment on the contact path allows for one of its own vision passes (it shares its SIMD) */
+#ifndef DRV_PV_DEADLINE_PCT
+#define DRV_PV_DEADLINE_PCT 100 /* fused vision passes start until this many percent of the forecast of the launch's slowest environment */
 #endif
 #ifndef DRV_FUSED_AGENTS
 #define DRV_FUSED_AGENTS 10 /* agent passes a light environment runs in the step launch */
@@ -1903,20 +1903,16 @@ DRV_PROF(const unsigned long long K1 = __builtin_amdgcn_s_memtime();)
   // here, the rest is left to the deferred launch.  An environment that spent the step on the contact path is among the
   // last to finish and defers everything; a light one keeps as many passes as fit before the heavy ones are done.
   int fusedAgents = !(PARTIAL && pobs) ? 0 : nContact >= DRV_DEFER_MIN_CONTACT ? 0 : (A < DRV_FUSED_AGENTS ? A : DRV_FUSED_AGENTS);
-  if (PARTIAL && pobs && nContact >= DRV_DEFER_MIN_CONTACT && S.iso_on >= 2) {
-    // ... but most environments on the contact path are done long before the slowest one (258 k cycles on average against 490 k):
-    // until then the launch has idle SIMD time that the deferred launch would have to find again.  The previous step's slowest
-    // environment is the forecast (drv_iso_report keeps it); this one runs as many of its passes as fit into what is left.
-    const int left = uniform_i(S.iso[3 + S.tick % 3]) - (int)(__builtin_amdgcn_s_memtime() - isoT0);
-    const int k = left / DRV_PV_PASS_CYCLES;
-    fusedAgents = k <= 0 ? 0 : (k < A ? k : A);
-  }
-  if (PARTIAL && lane == 0) {
-    envi[EI_DEFER_OBS] = fusedAgents;  // first agent the deferred launch has to do
-    if (pobs && fusedAgents < A) {  // ... and this environment on its list
-      const int k = atomicAdd(&S.pvq[16 * S.pv_par], 1);
-      if (k < S.E) S.pvq[32 + S.pv_par * S.E + k] = e;
-      else envi[EI_ERR] = envi[EI_ERR] | 4;  // only a host that replays a captured launch (frozen pv_par: the length is never cleared) gets here
+  // With a forecast of when the launch will end (the previous step's slowest environment, drv_iso_report keeps it) every
+  // environment, light or not, simply runs its passes until then and leaves the rest: the SIMDs whose four waves are all light are
+  // the ones with the most vision to do (an environment on the contact path is done with its physics later and gets to fewer of
+  // its passes), and they - not the slowest environment - were what the launch waited for.
+  int budget = 0;
+  if (PARTIAL && pobs && S.iso_on >= 2) {
+    const int slowest = uniform_i(S.iso[3 + S.tick % 3]);
+    if (slowest > 0) {
+      budget = (slowest / 100) * DRV_PV_DEADLINE_PCT - (int)(__builtin_amdgcn_s_memtime() - isoT0);
+      fusedAgents = budget > 0 ? A : 0;
     }
   }
   drv_iso_report(S, e, fresh_lane(), isoT0);
@@ -1929,7 +1925,16 @@ DRV_PROF(const unsigned long long K1 = __builtin_amdgcn_s_memtime();)
     }
     if (lane < nObst) { in.ox = L.ox[lane]; in.oy = L.oy[lane]; }
     if (lane < A) { in.gx = L.goalx[lane]; in.gy = L.goaly[lane]; }
-    drv_partial_obs_fused(in, S.seed, S.A, S.envi, S.env_id_offset, e, nPed | (nObst << 8), elapsed, episode, pvNoise, pvMagn, pobs, fusedAgents);
+    fusedAgents = drv_partial_obs_fused(in, S.seed, S.A, S.envi, S.env_id_offset, e, nPed | (nObst << 8), elapsed, episode, pvNoise | (fusedAgents << 8), pvMagn,
+                                        pobs, budget);
+  }
+  if (PARTIAL && fresh_lane() == 0) {
+    envi[EI_DEFER_OBS] = fusedAgents;  // first agent the deferred launch has to do
+    if (pobs && fusedAgents < A) {  // ... and this environment on its list
+      const int k = atomicAdd(&S.pvq[16 * S.pv_par], 1);
+      if (k < S.E) S.pvq[32 + S.pv_par * S.E + k] = e;
+      else envi[EI_ERR] = envi[EI_ERR] | 4;  // only a host that replays a captured launch (frozen pv_par: the length is never cleared) gets here
+    }
   }
 DRV_PROF(if (lane == 0 && e < 4096) { unsigned long long* d = g_dbgw + e * 12; const unsigned long long KE = __builtin_amdgcn_s_memtime(); d[0] = KE - KS; d[1] = nContact; d[2] = __popcll(occ); d[3] = nSteady + nQuiet; d[4] = K0 - KS; d[5] = tPh1; d[6] = tBroad; d[7] = tFast; d[8] = tCont; d[9] = (K1 - K0) - tPh1 - tBroad - tFast - tCont; d[10] = KE - K1; d[11] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned long long)__builtin_amdgcn_s_getreg(63492); })
 }

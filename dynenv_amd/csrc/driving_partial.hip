@@ -77,9 +77,10 @@ DE_DEV int pv_interact(int seen1, V2 point1, double angle1, const PvBlocker& b, 
 
 // The observation of every agent of environment e.  `in` carries the per-lane state (from HBM in the stand-alone kernel,
 // straight from the step kernel's LDS tile in the fused call); L is this wave's scratch tile.
-DE_DEV void pv_env(const DrvState& S, PvLds& L, const int e, const int lane, const int nPed, const int nObst, const int elapsed,
-                   const uint32_t episode, const PvIn& in, const int noiseType, const double magn, float* __restrict__ obs,
-                   const int aBegin, const int aEnd) {
+// Returns the first agent it did NOT do: aEnd, or less when `deadline` (a s_memtime value, 0 = none) had passed before a pass.
+DE_DEV int pv_env(const DrvState& S, PvLds& L, const int e, const int lane, const int nPed, const int nObst, const int elapsed,
+                  const uint32_t episode, const PvIn& in, const int noiseType, const double magn, float* __restrict__ obs,
+                  const int aBegin, const int aEnd, const unsigned long long deadline = 0ull) {
   const int A = S.A;
   int* envi = S.envi + (size_t)e * EI_COUNT;
   const uint32_t genv = (uint32_t)(S.env_id_offset + e);
@@ -98,8 +99,10 @@ DE_DEV void pv_env(const DrvState& S, PvLds& L, const int e, const int lane, con
   const uint64_t carLanes = wave_ballot(isCarLane), pedLanes = wave_ballot(isPedLane), obsLanes = wave_ballot(isObsLane);
   (void)carLanes;
 
+  int a = aBegin;
 #pragma unroll 1
-  for (int a = aBegin; a < aEnd; ++a) {
+  for (; a < aEnd; ++a) {
+    if (deadline != 0ull && __builtin_amdgcn_s_memtime() >= deadline) break;
     float* __restrict__ grow = obs + ((size_t)e * A + a) * PV_DIM;
     float* row = L.row;
     for (int i = lane; i < PV_DIM; i += DE_WAVE) row[i] = 0.0f;
@@ -533,6 +536,7 @@ DE_DEV void pv_env(const DrvState& S, PvLds& L, const int e, const int lane, con
     __syncthreads();
   }
   if (wave_ballot(overflow != 0) && lane == 0) envi[EI_ERR] = envi[EI_ERR] | 2;
+  return a;
 }
 
 DE_DEV PvIn pv_load_inputs(const DrvState& S, int e, int lane, int nPed, int nObst) {
@@ -569,14 +573,19 @@ static_assert(sizeof(PvLds) <= sizeof(DrvLds), "the Partial observation tile mus
 // The per-lane inputs come first in the argument list (an aggregate is passed in registers only while the function has 16 argument
 // registers left, else through scratch), and of the state the function receives the four fields it reads, as scalars, not a
 // reference to the struct (which the caller would first have to write to scratch, all of it, in every lane).
-DE_OOL void drv_partial_obs_fused(PvIn in, uint64_t seed, int A, int* envi, int env_id_offset, int e, int nPedObst, int elapsed,
-                                  uint32_t episode, int noiseType, double magn, float* __restrict__ obs, int nAgents) {
+DE_OOL int drv_partial_obs_fused(PvIn in, uint64_t seed, int A, int* envi, int env_id_offset, int e, int nPedObst, int elapsed,
+                                 uint32_t episode, int noiseTypeAgents, double magn, float* __restrict__ obs, int budgetCycles) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   const int nPed = nPedObst & 0xFF, nObst = nPedObst >> 8;  // (one register: with v31 reserved there are 31 for arguments)
+  const int noiseType = noiseTypeAgents & 0xFF, nAgents = noiseTypeAgents >> 8;
   DrvState S = DrvState();  // (a local that never leaves registers: pv_env is inlined)
   S.seed = uniform_u64(seed); S.A = uniform_i(A); S.envi = uniform_ptr(envi); S.env_id_offset = uniform_i(env_id_offset);
+  budgetCycles = uniform_i(budgetCycles);
   __syncthreads();  // every lane has taken what it needs out of the step tile
-  pv_env(S, *reinterpret_cast<PvLds*>(&g_L), uniform_i(e), lane_id(), uniform_i(nPed), uniform_i(nObst), uniform_i(elapsed),
-         (uint32_t)uniform_i((int)episode), in, uniform_i(noiseType), uniform_d(magn), uniform_ptr(obs), 0, uniform_i(nAgents));
+  // budgetCycles > 0: run passes until that many cycles from now have gone (the launch's forecast end), leave the rest
+  return pv_env(S, *reinterpret_cast<PvLds*>(&g_L), uniform_i(e), lane_id(), uniform_i(nPed), uniform_i(nObst), uniform_i(elapsed),
+                (uint32_t)uniform_i((int)episode), in, uniform_i(noiseType), uniform_d(magn), uniform_ptr(obs), 0, uniform_i(nAgents),
+                budgetCycles > 0 ? t0 + (unsigned long long)budgetCycles : 0ull);
 }
 
 // The agent passes the step launch left over (EI_DEFER_OBS = first agent not done there): all of them for the environments
