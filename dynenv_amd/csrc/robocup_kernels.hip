@@ -1699,8 +1699,8 @@ DE_OOL void rc_write_obs_ool(int lane, int R, int obs_dim, float* __restrict__ o
 // ------------------------------------------------------------------------------------------------
 #include "robocup_partial.hip"
 
-#ifndef RC_PV_PASS_CYCLES
-#define RC_PV_PASS_CYCLES 40000 /* what a contact-path environment allows for one of its own vision passes (it shares its SIMD) */
+#ifndef RC_PV_DEADLINE_PCT
+#define RC_PV_DEADLINE_PCT 95 /* fused vision passes start until this many percent of the forecast of the launch's slowest environment */
 #endif
 #define RC_SCHED_MIN 1800000    /* cycles from which an environment may be the step's slowest (a light one needs 1.4 M) */
 #ifndef RC_DEFER_MIN_GENERAL
@@ -1915,35 +1915,35 @@ RC_PROF(if (lane == 0 && e < 4096) { unsigned long long* d = g_rcprof + e * 12; 
   __syncthreads();
   // Partial: an environment that spent much of the step in rc_physics is among the last to finish and leaves its vision
   // to the deferred launch (five waves per environment) instead of appending 50 agent passes to the critical path
-  bool deferObs = PARTIAL && obs && nGeneral >= RC_DEFER_MIN_GENERAL;
-  // ... but most of those are done long before the step's slowest one: until then the launch has idle SIMD time the deferred
-  // launch would have to find again.  The slowest environment of the steps so far is the forecast (RcState.deferList); an environment runs the
-  // first `ownPasses` of its 5 R passes itself - as many as fit into what is left - and defers the rest.
-  int ownPasses = 0;
+  // Partial: with a forecast of when the launch will end (the running maximum of the environments' own times, RcState.deferList) every
+  // environment runs its vision passes - 5 R of them, in (snapshot, agent) order - until then and leaves the rest to the deferred
+  // launch: the SIMDs whose four waves are all light have the most vision to do and finish about when the slowest environment
+  // does; an environment that spent the step in rc_physics gets to fewer of its passes.  Without a forecast (no environment has
+  // been slow yet) the old rule: all or, from RC_DEFER_MIN_GENERAL substeps of contact work, nothing.
+  int budget = 0, ownPasses = 5 * R;
   if (PARTIAL && obs) {
     int* sc = S.deferList + S.E + 1;
     const int slowest = G::uniform_i(__atomic_load_n(sc, __ATOMIC_RELAXED));
     const int cycles = (int)(__builtin_amdgcn_s_memtime() - schedT0);
-    if (deferObs) {
-      const int k = (slowest - cycles) / RC_PV_PASS_CYCLES;
-      ownPasses = k <= 0 ? 0 : (k < 5 * R ? k : 5 * R);
-      if (ownPasses == 5 * R) deferObs = false;
-    }
+    if (slowest > 0) { budget = (slowest / 100) * RC_PV_DEADLINE_PCT - cycles; if (budget <= 0) ownPasses = 0; }
+    else if (nGeneral >= RC_DEFER_MIN_GENERAL) ownPasses = 0;
     // (only an environment slower than everything so far touches the shared word: thousands of atomics on one address serialise)
     if (lane == 0 && cycles > RC_SCHED_MIN && cycles > slowest) atomicMax(sc, cycles);
   }
   if (lane == 0) {
     dones[e] = (uint8_t)(L.envi[RE_ELAPSED] >= RC_MAX_TIME);
     L.envi[RE_OCC] = (int)(uint32_t)occ;
-    if (deferObs) S.deferList[1 + atomicAdd(&S.deferList[0], 1)] = e | (ownPasses << 20);
   }
   __syncthreads();
   rc_store_env(S, L, e, lane, occ, W);
   if constexpr (PARTIAL) {
-    if (obs && (!deferObs || ownPasses > 0)) {  // getAgentVision at the five snapshots + processSeens (or the first ownPasses passes)
-      __builtin_amdgcn_s_setprio(0);  // vision is nobody's critical path: behind every neighbour's physics (priority >= 1)
-      rc_partial_obs_fused(S.seed, S.env_id_offset, S.envi, S.n, S.R, S.noise_type, S.noise_magn, S.snap, S.flags, S.prew0, S.epr, S.E, S.epo, e, obs, rewards,
-                           S.seenPart, deferObs ? ownPasses : -1);
+    if (obs) {
+      if (ownPasses > 0) {  // getAgentVision at the five snapshots (+ processSeens if it gets through all of them)
+        __builtin_amdgcn_s_setprio(0);  // vision is nobody's critical path: behind every neighbour's physics (priority >= 1)
+        ownPasses = rc_partial_obs_fused(S.seed, S.env_id_offset, S.envi, S.n, S.R, S.noise_type, S.noise_magn, S.snap, S.flags, S.prew0, S.epr, S.E, S.epo, e, obs,
+                                         rewards, S.seenPart, budget);
+      }
+      if (ownPasses < 5 * R && G::lane() == 0) S.deferList[1 + atomicAdd(&S.deferList[0], 1)] = e | (ownPasses << 20);
     }
   }
 }

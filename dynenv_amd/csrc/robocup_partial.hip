@@ -53,15 +53,16 @@ struct RvSnap {
 //  RC_PARTIAL_FUNCTIONS - behind the step kernels, so that the distance between rc_step_kernel and the out-of-line functions it
 //  calls does not change with the size of the vision code: the launch's instruction working set is larger than the 64 KB
 //  instruction cache and its time moves by 1-2 % with that distance)
-DE_OOL void rc_partial_obs_fused(uint64_t seed, int env_id_offset, int* envi, int n, int R, int noise_type, double noise_magn, RvSnap* snap,
-                                 int flags, double* prew0, double* epr, int E, double* epo, int e, float* __restrict__ obs,
-                                 double* __restrict__ rewards, int* seenPart, int nPasses);
+DE_OOL int rc_partial_obs_fused(uint64_t seed, int env_id_offset, int* envi, int n, int R, int noise_type, double noise_magn, RvSnap* snap,
+                                int flags, double* prew0, double* epr, int E, double* epo, int e, float* __restrict__ obs,
+                                double* __restrict__ rewards, int* seenPart, int budgetCycles);
 #else
 struct RvLds {  // LDS of the observation kernel (2.7 KB: every environment of a 4096-env launch is resident)
   double px[RC_NB], py[RC_NB], ang[RC_NB], head[16];
   int rflags[16], owned, close0, close1, tkey;
   RvDetTable T;
   int seen[10 * RCP_SEEN_STRIDE];
+  int seenSum[10 * RCP_SEEN_STRIDE];  // (fused path with a deadline: the sum over the snapshots done so far)
 };
 __shared__ RvLds g_V;
 DE_DEV V2 rv_pos(const RvLds& V, int r) { return v2((V.px[2 * r] + V.px[2 * r + 1]) / 2.0, (V.py[2 * r] + V.py[2 * r + 1]) / 2.0); }  // Robot.getPos
@@ -98,7 +99,9 @@ struct RvArgs {
 };
 
 // One snapshot: rows of all R agents -> out[R][RCP_DIM]; seen += the snapshot's (numLandMarks, ballsSeen, robotsSeen)
-DE_DEV int rc_partial_vision(const RvArgs& A, RvLds& V, int lane, float* __restrict__ out, bool countSeen, int aBegin, int aEnd) {
+// Returns overflow (bit 0) | first agent NOT done << 8 (aEnd, or less when `deadline` - a s_memtime value, 0 = none - had passed).
+DE_DEV int rc_partial_vision(const RvArgs& A, RvLds& V, int lane, float* __restrict__ out, bool countSeen, int aBegin, int aEnd,
+                             unsigned long long deadline = 0ull) {
   RvDetTable& T = V.T;
   int* seen = countSeen ? V.seen : nullptr;
   const int R = A.R;
@@ -109,8 +112,10 @@ DE_DEV int rc_partial_vision(const RvArgs& A, RvLds& V, int lane, float* __restr
   const bool isBall = lane == 0, isRob = lane >= 1 && lane < R, isGoal = lane >= 10 && lane < 14, isCross = lane >= 14 && lane < 17;
   const bool isFc = lane >= 17 && lane < 33, isLine = lane >= 33 && lane < 44, isTrial = lane >= 44 && lane < 54;
   const bool isPoint = isBall || isRob || isGoal || isCross || isFc;
+  int a = aBegin;
 #pragma unroll 1
-  for (int a = aBegin; a < aEnd; ++a) {
+  for (; a < aEnd; ++a) {
+    if (deadline != 0ull && __builtin_amdgcn_s_memtime() >= deadline) break;
     float* __restrict__ row = out + (size_t)a * RCP_DIM;
     for (int i = lane; i < RCP_DIM; i += DE_WAVE) row[i] = 0.0f;
     const V2 pos = rv_pos(V, a);
@@ -403,7 +408,7 @@ DE_DEV int rc_partial_vision(const RvArgs& A, RvLds& V, int lane, float* __restr
     }
     __syncthreads();  // the detection table is rewritten by the next agent
   }
-  return (int)(wave_ballot(overflow != 0) != 0ull);
+  return (int)(wave_ballot(overflow != 0) != 0ull) | (a << 8);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -422,7 +427,7 @@ DE_DEV RvArgs rv_args(const RcState& S, int e) {
 }
 // snapshot t of environment e -> its R observation rows (+ the snapshot's seen counts into V.seen)
 DE_DEV int rv_snapshot(const RcState& S, RvLds& V, RvArgs va, int e, int lane, int t, float* __restrict__ obs, bool countSeen,
-                       int aBegin, int aEnd) {
+                       int aBegin, int aEnd, unsigned long long deadline = 0ull) {
   const RvSnap& sn = S.snap[(size_t)e * 5 + t];
   if (lane < 21) { V.px[lane] = sn.px[lane]; V.py[lane] = sn.py[lane]; }
   if (lane < 20) V.ang[lane] = sn.ang[lane];
@@ -430,7 +435,7 @@ DE_DEV int rv_snapshot(const RcState& S, RvLds& V, RvArgs va, int e, int lane, i
   if (lane == 0) { V.owned = sn.owned; V.close0 = sn.close0; V.close1 = sn.close1; V.tkey = sn.tkey; }
   __syncthreads();
   va.tkey = (uint32_t)uniform_i(V.tkey);
-  const int ov = rc_partial_vision(va, V, lane, obs + ((size_t)e * 5 + t) * S.R * RCP_DIM, countSeen, aBegin, aEnd);
+  const int ov = rc_partial_vision(va, V, lane, obs + ((size_t)e * 5 + t) * S.R * RCP_DIM, countSeen, aBegin, aEnd, deadline);
   __syncthreads();
   return ov;
 }
@@ -466,7 +471,7 @@ DE_DEV void rv_env(const RcState& S, RvLds& V, const int e, const int lane, floa
   const RvArgs va = rv_args(S, e);
   int ov = 0;
 #pragma unroll 1
-  for (int t = 0; t < 5; ++t) ov |= rv_snapshot(S, V, va, e, lane, t, obs, rewards != nullptr, 0, S.R);
+  for (int t = 0; t < 5; ++t) ov |= rv_snapshot(S, V, va, e, lane, t, obs, rewards != nullptr, 0, S.R) & 1;
   if (ov && lane == 0) S.envi[(size_t)e * RE_COUNT + RE_ERR] |= 2;
   if (rewards) rv_finalize(S, V.seen, e, lane, rewards);
 }
@@ -482,34 +487,42 @@ rc_partial_obs_kernel(RcState S, float* __restrict__ obs, double* __restrict__ r
 static_assert(sizeof(RvLds) <= sizeof(RcLds), "the vision tile must fit in the step kernel's LDS tile");
 // What it needs of the state arrives as scalar arguments (25 registers), not as a reference to the struct: a by-reference struct
 // has to exist in memory, i.e. the caller would write all 200-odd bytes of it to scratch in every lane before the call.
-DE_OOL void rc_partial_obs_fused(uint64_t seed, int env_id_offset, int* envi, int n, int R, int noise_type, double noise_magn, RvSnap* snap,
-                                 int flags, double* prew0, double* epr, int E, double* epo, int e, float* __restrict__ obs,
-                                 double* __restrict__ rewards, int* seenPart, int nPasses) {
+DE_OOL int rc_partial_obs_fused(uint64_t seed, int env_id_offset, int* envi, int n, int R, int noise_type, double noise_magn, RvSnap* snap,
+                                int flags, double* prew0, double* epr, int E, double* epo, int e, float* __restrict__ obs,
+                                double* __restrict__ rewards, int* seenPart, int budgetCycles) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   RcState S = RcState();  // (a local that never leaves registers: everything below is inlined)
   S.seed = uniform_u64(seed); S.env_id_offset = uniform_i(env_id_offset); S.envi = uniform_ptr(envi); S.n = uniform_i(n); S.R = uniform_i(R);
   S.noise_type = uniform_i(noise_type); S.noise_magn = uniform_d(noise_magn); S.snap = uniform_ptr(snap); S.flags = uniform_i(flags);
   S.prew0 = uniform_ptr(prew0); S.epr = uniform_ptr(epr); S.E = uniform_i(E); S.epo = uniform_ptr(epo);
   __threadfence();
   __syncthreads();
-  nPasses = uniform_i(nPasses);
-  if (nPasses < 0) { rv_env(S, *reinterpret_cast<RvLds*>(&g_R), uniform_i(e), lane_id(), uniform_ptr(obs), uniform_ptr(rewards)); return; }
-  // the first nPasses passes (pass = snapshot * R + agent) of an environment that leaves the rest to the deferred launch: the seen
-  // counts go where that launch puts its own, rc_partial_finalize_kernel adds the parts up
+  // Passes in (snapshot, agent) order until `budgetCycles` from now have gone (<= 0: no limit).  All 5 R done: processSeens right
+  // here.  Otherwise the seen counts of what was done go where the deferred launch puts its own (seenPart) and the number of
+  // passes done is returned: the caller lists the environment for the deferred launch, rc_partial_finalize_kernel adds the parts up.
+  budgetCycles = uniform_i(budgetCycles);
+  const unsigned long long deadline = budgetCycles > 0 ? t0 + (unsigned long long)budgetCycles : 0ull;
   RvLds& V = *reinterpret_cast<RvLds*>(&g_R);
   const int lane = lane_id();
   e = uniform_i(e);
   const RvArgs va = rv_args(S, e);
-  int ov = 0;
+  for (int i = lane; i < 10 * RCP_SEEN_STRIDE; i += DE_WAVE) V.seenSum[i] = 0;
+  int ov = 0, done = 0;
 #pragma unroll 1
-  for (int t = 0; t * S.R < nPasses; ++t) {
-    const int aEnd = nPasses - t * S.R < S.R ? nPasses - t * S.R : S.R;
+  for (int t = 0; t < 5; ++t) {
     for (int i = lane; i < 10 * RCP_SEEN_STRIDE; i += DE_WAVE) V.seen[i] = 0;
-    ov |= rv_snapshot(S, V, va, e, lane, t, uniform_ptr(obs), true, 0, aEnd);
+    const int r = rv_snapshot(S, V, va, e, lane, t, uniform_ptr(obs), true, 0, S.R, deadline);
+    const int aEnd = uniform_i(r >> 8);
+    ov |= r & 1;
     int* part = uniform_ptr(seenPart) + ((size_t)e * 5 + t) * 10 * RCP_SEEN_STRIDE;
-    for (int i = lane; i < aEnd * RCP_SEEN_STRIDE; i += DE_WAVE) part[i] = V.seen[i];
+    for (int i = lane; i < aEnd * RCP_SEEN_STRIDE; i += DE_WAVE) { const int v = V.seen[i]; part[i] = v; V.seenSum[i] += v; }
     __syncthreads();
+    done += aEnd;
+    if (aEnd < S.R) break;
   }
   if (ov && lane == 0) S.envi[(size_t)e * RE_COUNT + RE_ERR] |= 2;
+  if (done == 5 * S.R) rv_finalize(S, V.seenSum, e, lane, uniform_ptr(rewards));
+  return done;
 }
 
 // The environments that held a contact through the step finish last; their 50 agent passes run by one lone, latency-bound
@@ -528,7 +541,7 @@ rc_partial_obs_deferred_kernel(RcState S, float* __restrict__ obs) {
     const int entry = uniform_i(S.deferList[1 + k]), e = entry & 0xFFFFF;
     if (t * S.R + a < (entry >> 20)) continue;  // done in the step launch
     for (int i = lane; i < 10 * RCP_SEEN_STRIDE; i += DE_WAVE) V.seen[i] = 0;
-    const int ov = rv_snapshot(S, V, rv_args(S, e), e, lane, t, obs, true, a, a + 1);
+    const int ov = rv_snapshot(S, V, rv_args(S, e), e, lane, t, obs, true, a, a + 1) & 1;
     if (ov && lane == 0) atomicOr(&S.envi[(size_t)e * RE_COUNT + RE_ERR], 2);
     int* part = S.seenPart + ((size_t)e * 5 + t) * 10 * RCP_SEEN_STRIDE + a * RCP_SEEN_STRIDE;
     if (lane < RCP_SEEN_STRIDE) part[lane] = V.seen[a * RCP_SEEN_STRIDE + lane];
