@@ -1925,7 +1925,8 @@ RC_PROF(if (lane == 0 && e < 4096) { unsigned long long* d = g_rcprof + e * 12; 
     int* sc = S.deferList + S.E + 1;
     const int slowest = G::uniform_i(__atomic_load_n(sc, __ATOMIC_RELAXED));
     const int cycles = (int)(__builtin_amdgcn_s_memtime() - schedT0);
-    if (slowest > 0) { budget = (slowest / 100) * RC_PV_DEADLINE_PCT - cycles; if (budget <= 0) ownPasses = 0; }
+    // (a forecast below RC_SCHED_MIN is what is left of an old one, shrunk step by step while nobody was slow: no forecast)
+    if (slowest >= RC_SCHED_MIN) { budget = (slowest / 100) * RC_PV_DEADLINE_PCT - cycles; if (budget <= 0) ownPasses = 0; }
     else if (nGeneral >= RC_DEFER_MIN_GENERAL) ownPasses = 0;
     // (only an environment slower than everything so far touches the shared word: thousands of atomics on one address serialise)
     if (lane == 0 && cycles > RC_SCHED_MIN && cycles > slowest) atomicMax(sc, cycles);

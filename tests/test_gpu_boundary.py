@@ -395,6 +395,37 @@ def test_simd_isolation_changes_the_schedule_and_nothing_else(gpu, monkeypatch, 
     iso.close(); ref.close()
 
 
+@pytest.mark.parametrize("E,steps", [(4096, 300), (6000, 260)])
+def test_partial_vision_deadline_changes_the_schedule_and_nothing_else(gpu, monkeypatch, E, steps):
+    """Driving with Partial observations: with a forecast of the launch's end (scheduling mode 3, or 2 with more environments than
+    one residency round) every environment runs its vision passes until then and leaves the rest to the deferred launch; a handle
+    created with DYNENV_NO_ISOLATION=1 has no forecast and follows the static rule (all ten passes fused, or none from five
+    contact-path substeps on).  Who computes a pass must not matter: observations, rewards, dones and states bit for bit."""
+    dynenv_amd, torch, _ = gpu
+    from dynenv_amd import NoiseType, ObservationType
+    A = 10
+    kw = dict(observationType=ObservationType.PARTIAL, noiseType=NoiseType.REALISTIC, noiseMagnitude=3, seed=13)
+    dyn = dynenv_amd.BatchedDynEnv(dynenv_amd.DynEnvType.DRIVE, E, A, **kw)
+    monkeypatch.setenv("DYNENV_NO_ISOLATION", "1")
+    ref = dynenv_amd.BatchedDynEnv(dynenv_amd.DynEnvType.DRIVE, E, A, **kw)
+    monkeypatch.delenv("DYNENV_NO_ISOLATION")
+    assert ref.debug_counters()["isolation_mode"] == 0 and dyn.debug_counters()["isolation_mode"] in (2, 3)
+    o1, o2 = dyn.reset_flat(), ref.reset_flat()
+    assert torch.equal(o1, o2)
+    g = torch.Generator(device="cuda").manual_seed(6)
+    for s in range(steps):
+        a = torch.randint(0, 3, (E, A, 2), generator=g, device="cuda", dtype=torch.int32)
+        o1, r1, d1 = dyn.step_flat(a, auto_reset=False)
+        o2, r2, d2 = ref.step_flat(a, auto_reset=False)
+        if s % 10 == 9 or s == steps - 1:
+            assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2), "step %d" % s
+    assert dyn.debug_counters()["contact"] > 0
+    for e in (0, 1, 1023, 2048, E - 1):
+        assert bytes(dyn.get_state(e)) == bytes(ref.get_state(e)), "state of environment %d" % e
+    assert dyn.error_flags() == 0 and ref.error_flags() == 0
+    dyn.close(); ref.close()
+
+
 def test_two_handles_on_two_streams_isolation_validates_itself(gpu, monkeypatch):
     """Two 4096-environment Driving handles stepped concurrently on two streams: the block -> SIMD placement that isolation
     assumes (one launch owning the device) no longer holds.  Every launch records where its blocks ran and the next ones only
