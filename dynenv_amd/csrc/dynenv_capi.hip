@@ -209,8 +209,10 @@ static int rc_create(dynenv* h) {
   rc |= dev_alloc(h, &R.epo, E * 16);
   rc |= dev_alloc(h, &R.snap, E * 5);
   rc |= dev_alloc(h, &R.prew0, E * 16);
-  rc |= dev_alloc(h, &R.seenPart, (size_t)E * 5 * 10 * RCP_SEEN_STRIDE);
-  rc |= dev_alloc(h, &R.deferList, (size_t)E + 1 + 8);
+  // (per-step scratch of the Partial observation - who deferred what, the seen counts in transit, the scheduling forecast: rebuilt
+  //  by every step, never part of a checkpoint, whose bytes stay a function of the simulation state alone)
+  rc |= dev_alloc_scratch(h, &R.seenPart, (size_t)E * 5 * 10 * RCP_SEEN_STRIDE);
+  rc |= dev_alloc_scratch(h, &R.deferList, (size_t)E + 1 + 8);
   rc |= dev_alloc(h, &R.s_pair, E * RC_NS);
   rc |= dev_alloc(h, &R.s_meta, E * RC_NS);
   rc |= dev_alloc(h, &R.s_hash, 2 * E * RC_NS);
