@@ -76,9 +76,9 @@ struct RcState {
   int* seenPart; /* [E][5][120] per-snapshot seen counts of the environments whose vision runs in the deferred launch */
   int* deferList; /* [E + 1 + 8]: [0] = number of environments deferred in this step (zeroed before every step launch), then
                      id | first deferred pass << 20 (pass = snapshot * R + agent; the passes before it ran in the step launch);
-                     [E + 1] = RC_SCHED: the forecast of the step's slowest environment, in cycles - the running maximum of the
-                     environments' own times, shrunk by 1/64 at the start of every step (contact-path environments budget their own
-                     vision passes against it).  Kept here, not in a field of its own: this struct is a kernel argument and
+                     [E + 1] = the forecast of the step's slowest environment, in cycles = the previous step's maximum of the
+                     environments' own times (0: none above RC_SCHED_MIN), [E + 2] = this step's maximum so far (every environment
+                     runs its vision passes until the forecast end, rc_step_body).  Kept here, not in a field of its own: this struct is a kernel argument and
                      rc_step_kernel ran 1 % slower with it 16 bytes larger - same instructions, measured three times */
   int obs_type, noise_type;
   double noise_magn;

@@ -1828,7 +1828,9 @@ DE_DEV void rc_step_body(const RcState& S, const int e, const int* __restrict__ 
   else if (PARTIAL) __builtin_amdgcn_s_setprio(1);
   unsigned long long schedT0 = 0ull;
   if constexpr (PARTIAL) schedT0 = __builtin_amdgcn_s_memtime();
-  if (PARTIAL && e == 0 && lane == 0) { int* sc = S.deferList + S.E + 1; sc[0] = sc[0] - (sc[0] >> 6); }  // the forecast forgets slowly
+  // the forecast for this step = the slowest environment of the previous one (0: none was slow); block 0 is among the first to start,
+  // everybody else reads the word when its physics is done - a million cycles later
+  if (PARTIAL && e == 0 && lane == 0) { int* sc = S.deferList + S.E + 1; sc[0] = sc[1]; sc[1] = 0; }
   rc_load_env(S, L, e, lane, occ, W);
   RcCtx c;
   c.seed = S.seed; c.genv = (uint32_t)(S.env_id_offset + e); c.n = S.n; c.R = R;
@@ -1915,7 +1917,7 @@ RC_PROF(if (lane == 0 && e < 4096) { unsigned long long* d = g_rcprof + e * 12; 
   __syncthreads();
   // Partial: an environment that spent much of the step in rc_physics is among the last to finish and leaves its vision
   // to the deferred launch (five waves per environment) instead of appending 50 agent passes to the critical path
-  // Partial: with a forecast of when the launch will end (the running maximum of the environments' own times, RcState.deferList) every
+  // Partial: with a forecast of when the launch will end (the slowest environment of the previous step, RcState.deferList) every
   // environment runs its vision passes - 5 R of them, in (snapshot, agent) order - until then and leaves the rest to the deferred
   // launch: the SIMDs whose four waves are all light have the most vision to do and finish about when the slowest environment
   // does; an environment that spent the step in rc_physics gets to fewer of its passes.  Without a forecast (no environment has
@@ -1925,11 +1927,10 @@ RC_PROF(if (lane == 0 && e < 4096) { unsigned long long* d = g_rcprof + e * 12; 
     int* sc = S.deferList + S.E + 1;
     const int slowest = G::uniform_i(__atomic_load_n(sc, __ATOMIC_RELAXED));
     const int cycles = (int)(__builtin_amdgcn_s_memtime() - schedT0);
-    // (a forecast below RC_SCHED_MIN is what is left of an old one, shrunk step by step while nobody was slow: no forecast)
-    if (slowest >= RC_SCHED_MIN) { budget = (slowest / 100) * RC_PV_DEADLINE_PCT - cycles; if (budget <= 0) ownPasses = 0; }
+    if (slowest > 0) { budget = (slowest / 100) * RC_PV_DEADLINE_PCT - cycles; if (budget <= 0) ownPasses = 0; }
     else if (nGeneral >= RC_DEFER_MIN_GENERAL) ownPasses = 0;
     // (only an environment slower than everything so far touches the shared word: thousands of atomics on one address serialise)
-    if (lane == 0 && cycles > RC_SCHED_MIN && cycles > slowest) atomicMax(sc, cycles);
+    if (lane == 0 && cycles > RC_SCHED_MIN && cycles > __atomic_load_n(sc + 1, __ATOMIC_RELAXED)) atomicMax(sc + 1, cycles);
   }
   if (lane == 0) {
     dones[e] = (uint8_t)(L.envi[RE_ELAPSED] >= RC_MAX_TIME);
