@@ -100,6 +100,11 @@ DE_OOL DevSC dev_sincos(double x) {
   dm_sincos(x, &r.s, &r.c);
   return r;
 }
+DE_OOL DevSC dev_sincos_v(double x) {  // the observation code's variant (dm_sincos_f: fused polynomials)
+  DevSC r;
+  dm_sincos_f(x, &r.s, &r.c);
+  return r;
+}
 DE_DEV DevSC dev_sincos_inl(double x) {  // for functions that must not contain a call (their live values would need callee-saved registers)
   DevSC r;
   dm_sincos(x, &r.s, &r.c);

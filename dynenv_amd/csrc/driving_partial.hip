@@ -51,7 +51,7 @@ DE_DEV dm_u32x4 pv_rng(const DrvState& S, uint32_t genv, uint32_t episode, int e
 }
 DE_DEV double pv_normalize(double pt, double nf, double mean) { return ((pt * nf) - mean) * 2.0 * 1.0; }
 DE_DEV V2 pv_rotated(V2 v, double a) {
-  const DevSC sc = dev_sincos(a);
+  const DevSC sc = dev_sincos_v(a);
   return v2(v.x * sc.c - v.y * sc.s, v.x * sc.s + v.y * sc.c);
 }
 DE_DEV double pv_lensq(V2 v) { return v.x * v.x + v.y * v.y; }
@@ -148,7 +148,7 @@ DE_DEV int pv_env(const DrvState& S, PvLds& L, const int e, const int lane, cons
     if (isSelf) sarg = ang;
     else if (isObjLane) sarg = oangle - ang;
     else if (isLaneRow) sarg = C.roads[lroad].dirAngle - ang;
-    const DevSC sc1 = dev_sincos(sarg);
+    const DevSC sc1 = dev_sincos_v(sarg);
     const double rotC = bcast_d(sc1.c, 63), rotS = bcast_d(sc1.s, 63);
     if (isObjLane) {
       if (isSelf) {  // selfDet :755-756: absolute position, own corners, never filtered
@@ -383,7 +383,7 @@ DE_DEV int pv_env(const DrvState& S, PvLds& L, const int e, const int lane, cons
         }
       }
       if (objNoise || laneNoise) {
-        const DevSC sc = dev_sincos(angArg);
+        const DevSC sc = dev_sincos_v(angArg);
         if (applyAngle) { dc = sc.c; ds = sc.s; pos = newPos; }
         if (laneNoise) { lc = sc.c; ls = sc.s; }
       }
@@ -403,11 +403,11 @@ DE_DEV int pv_env(const DrvState& S, PvLds& L, const int e, const int lane, cons
         const double d = dm_unit(u.v[2]) * maxVis1;
         const double a1 = dm_unit(u.v[3]) * 2.0 * DM_PI;
         fpPos = pv_rotated(v2(d, 0.0), a1);
-        const DevSC sc = dev_sincos(dm_unit(u1.v[0]) * 2.0 * DM_PI);
+        const DevSC sc = dev_sincos_v(dm_unit(u1.v[0]) * 2.0 * DM_PI);
         fpc = sc.c; fps = sc.s;
         if (fpClass <= 1) { fpw = dm_unit(u1.v[1]) * 5.0 + 5.0; fph = dm_unit(u1.v[2]) * 10.0 + 5.0; }
         else if (fpClass == 3) {
-          const DevSC lsc = dev_sincos((dm_unit(u1.v[1]) - 0.5) * DM_PI * 2.0);
+          const DevSC lsc = dev_sincos_v((dm_unit(u1.v[1]) - 0.5) * DM_PI * 2.0);
           fpc = lsc.c; fps = lsc.s;
           fpLaneDist = __builtin_floor(dm_unit(u1.v[2]) * DRV_W / 2.0);
           fpLaneType = (double)dm_randint(u1.v[3], -1, 1);

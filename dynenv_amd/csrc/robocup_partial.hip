@@ -123,7 +123,7 @@ DE_DEV int rc_partial_vision(const RvArgs& A, RvLds& V, int lane, float* __restr
     const int team = rv_team(V, a);
     const int aflags = V.rflags[a];
     // one sincos call for the three uniform angles: lane 0 -> FoV edge 1, lane 1 -> FoV edge 2, others -> -headAngle
-    const DevSC sc0 = dev_sincos(lane == 0 ? headAngle + RV_FOV : (lane == 1 ? headAngle - RV_FOV : -headAngle));
+    const DevSC sc0 = dev_sincos_v(lane == 0 ? headAngle + RV_FOV : (lane == 1 ? headAngle - RV_FOV : -headAngle));
     const V2 vec1 = v2(1.0 * bcast_d(sc0.c, 0) - 0.0 * bcast_d(sc0.s, 0), 1.0 * bcast_d(sc0.s, 0) + 0.0 * bcast_d(sc0.c, 0));
     const V2 vec2 = v2(1.0 * bcast_d(sc0.c, 1) - 0.0 * bcast_d(sc0.s, 1), 1.0 * bcast_d(sc0.s, 1) + 0.0 * bcast_d(sc0.c, 1));
     const double cR = bcast_d(sc0.c, 2), sR = bcast_d(sc0.s, 2);
@@ -291,7 +291,7 @@ DE_DEV int rc_partial_vision(const RvArgs& A, RvLds& V, int lane, float* __restr
         fpClass = dm_randint(u.v[1], 0, 5);
         const double d = dm_unit(u.v[2]) * dm_sqrt(RV_MAXVIS1);
         const double an = dm_unit(u.v[3]) * 2.0 * RV_FOV - RV_FOV;
-        const DevSC sc = dev_sincos(an);
+        const DevSC sc = dev_sincos_v(an);
         p = v2(d * sc.c - 0.0 * sc.s, d * sc.s + 0.0 * sc.c);
         seenT = RV_NORMAL; has = true;
         const double f = 1.0 - 0.4 * (dm_unit(u1.v[0]) - 0.5);
@@ -365,11 +365,11 @@ DE_DEV int rc_partial_vision(const RvArgs& A, RvLds& V, int lane, float* __restr
     // bearing of polar rows and the direction of line rows: the groups live on disjoint lanes
     const V2 ldiff = vsub(p2, p);
     DevSC scA; scA.s = 0.0; scA.c = 0.0;
-    if (robPos >= 0 || (P >= 0 && feat == 8)) scA = dev_sincos(robPos >= 0 ? e3 : e5);
+    if (robPos >= 0 || (P >= 0 && feat == 8)) scA = dev_sincos_v(robPos >= 0 ? e3 : e5);
     DevSC scB; scB.s = 0.0; scB.c = 0.0;
     if (P >= 0 || lineKeep) {
       const double ang = lineKeep ? dev_atan2(ldiff.y, ldiff.x) : dev_atan2(p.y * (double)team, p.x * (double)team);
-      scB = dev_sincos(ang);
+      scB = dev_sincos_v(ang);
     }
     if (robPos >= 0) {
       if (robPos < RCP_CAP_ROB) {

@@ -102,6 +102,34 @@ DM_FN void dm_sincos(double x, double* s, double* c) {
   }
 }
 
+/* The same with the polynomials and the second reduction stage as chains of dm_fma (9 fewer instructions of ~45): for the
+ * OBSERVATION code only (getAgentVision's headings and noise angles: float32 outputs, hundreds of thousands of calls per step).
+ * Every body's rotation goes through dm_sincos above, which stays unfused - fused, RoboCup's joint iterations reach their
+ * bit-exact fixed point later and the step is 1.5-2 % slower (measured over four seeds). */
+DM_FN void dm_sincos_f(double x, double* s, double* c) {
+  const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00, pio2_2 = 6.07710050630396597660e-11,
+               pio2_2t = 2.02226624879595063154e-21;
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+               S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+               C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  const double fn = dm_rint(x * invpio2);
+  const double t = dm_fma(-fn, pio2_1, x); /* (the product is exact for |fn| < 2^20 anyway) */
+  const double w = fn * pio2_2;
+  const double r1 = t - w;
+  const double r = r1 - dm_fma(fn, pio2_2t, -((t - r1) - w));
+  const double z = r * r;
+  const double sr = dm_fma(z * r, dm_fma(z, dm_fma(z, dm_fma(z, dm_fma(z, dm_fma(z, S6, S5), S4), S3), S2), S1), r);
+  const double hz = 0.5 * z, w1 = 1.0 - hz;
+  const double cr = w1 + dm_fma(z, z * dm_fma(z, dm_fma(z, dm_fma(z, dm_fma(z, dm_fma(z, C6, C5), C4), C3), C2), C1), (1.0 - w1) - hz);
+  switch ((int)((int64_t)fn & 3)) {
+    case 0: *s = sr; *c = cr; break;
+    case 1: *s = cr; *c = -sr; break;
+    case 2: *s = -sr; *c = -cr; break;
+    default: *s = -cr; *c = sr; break;
+  }
+}
+
 DM_FN double dm_sin(double x) { double s, c; dm_sincos(x, &s, &c); return s; }
 DM_FN double dm_cos(double x) { double s, c; dm_sincos(x, &s, &c); return c; }
 

@@ -52,7 +52,7 @@ static inline double vlen(cpv v) { return dm_sqrt(v.x * v.x + v.y * v.y); }
 static inline double lensq(cpv v) { return v.x * v.x + v.y * v.y; }
 static inline cpv rotated(cpv v, double a) {
   double s, c;
-  dm_sincos(a, &s, &c);
+  dm_sincos_f(a, &s, &c);
   return cpv_(v.x * c - v.y * s, v.x * s + v.y * c);
 }
 static inline double vangle(cpv v) { return dm_atan2(v.y, v.x); } /* cutils.angle :600-601 */
@@ -79,7 +79,7 @@ static void is_seen_in_radius(Det* d, cpv point, const cpv* corners, double angl
     d->pos = rotated(trPt, -obsAngle);
     {
       double trAngle = angle - obsAngle, s, c;
-      dm_sincos(trAngle, &s, &c);
+      dm_sincos_f(trAngle, &s, &c);
       d->c = c; d->s = s;
     }
   } else {
@@ -139,7 +139,7 @@ static void add_noise_rect(const DrivingEnv* e, Det* obj, int noiseType, int int
       cpv newPos = cpvadd(obj->pos, noiseVec);
       double angleDiff = (dm_unit(u1.v[0]) - 0.5) * magn * ANGLE_NOISE;
       double ang = dm_atan2(obj->s, obj->c) + angleDiff, s, c;
-      dm_sincos(ang, &s, &c);
+      dm_sincos_f(ang, &s, &c);
       obj->c = c; obj->s = s;
       if (obj->hasCorners) for (i = 0; i < 4; ++i) obj->corners[i] = cpvadd(cpvsub(obj->corners[i], obj->pos), obj->pos);
       obj->pos = newPos;
@@ -156,7 +156,7 @@ static void add_noise_rect(const DrivingEnv* e, Det* obj, int noiseType, int int
     if (misClass && dm_unit(u.v[3]) < rnd * multiplier / 2.0) obj->seen = SIGHT_MISCLASS;
     angleDiff = (dm_unit(u1.v[0]) - 0.5) * magn * ANGLE_NOISE * 0.25;
     ang = dm_atan2(obj->s, obj->c) + angleDiff;
-    dm_sincos(ang, &s, &c);
+    dm_sincos_f(ang, &s, &c);
     obj->c = c; obj->s = s;
     if (obj->hasCorners) for (i = 0; i < 4; ++i) obj->corners[i] = cpvadd(cpvsub(obj->corners[i], obj->pos), newPos);
     obj->pos = newPos;
@@ -184,7 +184,7 @@ static void add_noise_lane(const DrivingEnv* e, LaneDet* obj, int noiseType, dou
     ang = dm_atan2(obj->s, obj->c);
     ang += ANGLE_NOISE * multiplier1 / 5.0 * angleDiff;
   }
-  dm_sincos(ang, &s, &c);
+  dm_sincos_f(ang, &s, &c);
   obj->c = c; obj->s = s;
 }
 
@@ -196,7 +196,7 @@ static int car_lane_distances(const Road* r, cpv carPos, double carAngle, LaneDe
   double a, c, s, distMult = 1.0, typeMult = 1.0;
   if (dm_abs(dist) > 10.0) { out[0].seen = SIGHT_NONE; out[0].dist = out[0].c = out[0].s = out[0].type = 0.0; return 1; }
   a = r->dirAngle - carAngle;
-  dm_sincos(a, &s, &c);
+  dm_sincos_f(a, &s, &c);
   if (c >= 0.0) { typeMult = -1.0; c *= -1.0; s *= -1.0; distMult = -1.0; }
   for (i = -n; i < n; ++i) {
     LaneDet* o = &out[i + n];
@@ -239,7 +239,7 @@ int drv_agent_vision(const DrivingEnv* e, int agentIdx, int noiseType, double ma
   double s, c;
   cpv corners[4];
   /* self detection :755-756 */
-  dm_sincos(ang, &s, &c);
+  dm_sincos_f(ang, &s, &c);
   self.seen = SIGHT_NORMAL; self.pos = P; self.c = c; self.s = s; self.hasCorners = 1;
   {
     double h = agent->height, w = agent->width;
@@ -383,7 +383,7 @@ int drv_agent_vision(const DrivingEnv* e, int agentIdx, int noiseType, double ma
       double a1 = dm_unit(u.v[3]) * 2.0 * DM_PI;
       cpv pos = rotated(cpv_(d, 0.0), a1);
       double angle = dm_unit(u1.v[0]) * 2.0 * DM_PI, co, si;
-      dm_sincos(angle, &si, &co);
+      dm_sincos_f(angle, &si, &co);
       if (cls <= 1) {
         double w = dm_unit(u1.v[1]) * 5.0 + 5.0, h = dm_unit(u1.v[2]) * 10.0 + 5.0;
         Det dt;
@@ -401,7 +401,7 @@ int drv_agent_vision(const DrivingEnv* e, int agentIdx, int noiseType, double ma
       } else if (cls == 3) {
         double a = (dm_unit(u1.v[1]) - 0.5) * DM_PI * 2.0, cc, ss;
         LaneDet l;
-        dm_sincos(a, &ss, &cc);
+        dm_sincos_f(a, &ss, &cc);
         l.seen = SIGHT_NORMAL;
         l.dist = floor(dm_unit(u1.v[2]) * DRV_W / 2.0); /* random.random() * self.W // 2 */
         l.c = cc; l.s = ss;

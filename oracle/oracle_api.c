@@ -234,6 +234,10 @@ void oracle_math(const double* x, const double* y, int n, double* out) {
     out[5 * i + 3] = dm_sqrt(dm_abs(x[i])); out[5 * i + 4] = (y[i] != 0.0) ? x[i] / y[i] : 0.0;
   }
 }
+void oracle_math_f(const double* x, int n, double* out) { /* dm_sincos_f: out[2 i] = sin, out[2 i + 1] = cos */
+  int i;
+  for (i = 0; i < n; ++i) dm_sincos_f(x[i], &out[2 * i], &out[2 * i + 1]);
+}
 void oracle_philox(uint32_t k0, uint32_t k1, const uint32_t* ctr, uint32_t* out) {
   dm_u32x4 r = dm_philox(k0, k1, ctr[0], ctr[1], ctr[2], ctr[3]);
   memcpy(out, r.v, 16);

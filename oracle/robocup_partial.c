@@ -58,7 +58,7 @@ static double vlensq_(cpv a) { return a.x * a.x + a.y * a.y; }
 static double vlen_(cpv a) { return dm_sqrt(a.x * a.x + a.y * a.y); }
 static cpv vrotated_(cpv v, double a) { /* Vec2d.rotated */
   double s, c;
-  dm_sincos(a, &s, &c);
+  dm_sincos_f(a, &s, &c);
   return v_(v.x * c - v.y * s, v.x * s + v.y * c);
 }
 static double unit_(uint32_t u) { return dm_unit(u); }
@@ -199,7 +199,7 @@ static double norm_after_scale_(double pt, double nf, double mean) { return (pt 
 static void polar_(const Det* d, double sizeMean, int team, float* o) { /* convertToPolar :308-315 */
   double dist = dm_sqrt(d->p.x * d->p.x + d->p.y * d->p.y);
   double ang = dm_atan2(d->p.y * (double)team, d->p.x * (double)team), s, c;
-  dm_sincos(ang, &s, &c);
+  dm_sincos_f(ang, &s, &c);
   o[0] = (float)scale_(dist, STD_NORM); o[1] = (float)c; o[2] = (float)s;
   o[3] = (float)((d->size - sizeMean) * SIZE_NORM); o[4] = (float)(d->e3 * (double)team); o[5] = (float)(d->e4 * (double)team);
 }
@@ -368,7 +368,7 @@ int rc_agent_vision(const RoboCupEnv* e, int agentIdx, int noiseType, double mag
     o = out + RCP_OFF_ROB;
     for (i = 0; i < nRob; ++i, o += 7) {
       double s, c;
-      dm_sincos(rob[i].e3, &s, &c);
+      dm_sincos_f(rob[i].e3, &s, &c);
       o[0] = (float)normalize_(rob[i].p.x, STD_NORM); o[1] = (float)normalize_(rob[i].p.y, STD_NORM);
       o[2] = (float)norm_after_scale_(rob[i].size, SIZE_NORM, TOTAL_RADIUS); o[3] = (float)c; o[4] = (float)s;
       o[5] = (float)rob[i].e4; o[6] = (float)rob[i].e5;
@@ -381,7 +381,7 @@ int rc_agent_vision(const RoboCupEnv* e, int agentIdx, int noiseType, double mag
     for (i = 0; i < nFc; ++i, o += 8) {
       double s, c;
       polar_(&fcr[i], PENALTY_RADIUS, team, o);
-      dm_sincos(fcr[i].e5, &s, &c);
+      dm_sincos_f(fcr[i].e5, &s, &c);
       o[6] = (float)c; o[7] = (float)(-s);
     }
     o = out + RCP_OFF_LINE;
@@ -389,7 +389,7 @@ int rc_agent_vision(const RoboCupEnv* e, int agentIdx, int noiseType, double mag
       cpv diff = vsub_(line[i].p2, line[i].p1);
       double dist = fabs(line[i].p2.x * line[i].p1.y - line[i].p2.y * line[i].p1.x) / (vlen_(diff) + 1e-7);
       double ang = dm_atan2(diff.y, diff.x), s, c;
-      dm_sincos(ang, &s, &c);
+      dm_sincos_f(ang, &s, &c);
       o[0] = (float)scale_(dist, STD_NORM); o[1] = (float)c; o[2] = (float)s; o[3] = (float)line[i].tx; o[4] = (float)line[i].ty;
     }
     o = out + RCP_OFF_TAIL;

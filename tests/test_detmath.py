@@ -30,6 +30,25 @@ def test_sincos_atan2_sqrt_within_2_ulp_of_libm():
     assert np.array_equal(out[:, 4], x / y)
 
 
+def test_fused_sincos_of_the_observation_code_within_2_ulp_of_libm():
+    """dm_sincos_f (the vision passes' variant: Horner chains of fma) against glibc, and against the unfused dm_sincos: the two
+    may differ in the last place, not more."""
+    rng = np.random.default_rng(3)
+    n = 400000
+    x = np.ascontiguousarray(np.concatenate([(rng.random(n // 2) - 0.5) * 2000.0, (rng.random(n // 2) - 0.5) * 8.0]))
+    out = np.zeros((n, 2))
+    ol.lib().oracle_math_f(x.ctypes.data_as(C.c_void_p), n, out.ctypes.data_as(C.c_void_p))
+    assert _ulps(out[:, 0], np.sin(x)).max() <= 2.0
+    assert _ulps(out[:, 1], np.cos(x)).max() <= 2.0
+    ref = np.zeros((n, 5))
+    ol.lib().oracle_math(x.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), n, ref.ctypes.data_as(C.c_void_p))
+    assert _ulps(out[:, 0], ref[:, 0]).max() <= 2.0 and _ulps(out[:, 1], ref[:, 1]).max() <= 2.0
+    ang = np.array([0.0, np.pi / 2, -np.pi / 2, np.pi, -np.pi, 2 * np.pi / 180])
+    o = np.zeros((len(ang), 2))
+    ol.lib().oracle_math_f(ang.ctypes.data_as(C.c_void_p), len(ang), o.ctypes.data_as(C.c_void_p))
+    assert _ulps(o[:, 0], np.sin(ang)).max() <= 1.0 and _ulps(o[:, 1], np.cos(ang)).max() <= 1.0
+
+
 def test_special_angles_used_by_the_scene_constants():
     x = np.array([0.0, -0.0, 90.0, -90.0, -0.0, 0.0, 1.0])
     y = np.array([90.0, -90.0, 0.0, -0.0, -0.0, 0.0, 1.0])
