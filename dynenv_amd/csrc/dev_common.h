@@ -111,6 +111,20 @@ DE_DEV DevSC dev_sincos_inl(double x) {  // for functions that must not contain 
   return r;
 }
 DE_OOL double dev_atan2(double y, double x) { return dm_atan2(y, x); }
+// The observation code's variant: the range's six constants come from a 30-double table in LDS (byte address `tab`, 16-byte
+// aligned; DEV_ATAN_TAB_INIT fills it) instead of six select chains - half of dm_atan2's vector instructions.  Same arithmetic
+// (dm_atan_core), same constants: bit-identical to dm_atan2.
+__device__ const double g_atanTab[30] = DM_ATAN_TAB;
+#define DEV_ATAN_TAB_INIT(dst, lane) do { if ((lane) < 30) (dst)[lane] = g_atanTab[lane]; } while (0)
+DE_DEV int dev_lds_addr(const void* p) { return (int)(size_t)(const __attribute__((address_space(3))) void*)p; }
+DE_OOL double dev_atan2_t(double y, double x, int tab) {
+  typedef double __attribute__((ext_vector_type(2))) d2;
+  const double aq = __builtin_fabs(y / x);
+  typedef const __attribute__((address_space(3))) d2* lds_d2p;
+  const lds_d2p row = (lds_d2p)(size_t)(unsigned)(tab + 48 * dm_atan_row(aq));
+  const d2 n = row[0], d = row[1], hl = row[2];
+  return dm_atan2_finish(y, x, aq, dm_atan_core(aq, n.x, n.y, d.x, d.y, hl.x, hl.y));
+}
 DE_DEV double dev_cos(double x) { return dev_sincos(x).c; }
 
 #define DE_DBL_MIN 2.2250738585072014e-308

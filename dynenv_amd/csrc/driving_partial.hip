@@ -42,6 +42,7 @@ struct PvLds {
   int flags[DRV_NB];
   PvBlocker blk[64];  // indexed by lane (cars 0..9, obstacles 30..49, buildings 50..53)
   float row[PV_DIM + 3];  // the agent's dense row is assembled here, then streamed out with coalesced stores
+  alignas(16) double atanTab[30];  // dev_atan2_t's table
 };
 __shared__ PvLds g_P;
 
@@ -86,6 +87,8 @@ DE_DEV int pv_env(const DrvState& S, PvLds& L, const int e, const int lane, cons
   const uint32_t genv = (uint32_t)(S.env_id_offset + e);
   if (lane < DRV_NB) { L.px[lane] = in.px; L.py[lane] = in.py; L.ang[lane] = in.ang; L.flags[lane] = in.flags; }
   if (lane < DRV_MAXO) { L.ox[lane] = in.ox; L.oy[lane] = in.oy; }
+  DEV_ATAN_TAB_INIT(L.atanTab, lane);
+  const int atanTab = dev_lds_addr(L.atanTab);
   __syncthreads();
   const double randBase = 0.01 * magn;
   const double maxVis0 = (DRV_W * 0.4) * (DRV_W * 0.4), maxVis1 = (DRV_W * 0.6) * (DRV_W * 0.6);
@@ -193,7 +196,7 @@ DE_DEV int pv_env(const DrvState& S, PvLds& L, const int e, const int lane, cons
     // The four corner angles of every visible blocker: 4 n evaluations of atan2 for n blockers, pooled over the whole wave (item =
     // 4 j + corner) instead of four calls with only the blocker lanes busy - n is ~10 of 64 lanes, so one call replaces four.  The
     // corners travel through the blocker's own table entry (not yet written) and come back as (angle, squared length) in place.
-    const double angle1 = (seen != SIGHT_NONE && !isSelf && (isCarLane || isPedLane || isObsLane || isBldLane)) ? dev_atan2(pos.y, pos.x) : 0.0;
+    const double angle1 = (seen != SIGHT_NONE && !isSelf && (isCarLane || isPedLane || isObsLane || isBldLane)) ? dev_atan2_t(pos.y, pos.x, atanTab) : 0.0;
     const bool isBlk = (isCarLane && !isSelf) || isObsLane || isBldLane;
     const bool blkSeen = isBlk && seen != SIGHT_NONE;
     const uint64_t blkMask = wave_ballot(blkSeen);
@@ -211,7 +214,7 @@ DE_DEV int pv_env(const DrvState& S, PvLds& L, const int e, const int lane, cons
       for (int it = lane; it < nItems; it += DE_WAVE) {
         double* c = reinterpret_cast<double*>(&L.blk[pool[it >> 2]]) + 2 * (it & 3);
         const V2 cor = v2(c[0], c[1]);
-        c[0] = dev_atan2(cor.y, cor.x);
+        c[0] = dev_atan2_t(cor.y, cor.x, atanTab);
         c[1] = pv_lensq(cor);
       }
       __syncthreads();
@@ -336,7 +339,7 @@ DE_DEV int pv_env(const DrvState& S, PvLds& L, const int e, const int lane, cons
         u1 = pv_rng(S, genv, episode, elapsed, a, kind, idx, 1);
       }
       if (trialHere) { fu = u; fu1 = u1; }
-      if (noisy) base = dev_atan2(objNoise ? ds : ls, objNoise ? dc : lc);
+      if (noisy) base = dev_atan2_t(objNoise ? ds : ls, objNoise ? dc : lc, atanTab);
       double angArg = base;
       bool applyAngle = false;
       V2 newPos = pos;

@@ -63,6 +63,7 @@ struct RvLds {  // LDS of the observation kernel (2.7 KB: every environment of a
   RvDetTable T;
   int seen[10 * RCP_SEEN_STRIDE];
   int seenSum[10 * RCP_SEEN_STRIDE];  // (fused path with a deadline: the sum over the snapshots done so far)
+  alignas(16) double atanTab[30];     // dev_atan2_t's table
 };
 __shared__ RvLds g_V;
 DE_DEV V2 rv_pos(const RvLds& V, int r) { return v2((V.px[2 * r] + V.px[2 * r + 1]) / 2.0, (V.py[2 * r] + V.py[2 * r + 1]) / 2.0); }  // Robot.getPos
@@ -108,6 +109,8 @@ DE_DEV int rc_partial_vision(const RvArgs& A, RvLds& V, int lane, float* __restr
   const double randBase = 0.01 * A.magn;
   const uint64_t below = lanemask_lt();
   int overflow = 0;
+  DEV_ATAN_TAB_INIT(V.atanTab, lane);  // (made visible by the barrier behind the first agent's detection table)
+  const int atanTab = dev_lds_addr(V.atanTab);
   // lane role (fixed over agents)
   const bool isBall = lane == 0, isRob = lane >= 1 && lane < R, isGoal = lane >= 10 && lane < 14, isCross = lane >= 14 && lane < 17;
   const bool isFc = lane >= 17 && lane < 33, isLine = lane >= 33 && lane < 44, isTrial = lane >= 44 && lane < 54;
@@ -368,7 +371,8 @@ DE_DEV int rc_partial_vision(const RvArgs& A, RvLds& V, int lane, float* __restr
     if (robPos >= 0 || (P >= 0 && feat == 8)) scA = dev_sincos_v(robPos >= 0 ? e3 : e5);
     DevSC scB; scB.s = 0.0; scB.c = 0.0;
     if (P >= 0 || lineKeep) {
-      const double ang = lineKeep ? dev_atan2(ldiff.y, ldiff.x) : dev_atan2(p.y * (double)team, p.x * (double)team);
+      // (one call for both kinds of row: operands selected, not two calls in the arms of a conditional - a wave executes both)
+      const double ang = dev_atan2_t(lineKeep ? ldiff.y : p.y * (double)team, lineKeep ? ldiff.x : p.x * (double)team, atanTab);
       scB = dev_sincos_v(ang);
     }
     if (robPos >= 0) {

@@ -143,29 +143,14 @@ DM_FN double dm_cos(double x) { double s, c; dm_sincos(x, &s, &c); return c; }
  * of glibc, test_detmath.py); the restatement fuses the same operations with an exact rational fma.  atan2 only feeds the
  * observations (headings and bearing angles) - dm_sincos, which every body's rotation goes through, stays unfused: with its
  * multiply-adds fused RoboCup's joint iterations reach their bit-exact fixed point later and the step is 1.5-2 % slower. */
-DM_FN double dm_atan_pos(double ax) {
-  const double atanhi0 = 4.63647609000806093515e-01, atanhi1 = 7.85398163397448278999e-01,
-               atanhi2 = 9.82793723247329054082e-01, atanhi3 = 1.57079632679489655800e+00;
-  const double atanlo0 = 2.26987774529616870924e-17, atanlo1 = 3.06161699786838301793e-17,
-               atanlo2 = 1.39033110312309984516e-17, atanlo3 = 6.12323399573676603587e-17;
+/* the arithmetic of one range: A..D, hi, lo as selected (or looked up: DM_ATAN_TAB below) for ax */
+DM_FN double dm_atan_core(double ax, double nA, double nB, double dA, double dB, double hi, double lo) {
   const double aT0 = 3.33333333333329318027e-01, aT1 = -1.99999999998764832476e-01,
                aT2 = 1.42857142725034663711e-01, aT3 = -1.11111104054623557880e-01,
                aT4 = 9.09088713343650656196e-02, aT5 = -7.69187620504482999495e-02,
                aT6 = 6.66107313738753120669e-02, aT7 = -5.83357013379057348645e-02,
                aT8 = 4.97687799461593236017e-02, aT9 = -3.65315727442169155270e-02,
                aT10 = 1.62858201153657823623e-02;
-  const int r0 = ax < 0.4375, r1 = ax < 0.6875, r2 = ax < 1.1875, r3 = ax < 2.4375;
-  /* the quotient's two halves as ax * A + B with selected A, B (products by 0, 1, 2 are exact; 1.5 ax is the one rounded
-   * product of the branching form), so that no arm is left for the compiler to branch around:
-   *                       [0, .4375)  [.4375, .6875)  [.6875, 1.1875)  [1.1875, 2.4375)  [2.4375, inf)
-   *   numerator           ax          2 ax - 1        ax - 1           ax - 1.5          -1
-   *   denominator         1           2 + ax          ax + 1           1 + 1.5 ax        ax                      */
-  const double nA = r0 ? 1.0 : (r1 ? 2.0     : (r2 ? 1.0     : (r3 ? 1.0     : 0.0)));
-  const double nB = r0 ? 0.0 : (r1 ? -1.0    : (r2 ? -1.0    : (r3 ? -1.5    : -1.0)));
-  const double dA = r0 ? 0.0 : (r1 ? 1.0     : (r2 ? 1.0     : (r3 ? 1.5     : 1.0)));
-  const double dB = r0 ? 1.0 : (r1 ? 2.0     : (r2 ? 1.0     : (r3 ? 1.0     : 0.0)));
-  const double hi = r0 ? 0.0 : (r1 ? atanhi0 : (r2 ? atanhi1 : (r3 ? atanhi2 : atanhi3)));
-  const double lo = r0 ? 0.0 : (r1 ? atanlo0 : (r2 ? atanlo1 : (r3 ? atanlo2 : atanlo3)));
   const double num = dm_fma(ax, nA, nB), den = dm_fma(ax, dA, dB); /* (ax = inf: 0 * inf, discarded by the last select below) */
   const double t = num / den;
   const double z = t * t;
@@ -174,8 +159,36 @@ DM_FN double dm_atan_pos(double ax) {
   const double s2 = w * dm_fma(w, dm_fma(w, dm_fma(w, dm_fma(w, aT9, aT7), aT5), aT3), aT1);
   double r = hi - (dm_fma(t, s1 + s2, -lo) - t);   /* first range: 0 - ((t s - 0) - t) = t - t s, exactly */
   if (ax < 3.7252902984619140625e-09) r = ax;      /* |x| < 2^-28 */
-  if (ax >= 1.0e300) r = atanhi3 + atanlo3;        /* huge (incl. inf) */
+  if (ax >= 1.0e300) r = 1.57079632679489655800e+00 + 6.12323399573676603587e-17; /* huge (incl. inf): atanhi3 + atanlo3 */
   return r;
+}
+/* the five ranges' {nA, nB, dA, dB, hi, lo}, for callers that look the row up instead of selecting it (the device's observation
+ * code keeps a copy in LDS: half of dm_atan2's vector instructions were the select chains); row = number of range bounds <= ax:
+ *                       [0, .4375)  [.4375, .6875)  [.6875, 1.1875)  [1.1875, 2.4375)  [2.4375, inf)
+ *   numerator           ax          2 ax - 1        ax - 1           ax - 1.5          -1
+ *   denominator         1           2 + ax          ax + 1           1 + 1.5 ax        ax                      */
+#define DM_ATAN_TAB                                                                                          \
+  {1.0, 0.0, 0.0, 1.0, 0.0, 0.0,                                                                             \
+   2.0, -1.0, 1.0, 2.0, 4.63647609000806093515e-01, 2.26987774529616870924e-17,                              \
+   1.0, -1.0, 1.0, 1.0, 7.85398163397448278999e-01, 3.06161699786838301793e-17,                              \
+   1.0, -1.5, 1.5, 1.0, 9.82793723247329054082e-01, 1.39033110312309984516e-17,                              \
+   0.0, -1.0, 1.0, 0.0, 1.57079632679489655800e+00, 6.12323399573676603587e-17}
+DM_FN int dm_atan_row(double ax) { return !(ax < 0.4375) + !(ax < 0.6875) + !(ax < 1.1875) + !(ax < 2.4375); }
+DM_FN double dm_atan_pos(double ax) {
+  const double atanhi0 = 4.63647609000806093515e-01, atanhi1 = 7.85398163397448278999e-01,
+               atanhi2 = 9.82793723247329054082e-01, atanhi3 = 1.57079632679489655800e+00;
+  const double atanlo0 = 2.26987774529616870924e-17, atanlo1 = 3.06161699786838301793e-17,
+               atanlo2 = 1.39033110312309984516e-17, atanlo3 = 6.12323399573676603587e-17;
+  const int r0 = ax < 0.4375, r1 = ax < 0.6875, r2 = ax < 1.1875, r3 = ax < 2.4375;
+  /* the quotient's two halves as ax * A + B with selected A, B (products by 0, 1, 2 are exact; 1.5 ax is the one rounded
+   * product of the branching form), so that no arm is left for the compiler to branch around */
+  const double nA = r0 ? 1.0 : (r1 ? 2.0     : (r2 ? 1.0     : (r3 ? 1.0     : 0.0)));
+  const double nB = r0 ? 0.0 : (r1 ? -1.0    : (r2 ? -1.0    : (r3 ? -1.5    : -1.0)));
+  const double dA = r0 ? 0.0 : (r1 ? 1.0     : (r2 ? 1.0     : (r3 ? 1.5     : 1.0)));
+  const double dB = r0 ? 1.0 : (r1 ? 2.0     : (r2 ? 1.0     : (r3 ? 1.0     : 0.0)));
+  const double hi = r0 ? 0.0 : (r1 ? atanhi0 : (r2 ? atanhi1 : (r3 ? atanhi2 : atanhi3)));
+  const double lo = r0 ? 0.0 : (r1 ? atanlo0 : (r2 ? atanlo1 : (r3 ? atanlo2 : atanlo3)));
+  return dm_atan_core(ax, nA, nB, dA, dB, hi, lo);
 }
 DM_FN double dm_atan(double x) {
   const double r = dm_atan_pos(__builtin_fabs(x));
@@ -193,10 +206,9 @@ DM_FN int dm_signbit(double x) {
  * general expression pi - (pi/2 - pi_lo) lands one ulp above pi/2).  A NaN operand propagates through the division.  One corner
  * differs from the branching form this replaces: a quotient that underflows to -0 (or x = +-inf with y < 0) now gives the -0 / -pi
  * of math.atan2, where the old form - whose |q| kept the sign of a zero - gave +0 / +pi. */
-DM_FN double dm_atan2(double y, double x) {
+/* quadrant logic and zero operands of dm_atan2, given z = atan |y / x| */
+DM_FN double dm_atan2_finish(double y, double x, double aq, double z) {
   const double pi = 3.1415926535897931160e+00, pi_lo = 1.2246467991473531772e-16;
-  const double aq = __builtin_fabs(y / x);
-  double z = dm_atan_pos(aq);                      /* aq >= 1e300: atanhi3 + atanlo3 == pi/2 */
   if (x < 0.0 && aq < 1.0e-300) z = 0.0;
   {
     double r = dm_signbit(x) ? pi - (z - pi_lo) : z; /* (z - pi_lo) - pi == -(pi - (z - pi_lo)) exactly */
@@ -204,6 +216,10 @@ DM_FN double dm_atan2(double y, double x) {
     if (y == 0.0) r = dm_signbit(x) ? pi : 0.0;
     return dm_signbit(y) ? -r : r;
   }
+}
+DM_FN double dm_atan2(double y, double x) {
+  const double aq = __builtin_fabs(y / x);
+  return dm_atan2_finish(y, x, aq, dm_atan_pos(aq)); /* aq >= 1e300: atanhi3 + atanlo3 == pi/2 */
 }
 
 /* ------------------------------------------------------------------------------------------
