@@ -1652,7 +1652,7 @@ DE_DEV int drv_iso_assign(const DrvState& S, int lane) {
       if (lane == 0) {
         // hysteresis: one launch that did not validate keeps isolation off for the next DRV_ISO_COOLDOWN validated ones as well - a
         // device shared with another kernel validates now and then by chance, and placeholders parked on such a launch's verdict
-        // hold wave slots the other kernel could use (two 4096-environment handles on two streams: 7 % slower without this)
+        // hold wave slots the other kernel could use
         int cd = S.iso[12];
         if (!ok) cd = DRV_ISO_COOLDOWN; else if (cd > 0) cd -= 1;
         S.iso[12] = cd;

@@ -53,8 +53,8 @@ struct dynenv {
   hipEvent_t ev_begin = nullptr, ev_main = nullptr, ev_end = nullptr;  // dynenv_set_step_events (caller-owned)
   // SIMD isolation, host side: iso_cfg = the mode the handle was created with (S.iso_on may be 0 while isolation is paused);
   // iso_seen = pinned word the device's count of launches whose placement did not validate is copied into now and then
-  int iso_cfg = 0, iso_last_invalid = 0, iso_paused_until = 0, iso_pauses = 0;
-  long long steps = 0;
+  int iso_cfg = 0, iso_last_invalid = 0, iso_pauses = 0;
+  long long steps = 0, iso_paused_until = 0;
   int* iso_seen = nullptr;
 };
 #define ISO_PROBE_EVERY 64     /* steps between two looks at the device's validation counter (an asynchronous 4-byte copy) */
@@ -661,7 +661,7 @@ int dynenv_step_head(dynenv_t* h, const int32_t* actions_dev, const double* head
   //  environment's SIMD run there - or nothing, and the block ends at once)
   // A device this handle does not have to itself (another handle stepping on another stream, another kernel): the placement
   // does not validate, isolation holds off on the device - and what is left of it (the spare blocks, the placement record, the
-  // per-environment report) still costs 7 % of a step once the device is saturated.  So the host looks at the device's count of
+  // per-environment report) still costs 0.5-0.9 % of a step.  So the host looks at the device's count of
   // launches that did not validate every ISO_PROBE_EVERY steps - an asynchronous 4-byte copy, read one window later, never
   // waited for - and when more than half of a window's launches did not validate it drops to the plain launch (mode 0: exactly
   // what DYNENV_NO_ISOLATION=1 gives) for ISO_PAUSE_STEPS steps, then starts isolation over.  Scheduling only, as ever.
@@ -673,7 +673,7 @@ int dynenv_step_head(dynenv_t* h, const int32_t* actions_dev, const double* head
     } else if (h->S.iso_on == 1 && h->steps % ISO_PROBE_EVERY == 0) {
       const int seen = *(volatile int*)h->iso_seen;  // the copy issued one window ago (stale at worst)
       if (seen - h->iso_last_invalid > ISO_PROBE_EVERY / 2) {
-        h->S.iso_on = 0; h->iso_paused_until = (int)(h->steps + ISO_PAUSE_STEPS); h->iso_pauses += 1;
+        h->S.iso_on = 0; h->iso_paused_until = h->steps + ISO_PAUSE_STEPS; h->iso_pauses += 1;
       } else {
         h->iso_last_invalid = seen;
         HIP_OK(hipMemcpyAsync(h->iso_seen, h->S.iso + 11, sizeof(int), hipMemcpyDeviceToHost, st));
