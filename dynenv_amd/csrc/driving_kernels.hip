@@ -1361,13 +1361,13 @@ DRV_PROF(if (lane == 0 && blockIdx.x < 4096) { unsigned long long* d = g_dbgp + 
 DE_OOL int drv_partial_obs_fused(PvIn in, uint64_t seed, int A, int* envi, int env_id_offset, int e, int nPedObst, int elapsed,
                                  uint32_t episode, int noiseTypeAgents, double magn, float* __restrict__ obs, int budgetCycles);  // driving_partial.hip
 #ifndef DRV_DEFER_MIN_CONTACT
-#define DRV_DEFER_MIN_CONTACT 5 /* contact-path substeps (of 10) from which an environment defers its Partial observation */
+#define DRV_DEFER_MIN_CONTACT 5 /* without a forecast: contact-path substeps (of 10) from which an environment defers its Partial observation */
 #endif
 #ifndef DRV_PV_DEADLINE_PCT
 #define DRV_PV_DEADLINE_PCT 100 /* fused vision passes start until this many percent of the forecast of the launch's slowest environment */
 #endif
 #ifndef DRV_FUSED_AGENTS
-#define DRV_FUSED_AGENTS 10 /* agent passes a light environment runs in the step launch */
+#define DRV_FUSED_AGENTS 10 /* without a forecast: agent passes a light environment runs in the step launch */
 #endif
 struct DrvLightRet {
   int cand, dirty, bits;
@@ -1900,8 +1900,8 @@ DRV_PROF(const unsigned long long K1 = __builtin_amdgcn_s_memtime();)
   }
   if (errBits && lane == 0) envi[EI_ERR] = g_err | errBits;
   // Partial observation of this environment, fused (see drv_partial_obs_fused): the first `fusedAgents` agent passes run
-  // here, the rest is left to the deferred launch.  An environment that spent the step on the contact path is among the
-  // last to finish and defers everything; a light one keeps as many passes as fit before the heavy ones are done.
+  // here, the rest is left to the deferred launch.  Without a forecast (DYNENV_NO_ISOLATION, or no environment was slow in the
+  // previous step): an environment that spent the step on the contact path defers everything, a light one nothing.
   int fusedAgents = !(PARTIAL && pobs) ? 0 : nContact >= DRV_DEFER_MIN_CONTACT ? 0 : (A < DRV_FUSED_AGENTS ? A : DRV_FUSED_AGENTS);
   // With a forecast of when the launch will end (the previous step's slowest environment, drv_iso_report keeps it) every
   // environment, light or not, simply runs its passes until then and leaves the rest: the SIMDs whose four waves are all light are

@@ -78,8 +78,8 @@ struct RcState {
                      id | first deferred pass << 20 (pass = snapshot * R + agent; the passes before it ran in the step launch);
                      [E + 1] = the forecast of the step's slowest environment, in cycles = the previous step's maximum of the
                      environments' own times (0: none above RC_SCHED_MIN), [E + 2] = this step's maximum so far (every environment
-                     runs its vision passes until the forecast end, rc_step_body).  Kept here, not in a field of its own: this struct is a kernel argument and
-                     rc_step_kernel ran 1 % slower with it 16 bytes larger - same instructions, measured three times */
+                     runs its vision passes until the forecast end, rc_step_body).  Per-step scratch, allocated outside the
+                     checkpointed arrays like seenPart. */
   int obs_type, noise_type;
   double noise_magn;
   int* s_pair;   /* [E][NS] */
