@@ -9,6 +9,7 @@ the timed region; lock-step episode resets (every 600 steps) are inside it.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--no-cpu-baseline]
   N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
+         or plain `python bench.py --gpus N`: without WORLD_SIZE in the environment the script starts that launcher itself, as a child
 """
 import argparse
 import json
@@ -301,6 +302,32 @@ def plumbing_leg(torch, device, seed):
             "note": "one environment cannot fill a GPU (one wave of 64 lanes): this leg is the plumbing check BASELINE.md asks for"}
 
 
+def launch_ranks(n):
+    """Start `python -m torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1 --master-port P bench.py
+    <the same arguments>` as a child process; -> its return code.  stdout of the job is rank 0's one JSON line (every rank diverts
+    whatever else would land on stdout to stderr); stderr passes through."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE)
+    lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.strip()]
+    json_lines = [ln for ln in lines if ln.lstrip().startswith("{")]
+    for ln in lines:
+        if ln not in json_lines:
+            print(ln, file=sys.stderr)
+    if json_lines:
+        print(json_lines[-1], flush=True)
+    if r.returncode == 0 and len(json_lines) != 1:
+        print("bench.py: expected one JSON line from rank 0, got %d" % len(json_lines), file=sys.stderr)
+        return 1
+    return r.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -332,6 +359,11 @@ def main():
                          "(RCCL refuses two ranks on one device); slabs, pack / unpack kernels, side stream and ring are the real ones. "
                          "The line it prints says so in config.parallelism and is not a measurement")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python3 bench.py --gpus N` typed as is: this process - which has not imported torch or touched the GPU - starts the
+        # one-process-per-GPU job as a CHILD (never an exec), relays rank 0's single JSON line and exits with the child's code
+        sys.exit(launch_ranks(args.gpus))
 
     # stdout carries exactly one JSON line: anything libraries print meanwhile (RCCL's version banner at init, ...) is
     # diverted to stderr at the file-descriptor level until the result is printed

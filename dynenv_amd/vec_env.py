@@ -504,9 +504,16 @@ class BatchedDynEnv(object):
         _capi.check(self._lib.dynenv_get_state(self._h, env, C.byref(st), C.sizeof(st)), "dynenv_get_state")
         return st
 
+    def _substeps(self):
+        return 50 if self.env_type == DynEnvType.ROBO_CUP else 10
+
     def set_state(self, env, st):
+        """Episodes are lock-step: `dones` and the auto-reset follow ONE host-side position in the episode, and that
+        position follows the blob's `elapsed` - like restore() - so a blob with an edited `elapsed` moves host and device together.
+        (Blobs that put different environments at different times make `dones` meaningless; the device keeps stepping them.)"""
         _capi.check(self._lib.dynenv_set_state(self._h, env, C.byref(st), C.sizeof(st)), "dynenv_set_state")
         self._needs_reset = False
+        self._episode_step = int(st.elapsed) // self._substeps()
 
     # ------------------------------------------------------------------ exact checkpoint (SURVEY §8 f4)
     def checkpoint(self):
@@ -526,8 +533,7 @@ class BatchedDynEnv(object):
         self._counts_np = None
         # the host's position in the (lock-step, fixed-length) episode follows the restored device state: auto-reset and
         # `dones` are driven by it
-        substeps = 50 if self.env_type == DynEnvType.ROBO_CUP else 10
-        self._episode_step = int(self.get_state(0).elapsed) // substeps
+        self._episode_step = int(self.get_state(0).elapsed) // self._substeps()
 
     def full_state_obs(self):
         """The noise-free Full observation of the current state, [E, A, full_obs_dim] float32 on the device, whatever the

@@ -415,6 +415,25 @@ static void collide(cpShape* a, cpShape* b, cpCollisionInfo* info) {
   /* segment-poly never occurs in DynEnv */
 }
 
+
+/* differential tests only (tests/test_kat_general.py): the narrowphase of one shape pair as cpSpaceStep would run it - bounding
+ * boxes refreshed, QueryReject, collide() in shape-type order.  out[0] = bounding boxes overlap, out[1] = contact count,
+ * out[2] = 1 if the shapes were swapped into type order, out[3..4] = n, then per contact p1.x p1.y p2.x p2.y hash */
+void cpTestCollide(cpShape* a, cpShape* b, double* out) {
+  cpCollisionInfo info;
+  int i;
+  cpShapeCacheBB(a); cpShapeCacheBB(b);
+  for (i = 0; i < 15; ++i) out[i] = 0.0;
+  if (!(a->bb_l <= b->bb_r && b->bb_l <= a->bb_r && a->bb_b <= b->bb_t && b->bb_b <= a->bb_t)) return;
+  out[0] = 1.0;
+  collide(a, b, &info);
+  out[1] = (double)info.count; out[2] = (info.a != a) ? 1.0 : 0.0; out[3] = info.n.x; out[4] = info.n.y;
+  for (i = 0; i < info.count; ++i) {
+    out[5 + 5 * i + 0] = info.p1[i].x; out[5 + 5 * i + 1] = info.p1[i].y;
+    out[5 + 5 * i + 2] = info.p2[i].x; out[5 + 5 * i + 3] = info.p2[i].y; out[5 + 5 * i + 4] = (double)info.hash[i];
+  }
+}
+
 /* ---------------------------------------------------------------- arbiters */
 
 static cpArbiter* arbiter_find_or_create(cpSpace* s, cpShape* a, cpShape* b) {

@@ -175,4 +175,7 @@ int cpSpacePointQuery(cpSpace* s, cpv p, double maxDist, cpShape** out, int cap)
  * which = 0 begin (returns its value), 1 post_solve, 2 separate; -1 if a shape is missing, 1 without a handler */
 int cpSpaceTestCallback(cpSpace* s, int slotA, int slotB, int which);
 
+/* differential tests only: one pair through the narrowphase (out[15], layout at the definition) */
+void cpTestCollide(cpShape* a, cpShape* b, double* out);
+
 #endif

@@ -448,3 +448,48 @@ void oracle_set_free_flight(oracle_t* o, int on) {
     else o->rc[e].space.test_free_flight = on;
   }
 }
+
+/* ---- narrowphase of single shape pairs for the differential fuzz against tests/kat_general.py ----
+ * desc[9] = {kind (0 circle, 1 capsule, 2 box), px, py, angle, g0..g4}: circle g0 = r; capsule g0..g3 = local ends a, b, g4 = r;
+ * box g0, g1 = half extents.  Shape a gets slot 0, shape b slot 1.  out[15] per pair: cpTestCollide's layout. */
+static void fuzz_shape(cpBody* body, cpShape* sh, const double* d, int slot) {
+  int kind = (int)d[0];
+  cpBodyInit(body, 1.0, 1.0, CP_BODY_DYNAMIC);
+  body->p = cpv_(d[1], d[2]);
+  cpBodySetAngle(body, d[3]);
+  if (kind == 0) cpCircleInit(sh, body, d[4], slot);
+  else if (kind == 1) cpSegmentInit(sh, body, cpv_(d[4], d[5]), cpv_(d[6], d[7]), d[8], slot);
+  else cpBoxInit(sh, body, d[4], d[5], slot);
+}
+void oracle_cp_collide_batch(int n, const double* descA, const double* descB, double* out) {
+  int i;
+  for (i = 0; i < n; ++i) {
+    cpBody ba, bb; cpShape sa, sb;
+    fuzz_shape(&ba, &sa, descA + 9 * i, 0);
+    fuzz_shape(&bb, &sb, descB + 9 * i, 1);
+    cpTestCollide(&sa, &sb, out + 15 * i);
+  }
+}
+
+/* differential tests only: n calls of cpSpaceStep(0.01) on one environment's space with NO game logic around them (for locating
+ * the substep in which tests/kat_general.py and cp_lite part ways; in the fuzz scenes the game logic is a no-op by construction) */
+void oracle_space_step(oracle_t* o, int env, int n) {
+  int i;
+  for (i = 0; i < n; ++i) cpSpaceStep(o->drv ? &o->drv[env].space : &o->rc[env].space, 0.01);
+}
+/* the active arbiters after the last cpSpaceStep: per arbiter slotA slotB count n.x n.y, then per contact r1 r2 jnAcc jtAcc (2 x 6) */
+int oracle_space_arbiters(oracle_t* o, int env, double* out, int cap) {
+  cpSpace* s = o->drv ? &o->drv[env].space : &o->rc[env].space;
+  int i, k;
+  for (i = 0; i < s->n_active && i < cap; ++i) {
+    const cpArbiter* a = s->active[i];
+    double* p = out + 17 * i;
+    p[0] = a->a->slot; p[1] = a->b->slot; p[2] = a->count; p[3] = a->n.x; p[4] = a->n.y;
+    for (k = 0; k < 2; ++k) {
+      const cpContact* c = &a->contacts[k];
+      p[5 + 6 * k + 0] = c->r1.x; p[5 + 6 * k + 1] = c->r1.y; p[5 + 6 * k + 2] = c->r2.x; p[5 + 6 * k + 3] = c->r2.y;
+      p[5 + 6 * k + 4] = c->jnAcc; p[5 + 6 * k + 5] = c->jtAcc;
+    }
+  }
+  return s->n_active;
+}

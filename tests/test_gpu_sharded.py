@@ -287,17 +287,22 @@ def test_two_ranks_sharing_the_gpu_match_one_big_batch(tmp_path, kind):
     assert open(os.path.join(str(tmp_path), "ok.txt")).read() == "ok"
 
 
-def test_bench_launched_like_the_driver_with_two_ranks_on_this_gpu():
-    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` as the driver starts the scaling runs, with
+@pytest.mark.parametrize("how", ["launcher", "as_typed"])
+def test_bench_launched_like_the_driver_with_two_ranks_on_this_gpu(how):
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` as the driver starts the scaling runs - and plain
+    `python3 bench.py --gpus 2 ...` (the script then starts that launcher itself, as a child process) - with
     --rehearse-one-gpu (both ranks on cuda:0, gloo): one JSON line on stdout, n_gpus 2, all ranks' environments counted"""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "8", "--warmup", "3", "--envs", "256", "--rehearse-one-gpu"]
-    r = subprocess.run(cmd, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    tail = ["bench.py", "--gpus", "2", "--steps", "8", "--warmup", "3", "--envs", "256", "--rehearse-one-gpu"]
+    cmd = [sys.executable] + tail if how == "as_typed" else \
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", str(port)] + tail
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
     assert len(lines) == 1, lines
