@@ -76,11 +76,13 @@ def test_narrowphase_fuzz_with_gjk_warm_started_like_chipmunk(pair):
 
 # ------------------------------------------------------------------------------------------------ scenes
 def _nudged(scene, rng, eps=1e-15):
-    def f(t):
-        return tuple(v * (1.0 + eps * rng.uniform(-1.0, 1.0)) if isinstance(v, float) else v for v in t)
+    """the scene with every VELOCITY changed by a relative 1e-15 (one rounding error).  Positions and angles stay: exact zeros in them
+    are structural (two feet created at one point with one angle keep the rotary limit joint inactive, quirk C14)"""
+    def f(t, lo):
+        return tuple(v * (1.0 + eps * rng.uniform(-1.0, 1.0)) if k >= lo else v for k, v in enumerate(t))
     if "cars" in scene:
-        return dict(cars=[f(c) for c in scene["cars"]], peds=[f(p) for p in scene["peds"]], obst=scene["obst"])
-    return dict(robots=[(f(L), f(R), t) for L, R, t in scene["robots"]], ball=f(scene["ball"]))
+        return dict(cars=[f(c, 4) for c in scene["cars"]], peds=[f(p, 2) for p in scene["peds"]], obst=scene["obst"])
+    return dict(robots=[(f(L, 3), f(R, 3), t) for L, R, t in scene["robots"]], ball=f(scene["ball"], 2))
 
 
 def classify(scene, dev, world, expected_fn, last):
