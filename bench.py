@@ -51,14 +51,14 @@ def host_core_share():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(E, n_players, A, seed, robocup=False, target_seconds=12.0, partial=False):
+def cpu_baseline(E, n_players, A, seed, robocup=False, target_seconds=12.0, partial=False, threads=None):
     """The CPU restatement (oracle, kind='port') timed on this box's host cores on a bounded sample of the same
     workload.  It is a C restatement, i.e. a much stronger baseline than the reference's Python+pymunk path, which
     cannot run here (pymunk absent; the reference never ships to the GPU box)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib as ol
-    cores = host_core_share()
+    cores = threads or host_core_share()
     ol.build()
     if robocup:
         env = ol.OracleEnv(env_type=0, num_envs=E, n_players=n_players, seed=seed, threads=cores, flags=ol.ROBOCUP_DEFAULT_FLAGS,
@@ -155,7 +155,29 @@ def measured_traffic(kernel):
                                                  "traffic_whole_step": d.get("step_bytes_all_kernels")}
 
 
-def episode_leg(torch, device, workload, E, seed, n_players=None, env_id_offset=0):
+def measured_sq(kernel):
+    """What actually bounds these kernels (issue and latency, not bytes): the SQ counters of `kernel` from the committed
+    rocprofv3 --pmc passes (profiles/sq_counters.json, tools/profile_round.sh), stamped with the kernel-source hash like the traffic
+    figures: stale -> nulls.  -> dict(valu_busy, wave_time_shares, insts_per_wave, sq_source)"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "sq_counters.json")) as f:
+            t = json.load(f)
+    except (OSError, ValueError):
+        return {"valu_busy": None, "wave_time_shares": None, "sq_source": None}
+    sha = kernel_source_sha()
+    if t.get("kernel_source_sha16") != sha:
+        return {"valu_busy": None, "wave_time_shares": None,
+                "sq_source": "profiles/sq_counters.json is STALE (measured on kernel sources %s, these are %s): null" % (t.get("kernel_source_sha16"), sha)}
+    d = t.get(kernel)
+    if not d:
+        return {"valu_busy": None, "wave_time_shares": None, "sq_source": "profiles/sq_counters.json holds no %s" % kernel}
+    return {"valu_busy": d["valu_busy"], "wave_time_shares": d["wave_time_shares"], "insts_per_wave": d.get("insts_per_wave"),
+            "valu_busy_is": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x the launch's duration x 2.4 GHz): the share of the chip's VALU issue "
+                            "slots the launch used - a LOWER bound on VALU-busy time (an fp64 instruction holds its SIMD longer than 4 cycles)",
+            "sq_source": "profiles/sq_counters.json (kernel sources %s, launch %.1f us under the profiler)" % (sha, d.get("launch_us", float("nan")))}
+
+
+def episode_leg(torch, device, workload, E, seed, n_players=None, env_id_offset=0, no_isolation=False):
     """One whole episode of `workload` (every step of it, the lock-step reset excluded), timed with HIP events on the launch
     stream: the episode mean is what a training run sees - a window at the start of an episode flatters Driving, whose
     contact work grows over the episode."""
@@ -172,6 +194,15 @@ def episode_leg(torch, device, workload, E, seed, n_players=None, env_id_offset=
         pool = [torch.randint(0, 3, (E, A, 2), generator=g, device=device, dtype=torch.int32) for _ in range(16)]
 
     def fresh_env():  # both passes below run the SAME episode (episode index 2 of a fresh handle: identical trajectories)
+        if no_isolation:  # read by dynenv_create: the plain grid, no SIMD isolation of the slow environments
+            os.environ["DYNENV_NO_ISOLATION"] = "1"
+        try:
+            return fresh_env_()
+        finally:
+            if no_isolation:
+                del os.environ["DYNENV_NO_ISOLATION"]
+
+    def fresh_env_():
         env = BatchedDynEnv(DynEnvType.ROBO_CUP if robocup else DynEnvType.DRIVE, E, players, seed=seed, device=device,
                             env_id_offset=env_id_offset, **kw)
         env.reset_flat()
@@ -190,6 +221,8 @@ def episode_leg(torch, device, workload, E, seed, n_players=None, env_id_offset=
     ms = k0.elapsed_time(k1) / ep_steps
     assert env.error_flags() == 0
     env.close()
+    if no_isolation:  # only the back-to-back figure is wanted
+        return {"workload": workload, "envs": E, "steps": ep_steps, "ms_per_step": ms, "value": E * A / (ms * 1e-3), "unit": "agent-steps/s"}
     env = fresh_env()
     # the named kernel's OWN launch duration: a second pass over the same episode (same seed, same actions) with the library
     # recording HIP events on the launch stream right before and after that kernel (dynenv_set_step_events), a fresh event
@@ -236,6 +269,7 @@ def episode_leg(torch, device, workload, E, seed, n_players=None, env_id_offset=
                            "step_ms_back_to_back": ms, "event_record_cost_ms": ev_cost, "alg_bytes_per_env_step": b_alg,
                            "env_steps_per_launch": E}
         out["roofline"].update(tdetail)
+        out["roofline"].update(measured_sq(kernel))   # `frac` stays the HBM figure; valu_busy / wave_time_shares say what binds instead
     if iso is not None:
         out["simd_isolation"] = iso
     return out
@@ -486,6 +520,7 @@ def main():
     pos[0] = args.warmup % L_ep
     untimed_advance = 0
     elapsed, gpu_ms, timed_at = 0.0, 0.0, []
+    raw_extra_ms = [0.0]  # what was subtracted from the timed region (N = 1 spread steps: one event record per step)
     fence()
     if n_full:
         if pos[0]:  # start whole episodes at an episode boundary
@@ -521,6 +556,7 @@ def main():
                 evs[j][2].record()
             fence()
             ev_cost_ms = sum(b.elapsed_time(c) for a, b, c in evs)
+            raw_extra_ms[0] = ev_cost_ms
             dt_ms = sum(a.elapsed_time(b) for a, b, c in evs) - ev_cost_ms
             elapsed += dt_ms * 1e-3
             gpu_ms += dt_ms
@@ -611,6 +647,9 @@ def main():
             "metric": "agent-steps/s", "value": value, "unit": "agent-steps/s", "n_gpus": world,
             **({"mode": "roofline-only: no timed region (value null); read roofline / ms_per_step_full_episode"} if args.roofline_only else {}),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": (elapsed / args.steps * 1e3 if elapsed > 0 else None),
+            "ms_per_step_raw": ((elapsed * 1e3 + raw_extra_ms[0]) / args.steps if elapsed > 0 else None),
+            "value_raw": (env_steps * A / (elapsed + raw_extra_ms[0] * 1e-3) if elapsed > 0 else None),
+            "raw_is": "the timed region with NOTHING subtracted (N = 1: each spread step's interval still holds the one HIP event record that brackets it)",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload_text,
                        "envs_per_gpu": E, "n_players": n_players, "n_agents": A, "obs": "partial" if partial else "full", "gather": (False if gather is None else "sync" if args.sync_gather else "overlapped (transport of step k on a side stream beside the next kernels, ring of %d slabs)" % args.ring),
@@ -634,6 +673,10 @@ def main():
             if "simd_isolation" in full:
                 out["simd_isolation"] = full["simd_isolation"]
             out["value_full_episode"] = full["value"] if world == 1 else None
+            if world == 1 and not robocup and not partial and not args.roofline_only:
+                # the same episode on the plain grid: what the E == 4096-on-256-CUs special case (SIMD isolation) is worth
+                noiso = episode_leg(torch, device, args.workload, E, args.seed, n_players=n_players, no_isolation=True)
+                out["value_no_isolation"], out["ms_per_step_no_isolation"] = noiso["value"], noiso["ms_per_step"]
         if world == 1 and not args.no_extra_legs and gather is None:
             env.close()
             out["other_configs"] = [episode_leg(torch, device, w, E, args.seed) for w in WORKLOADS if w != args.workload]
@@ -643,6 +686,11 @@ def main():
             out["plumbing_config0"] = plumbing_leg(torch, device, args.seed)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(E, n_players, A, args.seed, robocup, partial=partial)
+            # BASELINE.md section 3 / SURVEY 8d name threads = os.cpu_count(): the same sample with one thread per logical CPU of the box
+            # (on a GPU box whose cgroup grants 16 cores of an EPYC this OVERSUBSCRIBES the share; both figures are in the line)
+            allc = os.cpu_count() or 1
+            out["cpu_baseline_all_cores"] = (dict(out["cpu_baseline"], note="os.cpu_count() == the core share: same run") if allc == out["cpu_baseline"]["cores"]
+                                             else cpu_baseline(E, n_players, A, args.seed, robocup, partial=partial, target_seconds=8.0, threads=allc))
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
         sys.stdout.flush()

@@ -92,7 +92,7 @@ struct DrvState {
   /* SIMD isolation of the slow environments (scheduling only - which block steps which environment; see drv_iso_assign):
      iso[0..2] = list lengths, iso[3..5] = slowest environment's cycles, iso[7] = placeholders that gave up waiting,
      iso[8..10] = "the block -> SIMD placement isolation relies on was observed" (written by the launch before the one that
-     reads it), iso[11] = launches in which it was not, iso[12] = cool-down counter of the validation, iso[DRV_ISO_HDR + buf * DRV_ISO_LIST + k] = ids; three buffers used in
+     reads it), iso[11] = launches in which it was not, iso[12] = cool-down counter of the validation, iso[13] / iso[14] = tick / pv_par on the device (tick_src), iso[DRV_ISO_HDR + buf * DRV_ISO_LIST + k] = ids; three buffers used in
      rotation (step t reads buffer t % 3, fills (t + 1) % 3, clears (t + 2) % 3); iso_done[e] = tick of e's last finished step;
      iso_hw[t & 1][b] = hardware id (XCC | SE | SH | CU | SIMD) block b of step t ran on.  None of this is simulation state:
      it is allocated outside the checkpointed arrays and starts over at dynenv_checkpoint_load. */
@@ -105,6 +105,8 @@ struct DrvState {
   int* pvq;
   int pv_par;
   int tick, iso_on;  /* iso_on: 0 off, 1 isolation (E = one residency round), 2 slow environments first (E larger) */
+  int tick_src;      /* 0: `tick` / `pv_par` above, advanced by the host per launch; 1: the device words iso[13] / iso[14], advanced by
+                        drv_tick_advance_kernel in front of every step - set for good once a step has been captured into a hipGraph */
 };
 #ifndef DRV_ISO_MAX
 #define DRV_ISO_MAX 64   /* at most this many environments get a SIMD of their own (iso_on = 1) */

@@ -1625,11 +1625,16 @@ DE_DEV unsigned drv_hw_simd_key() {
   const unsigned hw = (unsigned)__builtin_amdgcn_s_getreg(63492) /* HW_REG_HW_ID, 32 bits */, xcc = (unsigned)__builtin_amdgcn_s_getreg(63508) /* XCC_ID */;
   return ((xcc & 0xFu) << 16) | (hw & 0xFF30u);
 }
-DE_DEV int drv_iso_assign(const DrvState& S, int lane) {
+// tick / pv_par of this launch: kernel arguments the host advances per step - or, once a step of the handle has been captured into
+// a hipGraph (tick_src = 1: a replayed launch has frozen arguments), two device words that a one-thread kernel in front of every
+// step advances (drv_tick_advance_kernel).  An eager launch mirrors its arguments into those words, so the switch is seamless.
+DE_DEV int drv_launch_tick(const DrvState& S) { return S.tick_src ? uniform_i(__atomic_load_n(&S.iso[13], __ATOMIC_RELAXED)) : S.tick; }
+DE_DEV int drv_launch_pv(const DrvState& S) { return S.tick_src ? uniform_i(__atomic_load_n(&S.iso[14], __ATOMIC_RELAXED)) : S.pv_par; }
+DE_DEV int drv_iso_assign(const DrvState& S, int lane, int tick) {
   const int b = blockIdx.x, E = S.E;
   if (!S.iso_on) return b;
-  const int buf = S.tick % 3;
-  if (b == 0 && lane == 0) { const int nn = (S.tick + 2) % 3; S.iso[nn] = 0; S.iso[3 + nn] = 0; }  // the buffer the NEXT step fills
+  const int buf = tick % 3;
+  if (b == 0 && lane == 0) { const int nn = (tick + 2) % 3; S.iso[nn] = 0; S.iso[3 + nn] = 0; }  // the buffer the NEXT step fills
   if (S.iso_on == 3) return b;  // timing only (Partial observations): see drv_iso_report and the fused passes in drv_step_body
   int K = uniform_i(S.iso[buf]);
   const int cap = S.iso_on == 1 ? DRV_ISO_MAX : DRV_ISO_LIST;
@@ -1640,9 +1645,9 @@ DE_DEV int drv_iso_assign(const DrvState& S, int lane) {
     // record of the previous launch and publishes the verdict for the next one.  Wherever the pattern does not hold - another
     // kernel sharing the device, a partitioned device, a different dispatcher - isolation stays off (K = 0): same results,
     // same bijection, no placeholders holding wave slots for nothing.
-    if (b < E) { if (lane == 0) S.iso_hw[(size_t)(S.tick & 1) * (4 * DRV_ISO_GROUPS) + b] = drv_hw_simd_key(); }
+    if (b < E) { if (lane == 0) S.iso_hw[(size_t)(tick & 1) * (4 * DRV_ISO_GROUPS) + b] = drv_hw_simd_key(); }
     else if (b == E + 3 * DRV_ISO_MAX) {  // (one block behind the spares, for this alone)
-      const unsigned* hw = S.iso_hw + (size_t)((S.tick + 1) & 1) * (4 * DRV_ISO_GROUPS);
+      const unsigned* hw = S.iso_hw + (size_t)((tick + 1) & 1) * (4 * DRV_ISO_GROUPS);
       bool bad = false;
       for (int g = DRV_ISO_G0 + lane; g < DRV_ISO_G0 + DRV_ISO_GSPAN; g += 64) {
         const unsigned k0 = hw[g], k1 = hw[g + DRV_ISO_GROUPS], k2 = hw[g + 2 * DRV_ISO_GROUPS], k3 = hw[g + 3 * DRV_ISO_GROUPS];
@@ -1656,8 +1661,8 @@ DE_DEV int drv_iso_assign(const DrvState& S, int lane) {
         int cd = S.iso[12];
         if (!ok) cd = DRV_ISO_COOLDOWN; else if (cd > 0) cd -= 1;
         S.iso[12] = cd;
-        S.iso[8 + (S.tick + 1) % 3] = (ok && cd == 0) ? 1 : 0;
-        if (!ok && S.tick > 1) atomicAdd(&S.iso[11], 1);
+        S.iso[8 + (tick + 1) % 3] = (ok && cd == 0) ? 1 : 0;
+        if (!ok && tick > 1) atomicAdd(&S.iso[11], 1);
       }
       return -1;
     }
@@ -1683,7 +1688,7 @@ DE_DEV int drv_iso_assign(const DrvState& S, int lane) {
       // placeholder: hold this wave slot idle while the slow environment of this SIMD runs (bounded wait, then exit)
       int i = 0;
       for (; i < 96; ++i) {
-        if (uniform_i(__atomic_load_n(&S.iso_done[h], __ATOMIC_RELAXED)) == S.tick) break;
+        if (uniform_i(__atomic_load_n(&S.iso_done[h], __ATOMIC_RELAXED)) == tick) break;
         __builtin_amdgcn_s_sleep(127);
       }
       if (i >= 96 && lane == 0) atomicAdd(&S.iso[7], 1);  // (diagnostic: a placeholder that gave up waiting; dynenv_debug_counters)
@@ -1714,10 +1719,10 @@ DE_DEV int drv_iso_assign(const DrvState& S, int lane) {
 #ifndef DRV_ISO_TENTHS
 #define DRV_ISO_TENTHS 8 /* ... for the environments above this many tenths of it */
 #endif
-DE_DEV void drv_iso_report(const DrvState& S, int e, int lane, unsigned long long t0) {
+DE_DEV void drv_iso_report(const DrvState& S, int e, int lane, unsigned long long t0, int tick) {
   if (!S.iso_on || lane != 0) return;
   const int cycles = (int)(__builtin_amdgcn_s_memtime() - t0);
-  const int buf = S.tick % 3, nxt = (S.tick + 1) % 3;
+  const int buf = tick % 3, nxt = (tick + 1) % 3;
   const int slowest = S.iso[3 + buf];
   // (only the few environments above the floor touch the shared words: 4096 atomics on one address serialise - 0.12 ms, measured)
   if (cycles > DRV_ISO_MIN && cycles > (slowest / 10) * DRV_ISO_TENTHS) atomicMax(&S.iso[3 + nxt], cycles);
@@ -1726,7 +1731,7 @@ DE_DEV void drv_iso_report(const DrvState& S, int e, int lane, unsigned long lon
     const int k = atomicAdd(&S.iso[nxt], 1);
     if (k < DRV_ISO_LIST) S.iso[DRV_ISO_HDR + nxt * DRV_ISO_LIST + k] = e;
   }
-  __atomic_store_n(&S.iso_done[e], S.tick, __ATOMIC_RELAXED);
+  __atomic_store_n(&S.iso_done[e], tick, __ATOMIC_RELAXED);
 }
 
 template <bool PARTIAL>
@@ -1736,7 +1741,9 @@ DE_DEV void drv_step_body(const DrvState& S, const int* __restrict__ actions, fl
 DRV_PROF(const unsigned long long KS = isoT0;)
   DrvLds& L = g_L;
   int lane = threadIdx.x;
-  const int e = drv_iso_assign(S, lane);  // (= blockIdx.x unless the slow environments of the previous step are being isolated)
+  const int tick = drv_launch_tick(S);
+  if (!S.tick_src && blockIdx.x == 0 && lane == 0) { S.iso[13] = S.tick; S.iso[14] = S.pv_par; }  // (mirror for a later switch to tick_src = 1)
+  const int e = drv_iso_assign(S, lane, tick);  // (= blockIdx.x unless the slow environments of the previous step are being isolated)
   if (e < 0) return;
 DRV_PROF(if (lane < 8 && e < 4096) { g_dbgp[e * 8 + lane] = 0ull; g_dbgs[e * 8 + lane] = 0ull; })
   const int A = S.A;
@@ -1909,13 +1916,13 @@ DRV_PROF(const unsigned long long K1 = __builtin_amdgcn_s_memtime();)
   // its passes), and they - not the slowest environment - were what the launch waited for.
   int budget = 0;
   if (PARTIAL && pobs && S.iso_on >= 2) {
-    const int slowest = uniform_i(S.iso[3 + S.tick % 3]);
+    const int slowest = uniform_i(S.iso[3 + tick % 3]);
     if (slowest > 0) {
       budget = (slowest / 100) * DRV_PV_DEADLINE_PCT - (int)(__builtin_amdgcn_s_memtime() - isoT0);
       fusedAgents = budget > 0 ? A : 0;
     }
   }
-  drv_iso_report(S, e, fresh_lane(), isoT0);
+  drv_iso_report(S, e, fresh_lane(), isoT0, tick);
   if (PARTIAL && fusedAgents > 0) {
     __builtin_amdgcn_s_setprio(0);  // (an environment that touched the contact path raised it: the vision passes are nobody's critical path)
     PvIn in;
@@ -1931,12 +1938,18 @@ DRV_PROF(const unsigned long long K1 = __builtin_amdgcn_s_memtime();)
   if (PARTIAL && fresh_lane() == 0) {
     envi[EI_DEFER_OBS] = fusedAgents;  // first agent the deferred launch has to do
     if (pobs && fusedAgents < A) {  // ... and this environment on its list
-      const int k = atomicAdd(&S.pvq[16 * S.pv_par], 1);
-      if (k < S.E) S.pvq[32 + S.pv_par * S.E + k] = e;
+      const int pv = drv_launch_pv(S);
+      const int k = atomicAdd(&S.pvq[16 * pv], 1);
+      if (k < S.E) S.pvq[32 + pv * S.E + k] = e;
       else envi[EI_ERR] = envi[EI_ERR] | 4;  // only a host that replays a captured launch (frozen pv_par: the length is never cleared) gets here
     }
   }
 DRV_PROF(if (lane == 0 && e < 4096) { unsigned long long* d = g_dbgw + e * 12; const unsigned long long KE = __builtin_amdgcn_s_memtime(); d[0] = KE - KS; d[1] = nContact; d[2] = __popcll(occ); d[3] = nSteady + nQuiet; d[4] = K0 - KS; d[5] = tPh1; d[6] = tBroad; d[7] = tFast; d[8] = tCont; d[9] = (K1 - K0) - tPh1 - tBroad - tFast - tCont; d[10] = KE - K1; d[11] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned long long)__builtin_amdgcn_s_getreg(63492); })
+}
+
+// tick_src = 1 (a step of this handle was captured into a hipGraph): what the host does between two eager launches, on the device
+extern "C" __global__ void drv_tick_advance_kernel(DrvState S) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { S.iso[13] = (S.iso[13] + 1) % (3 * (1 << 28)); S.iso[14] = S.iso[14] ^ 1; }
 }
 
 extern "C" __global__ void __launch_bounds__(64, DRV_WAVES_PER_SIMD)

@@ -600,10 +600,11 @@ DE_OOL int drv_partial_obs_fused(PvIn in, uint64_t seed, int A, int* envi, int e
 extern "C" __global__ void __launch_bounds__(64, 4)
 drv_partial_obs_deferred_kernel(DrvState S, int noiseType, double magn, float* __restrict__ obs) {
   const int lane = threadIdx.x, A = S.A;
-  const int* list = S.pvq + 32 + S.pv_par * S.E;
-  int n = uniform_i(S.pvq[16 * S.pv_par]);
+  const int pv = drv_launch_pv(S);
+  const int* list = S.pvq + 32 + pv * S.E;
+  int n = uniform_i(S.pvq[16 * pv]);
   n = n < S.E ? n : S.E;  // (longer only if the length was not cleared: see the append in drv_step_body)
-  if (blockIdx.x == 0 && lane == 0) S.pvq[16 * (S.pv_par ^ 1)] = 0;  // the next step's list starts empty (nobody reads or fills it now)
+  if (blockIdx.x == 0 && lane == 0) S.pvq[16 * (pv ^ 1)] = 0;  // the next step's list starts empty (nobody reads or fills it now)
   // item j = (agent j / n, listed environment j % n): neighbouring blocks work on different environments
 #pragma unroll 1
   for (int j = blockIdx.x; j < n * A; j += gridDim.x) {

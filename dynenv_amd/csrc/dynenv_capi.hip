@@ -665,7 +665,16 @@ int dynenv_step_head(dynenv_t* h, const int32_t* actions_dev, const double* head
   // launches that did not validate every ISO_PROBE_EVERY steps - an asynchronous 4-byte copy, read one window later, never
   // waited for - and when more than half of a window's launches did not validate it drops to the plain launch (mode 0: exactly
   // what DYNENV_NO_ISOLATION=1 gives) for ISO_PAUSE_STEPS steps, then starts isolation over.  Scheduling only, as ever.
-  if (h->iso_cfg == 1) {
+  // A step that is being CAPTURED into a hipGraph will be replayed with frozen kernel arguments, and none of the host logic below
+  // runs at replay: from the first captured step on, for good, the handle keeps tick / pv_par in two device words that a one-thread
+  // kernel advances in front of every step (eager steps included: ~2 us each), the isolation pause logic is off (the device-side
+  // validation still holds isolation off on a shared device), and a paused isolation stays paused.
+  if (!h->S.tick_src) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) h->S.tick_src = 1;
+  }
+  if (h->S.tick_src) hipLaunchKernelGGL(drv_tick_advance_kernel, dim3(1), dim3(64), 0, st, h->S);
+  if (h->iso_cfg == 1 && !h->S.tick_src) {
     h->steps += 1;
     if (h->S.iso_on == 0 && h->steps >= h->iso_paused_until) {
       if (iso_reset_async(h, st)) return DYNENV_ERR_HIP;
@@ -681,10 +690,10 @@ int dynenv_step_head(dynenv_t* h, const int32_t* actions_dev, const double* head
     }
   }
   const unsigned stepGrid = (unsigned)h->S.E + (h->S.iso_on == 1 ? 3u * DRV_ISO_MAX + 1u /* the placement validator */ : 0u);
-  h->S.tick = (h->S.tick + 1) % (3 * (1 << 28));  // (wraps at a multiple of 3: the three isolation lists keep rotating in order)
+  if (!h->S.tick_src) h->S.tick = (h->S.tick + 1) % (3 * (1 << 28));  // (wraps at a multiple of 3: the three isolation lists keep rotating in order)
   if (h->partial && obs_dev)
   {
-    h->S.pv_par ^= 1;
+    if (!h->S.tick_src) h->S.pv_par ^= 1;
     hipLaunchKernelGGL(drv_step_partial_kernel, dim3(stepGrid), dim3(64), 0, st, h->S, (const int*)actions_dev, rewards_dev, dones_dev, obs_dev,
                        (int)h->cfg.noise_type, (double)h->cfg.noise_magnitude);
     sev.main_done();
@@ -788,7 +797,7 @@ int dynenv_debug_counters(dynenv_t* h, int64_t* out4) {
   {  // SIMD isolation: how many environments the next step isolates, placeholders that gave up waiting (should stay 0)
     int iso[DRV_ISO_HDR];
     HIP_OK(hipMemcpy(iso, h->S.iso, sizeof(iso), hipMemcpyDeviceToHost));
-    const int nxt = (h->S.tick + 1) % 3, k = iso[nxt];
+    const int nxt = ((h->S.tick_src ? iso[13] : h->S.tick) + 1) % 3, k = iso[nxt];
     const int cap = h->S.iso_on == 1 ? DRV_ISO_MAX : DRV_ISO_LIST;
     out4[10] = h->S.iso_on ? (k < cap ? k : cap) : -1; out4[11] = iso[7];
     // out[12]: scheduling mode (0 off, 1 SIMD isolation, 2 slow environments first, 3 timing only: Partial); out[13]: 1 = the next step found the block ->
@@ -814,7 +823,9 @@ int dynenv_debug_placement(dynenv_t* h, uint32_t* out, int32_t n) {
   ON_DEVICE(h);
   HIP_OK(hipDeviceSynchronize());
   const int m = n < 4 * DRV_ISO_GROUPS ? n : 4 * DRV_ISO_GROUPS;
-  HIP_OK(hipMemcpy(out, h->S.iso_hw + (size_t)(h->S.tick & 1) * (4 * DRV_ISO_GROUPS), sizeof(uint32_t) * m, hipMemcpyDeviceToHost));
+  int tick = h->S.tick;
+  if (h->S.tick_src) HIP_OK(hipMemcpy(&tick, h->S.iso + 13, sizeof(int), hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(out, h->S.iso_hw + (size_t)(tick & 1) * (4 * DRV_ISO_GROUPS), sizeof(uint32_t) * m, hipMemcpyDeviceToHost));
   return m;
 }
 

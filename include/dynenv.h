@@ -156,7 +156,9 @@ int dynenv_reset(dynenv_t* h, float* obs_dev, void* stream);
  *   rewards_dev  float64 [E, A]                dones_dev uint8 [E]
  * Does NOT auto-reset: the host mirror calls dynenv_reset after a terminal step (SubprocVecEnv semantics).
  * obs_dev may be NULL (no observation written) except for RoboCup with Partial observations, whose rewards contain the
- * observation reward of processSeens (RoboCupEnvironment.py:497-524) and come out of the same pass: DYNENV_ERR_ARG then. */
+ * observation reward of processSeens (RoboCupEnvironment.py:497-524) and come out of the same pass: DYNENV_ERR_ARG then.
+ * May be captured into a hipGraph (stream capture) and replayed: per-step scheduling counters move to the device on the first
+ * captured call, for the rest of the handle's life (INTEGRATION.md "Scheduling, checkpoints and graphs"). */
 int dynenv_step(dynenv_t* h, const int32_t* actions_dev, float* obs_dev, double* rewards_dev, uint8_t* dones_dev,
                 void* stream);
 
@@ -211,8 +213,8 @@ int dynenv_sync(dynenv_t* h, void* stream);
  * outside the action space was seen - the reference raises there, DrivingEnvironment.py:365-368 / RoboCupEnvironment.py:543-550;
  * here that agent's action is ignored for the step and the flag stays up until the next reset - also: a Partial observation row
  * list longer than its capacity, rows dropped; bit 2: Driving Partial, the list of environments left to the deferred
- * observation launch is full - it is cleared between steps by launches that alternate a host-chosen parity, so only a host that
- * replays a captured dynenv_step gets here).
+ * observation launch is full - it is cleared between steps by launches that alternate a parity; a guard that no supported use
+ * reaches: a captured dynenv_step keeps that parity on the device).
  * Synchronises the device. */
 int dynenv_error_flags(dynenv_t* h, int32_t* out);
 

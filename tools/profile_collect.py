@@ -38,6 +38,17 @@ def main():
                    "step_bytes_all_kernels adds the Partial paths' deferred / finalize launches; tools/profile_round.sh")
     out["kernel_source_sha16"] = bench.kernel_source_sha()
     out["tag"] = tag
+    sq_path = "gpurun_out/sq_counters.json"
+    sq = {}
+    if os.path.exists(os.path.join(ROOT, "profiles", "sq_counters.json")):
+        old_sq = json.load(open(os.path.join(ROOT, "profiles", "sq_counters.json")))
+        if old_sq.get("kernel_source_sha16") == bench.kernel_source_sha():
+            sq = old_sq
+    sq["note"] = ("per launch of the workload's step kernel, mean over the launches of whole episodes at 4096 envs; rocprofv3 --pmc in two passes "
+                  "(tools/profile_round.sh).  valu_busy = SQ_INSTS_VALU x 4 / (1024 SIMDs x launch duration x 2.4 GHz), the launch duration being the "
+                  "AverageNs of the --kernel-trace --stats pass of the same round; wave_time_shares = SQ_ACTIVE_INST_* / SQ_WAIT_* over SQ_WAVE_CYCLES")
+    sq["kernel_source_sha16"] = bench.kernel_source_sha()
+    sq["tag"] = tag
     for w in workloads:
         f = counters("gpurun_out/%s_prof_%s_f/*/*counter_collection.csv" % (tag, w))
         wr = counters("gpurun_out/%s_prof_%s_w/*/*counter_collection.csv" % (tag, w))
@@ -75,6 +86,15 @@ def main():
                 try:  # VALU issue-slot utilisation over the launch: a wave64 VALU instruction occupies its SIMD for >= 4 cycles
                     rows = list(csv.DictReader(open("gpurun_out/%s_kernel_stats_%s.csv" % (tag, w))))
                     avg_ns = [float(r["AverageNs"]) for r in rows if r["Name"].split("(")[0] == STEP_KERNELS[w][0]][0]
+                    ws = m["SQ_WAVES"] if m.get("SQ_WAVES") else None
+                    sq[STEP_KERNELS[w][0]] = {
+                        "workload": w, "launch_us": avg_ns / 1e3, "valu_busy": m.get("SQ_INSTS_VALU", 0) * 4 / (1024 * avg_ns * 2.4),
+                        "wave_time_shares": {"executing": m.get("SQ_ACTIVE_INST_ANY", 0) / wc, "valu": m.get("SQ_ACTIVE_INST_VALU", 0) / wc,
+                                             "scalar": m.get("SQ_ACTIVE_INST_SCA", 0) / wc, "lds": m.get("SQ_ACTIVE_INST_LDS", 0) / wc,
+                                             "waitcnt": m.get("SQ_WAIT_ANY", 0) / wc, "issue_stall": m.get("SQ_WAIT_INST_ANY", 0) / wc},
+                        "insts_per_wave": (None if ws is None else {k_: m.get(c_, 0) / ws for k_, c_ in (
+                            ("valu", "SQ_INSTS_VALU"), ("salu", "SQ_INSTS_SALU"), ("lds", "SQ_INSTS_LDS"), ("branch", "SQ_INSTS_BRANCH"),
+                            ("vmem_rd", "SQ_INSTS_VMEM_RD"), ("vmem_wr", "SQ_INSTS_VMEM_WR"))})}
                     lines.append("SIMD VALU busy >= %.1f %% of the launch (SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x %.1f us x 2.4 GHz); fp64 instructions hold the "
                                  "SIMD longer than 4 cycles, so this is a lower bound)" % (100 * m.get("SQ_INSTS_VALU", 0) * 4 / (1024 * avg_ns * 2.4), avg_ns / 1e3))
                 except (OSError, IndexError, KeyError, ValueError):
@@ -82,6 +102,7 @@ def main():
             open("gpurun_out/%s_sq_breakdown_%s.txt" % (tag, w), "w").write(
                 "%s, 4096 envs, one whole episode (kernel sources %s); rocprofv3 --pmc, per launch\n" % (STEP_KERNELS[w][0], bench.kernel_source_sha()) + "\n".join(lines) + "\n")
     json.dump(out, open(path, "w"), indent=1)
+    json.dump(sq, open(sq_path, "w"), indent=1)
     print(json.dumps({k: v for k, v in out.items() if k.endswith("_bytes_per_launch") or k == "kernel_source_sha16"}, indent=1))
 
 

@@ -4,7 +4,8 @@
 #   2. rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) for EVERY kernel of the step, the Partial paths' deferred /
 #      finalize launches included -> gpurun_out/pmc_traffic.json, stamped with the hash of the kernel sources (bench.py reports
 #      roofline.traffic from profiles/pmc_traffic.json only while that hash matches)
-#   3. SQ counters (two passes) of the Full step kernels -> gpurun_out/<TAG>_sq_breakdown_<workload>.txt
+#   3. SQ counters (two passes) of every workload's step kernel -> gpurun_out/<TAG>_sq_breakdown_<workload>.txt and
+#      gpurun_out/sq_counters.json (valu_busy, wave_time_shares per kernel, stamped like pmc_traffic.json: bench.py's roofline reads it)
 # Every run is `bench.py --workload W --roofline-only`: the launches a profiler sees are the roofline leg's two passes over ONE
 # whole episode at 4096 envs (+ 7 first-touch launches), i.e. the average of the stats csv is that leg's launch_ms.
 # Usage (GPU box): bash tools/profile_round.sh r03_a ["driving robocup driving_partial robocup_partial"]; then copy into profiles/.
@@ -23,7 +24,7 @@ for W in $WORKLOADS; do
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d ${D}_f -- python3 bench.py --workload $W $B > /dev/null 2> ${D}_f.err || exit 1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d ${D}_w -- python3 bench.py --workload $W $B > /dev/null 2> ${D}_w.err || exit 1
   echo "[profile_round] $W traffic passes done"
-  case $W in driving|robocup)
+  case $W in driving|robocup|driving_partial|robocup_partial)
     rm -rf ${D}_s1 ${D}_s2
     rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS --output-format csv -d ${D}_s1 -- python3 bench.py --workload $W $B > /dev/null 2> ${D}_s1.err || exit 1
     rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES --output-format csv -d ${D}_s2 -- python3 bench.py --workload $W $B > /dev/null 2> ${D}_s2.err || exit 1
