@@ -13,6 +13,17 @@
 #define PV_CAP_OBST 32
 #define PV_CAP_PEDS 40
 #define PV_CAP_LANES 16
+// the LIMIT on a list's rows is its capacity in the layout - except in the test build that shows an overflow being reported
+// (dynenv_amd/libdynenv_hip_testcaps.so, tests/test_gpu_boundary.py): the reference's lists have no cap (DrivingEnvironment.py:816-890),
+// SURVEY Appendix E's worst case (39 cars) is above these capacities and astronomically unlikely (15 of ~30 objects misclassified / false
+// positives at 0.4 % each), so rows beyond a limit are dropped and error bit 3 tells the host
+#ifndef PV_LIM_CARS
+#define PV_LIM_CARS PV_CAP_CARS
+#define PV_LIM_OBST PV_CAP_OBST
+#define PV_LIM_PEDS PV_CAP_PEDS
+#define PV_LIM_LANES PV_CAP_LANES
+#endif
+static_assert(PV_LIM_CARS <= PV_CAP_CARS && PV_LIM_OBST <= PV_CAP_OBST && PV_LIM_PEDS <= PV_CAP_PEDS && PV_LIM_LANES <= PV_CAP_LANES, "limits inside the layout");
 #define PV_DIM (9 + PV_CAP_CARS * 7 + PV_CAP_OBST * 6 + PV_CAP_PEDS * 2 + PV_CAP_LANES * 4 + 4)
 #define PV_OFF_CARS 9
 #define PV_OFF_OBST (9 + PV_CAP_CARS * 7)
@@ -474,7 +485,7 @@ DE_DEV int pv_env(const DrvState& S, PvLds& L, const int e, const int lane, cons
 #define PV_PUT_RECT(on_, car_, P_, q_, c_, s_, w_, h_, fin_)                                                               \
   do {                                                                                                                    \
     if (on_) {                                                                                                            \
-      if ((P_) < ((car_) ? PV_CAP_CARS : PV_CAP_OBST)) {                                                                  \
+      if ((P_) < ((car_) ? PV_LIM_CARS : PV_LIM_OBST)) {                                                                  \
         float* o = row + ((car_) ? PV_OFF_CARS + (P_)*7 : PV_OFF_OBST + (P_)*6);                                          \
         o[0] = (float)pv_normalize((q_).x, (5.0 * 2.0 / DRV_W), 0.0); o[1] = (float)pv_normalize((q_).y, (5.0 * 2.0 / DRV_H), 0.0); \
         o[2] = (float)(c_); o[3] = (float)(s_);                                                                           \
@@ -500,7 +511,7 @@ DE_DEV int pv_env(const DrvState& S, PvLds& L, const int e, const int lane, cons
 #define PV_PUT_PED(on_, P_, q_)                                                                                            \
   do {                                                                                                                    \
     if (on_) {                                                                                                            \
-      if ((P_) < PV_CAP_PEDS) {                                                                                           \
+      if ((P_) < PV_LIM_PEDS) {                                                                                           \
         float* o = row + PV_OFF_PEDS + (P_)*2;                                                                            \
         o[0] = (float)pv_normalize((q_).x, (5.0 * 2.0 / DRV_W), 0.0); o[1] = (float)pv_normalize((q_).y, (5.0 * 2.0 / DRV_H), 0.0); \
       } else overflow = 1;                                                                                                \
@@ -513,7 +524,7 @@ DE_DEV int pv_env(const DrvState& S, PvLds& L, const int e, const int lane, cons
       const bool lReal = isLaneRow && lseen != SIGHT_NONE, lFp = fpClass == 3;
       if (lReal || lFp) {
         const int p = lReal ? __popcll(outLaneReal & below) : __popcll(outLaneReal) + __popcll(fpLaneMask & below);
-        if (p < PV_CAP_LANES) {
+        if (p < PV_LIM_LANES) {
           float* o = row + PV_OFF_LANES + p * 4;
           o[0] = (float)(lReal ? ldist : fpLaneDist); o[1] = (float)(lReal ? lc : fpc); o[2] = (float)(lReal ? ls : fps);
           o[3] = (float)(lReal ? ltype : fpLaneType);
@@ -528,17 +539,17 @@ DE_DEV int pv_env(const DrvState& S, PvLds& L, const int e, const int lane, cons
       const double gx = in.gx, gy = in.gy;  // isSelf: lane == a
       row[6] = (float)pv_normalize(gx, (5.0 * 2.0 / DRV_W), 5.0); row[7] = (float)pv_normalize(gy, (5.0 * 2.0 / DRV_H), 5.0);
       row[8] = (float)CF_FIN(L.flags[a]);
-      row[PV_DIM - 4] = (float)(nOutCars < PV_CAP_CARS ? nOutCars : PV_CAP_CARS);
-      row[PV_DIM - 3] = (float)(nOutObst < PV_CAP_OBST ? nOutObst : PV_CAP_OBST);
-      row[PV_DIM - 2] = (float)(nOutPeds < PV_CAP_PEDS ? nOutPeds : PV_CAP_PEDS);
-      row[PV_DIM - 1] = (float)(nOutLanes < PV_CAP_LANES ? nOutLanes : PV_CAP_LANES);
+      row[PV_DIM - 4] = (float)(nOutCars < PV_LIM_CARS ? nOutCars : PV_LIM_CARS);
+      row[PV_DIM - 3] = (float)(nOutObst < PV_LIM_OBST ? nOutObst : PV_LIM_OBST);
+      row[PV_DIM - 2] = (float)(nOutPeds < PV_LIM_PEDS ? nOutPeds : PV_LIM_PEDS);
+      row[PV_DIM - 1] = (float)(nOutLanes < PV_LIM_LANES ? nOutLanes : PV_LIM_LANES);
     }
     __syncthreads();
     for (int i = lane; i < PV_DIM; i += DE_WAVE) grow[i] = row[i];
     (void)nObst0; (void)nPeds0; (void)nLanes0;
     __syncthreads();
   }
-  if (wave_ballot(overflow != 0) && lane == 0) envi[EI_ERR] = envi[EI_ERR] | 2;
+  if (wave_ballot(overflow != 0) && lane == 0) envi[EI_ERR] = envi[EI_ERR] | 8;  // rows dropped (dynenv.h, error bit 3)
   return a;
 }
 

@@ -476,7 +476,7 @@ DE_DEV void rv_env(const RcState& S, RvLds& V, const int e, const int lane, floa
   int ov = 0;
 #pragma unroll 1
   for (int t = 0; t < 5; ++t) ov |= rv_snapshot(S, V, va, e, lane, t, obs, rewards != nullptr, 0, S.R) & 1;
-  if (ov && lane == 0) S.envi[(size_t)e * RE_COUNT + RE_ERR] |= 2;
+  if (ov && lane == 0) S.envi[(size_t)e * RE_COUNT + RE_ERR] |= 8;
   if (rewards) rv_finalize(S, V.seen, e, lane, rewards);
 }
 // stand-alone launch: after reset / set_state (rewards == nullptr)
@@ -524,7 +524,7 @@ DE_OOL int rc_partial_obs_fused(uint64_t seed, int env_id_offset, int* envi, int
     done += aEnd;
     if (aEnd < S.R) break;
   }
-  if (ov && lane == 0) S.envi[(size_t)e * RE_COUNT + RE_ERR] |= 2;
+  if (ov && lane == 0) S.envi[(size_t)e * RE_COUNT + RE_ERR] |= 8;
   if (done == 5 * S.R) rv_finalize(S, V.seenSum, e, lane, uniform_ptr(rewards));
   return done;
 }
@@ -546,7 +546,7 @@ rc_partial_obs_deferred_kernel(RcState S, float* __restrict__ obs) {
     if (t * S.R + a < (entry >> 20)) continue;  // done in the step launch
     for (int i = lane; i < 10 * RCP_SEEN_STRIDE; i += DE_WAVE) V.seen[i] = 0;
     const int ov = rv_snapshot(S, V, rv_args(S, e), e, lane, t, obs, true, a, a + 1) & 1;
-    if (ov && lane == 0) atomicOr(&S.envi[(size_t)e * RE_COUNT + RE_ERR], 2);
+    if (ov && lane == 0) atomicOr(&S.envi[(size_t)e * RE_COUNT + RE_ERR], 8);
     int* part = S.seenPart + ((size_t)e * 5 + t) * 10 * RCP_SEEN_STRIDE + a * RCP_SEEN_STRIDE;
     if (lane < RCP_SEEN_STRIDE) part[lane] = V.seen[a * RCP_SEEN_STRIDE + lane];
     __syncthreads();

@@ -429,7 +429,9 @@ class BatchedDynEnv(object):
         return a, head
 
     def step_flat(self, actions, auto_reset=True, validate=False):
-        """One env step of every environment: ONE kernel launch on torch's current stream."""
+        """One env step of every environment: ONE kernel launch on torch's current stream.  Nothing is waited for and no flag is
+        read here: a consumer of Partial observations that wants to know whether a list ever outgrew the layout's capacity (rows
+        dropped; astronomically unlikely, include/dynenv.h error bit 3) calls error_flags() at its own pace; step() does, and raises."""
         if self._needs_reset:
             raise _capi.DynEnvError("call reset() before step()")
         torch = self._torch
@@ -769,6 +771,10 @@ class BatchedDynEnv(object):
         full_dev = self.full_state_obs() if self.observationType != ObservationType.FULL else None
         glob_dev = self.global_state() if self.env_type == DynEnvType.ROBO_CUP else None  # 252 B per environment, one short launch
         rewards = self.rewards.cpu().numpy().copy()
+        if self.observationType == ObservationType.PARTIAL and self.error_flags() & 8:
+            # the reference's observation lists have no cap (DrivingEnvironment.py:816-890); the dense layout has, and rows beyond it were
+            # dropped: not the reference's observation any more - never silently (include/dynenv.h, error bit 3)
+            raise _capi.DynEnvError("Partial observation: a list had more rows than the dense layout's capacity; rows were dropped (error bit 3)")
         done = bool(self.last_done)
         dones = np.full((self.num_envs,), done, dtype=bool)
         # The step's observations stay in HBM (a snapshot: self.obs is rewritten by the next step) until somebody looks at them:

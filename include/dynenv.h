@@ -211,8 +211,10 @@ int dynenv_sync(dynenv_t* h, void* stream);
 
 /* OR over all environments of the kernels' error flags (bit 0: contact cache overflow, a pair was dropped; bit 1: an action
  * outside the action space was seen - the reference raises there, DrivingEnvironment.py:365-368 / RoboCupEnvironment.py:543-550;
- * here that agent's action is ignored for the step and the flag stays up until the next reset - also: a Partial observation row
- * list longer than its capacity, rows dropped; bit 2: Driving Partial, the list of environments left to the deferred
+ * here that agent's action is ignored for the step and the flag stays up until the next reset; bit 3: a Partial observation
+ * list had more rows than its capacity in the layout and the rows beyond it were DROPPED - the reference's lists have no cap
+ * (DrivingEnvironment.py:816-890); SURVEY Appendix E's worst case is above the Driving capacities (24 cars / 32 obstacles / 40
+ * pedestrians / 16 lanes), astronomically unlikely, and no longer silent: the host mirror's step() raises on it; bit 2: Driving Partial, the list of environments left to the deferred
  * observation launch is full - it is cleared between steps by launches that alternate a parity; a guard that no supported use
  * reaches: a captured dynenv_step keeps that parity on the device).
  * Synchronises the device. */

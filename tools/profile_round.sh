@@ -32,3 +32,6 @@ for W in $WORKLOADS; do
   esac
 done
 python3 tools/profile_collect.py $TAG $WORKLOADS
+# the RoboCup code's instruction-cache phase (RC_LAYOUT_PAD_WORDS): still within 0.5 % of the best candidate? (needs the candidate
+# libraries of `python3 tools/rc_layout_sweep.py build`; skipped without them)
+python3 tools/rc_layout_sweep.py check || echo "[profile_round] RoboCup code phase NOT within 0.5 % of the best candidate: see gpurun_out/rc_layout_sweep.txt"
