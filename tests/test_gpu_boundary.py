@@ -3,6 +3,7 @@ info['Full State'] with Partial observations equals the oracle's noise-free stat
 (randomInit, deterministicTurn) and the continuous head channel against the oracle, malformed actions, checkpoint / replay
 across an episode end, refresh_obs, the device guard."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
