@@ -5,11 +5,13 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 LIB = os.path.join(PKG, "libdynenv_hip.so")
-SRC = os.path.join(PKG, "csrc", "dynenv_capi.hip")
+SRC = os.path.join(PKG, "csrc", "dynenv_capi.hip")      # host code + RoboCup + arranger kernels: -O3
+SRC_DRV = os.path.join(PKG, "csrc", "driving_tu.hip")    # the Driving kernels, a translation unit of their own: -O2 (csrc/driving_host.h)
 DEPS = [os.path.join(PKG, "csrc", f) for f in
-        ("dynenv_capi.hip", "driving_kernels.hip", "driving_partial.hip", "robocup_kernels.hip", "robocup_partial.hip", "arranger_kernels.hip", "driving_dev.h",
-         "robocup_dev.h", "dev_common.h")] + \
+        ("dynenv_capi.hip", "driving_tu.hip", "driving_kernels.hip", "driving_partial.hip", "robocup_kernels.hip", "robocup_partial.hip",
+         "arranger_kernels.hip", "driving_dev.h", "driving_host.h", "robocup_dev.h", "dev_common.h")] + \
        [os.path.join(ROOT, "include", f) for f in ("dynenv.h", "dynenv_math.h")]
+UNITS = ((SRC, ("-O3",)), (SRC_DRV, ("-O2",)))
 
 
 def needs_build():
@@ -19,22 +21,41 @@ def needs_build():
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in DEPS)
 
 
-def build(force=False, verbose=False, out=None, defines=(), extra=()):
+def build(force=False, verbose=False, out=None, defines=(), extra=(), unit_flags=None):
     """hipcc --offload-arch=gfx950, FMA contraction off (bit-exact parity with the oracle); -fno-optimize-sibling-calls: see
-    DE_OOL in csrc/dev_common.h (out-of-line device functions without callee-saved registers).
-    `out` / `defines` build an instrumented variant next to the product library (e.g. -DDRV_PROFILE)."""
+    DE_OOL in csrc/dev_common.h (out-of-line device functions without callee-saved registers).  Two translation units, each compiled
+    to an object with its own optimisation level, then linked.
+    `out` / `defines` build an instrumented variant next to the product library (e.g. -DDRV_PROFILE); `extra` goes to both units,
+    `unit_flags` = {source basename: flags} replaces a unit's own flags (tools/flag_sweep.py)."""
     if out is None and not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-fno-optimize-sibling-calls", "-fPIC", "-shared",
-           "-std=c++17", "-Wno-unused-value", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc"),
-           "-o", out or LIB, SRC] + ["-D" + d for d in defines] + list(extra)
+    target = out or LIB
+    common = ["--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-fno-optimize-sibling-calls", "-fPIC", "-std=c++17",
+              "-Wno-unused-value", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc")] + ["-D" + d for d in defines]
+    objs = []
+    procs = []
+    for src, flags in UNITS:
+        if unit_flags and os.path.basename(src) in unit_flags:
+            flags = tuple(unit_flags[os.path.basename(src)])
+        obj = target + "." + os.path.basename(src) + ".o"
+        cmd = [hipcc, "-c"] + common + list(flags) + list(extra) + ["-o", obj, src]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    return out or LIB
+    for o in objs:
+        os.remove(o)
+    return target
 
 
 if __name__ == "__main__":

@@ -13,9 +13,7 @@
 
 __constant__ DrvConst C;
 
-#ifndef DRV_WAVES_PER_SIMD
-#define DRV_WAVES_PER_SIMD 4 /* 4096 envs / (256 CUs * 4 SIMDs) */
-#endif
+#include "driving_host.h" /* DRV_WAVES_PER_SIMD, kernel declarations */
 
 // ------------------------------------------------------------------------------------------------
 // LDS tile of one environment (10 KiB budget => 16 environments per CU)

@@ -9,26 +9,7 @@
 // Mirrors oracle/driving_partial.c operation by operation (bit-identical output); see that file for the RNG keying.
 #include "driving_dev.h"
 
-#define PV_CAP_CARS 24
-#define PV_CAP_OBST 32
-#define PV_CAP_PEDS 40
-#define PV_CAP_LANES 16
-// the LIMIT on a list's rows is its capacity in the layout - except in the test build that shows an overflow being reported
-// (dynenv_amd/libdynenv_hip_testcaps.so, tests/test_gpu_boundary.py): the reference's lists have no cap (DrivingEnvironment.py:816-890),
-// SURVEY Appendix E's worst case (39 cars) is above these capacities and astronomically unlikely (15 of ~30 objects misclassified / false
-// positives at 0.4 % each), so rows beyond a limit are dropped and error bit 3 tells the host
-#ifndef PV_LIM_CARS
-#define PV_LIM_CARS PV_CAP_CARS
-#define PV_LIM_OBST PV_CAP_OBST
-#define PV_LIM_PEDS PV_CAP_PEDS
-#define PV_LIM_LANES PV_CAP_LANES
-#endif
-static_assert(PV_LIM_CARS <= PV_CAP_CARS && PV_LIM_OBST <= PV_CAP_OBST && PV_LIM_PEDS <= PV_CAP_PEDS && PV_LIM_LANES <= PV_CAP_LANES, "limits inside the layout");
-#define PV_DIM (9 + PV_CAP_CARS * 7 + PV_CAP_OBST * 6 + PV_CAP_PEDS * 2 + PV_CAP_LANES * 4 + 4)
-#define PV_OFF_CARS 9
-#define PV_OFF_OBST (9 + PV_CAP_CARS * 7)
-#define PV_OFF_PEDS (PV_OFF_OBST + PV_CAP_OBST * 6)
-#define PV_OFF_LANES (PV_OFF_PEDS + PV_CAP_PEDS * 2)
+#include "driving_host.h" /* PV_CAP_*, PV_LIM_*, PV_DIM, PV_OFF_*: the dense layout, shared with the host code */
 #define SIGHT_NONE 0
 #define SIGHT_NORMAL 3
 #define SIGHT_MISCLASS 4

@@ -1,4 +1,5 @@
-// dynenv_capi.hip — the C ABI of include/dynenv.h on top of the gfx950 kernels (single translation unit).
+// dynenv_capi.hip — the C ABI of include/dynenv.h on top of the gfx950 kernels (this unit: RoboCup + arranger kernels + all host code;
+// driving_tu.hip: the Driving kernels).
 // Host code only does allocation, constant upload and launches.  There is NO CPU fallback: without a usable HIP
 // device every entry point fails with DYNENV_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
@@ -10,9 +11,8 @@
 #include <string>
 #include <vector>
 
-#include "driving_kernels.hip"
+#include "driving_host.h"   /* the Driving kernels are a translation unit of their own: driving_tu.hip */
 #include "robocup_kernels.hip"
-#include "driving_partial.hip"
 #include "arranger_kernels.hip"
 #include "dynenv.h"
 
@@ -117,25 +117,6 @@ static void build_consts(DrvConst& c) {
   }
   c.pedMass = 90.0;  // Pedestrian.py:11-14
   c.pedInertia = 90.0 * (0.5 * (0.0 * 0.0 + 5.0 * 5.0) + 0.0);
-}
-
-// the device code spells the road constants as literals (RoadK<R>): they must equal the computed ones bit for bit
-template <int R>
-static bool road_literals_ok(const DrvRoad& r) {
-  return r.p0.x == RoadK<R>::p0x && r.p0.y == RoadK<R>::p0y && r.dir.x == RoadK<R>::dirx && r.dir.y == RoadK<R>::diry &&
-         (double)r.nLanes * r.width + 5.0 == RoadK<R>::lat && r.length == RoadK<R>::length &&
-         r.dirAngle == RoadK<R>::dirAngle && r.cosDir0 == RoadK<R>::cosDir0 && r.normal.x == RoadK<R>::nx &&
-         r.normal.y == RoadK<R>::ny;
-}
-
-// ... and so are the car-type constants (CarK)
-static bool car_literals_ok(const DrvConst& c) {
-  const double m[4] = {CarK::carMass0, CarK::carMass1, CarK::carMass2, CarK::carMass3}, hx[4] = {CarK::carHx0, CarK::carHx1, CarK::carHx2, CarK::carHx3};
-  const double hy[4] = {CarK::carHy0, CarK::carHy1, CarK::carHy2, CarK::carHy3}, pw[4] = {CarK::carPower0, CarK::carPower1, CarK::carPower2, CarK::carPower3};
-  const double in[4] = {CarK::carInertia0, CarK::carInertia1, CarK::carInertia2, CarK::carInertia3};
-  for (int t = 0; t < 4; ++t)
-    if (c.carMass[t] != m[t] || c.carHx[t] != hx[t] || c.carHy[t] != hy[t] || c.carPower[t] != pw[t] || c.carInertia[t] != in[t]) return false;
-  return c.pedMass == CarK::pedMass && c.pedInertia == CarK::pedInertia;
 }
 
 // ---------------------------------------------------------------------------------------------- helpers
@@ -488,11 +469,11 @@ int dynenv_create(const dynenv_cfg_t* cfg, dynenv_t** out) {
   }
   DrvConst c;
   build_consts(c);
-  if (!road_literals_ok<0>(c.roads[0]) || !road_literals_ok<1>(c.roads[1]) || !car_literals_ok(c)) {
+  if (!drv_literals_ok(c)) {
     dynenv_destroy(h);
     return fail(DYNENV_ERR_HIP, "internal: RoadK / CarK literals differ from the computed constants");
   }
-  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(C), &c, sizeof(c));
+  hipError_t e = drv_upload_consts(c);
   if (e != hipSuccess) { dynenv_destroy(h); return fail(DYNENV_ERR_HIP, hipGetErrorString(e)); }
   *out = h;
   return DYNENV_OK;
@@ -806,11 +787,11 @@ int dynenv_debug_counters(dynenv_t* h, int64_t* out4) {
     out4[15] = h->iso_pauses;  // times the host dropped to the plain launch because the placement kept failing to validate
   }
 #ifdef DRV_PROFILE
-  { unsigned long long d[16]; HIP_OK(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_dbgr), sizeof(d))); FILE* f = fopen("gpurun_out/dbgr.txt", "w"); for (int k = 0; k < 16; ++k) fprintf(f, "%llu\n", d[k]); fclose(f); }
-  { static unsigned long long d[4096 * 12]; HIP_OK(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_dbgw), sizeof(d))); FILE* f = fopen("gpurun_out/dbgw.txt", "w"); for (int k = 0; k < 4096; ++k) { for (int q = 0; q < 12; ++q) fprintf(f, "%llu ", d[12*k+q]); fprintf(f, "\n"); } fclose(f); }
-  { static unsigned long long d[4096 * 8]; HIP_OK(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_dbgp), sizeof(d))); FILE* f = fopen("gpurun_out/dbgp.txt", "w"); for (int k = 0; k < 4096; ++k) { for (int q = 0; q < 8; ++q) fprintf(f, "%llu ", d[8*k+q]); fprintf(f, "\n"); } fclose(f); }
-  { static unsigned long long d[4096 * 8]; HIP_OK(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_dbgs), sizeof(d))); FILE* f = fopen("gpurun_out/dbgs.txt", "w"); for (int k = 0; k < 4096; ++k) { for (int q = 0; q < 8; ++q) fprintf(f, "%llu ", d[8*k+q]); fprintf(f, "\n"); } fclose(f); }
-  { static unsigned long long d[4096 * 8]; HIP_OK(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_dbgl), sizeof(d))); FILE* f = fopen("gpurun_out/dbgl.txt", "w"); for (int k = 0; k < 4096; ++k) { for (int q = 0; q < 8; ++q) fprintf(f, "%llu ", d[8*k+q]); fprintf(f, "\n"); } fclose(f); }
+  { unsigned long long d[16]; HIP_OK(drv_prof_read(0, d, sizeof(d))); FILE* f = fopen("gpurun_out/dbgr.txt", "w"); for (int k = 0; k < 16; ++k) fprintf(f, "%llu\n", d[k]); fclose(f); }
+  { static unsigned long long d[4096 * 12]; HIP_OK(drv_prof_read(1, d, sizeof(d))); FILE* f = fopen("gpurun_out/dbgw.txt", "w"); for (int k = 0; k < 4096; ++k) { for (int q = 0; q < 12; ++q) fprintf(f, "%llu ", d[12*k+q]); fprintf(f, "\n"); } fclose(f); }
+  { static unsigned long long d[4096 * 8]; HIP_OK(drv_prof_read(2, d, sizeof(d))); FILE* f = fopen("gpurun_out/dbgp.txt", "w"); for (int k = 0; k < 4096; ++k) { for (int q = 0; q < 8; ++q) fprintf(f, "%llu ", d[8*k+q]); fprintf(f, "\n"); } fclose(f); }
+  { static unsigned long long d[4096 * 8]; HIP_OK(drv_prof_read(3, d, sizeof(d))); FILE* f = fopen("gpurun_out/dbgs.txt", "w"); for (int k = 0; k < 4096; ++k) { for (int q = 0; q < 8; ++q) fprintf(f, "%llu ", d[8*k+q]); fprintf(f, "\n"); } fclose(f); }
+  { static unsigned long long d[4096 * 8]; HIP_OK(drv_prof_read(4, d, sizeof(d))); FILE* f = fopen("gpurun_out/dbgl.txt", "w"); for (int k = 0; k < 4096; ++k) { for (int q = 0; q < 8; ++q) fprintf(f, "%llu ", d[8*k+q]); fprintf(f, "\n"); } fclose(f); }
 #endif
   return DYNENV_OK;
 }
