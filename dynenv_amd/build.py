@@ -6,12 +6,12 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 LIB = os.path.join(PKG, "libdynenv_hip.so")
 SRC = os.path.join(PKG, "csrc", "dynenv_capi.hip")      # host code + RoboCup + arranger kernels: -O3
-SRC_DRV = os.path.join(PKG, "csrc", "driving_tu.hip")    # the Driving kernels, a translation unit of their own: -O2 (csrc/driving_host.h)
+SRC_DRV = os.path.join(PKG, "csrc", "driving_tu.hip")    # the Driving kernels, a translation unit of their own: -Os (csrc/driving_host.h)
 DEPS = [os.path.join(PKG, "csrc", f) for f in
         ("dynenv_capi.hip", "driving_tu.hip", "driving_kernels.hip", "driving_partial.hip", "robocup_kernels.hip", "robocup_partial.hip",
          "arranger_kernels.hip", "driving_dev.h", "driving_host.h", "robocup_dev.h", "dev_common.h")] + \
        [os.path.join(ROOT, "include", f) for f in ("dynenv.h", "dynenv_math.h")]
-UNITS = ((SRC, ("-O3",)), (SRC_DRV, ("-O2",)))
+UNITS = ((SRC, ("-O3",)), (SRC_DRV, ("-Os",)))
 
 
 def needs_build():

@@ -1,5 +1,5 @@
 // driving_host.h - what the host code (dynenv_capi.hip) needs from the Driving translation unit (driving_tu.hip).
-// The Driving kernels are a translation unit of their own since round 5: they are 1.3-1.7 % faster compiled with -O2 than with -O3
+// The Driving kernels are a translation unit of their own since round 5: they are 1.4-2 % faster compiled with -Os (-O2: 1.3-1.5 %) than with -O3
 // (whole-episode mean at 4096 envs, three interleaved A/Bs: profiles/HISTORY.md "Round 5"), the RoboCup kernels 1.2-2.2 % slower -
 // and a code object of their own also keeps edits to the Driving code away from the RoboCup code's instruction-cache phase.
 #pragma once

@@ -1,5 +1,5 @@
 // driving_tu.hip - the Driving translation unit: the kernels of driving_kernels.hip / driving_partial.hip and the host helpers that
-// need this unit's device symbols.  Compiled with -O2 (dynenv_amd/build.py; driving_host.h says why), linked with dynenv_capi.hip.
+// need this unit's device symbols.  Compiled with -Os (dynenv_amd/build.py; driving_host.h says why), linked with dynenv_capi.hip.
 #include <hip/hip_runtime.h>
 
 #include "driving_kernels.hip"
