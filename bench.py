@@ -674,7 +674,7 @@ def main():
                 out["simd_isolation"] = full["simd_isolation"]
             out["value_full_episode"] = full["value"] if world == 1 else None
             if world == 1 and not robocup and not partial and not args.roofline_only:
-                # the same episode on the plain grid: what the E == 4096-on-256-CUs special case (SIMD isolation) is worth
+                # the same episode on the plain grid: what SIMD isolation (3072 < E <= 4096 on a 256-CU device) is worth
                 noiso = episode_leg(torch, device, args.workload, E, args.seed, n_players=n_players, no_isolation=True)
                 out["value_no_isolation"], out["ms_per_step_no_isolation"] = noiso["value"], noiso["ms_per_step"]
         if world == 1 and not args.no_extra_legs and gather is None:

@@ -111,6 +111,9 @@ struct DrvState {
 #ifndef DRV_ISO_MAX
 #define DRV_ISO_MAX 64   /* at most this many environments get a SIMD of their own (iso_on = 1) */
 #endif
+#ifndef DRV_ISO_MIN_E
+#define DRV_ISO_MIN_E 3072 /* isolation (mode 1) for DRV_ISO_MIN_E < E <= 4096: measured -6.5 % at 4095, -6 % at 4000, -4 % at 3584, -0.8 % at 3072, +0.8 % at 2048 (HISTORY "Round 5") */
+#endif
 #define DRV_ISO_LIST 256 /* capacity of a list; iso_on = 2 (more environments than fit at once) starts up to this many slow ones first */
 #define DRV_ISO_HDR 16    /* header words of DrvState.iso in front of the three lists */
 #define DRV_ISO_WORDS (DRV_ISO_HDR + 3 * DRV_ISO_LIST)

@@ -1637,14 +1637,17 @@ DE_DEV int drv_iso_assign(const DrvState& S, int lane, int tick) {
   int K = uniform_i(S.iso[buf]);
   const int cap = S.iso_on == 1 ? DRV_ISO_MAX : DRV_ISO_LIST;
   K = K < cap ? K : cap;
+  // mode 1: the regular grid is ALWAYS one residency round of the device (G = 4096 blocks, whatever E <= G is: the block -> SIMD
+  // pattern belongs to the grid, not to the environments; blocks beyond the environments end at once), spares and validator behind it
+  const int G = S.iso_on == 1 ? 4 * DRV_ISO_GROUPS : E;
   if (S.iso_on == 1) {
     // Self-validation of the placement isolation relies on (blocks g, g + 1024, g + 2048, g + 3072 of the regular grid on one
     // SIMD, for the groups G0 <= g < G0 + GSPAN it may use): every regular block records where it runs; the LAST spare block of the launch (it steps no environment) checks the
     // record of the previous launch and publishes the verdict for the next one.  Wherever the pattern does not hold - another
     // kernel sharing the device, a partitioned device, a different dispatcher - isolation stays off (K = 0): same results,
     // same bijection, no placeholders holding wave slots for nothing.
-    if (b < E) { if (lane == 0) S.iso_hw[(size_t)(tick & 1) * (4 * DRV_ISO_GROUPS) + b] = drv_hw_simd_key(); }
-    else if (b == E + 3 * DRV_ISO_MAX) {  // (one block behind the spares, for this alone)
+    if (b < G) { if (lane == 0) S.iso_hw[(size_t)(tick & 1) * (4 * DRV_ISO_GROUPS) + b] = drv_hw_simd_key(); }
+    else if (b == G + 3 * DRV_ISO_MAX) {  // (one block behind the spares, for this alone)
       const unsigned* hw = S.iso_hw + (size_t)((tick + 1) & 1) * (4 * DRV_ISO_GROUPS);
       bool bad = false;
       for (int g = DRV_ISO_G0 + lane; g < DRV_ISO_G0 + DRV_ISO_GSPAN; g += 64) {
@@ -1674,10 +1677,10 @@ DE_DEV int drv_iso_assign(const DrvState& S, int lane, int tick) {
     // wherever their id falls in the later residency rounds -, every other environment follows in id order
     if (b < K) return uniform_i(H[b]);
     r = b - K;
-  } else if (b >= E) {
-    const int d = b - E;
+  } else if (b >= G) {
+    const int d = b - G;
     if (d >= 3 * K) return -1;
-    r = (E - 4 * K) + d;
+    r = (G - 4 * K) + d;
   } else {
     const int g = b & (DRV_ISO_GROUPS - 1), pos = b / DRV_ISO_GROUPS;
     if ((unsigned)(g - DRV_ISO_G0) < (unsigned)K) {

@@ -457,7 +457,10 @@ int dynenv_create(const dynenv_cfg_t* cfg, dynenv_t** out) {
       //    too long for the second round: +1.4 %);  2: more environments than fit at once - the slow ones simply start first;
       // 3: Partial observations - nothing is rescheduled, the step's slowest environment is timed all the same: an environment on
       //    the contact path runs as many of its own vision passes as fit before that one is done (drv_step_body)
-      S.iso_on = off || !dev256 ? 0 : (E == 4 * DRV_ISO_GROUPS ? (h->partial ? 0 : 1) : (E > 4 * DRV_ISO_GROUPS ? 2 : 0));
+      // (round 5: mode 1 for every E in (DRV_ISO_MIN_E, 4096], not for E == 4096 alone - the launch is 4096 regular blocks + spares
+      //  whatever E is, and the blocks without an environment end at once; below DRV_ISO_MIN_E a SIMD holds two waves or fewer)
+      const int isoMinE = getenv("DYNENV_ISO_MIN_E") ? atoi(getenv("DYNENV_ISO_MIN_E")) : DRV_ISO_MIN_E;
+      S.iso_on = off || !dev256 ? 0 : ((int)E > isoMinE && E <= 4 * DRV_ISO_GROUPS ? (h->partial ? 0 : 1) : (E > 4 * DRV_ISO_GROUPS ? 2 : 0));
       if (!off && S.iso_on == 0 && h->partial) S.iso_on = 3;
     }
     if (iso_reset(h)) { dynenv_destroy(h); return DYNENV_ERR_HIP; }
@@ -670,7 +673,7 @@ int dynenv_step_head(dynenv_t* h, const int32_t* actions_dev, const double* head
       }
     }
   }
-  const unsigned stepGrid = (unsigned)h->S.E + (h->S.iso_on == 1 ? 3u * DRV_ISO_MAX + 1u /* the placement validator */ : 0u);
+  const unsigned stepGrid = h->S.iso_on == 1 ? 4u * DRV_ISO_GROUPS + 3u * DRV_ISO_MAX + 1u /* one residency round + spares + the placement validator */ : (unsigned)h->S.E;
   if (!h->S.tick_src) h->S.tick = (h->S.tick + 1) % (3 * (1 << 28));  // (wraps at a multiple of 3: the three isolation lists keep rotating in order)
   if (h->partial && obs_dev)
   {

@@ -359,9 +359,10 @@ def test_refresh_obs_and_device_guard(gpu):
     env.close()
 
 
-@pytest.mark.parametrize("E,steps", [(4096, 420), (8192, 300)])
+@pytest.mark.parametrize("E,steps", [(4096, 420), (8192, 300), (4000, 420), (3100, 420)])
 def test_simd_isolation_changes_the_schedule_and_nothing_else(gpu, monkeypatch, E, steps):
-    """Driving on a 256-CU device.  4096 environments: those that were slowest in the previous step get a SIMD of their own;
+    """Driving on a 256-CU device.  3073 .. 4096 environments (round 5: any E in that range, the launch is 4096 regular blocks + spares
+    whatever E is): those that were slowest in the previous step get a SIMD of their own;
     8192: they start first (which block steps which environment).  A handle created with DYNENV_NO_ISOLATION=1
     must produce the same observations, rewards, dones and states, bit for bit, and no placeholder may ever give up waiting."""
     dynenv_amd, torch, _ = gpu
@@ -387,9 +388,9 @@ def test_simd_isolation_changes_the_schedule_and_nothing_else(gpu, monkeypatch, 
     assert seen > 0, "no environment was ever isolated in %d steps" % steps
     c = iso.debug_counters()
     assert c["isolation_timeouts"] == 0
-    if E == 4096:  # one launch at a time on this device: the placement the isolation relies on must have been observed throughout
+    if E <= 4096:  # one launch at a time on this device: the placement the isolation relies on must have been observed throughout
         assert c["isolation_mode"] == 1 and c["placement_validated"] == 1 and c["placement_invalid_launches"] == 0, c
-    for e in (0, 1, 1023, 1024, 2048, 4095, E - 1):
+    for e in (0, 1, 1023, 1024, 2048, min(4095, E - 1), E - 1):
         s1, s2 = iso.get_state(e), ref.get_state(e)
         assert bytes(s1) == bytes(s2), "state of environment %d" % e
     assert iso.error_flags() == 0 and ref.error_flags() == 0

@@ -143,7 +143,7 @@ def test_checkpoint_restore_continues_like_the_oracle(cfg, oracle_built):
     ora.close()
 
 
-@pytest.mark.parametrize("E", [4096, 8192])
+@pytest.mark.parametrize("E", [4096, 8192, 3600])
 def test_checkpoint_restore_with_the_isolation_scheduler_running(E, monkeypatch):
     """the SIMD-isolation lists are scheduling scratch, not state.  Run until environments are being isolated
     (4096) / started first (8192), checkpoint, go on for n = 1, 2, 3 more steps (every phase of the three-list rotation), restore
@@ -186,7 +186,7 @@ def test_checkpoint_restore_with_the_isolation_scheduler_running(E, monkeypatch)
             for h, what in ((iso, "same handle"), (fresh, "fresh handle")):
                 o, r, d = h.step_flat(a, auto_reset=False)
                 assert torch.equal(r, r0) and torch.equal(d, d0) and torch.equal(o, o0), "n=%d, %s, step %d after the restore" % (n, what, j)
-        for e in (0, 1023, 1024, 4095, E - 1):
+        for e in (0, 1023, 1024, min(4095, E - 1), E - 1):
             assert bytes(iso.get_state(e)) == bytes(ref.get_state(e)) == bytes(fresh.get_state(e)), "state of environment %d" % e
     assert iso.debug_counters()["isolation_timeouts"] == 0 and fresh.debug_counters()["isolation_timeouts"] == 0
     for x in (iso, ref, fresh):
