@@ -183,6 +183,18 @@ def test_robocup_scenes_full_state_against_the_oracle():
     assert events(scenes, "begin") > 2 * n and events(scenes, "separate") > n and events(scenes, "retouch") > 100
 
 
+def test_scene_outcomes_do_not_depend_on_the_gjk_warm_start():
+    """Chipmunk starts a pair's GJK from the closest features of its previous step (the collision id cached in the BB-tree pair);
+    kat_general does the same by default.  Started cold in every step the scenes must come out the same (to 1e-9, ill-conditioned
+    scenes aside): the cache is an accelerator, not a semantic."""
+    scenes = driving_scenes(300, 5)
+    dev = np.array([kw.deviation(list(exp[2]), list(kw.driving_expected(sc, warm_gjk=False)[0][2])) for sc, exp, _ in scenes])
+    assert (dev <= 1e-9).mean() >= 0.99 and np.median(dev) < 1e-12, (np.sort(dev)[-5:],)
+    scenes = robocup_scenes(100, 5)
+    dev = np.array([kw.deviation(list(exp[0]), list(kw.robocup_expected(sc, warm_gjk=False)[0][0])) for sc, exp, _ in scenes])
+    assert (dev <= 1e-9).mean() >= 0.95 and np.median(dev) < 1e-12, (np.sort(dev)[-5:],)
+
+
 def test_wrong_readings_of_the_recontact_rule_would_be_caught():
     """Chipmunk keeps a separated pair's arbiter - contacts and accumulated impulses included - for collision_persistence = 3 steps.
     On a re-touch inside that window `begin` fires again, the old impulses ARE carried over by contact id, and
