@@ -45,7 +45,7 @@ CIRCLE, SEGMENT, POLY = 0, 1, 2
 # ------------------------------------------------------------------------------------------------ bodies and shapes
 class Body:
     __slots__ = ("m", "i", "m_inv", "i_inv", "px", "py", "vx", "vy", "a", "w", "vbx", "vby", "wb", "cos", "sin", "fric", "static",
-                 "tag")
+                 "tag", "vel_func", "user")
 
     def __init__(self, m, i, px, py, a=0.0, vx=0.0, vy=0.0, w=0.0, fric=None, tag=None):
         self.static = not (m > 0.0) or math.isinf(m)
@@ -56,6 +56,8 @@ class Body:
         self.cos, self.sin = math.cos(a), math.sin(a)
         self.fric = fric      # None: cpBodyUpdateVelocity (gravity 0, damping 1: nothing); else (friction, rotFriction, spin)
         self.tag = tag
+        self.vel_func = None  # a callable(body, dt) instead of `fric`: the reference's own Python velocity function (tests/golden/gen_golden_contacts.py)
+        self.user = None
 
 
 def moment_for_box(m, hx, hy):
@@ -77,10 +79,11 @@ def moment_for_segment(m, ax, ay, bx, by, r):
 class Shape:
     """kind CIRCLE: r (centre at the body origin); SEGMENT: la, lb (local ends), r; POLY: a box with half extents hx, hy (r = 0)"""
     __slots__ = ("kind", "body", "sid", "e", "u", "ctype", "r", "la", "lb", "ln", "lverts", "lnormals", "tc", "ta", "tb", "tn", "verts",
-                 "normals", "bb")
+                 "normals", "bb", "user")
 
     def __init__(self, kind, body, sid, e=0.0, u=0.0, ctype=0, r=0.0, la=None, lb=None, hx=0.0, hy=0.0):
         self.kind, self.body, self.sid, self.e, self.u, self.ctype, self.r = kind, body, sid, e, u, ctype, r
+        self.user = None
         if kind == SEGMENT:
             self.la, self.lb = la, lb
             dx, dy = lb[0] - la[0], lb[1] - la[1]
@@ -624,7 +627,11 @@ class World:
             j.prestep(dt)
         # velocity functions
         for b in self.bodies:
-            if not b.static and b.fric is not None:
+            if b.static:
+                continue
+            if b.vel_func is not None:
+                b.vel_func(b, dt)
+            elif b.fric is not None:
                 apply_friction(b)
         # cached impulses
         dt_coef = 0.0 if prev_dt == 0.0 else dt / prev_dt

@@ -1,0 +1,58 @@
+"""The HIP path against the trajectories of the reference's OWN `step()` with collisions (tests/golden/gen_golden_contacts.py; see
+tests/test_oracle_golden_contacts.py for what they are and for the tolerances), through the C ABI.  -m gpu."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import test_oracle_golden_contacts as tc
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def gpu(oracle_built):
+    import torch
+    import dynenv_amd
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return dynenv_amd
+
+
+@pytest.mark.parametrize("tag", tc.TAGS)
+def test_reference_driving_step_with_collisions_on_the_hip_path(gpu, tag):
+    z = np.load(os.path.join(G, "driving_contacts.npz"))
+    envs = []
+
+    def make_env(n_players, seed, offset):
+        env = gpu.BatchedDynEnv(gpu.DynEnvType.DRIVE, 1, n_players, seed=seed, env_id_offset=offset)
+        env.reset_flat()
+        envs.append(env)
+
+        def step(a):
+            o, r, d = env.step_flat(a[None], auto_reset=False)
+            return o[0, 0].cpu().numpy(), r[0].cpu().numpy(), int(d[0])
+        return (lambda st: env.set_state(0, st)), step, (lambda: env.get_state(0))
+    tc.check_trajectory(z, tag, make_env)
+    assert envs[0].error_flags() == 0
+    envs[0].close()
+
+
+@pytest.mark.parametrize("tag", tc.RC_TAGS)
+def test_reference_robocup_step_with_collisions_on_the_hip_path(gpu, tag):
+    z = np.load(os.path.join(G, "robocup_contacts.npz"))
+    envs = []
+
+    def make_env(n, seed, offset, flags):
+        env = gpu.BatchedDynEnv(gpu.DynEnvType.ROBO_CUP, 1, n, seed=seed, env_id_offset=offset, flags=flags)
+        env.reset_flat()
+        envs.append(env)
+
+        def step(a):
+            o, r, d = env.step_flat(a[None], auto_reset=False)
+            return o[0].cpu().numpy(), r[0].cpu().numpy(), int(d[0])
+        return (lambda st: env.set_state(0, st)), step, (lambda: env.get_state(0))
+    assert tc.check_robocup_trajectory(z, tag, make_env) >= {"a": 30, "b": 40, "c": 50, "d": 25}[tag]
+    assert envs[0].error_flags() == 0
+    envs[0].close()

@@ -1,0 +1,138 @@
+"""The oracle against trajectories of the reference's OWN `DrivingEnvironment.step()` WITH collisions (tests/golden/gen_golden_contacts.py:
+the reference's Python - processAction, tick, move, carCrash / pedHit / carHit, the friction velocity functions, rewards, getFullState -
+on a functional pymunk facade over tests/kat_general.py, the independent GJK / EPA restatement of Chipmunk).  Unlike the free-flight
+fixtures these contain crashes, pushes, resting contacts and a killed pedestrian: they pin the COMPOSITION of callbacks and physics inside
+a step.  Tolerances: rewards / states 1e-9 (relative to max(1, |value|)), observations 2e-6 (float32), flags and dones exact."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from test_oracle_golden import _state_from_npz
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TAGS = ["a", "b", "c", "d"]
+
+
+def _close(got, want, tol, msg):
+    got, want = np.asarray(got, float), np.asarray(want, float)
+    err = np.abs(got - want) / np.maximum(1.0, np.abs(want))
+    assert err.size == 0 or float(err.max()) <= tol, "%s: deviation %.3e at %s" % (msg, err.max(), np.unravel_index(err.argmax(), err.shape))
+
+
+def check_trajectory(z, tag, make_env):
+    """make_env(n_players, seed, env_id_offset) -> (set_state(st), step(actions [A, 2]) -> (obs [A, D], rewards [A], done), get_state())"""
+    key = z["%s_key" % tag]
+    st0 = _state_from_npz(z, tag, "init", key)
+    set_state, step, get_state = make_env(st0.n_cars, int(key[0]), int(key[1]))
+    set_state(st0)
+    acts, marks = z["%s_actions" % tag], list(z["%s_state_steps" % tag])
+    for s in range(len(acts)):
+        o, r, d = step(acts[s].astype(np.int32))
+        _close(r, z["%s_rewards" % tag][s], 1e-9, "%s: rewards of step %d" % (tag, s))
+        assert int(d) == int(z["%s_dones" % tag][s])
+        np.testing.assert_allclose(o, z["%s_obs" % tag][s], rtol=0, atol=2e-6, err_msg="%s: observation of step %d" % (tag, s))
+        if s in marks:
+            k = marks.index(s)
+            got = ol.state_to_dict(get_state())
+            _close(got["cars_f"], z["%s_states_cars_f" % tag][k], 1e-9, "%s: cars after step %d" % (tag, s))
+            _close(got["peds_f"], z["%s_states_peds_f" % tag][k], 1e-9, "%s: pedestrians after step %d" % (tag, s))
+            np.testing.assert_array_equal(got["cars_i"], z["%s_states_cars_i" % tag][k], err_msg="%s: car flags after step %d" % (tag, s))
+            np.testing.assert_array_equal(got["peds_i"], z["%s_states_peds_i" % tag][k], err_msg="%s: pedestrian flags after step %d" % (tag, s))
+            _close(got["episode_r"], z["%s_states_episode_r" % tag][k], 1e-9, "%s: episode rewards after step %d" % (tag, s))
+            _close(got["episode_pos_r"], z["%s_states_episode_pos_r" % tag][k], 1e-9, "%s: positive episode rewards after step %d" % (tag, s))
+
+
+def test_the_fixtures_contain_what_they_are_for():
+    z = np.load(os.path.join(G, "driving_contacts.npz"))
+    crashed = sum(int(z["%s_states_cars_i" % t][-1][:, 3].sum()) for t in TAGS)      # CAR_I: type team finished crashed lane_pos fric
+    dead = sum(int(z["%s_states_peds_i" % t][-1][:, 2].sum()) for t in TAGS)         # PED_I: road side dead ...
+    begins = sum(int(z["%s_begins_per_step" % t].sum()) for t in TAGS)
+    assert crashed >= 15 and dead >= 2 and begins >= 30, (crashed, dead, begins)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_reference_step_with_collisions_against_the_oracle(oracle_built, tag):
+    z = np.load(os.path.join(G, "driving_contacts.npz"))
+
+    def make_env(n_players, seed, offset):
+        env = ol.OracleEnv(num_envs=1, n_players=n_players, seed=seed, env_id_offset=offset)
+        env.reset()
+
+        def step(a):
+            o, r, d = env.step(a[None])
+            return o[0, 0], r[0], d[0]
+        return (lambda st: env.set_state(0, st)), step, (lambda: env.get_state(0))
+    check_trajectory(z, tag, make_env)
+
+
+# ------------------------------------------------------------------------------------------------ RoboCup
+RC_TAGS = ["a", "b", "c", "d"]
+
+
+def _rc_check_state(st, rf, ri, sc, fl, msg, tol=1e-9):
+    n = int(sc[1])
+    got_f = np.array([[getattr(st.robots[i], k) for k in ol.ROBOT_F] for i in range(n)])
+    got_i = np.array([[getattr(st.robots[i], k) for k in ol.ROBOT_I] for i in range(n)])
+    _close(got_f, rf[:n], tol, msg + ": robot floats")
+    np.testing.assert_array_equal(got_i, ri[:n], err_msg=msg + ": robot flags")
+    assert [st.elapsed, st.ball_owned, st.n_last_kicked] == [int(sc[0]), int(sc[2]), int(sc[3])], msg
+    assert list(st.last_kicked)[:st.n_last_kicked] == [int(x) for x in sc[4:4 + int(sc[3])]], msg + ": lastKicked"
+    assert [st.goals[0], st.goals[1], st.closest[0], st.closest[1]] == [int(x) for x in sc[8:12]], msg + ": goals / closest"
+    assert [st.n_def[0], st.n_def[1]] == [int(sc[12]), int(sc[13])], msg + ": defenders"
+    _close([st.ball_free_cntr, st.grace_period, st.penal_times[0], st.penal_times[1], st.bpx, st.bpy, st.bvx, st.bvy, st.bw, st.bprevx,
+            st.bprevy], fl, tol, msg + ": ball / timers")
+
+
+def check_robocup_trajectory(z, tag, make_env):
+    """make_env(n, seed, offset, flags) -> (set_state(st), step(actions [R, 4]) -> (obs [5, R, D], rewards [R], done), get_state())"""
+    from test_oracle_golden_robocup import _to_state
+    n, can_fall, seed, genv, episode, _, _ = [int(x) for x in z[tag + "_meta"]]
+    flags = (ol.FLAG_CAN_FALL if can_fall else 0) | ol.FLAG_USE_OBS_REWARDS
+    set_state, step, get_state = make_env(n, seed, genv, flags)
+    set_state(_to_state(z[tag + "_b_rf"], z[tag + "_b_ri"], z[tag + "_b_sc"], z[tag + "_b_fl"], episode))
+    acts, marks, R = z[tag + "_actions"], list(z[tag + "_state_steps"]), 2 * n
+    # The fixture carries its own conditioning: at every recorded state, how far a twin of the reference run had drifted whose velocities
+    # got a relative 1e-15 nudge after every step.  RoboCup's contact phases amplify rounding by orders of magnitude now and then (duplicate
+    # end-cap contacts under friction 6.25; profiles/r05_kat_general_fuzz.txt): the tolerance of a window of steps is 1e-9 or 1000 x the
+    # twin's drift at the window's end, and where the twin is off by more than 1e-6 the trajectory pins nothing any more: the check ends.
+    cond = list(z[tag + "_conditioning"])
+    checked = 0
+    for s in range(len(acts)):
+        k = min(i for i, m in enumerate(marks) if m >= s)
+        if cond[k] > 1e-6:
+            break
+        tol = max(1e-9, 1e3 * cond[k])
+        o, r, d = step(acts[s].astype(np.int32))
+        _close(r, z[tag + "_rewards"][s], tol, "%s: rewards of step %d" % (tag, s))
+        assert int(d) == int(z[tag + "_dones"][s])
+        np.testing.assert_allclose(o, z[tag + "_obs"][s][:, :R, :o.shape[-1]], rtol=0, atol=max(2e-6, 10 * tol), err_msg="%s: observation (5 snapshots) of step %d" % (tag, s))
+        if s in marks:
+            _rc_check_state(get_state(), z[tag + "_states_rf"][k], z[tag + "_states_ri"][k], z[tag + "_states_sc"][k], z[tag + "_states_fl"][k],
+                            "%s: state after step %d" % (tag, s), tol)
+        checked = s + 1
+    return checked
+
+
+def test_the_robocup_fixtures_contain_what_they_are_for():
+    z = np.load(os.path.join(G, "robocup_contacts.npz"))
+    begins = sum(z[t + "_begins"] for t in RC_TAGS)     # robot-robot, robot-ball, robot-post, ball-post, own feet
+    assert begins[0] >= 30 and begins[1] >= 3, begins
+    fallen = sum(int(z[t + "_states_ri"][:, :, 5].max(0).sum()) for t in RC_TAGS)   # ROBOT_I[5] = fallen
+    assert fallen >= 2, fallen
+
+
+@pytest.mark.parametrize("tag", RC_TAGS)
+def test_reference_robocup_step_with_collisions_against_the_oracle(oracle_built, tag):
+    z = np.load(os.path.join(G, "robocup_contacts.npz"))
+
+    def make_env(n, seed, offset, flags):
+        env = ol.OracleEnv(env_type=0, num_envs=1, n_players=n, seed=seed, env_id_offset=offset, flags=flags)
+        env.reset()
+
+        def step(a):
+            o, r, d = env.step(a[None])
+            return o[0], r[0], d[0]
+        return (lambda st: env.set_state(0, st)), step, (lambda: env.get_state(0))
+    assert check_robocup_trajectory(z, tag, make_env) >= {"a": 30, "b": 40, "c": 50, "d": 25}[tag]
