@@ -355,7 +355,31 @@ def robocup_sids(env):
     return lambda sh: m[id(sh)]
 
 
-def gen_robocup(out, tag, n, can_fall, steps, seed, forward):
+def setup_kick(env):
+    """robot 0 stands right behind the ball and kicks it with its left foot (joint removed at 500 ms, foot at 150 px/s, RoboCupEnvironment.py:875-912)"""
+    r = env.agents[0]
+    p, ang = r.getPos(), r.leftFoot.body.angle
+    q = p + Vec2d(31.0, 10.0).rotated(ang)
+    env.ball.shape.body.position = q
+    env.ball.prevPos = Vec2d(q.x, q.y)
+    return {0: {0: [0, 0, 1, 3]}, 5: {0: [0, 0, 2, 3]}}
+
+
+def setup_posts(env):
+    """the ball rolls into the lower left goalpost; robot 5 (team -1: the left penalty box is not its own) walks into the upper left one"""
+    b = env.ball.shape.body
+    b.position = Vec2d(150.0, 300.0)
+    b.velocity = Vec2d(-320.0, -30.0)
+    env.ball.prevPos = Vec2d(150.0, 300.0)
+    r = env.agents[5]
+    for foot in (r.leftFoot, r.rightFoot):
+        foot.body.position = Vec2d(118.0, 447.0)
+        foot.body.angle = math.pi
+    r.prevPos = r.getPos()
+    return {s: {5: [3, 0, 0, 3]} for s in range(0, 12)}
+
+
+def gen_robocup(out, tag, n, can_fall, steps, seed, forward, setup=None):
     import gen_golden_robocup as gr
     import gen_golden_robocup_r2 as g2
     import random as pyrandom
@@ -370,6 +394,10 @@ def gen_robocup(out, tag, n, can_fall, steps, seed, forward):
     twin, _, _ = gr.make_env(n, seed, can_fall)
     twin.space.sid_of = robocup_sids(twin)
     twin.space.reindex()
+    forced = {}
+    if setup is not None:
+        forced = setup(env)
+        setup(twin)
     nrng = np.random.RandomState(seed + 1000)
     key = (42, seed, 1)
     dice = RoboDice(key, env)
@@ -384,6 +412,8 @@ def gen_robocup(out, tag, n, can_fall, steps, seed, forward):
             a[fw, 0], a[fw, 1] = 3, 0
             if s % 5 == 4:
                 a[:, 0] = 0; a[:, 1] = 0             # kicks need move == turn == 0
+            for rid, act in forced.get(s, {}).items():
+                a[rid] = act
             rc_mod.random.random = dice
             obs, r, done, info = env.step(a.copy())
             rc_mod.random.random = twin_dice
@@ -436,6 +466,8 @@ def main():
     gen_robocup(out, "b", 5, True, 40, 52, 0.6)
     gen_robocup(out, "c", 3, True, 50, 53, 0.5)
     gen_robocup(out, "d", 5, False, 30, 54, 0.8)
+    gen_robocup(out, "e", 5, False, 12, 55, 0.0, setup_kick)
+    gen_robocup(out, "f", 5, True, 20, 56, 0.2, setup_posts)
     np.savez_compressed(os.path.join(HERE, "robocup_contacts.npz"), **out)
     print("wrote", os.path.join(HERE, "robocup_contacts.npz"))
     out = {}
@@ -443,6 +475,7 @@ def main():
     gen_driving(out, 10, 21, 150, "b", 0.7)
     gen_driving(out, 6, 8, 200, "c", 0.6)
     gen_driving(out, 10, 34, 120, "d", 0.3)
+    gen_driving(out, 2, 13, 250, "e", 0.85)      # BASELINE configs[0]'s player count
     np.savez_compressed(os.path.join(HERE, "driving_contacts.npz"), **out)
     print("wrote", os.path.join(HERE, "driving_contacts.npz"))
 

@@ -53,6 +53,6 @@ def test_reference_robocup_step_with_collisions_on_the_hip_path(gpu, tag):
             o, r, d = env.step_flat(a[None], auto_reset=False)
             return o[0].cpu().numpy(), r[0].cpu().numpy(), int(d[0])
         return (lambda st: env.set_state(0, st)), step, (lambda: env.get_state(0))
-    assert tc.check_robocup_trajectory(z, tag, make_env) >= {"a": 30, "b": 40, "c": 50, "d": 25}[tag]
+    assert tc.check_robocup_trajectory(z, tag, make_env) >= tc.RC_MIN_STEPS[tag]
     assert envs[0].error_flags() == 0
     envs[0].close()

@@ -12,7 +12,7 @@ import oracle_lib as ol
 from test_oracle_golden import _state_from_npz
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-TAGS = ["a", "b", "c", "d"]
+TAGS = ["a", "b", "c", "d", "e"]
 
 
 def _close(got, want, tol, msg):
@@ -68,7 +68,8 @@ def test_reference_step_with_collisions_against_the_oracle(oracle_built, tag):
 
 
 # ------------------------------------------------------------------------------------------------ RoboCup
-RC_TAGS = ["a", "b", "c", "d"]
+RC_TAGS = ["a", "b", "c", "d", "e", "f"]
+RC_MIN_STEPS = {"a": 30, "b": 40, "c": 50, "d": 25, "e": 12, "f": 20}   # steps of each trajectory that are well-conditioned (and checked)
 
 
 def _rc_check_state(st, rf, ri, sc, fl, msg, tol=1e-9):
@@ -118,7 +119,9 @@ def check_robocup_trajectory(z, tag, make_env):
 def test_the_robocup_fixtures_contain_what_they_are_for():
     z = np.load(os.path.join(G, "robocup_contacts.npz"))
     begins = sum(z[t + "_begins"] for t in RC_TAGS)     # robot-robot, robot-ball, robot-post, ball-post, own feet
-    assert begins[0] >= 30 and begins[1] >= 3, begins
+    assert begins[0] >= 30 and begins[1] >= 6 and begins[2] >= 5 and begins[3] >= 1, begins
+    kicking = sum(int(z[t + "_states_ri"][:, :, 7].sum()) for t in RC_TAGS)          # ROBOT_I[7] = kicking (pivot joint removed mid-kick)
+    assert kicking >= 100, kicking
     fallen = sum(int(z[t + "_states_ri"][:, :, 5].max(0).sum()) for t in RC_TAGS)   # ROBOT_I[5] = fallen
     assert fallen >= 2, fallen
 
@@ -135,4 +138,4 @@ def test_reference_robocup_step_with_collisions_against_the_oracle(oracle_built,
             o, r, d = env.step(a[None])
             return o[0], r[0], d[0]
         return (lambda st: env.set_state(0, st)), step, (lambda: env.get_state(0))
-    assert check_robocup_trajectory(z, tag, make_env) >= {"a": 30, "b": 40, "c": 50, "d": 25}[tag]
+    assert check_robocup_trajectory(z, tag, make_env) >= RC_MIN_STEPS[tag]
