@@ -468,6 +468,8 @@ def main():
     gen_robocup(out, "d", 5, False, 30, 54, 0.8)
     gen_robocup(out, "e", 5, False, 12, 55, 0.0, setup_kick)
     gen_robocup(out, "f", 5, True, 20, 56, 0.2, setup_posts)
+    for k, (n, can_fall, steps, seed, fw) in enumerate(((5, True, 40, 61, 0.7), (4, True, 40, 62, 0.5), (5, True, 30, 63, 0.8), (2, True, 60, 64, 0.6))):
+        gen_robocup(out, "ghij"[k], n, can_fall, steps, seed, fw)
     np.savez_compressed(os.path.join(HERE, "robocup_contacts.npz"), **out)
     print("wrote", os.path.join(HERE, "robocup_contacts.npz"))
     out = {}
@@ -476,6 +478,8 @@ def main():
     gen_driving(out, 6, 8, 200, "c", 0.6)
     gen_driving(out, 10, 34, 120, "d", 0.3)
     gen_driving(out, 2, 13, 250, "e", 0.85)      # BASELINE configs[0]'s player count
+    for k, (n, seed, steps, bias) in enumerate(((10, 41, 150, 0.6), (10, 42, 150, 0.4), (8, 43, 150, 0.7), (10, 44, 200, 0.5), (4, 45, 200, 0.8))):
+        gen_driving(out, n, seed, steps, "fghij"[k], bias)
     np.savez_compressed(os.path.join(HERE, "driving_contacts.npz"), **out)
     print("wrote", os.path.join(HERE, "driving_contacts.npz"))
 
