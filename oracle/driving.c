@@ -3,7 +3,8 @@
  * friction/normalisers).  Every function cites the reference lines it follows.  RNG: the reference's serial
  * CPython/NumPy streams are replaced by Philox4x32-10 keyed per (seed, env, episode, purpose, entity, time) —
  * see include/dynenv_math.h and DESIGN.md "RNG".  Game logic is pinned by tests/golden/driving_*.json
- * (generated from the reference's own Python through tools/gen_golden.py); the physics underneath (cp_lite: Chipmunk's Space.step) is PARITY UNPINNED - no pymunk, no vectors - and held by closed-form KATs only. */
+ * (generated from the reference's own Python through tests/golden/gen_golden*.py - incl. whole step() trajectories WITH collisions, gen_golden_contacts.py);
+ * the physics underneath (cp_lite: Chipmunk's Space.step) is PARITY UNPINNED against pymunk itself - see cp_lite.h for what stands behind it. */
 #include "driving.h"
 
 #include <math.h>
