@@ -17,7 +17,7 @@ follow the oracle's slots: cars 0.., pedestrians 10.., obstacles 30.., buildings
 
 RNG: as in gen_golden.py, the reference's `random.*` calls inside `move` are served from the oracle's Philox words.
 
-Usage:  python tests/golden/gen_golden_contacts.py   (writes tests/golden/driving_contacts.npz, robocup_contacts.npz)"""
+Usage:  python tests/golden/gen_golden_contacts.py   (writes tests/golden/driving_contacts.npz, robocup_contacts.npz, driving_partial_contacts.npz)"""
 import math
 import os
 import sys
@@ -459,8 +459,111 @@ def gen_robocup(out, tag, n, can_fall, steps, seed, forward, setup=None):
     print("   conditioning (twin with 1e-15 velocity nudges) at the recorded states:", " ".join("%d:%.0e" % (m, c) for m, c in zip(marks, cond)))
 
 
+# ------------------------------------------------------------------ Driving, Partial observations + Realistic noise 3 (BASELINE configs[3])
+def gen_driving_partial(out, n_players, seed, steps, tag, action_bias, magn=3.0):
+    """the reference's step() with observationType PARTIAL: getAgentVision of every agent inside the step, its noise draws served by
+    source line from the oracle's Philox words exactly as in gen_golden_partial.py (Tape), the pedestrians' draws as in gen_golden.py"""
+    import gen_golden_partial as gp
+    import random as pyrandom
+    de, cut = gg.ref("DrivingEnvironment"), gg.ref("cutils")
+    pyrandom.seed(seed)
+    np.random.seed(seed)
+    env = de.DrivingEnvironment(n_players, render=False, observationType=cut.ObservationType.PARTIAL, noiseType=cut.NoiseType.REALISTIC,
+                                noiseMagnitude=magn)
+    env.space.sid_of = driving_sids(env)
+    pseed, genv, episode = 42, seed, 1
+    ped = gg.PedTape(pseed, genv, episode)
+
+    class Tape(gp.Tape):    # one dispatcher for both kinds of draw sites
+        def _site(self):
+            f = sys._getframe(3)
+            return f.f_code.co_name, f.f_lineno, f
+
+        def random(self):
+            return ped.random() if sys._getframe(1).f_code.co_name == "move" else gp.Tape.random(self)
+
+        def randint(self, lo, hi):
+            return ped.randint(lo, hi) if sys._getframe(1).f_code.co_name == "move" else gp.Tape.randint(self, lo, hi)
+    tape = Tape(pseed, genv, episode)
+    orig_rect, orig_lane, orig_move, orig_vision = cut.addNoiseRect, cut.addNoiseLane, env.move, env.getAgentVision
+
+    def rect(obj, noiseType, interaction, magn_, rand, maxDist, misClass=False):
+        kind = {9: 0, 8: 1, 5: 2, 7: 3}[len(obj)]
+        idx = tape.counters.get(kind, 0)
+        tape.counters[kind] = idx + 1
+        sites = [(0, 0), (0, 1), (0, 2)] + ([(0, 3)] if (misClass and noiseType == cut.NoiseType.REALISTIC) else []) + [(1, 0)]
+        tape.ctx = (kind, idx, iter(sites))
+        try:
+            return orig_rect(obj, noiseType, interaction, magn_, rand, maxDist, misClass)
+        finally:
+            tape.ctx = None
+
+    def lane(obj, noiseType, magn_, rand, maxDist):
+        idx = tape.counters.get(4, 0)
+        tape.counters[4] = idx + 1
+        tape.ctx = (4, idx, iter([(0, 0), (0, 1), (0, 2)]))
+        try:
+            return orig_lane(obj, noiseType, magn_, rand, maxDist)
+        finally:
+            tape.ctx = None
+
+    def move_with_tape(p):
+        ped.arm(env.pedestrians.index(p), env.elapsed)
+        return orig_move(p)
+
+    def vision_with_tape(agent):
+        tape.begin_agent(env.agents.index(agent), env.elapsed)
+        return orig_vision(agent)
+    env.move, env.getAgentVision = move_with_tape, vision_with_tape
+    de.addNoiseRect, de.addNoiseLane = rect, lane
+    de.random.random, de.random.randint = tape.random, tape.randint
+    A = len(env.agents)
+    try:
+        for k, v in gg.dump_state(env, cut).items():
+            out["%s_init_%s" % (tag, k)] = v
+        out["%s_key" % tag] = np.array([pseed, genv, episode], np.int64)
+        arng = np.random.RandomState(seed + 100)
+        acts, rews, dones, obss = [], [], [], []
+        for s in range(steps):
+            a = np.where(arng.rand(A, 2) < action_bias, [2, 1], arng.randint(0, 3, size=(A, 2)))
+            obs, r, d, info = env.step(a)
+            rows = np.zeros((A, gp.DIM), np.float32)
+            for ai, ((cars, obst, peds), (selfr, lanes), _) in enumerate(obs[0]):
+                row = rows[ai]
+                row[0:9] = selfr[0]
+                off = 9
+                for arr, cap, feat in ((cars, 24, 7), (obst, 32, 6), (peds, 40, 2), (lanes, 16, 4)):
+                    m = min(len(arr), cap)
+                    if m:
+                        row[off:off + m * feat] = np.asarray(arr, np.float32).reshape(len(arr), feat)[:m].reshape(-1)
+                    off += cap * feat
+                row[-4:] = [min(len(cars), 24), min(len(obst), 32), min(len(peds), 40), min(len(lanes), 16)]
+            acts.append(a); rews.append(np.array(r, float)); dones.append(int(d)); obss.append(rows)
+        st = gg.dump_state(env, cut)
+    finally:
+        de.addNoiseRect, de.addNoiseLane = orig_rect, orig_lane
+        de.random.random, de.random.randint = gg._ORIG_RANDOM, gg._ORIG_RANDINT
+    out["%s_actions" % tag] = np.array(acts, np.int64)
+    out["%s_rewards" % tag] = np.array(rews)
+    out["%s_dones" % tag] = np.array(dones, np.int64)
+    out["%s_obs" % tag] = np.array(obss, np.float32)
+    out["%s_cfg" % tag] = np.array([n_players, 1, magn], float)
+    for name in ("cars_f", "cars_i", "peds_f", "peds_i", "episode_r", "episode_pos_r"):
+        out["%s_final_%s" % (tag, name)] = st[name]
+    log = env.space.world.log
+    print("%s (Partial + Realistic %g): %d players, %d steps: %d first touches, %d cars crashed, %d pedestrians dead; rows per agent-step: cars %.1f obstacles %.1f pedestrians %.1f lanes %.1f" %
+          ((tag, magn, n_players, steps, sum(1 for e in log if e[1] == "begin"), sum(int(c.crashed) for c in env.agents), sum(int(p.dead) for p in env.pedestrians)) +
+           tuple(np.array(obss)[:, :, -4:].mean((0, 1)))))
+
+
 def main():
     install()
+    out = {}
+    gen_driving_partial(out, 10, 71, 100, "a", 0.6)
+    gen_driving_partial(out, 10, 72, 100, "b", 0.5)
+    gen_driving_partial(out, 6, 73, 120, "c", 0.7)
+    np.savez_compressed(os.path.join(HERE, "driving_partial_contacts.npz"), **out)
+    print("wrote", os.path.join(HERE, "driving_partial_contacts.npz"))
     out = {}
     gen_robocup(out, "a", 5, False, 40, 51, 0.6)
     gen_robocup(out, "b", 5, True, 40, 52, 0.6)

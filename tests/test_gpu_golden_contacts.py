@@ -56,3 +56,24 @@ def test_reference_robocup_step_with_collisions_on_the_hip_path(gpu, tag):
     assert tc.check_robocup_trajectory(z, tag, make_env) >= tc.RC_MIN_STEPS[tag]
     assert envs[0].error_flags() == 0
     envs[0].close()
+
+
+@pytest.mark.parametrize("tag", tc.P_TAGS)
+def test_reference_step_with_partial_observations_and_collisions_on_the_hip_path(gpu, tag):
+    """BASELINE configs[3] as the reference runs it (Partial observations + Realistic noise 3 inside step(), with crashes)"""
+    z = np.load(os.path.join(G, "driving_partial_contacts.npz"))
+    envs = []
+
+    def make_env(n_players, seed, offset, magn):
+        env = gpu.BatchedDynEnv(gpu.DynEnvType.DRIVE, 1, n_players, observationType=gpu.ObservationType.PARTIAL, noiseType=gpu.NoiseType.REALISTIC,
+                                noiseMagnitude=magn, seed=seed, env_id_offset=offset)
+        env.reset_flat()
+        envs.append(env)
+
+        def step(a):
+            o, r, d = env.step_flat(a[None], auto_reset=False)
+            return o[0, 0].cpu().numpy(), r[0].cpu().numpy(), int(d[0])
+        return (lambda st: env.set_state(0, st)), step, (lambda: env.get_state(0))
+    tc.check_partial_trajectory(z, tag, make_env)
+    assert envs[0].error_flags() == 0
+    envs[0].close()

@@ -139,3 +139,49 @@ def test_reference_robocup_step_with_collisions_against_the_oracle(oracle_built,
             return o[0], r[0], d[0]
         return (lambda st: env.set_state(0, st)), step, (lambda: env.get_state(0))
     assert check_robocup_trajectory(z, tag, make_env) >= RC_MIN_STEPS[tag]
+
+
+# ------------------------------------------------------------------------------------------------ Driving, Partial observations (configs[3])
+P_TAGS = ["a", "b", "c"]
+
+
+def check_partial_trajectory(z, tag, make_env):
+    """make_env(n_players, seed, offset, noise_magnitude) -> (set_state, step(actions [A, 2]) -> (obs [A, 517], rewards [A], done), get_state)"""
+    key = z["%s_key" % tag]
+    n_players, _, magn = z["%s_cfg" % tag]
+    st0 = _state_from_npz(z, tag, "init", key)
+    set_state, step, get_state = make_env(int(n_players), int(key[0]), int(key[1]), float(magn))
+    set_state(st0)
+    acts = z["%s_actions" % tag]
+    rows = np.zeros(4)
+    for s in range(len(acts)):
+        o, r, d = step(acts[s].astype(np.int32))
+        _close(r, z["%s_rewards" % tag][s], 1e-9, "%s: rewards of step %d" % (tag, s))
+        assert int(d) == int(z["%s_dones" % tag][s])
+        want = z["%s_obs" % tag][s]
+        np.testing.assert_array_equal(o[:, -4:], want[:, -4:], err_msg="%s: row counts of step %d" % (tag, s))
+        np.testing.assert_allclose(o, want, rtol=0, atol=3e-5, err_msg="%s: Partial observation of step %d" % (tag, s))   # (the tolerance of test_oracle_golden_partial.py)
+        rows += o[:, -4:].sum(0)
+    got = ol.state_to_dict(get_state())
+    _close(got["cars_f"], z["%s_final_cars_f" % tag], 1e-9, tag + ": final cars")
+    _close(got["peds_f"], z["%s_final_peds_f" % tag], 1e-9, tag + ": final pedestrians")
+    np.testing.assert_array_equal(got["cars_i"], z["%s_final_cars_i" % tag])
+    np.testing.assert_array_equal(got["peds_i"], z["%s_final_peds_i" % tag])
+    assert (rows > 50).all(), rows
+
+
+@pytest.mark.parametrize("tag", P_TAGS)
+def test_reference_step_with_partial_observations_and_collisions_against_the_oracle(oracle_built, tag):
+    """BASELINE configs[3] as the reference runs it: `step()` with ObservationType.PARTIAL, NoiseType.REALISTIC, noiseMagnitude 3 -
+    getAgentVision of every agent inside the step, on top of physics with crashes"""
+    z = np.load(os.path.join(G, "driving_partial_contacts.npz"))
+
+    def make_env(n_players, seed, offset, magn):
+        env = ol.OracleEnv(env_type=1, num_envs=1, n_players=n_players, obs_type=1, noise_type=1, noise_magnitude=magn, seed=seed, env_id_offset=offset)
+        env.reset()
+
+        def step(a):
+            o, r, d = env.step(a[None])
+            return o[0, 0], r[0], d[0]
+        return (lambda st: env.set_state(0, st)), step, (lambda: env.get_state(0))
+    check_partial_trajectory(z, tag, make_env)
