@@ -17,7 +17,7 @@ follow the oracle's slots: cars 0.., pedestrians 10.., obstacles 30.., buildings
 
 RNG: as in gen_golden.py, the reference's `random.*` calls inside `move` are served from the oracle's Philox words.
 
-Usage:  python tests/golden/gen_golden_contacts.py   (writes tests/golden/driving_contacts.npz, robocup_contacts.npz, driving_partial_contacts.npz)"""
+Usage:  python tests/golden/gen_golden_contacts.py   (writes tests/golden/driving_contacts.npz, robocup_contacts.npz, driving_partial_contacts.npz, robocup_partial_contacts.npz)"""
 import math
 import os
 import sys
@@ -331,7 +331,9 @@ class RoboDice(object):
         self.key, self.env, self.draws = key, env, 0
 
     def __call__(self):
-        f = sys._getframe(1)
+        return self.draw(sys._getframe(1))
+
+    def draw(self, f):
         line = f.f_lineno
         if line in (557, 565, 577, 932):
             robot = f.f_locals["robot"]
@@ -379,11 +381,93 @@ def setup_posts(env):
     return {s: {5: [3, 0, 0, 3]} for s in range(0, 12)}
 
 
-def gen_robocup(out, tag, n, can_fall, steps, seed, forward, setup=None):
+class _PartialRig(object):
+    """RoboCup with Partial observations: one dispatcher per environment for every random draw of a step - the dice of processAction /
+    tick / robotCollision / goalpostCollision (RoboDice) and the noise draws of getAgentVision / addNoise / addNoiseLine
+    (gen_golden_robocup_partial.Tape, keyed by agent and by the snapshot's `elapsed`)"""
+
+    def __init__(self, env, key, rc_mod, cut):
+        import gen_golden_robocup_partial as grp
+        if grp.SRC is None:
+            grp.SRC = open(rc_mod.__file__).read().split("\n")   # (the draw sites are told apart by their source line's text, as in grp)
+        self.grp, self.env, self.rc_mod, self.cut = grp, env, rc_mod, cut
+        self.dice = RoboDice(key, env)
+        rig = self
+
+        class Tape(grp.Tape):
+            def _frame(self):
+                f = sys._getframe(3)
+                return f.f_code.co_name, f.f_lineno, f
+
+            def random(self):
+                f = sys._getframe(1)
+                if f.f_code.co_name in ("processAction", "tick", "robotCollision", "goalpostCollision"):
+                    return rig.dice.draw(f)
+                return grp.Tape.random(self)
+
+            def randint(self, lo, hi):
+                return grp.Tape.randint(self, lo, hi)
+        self.tape = tape = Tape(*key)
+        self.orig_noise, self.orig_line = cut.addNoise, cut.addNoiseLine
+        orig_vision = env.getAgentVision
+
+        def vision(agent):
+            tape.begin_agent(env.agents.index(agent), int(env.elapsed))
+            return orig_vision(agent)
+        env.getAgentVision = vision
+
+    def noise(self, obj, noiseType, interaction, magn, rand, maxDist, misClass=False, angleNoise=False):
+        n, tape, cut = len(obj), self.tape, self.cut
+        kind = 9 if n == 3 else 0 if n == 4 else 4 if angleNoise else 1 if n == 6 else 3 if misClass else 2
+        idx = tape._nth(("noise", kind))
+        sites = [(0, 0), (0, 1), (0, 2)] + ([(0, 3)] if (misClass and noiseType == cut.NoiseType.REALISTIC) else []) + [(1, 0)] + ([(1, 1)] if angleNoise else [])
+        tape.ctx = (kind, idx, iter(sites))
+        try:
+            return self.orig_noise(obj, noiseType, interaction, magn, rand, maxDist, misClass, angleNoise)
+        finally:
+            tape.ctx = None
+
+    def noise_line(self, obj, noiseType, magn, rand, maxDist):
+        tape = self.tape
+        idx = tape._nth(("noise", 5))
+        tape.ctx = (5, idx, iter([(0, 0), (0, 1), (0, 2), (0, 3), (1, 0)]))
+        try:
+            return self.orig_line(obj, noiseType, magn, rand, maxDist)
+        finally:
+            tape.ctx = None
+
+    def arm(self):
+        m = self.rc_mod
+        m.random.random, m.random.randint = self.tape.random, self.tape.randint
+        m.addNoise, m.addNoiseLine = self.noise, self.noise_line
+
+    def disarm(self):
+        m = self.rc_mod
+        m.random.random, m.random.randint = gg._ORIG_RANDOM, gg._ORIG_RANDINT
+        m.addNoise, m.addNoiseLine = self.orig_noise, self.orig_line
+
+    def pack(self, obs):
+        grp, env = self.grp, self.env
+        return np.array([[grp.pack(env, agent, vis) for agent, vis in zip(env.agents, snap)] for snap in obs])
+
+
+def gen_robocup(out, tag, n, can_fall, steps, seed, forward, setup=None, partial_magn=None):
     import gen_golden_robocup as gr
     import gen_golden_robocup_r2 as g2
     import random as pyrandom
-    env, rc_mod, cut = gr.make_env(n, seed, can_fall)
+    if partial_magn is not None:
+        rc_mod, cut = gg.ref("RoboCupEnvironment"), gg.ref("cutils")
+
+        def make(n_, seed_, can_fall_):
+            pyrandom.seed(seed_); np.random.seed(seed_)
+            rc_mod.RoboCupEnvironment.canFall = can_fall_
+            e = rc_mod.RoboCupEnvironment(n_, render=False, observationType=cut.ObservationType.PARTIAL, noiseType=cut.NoiseType.REALISTIC,
+                                          noiseMagnitude=partial_magn)
+            return e, rc_mod, cut
+        gr_make_env = make
+    else:
+        gr_make_env = gr.make_env
+    env, rc_mod, cut = gr_make_env(n, seed, can_fall)
     env.space.sid_of = robocup_sids(env)
     env.space.reindex()
     # a TWIN of the environment (same scene, same actions, same dice) whose velocities get a relative 1e-15 nudge after every step - what
@@ -391,7 +475,7 @@ def gen_robocup(out, tag, n, can_fall, steps, seed, forward, setup=None):
     # that by orders of magnitude in a few percent of the contact phases (profiles/r05_kat_general_fuzz.txt): where the twin has drifted
     # from the trajectory, the trajectory is not determined to the test's tolerance by ANY implementation, and the fixture says so
     # (`<tag>_conditioning`: twin deviation at every recorded state).
-    twin, _, _ = gr.make_env(n, seed, can_fall)
+    twin, _, _ = gr_make_env(n, seed, can_fall)
     twin.space.sid_of = robocup_sids(twin)
     twin.space.reindex()
     forced = {}
@@ -402,6 +486,10 @@ def gen_robocup(out, tag, n, can_fall, steps, seed, forward, setup=None):
     key = (42, seed, 1)
     dice = RoboDice(key, env)
     twin_dice = RoboDice(key, twin)
+    rig = twin_rig = None
+    if partial_magn is not None:
+        rig, twin_rig = _PartialRig(env, key, rc_mod, cut), _PartialRig(twin, key, rc_mod, cut)
+        dice = rig.dice
     try:
         before = gr.dump(env)
         acts, rews, dones, obss, eps, marks, states, cond = [], [], [], [], [], [], [], []
@@ -414,14 +502,21 @@ def gen_robocup(out, tag, n, can_fall, steps, seed, forward, setup=None):
                 a[:, 0] = 0; a[:, 1] = 0             # kicks need move == turn == 0
             for rid, act in forced.get(s, {}).items():
                 a[rid] = act
-            rc_mod.random.random = dice
+            if rig is None:
+                rc_mod.random.random = dice
+            else:
+                rig.arm()
             obs, r, done, info = env.step(a.copy())
-            rc_mod.random.random = twin_dice
+            if rig is None:
+                rc_mod.random.random = twin_dice
+            else:
+                twin_rig.arm()
             twin.step(a.copy())
             for b in twin.space.bodies:
                 if not b.k.static:
                     b.k.vx *= 1.0 + 1e-15 * nrng.uniform(-1, 1); b.k.vy *= 1.0 + 1e-15 * nrng.uniform(-1, 1); b.k.w *= 1.0 + 1e-15 * nrng.uniform(-1, 1)
-            acts.append(a.astype(np.float64)); rews.append(np.array(r, float)); dones.append(int(done)); obss.append(g2.flat_snapshots(obs, 2 * n))
+            acts.append(a.astype(np.float64)); rews.append(np.array(r, float)); dones.append(int(done))
+            obss.append(g2.flat_snapshots(obs, 2 * n) if rig is None else rig.pack(obs))
             eps.append(np.concatenate([np.array(env.episodeRewards, float), np.array(env.episodePosRewards, float)]))
             if s % 5 == 4 or s == steps - 1:
                 marks.append(s); states.append(gr.dump(env)[:4])
@@ -430,6 +525,8 @@ def gen_robocup(out, tag, n, can_fall, steps, seed, forward, setup=None):
                                 float(np.max(np.abs(t[3] - states[-1][3]) / np.maximum(1.0, np.abs(states[-1][3]))))))
     finally:
         rc_mod.random.random = gg._ORIG_RANDOM
+        if rig is not None:
+            rig.disarm()
         rc_mod.RoboCupEnvironment.canFall = True      # the class default (RoboCupEnvironment.py:20)
     for k, v in zip(("rf", "ri", "sc", "fl"), before[:4]):
         out["%s_b_%s" % (tag, k)] = v
@@ -443,6 +540,8 @@ def gen_robocup(out, tag, n, can_fall, steps, seed, forward, setup=None):
     out[tag + "_obs"] = np.array(obss)
     out[tag + "_episode"] = np.array(eps)
     out[tag + "_meta"] = np.array([n, int(can_fall), key[0], key[1], key[2], 0, 0], np.int64)
+    if partial_magn is not None:
+        out[tag + "_noise"] = np.array([1, partial_magn], float)
     out[tag + "_goals"] = np.array(env.goals, np.int64)
     log = env.space.world.log
     kinds = {}
@@ -564,6 +663,12 @@ def main():
     gen_driving_partial(out, 6, 73, 120, "c", 0.7)
     np.savez_compressed(os.path.join(HERE, "driving_partial_contacts.npz"), **out)
     print("wrote", os.path.join(HERE, "driving_partial_contacts.npz"))
+    out = {}
+    gen_robocup(out, "a", 5, True, 35, 81, 0.8, partial_magn=3.0)
+    gen_robocup(out, "b", 5, False, 20, 82, 0.7, partial_magn=3.0)
+    gen_robocup(out, "c", 3, True, 25, 83, 0.5, partial_magn=3.0)
+    np.savez_compressed(os.path.join(HERE, "robocup_partial_contacts.npz"), **out)
+    print("wrote", os.path.join(HERE, "robocup_partial_contacts.npz"))
     out = {}
     gen_robocup(out, "a", 5, False, 40, 51, 0.6)
     gen_robocup(out, "b", 5, True, 40, 52, 0.6)

@@ -77,3 +77,23 @@ def test_reference_step_with_partial_observations_and_collisions_on_the_hip_path
     tc.check_partial_trajectory(z, tag, make_env)
     assert envs[0].error_flags() == 0
     envs[0].close()
+
+
+@pytest.mark.parametrize("tag", tc.RCP_TAGS)
+def test_reference_robocup_step_with_partial_observations_on_the_hip_path(gpu, tag):
+    z = np.load(os.path.join(G, "robocup_partial_contacts.npz"))
+    envs = []
+
+    def make_env(n, seed, offset, flags, magn):
+        env = gpu.BatchedDynEnv(gpu.DynEnvType.ROBO_CUP, 1, n, observationType=gpu.ObservationType.PARTIAL, noiseType=gpu.NoiseType.REALISTIC,
+                                noiseMagnitude=magn, seed=seed, env_id_offset=offset, flags=flags)
+        env.reset_flat()
+        envs.append(env)
+
+        def step(a):
+            o, r, d = env.step_flat(a[None], auto_reset=False)
+            return o[0].cpu().numpy(), r[0].cpu().numpy(), int(d[0])
+        return (lambda st: env.set_state(0, st)), step, (lambda: env.get_state(0))
+    assert tc.check_robocup_trajectory(z, tag, make_env, partial=True) >= tc.RCP_MIN_STEPS[tag]
+    assert envs[0].error_flags() == 0
+    envs[0].close()

@@ -86,12 +86,15 @@ def _rc_check_state(st, rf, ri, sc, fl, msg, tol=1e-9):
             st.bprevy], fl, tol, msg + ": ball / timers")
 
 
-def check_robocup_trajectory(z, tag, make_env):
-    """make_env(n, seed, offset, flags) -> (set_state(st), step(actions [R, 4]) -> (obs [5, R, D], rewards [R], done), get_state())"""
+RCP_TAIL = 793 - 17   # oracle/robocup_partial.h: the row's last 17 entries are list lengths and the seen tuple (exact)
+
+
+def check_robocup_trajectory(z, tag, make_env, partial=False):
+    """make_env(n, seed, offset, flags[, noise magnitude]) -> (set_state(st), step(actions [R, 4]) -> (obs [5, R, D], rewards [R], done), get_state())"""
     from test_oracle_golden_robocup import _to_state
     n, can_fall, seed, genv, episode, _, _ = [int(x) for x in z[tag + "_meta"]]
     flags = (ol.FLAG_CAN_FALL if can_fall else 0) | ol.FLAG_USE_OBS_REWARDS
-    set_state, step, get_state = make_env(n, seed, genv, flags)
+    set_state, step, get_state = make_env(n, seed, genv, flags, float(z[tag + "_noise"][1])) if partial else make_env(n, seed, genv, flags)
     set_state(_to_state(z[tag + "_b_rf"], z[tag + "_b_ri"], z[tag + "_b_sc"], z[tag + "_b_fl"], episode))
     acts, marks, R = z[tag + "_actions"], list(z[tag + "_state_steps"]), 2 * n
     # The fixture carries its own conditioning: at every recorded state, how far a twin of the reference run had drifted whose velocities
@@ -108,7 +111,12 @@ def check_robocup_trajectory(z, tag, make_env):
         o, r, d = step(acts[s].astype(np.int32))
         _close(r, z[tag + "_rewards"][s], tol, "%s: rewards of step %d" % (tag, s))
         assert int(d) == int(z[tag + "_dones"][s])
-        np.testing.assert_allclose(o, z[tag + "_obs"][s][:, :R, :o.shape[-1]], rtol=0, atol=max(2e-6, 10 * tol), err_msg="%s: observation (5 snapshots) of step %d" % (tag, s))
+        want = z[tag + "_obs"][s][:, :R, :o.shape[-1]]
+        if partial:   # list lengths and the seen tuple exact, rows to float32 accuracy (as tests/test_oracle_golden_robocup_partial.py)
+            np.testing.assert_array_equal(o[..., RCP_TAIL:], want[..., RCP_TAIL:], err_msg="%s: list lengths / seen tuple of step %d" % (tag, s))
+            np.testing.assert_allclose(o[..., :RCP_TAIL], want[..., :RCP_TAIL], rtol=2e-6, atol=max(2e-6, 10 * tol), err_msg="%s: Partial observation of step %d" % (tag, s))
+        else:
+            np.testing.assert_allclose(o, want, rtol=0, atol=max(2e-6, 10 * tol), err_msg="%s: observation (5 snapshots) of step %d" % (tag, s))
         if s in marks:
             _rc_check_state(get_state(), z[tag + "_states_rf"][k], z[tag + "_states_ri"][k], z[tag + "_states_sc"][k], z[tag + "_states_fl"][k],
                             "%s: state after step %d" % (tag, s), tol)
@@ -185,3 +193,24 @@ def test_reference_step_with_partial_observations_and_collisions_against_the_ora
             return o[0, 0], r[0], d[0]
         return (lambda st: env.set_state(0, st)), step, (lambda: env.get_state(0))
     check_partial_trajectory(z, tag, make_env)
+
+
+RCP_TAGS = ["a", "b", "c"]
+RCP_MIN_STEPS = {"a": 25, "b": 20, "c": 25}
+
+
+@pytest.mark.parametrize("tag", RCP_TAGS)
+def test_reference_robocup_step_with_partial_observations_against_the_oracle(oracle_built, tag):
+    """SURVEY section 8 a17 / f3 as the reference runs it: `RoboCupEnvironment.step()` with ObservationType.PARTIAL + Realistic noise 3 -
+    getAgentVision of every agent at the five snapshots inside the step, processSeens' observation rewards folded into the step's rewards"""
+    z = np.load(os.path.join(G, "robocup_partial_contacts.npz"))
+
+    def make_env(n, seed, offset, flags, magn):
+        env = ol.OracleEnv(env_type=0, num_envs=1, n_players=n, obs_type=1, noise_type=1, noise_magnitude=magn, seed=seed, env_id_offset=offset, flags=flags)
+        env.reset()
+
+        def step(a):
+            o, r, d = env.step(a[None])
+            return o[0], r[0], d[0]
+        return (lambda st: env.set_state(0, st)), step, (lambda: env.get_state(0))
+    assert check_robocup_trajectory(z, tag, make_env, partial=True) >= RCP_MIN_STEPS[tag]
