@@ -11,8 +11,17 @@ sys.path.insert(0, ROOT)
 PHI = ["-mllvm", "-phi-node-folding-threshold=12", "-mllvm", "-two-entry-phi-node-folding-threshold=8"]
 VARIANTS = {   # name: {translation unit: flags replacing that unit's own (dynenv_amd/build.py UNITS)}
     "base": {},
-    # an UPPER BOUND, not a build: compiler contraction changes results (digests differ) - what fusing the rest of the arithmetic could give
-    "contract_fast_both": {"driving_tu.hip": ["-Os", "-ffp-contract=fast"], "dynenv_capi.hip": ["-O3", "-ffp-contract=fast"]},
+    "drv_no_misched": {"driving_tu.hip": ["-Os", "-mllvm", "-enable-misched=0"]},
+    "drv_no_post_misched": {"driving_tu.hip": ["-Os", "-mllvm", "-enable-post-misched=0"]},
+    "drv_misched_topdown": {"driving_tu.hip": ["-Os", "-mllvm", "-misched-prera-direction=topdown"]},
+    "drv_misched_bottomup": {"driving_tu.hip": ["-Os", "-mllvm", "-misched-prera-direction=bottomup"]},
+    "drv_vgpr_liverange_off": {"driving_tu.hip": ["-Os", "-mllvm", "-amdgpu-opt-vgpr-liverange=0"]},
+    "drv_metric_bias_100": {"driving_tu.hip": ["-Os", "-mllvm", "-amdgpu-schedule-metric-bias=100"]},
+    "drv_metric_bias_0": {"driving_tu.hip": ["-Os", "-mllvm", "-amdgpu-schedule-metric-bias=0"]},
+    "drv_no_machine_sink": {"driving_tu.hip": ["-Os", "-mllvm", "-disable-machine-sink"]},
+    "rc_no_misched": {"dynenv_capi.hip": ["-O3", "-mllvm", "-enable-misched=0"]},
+    "rc_metric_bias_100": {"dynenv_capi.hip": ["-O3", "-mllvm", "-amdgpu-schedule-metric-bias=100"]},
+    "rc_no_machine_sink": {"dynenv_capi.hip": ["-O3", "-mllvm", "-disable-machine-sink"]},
 }
 
 
