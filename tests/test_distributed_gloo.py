@@ -88,11 +88,13 @@ def _worker(rank, world, port, total_envs, steps, out_dir, pipelined=False, robo
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("pipelined,robocup,transport", [(False, False, "dense"), (True, False, "dense"), (True, False, "compact"),
-                                                         (False, False, "tail"), (True, True, "dense")])
-def test_two_rank_gather_and_shard_invariance(tmp_path, oracle_built, pipelined, robocup, transport):
+@pytest.mark.parametrize("pipelined,robocup,transport,world", [(False, False, "dense", 2), (True, False, "dense", 2), (True, False, "compact", 2),
+                                                               (False, False, "tail", 2), (True, True, "dense", 2),
+                                                               (True, False, "compact", 4), (True, False, "compact", 8)])
+def test_two_rank_gather_and_shard_invariance(tmp_path, oracle_built, pipelined, robocup, transport, world):
+    """world 2 for every transport; world 4 and 8 (the rank counts of the driver's scaling run, rehearsed over gloo) for the one bench.py uses"""
     import torch.multiprocessing as mp
-    total, steps, world = 8, 6, 2
+    total, steps = 8, 6
     port = _free_port()
     mp.spawn(_worker, args=(world, port, total, steps, str(tmp_path), pipelined, robocup, transport), nprocs=world, join=True)
     z = np.load(os.path.join(str(tmp_path), "gathered.npz"))
