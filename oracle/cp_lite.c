@@ -391,6 +391,10 @@ static void closest_seg_seg(cpv p1, cpv q1, cpv p2, cpv q2, cpv* c1, cpv* c2) {
   *c2 = cpvadd(p2, cpvmult(d2, t));
 }
 
+/* diagnostics (tools / tests): capsule pairs whose CORES touched or crossed (closest distance 0: the normal falls back to s1's, where
+ * Chipmunk's EPA would give the minimum-translation axis - DESIGN.md 2b) */
+long cp_lite_cores_cross = 0;
+
 static void segment_to_segment(cpShape* s1, cpShape* s2, cpCollisionInfo* info) {
   cpv a, b, delta, n;
   double dsq, d, mind = s1->r + s2->r;
@@ -399,6 +403,10 @@ static void segment_to_segment(cpShape* s1, cpShape* s2, cpCollisionInfo* info) 
   dsq = cpvlengthsq(delta);
   if (dsq > mind * mind) return;
   d = dm_sqrt(dsq);
+  if (d == 0.0) {
+#pragma omp atomic
+    cp_lite_cores_cross++;
+  }
   n = (d != 0.0 ? cpvmult(delta, 1.0 / d) : s1->tn);
   contact_points(support_edge_segment(s1, n), support_edge_segment(s2, cpvneg(n)), n, info);
 }

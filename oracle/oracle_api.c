@@ -493,3 +493,7 @@ int oracle_space_arbiters(oracle_t* o, int env, double* out, int cap) {
   }
   return s->n_active;
 }
+
+/* how often a capsule pair's cores touched or crossed since the library was loaded (see cp_lite.c) */
+extern long cp_lite_cores_cross;
+long oracle_cp_cores_cross(void) { return cp_lite_cores_cross; }

@@ -195,6 +195,27 @@ def test_scene_outcomes_do_not_depend_on_the_gjk_warm_start():
     assert (dev <= 1e-9).mean() >= 0.95 and np.median(dev) < 1e-12, (np.sort(dev)[-5:],)
 
 
+def test_capsule_cores_never_cross_in_play():
+    """The one catalogued class in which the two restatements differ by MORE than rounding - two capsules 15 px deep, cores crossing: the
+    oracle's closest-point formula has no normal there and takes the first capsule's, Chipmunk's EPA would give the minimum-translation
+    axis - is a class the game does not reach: random play of 256 RoboCup environments over a whole episode (31 M robot-substeps; 246 M in
+    the run recorded in DESIGN.md 2b) never brings two cores together."""
+    import ctypes as C
+    l = ol.lib()
+    l.oracle_cp_cores_cross.restype = C.c_long
+    before = l.oracle_cp_cores_cross()
+    E = 256
+    env = ol.OracleEnv(env_type=0, num_envs=E, n_players=5, seed=42, flags=ol.ROBOCUP_DEFAULT_FLAGS, threads=8)
+    env.reset()
+    rng = np.random.default_rng(0)
+    contacts = 0
+    for s in range(240):
+        env.step_noobs(np.stack([rng.integers(0, k, (E, 10)) for k in (5, 3, 3, 7)], -1).astype(np.int32))
+        contacts += sum(env.active_contacts(e) for e in range(0, E, 16))
+    assert contacts > 50, "the episode must contain contacts"
+    assert l.oracle_cp_cores_cross() == before
+
+
 def test_wrong_readings_of_the_recontact_rule_would_be_caught():
     """Chipmunk keeps a separated pair's arbiter - contacts and accumulated impulses included - for collision_persistence = 3 steps.
     On a re-touch inside that window `begin` fires again, the old impulses ARE carried over by contact id, and
