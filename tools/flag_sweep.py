@@ -9,19 +9,12 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PHI = ["-mllvm", "-phi-node-folding-threshold=12", "-mllvm", "-two-entry-phi-node-folding-threshold=8"]
-VARIANTS = {   # name: {translation unit: flags replacing that unit's own (dynenv_amd/build.py UNITS)}
+VARIANTS = {   # name: {translation unit: flags replacing that unit's own (dynenv_amd/build.py UNITS)}; round 5's sweeps are in profiles/r05_flag_sweep_*.txt
     "base": {},
-    "drv_no_misched": {"driving_tu.hip": ["-Os", "-mllvm", "-enable-misched=0"]},
-    "drv_no_post_misched": {"driving_tu.hip": ["-Os", "-mllvm", "-enable-post-misched=0"]},
-    "drv_misched_topdown": {"driving_tu.hip": ["-Os", "-mllvm", "-misched-prera-direction=topdown"]},
-    "drv_misched_bottomup": {"driving_tu.hip": ["-Os", "-mllvm", "-misched-prera-direction=bottomup"]},
-    "drv_vgpr_liverange_off": {"driving_tu.hip": ["-Os", "-mllvm", "-amdgpu-opt-vgpr-liverange=0"]},
-    "drv_metric_bias_100": {"driving_tu.hip": ["-Os", "-mllvm", "-amdgpu-schedule-metric-bias=100"]},
-    "drv_metric_bias_0": {"driving_tu.hip": ["-Os", "-mllvm", "-amdgpu-schedule-metric-bias=0"]},
-    "drv_no_machine_sink": {"driving_tu.hip": ["-Os", "-mllvm", "-disable-machine-sink"]},
-    "rc_no_misched": {"dynenv_capi.hip": ["-O3", "-mllvm", "-enable-misched=0"]},
-    "rc_metric_bias_100": {"dynenv_capi.hip": ["-O3", "-mllvm", "-amdgpu-schedule-metric-bias=100"]},
-    "rc_no_machine_sink": {"dynenv_capi.hip": ["-O3", "-mllvm", "-disable-machine-sink"]},
+    "drv_O3": {"driving_tu.hip": ["-O3"]},
+    "drv_O2": {"driving_tu.hip": ["-O2"]},
+    "rc_O2": {"dynenv_capi.hip": ["-O2"]},
+    "rc_Os": {"dynenv_capi.hip": ["-Os"]},
 }
 
 
