@@ -5,7 +5,7 @@ import os
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DYNENV_HIP_LIB", os.path.join(PKG, "libdynenv_hip.so"))  # override: A/B builds only
 
-DYNENV_ABI_VERSION = 2
+DYNENV_ABI_VERSION = 3
 ERR_NO_DEVICE = -2
 
 

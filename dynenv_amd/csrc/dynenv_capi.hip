@@ -1128,7 +1128,8 @@ int dynenv_checkpoint_load(dynenv_t* h, const void* buf_host, size_t nbytes) {
   if (nbytes < sizeof(CkptHeader)) return fail(DYNENV_ERR_ARG, "not a checkpoint");
   CkptHeader hd;
   memcpy(&hd, buf_host, sizeof(hd));
-  if (memcmp(hd.magic, "DYNCKPT2", 8) != 0 || hd.abi_version != DYNENV_ABI_VERSION) return fail(DYNENV_ERR_ARG, "not a checkpoint of this ABI version");
+  // (ABI 3 changed no array and no layout: checkpoints written by an ABI 2 library load)
+  if (memcmp(hd.magic, "DYNCKPT2", 8) != 0 || (hd.abi_version != DYNENV_ABI_VERSION && hd.abi_version != 2)) return fail(DYNENV_ERR_ARG, "not a checkpoint of this ABI version");
   const dynenv_cfg_t& a = hd.cfg; const dynenv_cfg_t& b = h->cfg;
   if (a.env_type != b.env_type || a.num_envs != b.num_envs || a.n_players != b.n_players || a.obs_type != b.obs_type ||
       a.noise_type != b.noise_type || a.noise_magnitude != b.noise_magnitude || a.env_id_offset != b.env_id_offset || a.flags != b.flags)

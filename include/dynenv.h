@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DYNENV_ABI_VERSION 2 /* 2: dynenv_debug_counters writes 16 words; checkpoints hold simulation state only */
+#define DYNENV_ABI_VERSION 3 /* 2: dynenv_debug_counters writes 16 words; checkpoints hold simulation state only.  3: dynenv_error_flags - Partial-observation rows dropped moved from bit 1 to its own bit 3; dynenv_step may be stream-captured */
 
 /* DynEnvType / ObservationType / NoiseType values are the reference's (cutils.py:10-51) */
 #define DYNENV_ROBO_CUP 0

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(capi):
     for n in names:
         assert hasattr(lib, n), "libdynenv_hip.so does not export %s declared in include/dynenv.h" % n
     assert set(names) <= set(capi.EXPORTS) | {"dynenv_abi_version", "dynenv_last_error"}
-    assert lib.dynenv_abi_version() == capi.DYNENV_ABI_VERSION == 2
+    assert lib.dynenv_abi_version() == capi.DYNENV_ABI_VERSION == 3
 
 
 def test_struct_sizes_match_the_header(capi):
