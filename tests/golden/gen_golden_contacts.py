@@ -271,7 +271,7 @@ def driving_sids(env):
     return lambda sh: m[id(sh)]
 
 
-def gen_driving(out, n_players, seed, steps, tag, action_bias):
+def gen_driving(out, n_players, seed, steps, tag, action_bias, obs_every=1):
     env, de, cut = gg.make_driving(n_players, seed)
     env.space.sid_of = driving_sids(env)
     pseed, genv, episode = 42, seed, 1
@@ -295,7 +295,12 @@ def gen_driving(out, n_players, seed, steps, tag, action_bias):
         a = np.where(arng.rand(A, 2) < action_bias, [2, 1], arng.randint(0, 3, size=(A, 2)))
         before = len(env.space.world.log)
         obs, r, d, info = env.step(a)
-        acts.append(a); rews.append(np.array(r, float)); dones.append(int(d)); obss.append(gg.flat_obs(env, obs[0], A, dim))
+        acts.append(a); rews.append(np.array(r, float)); dones.append(int(d))
+        if s % obs_every == obs_every - 1 or s == steps - 1:
+            obss.append(gg.flat_obs(env, obs[0], A, dim))
+        if d:
+            out["%s_episode_info" % tag] = np.array([info["episode_r"], info["episode_p_r"], info["episode_o_r"]], float)
+            out["%s_episode_goals" % tag] = np.array(info["episode_g"], float).reshape(-1)
         ncontact.append(sum(1 for ev in env.space.world.log[before:] if ev[1] == "begin"))
         if s % 10 == 9 or s == steps - 1:
             st = gg.dump_state(env, cut)
@@ -304,6 +309,7 @@ def gen_driving(out, n_players, seed, steps, tag, action_bias):
     out["%s_rewards" % tag] = np.array(rews)
     out["%s_dones" % tag] = np.array(dones, np.int64)
     out["%s_obs" % tag] = np.array(obss, np.float32)
+    out["%s_obs_every" % tag] = np.array([obs_every], np.int64)
     out["%s_begins_per_step" % tag] = np.array(ncontact, np.int64)
     out["%s_state_steps" % tag] = np.array([s for s, _ in states], np.int64)
     for name in ("cars_f", "cars_i", "peds_f", "peds_i", "episode_r", "episode_pos_r"):
@@ -688,6 +694,7 @@ def main():
     gen_driving(out, 2, 13, 250, "e", 0.85)      # BASELINE configs[0]'s player count
     for k, (n, seed, steps, bias) in enumerate(((10, 41, 150, 0.6), (10, 42, 150, 0.4), (8, 43, 150, 0.7), (10, 44, 200, 0.5), (4, 45, 200, 0.8))):
         gen_driving(out, n, seed, steps, "fghij"[k], bias)
+    gen_driving(out, 10, 46, 600, "k", 0.5, obs_every=10)     # one WHOLE episode: the terminal step (done, info['episode_*']) included
     np.savez_compressed(os.path.join(HERE, "driving_contacts.npz"), **out)
     print("wrote", os.path.join(HERE, "driving_contacts.npz"))
 

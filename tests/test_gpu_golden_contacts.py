@@ -33,7 +33,11 @@ def test_reference_driving_step_with_collisions_on_the_hip_path(gpu, tag):
         def step(a):
             o, r, d = env.step_flat(a[None], auto_reset=False)
             return o[0, 0].cpu().numpy(), r[0].cpu().numpy(), int(d[0])
-        return (lambda st: env.set_state(0, st)), step, (lambda: env.get_state(0))
+
+        def stats():
+            r, p, o, g = env.episode_stats()
+            return r[0].cpu().numpy(), p[0].cpu().numpy(), o[0].cpu().numpy(), g[0].cpu().numpy()
+        return (lambda st: env.set_state(0, st)), step, (lambda: env.get_state(0)), stats
     tc.check_trajectory(z, tag, make_env)
     assert envs[0].error_flags() == 0
     envs[0].close()

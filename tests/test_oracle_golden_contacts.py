@@ -12,7 +12,7 @@ import oracle_lib as ol
 from test_oracle_golden import _state_from_npz
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-TAGS = list("abcdefghij")
+TAGS = list("abcdefghijk")   # k: one whole episode, terminal step included
 
 
 def _close(got, want, tol, msg):
@@ -25,14 +25,25 @@ def check_trajectory(z, tag, make_env):
     """make_env(n_players, seed, env_id_offset) -> (set_state(st), step(actions [A, 2]) -> (obs [A, D], rewards [A], done), get_state())"""
     key = z["%s_key" % tag]
     st0 = _state_from_npz(z, tag, "init", key)
-    set_state, step, get_state = make_env(st0.n_cars, int(key[0]), int(key[1]))
+    made = make_env(st0.n_cars, int(key[0]), int(key[1]))
+    set_state, step, get_state = made[:3]
     set_state(st0)
     acts, marks = z["%s_actions" % tag], list(z["%s_state_steps" % tag])
+    every = int(z["%s_obs_every" % tag][0]) if "%s_obs_every" % tag in z else 1   # (the whole-episode fixture keeps every 10th observation)
+    n_obs = 0
     for s in range(len(acts)):
         o, r, d = step(acts[s].astype(np.int32))
         _close(r, z["%s_rewards" % tag][s], 1e-9, "%s: rewards of step %d" % (tag, s))
         assert int(d) == int(z["%s_dones" % tag][s])
-        np.testing.assert_allclose(o, z["%s_obs" % tag][s], rtol=0, atol=2e-6, err_msg="%s: observation of step %d" % (tag, s))
+        if s % every == every - 1 or s == len(acts) - 1:
+            np.testing.assert_allclose(o, z["%s_obs" % tag][n_obs], rtol=0, atol=2e-6, err_msg="%s: observation of step %d" % (tag, s))
+            n_obs += 1
+        if int(d):   # the terminal step: info['episode_r'], ['episode_p_r'], ['episode_o_r'], ['episode_g'] (DrivingEnvironment.py:309-316)
+            assert s == len(acts) - 1 == 599 and len(made) == 4
+            er, ep, eo, g = made[3]()
+            want = z["%s_episode_info" % tag]
+            _close(er, want[0], 1e-9, tag + ": episode_r"); _close(ep, want[1], 1e-9, tag + ": episode_p_r"); _close(eo, want[2], 0.0, tag + ": episode_o_r")
+            np.testing.assert_array_equal(np.asarray(g, float), z["%s_episode_goals" % tag])
         if s in marks:
             k = marks.index(s)
             got = ol.state_to_dict(get_state())
@@ -63,7 +74,11 @@ def test_reference_step_with_collisions_against_the_oracle(oracle_built, tag):
         def step(a):
             o, r, d = env.step(a[None])
             return o[0, 0], r[0], d[0]
-        return (lambda st: env.set_state(0, st)), step, (lambda: env.get_state(0))
+
+        def stats():
+            r, p, o, g = env.episode_stats()
+            return r[0], p[0], o[0], g[0]
+        return (lambda st: env.set_state(0, st)), step, (lambda: env.get_state(0)), stats
     check_trajectory(z, tag, make_env)
 
 
