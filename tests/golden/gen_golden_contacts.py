@@ -457,6 +457,16 @@ class _PartialRig(object):
         return np.array([[grp.pack(env, agent, vis) for agent, vis in zip(env.agents, snap)] for snap in obs])
 
 
+def setup_goal(env):
+    """the ball rolls over the left goal line between the posts: a goal (+-25, RoboCupEnvironment.py:640-660), the ball back on the centre spot"""
+    b = env.ball.shape.body
+    b.position = Vec2d(118.0, 418.0)     # past the goalkeeper (who stands at y = 370 +- 25)
+    b.velocity = Vec2d(-290.0, 0.0)
+    env.ball.prevPos = Vec2d(118.0, 418.0)
+    env.ball.lastKicked = [7, 2]
+    return {}
+
+
 def gen_robocup(out, tag, n, can_fall, steps, seed, forward, setup=None, partial_magn=None):
     import gen_golden_robocup as gr
     import gen_golden_robocup_r2 as g2
@@ -684,6 +694,8 @@ def main():
     gen_robocup(out, "f", 5, True, 20, 56, 0.2, setup_posts)
     for k, (n, can_fall, steps, seed, fw) in enumerate(((5, True, 40, 61, 0.7), (4, True, 40, 62, 0.5), (5, True, 30, 63, 0.8), (2, True, 60, 64, 0.6))):
         gen_robocup(out, "ghij"[k], n, can_fall, steps, seed, fw)
+    gen_robocup(out, "k", 5, True, 15, 65, 0.5, setup_goal)
+    assert out["k_goals"].sum() == 1, "case k must score"
     np.savez_compressed(os.path.join(HERE, "robocup_contacts.npz"), **out)
     print("wrote", os.path.join(HERE, "robocup_contacts.npz"))
     out = {}

@@ -83,8 +83,8 @@ def test_reference_step_with_collisions_against_the_oracle(oracle_built, tag):
 
 
 # ------------------------------------------------------------------------------------------------ RoboCup
-RC_TAGS = list("abcdefghij")
-RC_MIN_STEPS = {"a": 30, "b": 40, "c": 50, "d": 25, "e": 12, "f": 20, "g": 25, "h": 40, "i": 30, "j": 60}   # steps of each trajectory that are well-conditioned (and checked)
+RC_TAGS = list("abcdefghijk")
+RC_MIN_STEPS = {"a": 30, "b": 40, "c": 50, "d": 25, "e": 12, "f": 20, "g": 25, "h": 40, "i": 30, "j": 60, "k": 15}   # steps of each trajectory that are well-conditioned (and checked)
 
 
 def _rc_check_state(st, rf, ri, sc, fl, msg, tol=1e-9):
