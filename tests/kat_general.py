@@ -360,6 +360,11 @@ def collide(a, b, cid=0, stats=None):
         if stats is not None and d <= 0.0:
             stats["cores_cross"] = stats.get("cores_cross", 0) + 1  # 15 px deep: the oracle's closest-point formula has no normal there
         cons = _contact_points(_support_edge_segment(a, n[0], n[1]), _support_edge_segment(b, -n[0], -n[1]), n, d)
+        if stats is not None and cons:   # touching capsules that are nearly parallel: their closest points are ill-conditioned (kat_fuzz's class)
+            ex, ey, fx, fy = a.tb[0] - a.ta[0], a.tb[1] - a.ta[1], b.tb[0] - b.ta[0], b.tb[1] - b.ta[1]
+            sn = abs(ex * fy - ey * fx) / (math.hypot(ex, ey) * math.hypot(fx, fy))
+            if sn != 0.0:                # (exactly parallel: both restatements agree, the narrowphase fuzz shows)
+                stats["min_sin_touching_capsules"] = min(stats.get("min_sin_touching_capsules", 1.0), sn)
         return a, b, (n if cons else (0.0, 0.0)), cons, cid
     if ka == POLY and kb == POLY:
         cons = _contact_points(_support_edge_poly(a, n[0], n[1]), _support_edge_poly(b, -n[0], -n[1]), n, d)

@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""The reference's OWN `step()` against the oracle on MANY random trajectories WITH collisions - the population behind the committed
+fixtures of tests/golden/gen_golden_contacts.py (same generator functions, same checks as tests/test_oracle_golden_contacts.py, nothing
+written to disk).  Build container only: it imports /root/reference (with the functional pymunk facade over tests/kat_general.py).
+
+   python3 tools/reference_step_fuzz.py [n_driving] [n_robocup] > profiles/r05_reference_step_fuzz.txt      (1000 300: ~10 min)
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import gen_golden_contacts as gc  # noqa: E402
+import oracle_lib as ol  # noqa: E402
+import test_oracle_golden_contacts as tc  # noqa: E402
+
+
+def driving_env(n_players, seed, offset):
+    env = ol.OracleEnv(num_envs=1, n_players=n_players, seed=seed, env_id_offset=offset)
+    env.reset()
+
+    def step(a):
+        o, r, d = env.step(a[None])
+        return o[0, 0], r[0], d[0]
+    return (lambda st: env.set_state(0, st)), step, (lambda: env.get_state(0))
+
+
+def robocup_env(n, seed, offset, flags):
+    env = ol.OracleEnv(env_type=0, num_envs=1, n_players=n, seed=seed, env_id_offset=offset, flags=flags)
+    env.reset()
+
+    def step(a):
+        o, r, d = env.step(a[None])
+        return o[0], r[0], d[0]
+    return (lambda st: env.set_state(0, st)), step, (lambda: env.get_state(0))
+
+
+def main():
+    n_drv = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    n_rc = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+    ol.build()
+    gc.install()
+    rng = np.random.default_rng(2026)
+    devnull = open(os.devnull, "w")
+    t0 = time.time()
+    steps = touches = crashed = dead = 0
+    failures = []
+    for k in range(n_drv):
+        n, seed, length, bias = int(rng.choice([2, 4, 6, 8, 10, 10, 10])), 1000 + k, int(rng.integers(40, 90)), float(rng.uniform(0.3, 0.9))
+        out = {}
+        stdout, sys.stdout = sys.stdout, devnull
+        try:
+            gc.gen_driving(out, n, seed, length, "t", bias)
+        finally:
+            sys.stdout = stdout
+        try:
+            tc.check_trajectory(out, "t", driving_env)
+        except AssertionError as e:
+            failures.append(("driving", n, seed, length, str(e)[:200]))
+        steps += length
+        touches += int(out["t_begins_per_step"].sum())
+        crashed += int(out["t_states_cars_i"][-1][:, 3].sum())
+        dead += int(out["t_states_peds_i"][-1][:, 2].sum())
+    print("Driving: %d trajectories of the reference's DrivingEnvironment.step() (2-10 players, 40-90 steps each, %d steps; %d first touches, %d cars crashed, "
+          "%d pedestrians killed) against the oracle - rewards / states 1e-9, observations 2e-6, flags exact: %d failures  (%.0f s)"
+          % (n_drv, steps, touches, crashed, dead, len([f for f in failures if f[0] == "driving"]), time.time() - t0))
+    t0 = time.time()
+    steps = checked = 0
+    begins = np.zeros(5, np.int64)
+    for k in range(n_rc):
+        n, can_fall, length, fw = int(rng.choice([2, 3, 4, 5, 5])), bool(rng.random() < 0.6), int(rng.integers(12, 30)), float(rng.uniform(0.4, 0.9))
+        out = {}
+        stdout, sys.stdout = sys.stdout, devnull
+        try:
+            gc.gen_robocup(out, "t", n, can_fall, length, 2000 + k, fw)
+        finally:
+            sys.stdout = stdout
+        try:
+            checked += tc.check_robocup_trajectory(out, "t", robocup_env)
+        except AssertionError as e:
+            failures.append(("robocup", n, 2000 + k, length, str(e)[:200]))
+        steps += length
+        begins += out["t_begins"]
+    print("RoboCup: %d trajectories of the reference's RoboCupEnvironment.step() (2-5 a side, canFall on in ~60 %%, 12-30 steps each, %d steps; first touches "
+          "robot-robot %d, robot-ball %d, robot-post %d, ball-post %d, own feet %d) against the oracle - tolerance 1e-9 or 1000 x the fixture's own conditioning, "
+          "flags exact: %d failures; %d of the %d steps were well-conditioned (twin drift <= 1e-6) and checked  (%.0f s)"
+          % ((n_rc, steps) + tuple(begins) + (len([f for f in failures if f[0] == "robocup"]), checked, steps, time.time() - t0)))
+    for f in failures:
+        print("FAILURE", f)
+    sys.exit(1 if failures else 0)
+
+
+if __name__ == "__main__":
+    main()
