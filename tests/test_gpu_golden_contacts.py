@@ -78,7 +78,7 @@ def test_reference_step_with_partial_observations_and_collisions_on_the_hip_path
             o, r, d = env.step_flat(a[None], auto_reset=False)
             return o[0, 0].cpu().numpy(), r[0].cpu().numpy(), int(d[0])
         return (lambda st: env.set_state(0, st)), step, (lambda: env.get_state(0))
-    tc.check_partial_trajectory(z, tag, make_env)
+    assert (tc.check_partial_trajectory(z, tag, make_env) > 50).all()
     assert envs[0].error_flags() == 0
     envs[0].close()
 

@@ -3,7 +3,7 @@
 fixtures of tests/golden/gen_golden_contacts.py (same generator functions, same checks as tests/test_oracle_golden_contacts.py, nothing
 written to disk).  Build container only: it imports /root/reference (with the functional pymunk facade over tests/kat_general.py).
 
-   python3 tools/reference_step_fuzz.py [n_driving] [n_robocup] > profiles/r05_reference_step_fuzz.txt      (1000 300: ~10 min)
+   python3 tools/reference_step_fuzz.py [n_driving] [n_robocup] [n_driving_partial] [n_robocup_partial] > profiles/r05_reference_step_fuzz.txt      (1000 300: ~10 min)
 """
 import os
 import sys
@@ -31,6 +31,26 @@ def driving_env(n_players, seed, offset):
 
 def robocup_env(n, seed, offset, flags):
     env = ol.OracleEnv(env_type=0, num_envs=1, n_players=n, seed=seed, env_id_offset=offset, flags=flags)
+    env.reset()
+
+    def step(a):
+        o, r, d = env.step(a[None])
+        return o[0], r[0], d[0]
+    return (lambda st: env.set_state(0, st)), step, (lambda: env.get_state(0))
+
+
+def driving_partial_env(n_players, seed, offset, magn):
+    env = ol.OracleEnv(env_type=1, num_envs=1, n_players=n_players, obs_type=1, noise_type=1, noise_magnitude=magn, seed=seed, env_id_offset=offset)
+    env.reset()
+
+    def step(a):
+        o, r, d = env.step(a[None])
+        return o[0, 0], r[0], d[0]
+    return (lambda st: env.set_state(0, st)), step, (lambda: env.get_state(0))
+
+
+def robocup_partial_env(n, seed, offset, flags, magn):
+    env = ol.OracleEnv(env_type=0, num_envs=1, n_players=n, obs_type=1, noise_type=1, noise_magnitude=magn, seed=seed, env_id_offset=offset, flags=flags)
     env.reset()
 
     def step(a):
@@ -89,6 +109,49 @@ def main():
           "robot-robot %d, robot-ball %d, robot-post %d, ball-post %d, own feet %d) against the oracle - tolerance 1e-9 or 1000 x the fixture's own conditioning, "
           "flags exact: %d failures; %d of the %d steps were well-conditioned (twin drift <= 1e-6) and checked  (%.0f s)"
           % ((n_rc, steps) + tuple(begins) + (len([f for f in failures if f[0] == "robocup"]), checked, steps, time.time() - t0)))
+    # Partial observations (BASELINE configs[3]): getAgentVision inside the step, noise draws served by source line
+    n_dp = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    n_rp = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    t0 = time.time()
+    steps, rows = 0, np.zeros(4)
+    for k in range(n_dp):
+        n, seed, length, bias = int(rng.choice([2, 4, 6, 10])), 3000 + k, int(rng.integers(30, 60)), float(rng.uniform(0.3, 0.9))
+        magn = float(rng.choice([0.5, 1.0, 3.0, 5.0]))
+        out = {}
+        stdout, sys.stdout = sys.stdout, devnull
+        try:
+            gc.gen_driving_partial(out, n, seed, length, "t", bias, magn)
+        finally:
+            sys.stdout = stdout
+        try:
+            rows += tc.check_partial_trajectory(out, "t", driving_partial_env)
+        except AssertionError as e:
+            failures.append(("driving_partial", n, seed, length, str(e)[:200]))
+        steps += length
+    if n_dp:
+        print("Driving, Partial observations + Realistic noise (magnitude 0.5 - 5): %d trajectories, %d steps, rows seen (cars, obstacles, pedestrians, lanes) %s - "
+              "rewards / final states 1e-9, observations 3e-5, row counts exact: %d failures  (%.0f s)"
+              % (n_dp, steps, [int(x) for x in rows], len([f for f in failures if f[0] == "driving_partial"]), time.time() - t0))
+    t0 = time.time()
+    steps = checked = 0
+    for k in range(n_rp):
+        n, can_fall, length, fw = int(rng.choice([2, 3, 5])), bool(rng.random() < 0.6), int(rng.integers(10, 25)), float(rng.uniform(0.4, 0.9))
+        magn = float(rng.choice([0.5, 1.0, 3.0, 5.0]))
+        out = {}
+        stdout, sys.stdout = sys.stdout, devnull
+        try:
+            gc.gen_robocup(out, "t", n, can_fall, length, 4000 + k, fw, partial_magn=magn)
+        finally:
+            sys.stdout = stdout
+        try:
+            checked += tc.check_robocup_trajectory(out, "t", robocup_partial_env, partial=True)
+        except AssertionError as e:
+            failures.append(("robocup_partial", n, 4000 + k, length, str(e)[:200]))
+        steps += length
+    if n_rp:
+        print("RoboCup, Partial observations + Realistic noise: %d trajectories, %d steps, %d of them well-conditioned and checked (rewards incl. processSeens, "
+              "five snapshots per step: list lengths / seen tuple exact, rows 2e-6): %d failures  (%.0f s)"
+              % (n_rp, steps, checked, len([f for f in failures if f[0] == "robocup_partial"]), time.time() - t0))
     for f in failures:
         print("FAILURE", f)
     sys.exit(1 if failures else 0)
