@@ -61,6 +61,12 @@ struct __align__(16) DrvLds {
   unsigned char act[16];   // cars: acc | steer << 2 (each 0..2), consumed by the first substep
   int still[DRV_NB];  // bit0: body had exactly zero v, w, v_bias, w_bias when positions were integrated; bit1: frozen
   unsigned short clist[DRV_CLIST];  // contact path: dense list of candidate pair ids in canonical order
+  // What the contact path derives from the STRUCTURE of the contact set alone - which pairs are candidates, which arbiters are active -
+  // is kept from call to call within a launch: a pile that is being relaxed keeps its structure for hundreds of substeps.
+  int clistN;                       // >= 0: clist holds the full list of the current candidate masks (that many pairs); -1: rebuild
+  int sLvMeta;                      // maxLevel & 0xFF | period << 8 of the schedule below
+  unsigned long long sActive;       // active-arbiter mask the cached level schedule was computed for (~0: none)
+  unsigned char sLevel[DRV_NS];     // level of slot s in that schedule
   union {
     DrvMailbox mb;
     DrvObsStage ob;
@@ -1072,14 +1078,18 @@ DRV_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime();)
   // none owns a slot, every remaining pair is unchanged and frozen, so the rest of this function would reproduce the
   // previous substep: return and let the caller replay it.  Otherwise, and in mode 1, process every candidate.
   bool lightOk = false;
+  int savedN = uniform_i(L.clistN);  // (the caller resets it whenever a lane's candidate mask changes)
+  int spair = lane < DRV_NS ? L.s_pair[lane] : -1;  // the slots' pairs, for the slot search below (one load, then v_readlane per occupied slot)
 DRV_PROF(int profCand = 0;)
 #pragma unroll 1
   for (int mode = light ? 0 : 1; mode < 2; ++mode) {
   const int bits = mode == 0 ? dirty : cand;
   bool lightBad = false;
   // ---- compact the pairs (bit i of lane j = pair (i, j)) into one dense list in canonical order, so that the
-  //      narrowphase runs once over up to 64 pairs
+  //      narrowphase runs once over up to 64 pairs.  The full list (mode 1) of unchanged candidate masks is still there.
   int nCand = 0;
+  if (mode == 1 && savedN >= 0) nCand = savedN;
+  else {
   // (straight-line over the ten car bits - `bits` has none at or above A: ten ballots and masked stores, no loop-carried wait)
 #pragma unroll
   for (int i = 0; i < DRV_MAXA; ++i) {
@@ -1091,7 +1101,10 @@ DRV_PROF(int profCand = 0;)
     }
     nCand += __popcll(m);
   }
+  savedN = mode == 1 && nCand <= DRV_CLIST ? nCand : -1;  // (the dirty list of mode 0 overwrites the full one; an overflow is reported by every build)
+  if (lane == 0) L.clistN = savedN;
   if (nCand > DRV_CLIST) nCand = DRV_CLIST;
+  }
 DRV_PROF(profCand += nCand;)
   __syncthreads();
 DRV_PROF(const unsigned long long N1 = __builtin_amdgcn_s_memtime(); unsigned long long nMath = 0ull;)
@@ -1099,7 +1112,7 @@ DRV_PROF(const unsigned long long N1 = __builtin_amdgcn_s_memtime(); unsigned lo
     bool owns = false;
     for (int k = lane; k < nCand; k += 64) {
       const int pr = (int)L.clist[k];
-      for (uint64_t mm = occ; mm; mm &= mm - 1) owns = owns || L.s_pair[__builtin_ctzll(mm)] == pr;
+      for (uint64_t mm = occ; mm; mm &= mm - 1) owns = owns || bcast_i(spair, __builtin_ctzll(mm)) == pr;
     }
     if (wave_ballot(owns) != 0ull) continue;
   }
@@ -1129,11 +1142,12 @@ DRV_PROF(nMath += __builtin_amdgcn_s_memtime();)
     const bool touch = isCand && q == 0 && ct.count > 0;  // lane 0 of the quad speaks for the pair
     // find my slot among the occupied ones
     int slot = -1;
-    if (touch && mode != 0) {
+    if (mode != 0 && wave_ballot(touch) != 0ull) {
       for (uint64_t mm = occ; mm; mm &= mm - 1) {
         int sidx = __builtin_ctzll(mm);
-        if (L.s_pair[sidx] == pr) slot = sidx;
+        if (bcast_i(spair, sidx) == pr) slot = sidx;
       }
+      if (!touch) slot = -1;
     }
     if (mode == 0) { lightBad = lightBad || touch; continue; }
     const uint64_t tmask = wave_ballot(touch);
@@ -1152,6 +1166,7 @@ DRV_PROF(nMath += __builtin_amdgcn_s_memtime();)
       int cnt = __popcll(newMask);
       uint64_t fm2 = (~occ) & slotBits;
       for (int r = 0; r < cnt && fm2; ++r) { occ |= (fm2 & (~fm2 + 1)); fm2 &= fm2 - 1; }
+      spair = lane < DRV_NS ? L.s_pair[lane] : -1;  // (slots were handed out: a later pass must see their pairs)
     }
     if (touch && slot >= 0) {
       M.flag[slot] = needNew ? 3 : 1;
@@ -1228,19 +1243,30 @@ DRV_PROF(const unsigned long long T1 = __builtin_amdgcn_s_memtime();)
 
 DRV_PROF(const unsigned long long U1 = __builtin_amdgcn_s_memtime();)
   // ---- rank touched slots by canonical pair order ------------------------------------------------------
+  // (the rank is needed by the begin callbacks and by the level computation; a call without a first contact whose active set is the
+  //  previous call's needs neither - see the level cache below)
   const uint64_t touchedMask = wave_ballot(touched);
   const int nTouched = __popcll(touchedMask);
+  // the cached schedule's key and values: loads issued here, used after the closure
+  const unsigned long long c_active = L.sActive;
+  const int c_meta = L.sLvMeta;
+  const int c_level = lane < DRV_NS ? (int)L.sLevel[lane] : 0;
   int rank = 0;
-  if (nTouched > 1)  // (a lone touched slot has rank 0)
-    for (uint64_t mm = touchedMask; mm; mm &= mm - 1) {
-      int b = __builtin_ctzll(mm);
-      int pk = bcast_i(a_pair, b);
-      rank += (pk < a_pair) ? 1 : 0;
-    }
+  bool haveRank = false;
+  const bool anyFirst = wave_ballot(touched && a_state == ARB_FIRST) != 0ull;
+  if (anyFirst) {
+    haveRank = true;
+    if (nTouched > 1)  // (a lone touched slot has rank 0)
+      for (uint64_t mm = touchedMask; mm; mm &= mm - 1) {
+        int b = __builtin_ctzll(mm);
+        int pk = bcast_i(a_pair, b);
+        rank += (pk < a_pair) ? 1 : 0;
+      }
+  }
 
 DRV_PROF(const unsigned long long U2 = __builtin_amdgcn_s_memtime();)
   // ---- begin callbacks in canonical order (first contact only) ------------------------------------------
-  if (wave_ballot(touched && a_state == ARB_FIRST) != 0ull)  // (most calls have no first contact: the loop would only skip)
+  if (anyFirst)  // (most calls have no first contact: the loop would only skip)
     for (int k = 0; k < nTouched; ++k) {
       uint64_t who = wave_ballot(touched && rank == k);
       int b = __builtin_ctzll(who);
@@ -1312,8 +1338,24 @@ DRV_PROF(const unsigned long long U4 = __builtin_amdgcn_s_memtime();)
   // arbiters), so the difference to that one (bfirst) is the largest difference this arbiter has with any earlier one.
   int myLevel = 0, maxLevel = -1, period = 1;
   const int nActive = __popcll(activeMask);
+  // The schedule is a function of the active arbiters' pairs alone (canonical order = ascending pair id, levels from shared bodies).
+  // sActive is the active mask of the PREVIOUS full evaluation (every one records its own).  An arbiter that is active in two
+  // consecutive evaluations was touched in both, so its slot was neither freed nor handed out again in between: the same active mask
+  // means the same pairs, and the previous evaluation's schedule is this one's.
+  const bool lvHit = uniform_u64(c_active) == activeMask;
+  if (!lvHit && lane == 0) L.sActive = activeMask;
   if (nActive == 1) maxLevel = 0;  // a lone active arbiter: level 0, nothing shared
-  else if (nActive > 1) {
+  else if (nActive > 1 && lvHit) {
+    myLevel = c_level;
+    maxLevel = (int)(signed char)(uniform_i(c_meta) & 0xFF);
+    period = uniform_i(c_meta) >> 8;
+  } else if (nActive > 1) {
+    if (!haveRank && nTouched > 1)
+      for (uint64_t mm = touchedMask; mm; mm &= mm - 1) {
+        int b = __builtin_ctzll(mm);
+        int pk = bcast_i(a_pair, b);
+        rank += (pk < a_pair) ? 1 : 0;
+      }
     // per body lane: level the next arbiter on this body gets | (level of the first arbiter on it + 1) << 8 (0: none yet) - one
     // v_readlane per body instead of two, and the arbiter's two bodies come over in one
     int bl = 0;
@@ -1333,6 +1375,8 @@ DRV_PROF(const unsigned long long U4 = __builtin_amdgcn_s_memtime();)
       if (lane == ba || lane == bb2) bl = (lv + 1) | (((bl >> 8) ? (bl >> 8) : lv + 1) << 8);  // static indices (>= 30) never equal a body lane (< 30)
       maxLevel = lv > maxLevel ? lv : maxLevel;
     }
+    if (lane < DRV_NS) L.sLevel[lane] = (unsigned char)myLevel;
+    if (lane == 0) L.sLvMeta = (maxLevel & 0xFF) | (period << 8);
   }
 
 DRV_PROF(const unsigned long long T2 = __builtin_amdgcn_s_memtime();)
@@ -1785,6 +1829,7 @@ DRV_PROF(if (lane < 8 && e < 4096) { g_dbgp[e * 8 + lane] = 0ull; g_dbgs[e * 8 +
   // quiescent-shortcut state carried across launches: candidate mask of the previous substep (-1: unknown) and
   // whether every cached arbiter was inert when the contact path last ran
   L.lastCand[lane] = g_lastCand;
+  if (lane == 0) { L.clistN = -1; L.sActive = ~0ull; L.sLvMeta = 0; }
   bool inertAll = (uniform_i(envi[EI_PAD]) & 1) != 0;
   // steady-replay state: the contact path ran (or was replayed) in the previous substep and reported every slot steady
   bool steadyAll = (uniform_i(envi[EI_PAD]) & 2) != 0;
@@ -1811,6 +1856,7 @@ DRV_PROF(const unsigned long long A1 = A0;)
     // update, warm start and all 10 solver iterations are exact no-ops (DESIGN.md "quiescent shortcut") and only the
     // velocity update remains.
     const bool candChanged = wave_ballot((lr.bits & 4) != 0) != 0ull, anyMoving = wave_ballot(candMoving) != 0ull;
+    if (candChanged && lane == 0) L.clistN = -1;  // the contact path's candidate list belongs to other masks now
     const bool quiescent = inertAll && !candChanged && !anyMoving;
     // Steady replay: the contact path of the previous substep reported every slot steady, the candidate set is the
     // same and every body in it is frozen => this substep's contact path would read the same inputs and reproduce the
