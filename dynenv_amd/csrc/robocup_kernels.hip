@@ -76,6 +76,14 @@ struct __align__(16) RcLds {
   int s_pair[RC_NS], s_meta[RC_NS], s_hash0[RC_NS], s_hash1[RC_NS];
   double s_jn0[RC_NS], s_jt0[RC_NS], s_jn1[RC_NS], s_jt1[RC_NS];
   unsigned short candList[128];  // compacted broadphase candidates (pair codes) in canonical order
+  // What rc_physics derives from the STRUCTURE of the contact set alone is kept from call to call within a launch (as in the Driving
+  // contact path): the candidate list while every lane's candidate mask is the one it was built from, the level schedule while the
+  // active-arbiter mask is the previous evaluation's.
+  unsigned char lastCand[64];    // the candidate masks candList was built from (0xFF: none)
+  unsigned char sLevel[RC_NS];   // level of slot s in the cached schedule
+  int candN;                     // entries of candList (-1: not valid)
+  int sMaxLevel;                 // maxLevel of the cached schedule
+  unsigned long long sActive;    // the active mask it belongs to: the previous evaluation's (every evaluation records its own)
   union {
     RcMailbox mb;
     RcArbShare sh;
@@ -1121,6 +1129,7 @@ RC_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime(); unsigned lon
   // --- contact detection / cache -------------------------------------------------------------------------
   bool touched = false, slotOcc = false, freeMe = false, active = false;
   int bodyA = 0, bodyB = 0, a_pair = 0xFFFF, a_state = ARB_FIRST_, a_count = 0, a_age = 0, rank = 0, nTouched = 0;
+  int arank = 0, nActive = 0;  // canonical order among the active arbiters (cached with the levels)
   int myLevel = 0, maxLevel = -1;
   double jn[2] = {0.0, 0.0}, jt[2] = {0.0, 0.0};
   double nMass[2] = {0.0, 0.0}, tMass[2] = {0.0, 0.0}, bias[2] = {0.0, 0.0}, bounce[2] = {0.0, 0.0}, jBias[2] = {0.0, 0.0};
@@ -1135,6 +1144,11 @@ RC_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime(); unsigned lon
     // is not live yet: every lane takes its entries into registers before the mailbox flags are cleared.
     unsigned short* cl = L.candList;
     int nCand = 0;
+    const int prevCand = (int)L.lastCand[lane], savedN = G::uniform_i(L.candN);
+    int spair = lane < RC_NS ? L.s_pair[lane] : -1;  // the slots' pairs for the slot search (one load, then v_readlane per occupied slot)
+    if (lane < RC_NS) M.flag[lane] = 0;
+    if (savedN >= 0 && G::ballot(prevCand != (cand & 0xFF)) == 0ull) nCand = savedN;  // same masks as when the list was built: it is still there
+    else {
     // (straight-line over the five rounds: five ballots, v_mbcnt, masked stores - no loop-carried wait, no branch per round)
 #pragma unroll
     for (int t = 0; t < NROUNDS; ++t) {
@@ -1146,8 +1160,10 @@ RC_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime(); unsigned lon
       }
       nCand += __popcll(m);
     }
+    L.lastCand[lane] = (unsigned char)(cand & 0xFF);
+    if (lane == 0) L.candN = nCand <= 128 ? nCand : -1;  // (an overflow is reported by every build)
     if (nCand > 128) nCand = 128;
-    if (lane < RC_NS) M.flag[lane] = 0;
+    }
     __syncthreads();
 RC_PROF(C0 = __builtin_amdgcn_s_memtime();)
 #pragma unroll 1
@@ -1160,12 +1176,11 @@ RC_PROF(C0 = __builtin_amdgcn_s_memtime();)
       const bool touch = isCand && ct.count > 0;
       if (G::ballot(touch) == 0ull) continue;
       int slot = -1;
-      if (touch) {
-        for (uint64_t mm = occ; mm; mm &= mm - 1) {
-          int sidx = __builtin_ctzll(mm);
-          if (L.s_pair[sidx] == pr) slot = sidx;
-        }
+      for (uint64_t mm = occ; mm; mm &= mm - 1) {
+        int sidx = __builtin_ctzll(mm);
+        if (G::bcast_i(spair, sidx) == pr) slot = sidx;
       }
+      if (!touch) slot = -1;
       const bool needNew = touch && slot < 0;
       const uint64_t newMask = G::ballot(needNew);
       if (newMask) {
@@ -1180,6 +1195,7 @@ RC_PROF(C0 = __builtin_amdgcn_s_memtime();)
         int cnt = __popcll(newMask);
         uint64_t fm2 = (~occ) & slotBits;
         for (int r = 0; r < cnt && fm2; ++r) { occ |= (fm2 & (~fm2 + 1)); fm2 &= fm2 - 1; }
+        spair = lane < RC_NS ? L.s_pair[lane] : -1;  // (slots were handed out: a later pass must see their pairs)
       }
       if (touch && slot >= 0) {
         M.flag[slot] = needNew ? 3 : 1;
@@ -1196,6 +1212,10 @@ RC_PROF(C0 = __builtin_amdgcn_s_memtime();)
     }
     __syncthreads();
 RC_PROF(C1 = __builtin_amdgcn_s_memtime();)
+    // the cached schedule's key and values: loads issued here, used at the levels below
+    const unsigned long long c_active = L.sActive;
+    const int c_maxLevel = L.sMaxLevel;
+    const int c_level = lane < RC_NS ? (int)L.sLevel[lane] : 0;
     // slot lanes: load the cached arbiter, match hashes (cpArbiterUpdate without the r1/r2 part, see below)
     slotOcc = lane < RC_NS && ((occ >> lane) & 1ull);
     int cnt = 0;
@@ -1231,10 +1251,14 @@ RC_PROF(C1 = __builtin_amdgcn_s_memtime();)
 RC_PROF(C2 = __builtin_amdgcn_s_memtime();)
     touchedMask = G::ballot(touched);
     nTouched = __popcll(touchedMask);
-    for (uint64_t mm = touchedMask; mm; mm &= mm - 1) {
-      int b = __builtin_ctzll(mm);
-      int pk = G::bcast_i(a_pair, b);
-      rank += (pk < a_pair) ? 1 : 0;
+    // (the rank - canonical order among the touched arbiters - is needed by the begin callbacks and by a level computation; a call
+    //  without a first contact whose active set is the previous evaluation's needs neither)
+    if (G::ballot(touched && a_state == ARB_FIRST_) != 0ull) {
+      for (uint64_t mm = touchedMask; mm; mm &= mm - 1) {
+        int b = __builtin_ctzll(mm);
+        int pk = G::bcast_i(a_pair, b);
+        rank += (pk < a_pair) ? 1 : 0;
+      }
     }
     // canonical order: r1/r2 relative to the bodies' CURRENT positions (an earlier begin callback may have teleported
     // a robot: ballCollision -> penalize), then the begin callback of first contacts (scalar, lane 0)
@@ -1291,10 +1315,22 @@ RC_PROF(C3 = __builtin_amdgcn_s_memtime();)
     // levels of the active arbiters
     active = touched && a_state != ARB_IGNORE_;
     activeMask = G::ballot(active);
+    // The schedule is a function of the active arbiters' pairs alone.  sActive is the active mask of the PREVIOUS evaluation (every
+    // one records its own; slots only change in evaluations).  An arbiter active in two consecutive evaluations was touched in both,
+    // so its slot was neither freed nor handed out again in between: same mask, same pairs, same schedule.
+    const bool lvHit = G::uniform_u64(c_active) == activeMask;
+    nActive = __popcll(activeMask);
+    if (!lvHit && lane == 0) L.sActive = activeMask;
+    if (lvHit) { myLevel = c_level & 15; arank = c_level >> 4; maxLevel = G::uniform_i(c_maxLevel); }
+    else {
+    for (uint64_t mm = activeMask; mm; mm &= mm - 1) {  // canonical order among the ACTIVE arbiters (ascending pair id)
+      int b = __builtin_ctzll(mm);
+      int pk = G::bcast_i(a_pair, b);
+      arank += (pk < a_pair) ? 1 : 0;
+    }
     int blvl = 0;
-    for (int k = 0; k < nTouched; ++k) {
-      const uint64_t who = G::ballot(active && rank == k);
-      if (who == 0ull) continue;
+    for (int k = 0; k < nActive; ++k) {
+      const uint64_t who = G::ballot(active && arank == k);
       const int b = __builtin_ctzll(who);
       const int ba = G::bcast_i(bodyA, b), bb2 = G::bcast_i(bodyB, b);
       const int la = ba <= RC_BALL ? G::bcast_i(blvl, ba) : 0;
@@ -1303,6 +1339,9 @@ RC_PROF(C3 = __builtin_amdgcn_s_memtime();)
       if (lane == b) myLevel = lv;
       if (lane == ba || lane == bb2) blvl = lv + 1;
       maxLevel = lv > maxLevel ? lv : maxLevel;
+    }
+    if (lane < RC_NS) L.sLevel[lane] = (unsigned char)(myLevel | (arank << 4));  // (RC_NS = 16 slots: both fit four bits)
+    if (lane == 0) L.sMaxLevel = maxLevel;
     }
 RC_PROF(C4 = __builtin_amdgcn_s_memtime();)
     // arbiter prestep
@@ -1519,9 +1558,8 @@ RC_PROF(const unsigned long long T5 = __builtin_amdgcn_s_memtime();)
   if (anyContactWork) {
     double dice0 = 0.0, dice1 = 0.0;
     if (active && c.canFall) rc_post_solve_dice(c, L, a_pair >> 8, a_pair & 0xFF, dice0, dice1);
-    for (int k = 0; k < nTouched; ++k) {
-      const uint64_t who = G::ballot(active && rank == k);
-      if (who == 0ull) continue;
+    for (int k = 0; k < nActive; ++k) {
+      const uint64_t who = G::ballot(active && arank == k);
       const int b = __builtin_ctzll(who);
       const int pk = G::bcast_i(a_pair, b);
       const double d0 = G::bcast_d(dice0, b), d1 = G::bcast_d(dice1, b);
@@ -1816,6 +1854,7 @@ DE_DEV void rc_step_body(const RcState& S, const int e, const int* __restrict__ 
                          double* __restrict__ rewards, uint8_t* __restrict__ dones) {
   typedef Grp<EPW> G;
   constexpr int W = G::W, NROUNDS = (RC_NPAIR_ROUNDS * 64) / W;
+  static_assert(RC_NS <= 16, "sLevel packs level and rank into four bits each");
   static_assert(!PARTIAL || EPW == 1, "the fused Partial observation works on one environment per wave");
   int lane = G::lane();
   const int R = S.R;
@@ -1832,6 +1871,8 @@ DE_DEV void rc_step_body(const RcState& S, const int e, const int* __restrict__ 
   // everybody else reads the word when its physics is done - a million cycles later
   if (PARTIAL && e == 0 && lane == 0) { int* sc = S.deferList + S.E + 1; sc[0] = sc[1]; sc[1] = 0; }
   rc_load_env(S, L, e, lane, occ, W);
+  L.lastCand[lane & 63] = 0xFF;  // rc_physics' call-to-call caches start empty
+  if (lane == 0) { L.candN = -1; L.sActive = ~0ull; L.sMaxLevel = -1; }
   RcCtx c;
   c.seed = S.seed; c.genv = (uint32_t)(S.env_id_offset + e); c.n = S.n; c.R = R;
   c.canFall = (S.flags & DYNENV_FLAG_CAN_FALL) != 0; c.allowHead = (S.flags & DYNENV_FLAG_ALLOW_HEAD_TURN) != 0;
