@@ -75,6 +75,7 @@ struct __align__(16) DrvLds {
 
 // One tile per workgroup (= one wavefront = one environment).  File scope so that the out-of-line contact path
 // addresses it with ds_* instructions instead of flat pointers.
+static_assert(sizeof(DrvLds) <= 10240, "16 one-wave workgroups per CU - one residency round of 4096 environments on 256 CUs - need <= 160 KB / 16 of LDS each");
 __shared__ DrvLds g_L;
 
 

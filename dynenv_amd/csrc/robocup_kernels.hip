@@ -92,6 +92,7 @@ struct __align__(16) RcLds {
   } u;
 };
 // the LDS tile of a wave's environment
+static_assert(sizeof(RcLds) <= 10240, "16 one-wave workgroups per CU - one residency round of 4096 environments on 256 CUs - need <= 160 KB / 16 of LDS each");
 __shared__ RcLds g_R;
 
 // Grp<EPW>: the lanes that serve ONE environment and how they talk to each other.  EPW = 1, the only layout shipped: the whole
@@ -1779,6 +1780,7 @@ DE_OOL RcCommonRet rc_common_substep(RcCtx c_, int serial_, int lane, const uint
       L.px[lane] = npx; L.py[lane] = npy; L.ang[lane] = nang;
       L.vbx[lane] = 0.0; L.vby[lane] = 0.0; L.wb[lane] = 0.0;
       float fcx, fcy, fhx, fhy;
+      double al, ab, ar, at;
       if (lane != RC_BALL) {
         if (!(nang == L.rotAng[lane])) {  // the shape cache's rotation is that of another angle (or, NaN, of an earlier launch)
           const DevSC sc = RC_COMMON_SINCOS(nang);
@@ -1790,12 +1792,12 @@ DE_OOL RcCommonRet rc_common_substep(RcCtx c_, int serial_, int lane, const uint
         double l, r, b, t;
         if (s.ta.x < s.tb.x) { l = s.ta.x; r = s.tb.x; } else { l = s.tb.x; r = s.ta.x; }
         if (s.ta.y < s.tb.y) { b = s.ta.y; t = s.tb.y; } else { b = s.tb.y; t = s.ta.y; }
-        L.aabb[lane][0] = l - FOOT_RADIUS; L.aabb[lane][1] = b - FOOT_RADIUS; L.aabb[lane][2] = r + FOOT_RADIUS; L.aabb[lane][3] = t + FOOT_RADIUS;
+        al = l - FOOT_RADIUS; ab = b - FOOT_RADIUS; ar = r + FOOT_RADIUS; at = t + FOOT_RADIUS;
       } else {
         L.cpx[lane] = npx; L.cpy[lane] = npy;
-        L.aabb[lane][0] = npx - BALL_R; L.aabb[lane][1] = npy - BALL_R; L.aabb[lane][2] = npx + BALL_R; L.aabb[lane][3] = npy + BALL_R;
+        al = npx - BALL_R; ab = npy - BALL_R; ar = npx + BALL_R; at = npy + BALL_R;
       }
-      const double al = L.aabb[lane][0], ab = L.aabb[lane][1], ar = L.aabb[lane][2], at = L.aabb[lane][3];
+      L.aabb[lane][0] = al; L.aabb[lane][1] = ab; L.aabb[lane][2] = ar; L.aabb[lane][3] = at;  // (kept in registers for the prefilter: no read-back)
       fcx = (float)(0.5 * (al + ar)); fcy = (float)(0.5 * (ab + at));
       fhx = (float)(0.5 * (ar - al)) + 1.0f; fhy = (float)(0.5 * (at - ab)) + 1.0f;
       L.u.pf.cx[lane] = fcx; L.u.pf.cy[lane] = fcy; L.u.pf.hx[lane] = fhx; L.u.pf.hy[lane] = fhy;
