@@ -29,3 +29,12 @@ def test_rank7_shard_of_the_8_gpu_configuration(oracle_built):
     a = ol.OracleEnv(num_envs=4, n_players=10, seed=20261003, env_id_offset=28672)
     b = ol.OracleEnv(num_envs=4, n_players=10, seed=20261003, env_id_offset=0)
     assert not np.array_equal(a.reset(), b.reset())
+
+
+def test_all_32768_environments_of_the_8_gpu_configuration_on_one_gpu(oracle_built):
+    """BASELINE configs[4]'s whole population - 32768 Driving environments, the global ids the eight ranks own together - as ONE handle
+    on this box's one GPU (eight residency rounds, the slow environments of the previous step started first: scheduling mode 2), a whole
+    episode, every environment against the oracle.  With the shard-count invariance of tests/test_distributed_gloo.py this is what
+    the eight ranks compute between them."""
+    import soak_parity
+    soak_parity.run("driving", 32768, 20261003)
