@@ -1003,8 +1003,8 @@ int dynenv_arrange_pad(const float* const* emb_dev, const int32_t* counts_dev, c
   const float* e[DYNENV_ARR_MAX_TYPES] = {nullptr, nullptr, nullptr, nullptr};
   for (int i = 0; i < n_types; ++i) e[i] = emb_dev[i];
   const long long perRow = (long long)P * (F / 4);
-  if (perRow > 0x7fffffffLL || (long long)T * max_count > 65535) return fail(DYNENV_ERR_ARG, "arranger: padded tensor too large for one launch");
-  hipLaunchKernelGGL(arr_pad_kernel, dim3((unsigned)((perRow + ARR_BLOCK - 1) / ARR_BLOCK), (unsigned)(T * max_count)), dim3(ARR_BLOCK), 0, (hipStream_t)stream,
+  if (perRow > 0x7fffffffLL || T > 65535) return fail(DYNENV_ERR_ARG, "arranger: padded tensor too large for one launch");
+  hipLaunchKernelGGL(arr_pad_cols_kernel, dim3((unsigned)((perRow + ARR_BLOCK - 1) / ARR_BLOCK), (unsigned)T), dim3(ARR_BLOCK), 0, (hipStream_t)stream,
                      e[0], e[1], e[2], e[3], counts_dev, base_dev, n_types, T, P, max_count, F / 4, reinterpret_cast<float4*>(padded_dev));
   HIP_OK(hipGetLastError());
   return DYNENV_OK;

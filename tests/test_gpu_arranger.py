@@ -32,9 +32,11 @@ def dense_from_ragged(x, feats, caps):
     return o, offs, D
 
 
+@pytest.mark.parametrize("dense_min", ["0", "2"])   # both forms of rearrange_outputs: one pass over the padded tensor / zero fill + scatter
 @pytest.mark.parametrize("name", CASES)
-def test_gpu_arranger_reproduces_reference_vectors(name):
+def test_gpu_arranger_reproduces_reference_vectors(name, dense_min, monkeypatch):
     import torch
+    monkeypatch.setenv("DYNENV_ARR_DENSE_MIN", dense_min)
     from dynenv_amd import GpuInOutArranger, _capi
     x, (E, T, A, nT) = ragged_from_golden(name)
     feats = [int(f) for f in G[name + "/feats"]]
