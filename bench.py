@@ -336,6 +336,43 @@ def plumbing_leg(torch, device, seed):
             "note": "one environment cannot fill a GPU (one wave of 64 lanes): this leg is the plumbing check BASELINE.md asks for"}
 
 
+def arranger_leg(torch, device, E, seed, feat=128, reps=30):
+    """SURVEY section 8 f1, the HBM-bound part of the path: the GPU arranger on real Driving Full observations of E environments -
+    rearrange_inputs (ragged -> per-type rows) and rearrange_outputs (embeddings of width `feat` -> the padded [T, maxCount, P, F]
+    tensor, written once).  Algorithmic bytes as tools/bench_arranger.py counts them; peak 8 TB/s."""
+    from dynenv_amd import BatchedDynEnv, DynEnvType, GpuInOutArranger, groups_for
+    env = BatchedDynEnv(DynEnvType.DRIVE, E, 10, seed=seed, device=device)
+    env.reset_flat()
+    g = torch.Generator(device=device).manual_seed(1)
+    for _ in range(20):
+        obs, _, _ = env.step_flat(torch.randint(0, 3, (E, env.n_agents, 2), generator=g, device=device, dtype=torch.int32), auto_reset=False)
+    obs = obs.contiguous()
+    cnt = env.counts()
+    types = groups_for(env)["movable"]
+    arr = GpuInOutArranger(types, E, env.n_agents, env.n_time_steps, env.obs_dim)
+    inputs, countArr = arr.rearrange_inputs(obs, cnt)
+    outs = [torch.randn((i.shape[0], feat), device=device) for i in inputs]
+    padded, _ = arr.rearrange_outputs(outs, countArr)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    ev[0].record()
+    for _ in range(reps):
+        arr.rearrange_inputs(obs, cnt)
+    ev[1].record()
+    for _ in range(reps):
+        padded, _ = arr.rearrange_outputs(outs, countArr)
+    ev[2].record()
+    torch.cuda.synchronize()
+    ms_in, ms_out = ev[0].elapsed_time(ev[1]) / reps, ev[1].elapsed_time(ev[2]) / reps
+    n_obj = [int(i.shape[0]) for i in inputs]
+    b_out = sum(n_obj) * feat * 4 + padded.numel() * 4
+    env.close()
+    return {"what": "GpuInOutArranger on Driving Full observations (SURVEY 8 f1)", "envs": E, "objects": n_obj, "max_count": int(countArr[1]),
+            "embed_width": feat, "rearrange_inputs_ms": ms_in, "rearrange_outputs_ms": ms_out,
+            "roofline": {"bound": "hbm", "kernel": "arr_pad_cols_kernel", "alg_bytes": b_out, "achieved": b_out / (ms_out * 1e-3) / 1e9,
+                         "peak": 8000.0, "unit": "GB/s", "frac": b_out / (ms_out * 1e-3) / 1e9 / 8000.0}}
+
+
 def launch_ranks(n):
     """Start `python -m torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1 --master-port P bench.py
     <the same arguments>` as a child process; -> its return code.  stdout of the job is rank 0's one JSON line (every rank diverts
@@ -684,6 +721,8 @@ def main():
                 out["throughput_vs_batch"] = [batch_leg(torch, device, e_, k_, args.seed)
                                               for e_, k_ in ((E, 2), (2 * E, 1), (4 * E, 1), (8 * E, 1))]
             out["plumbing_config0"] = plumbing_leg(torch, device, args.seed)
+            if args.workload == "driving":
+                out["arranger"] = arranger_leg(torch, device, E, args.seed)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(E, n_players, A, args.seed, robocup, partial=partial)
             # BASELINE.md section 3 / SURVEY 8d name threads = os.cpu_count(): the same sample with one thread per logical CPU of the box
