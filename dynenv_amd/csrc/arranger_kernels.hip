@@ -288,11 +288,15 @@ __device__ __forceinline__ void obs_unpack_peers_body(const float* __restrict__ 
 //  99 us when a thread keeps its column's indices in registers and walks down the rows - 1 KB bursts 9 KB apart.)
 #define PEER_ROWS_MAXA 16
 #define PEER_ROWS_MAXD (PEER_SELF + (PEER_ROWS_MAXA - 1) * PEER_COLS + 160)
+#define PEER_ROWS_MAXP (PEER_ROWS_MAXA * PEER_SELF + 160 + 8)
+#ifndef PEER_ROWS_BATCH
+#define PEER_ROWS_BATCH 4  /* rows expanded between two barriers (1 x 580 float4 columns over 256 threads leave 24 % of the last pass idle): 64.5 / 62.3 / 61.3 us for 1 / 2 / 4 */
+#endif
 extern "C" __global__ void __launch_bounds__(1024)
 obs_unpack_peers_rows_kernel(const float* __restrict__ packed, long long nET, int A, int D, float* __restrict__ obs, long long srcStride,
                              int rowsPerBlock) {
   __shared__ __align__(8) unsigned short tbl[PEER_ROWS_MAXA * PEER_ROWS_MAXD];
-  __shared__ float stage[2][PEER_ROWS_MAXA * PEER_SELF + 160 + 8];
+  __shared__ float stage[2][PEER_ROWS_BATCH * PEER_ROWS_MAXP];
   const int carsEnd = PEER_SELF + (A - 1) * PEER_COLS;
   const int P = A * PEER_SELF + (D - carsEnd);
   const int rowLen = A * D, nv = rowLen >> 2;
@@ -303,19 +307,24 @@ obs_unpack_peers_rows_kernel(const float* __restrict__ packed, long long nET, in
   float* dstBase = obs + (size_t)blockIdx.y * nET * rowLen;
   int nRows = rowsPerBlock;
   if (et0 + nRows > nET) nRows = (int)(nET - et0);
-  if (nRows > 0)
-    for (int i = tid; i < P; i += nt) stage[0][i] = srcBase[(size_t)et0 * P + i];
+  // (the compacted rows of a block are contiguous in the source: a batch of B rows is B * P consecutive floats)
+  const int first = nRows < PEER_ROWS_BATCH ? nRows : PEER_ROWS_BATCH;
+  for (int i = tid; i < first * P; i += nt) stage[0][(i / P) * PEER_ROWS_MAXP + (i % P)] = srcBase[(size_t)et0 * P + i];
   __syncthreads();
-  for (int e = 0; e < nRows; ++e) {
-    const float* cur = stage[e & 1];
-    if (e + 1 < nRows)  // the next row's compacted floats travel while this one is written out
-      for (int i = tid; i < P; i += nt) stage[(e + 1) & 1][i] = srcBase[(size_t)(et0 + e + 1) * P + i];
+  for (int e = 0, bi = 0; e < nRows; e += PEER_ROWS_BATCH, ++bi) {
+    const float* cur = stage[bi & 1];
+    const int nb = nRows - e < PEER_ROWS_BATCH ? nRows - e : PEER_ROWS_BATCH;
+    const int nn = nRows - (e + PEER_ROWS_BATCH) < PEER_ROWS_BATCH ? nRows - (e + PEER_ROWS_BATCH) : PEER_ROWS_BATCH;
+    if (nn > 0)  // the next batch's compacted floats travel while this one is written out
+      for (int i = tid; i < nn * P; i += nt) stage[(bi + 1) & 1][(i / P) * PEER_ROWS_MAXP + (i % P)] = srcBase[(size_t)(et0 + e + PEER_ROWS_BATCH) * P + i];
     float4* dst = reinterpret_cast<float4*>(dstBase + (size_t)(et0 + e) * rowLen);
-    for (int v = tid; v < nv; v += nt) {
-      const ushort4 ix = reinterpret_cast<const ushort4*>(tbl)[v];
+    for (int v = tid; v < nb * nv; v += nt) {
+      const int r = v >= nv ? v / nv : 0, c = v - r * nv;
+      const ushort4 ix = reinterpret_cast<const ushort4*>(tbl)[c];
+      const float* row = cur + r * PEER_ROWS_MAXP;
       float4 o;
-      o.x = cur[ix.x]; o.y = cur[ix.y]; o.z = cur[ix.z]; o.w = cur[ix.w];
-      dst[v] = o;
+      o.x = row[ix.x]; o.y = row[ix.y]; o.z = row[ix.z]; o.w = row[ix.w];
+      arr_st_nt(dst + v, o);  // (written once, read by somebody else later: non-temporal, 77 -> 65 us for 304 MB)
     }
     __syncthreads();
   }
