@@ -467,7 +467,7 @@ def setup_goal(env):
     return {}
 
 
-def gen_robocup(out, tag, n, can_fall, steps, seed, forward, setup=None, partial_magn=None):
+def gen_robocup(out, tag, n, can_fall, steps, seed, forward, setup=None, partial_magn=None, start_elapsed=None):
     import gen_golden_robocup as gr
     import gen_golden_robocup_r2 as g2
     import random as pyrandom
@@ -500,6 +500,8 @@ def gen_robocup(out, tag, n, can_fall, steps, seed, forward, setup=None, partial
     if setup is not None:
         forced = setup(env)
         setup(twin)
+    if start_elapsed is not None:   # late in the episode: the trajectory ends with the terminal step (`finished`, info['episode_*'] :516-521)
+        env.elapsed = twin.elapsed = int(start_elapsed)
     nrng = np.random.RandomState(seed + 1000)
     twin_space_step = twin.space.step
 
@@ -704,6 +706,7 @@ def main():
     for k, (n, can_fall, steps, seed, fw) in enumerate(((5, True, 40, 61, 0.7), (4, True, 40, 62, 0.5), (5, True, 30, 63, 0.8), (2, True, 60, 64, 0.6))):
         gen_robocup(out, "ghij"[k], n, can_fall, steps, seed, fw)
     gen_robocup(out, "k", 5, True, 15, 65, 0.5, setup_goal)
+    gen_robocup(out, "l", 5, True, 10, 66, 0.6, start_elapsed=12000 - 10 * 50)   # the last ten steps of an episode, terminal step included
     assert out["k_goals"].sum() == 1, "case k must score"
     np.savez_compressed(os.path.join(HERE, "robocup_contacts.npz"), **out)
     print("wrote", os.path.join(HERE, "robocup_contacts.npz"))

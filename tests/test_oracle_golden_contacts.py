@@ -83,8 +83,8 @@ def test_reference_step_with_collisions_against_the_oracle(oracle_built, tag):
 
 
 # ------------------------------------------------------------------------------------------------ RoboCup
-RC_TAGS = list("abcdefghijk")
-RC_MIN_STEPS = {"a": 30, "b": 40, "c": 50, "d": 30, "e": 12, "f": 20, "g": 25, "h": 40, "i": 30, "j": 60, "k": 15}   # steps of each trajectory that are well-conditioned (and checked)
+RC_TAGS = list("abcdefghijkl")   # l: the last ten steps of an episode, terminal step included
+RC_MIN_STEPS = {"a": 30, "b": 40, "c": 50, "d": 30, "e": 12, "f": 20, "g": 25, "h": 40, "i": 30, "j": 60, "k": 15, "l": 10}   # steps of each trajectory that are well-conditioned (and checked)
 
 
 def _rc_check_state(st, rf, ri, sc, fl, msg, tol=1e-9):
@@ -134,14 +134,18 @@ def check_robocup_trajectory(z, tag, make_env, partial=False):
         else:
             np.testing.assert_allclose(o, want, rtol=0, atol=max(2e-6, 10 * tol), err_msg="%s: observation (5 snapshots) of step %d" % (tag, s))
         if s in marks:
-            _rc_check_state(get_state(), z[tag + "_states_rf"][k], z[tag + "_states_ri"][k], z[tag + "_states_sc"][k], z[tag + "_states_fl"][k],
+            st = get_state()
+            _rc_check_state(st, z[tag + "_states_rf"][k], z[tag + "_states_ri"][k], z[tag + "_states_sc"][k], z[tag + "_states_fl"][k],
                             "%s: state after step %d" % (tag, s), tol)
+            # episodeRewards / episodePosRewards (info['episode_r'] / ['episode_p_r'] of the terminal step, RoboCupEnvironment.py:516-521)
+            _close(list(st.episode_r)[:R] + list(st.episode_pos_r)[:R], z[tag + "_episode"][s], max(tol, 1e-9) * (s + 1), "%s: episode sums after step %d" % (tag, s))
         checked = s + 1
     return checked
 
 
 def test_the_robocup_fixtures_contain_what_they_are_for():
     z = np.load(os.path.join(G, "robocup_contacts.npz"))
+    assert list(z["l_dones"]) == [0] * 9 + [1] and int(z["l_states_sc"][-1][0]) == 12000, "fixture l ends with the episode's terminal step"
     begins = sum(z[t + "_begins"] for t in RC_TAGS)     # robot-robot, robot-ball, robot-post, ball-post, own feet
     assert begins[0] >= 30 and begins[1] >= 6 and begins[2] >= 5 and begins[3] >= 1, begins
     kicking = sum(int(z[t + "_states_ri"][:, :, 7].sum()) for t in RC_TAGS)          # ROBOT_I[7] = kicking (pivot joint removed mid-kick)
