@@ -271,9 +271,34 @@ def driving_sids(env):
     return lambda sh: m[id(sh)]
 
 
-def gen_driving(out, n_players, seed, steps, tag, action_bias, obs_every=1):
+def setup_finish(env):
+    """every car 70 px in front of its goal (the end of a road, DrivingEnvironment.py:91), heading for it at 100 px / s, side by side: they
+    leave the road within 100 px of the goal one after the other (tick :399-405: AtGoal, finished, not crashed) and the last one sets
+    allFinished with its team reward (:281-285)"""
+    Vec2d = type(env.agents[0].goal)
+    per_goal = {}
+    for car in env.agents:
+        road = min(env.roads, key=lambda r: min((r.points[0] - car.goal).length, (r.points[1] - car.goal).length))
+        to_end1 = (road.points[1] - car.goal).length < 1e-9
+        u = road.direction if to_end1 else -road.direction
+        k = per_goal.setdefault((car.goal.x, car.goal.y), [])
+        lateral = (len(k) - 1) * 25.0    # -25, 0, 25: inside both roads' width, clear of each other (half widths 5-8)
+        k.append(car)
+        pos = car.goal - u * (70.0 + 3.0 * len(k)) + road.normal * lateral
+        body = car.shape.body
+        body.position = Vec2d(pos.x, pos.y)
+        body.angle = u.angle
+        body.velocity = Vec2d(u.x * 100.0, u.y * 100.0)
+        body.angular_velocity = 0.0
+        car.direction = Vec2d(u.x, u.y)
+        car.prevPos = Vec2d(pos.x, pos.y)
+
+
+def gen_driving(out, n_players, seed, steps, tag, action_bias, obs_every=1, setup=None):
     env, de, cut = gg.make_driving(n_players, seed)
     env.space.sid_of = driving_sids(env)
+    if setup is not None:
+        setup(env)
     pseed, genv, episode = 42, seed, 1
     tape = gg.PedTape(pseed, genv, episode)
     orig_move = env.move
@@ -312,7 +337,7 @@ def gen_driving(out, n_players, seed, steps, tag, action_bias, obs_every=1):
     out["%s_obs_every" % tag] = np.array([obs_every], np.int64)
     out["%s_begins_per_step" % tag] = np.array(ncontact, np.int64)
     out["%s_state_steps" % tag] = np.array([s for s, _ in states], np.int64)
-    for name in ("cars_f", "cars_i", "peds_f", "peds_i", "episode_r", "episode_pos_r"):
+    for name in ("cars_f", "cars_i", "peds_f", "peds_i", "episode_r", "episode_pos_r", "scalars"):
         out["%s_states_%s" % (tag, name)] = np.array([st[name] for _, st in states])
     log = env.space.world.log
     crashed = int(sum(int(c.crashed) for c in env.agents))
@@ -719,6 +744,9 @@ def main():
     for k, (n, seed, steps, bias) in enumerate(((10, 41, 150, 0.6), (10, 42, 150, 0.4), (8, 43, 150, 0.7), (10, 44, 200, 0.5), (4, 45, 200, 0.8))):
         gen_driving(out, n, seed, steps, "fghij"[k], bias)
     gen_driving(out, 10, 46, 600, "k", 0.5, obs_every=10)     # one WHOLE episode: the terminal step (done, info['episode_*']) included
+    gen_driving(out, 3, 91, 16, "l", 1.0, setup=setup_finish)    # every car reaches its goal: allFinished and the team reward (:281-285, :301)
+    gen_driving(out, 3, 96, 16, "m", 1.0, setup=setup_finish)    # the same with four touches on the way
+    gen_driving(out, 3, 93, 16, "n", 1.0, setup=setup_finish)    # ... and with one car that does not make it: no team reward
     np.savez_compressed(os.path.join(HERE, "driving_contacts.npz"), **out)
     print("wrote", os.path.join(HERE, "driving_contacts.npz"))
 

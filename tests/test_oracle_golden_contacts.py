@@ -12,7 +12,7 @@ import oracle_lib as ol
 from test_oracle_golden import _state_from_npz
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-TAGS = list("abcdefghijk")   # k: one whole episode, terminal step included
+TAGS = list("abcdefghijklmn")   # k: one whole episode, terminal step included; l, m: every car reaches its goal (allFinished, team reward); n: all but one
 
 
 def _close(got, want, tol, msg):
@@ -53,6 +53,8 @@ def check_trajectory(z, tag, make_env):
             np.testing.assert_array_equal(got["peds_i"], z["%s_states_peds_i" % tag][k], err_msg="%s: pedestrian flags after step %d" % (tag, s))
             _close(got["episode_r"], z["%s_states_episode_r" % tag][k], 1e-9, "%s: episode rewards after step %d" % (tag, s))
             _close(got["episode_pos_r"], z["%s_states_episode_pos_r" % tag][k], 1e-9, "%s: positive episode rewards after step %d" % (tag, s))
+            if "%s_states_scalars" % tag in z:   # elapsed, allFinished
+                np.testing.assert_array_equal(got["scalars"][:2], z["%s_states_scalars" % tag][k], err_msg="%s: elapsed / allFinished after step %d" % (tag, s))
 
 
 def test_the_fixtures_contain_what_they_are_for():
@@ -61,6 +63,12 @@ def test_the_fixtures_contain_what_they_are_for():
     dead = sum(int(z["%s_states_peds_i" % t][-1][:, 2].sum()) for t in TAGS)         # PED_I: road side dead ...
     begins = sum(int(z["%s_begins_per_step" % t].sum()) for t in TAGS)
     assert crashed >= 15 and dead >= 2 and begins >= 30, (crashed, dead, begins)
+    # l, m: all three cars finished without a crash, allFinished set, and the step in which the last one arrived carries the team reward
+    # (maxTime - elapsed) / 100 ~ 59 for every car (DrivingEnvironment.py:281-285, :301); n: one car short, no such step
+    for t in "lm":
+        assert z[t + "_states_scalars"][-1][1] == 1 and z[t + "_states_cars_i"][-1][:, 2].all() and not z[t + "_states_cars_i"][-1][:, 3].any()
+        assert (z[t + "_rewards"] > 50).all(1).sum() == 1 and (z[t + "_rewards"].sum(0) > 115).all(), "one step with the team reward for everybody, on top of each car's own arrival reward"
+    assert z["n_states_scalars"][-1][1] == 0 and not (z["n_rewards"] > 50).all(1).any()
 
 
 @pytest.mark.parametrize("tag", TAGS)
