@@ -412,6 +412,23 @@ def setup_posts(env):
     return {s: {5: [3, 0, 0, 3]} for s in range(0, 12)}
 
 
+def setup_unpenalize(env):
+    """robots 1 and 7 (one per team) are serving penalties that end 13 and 62 substeps from now: tick's un-penalize branch - flags reset, a free
+    penalty spot, both feet moved there (RoboCupEnvironment.py:948-968) - which no other fixture reaches (tools/reference_coverage.py)"""
+    for rid, left in ((1, 130), (7, 620)):
+        r = env.agents[rid]
+        env.penalize(r)
+        r.penalTime = left
+        r.prevPos = r.getPos()
+    return {}
+
+
+def setup_trip(env):
+    """seed 68, elapsed 1050: the die of robot 7's processAction is 0.99982 > 0.999 - a robot that moves falls over by itself
+    (RoboCupEnvironment.py:556-560); it is told to walk forward in that step"""
+    return {0: {7: [3, 0, 0, 3]}}
+
+
 class _PartialRig(object):
     """RoboCup with Partial observations: one dispatcher per environment for every random draw of a step - the dice of processAction /
     tick / robotCollision / goalpostCollision (RoboDice) and the noise draws of getAgentVision / addNoise / addNoiseLine
@@ -611,7 +628,16 @@ def gen_robocup(out, tag, n, can_fall, steps, seed, forward, setup=None, partial
 
 
 # ------------------------------------------------------------------ Driving, Partial observations + Realistic noise 3 (BASELINE configs[3])
-def gen_driving_partial(out, n_players, seed, steps, tag, action_bias, magn=3.0):
+def setup_peds_beside_obstacles(env):
+    """four pedestrians 16 px from an obstacle's centre (just clear of its 10 px half size + their 5 px radius): doesInteractPoly's
+    proximity test - squared distance < 400, cutils.py:654-655 - makes them `Nearby`, which doubles their Realistic noise (cutils.py:514-515)"""
+    Vec2d = type(env.agents[0].goal)
+    for k in range(min(4, len(env.pedestrians), len(env.obstacles))):
+        o = env.obstacles[k].getPos()
+        env.pedestrians[k].shape.body.position = Vec2d(o.x + (16.0 if k % 2 == 0 else -16.0), o.y + (3.0 * k))
+
+
+def gen_driving_partial(out, n_players, seed, steps, tag, action_bias, magn=3.0, setup=None):
     """the reference's step() with observationType PARTIAL: getAgentVision of every agent inside the step, its noise draws served by
     source line from the oracle's Philox words exactly as in gen_golden_partial.py (Tape), the pedestrians' draws as in gen_golden.py"""
     import gen_golden_partial as gp
@@ -622,8 +648,11 @@ def gen_driving_partial(out, n_players, seed, steps, tag, action_bias, magn=3.0)
     env = de.DrivingEnvironment(n_players, render=False, observationType=cut.ObservationType.PARTIAL, noiseType=cut.NoiseType.REALISTIC,
                                 noiseMagnitude=magn)
     env.space.sid_of = driving_sids(env)
+    if setup is not None:
+        setup(env)
     pseed, genv, episode = 42, seed, 1
     ped = gg.PedTape(pseed, genv, episode)
+    nearby = [0]
 
     class Tape(gp.Tape):    # one dispatcher for both kinds of draw sites
         def _site(self):
@@ -644,6 +673,8 @@ def gen_driving_partial(out, n_players, seed, steps, tag, action_bias, magn=3.0)
         tape.counters[kind] = idx + 1
         sites = [(0, 0), (0, 1), (0, 2)] + ([(0, 3)] if (misClass and noiseType == cut.NoiseType.REALISTIC) else []) + [(1, 0)]
         tape.ctx = (kind, idx, iter(sites))
+        if interaction == cut.InteractionType.Nearby and obj[0] != cut.SightingType.NoSighting:
+            nearby[0] += 1
         try:
             return orig_rect(obj, noiseType, interaction, magn_, rand, maxDist, misClass)
         finally:
@@ -699,6 +730,7 @@ def gen_driving_partial(out, n_players, seed, steps, tag, action_bias, magn=3.0)
     out["%s_dones" % tag] = np.array(dones, np.int64)
     out["%s_obs" % tag] = np.array(obss, np.float32)
     out["%s_cfg" % tag] = np.array([n_players, 1, magn], float)
+    out["%s_nearby_rows" % tag] = np.array([nearby[0]], np.int64)   # rows whose noise took the `Nearby` multiplier (cutils.py:514-515)
     for name in ("cars_f", "cars_i", "peds_f", "peds_i", "episode_r", "episode_pos_r"):
         out["%s_final_%s" % (tag, name)] = st[name]
     log = env.space.world.log
@@ -713,6 +745,7 @@ def main():
     gen_driving_partial(out, 10, 71, 100, "a", 0.6)
     gen_driving_partial(out, 10, 72, 100, "b", 0.5)
     gen_driving_partial(out, 6, 73, 120, "c", 0.7)
+    gen_driving_partial(out, 6, 74, 12, "d", 0.5, setup=setup_peds_beside_obstacles)   # pedestrians `Nearby` an obstacle: doubled noise
     np.savez_compressed(os.path.join(HERE, "driving_partial_contacts.npz"), **out)
     print("wrote", os.path.join(HERE, "driving_partial_contacts.npz"))
     out = {}
@@ -732,6 +765,8 @@ def main():
         gen_robocup(out, "ghij"[k], n, can_fall, steps, seed, fw)
     gen_robocup(out, "k", 5, True, 15, 65, 0.5, setup_goal)
     gen_robocup(out, "l", 5, True, 10, 66, 0.6, start_elapsed=12000 - 10 * 50)   # the last ten steps of an episode, terminal step included
+    gen_robocup(out, "m", 5, True, 6, 67, 0.3, setup_unpenalize)                  # two penalties expire: tick's un-penalize branch
+    gen_robocup(out, "n", 5, True, 5, 68, 0.3, setup_trip, start_elapsed=1050)    # a walking robot falls over by itself (die > 0.999)
     assert out["k_goals"].sum() == 1, "case k must score"
     np.savez_compressed(os.path.join(HERE, "robocup_contacts.npz"), **out)
     print("wrote", os.path.join(HERE, "robocup_contacts.npz"))

@@ -91,8 +91,8 @@ def test_reference_step_with_collisions_against_the_oracle(oracle_built, tag):
 
 
 # ------------------------------------------------------------------------------------------------ RoboCup
-RC_TAGS = list("abcdefghijkl")   # l: the last ten steps of an episode, terminal step included
-RC_MIN_STEPS = {"a": 30, "b": 40, "c": 50, "d": 30, "e": 12, "f": 20, "g": 25, "h": 40, "i": 30, "j": 60, "k": 15, "l": 10}   # steps of each trajectory that are well-conditioned (and checked)
+RC_TAGS = list("abcdefghijklmn")   # l: the last ten steps of an episode, terminal step included; m: two penalties expire; n: a walking robot trips
+RC_MIN_STEPS = {"a": 30, "b": 40, "c": 50, "d": 30, "e": 12, "f": 20, "g": 25, "h": 40, "i": 30, "j": 60, "k": 15, "l": 10, "m": 6, "n": 5}   # steps of each trajectory that are well-conditioned (and checked)
 
 
 def _rc_check_state(st, rf, ri, sc, fl, msg, tol=1e-9):
@@ -154,6 +154,10 @@ def check_robocup_trajectory(z, tag, make_env, partial=False):
 def test_the_robocup_fixtures_contain_what_they_are_for():
     z = np.load(os.path.join(G, "robocup_contacts.npz"))
     assert list(z["l_dones"]) == [0] * 9 + [1] and int(z["l_states_sc"][-1][0]) == 12000, "fixture l ends with the episode's terminal step"
+    # ROBOT_I[1] = penalized, [5] = fallen.  m: robots 1 and 7 start penalized and are back in play at the first recorded state (tick's
+    # un-penalize branch, RoboCupEnvironment.py:948-968); n: robot 7 falls in a step without any robot-robot touch (processAction :556-560)
+    assert z["m_b_ri"][[1, 7], 1].all() and not z["m_states_ri"][0][:, 1].any()
+    assert z["n_states_ri"][-1][7, 5] == 1 and z["n_begins"][0] == 0
     begins = sum(z[t + "_begins"] for t in RC_TAGS)     # robot-robot, robot-ball, robot-post, ball-post, own feet
     assert begins[0] >= 30 and begins[1] >= 6 and begins[2] >= 5 and begins[3] >= 1, begins
     kicking = sum(int(z[t + "_states_ri"][:, :, 7].sum()) for t in RC_TAGS)          # ROBOT_I[7] = kicking (pivot joint removed mid-kick)
@@ -178,7 +182,7 @@ def test_reference_robocup_step_with_collisions_against_the_oracle(oracle_built,
 
 
 # ------------------------------------------------------------------------------------------------ Driving, Partial observations (configs[3])
-P_TAGS = ["a", "b", "c"]
+P_TAGS = ["a", "b", "c", "d"]   # d: pedestrians within 20 px of an obstacle's centre: the `Nearby` noise multiplier (cutils.py:514-515) on 36 rows
 
 
 def check_partial_trajectory(z, tag, make_env):
@@ -222,6 +226,7 @@ def test_reference_step_with_partial_observations_and_collisions_against_the_ora
         return (lambda st: env.set_state(0, st)), step, (lambda: env.get_state(0))
     rows = check_partial_trajectory(z, tag, make_env)
     assert (rows > 50).all(), rows      # cars, obstacles, pedestrians, lanes seen over the trajectory
+    assert tag != "d" or int(z["d_nearby_rows"][0]) >= 30
 
 
 RCP_TAGS = ["a", "b", "c"]
