@@ -16,8 +16,8 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference/DynEnv"
 FILES = ["DrivingEnvironment.py", "RoboCupEnvironment.py", "Car.py", "Robot.py", "Ball.py", "Pedestrian.py", "Obstacle.py", "Goalpost.py", "Road.py",
-         "cutils.py", "environment_base.py", "models/models.py", "utils/subproc_vec_env.py"]
-ONLY = {"models/models.py": ("Indexer", "InOutArranger"), "utils/subproc_vec_env.py": ()}   # of these files only the named classes belong to the path
+         "cutils.py", "environment_base.py", "models/models.py"]
+ONLY = {"models/models.py": ("Indexer", "InOutArranger")}   # of these files only the named classes belong to the path
 hit = {}
 
 
