@@ -64,7 +64,7 @@ def main():
     n_rc = int(sys.argv[2]) if len(sys.argv) > 2 else 60
     ol.build()
     gc.install()
-    rng = np.random.default_rng(2026)
+    rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "2026")))
     devnull = open(os.devnull, "w")
     t0 = time.time()
     steps = touches = crashed = dead = 0
