@@ -32,7 +32,7 @@ static_assert(PV_LIM_CARS <= PV_CAP_CARS && PV_LIM_OBST <= PV_CAP_OBST && PV_LIM
 #define PV_OFF_PEDS (PV_OFF_OBST + PV_CAP_OBST * 6)
 #define PV_OFF_LANES (PV_OFF_PEDS + PV_CAP_PEDS * 2)
 
-extern "C" __global__ void drv_tick_advance_kernel(DrvState S);
+extern "C" __global__ void drv_tick_advance_kernel(DrvState S, int flipPv);
 extern "C" __global__ void __launch_bounds__(64, DRV_WAVES_PER_SIMD)
 drv_step_kernel(DrvState S, const int* __restrict__ actions, float* __restrict__ obs, double* __restrict__ rewards, uint8_t* __restrict__ dones);
 extern "C" __global__ void __launch_bounds__(64, DRV_WAVES_PER_SIMD)

@@ -1996,8 +1996,10 @@ DRV_PROF(if (lane == 0 && e < 4096) { unsigned long long* d = g_dbgw + e * 12; c
 }
 
 // tick_src = 1 (a step of this handle was captured into a hipGraph): what the host does between two eager launches, on the device
-extern "C" __global__ void drv_tick_advance_kernel(DrvState S) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) { S.iso[13] = (S.iso[13] + 1) % (3 * (1 << 28)); S.iso[14] = S.iso[14] ^ 1; }
+// (flipPv: the deferred-vision parity alternates only over steps that run the Partial + deferred pair - a list's length word is cleared by
+//  the deferred launch of the OTHER parity, so a step without an observation buffer must leave the parity alone, as the eager host does)
+extern "C" __global__ void drv_tick_advance_kernel(DrvState S, int flipPv) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { S.iso[13] = (S.iso[13] + 1) % (3 * (1 << 28)); if (flipPv) S.iso[14] = S.iso[14] ^ 1; }
 }
 
 extern "C" __global__ void __launch_bounds__(64, DRV_WAVES_PER_SIMD)

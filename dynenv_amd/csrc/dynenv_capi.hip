@@ -638,7 +638,6 @@ int dynenv_step_head(dynenv_t* h, const int32_t* actions_dev, const double* head
     HIP_OK(hipGetLastError());
     return DYNENV_OK;
   }
-  if (h->ev_begin) HIP_OK(hipEventRecord(h->ev_begin, st));
   // Partial: getAgentVision for every agent (DrivingEnvironment.py:294) is fused into the step kernel - each wave writes its
   // environment's observation as soon as its step is done, which fills the launch's tail
   // (with isolation on, 3 x DRV_ISO_MAX spare blocks behind the E regular ones: the environments displaced from a slow
@@ -657,7 +656,8 @@ int dynenv_step_head(dynenv_t* h, const int32_t* actions_dev, const double* head
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) h->S.tick_src = 1;
   }
-  if (h->S.tick_src) hipLaunchKernelGGL(drv_tick_advance_kernel, dim3(1), dim3(64), 0, st, h->S);
+  if (h->S.tick_src) hipLaunchKernelGGL(drv_tick_advance_kernel, dim3(1), dim3(64), 0, st, h->S, (h->partial && obs_dev) ? 1 : 0);
+  if (h->ev_begin) HIP_OK(hipEventRecord(h->ev_begin, st));  // (behind the advance kernel: the event window is the step kernel's own duration)
   if (h->iso_cfg == 1 && !h->S.tick_src) {
     h->steps += 1;
     if (h->S.iso_on == 0 && h->steps >= h->iso_paused_until) {
@@ -769,6 +769,7 @@ int dynenv_debug_counters(dynenv_t* h, int64_t* out4) {
     HIP_OK(hipDeviceSynchronize());
     { static unsigned long long d[4096 * 12]; HIP_OK(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_rcprof), sizeof(d))); FILE* f = fopen("gpurun_out/rcprof.txt", "w"); for (int k = 0; k < 4096; ++k) { for (int q = 0; q < 12; ++q) fprintf(f, "%llu ", d[12*k+q]); fprintf(f, "\n"); } fclose(f); }
     { static unsigned long long d[4096 * 8]; HIP_OK(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_rcprof2), sizeof(d))); FILE* f = fopen("gpurun_out/rcprof2.txt", "w"); for (int k = 0; k < 4096; ++k) { for (int q = 0; q < 8; ++q) fprintf(f, "%llu ", d[8*k+q]); fprintf(f, "\n"); } fclose(f); }
+    { static unsigned long long d[4096 * 8]; HIP_OK(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_rcprof3), sizeof(d))); FILE* f = fopen("gpurun_out/rcprof3.txt", "w"); for (int k = 0; k < 4096; ++k) { for (int q = 0; q < 8; ++q) fprintf(f, "%llu ", d[8*k+q]); fprintf(f, "\n"); } fclose(f); }
 #endif
     return DYNENV_OK;
   }

@@ -760,6 +760,7 @@ struct RcContacts {
   int count;
   V2 n, p1[2], p2[2];
   int hash[2];
+  bool degenerate;  // capsule cores touched or crossed: the normal is shape 1's own, not a contact normal (error bit 4)
 };
 struct SegW {
   V2 ta, tb, tn;
@@ -834,6 +835,7 @@ DE_DEV bool feet_far_apart(const RcLds& L, int r) {
 }
 DE_DEV void rc_narrowphase(const RcLds& L, int i, int j, RcContacts& out) {  // pair i < j in canonical slot order
   out.count = 0;
+  out.degenerate = false;
   if (j < RC_BALL) {  // capsule - capsule
     SegW s1, s2;
     seg_world(L, i, s1);
@@ -850,9 +852,10 @@ DE_DEV void rc_narrowphase(const RcLds& L, int i, int j, RcContacts& out) {  // 
     if (dsq > mind * mind) return;
     const double d = dm_sqrt(dsq);
     const V2 n = (d != 0.0) ? vmul(delta, 1.0 / d) : s1.tn;
+    out.degenerate = dsq < 1e-12;  // cores touching or crossing (d = 0 or rounding noise): no contact normal, where Chipmunk's EPA has the minimum-translation axis (oracle/cp_lite.c segment_to_segment, CP_CORES_TOUCH_DSQ): reported, never silent
     rc_contact_points(support_edge_segment(s1, i, n), support_edge_segment(s2, j, vneg(n)), FOOT_RADIUS, FOOT_RADIUS, n, out);
   } else if (i < RC_BALL) {  // circle (ball or goalpost) = shape a, capsule foot i = shape b
-    const V2 center = j == RC_BALL ? v2(L.cpx[RC_BALL], L.cpy[RC_BALL]) : post_pos(j);
+    const V2 center = v2(L.cpx[j], L.cpy[j]);  // (the ball's shape cache or a goalpost's constant slot)
     const double cr = 10.0;
     SegW s;
     seg_world(L, i, s);
@@ -869,7 +872,7 @@ DE_DEV void rc_narrowphase(const RcLds& L, int i, int j, RcContacts& out) {  // 
       out.hash[0] = 0; out.count = 1;
     }
   } else {  // ball - goalpost: circle_to_circle (a = ball)
-    const V2 c1 = v2(L.cpx[RC_BALL], L.cpy[RC_BALL]), c2 = post_pos(j);
+    const V2 c1 = v2(L.cpx[RC_BALL], L.cpy[RC_BALL]), c2 = v2(L.cpx[j], L.cpy[j]);
     const double mindist = BALL_R + POST_R;
     const V2 delta = vsub(c2, c1);
     const double distsq = vlensq(delta);
@@ -889,13 +892,9 @@ struct RBody {
   V2 p, v, vb;
   double w, wb, minv, iinv;
 };
-DE_DEV void rbody_load(const RcLds& L, int idx, RBody& b) {
-  if (idx <= RC_BALL) {
-    b.p = v2(L.px[idx], L.py[idx]); b.v = v2(L.vx[idx], L.vy[idx]); b.w = L.w[idx];
-    b.vb = v2(L.vbx[idx], L.vby[idx]); b.wb = L.wb[idx]; b.minv = rc_minv(idx); b.iinv = rc_iinv(idx);
-  } else {
-    b.p = post_pos(idx); b.v = v2(0.0, 0.0); b.w = 0.0; b.vb = v2(0.0, 0.0); b.wb = 0.0; b.minv = 0.0; b.iinv = 0.0;
-  }
+DE_DEV void rbody_load(const RcLds& L, int idx, RBody& b) {  // (a goalpost's slot holds its position and zero velocities: rc_load_env)
+  b.p = v2(L.px[idx], L.py[idx]); b.v = v2(L.vx[idx], L.vy[idx]); b.w = L.w[idx];
+  b.vb = v2(L.vbx[idx], L.vby[idx]); b.wb = L.wb[idx]; b.minv = rc_minv(idx); b.iinv = rc_iinv(idx);
 }
 DE_DEV void rbody_load_vel(const RcLds& L, int idx, RBody& b) {
   if (idx <= RC_BALL) {
@@ -1108,6 +1107,7 @@ DE_DEV void rc_joints_only(int lane, int R) { rc_joints_only_ool(lane, R); }
 #endif
 RC_PROF(__device__ unsigned long long g_rcprof[4096 * 12];)
 RC_PROF(__device__ unsigned long long g_rcprof2[4096 * 8];)  // stages of "contacts + prestep", summed over the step's rc_physics calls
+RC_PROF(__device__ unsigned long long g_rcprof3[4096 * 8];)  // stages of the common part: game logic | position + shape cache | broadphase | quiet test | velocity | quiet joints | quiet substeps | calls
 struct RcStepRet {
   uint64_t occ;
   int err;
@@ -1172,10 +1172,11 @@ RC_PROF(C0 = __builtin_amdgcn_s_memtime();)
       const int pr = pass * W + lane < nCand ? (int)cl[pass * W + lane] : 0xFFFF;
       const bool isCand = pr != 0xFFFF;
       RcContacts ct;
-      ct.count = 0;
+      ct.count = 0; ct.degenerate = false;
       if (isCand) rc_narrowphase(L, pr >> 8, pr & 0xFF, ct);
       const bool touch = isCand && ct.count > 0;
       if (G::ballot(touch) == 0ull) continue;
+      if (ct.degenerate) err |= 16;  // (a degenerate pair always has contacts: the check sits behind the early continue)
       int slot = -1;
       for (uint64_t mm = occ; mm; mm &= mm - 1) {
         int sidx = __builtin_ctzll(mm);
@@ -1270,8 +1271,7 @@ RC_PROF(C2 = __builtin_amdgcn_s_memtime();)
       const uint64_t who = G::ballot(touched && rank == k);
       const int b = __builtin_ctzll(who);
       if (anyFirst ? lane == b : touched) {
-        const V2 pa = bodyA <= RC_BALL ? v2(L.px[bodyA], L.py[bodyA]) : post_pos(bodyA);
-        const V2 pb = bodyB <= RC_BALL ? v2(L.px[bodyB], L.py[bodyB]) : post_pos(bodyB);
+        const V2 pa = v2(L.px[bodyA], L.py[bodyA]), pb = v2(L.px[bodyB], L.py[bodyB]);
         r1[0] = vsub(v2(M.p1x[lane][0], M.p1y[lane][0]), pa);
         r2[0] = vsub(v2(M.p2x[lane][0], M.p2y[lane][0]), pb);
         if (a_count > 1) {
@@ -1426,24 +1426,33 @@ RC_PROF(T4 = __builtin_amdgcn_s_memtime();)
     rc_joints_only<EPW>(lane, c.R);
   } else {
     // --- warm start: arbiters (level by level), then joints -------------------------------------------------
-    for (int lv = 0; lv <= maxLevel; ++lv) {
-      if (active && myLevel == lv && a_state != ARB_FIRST_) {
-        RBody a, b;
-        rbody_load(L, bodyA, a);
-        rbody_load(L, bodyB, b);
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          if (q < a_count) {
-            V2 j = vrotate_f(n, v2(jn[q], jt[q]));
+    bool jointsDirty = false;
+    {
+      // (only v and w change; a goalpost reads its zeros and writes to the scratch slot, as in the iterations below)
+      const int nLvW = G::uniform_i(maxLevel) + 1;
+      const int wa = bodyA <= RC_BALL ? bodyA : RC_NB - 1, wb_ = bodyB <= RC_BALL ? bodyB : RC_NB - 1;
+      for (int lv = 0; lv < nLvW; ++lv) {
+        if (active && myLevel == lv && a_state != ARB_FIRST_) {
+          RBody a, b;
+          a.v = v2(L.vx[bodyA], L.vy[bodyA]); a.w = L.w[bodyA]; a.minv = rc_minv(bodyA); a.iinv = rc_iinv(bodyA);
+          b.v = v2(L.vx[bodyB], L.vy[bodyB]); b.w = L.w[bodyB]; b.minv = rc_minv(bodyB); b.iinv = rc_iinv(bodyB);
+          {
+            V2 j = vrotate_f(n, v2(jn[0], jt[0]));
             j = vmul(j, 1.0);
-            rapply_impulse(a, vneg(j), r1[q]);
-            rapply_impulse(b, j, r2[q]);
+            rapply_impulse(a, vneg(j), r1[0]);
+            rapply_impulse(b, j, r2[0]);
           }
+          if (a_count > 1) {
+            V2 j = vrotate_f(n, v2(jn[1], jt[1]));
+            j = vmul(j, 1.0);
+            rapply_impulse(a, vneg(j), r1[1]);
+            rapply_impulse(b, j, r2[1]);
+          }
+          L.vx[wa] = a.v.x; L.vy[wa] = a.v.y; L.w[wa] = a.w;
+          L.vx[wb_] = b.v.x; L.vy[wb_] = b.v.y; L.w[wb_] = b.w;
         }
-        rbody_store_vel(L, bodyA, a);
-        rbody_store_vel(L, bodyB, b);
+        __syncthreads();
       }
-      __syncthreads();
     }
     if (isRobot) {  // both constraints of a robot in one LDS round trip: nobody else touches its feet in between
       RC_JOINT_VIEW(J)
@@ -1451,12 +1460,13 @@ RC_PROF(T4 = __builtin_amdgcn_s_memtime();)
       f.vx0 = L.vx[la]; f.vy0 = L.vy[la]; f.w0 = L.w[la]; f.vx1 = L.vx[lb]; f.vy1 = L.vy[lb]; f.w1 = L.w[lb];
       joints_warm_start_ordered(J, f, jn[0], jn[1], jt[0]);
       L.vx[la] = f.vx0; L.vy[la] = f.vy0; L.w[la] = f.w0; L.vx[lb] = f.vx1; L.vy[lb] = f.vy1; L.w[lb] = f.w1;
+      jointsDirty = !(feet_clean(f) && is_finite(jn[0]) && is_finite(jn[1]));
     }
     __syncthreads();
 RC_PROF(T4 = __builtin_amdgcn_s_memtime();)
     // --- 10 iterations: all arbiters (canonical order via levels), then all constraints ----------------------
     RBody a, b;
-    if (active) { rbody_load(L, bodyA, a); rbody_load(L, bodyB, b); }  // p, minv, iinv do not change during the solve
+    if constexpr (!SPLIT) { if (active) { rbody_load(L, bodyA, a); rbody_load(L, bodyB, b); } }  // p, minv, iinv do not change during the solve
     if constexpr (SPLIT) {
       // velocity lanes (the slot lanes) work on (v, w), bias lanes on (v_bias, w_bias): same code, other fields
       double* const fX = biasLane ? L.vbx : L.vx;
@@ -1464,48 +1474,69 @@ RC_PROF(T4 = __builtin_amdgcn_s_memtime();)
       double* const fW = biasLane ? L.wb : L.w;
       const bool solveMe = active || biasLane;
       const bool aDyn = bodyA <= RC_BALL, bDyn = bodyB <= RC_BALL;
-      if (biasLane) {
-        a.minv = aDyn ? rc_minv(bodyA) : 0.0; a.iinv = aDyn ? rc_iinv(bodyA) : 0.0;
-        b.minv = bDyn ? rc_minv(bodyB) : 0.0; b.iinv = bDyn ? rc_iinv(bodyB) : 0.0;
-        a.v = b.v = v2(0.0, 0.0); a.w = b.w = 0.0;
-      }
-      for (int iter = 0; iter < 10; ++iter) {
-        for (int lv = 0; lv <= maxLevel; ++lv) {
-          if (solveMe && myLevel == lv) {
-            if (aDyn) { a.v = v2(fX[bodyA], fY[bodyA]); a.w = fW[bodyA]; }
-            if (bDyn) { b.v = v2(fX[bodyB], fY[bodyB]); b.w = fW[bodyB]; }
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-              if (q < a_count) {
-                const V2 vr = rrelative_velocity(a, b, r1[q], r2[q]);
-                const double vrn = vdot_f(vr, n);
-                const double vrt = vdot_f(vr, vperp(n));
-                const double jnOld = jn[q];
-                jn[q] = dms_acc_clamp0(-(bounce[q] + vrn), nMass[q], jnOld);
-                const double jtMax = arb_u * jn[q];
-                const double jtOld = jt[q];
-                jt[q] = fclamp_cp(dm_fma(-vrt, tMass[q], jtOld), -jtMax, jtMax);
-                const double dj = jn[q] - jnOld;
-                const V2 jr = vrotate_f(n, v2(dj, jt[q] - jtOld));
-                const V2 jl = vmul(n, dj);  // the bias impulse has no tangent term: not even a zero one (sign of zero)
-                const V2 jj = biasLane ? jl : jr;
-                rapply_impulse(a, vneg(jj), r1[q]);
-                rapply_impulse(b, jj, r2[q]);
-              }
+      a.minv = rc_minv(bodyA); a.iinv = rc_iinv(bodyA); b.minv = rc_minv(bodyB); b.iinv = rc_iinv(bodyB);  // (0 for a goalpost)
+      a.v = b.v = v2(0.0, 0.0); a.w = b.w = 0.0;
+      {
+        // A static partner (a goalpost) reads the zeros of its own, never written LDS slot and writes to a scratch slot nobody reads:
+        // no branch around the loads and stores.  (Its velocity is +0 after every finite impulse - x * 0 + 0 - so reloading the zeros
+        // is what keeping it in registers was.)
+        const bool cleanAll = G::ballot(jointsDirty) == 0ull;
+        bool notFinite = false;
+        const int nLv = G::uniform_i(maxLevel) + 1;
+        const int sa = aDyn ? bodyA : RC_NB - 1, sb = bDyn ? bodyB : RC_NB - 1;
+        const bool two = a_count > 1;
+#define RC_CONTACT_PASS(q)                                                                     \
+        {                                                                                      \
+          const V2 vr = rrelative_velocity(a, b, r1[q], r2[q]);                                \
+          const double vrn = vdot_f(vr, n);                                                    \
+          const double vrt = vdot_f(vr, vperp(n));                                             \
+          const double jnOld = jn[q];                                                          \
+          jn[q] = dms_acc_clamp0(-(bounce[q] + vrn), nMass[q], jnOld);                         \
+          const double jtMax = arb_u * jn[q];                                                  \
+          const double jtOld = jt[q];                                                          \
+          jt[q] = fclamp_cp(dm_fma(-vrt, tMass[q], jtOld), -jtMax, jtMax);                     \
+          const double dj = jn[q] - jnOld;                                                     \
+          const V2 jr = vrotate_f(n, v2(dj, jt[q] - jtOld));                                   \
+          const V2 jl = vmul(n, dj);                                                           \
+          const V2 jj = biasLane ? jl : jr;                                                    \
+          rapply_impulse(a, vneg(jj), r1[q]);                                                  \
+          rapply_impulse(b, jj, r2[q]);                                                        \
+        }
+        for (int iter = 0; iter < 10; ++iter) {
+          for (int lv = 0; lv < nLv; ++lv) {
+            if (solveMe && myLevel == lv) {
+              a.v = v2(fX[bodyA], fY[bodyA]); a.w = fW[bodyA];
+              b.v = v2(fX[bodyB], fY[bodyB]); b.w = fW[bodyB];
+              RC_CONTACT_PASS(0)
+              if (two) RC_CONTACT_PASS(1)
+              fX[sa] = a.v.x; fY[sa] = a.v.y; fW[sa] = a.w;
+              fX[sb] = b.v.x; fY[sb] = b.v.y; fW[sb] = b.w;
             }
-            if (aDyn) { fX[bodyA] = a.v.x; fY[bodyA] = a.v.y; fW[bodyA] = a.w; }
-            if (bDyn) { fX[bodyB] = b.v.x; fY[bodyB] = b.v.y; fW[bodyB] = b.w; }
+            __syncthreads();
+          }
+          if (isRobot) {
+            RC_JOINT_VIEW(J)
+            RcFeet f;
+            f.vx0 = L.vx[la]; f.vy0 = L.vy[la]; f.w0 = L.w[la]; f.vx1 = L.vx[lb]; f.vy1 = L.vy[lb]; f.w1 = L.w[lb];
+            if (cleanAll) {
+              // CLEAN arithmetic (pivot_warm_start's comment): no foot velocity is -0 - checked after the warm start, and an accumulation
+              // v = fma(x, y, v) cannot produce a -0 from a v that is not one, so the arbiters' impulses keep it so - hence the pivot
+              // reads and writes (vx, vy) only, the rotary limit w only: the two are independent and their order is immaterial.
+              pivot_iterate<true>(J, f, jn[0], jn[1]);
+              rotary_iterate(J, f, jt[0]);
+              if (iter == 9) notFinite = !(is_finite(jn[0]) && is_finite(jn[1]) && is_finite(f.vx0) && is_finite(f.vy0) && is_finite(f.vx1) &&
+                                           is_finite(f.vy1) && is_finite(f.w0) && is_finite(f.w1));
+            } else
+            joints_iterate_ordered(J, f, jn[0], jn[1], jt[0]);
+            L.vx[la] = f.vx0; L.vy[la] = f.vy0; L.w[la] = f.w0; L.vx[lb] = f.vx1; L.vy[lb] = f.vy1; L.w[lb] = f.w1;
           }
           __syncthreads();
         }
-        if (isRobot) {
-          RC_JOINT_VIEW(J)
-          RcFeet f;
-          f.vx0 = L.vx[la]; f.vy0 = L.vy[la]; f.w0 = L.w[la]; f.vx1 = L.vx[lb]; f.vy1 = L.vy[lb]; f.w1 = L.w[lb];
-          joints_iterate_ordered(J, f, jn[0], jn[1], jt[0]);
-          L.vx[la] = f.vx0; L.vy[la] = f.vy0; L.w[la] = f.w0; L.vx[lb] = f.vx1; L.vy[lb] = f.vy1; L.w[lb] = f.w1;
-        }
-        __syncthreads();
+        // Non-finite values persist through accumulations: finite feet velocities and pivot impulses at the end mean they were finite
+        // all along, i.e. every product the CLEAN arithmetic dropped was a zero.  Otherwise (an overflowing state: never seen) this
+        // substep's joints are not the reference's: reported, error bit 5.
+        if (G::ballot(notFinite) != 0ull) err |= 32;
+#undef RC_CONTACT_PASS
       }
     } else
     for (int iter = 0; iter < 10; ++iter) {
@@ -1611,6 +1642,12 @@ DE_DEV void rc_load_env(const RcState& S, RcLds& L, int e, int lane, uint64_t oc
     L.cpx[lane] = used ? b[(RB_COUNT + 0) * E * RC_NB] : 0.0; L.cpy[lane] = used ? b[(RB_COUNT + 1) * E * RC_NB] : 0.0;
     L.crc[lane] = used ? b[(RB_COUNT + 2) * E * RC_NB] : 1.0; L.crs[lane] = used ? b[(RB_COUNT + 3) * E * RC_NB] : 0.0;
     if (lane < RC_BALL) L.rotAng[lane] = __builtin_nan("");
+    // the goalposts (static bodies 21..24) live in the same arrays - their positions, zero velocities, never written - so that a
+    // contact's bodies are read without a branch on "is it a post" (rbody_load, the narrowphase, the broadphase)
+    if (lane >= RC_POST && lane < RC_POST + 4) {
+      const V2 pp = post_pos(lane);
+      L.px[lane] = pp.x; L.py[lane] = pp.y; L.cpx[lane] = pp.x; L.cpy[lane] = pp.y;
+    }
   }
   if (lane < 16) {
     const bool used = lane < S.R;
@@ -1765,6 +1802,7 @@ DE_OOL RcCommonRet rc_common_substep(RcCtx c_, int serial_, int lane, const uint
   const uint64_t pairLo = pairTab[2 * lane], pairHiFeet = pairTab[2 * lane + 1];
   const uint64_t pairHi = pairHiFeet & 0xFFFFull, pairTop = 0ull;
   const int feetPairs = (int)(pairHiFeet >> 32);  // bit t: my pair of round t is the two feet of one robot
+RC_PROF(const unsigned long long P0 = __builtin_amdgcn_s_memtime();)
     // ---- game logic: tick per robot (one robot per lane, unless the sequential form has run), then the ball (:465-475) ----
     if (!rc_game_logic_batched<EPW>(c, L, lane, !serial)) {
       RcCommonRet ret;  // a robot's tick has a cross-robot event: nothing has been changed, the kernel runs the sequential form
@@ -1772,6 +1810,7 @@ DE_OOL RcCommonRet rc_common_substep(RcCtx c_, int serial_, int lane, const uint
       return ret;
     }
     __syncthreads();
+RC_PROF(const unsigned long long P1 = __builtin_amdgcn_s_memtime();)
     // ---- cpBodyUpdatePosition + shape cache + AABB ------------------------------------------------------
     if (isBody) {
       const double npx = L.px[lane] + (L.vx[lane] + L.vbx[lane]) * DE_DT;
@@ -1801,8 +1840,12 @@ DE_OOL RcCommonRet rc_common_substep(RcCtx c_, int serial_, int lane, const uint
       fcx = (float)(0.5 * (al + ar)); fcy = (float)(0.5 * (ab + at));
       fhx = (float)(0.5 * (ar - al)) + 1.0f; fhy = (float)(0.5 * (at - ab)) + 1.0f;
       L.u.pf.cx[lane] = fcx; L.u.pf.cy[lane] = fcy; L.u.pf.hx[lane] = fhx; L.u.pf.hy[lane] = fhy;
+    } else if (lane >= RC_POST && lane < RC_POST + 4) {  // the goalposts' entries (the table shares its LDS with the mailbox: rewritten every substep)
+      const V2 pc = post_pos(lane);
+      L.u.pf.cx[lane] = (float)pc.x; L.u.pf.cy[lane] = (float)pc.y; L.u.pf.hx[lane] = 11.0f; L.u.pf.hy[lane] = 11.0f;
     }
     __syncthreads();
+RC_PROF(const unsigned long long P2 = __builtin_amdgcn_s_memtime();)
     // ---- broadphase ---------------------------------------------------------------------------------------
     // The two feet of one robot overlap in every substep: they are candidates without a test (a candidate whose boxes
     // do not overlap is harmless - shapes that touch have overlapping boxes, so the narrowphase finds nothing), which
@@ -1813,9 +1856,7 @@ DE_OOL RcCommonRet rc_common_substep(RcCtx c_, int serial_, int lane, const uint
       const int pr = RC_MY_PAIR(t);
       if (pr != 0xFFFF && !((feetPairs >> t) & 1)) {
         const int i = pr >> 8, j = pr & 0xFF;
-        float bx, by, bhx, bhy;
-        if (j <= RC_BALL) { bx = L.u.pf.cx[j]; by = L.u.pf.cy[j]; bhx = L.u.pf.hx[j]; bhy = L.u.pf.hy[j]; }
-        else { const V2 pc = post_pos(j); bx = (float)pc.x; by = (float)pc.y; bhx = 11.0f; bhy = 11.0f; }
+        const float bx = L.u.pf.cx[j], by = L.u.pf.cy[j], bhx = L.u.pf.hx[j], bhy = L.u.pf.hy[j];
         const float dx = L.u.pf.cx[i] - bx, dy = L.u.pf.cy[i] - by;
         if (__builtin_fabsf(dx) <= L.u.pf.hx[i] + bhx && __builtin_fabsf(dy) <= L.u.pf.hy[i] + bhy) pre |= 1 << t;
       }
@@ -1836,17 +1877,22 @@ DE_OOL RcCommonRet rc_common_substep(RcCtx c_, int serial_, int lane, const uint
     // The common substep never enters rc_physics: no cached arbiter, the only candidates are the robots' own feet pairs, and
     // the narrowphase's separating-axis early out rejects every one of them.  What rc_physics does then is exactly this:
     // velocity update, then every robot's joints (prestep, warm start, 10 iterations) in registers.
+RC_PROF(const unsigned long long P3 = __builtin_amdgcn_s_memtime(); unsigned long long P4 = P3, P5 = P3, P6 = P3;)
     bool quiet = occ == 0ull && G::ballot((cand & ~feetPairs) != 0) == 0ull;
     if (quiet) {
       const bool far = lane < R ? feet_far_apart(L, lane) : true;
       quiet = G::ballot(!far) == 0ull;
     }
+RC_PROF(P4 = P5 = P6 = __builtin_amdgcn_s_memtime();)
     if (quiet) {
       if (isBody) rc_velocity_update(L, lane);
       __syncthreads();
+RC_PROF(P5 = __builtin_amdgcn_s_memtime();)
       rc_joints_only_inl<EPW>(lane, R);
       __syncthreads();
+RC_PROF(P6 = __builtin_amdgcn_s_memtime();)
     }
+RC_PROF(if (lane == 0 && c.genv < 4096u) { unsigned long long* d = g_rcprof3 + c.genv * 8; d[0] += P1 - P0; d[1] += P2 - P1; d[2] += P3 - P2; d[3] += P4 - P3; d[4] += P5 - P4; d[5] += P6 - P5; d[6] += quiet ? 1ull : 0ull; d[7] += 1ull; })
   RcCommonRet ret;
   ret.pairLo = pairLo; ret.pairHi = pairHi; ret.cand = cand; ret.bits = quiet ? 1 : 0;
   return ret;
@@ -1889,7 +1935,7 @@ DE_DEV void rc_step_body(const RcState& S, const int e, const int* __restrict__ 
   const double* myHead = headActions ? headActions + (size_t)e * R : nullptr;
   int snap = 0, nGeneral = 0;  // substeps that went through rc_physics
 
-RC_PROF(if (lane < 8 && e < 4096) g_rcprof2[e * 8 + lane] = 0ull;)
+RC_PROF(if (lane < 8 && e < 4096) { g_rcprof2[e * 8 + lane] = 0ull; g_rcprof3[e * 8 + lane] = 0ull; })
 RC_PROF(if (lane < 12 && e < 4096) g_rcprof[e * 12 + lane] = 0ull; const unsigned long long K0 = __builtin_amdgcn_s_memtime(); unsigned long long tG = 0, tP = 0, tB = 0;)
   for (int it = 0; it < 50; ++it) {
     lane = fresh_lane();  // per substep: nothing derived from the lane id is hoisted out of the loop, and the id itself is not kept across the calls
@@ -1921,7 +1967,10 @@ RC_PROF(tP += __builtin_amdgcn_s_memtime() - A0;)
       const RcStepRet sr = rc_physics<EPW>(c, fresh_lane(), cand, cr.pairLo, cr.pairHi, 0ull, occ);
       occ = G::uniform_u64(sr.occ);
       lane = fresh_lane();
-      if (G::ballot(sr.err != 0) != 0ull && lane == 0) L.envi[RE_ERR] |= 1;  // (a full slot table / candidate list: reported, never silent)
+      {  // a full slot table / candidate list (bit 0), a capsule pair on the fallback normal (bit 4): reported, never silent
+        const int eb = (G::ballot((sr.err & 1) != 0) != 0ull ? 1 : 0) | (G::ballot((sr.err & 16) != 0) != 0ull ? 16 : 0) | (G::ballot((sr.err & 32) != 0) != 0ull ? 32 : 0);
+        if (eb != 0 && lane == 0) L.envi[RE_ERR] |= eb;
+      }
     }
     lane = fresh_lane();
     if (lane == 0) L.envi[RE_ELAPSED] += 1;

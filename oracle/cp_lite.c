@@ -211,7 +211,7 @@ void cpBodyApplyForceAtWorldPoint(cpBody* b, cpv force, cpv point) {
 
 /* ---------------------------------------------------------------- narrowphase */
 
-typedef struct { cpShape *a, *b; cpv n; int count; cpv p1[2], p2[2]; uint32_t hash[2]; } cpCollisionInfo;
+typedef struct { cpShape *a, *b; cpv n; int count; cpv p1[2], p2[2]; uint32_t hash[2]; int degenerate; /* the normal is a fallback, not a contact normal */ } cpCollisionInfo;
 
 static void push_contact(cpCollisionInfo* info, cpv p1, cpv p2, uint32_t hash) {
   info->p1[info->count] = p1; info->p2[info->count] = p2; info->hash[info->count] = hash;
@@ -391,9 +391,10 @@ static void closest_seg_seg(cpv p1, cpv q1, cpv p2, cpv q2, cpv* c1, cpv* c2) {
   *c2 = cpvadd(p2, cpvmult(d2, t));
 }
 
-/* diagnostics (tools / tests): capsule pairs whose CORES touched or crossed (closest distance 0: the normal falls back to s1's, where
- * Chipmunk's EPA would give the minimum-translation axis - DESIGN.md 2b) */
+/* diagnostics (tools / tests): capsule pairs whose CORES touched or crossed (closest distance below 1e-6: the normal is s1's own or the
+ * direction of a rounding error, where Chipmunk's EPA would give the minimum-translation axis - DESIGN.md 2b) */
 long cp_lite_cores_cross = 0;
+#define CP_CORES_TOUCH_DSQ 1e-12 /* (1e-6 px)^2; the kernels use the same constant (robocup_kernels.hip rc_narrowphase) */
 
 static void segment_to_segment(cpShape* s1, cpShape* s2, cpCollisionInfo* info) {
   cpv a, b, delta, n;
@@ -403,7 +404,8 @@ static void segment_to_segment(cpShape* s1, cpShape* s2, cpCollisionInfo* info) 
   dsq = cpvlengthsq(delta);
   if (dsq > mind * mind) return;
   d = dm_sqrt(dsq);
-  if (d == 0.0) {
+  if (dsq < CP_CORES_TOUCH_DSQ) { /* crossing cores come out as d = 0 or as rounding noise (~1e-15): neither has a contact normal */
+    info->degenerate = 1; /* -> cpSpace.degenerate, error bit 4 of both sides (include/dynenv.h) */
 #pragma omp atomic
     cp_lite_cores_cross++;
   }
@@ -412,7 +414,7 @@ static void segment_to_segment(cpShape* s1, cpShape* s2, cpCollisionInfo* info) 
 }
 
 static void collide(cpShape* a, cpShape* b, cpCollisionInfo* info) {
-  info->a = a; info->b = b; info->count = 0; info->n = cpv_(0.0, 0.0);
+  info->a = a; info->b = b; info->count = 0; info->n = cpv_(0.0, 0.0); info->degenerate = 0;
   if (a->type > b->type) { info->a = b; info->b = a; }
   a = info->a; b = info->b;
   if (a->type == CP_SHAPE_CIRCLE && b->type == CP_SHAPE_CIRCLE) circle_to_circle(a, b, info);
@@ -495,6 +497,7 @@ static void collide_shapes(cpSpace* s, cpShape* a, cpShape* b) {
   if (!(a->bb_l <= b->bb_r && b->bb_l <= a->bb_r && a->bb_b <= b->bb_t && b->bb_b <= a->bb_t)) return;
   if (a->body == b->body) return;
   collide(a, b, &info);
+  if (info.degenerate) s->degenerate = 1;
   if (info.count == 0) return;
   arb = arbiter_find_or_create(s, info.a, info.b);
   if (!arb) return;

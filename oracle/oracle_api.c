@@ -208,6 +208,12 @@ int oracle_overflow(oracle_t* o) {
   for (e = 0; e < o->cfg.num_envs; ++e) f |= o->drv ? o->drv[e].space.overflow : o->rc[e].space.overflow;
   return f;
 }
+int oracle_degenerate(oracle_t* o) { /* 16 (error bit 4) if an environment's narrowphase took a fallback normal since its last reset / set_state */
+  int e, f = 0;
+  for (e = 0; e < o->cfg.num_envs; ++e) f |= o->drv ? o->drv[e].space.degenerate : o->rc[e].space.degenerate;
+  return f ? 16 : 0;
+}
+int oracle_degenerate_env(oracle_t* o, int32_t env) { return (o->drv ? o->drv[env].space.degenerate : o->rc[env].space.degenerate) ? 16 : 0; }
 int oracle_obs_overflow(oracle_t* o) {
   int e, f = 0;
   if (o->drv) for (e = 0; e < o->cfg.num_envs; ++e) f |= o->drv[e].obsOverflow;

@@ -187,6 +187,13 @@ class OracleEnv:
     def overflow(self):
         return self.l.oracle_overflow(self.h)
 
+    def degenerate(self):
+        """16 (error bit 4 of dynenv_error_flags) if a capsule pair's narrowphase took the fallback normal since the last reset / set_state"""
+        return self.l.oracle_degenerate(self.h)
+
+    def degenerate_env(self, env):
+        return self.l.oracle_degenerate_env(self.h, env)
+
     def active_contacts(self, env=0):
         return self.l.oracle_active_contacts(self.h, env)
 

@@ -79,3 +79,62 @@ def test_captured_steps_replay_like_eager_steps(gpu, kind, E, partial, replays):
         assert dc["isolation_timeouts"] == 0, dc      # ... and no placeholder ever waited for a tick that did not come
     eager.close()
     graphed.close()
+
+
+def test_steps_without_observation_after_a_capture_keep_the_deferred_lists_in_step(gpu):
+    """once a step of a Driving Partial handle has been captured the deferred-vision parity lives on the device; a step WITHOUT
+    an observation buffer (include/dynenv.h allows it for Driving) must leave it alone, as the eager host does - else the list such a step
+    skips is never cleared, fills up with stale entries and, after E of them, drops environments (error bit 2, rows not written)."""
+    import torch
+    from dynenv_amd import _capi
+    dev = torch.device("cuda", 0)
+    E = 4096
+    eager, graphed = _mk(gpu, "driving", E, True), _mk(gpu, "driving", E, True)
+    A, K = eager.n_agents, eager.action_dim
+    gen = torch.Generator(device=dev).manual_seed(9)
+
+    def draw():
+        return torch.randint(0, 3, (E, A, K), generator=gen, device=dev, dtype=torch.int32)
+
+    def step_no_obs(env, a):
+        _capi.check(env._lib.dynenv_step(env._h, C.c_void_p(a.data_ptr()), None, C.c_void_p(env.rewards.data_ptr()),
+                                         C.c_void_p(env.dones.data_ptr()), env._stream()), "dynenv_step")
+        env._episode_step += 1
+    eager.reset_flat()
+    graphed.reset_flat()
+    static_a = draw()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        graphed.step_flat(static_a, auto_reset=False)
+    g.replay()
+    eager.step_flat(static_a, auto_reset=False)
+    for it in range(150):
+        a = draw()
+        step_no_obs(eager, a)
+        step_no_obs(graphed, a)
+        assert torch.equal(eager.rewards.view(torch.int64), graphed.rewards.view(torch.int64)), it
+        a = draw()
+        o, rw, _ = eager.step_flat(a, auto_reset=False)
+        o2, rw2, _ = graphed.step_flat(a, auto_reset=False)
+        assert torch.equal(o.view(torch.int32), o2.view(torch.int32)), (it, "observations")
+        assert torch.equal(rw.view(torch.int64), rw2.view(torch.int64)), (it, "rewards")
+    assert eager.error_flags() == 0 and graphed.error_flags() == 0
+    eager.close()
+    graphed.close()
+
+
+def test_auto_reset_inside_a_capture_is_refused(gpu):
+    """The host's episode position is not advanced by a replay: an auto-reset decided at capture time would be frozen into the graph."""
+    import torch
+    env = _mk(gpu, "driving", 64, False)
+    env.reset_flat()
+    a = torch.zeros((64, env.n_agents, env.action_dim), dtype=torch.int32, device="cuda")
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(Exception, match="auto_reset"):
+        with torch.cuda.graph(g, stream=s):
+            env.step_flat(a, auto_reset=True)
+    torch.cuda.synchronize()
+    env.close()

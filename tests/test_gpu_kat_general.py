@@ -75,7 +75,7 @@ def test_robocup_scenes_full_state_on_the_hip_path(gpu):
         got = kw.robocup_readback(env.get_state(i))
         dev[i] = kw.deviation(list(got), list(exp[0]))
         assert _same_bits(got, kw.robocup_readback(ora.get_state(i))), (i, "HIP != oracle")
-    assert env.error_flags() == 0
+    assert env.error_flags() == ora.degenerate() == 0   # (no capsule cores within 1e-6 px of each other: error bit 4 stays down on both sides)
     classes = tk.tally(scenes, dev, lambda sc: kw.robocup_expected(sc), 0)
     assert "UNEXPLAINED" not in classes, classes["UNEXPLAINED"]
     assert len(classes["agree"]) >= 0.96 * n, {k: len(v) for k, v in classes.items()}

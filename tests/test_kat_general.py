@@ -181,6 +181,43 @@ def test_robocup_scenes_full_state_against_the_oracle():
     assert "UNEXPLAINED" not in classes, classes["UNEXPLAINED"]
     assert len(classes["agree"]) >= 0.96 * n, {k: len(v) for k, v in classes.items()}
     assert events(scenes, "begin") > 2 * n and events(scenes, "separate") > n and events(scenes, "retouch") > 100
+    # error bit 4 (capsule cores closer than 1e-6 px) stays down: the population's one "capsule cores cross" scene is kat_general's EPA
+    # answering -20 for the two exactly parallel feet of ONE robot, 20 px apart (a degenerate Minkowski difference) - the cores do not touch
+    assert ora.degenerate() == 0
+
+
+def test_crossed_capsule_cores_are_reported():
+    """a foot laid across another robot's foot (set_state; a penalty teleport or a trained policy could get there too)
+    has no contact normal - closest_seg_seg returns the crossing point twice, up to rounding - and is REPORTED (error bit 4), sticky until
+    reset / set_state; two feet side by side, 1e-3 px from touching cores, are not."""
+    import math
+    ora = ol.OracleEnv(env_type=0, num_envs=3, n_players=5, seed=3, flags=ol.FLAG_USE_OBS_REWARDS, threads=1)
+    ora.reset()
+    a = np.zeros((3, 10, 4), np.int32)
+    a[..., 3] = 3
+    st = ora.get_state(1)
+    A, B = st.robots[0], st.robots[5]
+    # A at angle 0: its left core runs from (x - 10, y + 10) to (x + 10, y + 10); B turned by 90 degrees and moved so that its left core
+    # - then the vertical segment from (Bx - 10, By - 10) to (Bx - 10, By + 10) - crosses that one in the middle
+    for f in ("l", "r"):
+        setattr(A, f + "a", 0.0)
+        setattr(B, f + "a", math.pi / 2)
+        setattr(B, f + "px", A.lpx + 10.0)
+        setattr(B, f + "py", A.lpy + 10.0)
+    ora.set_state(1, st)
+    st2 = ora.get_state(2)
+    A, B = st2.robots[0], st2.robots[5]
+    for f in ("l", "r"):                    # B beside A, same angle: cores parallel, 15.001 apart (capsules overlap by 0.001 less than a radius)
+        setattr(A, f + "a", 0.0)
+        setattr(B, f + "a", 0.0)
+        setattr(B, f + "px", A.lpx)
+        setattr(B, f + "py", A.lpy + 20.0 + 1e-3)   # B's right core (y - 10) against A's left core (y + 10): 1e-3 apart
+    ora.set_state(2, st2)
+    ora.step(a)
+    assert [ora.degenerate_env(i) for i in range(3)] == [0, 16, 0]
+    assert ora.degenerate() == 16
+    ora.set_state(1, ora.get_state(0))
+    assert ora.degenerate() == 0
 
 
 def test_scene_outcomes_do_not_depend_on_the_gjk_warm_start():

@@ -19,7 +19,7 @@ env.reset_flat()
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 hi = torch.tensor([5, 3, 3, 7], device="cuda")  # MultiDiscrete([5, 3, 3, 7]) RoboCupEnvironment.py:342
 for s in range(STEP):
-    a = (torch.rand((NE, 10, 4), device="cuda", generator=g) * hi).to(torch.int32)
+    a = (torch.rand((4096, 10, 4), device="cuda", generator=g) * hi).to(torch.int32)[:NE].contiguous()  # (the same actions per environment id whatever NE is)
     env.step_flat(a)
 env.debug_counters()
 d = np.loadtxt("gpurun_out/rcprof.txt")[:NE]
@@ -34,3 +34,8 @@ for k in top: print("  ", " ".join("%8d" % v for v in d[k]))
 q = np.loadtxt("gpurun_out/rcprof2.txt")[:NE]
 print("contacts + prestep of the slowest environments, cycles per step: candidate list | narrowphase passes | slot record | callbacks, expiry | levels | prestep + bias-lane share | rc_physics calls with contact work")
 for k in top: print("  ", " ".join("%8d" % v for v in q[k, :7]))
+p3 = np.loadtxt("gpurun_out/rcprof3.txt")[:NE]
+n3 = ["game logic", "position + shape cache + AABB", "broadphase", "quiet test (feet_far_apart)", "velocity update (quiet)", "joints (quiet)", "quiet substeps", "calls of the common part"]
+print("the common part, cycles per step: mean over all environments / mean of the 12 slowest")
+for k, n in enumerate(n3): print("  %-34s %10.0f %10.0f" % (n, p3[:, k].mean(), p3[top, k].mean()))
+if os.environ.get("PROFILE_SAVE"): np.save(os.environ["PROFILE_SAVE"], d[:, 11])
