@@ -35,26 +35,32 @@ def build(force=False, verbose=False, out=None, defines=(), extra=(), unit_flags
     target = out or LIB
     common = ["--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-fno-optimize-sibling-calls", "-fPIC", "-std=c++17",
               "-Wno-unused-value", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc")] + ["-D" + d for d in defines]
-    objs = []
-    procs = []
-    for src, flags in UNITS:
-        if unit_flags and os.path.basename(src) in unit_flags:
-            flags = tuple(unit_flags[os.path.basename(src)])
-        obj = target + "." + os.path.basename(src) + ".o"
-        cmd = [hipcc, "-c"] + common + list(flags) + list(extra) + ["-o", obj, src]
+    import shutil
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="dynenv_build_")   # (objects of concurrent builds of one target never collide)
+    try:
+        objs, procs = [], []
+        for src, flags in UNITS:
+            if unit_flags and os.path.basename(src) in unit_flags:
+                flags = tuple(unit_flags[os.path.basename(src)])
+            obj = os.path.join(tmp, os.path.basename(src) + ".o")
+            cmd = [hipcc, "-c"] + common + list(flags) + list(extra) + ["-o", obj, src]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((cmd, subprocess.Popen(cmd)))
+            objs.append(obj)
+        failed = [(cmd, p.returncode) for cmd, p in procs if p.wait() != 0]   # (every compile is waited for before anything is raised)
+        if failed:
+            raise subprocess.CalledProcessError(failed[0][1], failed[0][0])
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target + ".tmp"] + objs
         if verbose:
             print(" ".join(cmd))
-        procs.append((cmd, subprocess.Popen(cmd)))
-        objs.append(obj)
-    for cmd, p in procs:
-        if p.wait() != 0:
-            raise subprocess.CalledProcessError(p.returncode, cmd)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + objs
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
-    for o in objs:
-        os.remove(o)
+        subprocess.run(cmd, check=True)
+        os.replace(target + ".tmp", target)   # (a reader never sees a half-written library)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+        if os.path.exists(target + ".tmp"):
+            os.remove(target + ".tmp")
     return target
 
 

@@ -1139,8 +1139,21 @@ int dynenv_checkpoint_load(dynenv_t* h, const void* buf_host, size_t nbytes) {
     return fail(DYNENV_ERR_ARG, "checkpoint layout does not match this build");
   HIP_OK(hipDeviceSynchronize());
   const char* in = (const char*)buf_host + sizeof(hd);
+  // ABI 2 kept "an invalid action was seen" and, for Partial observations, "rows beyond the layout's capacity were dropped" in ONE bit
+  // (1) of the per-environment error word, which is part of the checkpointed array; ABI 3 gave the second its own bit 3.  A set bit 1
+  // of an ABI 2 blob of a Partial handle may mean either: it is loaded as both (nothing that was reported goes unreported).
+  const bool partialHandle = h->robocup ? h->R.obs_type == DYNENV_OBS_PARTIAL : h->partial;
+  const void* errArray = h->robocup ? (const void*)h->R.envi : (const void*)h->S.envi;
+  const size_t errStride = h->robocup ? RE_COUNT : EI_COUNT, errWord = h->robocup ? RE_ERR : EI_ERR;
   for (size_t i = 0; i < h->allocs.size(); ++i) {
-    HIP_OK(hipMemcpy(h->allocs[i], in, h->alloc_bytes[i], hipMemcpyHostToDevice));
+    if (hd.abi_version == 2 && partialHandle && h->allocs[i] == errArray) {
+      std::vector<int> w(h->alloc_bytes[i] / sizeof(int));
+      memcpy(w.data(), in, w.size() * sizeof(int));
+      for (size_t e = 0; (e + 1) * errStride <= w.size(); ++e) if (w[e * errStride + errWord] & 2) w[e * errStride + errWord] |= 8;
+      HIP_OK(hipMemcpy(h->allocs[i], w.data(), h->alloc_bytes[i], hipMemcpyHostToDevice));
+    } else {
+      HIP_OK(hipMemcpy(h->allocs[i], in, h->alloc_bytes[i], hipMemcpyHostToDevice));
+    }
     in += h->alloc_bytes[i];
   }
   h->cfg.seed = a.seed;

@@ -1502,7 +1502,9 @@ RC_PROF(T4 = __builtin_amdgcn_s_memtime();)
           rapply_impulse(a, vneg(jj), r1[q]);                                                  \
           rapply_impulse(b, jj, r2[q]);                                                        \
         }
+RC_PROF(unsigned long long nNoop = 0ull;)
         for (int iter = 0; iter < 10; ++iter) {
+RC_PROF(const double pj0 = jn[0], pj1 = jn[1], pj2 = jt[0], pj3 = jt[1];)
           for (int lv = 0; lv < nLv; ++lv) {
             if (solveMe && myLevel == lv) {
               a.v = v2(fX[bodyA], fY[bodyA]); a.w = fW[bodyA];
@@ -1531,7 +1533,9 @@ RC_PROF(T4 = __builtin_amdgcn_s_memtime();)
             L.vx[la] = f.vx0; L.vy[la] = f.vy0; L.w[la] = f.w0; L.vx[lb] = f.vx1; L.vy[lb] = f.vy1; L.w[lb] = f.w1;
           }
           __syncthreads();
+RC_PROF(if (G::ballot((solveMe || isRobot) && !(pj0 == jn[0] && pj1 == jn[1] && pj2 == jt[0] && (isRobot || pj3 == jt[1]))) == 0ull) nNoop += 1ull;)
         }
+RC_PROF(if (lane == 0 && c.genv < 4096u) g_rcprof2[c.genv * 8 + 7] += nNoop;)
         // Non-finite values persist through accumulations: finite feet velocities and pivot impulses at the end mean they were finite
         // all along, i.e. every product the CLEAN arithmetic dropped was a zero.  Otherwise (an overflowing state: never seen) this
         // substep's joints are not the reference's: reported, error bit 5.

@@ -435,6 +435,9 @@ class BatchedDynEnv(object):
         if self._needs_reset:
             raise _capi.DynEnvError("call reset() before step()")
         torch = self._torch
+        if auto_reset and torch.cuda.is_current_stream_capturing():
+            # the host's position in the episode does not advance at replay: a reset decided now would be frozen into the graph (or never come)
+            raise _capi.DynEnvError("step_flat(auto_reset=True) inside a stream capture: capture with auto_reset=False and reset between replays")
         a, head = self._stage_actions(actions)
         if validate and self.env_type == DynEnvType.DRIVE:
             if bool(((a < 0) | (a > 2)).any()):  # DrivingEnvironment.py:365-368
@@ -514,8 +517,17 @@ class BatchedDynEnv(object):
         position follows the blob's `elapsed` - like restore() - so a blob with an edited `elapsed` moves host and device together.
         (Blobs that put different environments at different times make `dones` meaningless; the device keeps stepping them.)"""
         _capi.check(self._lib.dynenv_set_state(self._h, env, C.byref(st), C.sizeof(st)), "dynenv_set_state")
+        step = int(st.elapsed) // self._substeps()
+        if not self._needs_reset and step != self._episode_step and self.num_envs > 1 and not getattr(self, "_set_state_moved", False):
+            # ONE blob with another `elapsed` than the batch's moves the host's episode position - and with it `dones` and the auto-reset of
+            # ALL environments; the device keeps per-environment times.  Legitimate when every environment is being set (the tests do);
+            # said once so that a scene written into one environment does not silently shift the others' episode end.
+            import warnings
+            warnings.warn("set_state: the blob's elapsed (%d) puts the batch's episode position at step %d (was %d): dones / auto-reset of every "
+                          "environment follow it" % (int(st.elapsed), step, self._episode_step), stacklevel=2)
+            self._set_state_moved = True
         self._needs_reset = False
-        self._episode_step = int(st.elapsed) // self._substeps()
+        self._episode_step = step
 
     # ------------------------------------------------------------------ exact checkpoint (SURVEY §8 f4)
     def checkpoint(self):

@@ -716,11 +716,33 @@ static int pair_key(const cpArbiter* arb) {
   return sa < sb ? sa * 64 + sb : sb * 64 + sa;
 }
 
+/* ---------------------------------------------------------------- test modes (tools / tests only; both off in every parity run)
+ * cp_lite_test_reverse_order: colliding pairs are found in DESCENDING slot order instead of ascending - the same pair set, another
+ *   arbiter (= callback and solver) order.  Chipmunk's own order comes out of its BB-tree and nobody here can know it; this is the
+ *   other extreme, to measure what the order is worth (tools/pair_order_cost.py).
+ * cp_lite_test_nudge: every dynamic body's velocity is multiplied by 1 + nudge * u, u in [-1, 1) a hash of (body, step), before the
+ *   step - what another rounding of the same arithmetic does (nudge = 1e-15): the yardstick beside the reversed order.
+ * cpSpace.trace_fn: called at the end of every step (tools/pymunk_crosscheck.py records per-substep states and the arbiter order). */
+int cp_lite_test_reverse_order = 0;
+double cp_lite_test_nudge = 0.0;
+static double nudge_unit(unsigned a, unsigned b, unsigned c) {
+  unsigned h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA6Bu ^ (c + 0x165667B1u) * 0xC2B2AE35u;
+  h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+  return (double)h / 2147483648.0 - 1.0;
+}
+
 void cpSpaceStep(cpSpace* s, double dt) {
   int i, j, it;
   double prev_dt;
   if (dt == 0.0) return;
   s->stamp++;
+  if (cp_lite_test_nudge != 0.0)
+    for (i = 0; i < s->n_bodies; ++i) {
+      cpBody* b = s->bodies[i];
+      b->v.x *= 1.0 + cp_lite_test_nudge * nudge_unit((unsigned)s->stamp, (unsigned)i, 0u);
+      b->v.y *= 1.0 + cp_lite_test_nudge * nudge_unit((unsigned)s->stamp, (unsigned)i, 1u);
+      b->w *= 1.0 + cp_lite_test_nudge * nudge_unit((unsigned)s->stamp, (unsigned)i, 2u);
+    }
   prev_dt = s->curr_dt;
   s->curr_dt = dt;
   for (i = 0; i < s->n_active; ++i) s->active[i]->state = CP_ARB_NORMAL;
@@ -745,11 +767,21 @@ void cpSpaceStep(cpSpace* s, double dt) {
     }
     return;
   }
-  for (i = 0; i < s->n_shapes; ++i) {
-    for (j = i + 1; j < s->n_shapes; ++j) {
-      cpShape *a = s->shapes[i], *b = s->shapes[j];
-      if (a->body->type != CP_BODY_DYNAMIC && b->body->type != CP_BODY_DYNAMIC) continue;
-      collide_shapes(s, a, b);
+  if (!cp_lite_test_reverse_order) {
+    for (i = 0; i < s->n_shapes; ++i) {
+      for (j = i + 1; j < s->n_shapes; ++j) {
+        cpShape *a = s->shapes[i], *b = s->shapes[j];
+        if (a->body->type != CP_BODY_DYNAMIC && b->body->type != CP_BODY_DYNAMIC) continue;
+        collide_shapes(s, a, b);
+      }
+    }
+  } else { /* test mode: the same pairs (a = lower slot), last pair first */
+    for (i = s->n_shapes - 1; i >= 0; --i) {
+      for (j = s->n_shapes - 1; j > i; --j) {
+        cpShape *a = s->shapes[i], *b = s->shapes[j];
+        if (a->body->type != CP_BODY_DYNAMIC && b->body->type != CP_BODY_DYNAMIC) continue;
+        collide_shapes(s, a, b);
+      }
     }
   }
   /* cpSpaceArbiterSetFilter in canonical pair order: separate callbacks + expiry */
@@ -763,7 +795,7 @@ void cpSpaceStep(cpSpace* s, double dt) {
         order[k] = i;
       }
     for (k = 0; k < n; ++k) {
-      cpArbiter* arb = &s->pool[order[k]];
+      cpArbiter* arb = &s->pool[order[cp_lite_test_reverse_order ? n - 1 - k : k]];
       int ticks = s->stamp - arb->stamp;
       if (ticks >= 1 && arb->state != CP_ARB_CACHED) {
         arb->state = CP_ARB_CACHED;
@@ -804,6 +836,7 @@ void cpSpaceStep(cpSpace* s, double dt) {
     cpArbiter* arb = s->active[i];
     if (arb->handler->post_solve) arb->handler->post_solve(arb, s, arb->handler->data);
   }
+  if (s->trace_fn) s->trace_fn(s, s->trace_data);
 }
 
 /* ---------------------------------------------------------------- golden-test hook */

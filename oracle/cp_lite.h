@@ -137,6 +137,8 @@ typedef struct cpSpace {
   int degenerate; /* set (until the space is rebuilt) when two capsule CORES touched or crossed: segment_to_segment then takes shape 1's own
                      normal where Chipmunk's EPA gives the minimum-translation axis - the one narrowphase case in which this restatement
                      and the kernels knowingly leave Chipmunk; error bit 4 of dynenv_error_flags */
+  void (*trace_fn)(struct cpSpace*, void*); /* tools only: called at the end of every cpSpaceStep (NULL: nothing) */
+  void* trace_data;
   int test_free_flight; /* golden tests only: cpSpaceStep = position update + velocity functions, nothing collides, no
                            constraint is solved (what the generator scripts' Space stand-in does, tests/golden/gen_golden.py) */
 } cpSpace;

@@ -503,3 +503,39 @@ int oracle_space_arbiters(oracle_t* o, int env, double* out, int cap) {
 /* how often a capsule pair's cores touched or crossed since the library was loaded (see cp_lite.c) */
 extern long cp_lite_cores_cross;
 long oracle_cp_cores_cross(void) { return cp_lite_cores_cross; }
+
+/* ---- round 6: test modes of the mini-Chipmunk (oracle/cp_lite.c) and the per-substep trace (tools/pair_order_cost.py, tools/pymunk_crosscheck.py) ---- */
+extern int cp_lite_test_reverse_order;
+extern double cp_lite_test_nudge;
+void oracle_test_modes(int reverse_order, double nudge) { cp_lite_test_reverse_order = reverse_order; cp_lite_test_nudge = nudge; }
+
+#define ORACLE_TRACE_BODIES 32
+#define ORACLE_TRACE_ARBS 40
+typedef struct { double* states; int32_t* arbs; int cap, n; } oracle_trace_t;
+static oracle_trace_t g_trace; /* one traced environment at a time (a single-threaded tool) */
+static void trace_step(cpSpace* s, void* data) {
+  oracle_trace_t* t = (oracle_trace_t*)data;
+  int i;
+  if (t->n < t->cap) {
+    double* d = t->states + (size_t)t->n * ORACLE_TRACE_BODIES * 6;
+    int32_t* a = t->arbs + (size_t)t->n * ORACLE_TRACE_ARBS;
+    for (i = 0; i < s->n_bodies && i < ORACLE_TRACE_BODIES; ++i) {
+      const cpBody* b = s->bodies[i];
+      d[6 * i + 0] = b->p.x; d[6 * i + 1] = b->p.y; d[6 * i + 2] = b->a; d[6 * i + 3] = b->v.x; d[6 * i + 4] = b->v.y; d[6 * i + 5] = b->w;
+    }
+    a[0] = s->n_active;
+    for (i = 0; i < s->n_active && i + 1 < ORACLE_TRACE_ARBS; ++i) a[i + 1] = (s->active[i]->a->slot << 8) | s->active[i]->b->slot;
+  }
+  t->n += 1;
+}
+/* After every physics substep of environment `env` from now on (until its space is rebuilt: reset / set_state), record the dynamic
+ * bodies' (px, py, angle, vx, vy, w) in the space's body order into states[cap][32][6] and the active arbiters, in solver order, as
+ * (slotA << 8 | slotB) of the narrowphase's shape order into arbs[cap][40] ([0] = count).  Returns the number of bodies. */
+int oracle_trace_begin(oracle_t* o, int32_t env, double* states, int32_t* arbs, int cap) {
+  cpSpace* s = o->drv ? &o->drv[env].space : &o->rc[env].space;
+  g_trace.states = states; g_trace.arbs = arbs; g_trace.cap = cap; g_trace.n = 0;
+  s->trace_fn = trace_step; s->trace_data = &g_trace;
+  return s->n_bodies;
+}
+int oracle_trace_count(void) { return g_trace.n; }
+void oracle_trace_rewind(void) { g_trace.n = 0; }

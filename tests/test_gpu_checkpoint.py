@@ -192,3 +192,41 @@ def test_checkpoint_restore_with_the_isolation_scheduler_running(E, monkeypatch)
     for x in (iso, ref, fresh):
         assert x.error_flags() == 0
         x.close()
+
+
+@pytest.mark.parametrize("kind", ["driving", "robocup"])
+def test_abi2_checkpoint_of_a_partial_handle_keeps_what_its_error_bit_reported(kind):
+    """ABI 2 kept "invalid action" and, for Partial observations, "rows dropped" in ONE bit (1) of the per-environment error word,
+    which is part of the checkpointed arrays; ABI 3 moved the second to bit 3.  An ABI 2 blob with that bit set loads as BOTH (bits 1 | 3)
+    on a Partial handle - nothing that was reported goes unreported -, an ABI 3 blob as it is."""
+    import struct
+    import dynenv_amd as d
+    kw = dict(observationType=d.ObservationType.PARTIAL, noiseType=d.NoiseType.REALISTIC, noiseMagnitude=3)
+    et, n, k = (d.DynEnvType.DRIVE, 10, 2) if kind == "driving" else (d.DynEnvType.ROBO_CUP, 5, 4)
+    env = d.BatchedDynEnv(et, 8, n, seed=3, **kw)
+    env.reset_flat()
+    a = np.zeros((8, 10, k), np.int32)
+    if k == 4:
+        a[..., 3] = 3
+    a[5, 1, 0] = 9                         # outside the action space: error bit 1
+    env.step_flat(a, auto_reset=False)
+    assert env.error_flags() == 2
+    blob3 = env.checkpoint()
+    assert bytes(blob3[:8]) == b"DYNCKPT2" and struct.unpack_from("<i", blob3, 8)[0] == 3
+    blob2 = blob3.copy()
+    struct.pack_into("<i", blob2, 8, 2)    # the header of a library of ABI 2; no array and no layout changed between the two
+    other = d.BatchedDynEnv(et, 8, n, seed=3, **kw)
+    other.reset_flat()
+    other.restore(blob3)
+    assert other.error_flags() == 2
+    other.restore(blob2)
+    assert other.error_flags() == 2 | 8
+    full = d.BatchedDynEnv(et, 8, n, seed=3)       # Full observations: bit 1 never meant anything else
+    full.reset_flat()
+    full.step_flat(a, auto_reset=False)
+    b = full.checkpoint()
+    struct.pack_into("<i", b, 8, 2)
+    full.restore(b)
+    assert full.error_flags() == 2
+    for e in (env, other, full):
+        e.close()

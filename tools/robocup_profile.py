@@ -34,6 +34,7 @@ for k in top: print("  ", " ".join("%8d" % v for v in d[k]))
 q = np.loadtxt("gpurun_out/rcprof2.txt")[:NE]
 print("contacts + prestep of the slowest environments, cycles per step: candidate list | narrowphase passes | slot record | callbacks, expiry | levels | prestep + bias-lane share | rc_physics calls with contact work")
 for k in top: print("  ", " ".join("%8d" % v for v in q[k, :7]))
+print("solver iterations of the step that changed NO accumulated impulse (of 10 per rc_physics call with an active arbiter), slowest environments:", [int(q[k, 7]) for k in top])
 p3 = np.loadtxt("gpurun_out/rcprof3.txt")[:NE]
 n3 = ["game logic", "position + shape cache + AABB", "broadphase", "quiet test (feet_far_apart)", "velocity update (quiet)", "joints (quiet)", "quiet substeps", "calls of the common part"]
 print("the common part, cycles per step: mean over all environments / mean of the 12 slowest")

@@ -54,7 +54,8 @@ def run(cfg, E, seed, players=None, env_id_offset=0):
     assert dc.all(), "episode should have ended"
     for g, o in zip([x.cpu().numpy() for x in env.episode_stats()], ora.episode_stats()):
         assert np.array_equal(g, o), cfg + ": episode statistics differ"
-    assert env.error_flags() == 0, env.error_flags()
+    assert env.error_flags() == 0, env.error_flags()   # incl. bit 4 (capsule cores touching: a fallback normal) and bit 5 (non-finite solve)
+    assert ora.degenerate() == 0 and ora.overflow() == 0
     extra = ""
     if cfg == "driving":
         c = env.debug_counters()
