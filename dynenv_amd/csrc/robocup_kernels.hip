@@ -851,8 +851,27 @@ DE_DEV void rc_narrowphase(const RcLds& L, int i, int j, RcContacts& out) {  // 
     const double dsq = vlensq(delta), mind = FOOT_RADIUS + FOOT_RADIUS;
     if (dsq > mind * mind) return;
     const double d = dm_sqrt(dsq);
-    const V2 n = (d != 0.0) ? vmul(delta, 1.0 / d) : s1.tn;
-    out.degenerate = dsq < 1e-12;  // cores touching or crossing (d = 0 or rounding noise): no contact normal, where Chipmunk's EPA has the minimum-translation axis (oracle/cp_lite.c segment_to_segment, CP_CORES_TOUCH_DSQ): reported, never silent
+    V2 n = (d != 0.0) ? vmul(delta, 1.0 / d) : s1.tn;
+    if (dsq < 1e-12) {
+      // Cores that touch or CROSS (oracle/cp_lite.c cores_crossing_normal, operation for operation): Chipmunk's EPA answers with the inward
+      // normal of the edge of the Minkowski difference closest to the origin = the smallest of the four "one end point back onto the
+      // other core's line" translations.  Reached in play by the two feet of one robot that has been knocked about.
+      const V2 dA = vsub(s1.tb, s1.ta), dB = vsub(s2.tb, s2.ta);
+      const V2 uA = vmul(dA, 1.0 / dm_sqrt(vlensq(dA))), uB = vmul(dB, 1.0 / dm_sqrt(vlensq(dB)));
+      const double s0 = vcross(uA, vsub(s2.ta, s1.ta)), s1_ = vcross(uA, vsub(s2.tb, s1.ta));
+      const double t0 = vcross(uB, vsub(s1.ta, s2.ta)), t1 = vcross(uB, vsub(s1.tb, s2.ta));
+      const bool crossing = s0 * s1_ <= 0.0 && t0 * t1 <= 0.0;
+      bool exact0 = false;
+      if (crossing) {
+        double best = dm_abs(s0);
+        n = s0 > 0.0 ? vneg(vperp(uA)) : vperp(uA);
+        if (dm_abs(s1_) < best) { best = dm_abs(s1_); n = s1_ > 0.0 ? vneg(vperp(uA)) : vperp(uA); }
+        if (dm_abs(t0) < best) { best = dm_abs(t0); n = t0 > 0.0 ? vperp(uB) : vneg(vperp(uB)); }
+        if (dm_abs(t1) < best) { best = dm_abs(t1); n = t1 > 0.0 ? vperp(uB) : vneg(vperp(uB)); }
+        exact0 = best == 0.0;
+      }
+      out.degenerate = exact0 || (!crossing && d == 0.0);  // the normal's sign is a convention there: reported, error bit 4
+    }
     rc_contact_points(support_edge_segment(s1, i, n), support_edge_segment(s2, j, vneg(n)), FOOT_RADIUS, FOOT_RADIUS, n, out);
   } else if (i < RC_BALL) {  // circle (ball or goalpost) = shape a, capsule foot i = shape b
     const V2 center = v2(L.cpx[j], L.cpy[j]);  // (the ball's shape cache or a goalpost's constant slot)

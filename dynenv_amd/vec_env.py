@@ -790,10 +790,10 @@ class BatchedDynEnv(object):
         if self.env_type == DynEnvType.ROBO_CUP and self.error_flags() & 32:
             raise _capi.DynEnvError("RoboCup: a velocity or joint impulse left the finite range (error bit 5): the state is not the reference's any more")
         if self.env_type == DynEnvType.ROBO_CUP and self.error_flags() & 16:
-            # two capsule cores touched or crossed: the narrowphase took a fallback normal where Chipmunk's EPA has a real one
-            # (Robot.py:38-52; include/dynenv.h, error bit 4) - not pymunk's trajectory from here on, never silently
-            raise _capi.DynEnvError("RoboCup: two feet lie across each other (capsule cores crossed): the contact normal is a fallback, "
-                                    "not Chipmunk's (error bit 4); reset() or set_state() clears it")
+            # two capsule cores exactly collinear / exactly touching: the sign of the contact normal is a convention there
+            # (Robot.py:38-52; include/dynenv.h, error bit 4) - possibly not pymunk's trajectory from here on, never silently
+            raise _capi.DynEnvError("RoboCup: the cores of two feet are exactly collinear / touching: the contact normal's sign is a convention "
+                                    "(error bit 4); reset() or set_state() clears it")
         done = bool(self.last_done)
         dones = np.full((self.num_envs,), done, dtype=bool)
         # The step's observations stay in HBM (a snapshot: self.obs is rewritten by the next step) until somebody looks at them:

@@ -217,10 +217,11 @@ int dynenv_sync(dynenv_t* h, void* stream);
  * pedestrians / 16 lanes), astronomically unlikely, and no longer silent: the host mirror's step() raises on it; bit 2: Driving Partial, the list of environments left to the deferred
  * observation launch is full - it is cleared between steps by launches that alternate a parity; a guard that no supported use
  * reaches: a captured dynenv_step keeps that parity on the device); bit 4 (value 16): RoboCup, the CORES of two
- * capsules (feet, Robot.py:38-52) touched or crossed (closer than 1e-6 px) - the narrowphase then has no contact normal and takes shape 1's own or the direction of a rounding error, where
- * Chipmunk's EPA gives the minimum-translation axis: from that substep on the environment is no longer what pymunk would have
- * computed.  Never reached in play (feet are 15 px thick); a dynenv_set_state blob or a teleport can put two
- * feet across each other.  Sticky until the next reset / set_state; the host mirror's step() raises on it; bit 5 (value 32):
+ * capsules (feet, Robot.py:38-52) were exactly collinear or exactly touching.  Cores that CROSS - the two feet of one robot that
+ * has been knocked about get there in play - take the normal Chipmunk's EPA gives (the minimum-translation axis of the two cores;
+ * DESIGN.md 2b); in this measure-zero case even that normal's SIGN is a convention, and from that substep on the environment may
+ * not be what pymunk would have computed.  A dynenv_set_state blob can put two feet on one line.  Sticky until the next reset /
+ * set_state; the host mirror's step() raises on it; bit 5 (value 32):
  * RoboCup, a foot velocity or a joint impulse left the finite range during a solve (never seen): the joints' arithmetic drops
  * products that are zeros for finite operands only, so that substep is not the reference's - reported like bit 4.
  * Synchronises the device. */

@@ -391,25 +391,57 @@ static void closest_seg_seg(cpv p1, cpv q1, cpv p2, cpv q2, cpv* c1, cpv* c2) {
   *c2 = cpvadd(p2, cpvmult(d2, t));
 }
 
-/* diagnostics (tools / tests): capsule pairs whose CORES touched or crossed (closest distance below 1e-6: the normal is s1's own or the
- * direction of a rounding error, where Chipmunk's EPA would give the minimum-translation axis - DESIGN.md 2b) */
-long cp_lite_cores_cross = 0;
+/* Capsule cores that touch or CROSS (closest distance below 1e-6: an exact 0, or the rounding noise of the crossing point computed twice).
+ * Two feet of ONE robot get there in play once the robot has been knocked about (the rotary limit joint is soft: feet a radian apart,
+ * RoboCup seed 42, environment 1193, step 119 - found by error bit 4 in round 6; the `d == 0` counter of round 5 never saw it because a
+ * crossing comes out as ~1e-15, not 0).  The closest-point formula has no normal there.  Chipmunk's GJK finds the origin INSIDE the
+ * Minkowski difference B - A of the two cores - a parallelogram with two edges parallel to each core - and its EPA answers with the
+ * inward normal of the edge closest to the origin and minus that distance (cpCollision.c EPA / ClosestPointsNew).  The four edges are the
+ * four "bring one end point back onto the other core's line" translations:
+ *   edge {b_k - a(t)}: distance |s_k|, s_k = cross(uA, b_k - a_0), inward normal -sign(s_k) perp(uA)      (end k of B against A's line)
+ *   edge {b(t) - a_k}: distance |t_k|, t_k = cross(uB, a_k - b_0), inward normal +sign(t_k) perp(uB)      (end k of A against B's line)
+ * (n points from shape 1 to shape 2: pushing shape 2 along n by the distance separates the cores).  Candidates in the order s_0, s_1, t_0,
+ * t_1, the first strictly smallest wins (which of two EQUAL edges Chipmunk's EPA takes depends on its hull order: unknowable, measure zero).
+ * Returns 0 when the cores are close without crossing (the end points of one core on ONE side of the other's line): then the closest
+ * points have a direction, however small the distance.  *exact0 = the winning distance is exactly 0 (collinear or exactly touching
+ * cores: the normal's SIGN is a convention) -> cpSpace.degenerate, error bit 4. */
+long cp_lite_cores_cross = 0; /* diagnostics (tools / tests): narrowphase calls that took the crossing branch */
 #define CP_CORES_TOUCH_DSQ 1e-12 /* (1e-6 px)^2; the kernels use the same constant (robocup_kernels.hip rc_narrowphase) */
+static int cores_crossing_normal(const cpShape* s1, const cpShape* s2, cpv* n, int* exact0) {
+  cpv dA = cpvsub(s1->tb, s1->ta), dB = cpvsub(s2->tb, s2->ta);
+  cpv uA = cpvmult(dA, 1.0 / dm_sqrt(cpvlengthsq(dA))), uB = cpvmult(dB, 1.0 / dm_sqrt(cpvlengthsq(dB)));
+  double s0 = cpvcross(uA, cpvsub(s2->ta, s1->ta)), s1_ = cpvcross(uA, cpvsub(s2->tb, s1->ta));
+  double t0 = cpvcross(uB, cpvsub(s1->ta, s2->ta)), t1 = cpvcross(uB, cpvsub(s1->tb, s2->ta));
+  double best;
+  if (!(s0 * s1_ <= 0.0 && t0 * t1 <= 0.0)) return 0;
+  best = fabs(s0); *n = (s0 > 0.0 ? cpvneg(cpvperp(uA)) : cpvperp(uA));
+  if (fabs(s1_) < best) { best = fabs(s1_); *n = (s1_ > 0.0 ? cpvneg(cpvperp(uA)) : cpvperp(uA)); }
+  if (fabs(t0) < best) { best = fabs(t0); *n = (t0 > 0.0 ? cpvperp(uB) : cpvneg(cpvperp(uB))); }
+  if (fabs(t1) < best) { best = fabs(t1); *n = (t1 > 0.0 ? cpvperp(uB) : cpvneg(cpvperp(uB))); }
+  *exact0 = best == 0.0;
+  return 1;
+}
 
 static void segment_to_segment(cpShape* s1, cpShape* s2, cpCollisionInfo* info) {
   cpv a, b, delta, n;
   double dsq, d, mind = s1->r + s2->r;
+  int crossing = 0, exact0 = 0;
   closest_seg_seg(s1->ta, s1->tb, s2->ta, s2->tb, &a, &b);
   delta = cpvsub(b, a);
   dsq = cpvlengthsq(delta);
   if (dsq > mind * mind) return;
   d = dm_sqrt(dsq);
-  if (dsq < CP_CORES_TOUCH_DSQ) { /* crossing cores come out as d = 0 or as rounding noise (~1e-15): neither has a contact normal */
-    info->degenerate = 1; /* -> cpSpace.degenerate, error bit 4 of both sides (include/dynenv.h) */
-#pragma omp atomic
-    cp_lite_cores_cross++;
-  }
   n = (d != 0.0 ? cpvmult(delta, 1.0 / d) : s1->tn);
+  if (dsq < CP_CORES_TOUCH_DSQ) {
+    cpv nx;
+    crossing = cores_crossing_normal(s1, s2, &nx, &exact0);
+    if (crossing) {
+      n = nx;
+#pragma omp atomic
+      cp_lite_cores_cross++;
+    }
+    if (exact0 || (!crossing && d == 0.0)) info->degenerate = 1; /* -> cpSpace.degenerate, error bit 4 of both sides (include/dynenv.h) */
+  }
   contact_points(support_edge_segment(s1, n), support_edge_segment(s2, cpvneg(n)), n, info);
 }
 

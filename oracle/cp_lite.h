@@ -134,9 +134,9 @@ typedef struct cpSpace {
   cpHandler handlers[CP_MAX_HANDLERS];
   cpHandler default_handler;
   int overflow; /* set if a fixed capacity was exceeded */
-  int degenerate; /* set (until the space is rebuilt) when two capsule CORES touched or crossed: segment_to_segment then takes shape 1's own
-                     normal where Chipmunk's EPA gives the minimum-translation axis - the one narrowphase case in which this restatement
-                     and the kernels knowingly leave Chipmunk; error bit 4 of dynenv_error_flags */
+  int degenerate; /* set (until the space is rebuilt) when two capsule CORES were exactly collinear / exactly touching: the sign of the
+                     minimum-translation normal segment_to_segment takes for crossing cores is a convention there (cores_crossing_normal in
+                     cp_lite.c); error bit 4 of dynenv_error_flags */
   void (*trace_fn)(struct cpSpace*, void*); /* tools only: called at the end of every cpSpaceStep (NULL: nothing) */
   void* trace_data;
   int test_free_flight; /* golden tests only: cpSpaceStep = position update + velocity functions, nothing collides, no

@@ -309,48 +309,40 @@ def test_malformed_actions_raise_a_flag_and_move_nothing(gpu, kind):
     env.close()
 
 
-def test_crossed_capsule_cores_are_reported_on_both_sides(gpu):
-    """two feet laid across each other (dynenv_set_state) have no contact normal - error bit 4 on the HIP path and in the
-    oracle, states still bit-identical, sticky until set_state / reset; the compat step() raises like for dropped rows; feet that merely
-    overlap (cores 1e-3 px from touching) raise nothing.  The 4096 x 240 soaks assert the flag stays down in play."""
+def test_crossed_capsule_cores_on_both_sides(gpu):
+    """a foot laid across another (dynenv_set_state) takes Chipmunk's minimum-translation normal on both sides, bit for
+    bit; cores exactly collinear - where even that normal's sign is a convention - raise error bit 4 on the HIP path and in the oracle,
+    sticky until set_state / reset, and the compat step() raises; feet that merely overlap raise nothing.  The 4096 x 240 soaks assert
+    the flag stays down in play."""
     import math
+    from test_kat_general import _feet_scene
     dynenv_amd, torch, _ = gpu
     flags = ol.FLAG_USE_OBS_REWARDS
-    env = dynenv_amd.BatchedDynEnv(dynenv_amd.DynEnvType.ROBO_CUP, 3, 5, seed=3, flags=flags)
-    ora = ol.OracleEnv(env_type=0, num_envs=3, n_players=5, seed=3, flags=flags)
+    env = dynenv_amd.BatchedDynEnv(dynenv_amd.DynEnvType.ROBO_CUP, 4, 5, seed=3, flags=flags)
+    ora = ol.OracleEnv(env_type=0, num_envs=4, n_players=5, seed=3, flags=flags)
     env.reset_flat(); ora.reset()
-    a = np.zeros((3, 10, 4), np.int32)
+    a = np.zeros((4, 10, 4), np.int32)
     a[..., 3] = 3
-    st = ora.get_state(1)
-    A, B = st.robots[0], st.robots[5]
-    for f in ("l", "r"):      # A's left core: (x - 10, y + 10)..(x + 10, y + 10); B turned by 90 degrees, its left core crossing that one in the middle
-        setattr(A, f + "a", 0.0); setattr(B, f + "a", math.pi / 2)
-        setattr(B, f + "px", A.lpx + 10.0); setattr(B, f + "py", A.lpy + 10.0)
-    st2 = ora.get_state(2)
-    A, B = st2.robots[0], st2.robots[5]
-    for f in ("l", "r"):      # B beside A: B's right core 1e-3 px above A's left core (capsules 15 px deep into each other)
-        setattr(A, f + "a", 0.0); setattr(B, f + "a", 0.0)
-        setattr(B, f + "px", A.lpx); setattr(B, f + "py", A.lpy + 20.0 + 1e-3)
+    scenes = {1: _feet_scene(ora, 1, math.pi / 2, 10.0, 19.0), 2: _feet_scene(ora, 2, 0.0, 0.0, 20.0 + 1e-3), 3: _feet_scene(ora, 3, 0.0, 5.0, 20.0)}
     for sim in (ora, env):
-        sim.set_state(1, st); sim.set_state(2, st2)
+        for i, st in scenes.items():
+            sim.set_state(i, st)
     assert env.error_flags() == 0
-    og, rg, _ = env.step_flat(a, auto_reset=False)
-    oc, rc, _ = ora.step(a)
-    np.testing.assert_array_equal(og.cpu().numpy(), oc)
-    np.testing.assert_array_equal(rg.cpu().numpy(), rc)
-    assert [ora.degenerate_env(i) for i in range(3)] == [0, 16, 0]
-    assert env.error_flags() == ora.degenerate() == 16
-    for i in range(3):
-        assert bytes(env.get_state(i)) == bytes(ora.get_state(i)), i
-    env.step_flat(a, auto_reset=False)
-    assert env.error_flags() == 16                      # sticky
-    env.set_state(1, ora.get_state(0))
-    assert env.error_flags() == 0                       # set_state clears the environment's flags
+    for _ in range(2):
+        og, rg, _d = env.step_flat(a, auto_reset=False)
+        oc, rc, _d = ora.step(a)
+        np.testing.assert_array_equal(og.cpu().numpy(), oc)
+        np.testing.assert_array_equal(rg.cpu().numpy(), rc)
+        for i in range(4):
+            assert bytes(env.get_state(i)) == bytes(ora.get_state(i)), i
+    assert [ora.degenerate_env(i) for i in range(4)] == [0, 0, 0, 16]
+    assert env.error_flags() == ora.degenerate() == 16      # sticky
+    env.set_state(3, ora.get_state(0))
+    assert env.error_flags() == 0                           # set_state clears the environment's flags
     env.close()
-    # the compat step() raises
     venv, _ = dynenv_amd.make_dyn_env(dynenv_amd.DynEnvType.ROBO_CUP, 2, 5, False, dynenv_amd.ObservationType.FULL, dynenv_amd.NoiseType.REALISTIC, 0.0, False)
     venv.reset()
-    venv.set_state(1, st)
+    venv.set_state(1, scenes[3])
     with pytest.raises(Exception, match="error bit 4"):
         venv.step(np.zeros((2, 10, 4), np.int64) + np.array([0, 0, 0, 3]))
     venv.close()
