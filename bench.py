@@ -51,6 +51,12 @@ def host_core_share():
     return max(1, min(n, 16))
 
 
+# idle OpenMP workers sleep instead of spinning: a thread count above the cgroup's core share (cpu_baseline_all_cores) then measures the
+# share's throughput instead of 256 threads burning 16 cores' time slices in spin loops (read by libgomp when it starts, i.e. before
+# oracle/liboracle.so is loaded)
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
+
 def cpu_baseline(E, n_players, A, seed, robocup=False, target_seconds=12.0, partial=False, threads=None):
     """The CPU restatement (oracle, kind='port') timed on this box's host cores on a bounded sample of the same
     workload.  It is a C restatement, i.e. a much stronger baseline than the reference's Python+pymunk path, which
@@ -321,6 +327,7 @@ def plumbing_leg(torch, device, seed):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib as ol
+    from dynenv_amd import BatchedDynEnv, DynEnvType
     ol.build()
     env = ol.OracleEnv(env_type=1, num_envs=1, n_players=2, seed=seed, threads=1)
     env.reset()
@@ -330,7 +337,21 @@ def plumbing_leg(torch, device, seed):
     for a in acts:
         env.step(a)
     dt = time.perf_counter() - t0
-    return {"workload": "DrivingEnvironment nPlayers=2 Full obs, noise=0, 1 env (BASELINE.json configs[0])", "steps": 600,
+    # BASELINE.md B0 asks for the parity result of this configuration beside its rate: the same 600 steps on both sides, untimed,
+    # observations / rewards / dones of every step compared bit for bit (the oracle here is the CHECKER, never the thing measured)
+    genv = BatchedDynEnv(DynEnvType.DRIVE, 1, 2, seed=seed, device=device)
+    oenv = ol.OracleEnv(env_type=1, num_envs=1, n_players=2, seed=seed, threads=1)
+    same = bool(np.array_equal(genv.reset_flat().cpu().numpy(), oenv.reset()))
+    mismatches = 0 if same else 1
+    for a in acts:
+        og, rg, dg = genv.step_flat(a, auto_reset=False)
+        oc, rc, dc = oenv.step(a)
+        ok = np.array_equal(og.cpu().numpy(), oc) and np.array_equal(rg.cpu().numpy(), rc) and np.array_equal(dg.cpu().numpy(), dc)
+        mismatches += 0 if ok else 1
+    parity = {"steps_compared": len(acts), "steps_with_a_mismatch": mismatches, "error_flags": genv.error_flags(),
+              "what": "reset observation + observations, rewards, dones of all 600 steps of the episode, HIP path vs CPU oracle, bit for bit"}
+    genv.close()
+    return {"workload": "DrivingEnvironment nPlayers=2 Full obs, noise=0, 1 env (BASELINE.json configs[0])", "steps": 600, "parity": parity,
             "gpu_env_steps_per_s": 1.0 / (gpu["ms_per_step"] * 1e-3), "gpu_ms_per_step": gpu["ms_per_step"],
             "cpu_port_env_steps_per_s": 600 / dt, "cpu_threads": 1,
             "note": "one environment cannot fill a GPU (one wave of 64 lanes): this leg is the plumbing check BASELINE.md asks for"}
@@ -367,10 +388,12 @@ def arranger_leg(torch, device, E, seed, feat=128, reps=30):
     n_obj = [int(i.shape[0]) for i in inputs]
     b_out = sum(n_obj) * feat * 4 + padded.numel() * 4
     env.close()
+    traffic, tdetail = measured_traffic("arr_pad_cols_kernel")   # (tools/profile_round.sh "hbm": the same sizes under rocprofv3 --pmc; stale -> null)
     return {"what": "GpuInOutArranger on Driving Full observations (SURVEY 8 f1)", "envs": E, "objects": n_obj, "max_count": int(countArr[1]),
             "embed_width": feat, "rearrange_inputs_ms": ms_in, "rearrange_outputs_ms": ms_out,
             "roofline": {"bound": "hbm", "kernel": "arr_pad_cols_kernel", "alg_bytes": b_out, "achieved": b_out / (ms_out * 1e-3) / 1e9,
-                         "peak": 8000.0, "unit": "GB/s", "frac": b_out / (ms_out * 1e-3) / 1e9 / 8000.0}}
+                         "peak": 8000.0, "unit": "GB/s", "frac": b_out / (ms_out * 1e-3) / 1e9 / 8000.0, "traffic": traffic,
+                         "traffic_source": tdetail.get("traffic_source")}}
 
 
 def launch_ranks(n):
@@ -717,6 +740,10 @@ def main():
         if world == 1 and not args.no_extra_legs and gather is None:
             env.close()
             out["other_configs"] = [episode_leg(torch, device, w, E, args.seed) for w in WORKLOADS if w != args.workload]
+            if not args.no_cpu_baseline:   # the CPU port beside every MI355X figure, a bounded sample each
+                for leg in out["other_configs"]:
+                    wl = WORKLOADS[leg["workload"]]
+                    leg["cpu_baseline"] = cpu_baseline(E, wl[2], 10, args.seed, wl[0], target_seconds=5.0, partial=wl[1])
             if args.workload == "driving":  # what the idle tail of a 4096-environment launch is worth (DESIGN.md "Batch size")
                 out["throughput_vs_batch"] = [batch_leg(torch, device, e_, k_, args.seed)
                                               for e_, k_ in ((E, 2), (2 * E, 1), (4 * E, 1), (8 * E, 1))]
@@ -727,9 +754,22 @@ def main():
             out["cpu_baseline"] = cpu_baseline(E, n_players, A, args.seed, robocup, partial=partial)
             # BASELINE.md section 3 / SURVEY 8d name threads = os.cpu_count(): the same sample with one thread per logical CPU of the box
             # (on a GPU box whose cgroup grants 16 cores of an EPYC this OVERSUBSCRIBES the share; both figures are in the line)
+            # (threads beyond the cgroup's core share are OVERSUBSCRIBED: with OMP_WAIT_POLICY=passive, set above, idle workers sleep, so
+            #  the figure measures what the share delivers with that many threads - it cannot exceed the share's - and the note says so)
             allc = os.cpu_count() or 1
-            out["cpu_baseline_all_cores"] = (dict(out["cpu_baseline"], note="os.cpu_count() == the core share: same run") if allc == out["cpu_baseline"]["cores"]
-                                             else cpu_baseline(E, n_players, A, args.seed, robocup, partial=partial, target_seconds=8.0, threads=allc))
+            try:
+                allc = min(allc, len(os.sched_getaffinity(0)))
+            except AttributeError:
+                pass
+            share = out["cpu_baseline"]["cores"]
+            if allc == share:
+                out["cpu_baseline_all_cores"] = dict(out["cpu_baseline"], note="threads = min(os.cpu_count(), affinity mask) = the cgroup's core share (%d): the same run" % share)
+            else:
+                out["cpu_baseline_all_cores"] = dict(
+                    cpu_baseline(E, n_players, A, args.seed, robocup, partial=partial, target_seconds=8.0, threads=allc),
+                    note="%d OpenMP threads (min of os.cpu_count() and the affinity mask) on a cgroup share of %d cores: OVERSUBSCRIBED %.0fx; "
+                         "OMP_WAIT_POLICY=%s. Not a measurement of %d cores - read cpu_baseline (threads = the share) for the host's rate"
+                         % (allc, share, allc / share, os.environ.get("OMP_WAIT_POLICY"), allc))
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
         sys.stdout.flush()

@@ -745,18 +745,19 @@ DE_DEV void arb_apply_impulse(BodyV& a, BodyV& b, V2 n, const V2* r1, const V2* 
 DE_DEV bool arb_apply_bias_only(BodyV& a, BodyV& b, V2 n, const V2* r1, const V2* r2, const double* nMass, const double* bias,
                                 double* jBias, int count) {
   bool changed = false;
-#pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    if (c < count) {
-      double vbn = bias_rel_n(a, b, r1[c], r2[c], n);
-      double jbnOld = jBias[c];
-      jBias[c] = dms_acc_clamp0(bias[c] - vbn, nMass[c], jbnOld);
-      changed |= jBias[c] != jbnOld;
-      V2 jb = vmul(n, jBias[c] - jbnOld);
-      apply_bias_impulse(a, vneg(jb), r1[c]);
-      apply_bias_impulse(b, jb, r2[c]);
-    }
+#define DRV_BIAS_PASS(c)                                              \
+  {                                                                   \
+    double vbn = bias_rel_n(a, b, r1[c], r2[c], n);                   \
+    double jbnOld = jBias[c];                                         \
+    jBias[c] = dms_acc_clamp0(bias[c] - vbn, nMass[c], jbnOld);       \
+    changed |= jBias[c] != jbnOld;                                    \
+    V2 jb = vmul(n, jBias[c] - jbnOld);                               \
+    apply_bias_impulse(a, vneg(jb), r1[c]);                           \
+    apply_bias_impulse(b, jb, r2[c]);                                 \
   }
+  DRV_BIAS_PASS(0)   // (an active arbiter has one contact or two)
+  if (count > 1) DRV_BIAS_PASS(1)
+#undef DRV_BIAS_PASS
   return changed;
 }
 DE_DEV bool arb_is_bias_only(const BodyV& a, const BodyV& b, const double* jn, const double* jt, const double* bounce, int count) {
@@ -774,6 +775,15 @@ DE_DEV void body_load_bias(const DrvLds& L, int idx, BodyV& b) {
 DE_DEV void body_store_bias(DrvLds& L, int idx, const BodyV& b) {
   if (idx < DRV_SLOT_OBST) { L.vbx[idx] = b.vb.x; L.vby[idx] = b.vb.y; L.wb[idx] = b.wb; }
 }
+// Branch-free access for the sweeps (round 6, as in the RoboCup solver): a static partner reads the zeros of body slot 30 - unused,
+// cleared by load_env, never written - and writes to slot 31, which nobody reads; its velocities are +0 after every finite impulse
+// (x * 0 + 0), so reloading zeros is what keeping them in registers was.  Every `if (dynamic)` around a load or a store was a
+// saveexec + a taken branch into an out-of-line block: ~40 cycles each for a lone wave, four per pass.
+#define DRV_ZERO_SLOT 30
+#define DRV_SINK_SLOT 31
+static_assert(DRV_SLOT_OBST == DRV_ZERO_SLOT && DRV_NB == 32, "body slots 30 and 31 are free");
+DE_DEV int body_rd(int idx) { return idx < DRV_SLOT_OBST ? idx : DRV_ZERO_SLOT; }
+DE_DEV int body_wr(int idx) { return idx < DRV_SLOT_OBST ? idx : DRV_SINK_SLOT; }
 
 // ------------------------------------------------------------------------------------------------
 // The sweeps of a GENERAL multi-level solve (some arbiter with moving bodies or accumulated impulses, arbiters sharing bodies:
@@ -829,34 +839,34 @@ DE_OOL DrvSplitRet drv_solve_general_split(int lane, int myLevel_, int bodyAB, i
   a.v = b.v = v2(0.0, 0.0); a.w = b.w = 0.0;  // statics: all-zero and never stored
   const int nSteps = maxLevel + 1 + period * 9;  // pipelined sweeps, see drv_prestep_solve
   int due = myLevel, passes = 0;
+  const int ra = body_rd(bodyA), rb = body_rd(bodyB), wa = body_wr(bodyA), wb_ = body_wr(bodyB);
+#define DRV_SPLIT_PASS(q)                                                                   \
+  {                                                                                         \
+    const V2 vr = relative_velocity(a, b, r1[q], r2[q]);                                    \
+    const double vn = vdot_f(vr, n);                                                        \
+    const double t0 = cq[q] + (biasLane ? -vn : vn);                                        \
+    const double old = acc[q];                                                              \
+    acc[q] = dms_acc_clamp0(biasLane ? t0 : -t0, nM[q], old);                               \
+    const double dj = acc[q] - old;                                                         \
+    const V2 jr = vrotate_f(n, v2(dj, 0.0));                                                \
+    const V2 jl = vmul(n, dj);                                                              \
+    const V2 jj = biasLane ? jl : jr;                                                       \
+    apply_impulse(a, vneg(jj), r1[q]);                                                      \
+    apply_impulse(b, jj, r2[q]);                                                            \
+  }
   for (int t = 0; t < nSteps; ++t) {
     if (active && t == due && passes < 10) {
-      if (aDyn) { a.v = v2(fX[bodyA], fY[bodyA]); a.w = fW[bodyA]; }
-      if (bDyn) { b.v = v2(fX[bodyB], fY[bodyB]); b.w = fW[bodyB]; }
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        if (q < count) {
-          const V2 vr = relative_velocity(a, b, r1[q], r2[q]);
-          const double vn = vdot_f(vr, n);
-          // velocity: jn = max(jn - (bounce + vrn) * nMass, 0);  bias: jBias = max(jBias + (bias - vbn) * nMass, 0), each one fma
-          // (x - y is x + (-y), negation is exact)
-          const double t0 = cq[q] + (biasLane ? -vn : vn);
-          const double old = acc[q];
-          acc[q] = dms_acc_clamp0(biasLane ? t0 : -t0, nM[q], old);
-          const double dj = acc[q] - old;
-          const V2 jr = vrotate_f(n, v2(dj, 0.0));  // velocity: normal + (zero) tangent impulse through cpvrotate, as in the reference
-          const V2 jl = vmul(n, dj);              // bias: no tangent term, not even a zero one (sign of zero)
-          const V2 jj = biasLane ? jl : jr;
-          apply_impulse(a, vneg(jj), r1[q]);
-          apply_impulse(b, jj, r2[q]);
-        }
-      }
-      if (aDyn) { fX[bodyA] = a.v.x; fY[bodyA] = a.v.y; fW[bodyA] = a.w; }
-      if (bDyn) { fX[bodyB] = b.v.x; fY[bodyB] = b.v.y; fW[bodyB] = b.w; }
+      a.v = v2(fX[ra], fY[ra]); a.w = fW[ra];
+      b.v = v2(fX[rb], fY[rb]); b.w = fW[rb];
+      DRV_SPLIT_PASS(0)
+      if (count > 1) DRV_SPLIT_PASS(1)
+      fX[wa] = a.v.x; fY[wa] = a.v.y; fW[wa] = a.w;
+      fX[wb_] = b.v.x; fY[wb_] = b.v.y; fW[wb_] = b.w;
       due += period; ++passes;
     }
     __syncthreads();
   }
+#undef DRV_SPLIT_PASS
   DrvSplitRet r;
   r.jt0 = jt0; r.jt1 = jt1; r.pk = pk; r.pair = pair; r.bits = bits3;  // the caller's own values, handed back
   r.jn0 = acc[0]; r.jn1 = acc[1];
@@ -987,13 +997,14 @@ DRV_PROF(profMode = wave_ballot(!biasOnly) == 0ull ? 3 : 4;)
     if (wave_ballot(!biasOnly) == 0ull) {
       // every active arbiter is a resting contact being pushed out of penetration (the pile-ups that make up the launch's
       // tail): only bias velocities move, through LDS
+      const int ra = body_rd(bodyA), rb = body_rd(bodyB), wa = body_wr(bodyA), wb_ = body_wr(bodyB);
       for (int t = 0; t < nSteps; ++t) {
         if (active && t == due && passes < 10) {
-          body_load_bias(L, bodyA, a);
-          body_load_bias(L, bodyB, b);
+          a.vb = v2(L.vbx[ra], L.vby[ra]); a.wb = L.wb[ra];
+          b.vb = v2(L.vbx[rb], L.vby[rb]); b.wb = L.wb[rb];
           arb_apply_bias_only(a, b, n, r1, r2, nMass, bias, jBias, a_count);
-          body_store_bias(L, bodyA, a);
-          body_store_bias(L, bodyB, b);
+          L.vbx[wa] = a.vb.x; L.vby[wa] = a.vb.y; L.wb[wa] = a.wb;
+          L.vbx[wb_] = b.vb.x; L.vby[wb_] = b.vb.y; L.wb[wb_] = b.wb;
           due += period; ++passes;
         }
         __syncthreads();

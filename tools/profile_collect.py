@@ -14,7 +14,8 @@ import bench  # noqa: E402  (kernel_source_sha, nothing else)
 
 STEP_KERNELS = {"driving": ["drv_step_kernel"], "robocup": ["rc_step_kernel"],
                 "driving_partial": ["drv_step_partial_kernel", "drv_partial_obs_deferred_kernel"],
-                "robocup_partial": ["rc_step_partial_kernel", "rc_partial_obs_deferred_kernel", "rc_partial_finalize_kernel"]}
+                "robocup_partial": ["rc_step_partial_kernel", "rc_partial_obs_deferred_kernel", "rc_partial_finalize_kernel"],
+                "hbm": ["arr_pad_cols_kernel", "obs_unpack_peers_rows_kernel"]}   # tools/hbm_kernels_run.py: the two HBM-bound kernels, separate programs of one run
 
 
 def counters(pattern):
@@ -61,6 +62,24 @@ def main():
             fb, wb = sum(fv) / len(fv) * 1024 * 2, sum(wv) / len(wv) * 1024
             per[k] = {"fetch_bytes_x2": fb, "write_bytes": wb, "launches": len(fv), "workload": w}
             total += fb + wb
+        if w == "hbm":   # two unrelated kernels: each its own total; their algorithmic bytes and kernel-stats durations beside the traffic
+            try:
+                alg = json.loads(open("gpurun_out/%s_bench_hbm_under_rocprof.json" % tag).read().strip().splitlines()[-1])
+                rows = {r["Name"].split("(")[0]: float(r["AverageNs"]) for r in csv.DictReader(open("gpurun_out/%s_kernel_stats_hbm.csv" % tag))}
+            except (OSError, ValueError, IndexError):
+                alg, rows = {}, {}
+            for k, d in per.items():
+                d["alg_bytes"] = alg.get(k, {}).get("alg_bytes")
+                d["average_ns"] = rows.get(k)
+                if d["alg_bytes"] and d["average_ns"]:
+                    d["achieved_GBps"] = d["alg_bytes"] / d["average_ns"]
+                    d["frac_of_8TBps"] = d["achieved_GBps"] / 8000.0
+                    d["traffic_over_alg"] = (d["fetch_bytes_x2"] + d["write_bytes"]) / d["alg_bytes"]
+                total = d["fetch_bytes_x2"] + d["write_bytes"]
+                d["step_bytes_all_kernels"] = total
+                out[k + "_bytes_per_launch"] = total
+                out[k + "_detail"] = d
+            continue
         for k, d in per.items():
             d["step_bytes_all_kernels"] = total
             out[k + "_bytes_per_launch"] = d["fetch_bytes_x2"] + d["write_bytes"]

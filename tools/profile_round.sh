@@ -10,7 +10,7 @@
 # whole episode at 4096 envs (+ 7 first-touch launches), i.e. the average of the stats csv is that leg's launch_ms.
 # Usage (GPU box): bash tools/profile_round.sh r03_a ["driving robocup driving_partial robocup_partial"]; then copy into profiles/.
 TAG=${1:-rXX}
-WORKLOADS=${2:-"driving robocup driving_partial robocup_partial"}
+WORKLOADS=${2:-"driving robocup driving_partial robocup_partial hbm"}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 B="--roofline-only"
@@ -18,11 +18,13 @@ for W in $WORKLOADS; do
   case $W in robocup*) STEPS=240;; *) STEPS=600;; esac
   D=gpurun_out/${TAG}_prof_$W
   rm -rf $D ${D}_f ${D}_w
-  rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 bench.py --workload $W $B > gpurun_out/${TAG}_bench_${W}_under_rocprof.json 2> $D.err || exit 1
+  # "hbm": the arranger's padded-tensor kernel and the transport's expansion kernel (tools/hbm_kernels_run.py), the two HBM-bound kernels
+  case $W in hbm) PROG="tools/hbm_kernels_run.py";; *) PROG="bench.py --workload $W $B";; esac
+  rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 $PROG > gpurun_out/${TAG}_bench_${W}_under_rocprof.json 2> $D.err || exit 1
   cp "$(ls $D/*/*kernel_stats.csv | head -1)" gpurun_out/${TAG}_kernel_stats_$W.csv
   echo "[profile_round] $W kernel stats done"
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d ${D}_f -- python3 bench.py --workload $W $B > /dev/null 2> ${D}_f.err || exit 1
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d ${D}_w -- python3 bench.py --workload $W $B > /dev/null 2> ${D}_w.err || exit 1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d ${D}_f -- python3 $PROG > /dev/null 2> ${D}_f.err || exit 1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d ${D}_w -- python3 $PROG > /dev/null 2> ${D}_w.err || exit 1
   echo "[profile_round] $W traffic passes done"
   case $W in driving|robocup|driving_partial|robocup_partial)
     rm -rf ${D}_s1 ${D}_s2
@@ -32,6 +34,20 @@ for W in $WORKLOADS; do
   esac
 done
 python3 tools/profile_collect.py $TAG $WORKLOADS
+# regression gates: the step kernels' average launch durations of this round's kernel-stats passes
+python3 - "$TAG" <<'PY'
+import csv, sys
+tag = sys.argv[1]
+GATES = {"driving": ("drv_step_kernel", 165.0), "driving_partial": ("drv_step_partial_kernel", 201.0), "robocup": ("rc_step_kernel", 1280.0), "robocup_partial": ("rc_step_partial_kernel", 1300.0)}
+for w, (k, gate_us) in GATES.items():
+    try:
+        rows = list(csv.DictReader(open("gpurun_out/%s_kernel_stats_%s.csv" % (tag, w))))
+    except OSError:
+        continue
+    us = [float(r["AverageNs"]) / 1e3 for r in rows if r["Name"].split("(")[0] == k]
+    if us:
+        print("[profile_round] gate %-16s %-26s %8.1f us  (<= %.1f us: %s)" % (w, k, us[0], gate_us, "ok" if us[0] <= gate_us else "REGRESSION"))
+PY
 # the RoboCup code's instruction-cache phase (RC_LAYOUT_PAD_WORDS): still within 0.5 % of the best candidate? (needs the candidate
 # libraries of `python3 tools/rc_layout_sweep.py build`; skipped without them)
 python3 tools/rc_layout_sweep.py check || echo "[profile_round] RoboCup code phase NOT within 0.5 % of the best candidate: see gpurun_out/rc_layout_sweep.txt"
