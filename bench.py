@@ -520,6 +520,20 @@ def main():
         gather = StepGather(torch, dist, slab, more=more)
     env = BatchedDynEnv(env_type, E, n_players, seed=args.seed, device=device, env_id_offset=rank * E,
                         out_buffers=out_buffers, **obs_kw)
+    preflight = None
+    if dist is not None:
+        # Before anything is timed, every rank says where it is and what it owns, so that the first real multi-GPU record explains
+        # itself if it fails: world size and backend as torch.distributed sees them, the device this rank bound, its slice of the
+        # global environment ids, the bytes of the slab it contributes to every all-gather.
+        props = torch.cuda.get_device_properties(device)
+        mine = {"rank": rank, "world_size": dist.get_world_size(), "backend": dist.get_backend(), "local_rank": local_rank,
+                "device": "cuda:%d %s (%d CUs, %.0f GB)" % (local_rank, props.name, props.multi_processor_count, props.total_memory / 2 ** 30),
+                "visible_devices": ndev, "env_ids": [rank * E, (rank + 1) * E], "slab_bytes": (None if slab is None else slab.nbytes),
+                "transport": (None if gather is None else args.transport), "pid": os.getpid()}
+        print("[bench preflight] rank %(rank)d of world_size %(world_size)d (%(backend)s): %(device)s, %(visible_devices)d visible; environments "
+              "[%(env_ids)s); slab %(slab_bytes)s B (%(transport)s)" % dict(mine, env_ids="%d, %d" % tuple(mine["env_ids"])), file=sys.stderr, flush=True)
+        preflight = [None] * world
+        dist.all_gather_object(preflight, mine)
     # synthetic inputs: i.i.d. uniform actions (action_space MultiDiscrete([3,3])), resident in HBM
     g = torch.Generator(device=device).manual_seed(1234 + rank)
     if robocup:  # MultiDiscrete([5, 3, 3, 7]) RoboCupEnvironment.py:342
@@ -689,7 +703,7 @@ def main():
         shard_check = {"rccl_world_size": dist.get_world_size(), "backend": dist.get_backend(), "n_gpus_flag": args.gpus,
                        "env_id_offset_per_rank": offs, "envs_per_rank": [int(x[3]) for x in allr],
                        "value_full_episode_per_rank": [float(x[1]) for x in allr],
-                       "ms_per_step_full_episode_per_rank": [float(x[2]) for x in allr],
+                       "ms_per_step_full_episode_per_rank": [float(x[2]) for x in allr], "preflight": preflight,
                        "note": "per rank: the N = 1-equivalent whole-episode figure of that rank's shard (kernel alone, no transport)"}
         # a line that claims N GPUs must have been produced by N RCCL ranks, each owning its own slice of the global environment ids
         assert dist.get_world_size() == args.gpus or args.force_gather, "bench.py --gpus %d ran with world size %d" % (args.gpus, dist.get_world_size())

@@ -239,7 +239,7 @@ def _two_rank_worker(rank, world, port, kind, out_dir):
     from dynenv_amd.distributed import ShardedDynEnv, shard_range
     robocup = kind == "ROBO_CUP"
     et = DynEnvType.ROBO_CUP if robocup else DynEnvType.DRIVE
-    total, n, steps = 48, 5 if robocup else 10, 14
+    total, n, steps = int(os.environ.get("SHARD_TEST_TOTAL", "48")), 5 if robocup else 10, 14
     sh = ShardedDynEnv(et, total, n, gather=True, seed=9, device="cuda:0")
     off, per = shard_range(total, rank, world)
     A = sh.env.n_agents
@@ -285,6 +285,41 @@ def test_two_ranks_sharing_the_gpu_match_one_big_batch(tmp_path, kind):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_two_rank_worker, args=(2, port, kind, str(tmp_path)), nprocs=2, join=True)
     assert open(os.path.join(str(tmp_path), "ok.txt")).read() == "ok"
+
+
+def test_four_ranks_sharing_the_gpu_match_one_big_batch(tmp_path, monkeypatch):
+    """the same with FOUR ranks of 512 environments each (the n-rank unpack kernel with more than one peer, the ring of
+    slabs with three peers' data in flight) against a single 2048-environment handle, bit for bit.  Four processes on the card: inside
+    the box's limit of six."""
+    import torch.multiprocessing as mp
+    monkeypatch.setenv("SHARD_TEST_TOTAL", "2048")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_two_rank_worker, args=(4, port, "DRIVE", str(tmp_path)), nprocs=4, join=True)
+    assert open(os.path.join(str(tmp_path), "ok.txt")).read() == "ok"
+
+
+def test_bench_rehearsal_with_four_ranks_on_this_gpu():
+    """`python3 bench.py --gpus 4 --rehearse-one-gpu --envs 512`: the launcher with more than two children, every rank's preflight line
+    (world size, device, environment ids, slab bytes) BEFORE anything is timed, one JSON line whose shard_check is green."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--steps", "8", "--warmup", "3", "--envs", "512", "--rehearse-one-gpu"], cwd=root, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    err = r.stderr.decode()
+    assert r.returncode == 0, err[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    sc = d["shard_check"]
+    assert d["n_gpus"] == 4 and sc["rccl_world_size"] == 4 and sc["env_id_offset_per_rank"] == [0, 512, 1024, 1536] and sc["envs_per_rank"] == [512] * 4
+    assert d["kernel_error_flags"] == 0 and min(sc["value_full_episode_per_rank"]) > 0
+    assert len(sc["preflight"]) == 4 and all(p["world_size"] == 4 and p["slab_bytes"] == d["config"]["gather_bytes_per_rank"] for p in sc["preflight"])
+    pre = [ln for ln in err.splitlines() if ln.startswith("[bench preflight]")]
+    assert len(pre) >= 4 and "world_size 4" in pre[0], err[-1500:]
+    assert abs(d["env_steps_per_s"] - 4 * 512 * 8 / (d["ms_per_step"] * 8e-3)) < 1e-6 * d["env_steps_per_s"]
 
 
 @pytest.mark.parametrize("how", ["launcher", "as_typed"])

@@ -109,6 +109,57 @@ def main():
           "robot-robot %d, robot-ball %d, robot-post %d, ball-post %d, own feet %d) against the oracle - tolerance 1e-9 or 1000 x the fixture's own conditioning, "
           "flags exact: %d failures; %d of the %d steps were well-conditioned (twin drift <= 1e-6) and checked  (%.0f s)"
           % ((n_rc, steps) + tuple(begins) + (len([f for f in failures if f[0] == "robocup"]), checked, steps, time.time() - t0)))
+    # Goalposts (both populations above report "robot-post 0"): scenes that start a robot within reach of a post, walking
+    # into it, and the ball rolling into another one - goalpostCollision (RoboCupEnvironment.py:1106-1125: touch counter, the fall die
+    # 0.9998 ** touchCntr, fall(punish)), its separate handler, and the default-handled ball-post bounce (Goalpost.py:4-14: e = 0.95)
+    n_gp = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+    t0 = time.time()
+    steps = checked = 0
+    begins = np.zeros(5, np.int64)
+    for k in range(n_gp):
+        n, can_fall, length = int(rng.choice([3, 4, 5, 5])), bool(rng.random() < 0.7), int(rng.integers(8, 16))
+        posts = [(70.0, 450.0), (70.0, 290.0), (970.0, 450.0), (970.0, 290.0)]
+        pr, pb = [int(x) for x in rng.choice(4, 2, replace=False)]
+        ru, bu = float(rng.uniform(-1.0, 1.0)), float(rng.uniform(-1.2, 1.2))          # bearing from the post, field side
+        rd, bd, bv, jit = float(rng.uniform(42.0, 58.0)), float(rng.uniform(60.0, 130.0)), float(rng.uniform(200.0, 380.0)), float(rng.uniform(-0.06, 0.06))
+        rsel = int(rng.integers(0, n))
+
+        def setup(env, pr=pr, pb=pb, ru=ru, bu=bu, rd=rd, bd=bd, bv=bv, jit=jit, rsel=rsel, n=n, posts=posts):
+            import math
+            Vec2d = gc.Vec2d
+            px, py = posts[pb]
+            side = 1.0 if px < 520.0 else -1.0
+            ux, uy = side * math.cos(bu), math.sin(bu)
+            b = env.ball.shape.body
+            b.position = Vec2d(px + bd * ux, py + bd * uy)
+            b.velocity = Vec2d(-bv * math.cos(math.atan2(uy, ux) + jit), -bv * math.sin(math.atan2(uy, ux) + jit))
+            env.ball.prevPos = Vec2d(px + bd * ux, py + bd * uy)
+            qx, qy = posts[pr]
+            side = 1.0 if qx < 520.0 else -1.0
+            vx, vy = side * math.cos(ru), math.sin(ru)
+            rid = (n + rsel) if qx < 520.0 else rsel      # the team whose own penalty box is on the OTHER side (no illegal-defender teleport)
+            r = env.agents[rid]
+            for foot in (r.leftFoot, r.rightFoot):
+                foot.body.position = Vec2d(qx + rd * vx, qy + rd * vy)
+                foot.body.angle = math.atan2(-vy, -vx)    # facing the post: walking forward (action 3) runs into it
+            r.prevPos = r.getPos()
+            return {s_: {rid: [3, 0, 0, 3]} for s_ in range(0, 10)}
+        out = {}
+        stdout, sys.stdout = sys.stdout, devnull
+        try:
+            gc.gen_robocup(out, "t", n, can_fall, length, 6000 + k, 0.3, setup)
+        finally:
+            sys.stdout = stdout
+        try:
+            checked += tc.check_robocup_trajectory(out, "t", robocup_env)
+        except AssertionError as e:
+            failures.append(("robocup_posts", n, 6000 + k, length, str(e)[:200]))
+        steps += length
+        begins += out["t_begins"]
+    if n_gp:
+        print("RoboCup at the goalposts: %d trajectories (3-5 a side, a robot walking into one post, the ball rolling into another; 8-16 steps each, %d steps; first "
+              "touches robot-robot %d, robot-ball %d, ROBOT-POST %d, BALL-POST %d, own feet %d) against the oracle - same tolerances: %d failures; %d of the %d steps "
+              "well-conditioned and checked  (%.0f s)" % ((n_gp, steps) + tuple(begins) + (len([f for f in failures if f[0] == "robocup_posts"]), checked, steps, time.time() - t0)))
     # Partial observations (BASELINE configs[3]): getAgentVision inside the step, noise draws served by source line
     n_dp = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     n_rp = int(sys.argv[4]) if len(sys.argv) > 4 else 0
