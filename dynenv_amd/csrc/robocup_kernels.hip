@@ -1068,6 +1068,24 @@ DE_DEV void joint_prestep(const RcLds& L, int lane, RcJoint& J, double& jx, doub
 // and each block is issued once per iteration instead of once per order.
 template <bool CLEAN>
 DE_DEV void joints_solve(const RcJoint& J, RcFeet& f, double& jx, double& jy, double& jr) {
+  if constexpr (CLEAN) {
+    // CLEAN: the pivot reads and writes (vx, vy) only, the rotary limit w only (pivot_warm_start's comment): two independent chains of a
+    // warm start + ten iterations each, the same in either constraint order - no `pivotFirst` bookkeeping, no branch per order.
+    // Fixed-point exit: an iteration that leaves the three accumulated impulses where they were has applied impulses of +-0 to
+    // velocities none of which is -0: it changed nothing, and every later one - a function of the same state - changes nothing either.
+    // All robots of the wave must have got there: the lanes share the loop.  A walking robot's pivot is solved exactly by its first
+    // pass up to rounding; the second or third pass adds zero.
+    rotary_warm_start(J, f, jr);
+    pivot_warm_start<true>(J, f, jx, jy);
+#pragma unroll 1
+    for (int iter = 0; iter < 10; ++iter) {
+      const double jx0 = jx, jy0 = jy, jr0 = jr;
+      pivot_iterate<true>(J, f, jx, jy);
+      rotary_iterate(J, f, jr);
+      if (__ballot(!(jx == jx0 && jy == jy0 && jr == jr0)) == 0ull) break;
+    }
+    return;
+  }
   const bool pf = J.pivotFirst;
   if (!pf) rotary_warm_start(J, f, jr);
   pivot_warm_start<CLEAN>(J, f, jx, jy);
