@@ -408,13 +408,17 @@ DE_DEV V2 static_pos(const DrvLds& L, int idx) {
   }
   return v2(L.ox[idx - DRV_SLOT_OBST], L.oy[idx - DRV_SLOT_OBST]);
 }
+// branch-free (round 6): every field from body slot idx, or from the all-zero slot 30 for a static body (body_rd below); the position of a
+// static body from the obstacle table or the buildings' constants by selection, both loads issued
 DE_DEV void body_load(const DrvLds& L, int idx, BodyV& b) {
-  if (idx < DRV_SLOT_OBST) {
-    b.p = v2(L.px[idx], L.py[idx]); b.v = v2(L.vx[idx], L.vy[idx]); b.w = L.w[idx];
-    b.vb = v2(L.vbx[idx], L.vby[idx]); b.wb = L.wb[idx]; b.minv = L.minv[idx]; b.iinv = L.iinv[idx];
-  } else {
-    b.p = static_pos(L, idx); b.v = v2(0.0, 0.0); b.w = 0.0; b.vb = v2(0.0, 0.0); b.wb = 0.0; b.minv = 0.0; b.iinv = 0.0;
-  }
+  const bool dyn = idx < DRV_SLOT_OBST;
+  const int bi = dyn ? idx : DRV_SLOT_OBST /* = the zero slot */, oi = (idx >= DRV_SLOT_OBST && idx < DRV_SLOT_BLD) ? idx - DRV_SLOT_OBST : 0;
+  const double dpx = L.px[bi], dpy = L.py[bi], sox = L.ox[oi], soy = L.oy[oi];
+  const int k = idx - DRV_SLOT_BLD;
+  const double bx = (k & 2) ? 1385.0 : 365.0, by = (k & 1) ? 800.0 : 200.0;  // DrivingEnvironment.py:101-106
+  b.p = dyn ? v2(dpx, dpy) : (idx >= DRV_SLOT_BLD ? v2(bx, by) : v2(sox, soy));
+  b.v = v2(L.vx[bi], L.vy[bi]); b.w = L.w[bi];
+  b.vb = v2(L.vbx[bi], L.vby[bi]); b.wb = L.wb[bi]; b.minv = L.minv[bi]; b.iinv = L.iinv[bi];
 }
 // the solver's per-iteration view of a body: p, minv and iinv do not change while a substep is being solved
 DE_DEV void body_load_vel(const DrvLds& L, int idx, BodyV& b) {
@@ -422,10 +426,9 @@ DE_DEV void body_load_vel(const DrvLds& L, int idx, BodyV& b) {
     b.v = v2(L.vx[idx], L.vy[idx]); b.w = L.w[idx]; b.vb = v2(L.vbx[idx], L.vby[idx]); b.wb = L.wb[idx];
   }
 }
-DE_DEV void body_store_vel(DrvLds& L, int idx, const BodyV& b) {
-  if (idx < DRV_SLOT_OBST) {
-    L.vx[idx] = b.v.x; L.vy[idx] = b.v.y; L.w[idx] = b.w; L.vbx[idx] = b.vb.x; L.vby[idx] = b.vb.y; L.wb[idx] = b.wb;
-  }
+DE_DEV void body_store_vel(DrvLds& L, int idx, const BodyV& b) {  // (a static body's all-zero velocities go to slot 31, which nobody reads)
+  const int wi = idx < DRV_SLOT_OBST ? idx : DRV_NB - 1;
+  L.vx[wi] = b.v.x; L.vy[wi] = b.v.y; L.w[wi] = b.w; L.vbx[wi] = b.vb.x; L.vby[wi] = b.vb.y; L.wb[wi] = b.wb;
 }
 // The arbiter solver's arithmetic with its multiply-adds FUSED: the dms_* functions of include/dynenv_math.h, the same ones
 // oracle/cp_lite.c calls (k_scalar_body_f, relative_velocity_f, apply_impulse_f ...).
@@ -689,7 +692,7 @@ DE_DEV void arb_warm_start(BodyV& a, BodyV& b, V2 n, const V2* r1, const V2* r2,
                            int count) {
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
-    if (c < count) {
+    if (c == 0 || count > 1) {  // (an arbiter that is warm-started has one contact or two)
       V2 j = vrotate_f(n, v2(jn[c], jt[c]));
       j = vmul(j, 1.0);  // dt_coef = dt/prev_dt = 1
       apply_impulse(a, vneg(j), r1[c]);
@@ -703,7 +706,7 @@ DE_DEV void arb_apply_impulse(BodyV& a, BodyV& b, V2 n, const V2* r1, const V2* 
                               double* jt, int count, double arb_u) {
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
-    if (c < count) {
+    if (c == 0 || count > 1) {
       double vbn = bias_rel_n(a, b, r1[c], r2[c], n);
       // Bias-only contact (a resting contact that is still being pushed out of penetration): both bodies have all-zero
       // (+0) velocities, no accumulated impulse and no bounce.  Then vr = +-0, jn and jt come out as +0 again and the
@@ -766,7 +769,7 @@ DE_DEV bool arb_is_bias_only(const BodyV& a, const BodyV& b, const double* jn, c
   bool ok = true;
 #pragma unroll
   for (int c = 0; c < 2; ++c)
-    if (c < count) { z |= __double_as_longlong(jn[c]) | __double_as_longlong(jt[c]); ok = ok && bounce[c] == 0.0; }
+    if (c == 0 || count > 1) { z |= __double_as_longlong(jn[c]) | __double_as_longlong(jt[c]); ok = ok && bounce[c] == 0.0; }
   return ok && z == 0ll;
 }
 DE_DEV void body_load_bias(const DrvLds& L, int idx, BodyV& b) {
@@ -923,7 +926,7 @@ DRV_PROF(const unsigned long long P0 = __builtin_amdgcn_s_memtime();)
     V2 body_delta = vsub(b.p, a.p);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      if (c < a_count) {
+      if (c == 0 || a_count > 1) {  // (an active arbiter has one contact or two)
         nMass[c] = 1.0 / (k_scalar_body(a, r1[c], n) + k_scalar_body(b, r2[c], n));
         double dist = vdot_f(vadd(vsub(r2[c], r1[c]), body_delta), n);  // (tMass is not needed: see arb_apply_impulse)
         bias[c] = -DE_CONTACT_BIAS_COEF * fmin_cp(0.0, dist + DE_COLLISION_SLOP) / DE_DT;
