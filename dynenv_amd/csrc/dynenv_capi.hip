@@ -770,6 +770,7 @@ int dynenv_debug_counters(dynenv_t* h, int64_t* out4) {
     { static unsigned long long d[4096 * 12]; HIP_OK(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_rcprof), sizeof(d))); FILE* f = fopen("gpurun_out/rcprof.txt", "w"); for (int k = 0; k < 4096; ++k) { for (int q = 0; q < 12; ++q) fprintf(f, "%llu ", d[12*k+q]); fprintf(f, "\n"); } fclose(f); }
     { static unsigned long long d[4096 * 8]; HIP_OK(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_rcprof2), sizeof(d))); FILE* f = fopen("gpurun_out/rcprof2.txt", "w"); for (int k = 0; k < 4096; ++k) { for (int q = 0; q < 8; ++q) fprintf(f, "%llu ", d[8*k+q]); fprintf(f, "\n"); } fclose(f); }
     { static unsigned long long d[4096 * 8]; HIP_OK(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_rcprof3), sizeof(d))); FILE* f = fopen("gpurun_out/rcprof3.txt", "w"); for (int k = 0; k < 4096; ++k) { for (int q = 0; q < 8; ++q) fprintf(f, "%llu ", d[8*k+q]); fprintf(f, "\n"); } fclose(f); }
+    { static unsigned long long d[4096 * 8]; HIP_OK(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_rcprof4), sizeof(d))); FILE* f = fopen("gpurun_out/rcprof4.txt", "w"); for (int k = 0; k < 4096; ++k) { for (int q = 0; q < 8; ++q) fprintf(f, "%llu ", d[8*k+q]); fprintf(f, "\n"); } fclose(f); }
 #endif
     return DYNENV_OK;
   }

@@ -459,8 +459,31 @@ DE_DEV void rc_tick(const RcCtx& c, RcLds& L, int r) {  // :862-1007
 // On loaded values because a lone wave cannot hide an LDS round trip (~110 cycles): the plain form made some forty of them per
 // substep, one after the other.
 // ------------------------------------------------------------------------------------------------
+// min over the 16 lanes of a DPP row, in every lane of the row: four rotate-and-min steps (row_ror 8, 4, 2, 1), no LDS, no loop.
+// v_min_f64 ignores a NaN operand, like the `qi < d0` scan this replaces.
+template <int ROT>
+DE_DEV double rc_row_ror(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x120 + ROT, 0xF, 0xF, false);  // DPP row_ror:ROT
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x120 + ROT, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+DE_DEV double rc_row_min(double x) {
+  x = __builtin_fmin(x, rc_row_ror<8>(x));
+  x = __builtin_fmin(x, rc_row_ror<4>(x));
+  x = __builtin_fmin(x, rc_row_ror<2>(x));
+  x = __builtin_fmin(x, rc_row_ror<1>(x));
+  return x;
+}
+#ifdef DRV_PROFILE
+__device__ unsigned long long g_rcprof4[4096 * 8];  // stages of the batched game logic: loads + events | tick | ball | closest robots | lane-0 stores
+#define RC_PROF_G(...) __VA_ARGS__
+#else
+#define RC_PROF_G(...)
+#endif
 template <int EPW>
 DE_DEV bool rc_game_logic_batched(const RcCtx& c, RcLds& L, int lane, bool withTick) {
+RC_PROF_G(const unsigned long long G0 = __builtin_amdgcn_s_memtime(); unsigned long long G1 = G0, G2 = G0;)
   const int R = c.R, n = c.n;
   const bool isRobot = lane < R;
   const int r = isRobot ? lane : 0;
@@ -503,6 +526,7 @@ DE_DEV bool rc_game_logic_batched(const RcCtx& c, RcLds& L, int lane, bool withT
       if (rpos.y < 0.0 || rpos.x < 0.0 || rpos.y > RC_H || rpos.x > RC_W) ev = true;
     }
     if (Grp<EPW>::ballot(ev) != 0ull) return false;
+RC_PROF_G(G1 = __builtin_amdgcn_s_memtime();)
     // ---- (2) the event-free tick (:862-1007) ----
     if (isRobot) {
       if (moveT > 0.0) {
@@ -547,6 +571,7 @@ DE_DEV bool rc_game_logic_batched(const RcCtx& c, RcLds& L, int lane, bool withT
       }
     }
   }
+RC_PROF_G(G2 = __builtin_amdgcn_s_memtime(); if (!withTick) G1 = G2;)
   // ---- (3) the ball (:622-732) ----
   bool finished = false, moved = false;
   int team = 0;
@@ -603,22 +628,25 @@ DE_DEV bool rc_game_logic_batched(const RcCtx& c, RcLds& L, int lane, bool withT
     if ((cond1 || cond2) && !inLk) rrew += dm_min(0.0, (lane < n ? cr0 : cr1) * 0.5);
   }
   if (isRobot) { L.rrew[r] = rrew; L.rposrew[r] = rposrew; }
+RC_PROF_G(const unsigned long long G3 = __builtin_amdgcn_s_memtime();)
   // closest robot of each team to the (possibly reset) ball
   double q = INFINITY;
   if (isRobot) {
     const V2 d = vsub(v2(x, y), rpos);
     q = d.x * d.x + d.y * d.y;
   }
+  // The reference scans each team in ascending order with a strict `<` from +inf: the FIRST robot at the smallest distance wins, a NaN
+  // never does, and with no finite distance at all the answer is robot 0.  The same without a loop: the team's minimum by four DPP
+  // rotate-and-min steps over the row (robots sit on lanes 0 .. 2n-1 <= 9 of row 0), then the lowest lane that holds it.
   int best0 = 0, best1 = 0;
-  double d0 = INFINITY, d1 = INFINITY;
-  for (int i = 0; i < n; ++i) {
-    const double qi = Grp<EPW>::bcast_d(q, i);
-    if (qi < d0) { d0 = qi; best0 = i; }
+  {
+    const bool t0 = lane < n, t1 = lane >= n && lane < 2 * n;
+    const double m0 = rc_row_min(t0 ? q : INFINITY), m1 = rc_row_min(t1 ? q : INFINITY);
+    const uint64_t w0 = Grp<EPW>::ballot(t0 && q == m0 && q < INFINITY), w1 = Grp<EPW>::ballot(t1 && q == m1 && q < INFINITY);
+    best0 = w0 ? (int)__builtin_ctzll(w0) : 0;
+    best1 = w1 ? (int)__builtin_ctzll(w1) - n : 0;
   }
-  for (int i = 0; i < n; ++i) {
-    const double qi = Grp<EPW>::bcast_d(q, n + i);
-    if (qi < d1) { d1 = qi; best1 = i; }
-  }
+RC_PROF_G(const unsigned long long G4 = __builtin_amdgcn_s_memtime();)
   __syncthreads();  // every lane has read the shared scalars it needs
   if (lane == 0) {
     if (moved) { L.px[RC_BALL] = x; L.py[RC_BALL] = y; L.vx[RC_BALL] = 0.0; L.vy[RC_BALL] = 0.0; L.w[RC_BALL] = 0.0; }
@@ -644,6 +672,7 @@ DE_DEV bool rc_game_logic_batched(const RcCtx& c, RcLds& L, int lane, bool withT
     L.envi[RE_CLOSE0] = best0;
     L.envi[RE_CLOSE1] = n + best1;
   }
+RC_PROF_G(if (lane == 0 && c.genv < 4096u) { unsigned long long* d = g_rcprof4 + c.genv * 8; const unsigned long long G5 = __builtin_amdgcn_s_memtime(); d[0] += G1 - G0; d[1] += G2 - G1; d[2] += G3 - G2; d[3] += G4 - G3; d[4] += G5 - G4; })
   return true;
 }
 
@@ -1976,7 +2005,7 @@ DE_DEV void rc_step_body(const RcState& S, const int e, const int* __restrict__ 
   const double* myHead = headActions ? headActions + (size_t)e * R : nullptr;
   int snap = 0, nGeneral = 0;  // substeps that went through rc_physics
 
-RC_PROF(if (lane < 8 && e < 4096) { g_rcprof2[e * 8 + lane] = 0ull; g_rcprof3[e * 8 + lane] = 0ull; })
+RC_PROF(if (lane < 8 && e < 4096) { g_rcprof2[e * 8 + lane] = 0ull; g_rcprof3[e * 8 + lane] = 0ull; g_rcprof4[e * 8 + lane] = 0ull; })
 RC_PROF(if (lane < 12 && e < 4096) g_rcprof[e * 12 + lane] = 0ull; const unsigned long long K0 = __builtin_amdgcn_s_memtime(); unsigned long long tG = 0, tP = 0, tB = 0;)
   for (int it = 0; it < 50; ++it) {
     lane = fresh_lane();  // per substep: nothing derived from the lane id is hoisted out of the loop, and the id itself is not kept across the calls

@@ -39,4 +39,7 @@ p3 = np.loadtxt("gpurun_out/rcprof3.txt")[:NE]
 n3 = ["game logic", "position + shape cache + AABB", "broadphase", "quiet test (feet_far_apart)", "velocity update (quiet)", "joints (quiet)", "quiet substeps", "calls of the common part"]
 print("the common part, cycles per step: mean over all environments / mean of the 12 slowest")
 for k, n in enumerate(n3): print("  %-34s %10.0f %10.0f" % (n, p3[:, k].mean(), p3[top, k].mean()))
+p4 = np.loadtxt("gpurun_out/rcprof4.txt")[:NE]
+print("the batched game logic, cycles per step: mean over all environments / mean of the 12 slowest")
+for k, n in enumerate(["loads + event test", "tick", "ball", "closest robots", "barrier + lane-0 stores"]): print("  %-34s %10.0f %10.0f" % (n, p4[:, k].mean(), p4[top, k].mean()))
 if os.environ.get("PROFILE_SAVE"): np.save(os.environ["PROFILE_SAVE"], d[:, 11])
