@@ -1207,8 +1207,8 @@ RC_PROF(const unsigned long long T0 = __builtin_amdgcn_s_memtime(); unsigned lon
   if (anyContactWork) {
     // Compact the candidates of all rounds into one dense list in canonical order (round-major, lane-minor = pair index
     // order), so that the narrowphase runs once over up to 64 pairs instead of once per round that holds a candidate
-    // (the two feet of one robot are a candidate pair in every substep).  The list borrows the mailbox's LDS, which
-    // is not live yet: every lane takes its entries into registers before the mailbox flags are cleared.
+    // (the two feet of one robot are a candidate pair in every substep).  candList is a member of its own, kept from call to call
+    // within a launch: it stays valid while every lane's candidate mask is the one it was built from (lastCand / candN).
     unsigned short* cl = L.candList;
     int nCand = 0;
     const int prevCand = (int)L.lastCand[lane], savedN = G::uniform_i(L.candN);
