@@ -38,3 +38,34 @@ def test_all_32768_environments_of_the_8_gpu_configuration_on_one_gpu(oracle_bui
     the eight ranks compute between them."""
     import soak_parity
     soak_parity.run("driving", 32768, 20261003)
+
+
+def test_crossing_feet_in_play_take_the_same_normal_on_both_sides(oracle_built):
+    """Round 6: capsule cores that CROSS are reached in play (the two feet of a robot that has been knocked about) and take Chipmunk's
+    minimum-translation normal on both sides (oracle/cp_lite.c cores_crossing_normal, rc_narrowphase).  An episode that contains such
+    substeps - 4096 environments, seed 1, a pool of 16 action tensors repeated, the first crossing at step 138 - stays bit-identical
+    between the HIP path and the oracle through them, with no error flag (crossing is not the degenerate case bit 4 reports)."""
+    import ctypes as C
+    import numpy as np
+    import oracle_lib as ol
+    from dynenv_amd import BatchedDynEnv, DynEnvType
+    E, seed, steps = 4096, 1, 150
+    lib = ol.lib()
+    lib.oracle_cp_cores_cross.restype = C.c_long
+    before = lib.oracle_cp_cores_cross()
+    env = BatchedDynEnv(DynEnvType.ROBO_CUP, E, 5, seed=seed, flags=ol.ROBOCUP_DEFAULT_FLAGS)
+    ora = ol.OracleEnv(env_type=0, num_envs=E, n_players=5, seed=seed, flags=ol.ROBOCUP_DEFAULT_FLAGS, threads=16)
+    assert np.array_equal(env.reset_flat().cpu().numpy(), ora.reset())
+    rng = np.random.default_rng(seed)
+    pool = [np.stack([rng.integers(0, k, (E, 10)) for k in (5, 3, 3, 7)], -1).astype(np.int32) for _ in range(16)]
+    for s in range(steps):
+        og, rg, dg = env.step_flat(pool[s & 15], auto_reset=False)
+        if s >= 136:
+            oc, rc, dc = ora.step(pool[s & 15])
+            assert np.array_equal(og.cpu().numpy(), oc), "observations of step %d" % s
+        else:
+            rc, dc = ora.step_noobs(pool[s & 15])
+        assert np.array_equal(rg.cpu().numpy(), rc), "rewards of step %d" % s
+    assert lib.oracle_cp_cores_cross() > before, "the episode must contain crossing capsule cores"
+    assert env.error_flags() == 0 and ora.degenerate() == 0
+    env.close()
