@@ -109,7 +109,9 @@ struct DrvState {
                         drv_tick_advance_kernel in front of every step - set for good once a step has been captured into a hipGraph */
 };
 #ifndef DRV_ISO_MAX
-#define DRV_ISO_MAX 64   /* at most this many environments get a SIMD of their own (iso_on = 1) */
+#define DRV_ISO_MAX 192  /* at most this many environments get a SIMD of their own (iso_on = 1).  The list fills in FINISHING order: a cap
+                            below the number of listed environments drops the slowest of them (round 6: 64 -> 192 with the threshold at
+                            75 % instead of 80 %: -0.6 %; 40: +2.2 %; 256 at 65 %: +2 %) */
 #endif
 #ifndef DRV_ISO_MIN_E
 #define DRV_ISO_MIN_E 3072 /* isolation (mode 1) for DRV_ISO_MIN_E < E <= 4096: measured -6.5 % at 4095, -6 % at 4000, -4 % at 3584, -0.8 % at 3072, +0.8 % at 2048 (HISTORY "Round 5") */

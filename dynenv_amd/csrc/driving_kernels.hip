@@ -1421,7 +1421,7 @@ DE_OOL int drv_partial_obs_fused(PvIn in, uint64_t seed, int A, int* envi, int e
 #define DRV_DEFER_MIN_CONTACT 5 /* without a forecast: contact-path substeps (of 10) from which an environment defers its Partial observation */
 #endif
 #ifndef DRV_PV_DEADLINE_PCT
-#define DRV_PV_DEADLINE_PCT 100 /* fused vision passes start until this many percent of the forecast of the launch's slowest environment */
+#define DRV_PV_DEADLINE_PCT 110 /* fused vision passes start until this many percent of the forecast of the launch's slowest environment (round 6 sweep: 90 +2.5 %, 100 0, 105 -0.7 %, 110 -0.9 %, 115 -0.1 %, 120 +1.5 %) */
 #endif
 #ifndef DRV_FUSED_AGENTS
 #define DRV_FUSED_AGENTS 10 /* without a forecast: agent passes a light environment runs in the step launch */
@@ -1776,8 +1776,9 @@ DE_DEV int drv_iso_assign(const DrvState& S, int lane, int tick) {
 #ifndef DRV_ISO_MIN
 #define DRV_ISO_MIN 300000 /* isolation starts when the slowest environment of a step needed this many cycles */
 #endif
-#ifndef DRV_ISO_TENTHS
-#define DRV_ISO_TENTHS 8 /* ... for the environments above this many tenths of it */
+#ifndef DRV_ISO_PCT
+#define DRV_ISO_PCT 75 /* ... for the environments above this many percent of it (round 6, with DRV_ISO_MAX = 64: 70 +5.4 %, 75 +2.4 %, 80 0,
+                          85 +2.1 %, 90 +3.8 % - the list overflowed below 80; with DRV_ISO_MAX = 192: 70 -0.25 %, 75 -0.6 %) */
 #endif
 DE_DEV void drv_iso_report(const DrvState& S, int e, int lane, unsigned long long t0, int tick) {
   if (!S.iso_on || lane != 0) return;
@@ -1785,9 +1786,9 @@ DE_DEV void drv_iso_report(const DrvState& S, int e, int lane, unsigned long lon
   const int buf = tick % 3, nxt = (tick + 1) % 3;
   const int slowest = S.iso[3 + buf];
   // (only the few environments above the floor touch the shared words: 4096 atomics on one address serialise - 0.12 ms, measured)
-  if (cycles > DRV_ISO_MIN && cycles > (slowest / 10) * DRV_ISO_TENTHS) atomicMax(&S.iso[3 + nxt], cycles);
+  if (cycles > DRV_ISO_MIN && cycles > (slowest / 100) * DRV_ISO_PCT) atomicMax(&S.iso[3 + nxt], cycles);
   if (S.iso_on == 3) return;
-  if (slowest > DRV_ISO_MIN && cycles > (slowest / 10) * DRV_ISO_TENTHS) {
+  if (slowest > DRV_ISO_MIN && cycles > (slowest / 100) * DRV_ISO_PCT) {
     const int k = atomicAdd(&S.iso[nxt], 1);
     if (k < DRV_ISO_LIST) S.iso[DRV_ISO_HDR + nxt * DRV_ISO_LIST + k] = e;
   }

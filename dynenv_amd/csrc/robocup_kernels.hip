@@ -1846,7 +1846,7 @@ DE_OOL void rc_write_obs_ool(int lane, int R, int obs_dim, float* __restrict__ o
 #include "robocup_partial.hip"
 
 #ifndef RC_PV_DEADLINE_PCT
-#define RC_PV_DEADLINE_PCT 95 /* fused vision passes start until this many percent of the forecast of the launch's slowest environment */
+#define RC_PV_DEADLINE_PCT 98 /* fused vision passes start until this many percent of the forecast of the launch's slowest environment (round 6 sweep: 85 +5 %, 90 +2 %, 95 0, 98 -0.5 %, 100 -0.3 %, 105 +1 %, 115 +7.5 %) */
 #endif
 #define RC_SCHED_MIN 1800000    /* cycles from which an environment may be the step's slowest (a light one needs 1.4 M) */
 #ifndef RC_DEFER_MIN_GENERAL
