@@ -17,14 +17,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as ol  # noqa: E402
 
-E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+E = 4096
 THREADS = os.cpu_count() or 8
-ol.build()
-L = ol.lib()
-L.oracle_test_modes.argtypes = [C.c_int, C.c_double]
+L = None
+
+
+def _lib():
+    global L
+    if L is None:
+        ol.build()
+        L = ol.lib()
+        L.oracle_test_modes.argtypes = [C.c_int, C.c_double]
+    return L
 
 
 def episode(kind, reverse, nudge):
+    L = _lib()
     L.oracle_test_modes(int(reverse), float(nudge))
     try:
         if kind == "driving":
@@ -67,8 +75,14 @@ def report(kind):
     sys.stdout.flush()
 
 
-if __name__ == "__main__":
+def main(envs=4096):
+    global E
+    E = int(envs)
     print("tools/pair_order_cost.py: per-environment |difference of the episode reward| against the shipped (ascending shape id) pair order - share of the "
           "environments above a threshold, quantiles - the share whose crash / goal counts differ, and the population mean")
     for kind in ("driving", "robocup"):
         report(kind)
+
+
+if __name__ == "__main__":
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 4096)
