@@ -56,7 +56,7 @@ struct RcObsStage {
   float bx, by;
 };
 struct RcPrefilter {
-  float cx[RC_NB], cy[RC_NB], hx[RC_NB], hy[RC_NB];
+  float4 box[RC_NB];  // (centre x, centre y, half width + 1, half height + 1) of a body's box in fp32: ONE 16-byte LDS read per body of a pair
 };
 struct __align__(16) RcLds {
   // bodies: feet 0..19, ball 20 (home location of the state); posts 21..24 are constants
@@ -1909,10 +1909,10 @@ RC_PROF(const unsigned long long P1 = __builtin_amdgcn_s_memtime();)
       L.aabb[lane][0] = al; L.aabb[lane][1] = ab; L.aabb[lane][2] = ar; L.aabb[lane][3] = at;  // (kept in registers for the prefilter: no read-back)
       fcx = (float)(0.5 * (al + ar)); fcy = (float)(0.5 * (ab + at));
       fhx = (float)(0.5 * (ar - al)) + 1.0f; fhy = (float)(0.5 * (at - ab)) + 1.0f;
-      L.u.pf.cx[lane] = fcx; L.u.pf.cy[lane] = fcy; L.u.pf.hx[lane] = fhx; L.u.pf.hy[lane] = fhy;
+      L.u.pf.box[lane] = make_float4(fcx, fcy, fhx, fhy);
     } else if (lane >= RC_POST && lane < RC_POST + 4) {  // the goalposts' entries (the table shares its LDS with the mailbox: rewritten every substep)
       const V2 pc = post_pos(lane);
-      L.u.pf.cx[lane] = (float)pc.x; L.u.pf.cy[lane] = (float)pc.y; L.u.pf.hx[lane] = 11.0f; L.u.pf.hy[lane] = 11.0f;
+      L.u.pf.box[lane] = make_float4((float)pc.x, (float)pc.y, 11.0f, 11.0f);
     }
     __syncthreads();
 RC_PROF(const unsigned long long P2 = __builtin_amdgcn_s_memtime();)
@@ -1926,9 +1926,9 @@ RC_PROF(const unsigned long long P2 = __builtin_amdgcn_s_memtime();)
       const int pr = RC_MY_PAIR(t);
       if (pr != 0xFFFF && !((feetPairs >> t) & 1)) {
         const int i = pr >> 8, j = pr & 0xFF;
-        const float bx = L.u.pf.cx[j], by = L.u.pf.cy[j], bhx = L.u.pf.hx[j], bhy = L.u.pf.hy[j];
-        const float dx = L.u.pf.cx[i] - bx, dy = L.u.pf.cy[i] - by;
-        if (__builtin_fabsf(dx) <= L.u.pf.hx[i] + bhx && __builtin_fabsf(dy) <= L.u.pf.hy[i] + bhy) pre |= 1 << t;
+        const float4 bi = L.u.pf.box[i], bj = L.u.pf.box[j];
+        const float dx = bi.x - bj.x, dy = bi.y - bj.y;
+        if (__builtin_fabsf(dx) <= bi.z + bj.z && __builtin_fabsf(dy) <= bi.w + bj.w) pre |= 1 << t;
       }
     }
 #pragma unroll 1
