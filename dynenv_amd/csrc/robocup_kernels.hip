@@ -476,7 +476,7 @@ DE_DEV double rc_row_min(double x) {
   return x;
 }
 #ifdef DRV_PROFILE
-__device__ unsigned long long g_rcprof4[4096 * 8];  // stages of the batched game logic: loads + events | tick | ball | closest robots | lane-0 stores
+__device__ unsigned long long g_rcprof4[4096 * 8];  // stages of the batched game logic: loads + events | tick | ball | closest robots | lane-0 stores; [5..7] the general solve: level passes | joint phases | number of level passes + (number of joint phases << 32)
 #define RC_PROF_G(...) __VA_ARGS__
 #else
 #define RC_PROF_G(...)
@@ -1568,9 +1568,9 @@ RC_PROF(T4 = __builtin_amdgcn_s_memtime();)
           rapply_impulse(a, vneg(jj), r1[q]);                                                  \
           rapply_impulse(b, jj, r2[q]);                                                        \
         }
-RC_PROF(unsigned long long nNoop = 0ull;)
+RC_PROF(unsigned long long nNoop = 0ull, tLv = 0ull, tJt = 0ull;)
         for (int iter = 0; iter < 10; ++iter) {
-RC_PROF(const double pj0 = jn[0], pj1 = jn[1], pj2 = jt[0], pj3 = jt[1];)
+RC_PROF(const double pj0 = jn[0], pj1 = jn[1], pj2 = jt[0], pj3 = jt[1]; const unsigned long long S0 = __builtin_amdgcn_s_memtime();)
           for (int lv = 0; lv < nLv; ++lv) {
             if (solveMe && myLevel == lv) {
               a.v = v2(fX[bodyA], fY[bodyA]); a.w = fW[bodyA];
@@ -1582,6 +1582,7 @@ RC_PROF(const double pj0 = jn[0], pj1 = jn[1], pj2 = jt[0], pj3 = jt[1];)
             }
             __syncthreads();
           }
+RC_PROF(const unsigned long long S1 = __builtin_amdgcn_s_memtime();)
           if (isRobot) {
             RC_JOINT_VIEW(J)
             RcFeet f;
@@ -1599,9 +1600,10 @@ RC_PROF(const double pj0 = jn[0], pj1 = jn[1], pj2 = jt[0], pj3 = jt[1];)
             L.vx[la] = f.vx0; L.vy[la] = f.vy0; L.w[la] = f.w0; L.vx[lb] = f.vx1; L.vy[lb] = f.vy1; L.w[lb] = f.w1;
           }
           __syncthreads();
+RC_PROF(tLv += S1 - S0; tJt += __builtin_amdgcn_s_memtime() - S1;)
 RC_PROF(if (G::ballot((solveMe || isRobot) && !(pj0 == jn[0] && pj1 == jn[1] && pj2 == jt[0] && (isRobot || pj3 == jt[1]))) == 0ull) nNoop += 1ull;)
         }
-RC_PROF(if (lane == 0 && c.genv < 4096u) g_rcprof2[c.genv * 8 + 7] += nNoop;)
+RC_PROF(if (lane == 0 && c.genv < 4096u) { g_rcprof2[c.genv * 8 + 7] += nNoop; g_rcprof4[c.genv * 8 + 5] += tLv; g_rcprof4[c.genv * 8 + 6] += tJt; g_rcprof4[c.genv * 8 + 7] += (unsigned long long)(10 * nLv) + (10ull << 32); })
         // Non-finite values persist through accumulations: finite feet velocities and pivot impulses at the end mean they were finite
         // all along, i.e. every product the CLEAN arithmetic dropped was a zero.  Otherwise (an overflowing state: never seen) this
         // substep's joints are not the reference's: reported, error bit 5.

@@ -42,4 +42,8 @@ for k, n in enumerate(n3): print("  %-34s %10.0f %10.0f" % (n, p3[:, k].mean(), 
 p4 = np.loadtxt("gpurun_out/rcprof4.txt")[:NE]
 print("the batched game logic, cycles per step: mean over all environments / mean of the 12 slowest")
 for k, n in enumerate(["loads + event test", "tick", "ball", "closest robots", "barrier + lane-0 stores"]): print("  %-34s %10.0f %10.0f" % (n, p4[:, k].mean(), p4[top, k].mean()))
+print("the general solve of the slowest environments, cycles per step: level passes | joint phases | level passes run | cycles per level pass | per joint phase (10 per general solve)")
+for k in top:
+    nl, nj = int(p4[k, 7]) & 0xFFFFFFFF, int(p4[k, 7]) >> 32
+    print("  %9d %9d %6d %8.0f %8.0f" % (p4[k, 5], p4[k, 6], nl, p4[k, 5] / max(nl, 1), p4[k, 6] / max(nj, 1)))
 if os.environ.get("PROFILE_SAVE"): np.save(os.environ["PROFILE_SAVE"], d[:, 11])
