@@ -17,6 +17,11 @@ import os
 import sys
 import time
 
+# dmabuf IPC: the pool's host driver supports nothing else, and RCCL / tensor sharing across processes fails with
+# "hipIpcGetMemHandle: invalid argument" without it.  Exported by the image; kept here for a shell that dropped it (must be set
+# before the HIP runtime starts, i.e. before the first torch.cuda call of this process and of every rank it starts).
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

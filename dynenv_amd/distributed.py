@@ -7,6 +7,9 @@ runs on a side stream beside the kernel of step k+1.
 RNG streams are keyed by GLOBAL env id (dynenv_cfg.env_id_offset), so per-env results are invariant to the number of
 shards.  If the consumer (policy) is itself data-parallel, pass gather=False and skip the collective entirely.
 """
+import os
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (the only mode this pool's driver supports); effective if HIP has not started yet
 import numpy as np
 
 
