@@ -49,4 +49,4 @@ extern "C" __global__ void __launch_bounds__(64, 4) drv_partial_obs_deferred_ker
 // host helpers defined in driving_tu.hip (they touch that translation unit's device symbols / literal tables)
 hipError_t drv_upload_consts(const DrvConst& c);   // -> __constant__ DrvConst C
 bool drv_literals_ok(const DrvConst& c);           // the RoadK / CarK literals of the device code equal the computed constants, bit for bit
-hipError_t drv_prof_read(int which, void* dst, size_t bytes);  // -DDRV_PROFILE builds: g_dbgr / g_dbgw / g_dbgp / g_dbgs / g_dbgl = 0..4
+hipError_t drv_prof_read(int which, void* dst, size_t bytes);  // -DDRV_PROFILE builds: g_dbgr / g_dbgw / g_dbgp / g_dbgs / g_dbgl / g_pvprof = 0..5

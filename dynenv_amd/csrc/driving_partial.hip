@@ -37,6 +37,12 @@ struct PvLds {
   alignas(16) double atanTab[30];  // dev_atan2_t's table
 };
 __shared__ PvLds g_P;
+#ifdef DRV_PROFILE
+#define PV_PROF(...) __VA_ARGS__
+__device__ unsigned long long g_pvprof[4096 * 16];  // per environment (atomics on ONE set of counters serialise in L2 and the queue's back-pressure lands in the next phase), cycles summed over its agent passes of the run: detection | lane rows | blockers | buildings + list positions | pedestrian pairs | noise | random FPs | assembly + row out; [8] passes
+#else
+#define PV_PROF(...)
+#endif
 
 DE_DEV dm_u32x4 pv_rng(const DrvState& S, uint32_t genv, uint32_t episode, int elapsed, int agent, int kind, int index, int block) {
   uint32_t entity = (uint32_t)agent | ((uint32_t)kind << 4) | ((uint32_t)index << 8) | ((uint32_t)block << 16);
@@ -98,6 +104,7 @@ DE_DEV int pv_env(const DrvState& S, PvLds& L, const int e, const int lane, cons
 #pragma unroll 1
   for (; a < aEnd; ++a) {
     if (deadline != 0ull && __builtin_amdgcn_s_memtime() >= deadline) break;
+PV_PROF(const unsigned long long VT0 = __builtin_amdgcn_s_memtime();)
     float* __restrict__ grow = obs + ((size_t)e * A + a) * PV_DIM;
     float* row = L.row;
     for (int i = lane; i < PV_DIM; i += DE_WAVE) row[i] = 0.0f;
@@ -165,6 +172,7 @@ DE_DEV int pv_env(const DrvState& S, PvLds& L, const int e, const int lane, cons
         }
       }
     }
+PV_PROF(const unsigned long long VT1 = __builtin_amdgcn_s_memtime();)
     // ---- lane rows: Road.getCarLaneDistances :36-71 (rows 0..3 road 0, rows 4..5 road 1) ---------------------
     double ldist = 0.0, lc = 0.0, ls = 0.0, ltype = 0.0;
     int lseen = SIGHT_NONE;
@@ -184,6 +192,7 @@ DE_DEV int pv_env(const DrvState& S, PvLds& L, const int e, const int lane, cons
         ltype = ((i + n) < n ? 1.0 : -1.0) * typeMult;
       }
     }
+PV_PROF(const unsigned long long VT2 = __builtin_amdgcn_s_memtime();)
     // ---- phase 2: publish blockers (cars other than self, obstacles, buildings) ------------------------------
     // The four corner angles of every visible blocker: 4 n evaluations of atan2 for n blockers, pooled over the whole wave (item =
     // 4 j + corner) instead of four calls with only the blocker lanes busy - n is ~10 of 64 lanes, so one call replaces four.  The
@@ -239,6 +248,7 @@ DE_DEV int pv_env(const DrvState& S, PvLds& L, const int e, const int lane, cons
       L.blk[lane] = b;
     }
     __syncthreads();
+PV_PROF(const unsigned long long VT3 = __builtin_amdgcn_s_memtime();)
     // ---- phase 3: building occlusion :782-789, then list positions ------------------------------------------
     const bool isObj = (isCarLane && !isSelf) || isPedLane || isObsLane;
     bool alive = isObj && seen != SIGHT_NONE;
@@ -258,6 +268,7 @@ DE_DEV int pv_env(const DrvState& S, PvLds& L, const int e, const int lane, cons
     int listIdx = 0;
     if (alive) listIdx = isCarLane ? __popcll(carMask & below) : (isPedLane ? __popcll(pedMask & below) : __popcll(obsMask & below));
     if (isLaneRow) listIdx = __popcll(laneAlive & below);
+PV_PROF(const unsigned long long VT4 = __builtin_amdgcn_s_memtime();)
     // ---- phase 4: pedestrian interactions :792-801 ----------------------------------------------------------
     int pedInter = INTER_NONE;
     {
@@ -302,6 +313,7 @@ DE_DEV int pv_env(const DrvState& S, PvLds& L, const int e, const int lane, cons
       pedInter = useObs ? obsPed : carPed;
       if (alive && isPedLane && pedInter == INTER_OCCLUDE) seen = SIGHT_NONE;  // filterOcclude (row stays in the list)
     }
+PV_PROF(const unsigned long long VT5 = __builtin_amdgcn_s_memtime();)
     // ---- phase 5: noise (addNoiseRect :479-542 on self / cars / pedestrians / obstacles; addNoiseLane :382-413) ---
     // Objects and lane rows live on disjoint lanes: one pair of Philox blocks, one atan2 and one sincos serve both.  The ten
     // random-FP trials of phase 6 need a pair of blocks each as well: a Philox block costs the wave the same whatever the number
@@ -383,6 +395,7 @@ DE_DEV int pv_env(const DrvState& S, PvLds& L, const int e, const int lane, cons
         if (laneNoise) { lc = sc.c; ls = sc.s; }
       }
     }
+PV_PROF(const unsigned long long VT6 = __builtin_amdgcn_s_memtime();)
     // ---- phase 6: random false positives :824-874, one trial per lane (see phase 5 for which lanes) -------------
     int fpClass = -1;
     V2 fpPos = v2(0.0, 0.0);
@@ -409,6 +422,7 @@ DE_DEV int pv_env(const DrvState& S, PvLds& L, const int e, const int lane, cons
         }
       }
     }
+PV_PROF(const unsigned long long VT7 = __builtin_amdgcn_s_memtime();)
     // ---- phase 7: list assembly (misclassification swap :816-821, FP pedestrians near cars :877-882, final filter) ---
     // A lane can hold a real object AND a random-FP trial (lanes 0..9, in a crowded view): two independent code paths.
     const bool realCar = alive && isCarLane, realObs = alive && isObsLane, realPed = alive && isPedLane;
@@ -529,6 +543,7 @@ DE_DEV int pv_env(const DrvState& S, PvLds& L, const int e, const int lane, cons
     for (int i = lane; i < PV_DIM; i += DE_WAVE) grow[i] = row[i];
     (void)nObst0; (void)nPeds0; (void)nLanes0;
     __syncthreads();
+PV_PROF(if (lane == 0) { const unsigned long long VT8 = __builtin_amdgcn_s_memtime(); atomicAdd(&g_pvprof[(e & 4095) * 16 + 0], VT1 - VT0); atomicAdd(&g_pvprof[(e & 4095) * 16 + 1], VT2 - VT1); atomicAdd(&g_pvprof[(e & 4095) * 16 + 2], VT3 - VT2); atomicAdd(&g_pvprof[(e & 4095) * 16 + 3], VT4 - VT3); atomicAdd(&g_pvprof[(e & 4095) * 16 + 4], VT5 - VT4); atomicAdd(&g_pvprof[(e & 4095) * 16 + 5], VT6 - VT5); atomicAdd(&g_pvprof[(e & 4095) * 16 + 6], VT7 - VT6); atomicAdd(&g_pvprof[(e & 4095) * 16 + 7], VT8 - VT7); atomicAdd(&g_pvprof[(e & 4095) * 16 + 8], 1ull); })
   }
   if (wave_ballot(overflow != 0) && lane == 0) envi[EI_ERR] = envi[EI_ERR] | 8;  // rows dropped (dynenv.h, error bit 3)
   return a;

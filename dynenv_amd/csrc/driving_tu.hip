@@ -37,6 +37,7 @@ hipError_t drv_prof_read(int which, void* dst, size_t bytes) {
     case 2: return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dbgp), bytes);
     case 3: return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dbgs), bytes);
     case 4: return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dbgl), bytes);
+    case 5: return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_pvprof), bytes);
   }
 #endif
   (void)which; (void)dst; (void)bytes;

@@ -796,6 +796,7 @@ int dynenv_debug_counters(dynenv_t* h, int64_t* out4) {
   { static unsigned long long d[4096 * 12]; HIP_OK(drv_prof_read(1, d, sizeof(d))); FILE* f = fopen("gpurun_out/dbgw.txt", "w"); for (int k = 0; k < 4096; ++k) { for (int q = 0; q < 12; ++q) fprintf(f, "%llu ", d[12*k+q]); fprintf(f, "\n"); } fclose(f); }
   { static unsigned long long d[4096 * 8]; HIP_OK(drv_prof_read(2, d, sizeof(d))); FILE* f = fopen("gpurun_out/dbgp.txt", "w"); for (int k = 0; k < 4096; ++k) { for (int q = 0; q < 8; ++q) fprintf(f, "%llu ", d[8*k+q]); fprintf(f, "\n"); } fclose(f); }
   { static unsigned long long d[4096 * 8]; HIP_OK(drv_prof_read(3, d, sizeof(d))); FILE* f = fopen("gpurun_out/dbgs.txt", "w"); for (int k = 0; k < 4096; ++k) { for (int q = 0; q < 8; ++q) fprintf(f, "%llu ", d[8*k+q]); fprintf(f, "\n"); } fclose(f); }
+  { static unsigned long long d[4096 * 16]; HIP_OK(drv_prof_read(5, d, sizeof(d))); FILE* f = fopen("gpurun_out/dbgv.txt", "w"); for (int k = 0; k < 4096; ++k) { for (int q = 0; q < 16; ++q) fprintf(f, "%llu ", d[16*k+q]); fprintf(f, "\n"); } fclose(f); }
   { static unsigned long long d[4096 * 8]; HIP_OK(drv_prof_read(4, d, sizeof(d))); FILE* f = fopen("gpurun_out/dbgl.txt", "w"); for (int k = 0; k < 4096; ++k) { for (int q = 0; q < 8; ++q) fprintf(f, "%llu ", d[8*k+q]); fprintf(f, "\n"); } fclose(f); }
 #endif
   return DYNENV_OK;

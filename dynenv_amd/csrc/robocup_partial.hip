@@ -535,7 +535,9 @@ DE_OOL int rc_partial_obs_fused(uint64_t seed, int env_id_offset, int* envi, int
 // seenPart.  The counts are integer sums, so adding the parts reproduces the sequential accumulation exactly;
 // rc_partial_finalize_kernel does that and processSeens.  (The order of the list varies from run to run; nothing depends
 // on it.)
-#define RC_DEFER_BLOCKS 512
+#ifndef RC_DEFER_BLOCKS
+#define RC_DEFER_BLOCKS 1024 /* round 6: 128 +4.4 %, 256 +1.4 %, 512 0, 1024 -0.65 %, 2048 -0.6 %, 4096 0 (RoboCup Partial step time) */
+#endif
 extern "C" __global__ void __launch_bounds__(64, 4)
 rc_partial_obs_deferred_kernel(RcState S, float* __restrict__ obs) {
   const int t = blockIdx.y, a = blockIdx.z, lane = threadIdx.x;
