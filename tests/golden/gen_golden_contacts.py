@@ -226,6 +226,13 @@ class Space(object):
                 out.append(_PointQueryInfo(s.user))
         return out
 
+    def reindex_shapes_for_body(self, body):
+        """cpSpaceReindexShapesForBody: refresh the cached world geometry of a body that was moved by hand (point_query reads the cache)"""
+        self.reindex()
+        for s in self.world.shapes:
+            if s.body is body.k:
+                s.update()
+
     shapes = property(lambda s: s._shapes + [j.user for j in s.world.joints])   # (gen_golden_robocup.dump counts the joints in the space)
     bodies = property(lambda s: s._bodies)
 
