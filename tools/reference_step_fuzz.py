@@ -3,7 +3,7 @@
 fixtures of tests/golden/gen_golden_contacts.py (same generator functions, same checks as tests/test_oracle_golden_contacts.py, nothing
 written to disk).  Build container only: it imports /root/reference (with the functional pymunk facade over tests/kat_general.py).
 
-   python3 tools/reference_step_fuzz.py [n_driving] [n_robocup] [n_driving_partial] [n_robocup_partial] > profiles/r05_reference_step_fuzz.txt      (1000 300: ~10 min)
+   python3 tools/reference_step_fuzz.py [n_driving] [n_robocup] [n_driving_partial] [n_robocup_partial] [n_goalposts] [n_ball_out] [n_kicks] > profiles/r05_reference_step_fuzz.txt      (1000 300: ~10 min)
 """
 import os
 import sys
@@ -208,6 +208,104 @@ def main():
         print("RoboCup, Partial observations + Realistic noise: %d trajectories, %d steps, %d of them well-conditioned and checked (rewards incl. processSeens, "
               "five snapshots per step: list lengths / seen tuple exact, rows 2e-6): %d failures  (%.0f s)"
               % (n_rp, steps, checked, len([f for f in failures if f[0] == "robocup_partial"]), time.time() - t0))
+    # The ball leaving the field (isBallOutOfField, RoboCupEnvironment.py:622-732): over a side line, over an end line beside the goal (goal kick
+    # or corner, by who kicked last), into the goal; the ball put back, the free kick's owner, grace period and counter (ballFreeKickProcess
+    # :600-619), the personal rewards of lastKicked, and - in the steps after - robots of the wrong team touching an owned ball (ballCollision)
+    n_out = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+    t0 = time.time()
+    steps = checked = 0
+    begins = np.zeros(5, np.int64)
+    kinds, goals = np.zeros(4, np.int64), np.zeros(2, np.int64)
+    for k in range(n_out):
+        n, can_fall, length, fw = int(rng.choice([2, 3, 5, 5])), bool(rng.random() < 0.5), int(rng.integers(6, 14)), float(rng.uniform(0.3, 0.9))
+        kind = int(rng.choice(4, p=[0.3, 0.3, 0.2, 0.2]))                    # side line | end line beside the goal | goal | a slow ball that stays in
+        far, u, inset, speed = bool(rng.random() < 0.5), float(rng.random()), float(rng.uniform(4.0, 25.0)), float(rng.uniform(120.0, 380.0))
+        tang = float(rng.uniform(-0.5, 0.5))
+        kickers = [int(x) for x in rng.choice(2 * n, int(rng.integers(0, 4)), replace=False)]
+        kinds[kind] += 1
+
+        def setup(env, kind=kind, far=far, u=u, inset=inset, speed=speed, tang=tang, kickers=kickers):
+            Vec2d = gc.Vec2d
+            lo, hx, hy = env.sideLength, env.W - env.sideLength, env.H - env.sideLength
+            if kind == 0:      # over a side line
+                x, y = lo + 60.0 + u * (hx - lo - 120.0), (hy - inset if far else lo + inset)
+                vx, vy = tang * speed, (speed if far else -speed)
+            else:              # towards an end line: beside the goal (1), between the posts (2), or too slow to get there (3)
+                gw = env.goalWidth
+                if kind == 2:
+                    y = env.H / 2 + (2.0 * u - 1.0) * (gw - 25.0)
+                else:
+                    y = (env.H / 2 + gw + 25.0 + u * (hy - env.H / 2 - gw - 50.0)) if u < 0.5 else (env.H / 2 - gw - 25.0 - (u - 0.5) * 2.0 * (env.H / 2 - gw - lo - 50.0))
+                x = hx - inset if far else lo + inset
+                sp = 3.0 if kind == 3 else speed
+                vx, vy = (sp if far else -sp), tang * sp * 0.3
+            b = env.ball.shape.body
+            b.position = Vec2d(x, y)
+            b.velocity = Vec2d(vx, vy)
+            env.ball.prevPos = Vec2d(x, y)
+            env.ball.lastKicked = list(kickers)
+            env.space.reindex_shapes_for_body(b)
+            return {}
+        out = {}
+        stdout, sys.stdout = sys.stdout, devnull
+        try:
+            gc.gen_robocup(out, "t", n, can_fall, length, 7000 + SB + k, fw, setup)
+        finally:
+            sys.stdout = stdout
+        try:
+            checked += tc.check_robocup_trajectory(out, "t", robocup_env)
+        except AssertionError as e:
+            failures.append(("robocup_out", n, 7000 + SB + k, length, str(e)[:200]))
+        steps += length
+        begins += out["t_begins"]
+        goals += np.asarray(out["t_goals"]).reshape(-1)[-2:].astype(np.int64)
+    if n_out:
+        print("RoboCup, the ball leaving the field: %d trajectories (side line %d, end line beside the goal %d, into the goal %d, staying in %d; 0-3 last kickers; "
+              "6-14 steps each, %d steps; goals %d / %d; first touches robot-robot %d, robot-ball %d, robot-post %d, ball-post %d, own feet %d) against the oracle - "
+              "same tolerances: %d failures; %d of the %d steps well-conditioned and checked  (%.0f s)"
+              % ((n_out,) + tuple(kinds) + (steps, goals[0], goals[1]) + tuple(begins) + (len([f for f in failures if f[0] == "robocup_out"]), checked, steps, time.time() - t0)))
+    # Kicks (Robot.kick, tick's kick phases :875-912: the pivot joint removed at 500 ms, the foot at 150 px/s, back at -125, the foot put back on its
+    # starting position, the joint re-added; ballCollision's lastKicked): the ball at a random spot in front of a robot that kicks with a random foot,
+    # a second robot kicking a few steps later, everybody else walking about
+    n_kick = int(sys.argv[7]) if len(sys.argv) > 7 else 0
+    t0 = time.time()
+    steps = checked = 0
+    begins = np.zeros(5, np.int64)
+    kicking = 0
+    for k in range(n_kick):
+        n, can_fall, length, fw = int(rng.choice([2, 3, 5, 5])), bool(rng.random() < 0.5), int(rng.integers(6, 14)), float(rng.uniform(0.2, 0.8))
+        r0, r1 = [int(x) for x in rng.choice(2 * n, 2, replace=False)]
+        fx, fy, foot0, foot1, s1 = float(rng.uniform(22.0, 50.0)), float(rng.uniform(-24.0, 24.0)), int(rng.integers(1, 3)), int(rng.integers(1, 3)), int(rng.integers(1, 5))
+        bvx, bvy = float(rng.uniform(-40.0, 40.0)), float(rng.uniform(-40.0, 40.0))
+
+        def setup(env, r0=r0, r1=r1, fx=fx, fy=fy, foot0=foot0, foot1=foot1, s1=s1, bvx=bvx, bvy=bvy):
+            Vec2d = gc.Vec2d
+            r = env.agents[r0]
+            q = r.getPos() + Vec2d(fx, fy).rotated(r.leftFoot.body.angle)
+            b = env.ball.shape.body
+            b.position = Vec2d(q.x, q.y)
+            b.velocity = Vec2d(bvx, bvy)
+            env.ball.prevPos = Vec2d(q.x, q.y)
+            env.space.reindex_shapes_for_body(b)
+            return {0: {r0: [0, 0, foot0, 3]}, s1: {r1: [0, 0, foot1, 3]}}
+        out = {}
+        stdout, sys.stdout = sys.stdout, devnull
+        try:
+            gc.gen_robocup(out, "t", n, can_fall, length, 8000 + SB + k, fw, setup)
+        finally:
+            sys.stdout = stdout
+        try:
+            checked += tc.check_robocup_trajectory(out, "t", robocup_env)
+        except AssertionError as e:
+            failures.append(("robocup_kick", n, 8000 + SB + k, length, str(e)[:200]))
+        steps += length
+        begins += out["t_begins"]
+        kicking += int(np.asarray(out["t_states_ri"])[:, :, 7].sum())
+    if n_kick:
+        print("RoboCup, kicks: %d trajectories (the ball 22-50 px in front of a robot that kicks with a random foot, a second robot kicking 1-4 steps later; 6-14 steps "
+              "each, %d steps; robots seen mid-kick in the recorded states %d; first touches robot-robot %d, robot-ball %d, robot-post %d, ball-post %d, own feet %d) "
+              "against the oracle - same tolerances: %d failures; %d of the %d steps well-conditioned and checked  (%.0f s)"
+              % ((n_kick, steps, kicking) + tuple(begins) + (len([f for f in failures if f[0] == "robocup_kick"]), checked, steps, time.time() - t0)))
     for f in failures:
         print("FAILURE", f)
     sys.exit(1 if failures else 0)
