@@ -3,7 +3,7 @@
 fixtures of tests/golden/gen_golden_contacts.py (same generator functions, same checks as tests/test_oracle_golden_contacts.py, nothing
 written to disk).  Build container only: it imports /root/reference (with the functional pymunk facade over tests/kat_general.py).
 
-   python3 tools/reference_step_fuzz.py [n_driving] [n_robocup] [n_driving_partial] [n_robocup_partial] [n_goalposts] [n_ball_out] [n_kicks] > profiles/r05_reference_step_fuzz.txt      (1000 300: ~10 min)
+   python3 tools/reference_step_fuzz.py [n_driving] [n_robocup] [n_driving_partial] [n_robocup_partial] [n_goalposts] [n_ball_out] [n_kicks] [n_penalties] > profiles/r05_reference_step_fuzz.txt      (1000 300: ~10 min)
 """
 import os
 import sys
@@ -306,6 +306,71 @@ def main():
               "each, %d steps; robots seen mid-kick in the recorded states %d; first touches robot-robot %d, robot-ball %d, robot-post %d, ball-post %d, own feet %d) "
               "against the oracle - same tolerances: %d failures; %d of the %d steps well-conditioned and checked  (%.0f s)"
               % ((n_kick, steps, kicking) + tuple(begins) + (len([f for f in failures if f[0] == "robocup_kick"]), checked, steps, time.time() - t0)))
+    # Penalties (tick :945-995, penalize :824-859, getFreePenaltySpot): three or four robots of one team inside their own penalty box (the third is an
+    # illegal defender), a robot of the other team walking off the field, one more serving a penalty that ends within the trajectory (un-penalize:
+    # a free penalty spot, both feet moved there), everybody else walking about - and whatever the teleported robots run into afterwards
+    n_pen = int(sys.argv[8]) if len(sys.argv) > 8 else 0
+    t0 = time.time()
+    steps = checked = 0
+    begins = np.zeros(5, np.int64)
+    penalized = 0
+    for k in range(n_pen):
+        n, can_fall, length, fw = int(rng.choice([3, 4, 5, 5])), bool(rng.random() < 0.5), int(rng.integers(6, 14)), float(rng.uniform(0.2, 0.8))
+        team = int(rng.integers(0, 2))                        # whose box gets crowded (0: ids 0..n-1, the left box)
+        m = min(n, int(rng.integers(3, 5)))
+        inbox = [int(x) + team * n for x in rng.choice(n, m, replace=False)]
+        ys = [float(v) for v in rng.permutation(4)[:m] * 50.0 + rng.uniform(-8.0, 8.0, m)]
+        xs = [float(v) for v in rng.uniform(12.0, 48.0, m)]
+        leaver = int(rng.integers(0, n)) + (1 - team) * n
+        edge, eu, ed = int(rng.integers(0, 4)), float(rng.random()), float(rng.uniform(6.0, 30.0))
+        others = [i for i in range(2 * n) if i not in inbox and i != leaver]
+        served = int(rng.choice(others)) if others and rng.random() < 0.7 else -1
+        left_ms = int(rng.integers(10, 3000))
+
+        def setup(env, team=team, inbox=inbox, xs=xs, ys=ys, leaver=leaver, edge=edge, eu=eu, ed=ed, served=served, left_ms=left_ms):
+            import math
+            Vec2d = gc.Vec2d
+
+            def put(r, x, y, a):
+                for foot in (r.leftFoot, r.rightFoot):
+                    foot.body.position = Vec2d(x, y)
+                    foot.body.angle = a
+                    env.space.reindex_shapes_for_body(foot.body)
+                r.prevPos = r.getPos()
+            for rid, x, y in zip(inbox, xs, ys):
+                X = env.sideLength + x if team == 0 else env.W - env.sideLength - x
+                put(env.agents[rid], X, env.H / 2 - 75.0 + y, 0.0 if team == 0 else math.pi)
+            if edge == 0: x, y, a = 100.0 + eu * (env.W - 200.0), ed, -math.pi / 2
+            elif edge == 1: x, y, a = 100.0 + eu * (env.W - 200.0), env.H - ed, math.pi / 2
+            elif edge == 2: x, y, a = ed, 60.0 + eu * (env.H - 120.0), math.pi
+            else: x, y, a = env.W - ed, 60.0 + eu * (env.H - 120.0), 0.0
+            put(env.agents[leaver], x, y, a)
+            if served >= 0:
+                r = env.agents[served]
+                env.penalize(r)
+                r.penalTime = left_ms
+                r.prevPos = r.getPos()
+                for foot in (r.leftFoot, r.rightFoot):
+                    env.space.reindex_shapes_for_body(foot.body)
+            return {s_: {leaver: [3, 0, 0, 3]} for s_ in range(0, 14)}
+        out = {}
+        stdout, sys.stdout = sys.stdout, devnull
+        try:
+            gc.gen_robocup(out, "t", n, can_fall, length, 9000 + SB + k, fw, setup)
+        finally:
+            sys.stdout = stdout
+        try:
+            checked += tc.check_robocup_trajectory(out, "t", robocup_env)
+        except AssertionError as e:
+            failures.append(("robocup_penalties", n, 9000 + SB + k, length, str(e)[:200]))
+        steps += length
+        begins += out["t_begins"]
+        penalized += int((np.asarray(out["t_states_ri"])[:, :, 1].max(0) > np.asarray(out["t_b_ri"])[:np.asarray(out["t_states_ri"]).shape[1], 1]).sum())
+    if n_pen:
+        print("RoboCup, penalties: %d trajectories (3-4 robots of a team in their own box, a robot walking off the field, a penalty ending; 6-14 steps each, %d "
+              "steps; robots penalized on the way %d; first touches robot-robot %d, robot-ball %d, robot-post %d, ball-post %d, own feet %d) against the oracle - same "
+              "tolerances: %d failures; %d of the %d steps well-conditioned and checked  (%.0f s)"
+              % ((n_pen, steps, penalized) + tuple(begins) + (len([f for f in failures if f[0] == "robocup_penalties"]), checked, steps, time.time() - t0)))
     for f in failures:
         print("FAILURE", f)
     sys.exit(1 if failures else 0)
