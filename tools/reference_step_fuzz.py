@@ -3,7 +3,7 @@
 fixtures of tests/golden/gen_golden_contacts.py (same generator functions, same checks as tests/test_oracle_golden_contacts.py, nothing
 written to disk).  Build container only: it imports /root/reference (with the functional pymunk facade over tests/kat_general.py).
 
-   python3 tools/reference_step_fuzz.py [n_driving] [n_robocup] [n_driving_partial] [n_robocup_partial] [n_goalposts] [n_ball_out] [n_kicks] [n_penalties] > profiles/r05_reference_step_fuzz.txt      (1000 300: ~10 min)
+   python3 tools/reference_step_fuzz.py [n_driving] [n_robocup] [n_driving_partial] [n_robocup_partial] [n_goalposts] [n_ball_out] [n_kicks] [n_penalties] [n_driving_finish] > profiles/r05_reference_step_fuzz.txt      (1000 300: ~10 min)
 """
 import os
 import sys
@@ -371,6 +371,52 @@ def main():
               "steps; robots penalized on the way %d; first touches robot-robot %d, robot-ball %d, robot-post %d, ball-post %d, own feet %d) against the oracle - same "
               "tolerances: %d failures; %d of the %d steps well-conditioned and checked  (%.0f s)"
               % ((n_pen, steps, penalized) + tuple(begins) + (len([f for f in failures if f[0] == "robocup_penalties"]), checked, steps, time.time() - t0)))
+    # Driving, cars reaching their goals (tick :399-405 AtGoal / finished; step :281-285 allFinished and the team reward; the time bonus): a random
+    # subset of the cars starts 60-170 px in front of its goal, heading for it at 60-160 px/s with a lateral offset; the others drive about
+    n_fin = int(sys.argv[9]) if len(sys.argv) > 9 else 0
+    t0 = time.time()
+    steps = touches = finished = allfin = 0
+    for k in range(n_fin):
+        n, seed, length, bias = int(rng.choice([2, 3, 4, 6, 10])), 10000 + SB + k, int(rng.integers(12, 30)), float(rng.uniform(0.5, 1.0))
+        chosen = rng.random(n) < float(rng.choice([0.5, 0.8, 1.0, 1.0]))
+        dist, lat, spd = rng.uniform(60.0, 170.0, n), rng.uniform(-28.0, 28.0, n), rng.uniform(60.0, 160.0, n)
+
+        def setup(env, chosen=chosen, dist=dist, lat=lat, spd=spd):
+            Vec2d = type(env.agents[0].goal)
+            for i, car in enumerate(env.agents):
+                if not chosen[i]:
+                    continue
+                road = min(env.roads, key=lambda r: min((r.points[0] - car.goal).length, (r.points[1] - car.goal).length))
+                u = road.direction if (road.points[1] - car.goal).length < 1e-9 else -road.direction
+                pos = car.goal - u * float(dist[i]) + road.normal * float(lat[i])
+                body = car.shape.body
+                body.position = Vec2d(pos.x, pos.y)
+                body.angle = u.angle
+                body.velocity = Vec2d(u.x * float(spd[i]), u.y * float(spd[i]))
+                body.angular_velocity = 0.0
+                car.direction = Vec2d(u.x, u.y)
+                car.prevPos = Vec2d(pos.x, pos.y)
+                if hasattr(env.space, "reindex_shapes_for_body"):
+                    env.space.reindex_shapes_for_body(body)
+        out = {}
+        stdout, sys.stdout = sys.stdout, devnull
+        try:
+            gc.gen_driving(out, n, seed, length, "t", bias, setup=setup)
+        finally:
+            sys.stdout = stdout
+        try:
+            tc.check_trajectory(out, "t", driving_env)
+        except AssertionError as e:
+            failures.append(("driving_finish", n, seed, length, str(e)[:200]))
+        steps += length
+        touches += int(out["t_begins_per_step"].sum())
+        fin = np.asarray(out["t_states_cars_i"][-1])[:, 2] if np.asarray(out["t_states_cars_i"][-1]).shape[1] > 2 else np.zeros(n)
+        finished += int(np.asarray(fin).sum())
+        allfin += int(np.asarray(fin).all())
+    if n_fin:
+        print("Driving, cars reaching their goals: %d trajectories (2-10 players, a random subset 60-170 px in front of its goal; 12-30 steps each, %d steps; %d "
+              "first touches on the way; cars finished at the end %d, trajectories in which every car had %d) against the oracle - rewards / states 1e-9, "
+              "observations 2e-6, flags exact: %d failures  (%.0f s)" % (n_fin, steps, touches, finished, allfin, len([f for f in failures if f[0] == "driving_finish"]), time.time() - t0))
     for f in failures:
         print("FAILURE", f)
     sys.exit(1 if failures else 0)
