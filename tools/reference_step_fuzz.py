@@ -67,6 +67,13 @@ def main():
     rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "2026")))
     SB = int(os.environ.get("FUZZ_SEED_BASE", "0"))  # added to every trajectory seed: a population of its own, not the default one with other lengths
     devnull = open(os.devnull, "w")
+    dump_dir = os.environ.get("FUZZ_DUMP")    # keep every trajectory as <dir>/<kind>_<k>.npz: tools/hip_reference_step_fuzz.py runs the HIP path on them (GPU box)
+    if dump_dir:
+        os.makedirs(dump_dir, exist_ok=True)
+
+    def dump(kind, k, out):
+        if dump_dir:
+            np.savez_compressed(os.path.join(dump_dir, "%s_%05d.npz" % (kind, k)), **out)
     t0 = time.time()
     steps = touches = crashed = dead = 0
     failures = []
@@ -78,6 +85,7 @@ def main():
             gc.gen_driving(out, n, seed, length, "t", bias)
         finally:
             sys.stdout = stdout
+        dump("driving", k, out)
         try:
             tc.check_trajectory(out, "t", driving_env)
         except AssertionError as e:
@@ -100,6 +108,7 @@ def main():
             gc.gen_robocup(out, "t", n, can_fall, length, 2000 + SB + k, fw)
         finally:
             sys.stdout = stdout
+        dump("robocup", k, out)
         try:
             checked += tc.check_robocup_trajectory(out, "t", robocup_env)
         except AssertionError as e:
@@ -155,6 +164,7 @@ def main():
             gc.gen_robocup(out, "t", n, can_fall, length, 6000 + SB + k, 0.3, setup)
         finally:
             sys.stdout = stdout
+        dump("robocup_posts", k, out)
         try:
             checked += tc.check_robocup_trajectory(out, "t", robocup_env)
         except AssertionError as e:
@@ -179,6 +189,7 @@ def main():
             gc.gen_driving_partial(out, n, seed, length, "t", bias, magn)
         finally:
             sys.stdout = stdout
+        dump("driving_partial", k, out)
         try:
             rows += tc.check_partial_trajectory(out, "t", driving_partial_env)
         except AssertionError as e:
@@ -199,6 +210,7 @@ def main():
             gc.gen_robocup(out, "t", n, can_fall, length, 4000 + SB + k, fw, partial_magn=magn)
         finally:
             sys.stdout = stdout
+        dump("robocup_partial", k, out)
         try:
             checked += tc.check_robocup_trajectory(out, "t", robocup_partial_env, partial=True)
         except AssertionError as e:
@@ -252,6 +264,7 @@ def main():
             gc.gen_robocup(out, "t", n, can_fall, length, 7000 + SB + k, fw, setup)
         finally:
             sys.stdout = stdout
+        dump("robocup_out", k, out)
         try:
             checked += tc.check_robocup_trajectory(out, "t", robocup_env)
         except AssertionError as e:
@@ -294,6 +307,7 @@ def main():
             gc.gen_robocup(out, "t", n, can_fall, length, 8000 + SB + k, fw, setup)
         finally:
             sys.stdout = stdout
+        dump("robocup_kick", k, out)
         try:
             checked += tc.check_robocup_trajectory(out, "t", robocup_env)
         except AssertionError as e:
@@ -359,6 +373,7 @@ def main():
             gc.gen_robocup(out, "t", n, can_fall, length, 9000 + SB + k, fw, setup)
         finally:
             sys.stdout = stdout
+        dump("robocup_penalties", k, out)
         try:
             checked += tc.check_robocup_trajectory(out, "t", robocup_env)
         except AssertionError as e:
@@ -404,6 +419,7 @@ def main():
             gc.gen_driving(out, n, seed, length, "t", bias, setup=setup)
         finally:
             sys.stdout = stdout
+        dump("driving_finish", k, out)
         try:
             tc.check_trajectory(out, "t", driving_env)
         except AssertionError as e:
