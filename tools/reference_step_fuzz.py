@@ -3,8 +3,9 @@
 fixtures of tests/golden/gen_golden_contacts.py (same generator functions, same checks as tests/test_oracle_golden_contacts.py, nothing
 written to disk).  Build container only: it imports /root/reference (with the functional pymunk facade over tests/kat_general.py).
 
-   python3 tools/reference_step_fuzz.py [n_driving] [n_robocup] [n_driving_partial] [n_robocup_partial] [n_goalposts] [n_ball_out] [n_kicks] [n_penalties] [n_driving_finish] > profiles/r05_reference_step_fuzz.txt      (1000 300: ~10 min)
+   python3 tools/reference_step_fuzz.py [n_driving] [n_robocup] [n_driving_partial] [n_robocup_partial] [n_goalposts] [n_ball_out] [n_kicks] [n_penalties] [n_driving_finish] [n_falls] > profiles/r05_reference_step_fuzz.txt      (1000 300: ~10 min)
 """
+import math
 import os
 import sys
 import time
@@ -433,6 +434,58 @@ def main():
         print("Driving, cars reaching their goals: %d trajectories (2-10 players, a random subset 60-170 px in front of its goal; 12-30 steps each, %d steps; %d "
               "first touches on the way; cars finished at the end %d, trajectories in which every car had %d) against the oracle - rewards / states 1e-9, "
               "observations 2e-6, flags exact: %d failures  (%.0f s)" % (n_fin, steps, touches, finished, allfin, len([f for f in failures if f[0] == "driving_finish"]), time.time() - t0))
+    # Falls (tick :925-944: getting up, or falling AGAIN with the die > 0.9; fall :735-792: the push on everything within 40 px, the ball's
+    # lastKicked / ownership branch, the third fall's penalty): two to four robots start on the ground with one or two falls behind them and
+    # 10-1500 ms to go, the ball lies next to one of them - owned by a team, in its grace period or counting down, or free - canFall on
+    n_fall = int(sys.argv[10]) if len(sys.argv) > 10 else 0
+    t0 = time.time()
+    steps = checked = 0
+    begins = np.zeros(5, np.int64)
+    refalls = penal = 0
+    for k in range(n_fall):
+        n, length, fw = int(rng.choice([2, 3, 5, 5])), int(rng.integers(6, 14)), float(rng.uniform(0.2, 0.8))
+        down = [int(x) for x in rng.choice(2 * n, min(2 * n, int(rng.integers(2, 5))), replace=False)]
+        cnt, left = [int(x) for x in rng.integers(1, 3, len(down))], [float(x) for x in rng.integers(10, 1500, len(down))]
+        bang, bdist = float(rng.uniform(-math.pi, math.pi)), float(rng.uniform(24.0, 46.0))
+        owned, grace, freec = int(rng.integers(-1, 2)), float(rng.choice([0.0, 0.0, 700.0, 14999.0])), float(rng.choice([0.0, 300.0, 9999.0]))
+        kickers = [int(x) for x in rng.choice(2 * n, int(rng.integers(0, 4)), replace=False)]
+
+        def setup(env, down=down, cnt=cnt, left=left, bang=bang, bdist=bdist, owned=owned, grace=grace, freec=freec, kickers=kickers):
+            Vec2d = gc.Vec2d
+            for rid, c, ms in zip(down, cnt, left):
+                r = env.agents[rid]
+                r.fallen, r.fallCntr, r.fallTime = True, c, ms
+            p = env.agents[down[0]].getPos()
+            b = env.ball.shape.body
+            b.position = Vec2d(p.x + bdist * math.cos(bang), p.y + bdist * math.sin(bang))
+            env.ball.prevPos = Vec2d(b.position.x, b.position.y)
+            env.ball.lastKicked = list(kickers)
+            env.ballOwned = owned
+            if owned != 0:
+                env.gracePeriod, env.ballFreeCntr = (grace, 0.0) if grace > 0 else (0.0, freec)
+            env.space.reindex_shapes_for_body(b)
+            return {}
+        out = {}
+        stdout, sys.stdout = sys.stdout, devnull
+        try:
+            gc.gen_robocup(out, "t", n, True, length, 11000 + SB + k, fw, setup)
+        finally:
+            sys.stdout = stdout
+        dump("robocup_falls", k, out)
+        try:
+            checked += tc.check_robocup_trajectory(out, "t", robocup_env)
+        except AssertionError as e:
+            failures.append(("robocup_falls", n, 11000 + SB + k, length, str(e)[:200]))
+        steps += length
+        begins += out["t_begins"]
+        ri, b0 = np.asarray(out["t_states_ri"]), np.asarray(out["t_b_ri"])
+        refalls += int((ri[:, :, 6].max(0) > b0[:ri.shape[1], 6]).sum())
+        penal += int((ri[:, :, 1].max(0) > b0[:ri.shape[1], 1]).sum())
+    if n_fall:
+        print("RoboCup, falls: %d trajectories (2-4 robots on the ground with 10-1500 ms to go and one or two falls behind them, the ball beside one of them, owned / in "
+              "its grace period / counting down / free; 6-14 steps each, %d steps; robots that fell (again) on the way %d, penalized %d; first touches robot-robot %d, "
+              "robot-ball %d, robot-post %d, ball-post %d, own feet %d) against the oracle - same tolerances: %d failures; %d of the %d steps well-conditioned and checked  (%.0f s)"
+              % ((n_fall, steps, refalls, penal) + tuple(begins) + (len([f for f in failures if f[0] == "robocup_falls"]), checked, steps, time.time() - t0)))
     for f in failures:
         print("FAILURE", f)
     sys.exit(1 if failures else 0)
