@@ -3,7 +3,7 @@
 fixtures of tests/golden/gen_golden_contacts.py (same generator functions, same checks as tests/test_oracle_golden_contacts.py, nothing
 written to disk).  Build container only: it imports /root/reference (with the functional pymunk facade over tests/kat_general.py).
 
-   python3 tools/reference_step_fuzz.py [n_driving] [n_robocup] [n_driving_partial] [n_robocup_partial] [n_goalposts] [n_ball_out] [n_kicks] [n_penalties] [n_driving_finish] [n_falls] > profiles/r05_reference_step_fuzz.txt      (1000 300: ~10 min)
+   python3 tools/reference_step_fuzz.py [n_driving] [n_robocup] [n_driving_partial] [n_robocup_partial] [n_goalposts] [n_ball_out] [n_kicks] [n_penalties] [n_driving_finish] [n_falls] [n_duels] > profiles/r05_reference_step_fuzz.txt      (1000 300: ~10 min)
 """
 import math
 import os
@@ -486,6 +486,61 @@ def main():
               "its grace period / counting down / free; 6-14 steps each, %d steps; robots that fell (again) on the way %d, penalized %d; first touches robot-robot %d, "
               "robot-ball %d, robot-post %d, ball-post %d, own feet %d) against the oracle - same tolerances: %d failures; %d of the %d steps well-conditioned and checked  (%.0f s)"
               % ((n_fall, steps, refalls, penal) + tuple(begins) + (len([f for f in failures if f[0] == "robocup_falls"]), checked, steps, time.time() - t0)))
+    # Duels (robotPushingDet :1010-1036 might-push flags; robotCollision :1039-1088: touch counters, the fall dice 0.9999 / 0.99995 ** touchCntr,
+    # fall(), the pusher's penalty when the pushed robot goes down; separate :1091-1103): one to three pairs of opposing robots 45-80 px apart,
+    # facing each other within +-0.6 rad, both told to walk forward for the whole trajectory; canFall on
+    n_duel = int(sys.argv[11]) if len(sys.argv) > 11 else 0
+    t0 = time.time()
+    steps = checked = 0
+    begins = np.zeros(5, np.int64)
+    fell = penal = 0
+    for k in range(n_duel):
+        n, length, fw = int(rng.choice([2, 3, 5, 5])), int(rng.integers(8, 18)), float(rng.uniform(0.2, 0.8))
+        pairs = min(n, int(rng.integers(1, 4)))
+        ia, ib = [int(x) for x in rng.choice(n, pairs, replace=False)], [int(x) + n for x in rng.choice(n, pairs, replace=False)]
+        cx, cy = rng.uniform(200.0, 840.0, pairs), (np.arange(pairs) * 180.0 + 150.0 + rng.uniform(-30.0, 30.0, pairs))
+        dirs, gaps, skew = rng.uniform(-math.pi, math.pi, pairs), rng.uniform(45.0, 80.0, pairs), rng.uniform(-0.6, 0.6, (pairs, 2))
+        pre = rng.integers(0, 400, (pairs, 2))       # touch counters already run up: the dice get teeth within the trajectory
+
+        def setup(env, ia=ia, ib=ib, cx=cx, cy=cy, dirs=dirs, gaps=gaps, skew=skew, pre=pre):
+            Vec2d = gc.Vec2d
+            forced = {}
+            for j in range(len(ia)):
+                ux, uy = math.cos(float(dirs[j])), math.sin(float(dirs[j]))
+                for rid, sgn, sk, tc_ in ((ia[j], -1.0, float(skew[j][0]), int(pre[j][0])), (ib[j], 1.0, float(skew[j][1]), int(pre[j][1]))):
+                    r = env.agents[rid]
+                    x, y = float(cx[j]) + sgn * 0.5 * float(gaps[j]) * ux, float(cy[j]) + sgn * 0.5 * float(gaps[j]) * uy
+                    a = math.atan2(-sgn * uy, -sgn * ux) + sk
+                    for foot in (r.leftFoot, r.rightFoot):
+                        foot.body.position = Vec2d(x, y)
+                        foot.body.angle = a
+                        env.space.reindex_shapes_for_body(foot.body)
+                    r.prevPos = r.getPos()
+                    r.touchCntr = tc_
+                    for s_ in range(0, 18):
+                        forced.setdefault(s_, {})[rid] = [3, 0, 0, 3]
+            return forced
+        out = {}
+        stdout, sys.stdout = sys.stdout, devnull
+        try:
+            gc.gen_robocup(out, "t", n, True, length, 12000 + SB + k, fw, setup)
+        finally:
+            sys.stdout = stdout
+        dump("robocup_duels", k, out)
+        try:
+            checked += tc.check_robocup_trajectory(out, "t", robocup_env)
+        except AssertionError as e:
+            failures.append(("robocup_duels", n, 12000 + SB + k, length, str(e)[:200]))
+        steps += length
+        begins += out["t_begins"]
+        ri, b0 = np.asarray(out["t_states_ri"]), np.asarray(out["t_b_ri"])
+        fell += int((ri[:, :, 6].max(0) > b0[:ri.shape[1], 6]).sum())
+        penal += int((ri[:, :, 1].max(0) > b0[:ri.shape[1], 1]).sum())
+    if n_duel:
+        print("RoboCup, duels: %d trajectories (1-3 pairs of opposing robots walking into each other, touch counters run up to 0-400; 8-18 steps each, %d steps; robots that "
+              "fell on the way %d, penalized %d; first touches robot-robot %d, robot-ball %d, robot-post %d, ball-post %d, own feet %d) against the oracle - same tolerances: "
+              "%d failures; %d of the %d steps well-conditioned and checked  (%.0f s)"
+              % ((n_duel, steps, fell, penal) + tuple(begins) + (len([f for f in failures if f[0] == "robocup_duels"]), checked, steps, time.time() - t0)))
     for f in failures:
         print("FAILURE", f)
     sys.exit(1 if failures else 0)
