@@ -74,7 +74,7 @@ def main():
             z = np.load(f)
             del envs[:]
             try:
-                if kind in ("driving", "driving_finish"):
+                if kind in ("driving", "driving_finish", "driving_aimed"):
                     tc.check_trajectory(z, "t", driving)
                     steps += len(z["t_actions"])
                 elif kind == "driving_partial":

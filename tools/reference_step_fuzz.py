@@ -3,7 +3,7 @@
 fixtures of tests/golden/gen_golden_contacts.py (same generator functions, same checks as tests/test_oracle_golden_contacts.py, nothing
 written to disk).  Build container only: it imports /root/reference (with the functional pymunk facade over tests/kat_general.py).
 
-   python3 tools/reference_step_fuzz.py [n_driving] [n_robocup] [n_driving_partial] [n_robocup_partial] [n_goalposts] [n_ball_out] [n_kicks] [n_penalties] [n_driving_finish] [n_falls] [n_duels] > profiles/r05_reference_step_fuzz.txt      (1000 300: ~10 min)
+   python3 tools/reference_step_fuzz.py [n_driving] [n_robocup] [n_driving_partial] [n_robocup_partial] [n_goalposts] [n_ball_out] [n_kicks] [n_penalties] [n_driving_finish] [n_falls] [n_duels] [n_driving_aimed] > profiles/r05_reference_step_fuzz.txt      (1000 300: ~10 min)
 """
 import math
 import os
@@ -541,6 +541,61 @@ def main():
               "fell on the way %d, penalized %d; first touches robot-robot %d, robot-ball %d, robot-post %d, ball-post %d, own feet %d) against the oracle - same tolerances: "
               "%d failures; %d of the %d steps well-conditioned and checked  (%.0f s)"
               % ((n_duel, steps, fell, penal) + tuple(begins) + (len([f for f in failures if f[0] == "robocup_duels"]), checked, steps, time.time() - t0)))
+    # Driving, aimed collisions (carCrash / pedHit / carHit :587-683: speed-proportional penalties, the lane-fault extra, the responsibility test
+    # cos(angle to the other - own heading) against -+0.4, crash() and the crashed friction inside the same substep, ped.die()): every car is, with
+    # probability 0.8, put 45-130 px from a target - another car, a pedestrian, an obstacle - heading for it within +-0.35 rad at 50-220 px/s
+    n_aim = int(sys.argv[12]) if len(sys.argv) > 12 else 0
+    t0 = time.time()
+    steps = touches = crashed = dead = 0
+    for k in range(n_aim):
+        n, seed, length, bias = int(rng.choice([2, 4, 6, 8, 10, 10])), 13000 + SB + k, int(rng.integers(8, 24)), float(rng.uniform(0.3, 0.9))
+        aimed = rng.random(n) < 0.8
+        what, pick, dist = rng.integers(0, 3, n), rng.random(n), rng.uniform(45.0, 130.0, n)
+        off, spd, bearing = rng.uniform(-0.35, 0.35, n), rng.uniform(50.0, 220.0, n), rng.uniform(-math.pi, math.pi, n)
+
+        def setup(env, aimed=aimed, what=what, pick=pick, dist=dist, off=off, spd=spd, bearing=bearing):
+            Vec2d = type(env.agents[0].goal)
+            for i, car in enumerate(env.agents):
+                if not aimed[i]:
+                    continue
+                if what[i] == 0 and len(env.agents) > 1:
+                    others = [c for c in env.agents if c is not car]
+                    tp = others[int(pick[i] * len(others)) % len(others)].shape.body.position
+                elif what[i] == 1 and len(env.pedestrians):
+                    tp = env.pedestrians[int(pick[i] * len(env.pedestrians)) % len(env.pedestrians)].shape.body.position
+                elif len(env.obstacles):
+                    tp = env.obstacles[int(pick[i] * len(env.obstacles)) % len(env.obstacles)].shape.body.position
+                else:
+                    continue
+                b = float(bearing[i])
+                pos = Vec2d(tp.x - float(dist[i]) * math.cos(b), tp.y - float(dist[i]) * math.sin(b))
+                h = b + float(off[i])
+                body = car.shape.body
+                body.position = Vec2d(pos.x, pos.y)
+                body.angle = h
+                body.velocity = Vec2d(math.cos(h) * float(spd[i]), math.sin(h) * float(spd[i]))
+                body.angular_velocity = 0.0
+                car.direction = Vec2d(math.cos(h), math.sin(h))
+                car.prevPos = Vec2d(pos.x, pos.y)
+        out = {}
+        stdout, sys.stdout = sys.stdout, devnull
+        try:
+            gc.gen_driving(out, n, seed, length, "t", bias, setup=setup)
+        finally:
+            sys.stdout = stdout
+        dump("driving_aimed", k, out)
+        try:
+            tc.check_trajectory(out, "t", driving_env)
+        except AssertionError as e:
+            failures.append(("driving_aimed", n, seed, length, str(e)[:200]))
+        steps += length
+        touches += int(out["t_begins_per_step"].sum())
+        crashed += int(out["t_states_cars_i"][-1][:, 3].sum())
+        dead += int(out["t_states_peds_i"][-1][:, 2].sum())
+    if n_aim:
+        print("Driving, aimed collisions: %d trajectories (2-10 players, 80 %% of the cars heading for another car / a pedestrian / an obstacle from 45-130 px at 50-220 px/s; "
+              "8-24 steps each, %d steps; %d first touches, %d cars crashed, %d pedestrians killed) against the oracle - rewards / states 1e-9, observations 2e-6, flags "
+              "exact: %d failures  (%.0f s)" % (n_aim, steps, touches, crashed, dead, len([f for f in failures if f[0] == "driving_aimed"]), time.time() - t0))
     for f in failures:
         print("FAILURE", f)
     sys.exit(1 if failures else 0)
