@@ -115,7 +115,9 @@ static LineDet line_in_area(cpv p1, cpv p2, cpv dir1, cpv dir2, double maxDist, 
         L.seen = S_PARTIAL;
       }
       if (vlensq_(pt1) > maxDist || vlensq_(pt2) > maxDist) L.seen = S_DISTANT;
-      /* `if pt1 and pt2` (Vec2d truthiness): a point exactly at the origin is not rotated; measure zero, not modelled */
+      /* `if pt1 and pt2` (:813): both are set here; a Vec2d is truthy whatever its value under Python 3 (pymunk 5 defines the Python-2
+       * `__nonzero__` only, tests/golden/gen_golden.py Vec2d), so the rotation is unconditional - also for a point exactly at the origin,
+       * which is what a penalized robot on its side line gets from that line in every snapshot */
       pt1 = vrotated_(pt1, -angle);
       pt2 = vrotated_(pt2, -angle);
       if (pt1.x < 0.0 || pt2.x < 0.0) L.seen = S_NONE;

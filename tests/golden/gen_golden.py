@@ -58,7 +58,11 @@ class Vec2d(object):
     def __iter__(self): return iter((self.x, self.y))
     def __eq__(self, o): return hasattr(o, "__getitem__") and len(o) == 2 and self.x == o[0] and self.y == o[1]
     def __ne__(self, o): return not self.__eq__(o)
-    def __bool__(self): return self.x != 0.0 or self.y != 0.0
+    # Truthiness: pymunk 5's Vec2d (the version the reference's in-place `rotate` / `position.x = ...` imply) defines the Python-2 hook
+    # `__nonzero__` only, which Python 3 (setup.py: python_requires >= 3.5) never calls: bool(Vec2d(0, 0)) falls back on __len__ == 2 and
+    # is True (in pymunk >= 6 a NamedTuple: True as well).  So cutils.isLineInArea's `if pt1 and pt2` (:813) tests for None only and a
+    # point exactly at the origin IS rotated - rounds 2-5 had a `__bool__` here that made the zero vector falsy; the oracle never did.
+    # It matters: a penalized robot stands exactly ON its side line, whose intersection with the edge of its field of view is (0, 0).
     def __repr__(self): return "Vec2d(%r, %r)" % (self.x, self.y)
     def __add__(self, o): return Vec2d(self.x + o[0], self.y + o[1])
     __radd__ = __add__

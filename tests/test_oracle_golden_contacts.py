@@ -112,8 +112,31 @@ def _rc_check_state(st, rf, ri, sc, fl, msg, tol=1e-9):
 RCP_TAIL = 793 - 17   # oracle/robocup_partial.h: the row's last 17 entries are list lengths and the seen tuple (exact)
 
 
-def check_robocup_trajectory(z, tag, make_env, partial=False):
-    """make_env(n, seed, offset, flags[, noise magnitude]) -> (set_state(st), step(actions [R, 4]) -> (obs [5, R, D], rewards [R], done), get_state())"""
+RCP_OFF_LINE = 32 * 5 + 20 * 7 + 16 * 6 + 16 * 6 + 28 * 8   # oracle/robocup_partial.h: the line block [12][5] of a Partial row
+
+
+def _own_line_excused(got, want, tol):
+    """A penalized robot stands exactly ON its side line (its penalty spot), so that line passes through the robot's own position and
+    cutils.isLineInArea (:751-828) returns either nothing or a zero-length line AT the robot - which of the two is decided by the last
+    bit of libm's sin / cos of the field-of-view edges (the oracle's are within 2 ulp of glibc's, tests/test_detmath.py, not identical).
+    True if two rows differ by exactly that: one more line on one side, that line degenerate (normalized distance -1), everything else equal."""
+    gt, wt = got[RCP_TAIL:], want[RCP_TAIL:]
+    d = gt - wt
+    if not (abs(d[5]) == 1 and d[6] == d[5] and not np.delete(d, [5, 6]).any()):
+        return False
+    lng, sht = (got, want) if d[5] > 0 else (want, got)
+    nl = int(lng[RCP_TAIL + 5])
+    a, b = lng[RCP_OFF_LINE:RCP_OFF_LINE + 5 * nl].reshape(nl, 5), sht[RCP_OFF_LINE:RCP_OFF_LINE + 5 * (nl - 1)].reshape(nl - 1, 5)
+    for j in range(nl):
+        if a[j][0] < -0.999 and np.allclose(np.delete(a, j, 0), b, rtol=2e-6, atol=max(2e-6, 10 * tol)):
+            return np.allclose(got[:RCP_OFF_LINE], want[:RCP_OFF_LINE], rtol=2e-6, atol=max(2e-6, 10 * tol))
+    return False
+
+
+def check_robocup_trajectory(z, tag, make_env, partial=False, own_line_slack=None):
+    """make_env(n, seed, offset, flags[, noise magnitude]) -> (set_state(st), step(actions [R, 4]) -> (obs [5, R, D], rewards [R], done), get_state())
+    own_line_slack (a list, Partial only; tools/reference_step_fuzz.py): rows that differ by `_own_line_excused` are appended to it as (step, snapshot,
+    robot) instead of failing; such a robot's rewards (processSeens: 0.0025 x the mean landmark count of the five snapshots) get 0.0026 of slack"""
     from test_oracle_golden_robocup import _to_state
     n, can_fall, seed, genv, episode, _, _ = [int(x) for x in z[tag + "_meta"]]
     flags = (ol.FLAG_CAN_FALL if can_fall else 0) | ol.FLAG_USE_OBS_REWARDS
@@ -127,15 +150,27 @@ def check_robocup_trajectory(z, tag, make_env, partial=False):
     # trajectory pins nothing any more: the check ends.
     cond = list(z[tag + "_conditioning"])
     checked = 0
+    mine = []    # this trajectory's excused rows
     for s in range(len(acts)):
         k = min(i for i, m in enumerate(marks) if m >= s)
         if cond[k] > 1e-6:
             break
         tol = max(1e-9, 1e3 * cond[k])
         o, r, d = step(acts[s].astype(np.int32))
+        want = z[tag + "_obs"][s][:, :R, :o.shape[-1]]
+        if partial and own_line_slack is not None:
+            o, want, r = np.array(o), np.array(want), np.array(r)
+            for t in range(o.shape[0]):
+                for a in range(R):
+                    if not np.array_equal(o[t, a, RCP_TAIL:], want[t, a, RCP_TAIL:]) and _own_line_excused(o[t, a], want[t, a], tol):
+                        own_line_slack.append((s, t, a)); mine.append((s, t, a))
+                        o[t, a] = want[t, a]
+            slack = sorted(set(a for (s_, _, a) in mine))          # (episode sums carry a deviation on)
+            for a in slack:
+                if abs(r[a] - z[tag + "_rewards"][s][a]) <= 0.0026:
+                    r[a] = z[tag + "_rewards"][s][a]
         _close(r, z[tag + "_rewards"][s], tol, "%s: rewards of step %d" % (tag, s))
         assert int(d) == int(z[tag + "_dones"][s])
-        want = z[tag + "_obs"][s][:, :R, :o.shape[-1]]
         if partial:   # list lengths and the seen tuple exact, rows to float32 accuracy (as tests/test_oracle_golden_robocup_partial.py)
             np.testing.assert_array_equal(o[..., RCP_TAIL:], want[..., RCP_TAIL:], err_msg="%s: list lengths / seen tuple of step %d" % (tag, s))
             np.testing.assert_allclose(o[..., :RCP_TAIL], want[..., :RCP_TAIL], rtol=2e-6, atol=max(2e-6, 10 * tol), err_msg="%s: Partial observation of step %d" % (tag, s))
@@ -146,7 +181,8 @@ def check_robocup_trajectory(z, tag, make_env, partial=False):
             _rc_check_state(st, z[tag + "_states_rf"][k], z[tag + "_states_ri"][k], z[tag + "_states_sc"][k], z[tag + "_states_fl"][k],
                             "%s: state after step %d" % (tag, s), tol)
             # episodeRewards / episodePosRewards (info['episode_r'] / ['episode_p_r'] of the terminal step, RoboCupEnvironment.py:516-521)
-            _close(list(st.episode_r)[:R] + list(st.episode_pos_r)[:R], z[tag + "_episode"][s], max(tol, 1e-9) * (s + 1), "%s: episode sums after step %d" % (tag, s))
+            if not mine:
+                _close(list(st.episode_r)[:R] + list(st.episode_pos_r)[:R], z[tag + "_episode"][s], max(tol, 1e-9) * (s + 1), "%s: episode sums after step %d" % (tag, s))
         checked = s + 1
     return checked
 

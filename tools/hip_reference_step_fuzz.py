@@ -69,19 +69,19 @@ def main():
         kinds.setdefault(os.path.basename(f).rsplit("_", 1)[0], []).append(f)
     bad = 0
     for kind, files in kinds.items():
-        t0, fails, steps, flags = time.time(), [], 0, 0
+        t0, fails, steps, flags, excused = time.time(), [], 0, 0, []
         for f in files:
             z = np.load(f)
             del envs[:]
             try:
-                if kind in ("driving", "driving_finish", "driving_aimed"):
-                    tc.check_trajectory(z, "t", driving)
-                    steps += len(z["t_actions"])
-                elif kind == "driving_partial":
+                if kind.startswith("driving_partial"):
                     tc.check_partial_trajectory(z, "t", driving_partial)
                     steps += len(z["t_actions"])
-                elif kind == "robocup_partial":
-                    steps += tc.check_robocup_trajectory(z, "t", robocup, partial=True)
+                elif kind.startswith("driving"):
+                    tc.check_trajectory(z, "t", driving)
+                    steps += len(z["t_actions"])
+                elif kind.startswith("robocup_partial"):
+                    steps += tc.check_robocup_trajectory(z, "t", robocup, partial=True, own_line_slack=excused)
                 else:
                     steps += tc.check_robocup_trajectory(z, "t", robocup)
             except AssertionError as e:
@@ -90,7 +90,8 @@ def main():
                 flags |= int(env.error_flags()) & ~16   # (bit 4: exactly touching capsule cores, reported by design)
                 env.close()
         print("%-18s %4d trajectories of the reference's step(), %6d steps replayed on the HIP path (tolerances of tests/test_oracle_golden_contacts.py): "
-              "%d failures, error flags %d  (%.0f s)" % (kind, len(files), steps, len(fails), flags, time.time() - t0))
+              "%d failures, error flags %d%s  (%.0f s)" % (kind, len(files), steps, len(fails), flags,
+                 ", %d rows excused (a penalized robot's own side line: decided by the last bit of libm's sin / cos)" % len(excused) if excused else "", time.time() - t0))
         for x in fails:
             print("   FAILURE", x)
         bad += len(fails) + (1 if flags else 0)

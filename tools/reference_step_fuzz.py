@@ -72,7 +72,15 @@ def main():
     if dump_dir:
         os.makedirs(dump_dir, exist_ok=True)
 
+    # FUZZ_PARTIAL_MAGN=<noise magnitude>: the SCENARIO populations (goalposts ... aimed collisions) run with Partial observations + Realistic noise
+    # (getAgentVision inside the step; RoboCup: processSeens rewards), checked like the two Partial populations
+    PM = float(os.environ["FUZZ_PARTIAL_MAGN"]) if "FUZZ_PARTIAL_MAGN" in os.environ else None
+    excused = []     # Partial: rows a penalized robot's own side line decided by the last bit of libm's sin / cos (tests/test_oracle_golden_contacts.py _own_line_excused)
+    rc_env, rc_kw = (robocup_partial_env, dict(partial=True, own_line_slack=excused)) if PM is not None else (robocup_env, {})
+
     def dump(kind, k, out):
+        if PM is not None:
+            kind = kind.replace("robocup_", "robocup_partial_", 1).replace("driving_", "driving_partial_", 1)
         if dump_dir:
             np.savez_compressed(os.path.join(dump_dir, "%s_%05d.npz" % (kind, k)), **out)
     t0 = time.time()
@@ -162,12 +170,12 @@ def main():
         out = {}
         stdout, sys.stdout = sys.stdout, devnull
         try:
-            gc.gen_robocup(out, "t", n, can_fall, length, 6000 + SB + k, 0.3, setup)
+            gc.gen_robocup(out, "t", n, can_fall, length, 6000 + SB + k, 0.3, setup, partial_magn=PM)
         finally:
             sys.stdout = stdout
         dump("robocup_posts", k, out)
         try:
-            checked += tc.check_robocup_trajectory(out, "t", robocup_env)
+            checked += tc.check_robocup_trajectory(out, "t", rc_env, **rc_kw)
         except AssertionError as e:
             failures.append(("robocup_posts", n, 6000 + SB + k, length, str(e)[:200]))
         steps += length
@@ -262,12 +270,12 @@ def main():
         out = {}
         stdout, sys.stdout = sys.stdout, devnull
         try:
-            gc.gen_robocup(out, "t", n, can_fall, length, 7000 + SB + k, fw, setup)
+            gc.gen_robocup(out, "t", n, can_fall, length, 7000 + SB + k, fw, setup, partial_magn=PM)
         finally:
             sys.stdout = stdout
         dump("robocup_out", k, out)
         try:
-            checked += tc.check_robocup_trajectory(out, "t", robocup_env)
+            checked += tc.check_robocup_trajectory(out, "t", rc_env, **rc_kw)
         except AssertionError as e:
             failures.append(("robocup_out", n, 7000 + SB + k, length, str(e)[:200]))
         steps += length
@@ -305,12 +313,12 @@ def main():
         out = {}
         stdout, sys.stdout = sys.stdout, devnull
         try:
-            gc.gen_robocup(out, "t", n, can_fall, length, 8000 + SB + k, fw, setup)
+            gc.gen_robocup(out, "t", n, can_fall, length, 8000 + SB + k, fw, setup, partial_magn=PM)
         finally:
             sys.stdout = stdout
         dump("robocup_kick", k, out)
         try:
-            checked += tc.check_robocup_trajectory(out, "t", robocup_env)
+            checked += tc.check_robocup_trajectory(out, "t", rc_env, **rc_kw)
         except AssertionError as e:
             failures.append(("robocup_kick", n, 8000 + SB + k, length, str(e)[:200]))
         steps += length
@@ -371,12 +379,12 @@ def main():
         out = {}
         stdout, sys.stdout = sys.stdout, devnull
         try:
-            gc.gen_robocup(out, "t", n, can_fall, length, 9000 + SB + k, fw, setup)
+            gc.gen_robocup(out, "t", n, can_fall, length, 9000 + SB + k, fw, setup, partial_magn=PM)
         finally:
             sys.stdout = stdout
         dump("robocup_penalties", k, out)
         try:
-            checked += tc.check_robocup_trajectory(out, "t", robocup_env)
+            checked += tc.check_robocup_trajectory(out, "t", rc_env, **rc_kw)
         except AssertionError as e:
             failures.append(("robocup_penalties", n, 9000 + SB + k, length, str(e)[:200]))
         steps += length
@@ -417,17 +425,17 @@ def main():
         out = {}
         stdout, sys.stdout = sys.stdout, devnull
         try:
-            gc.gen_driving(out, n, seed, length, "t", bias, setup=setup)
+            (gc.gen_driving_partial(out, n, seed, length, "t", bias, PM, setup=setup) if PM is not None else gc.gen_driving(out, n, seed, length, "t", bias, setup=setup))
         finally:
             sys.stdout = stdout
         dump("driving_finish", k, out)
         try:
-            tc.check_trajectory(out, "t", driving_env)
+            (tc.check_partial_trajectory(out, "t", driving_partial_env) if PM is not None else tc.check_trajectory(out, "t", driving_env))
         except AssertionError as e:
             failures.append(("driving_finish", n, seed, length, str(e)[:200]))
         steps += length
-        touches += int(out["t_begins_per_step"].sum())
-        fin = np.asarray(out["t_states_cars_i"][-1])[:, 2] if np.asarray(out["t_states_cars_i"][-1]).shape[1] > 2 else np.zeros(n)
+        touches += int(out["t_begins_per_step"].sum()) if PM is None else 0
+        fin = np.asarray(out["t_states_cars_i"][-1] if PM is None else out["t_final_cars_i"])[:, 2]
         finished += int(np.asarray(fin).sum())
         allfin += int(np.asarray(fin).all())
     if n_fin:
@@ -468,12 +476,12 @@ def main():
         out = {}
         stdout, sys.stdout = sys.stdout, devnull
         try:
-            gc.gen_robocup(out, "t", n, True, length, 11000 + SB + k, fw, setup)
+            gc.gen_robocup(out, "t", n, True, length, 11000 + SB + k, fw, setup, partial_magn=PM)
         finally:
             sys.stdout = stdout
         dump("robocup_falls", k, out)
         try:
-            checked += tc.check_robocup_trajectory(out, "t", robocup_env)
+            checked += tc.check_robocup_trajectory(out, "t", rc_env, **rc_kw)
         except AssertionError as e:
             failures.append(("robocup_falls", n, 11000 + SB + k, length, str(e)[:200]))
         steps += length
@@ -523,12 +531,12 @@ def main():
         out = {}
         stdout, sys.stdout = sys.stdout, devnull
         try:
-            gc.gen_robocup(out, "t", n, True, length, 12000 + SB + k, fw, setup)
+            gc.gen_robocup(out, "t", n, True, length, 12000 + SB + k, fw, setup, partial_magn=PM)
         finally:
             sys.stdout = stdout
         dump("robocup_duels", k, out)
         try:
-            checked += tc.check_robocup_trajectory(out, "t", robocup_env)
+            checked += tc.check_robocup_trajectory(out, "t", rc_env, **rc_kw)
         except AssertionError as e:
             failures.append(("robocup_duels", n, 12000 + SB + k, length, str(e)[:200]))
         steps += length
@@ -580,22 +588,25 @@ def main():
         out = {}
         stdout, sys.stdout = sys.stdout, devnull
         try:
-            gc.gen_driving(out, n, seed, length, "t", bias, setup=setup)
+            (gc.gen_driving_partial(out, n, seed, length, "t", bias, PM, setup=setup) if PM is not None else gc.gen_driving(out, n, seed, length, "t", bias, setup=setup))
         finally:
             sys.stdout = stdout
         dump("driving_aimed", k, out)
         try:
-            tc.check_trajectory(out, "t", driving_env)
+            (tc.check_partial_trajectory(out, "t", driving_partial_env) if PM is not None else tc.check_trajectory(out, "t", driving_env))
         except AssertionError as e:
             failures.append(("driving_aimed", n, seed, length, str(e)[:200]))
         steps += length
-        touches += int(out["t_begins_per_step"].sum())
-        crashed += int(out["t_states_cars_i"][-1][:, 3].sum())
-        dead += int(out["t_states_peds_i"][-1][:, 2].sum())
+        touches += int(out["t_begins_per_step"].sum()) if PM is None else 0
+        crashed += int((out["t_states_cars_i"][-1] if PM is None else out["t_final_cars_i"])[:, 3].sum())
+        dead += int((out["t_states_peds_i"][-1] if PM is None else out["t_final_peds_i"])[:, 2].sum())
     if n_aim:
         print("Driving, aimed collisions: %d trajectories (2-10 players, 80 %% of the cars heading for another car / a pedestrian / an obstacle from 45-130 px at 50-220 px/s; "
               "8-24 steps each, %d steps; %d first touches, %d cars crashed, %d pedestrians killed) against the oracle - rewards / states 1e-9, observations 2e-6, flags "
               "exact: %d failures  (%.0f s)" % (n_aim, steps, touches, crashed, dead, len([f for f in failures if f[0] == "driving_aimed"]), time.time() - t0))
+    if PM is not None:
+        print("Partial observations (noise magnitude %g): %d (step, snapshot, robot) rows excused - a penalized robot's own side line, seen as a zero-length line at the "
+              "robot or not at all by the last bit of libm's sin / cos" % (PM, len(excused)))
     for f in failures:
         print("FAILURE", f)
     sys.exit(1 if failures else 0)
