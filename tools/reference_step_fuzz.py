@@ -75,6 +75,11 @@ def main():
     # FUZZ_PARTIAL_MAGN=<noise magnitude>: the SCENARIO populations (goalposts ... aimed collisions) run with Partial observations + Realistic noise
     # (getAgentVision inside the step; RoboCup: processSeens rewards), checked like the two Partial populations
     PM = float(os.environ["FUZZ_PARTIAL_MAGN"]) if "FUZZ_PARTIAL_MAGN" in os.environ else None
+    FORCE_N = int(os.environ.get("FUZZ_PLAYERS", "0"))     # every population with this many players (a side), e.g. 1: the single-robot special cases
+
+    def pick_n(opts):
+        v = int(rng.choice(opts))
+        return FORCE_N if FORCE_N else v
     excused = []     # Partial: rows a penalized robot's own side line decided by the last bit of libm's sin / cos (tests/test_oracle_golden_contacts.py _own_line_excused)
     rc_env, rc_kw = (robocup_partial_env, dict(partial=True, own_line_slack=excused)) if PM is not None else (robocup_env, {})
 
@@ -87,7 +92,7 @@ def main():
     steps = touches = crashed = dead = 0
     failures = []
     for k in range(n_drv):
-        n, seed, length, bias = int(rng.choice([2, 4, 6, 8, 10, 10, 10])), 1000 + SB + k, int(rng.integers(40, 90)), float(rng.uniform(0.3, 0.9))
+        n, seed, length, bias = pick_n([2, 4, 6, 8, 10, 10, 10]), 1000 + SB + k, int(rng.integers(40, 90)), float(rng.uniform(0.3, 0.9))
         out = {}
         stdout, sys.stdout = sys.stdout, devnull
         try:
@@ -110,7 +115,7 @@ def main():
     steps = checked = 0
     begins = np.zeros(5, np.int64)
     for k in range(n_rc):
-        n, can_fall, length, fw = int(rng.choice([2, 3, 4, 5, 5])), bool(rng.random() < 0.6), int(rng.integers(12, 30)), float(rng.uniform(0.4, 0.9))
+        n, can_fall, length, fw = pick_n([2, 3, 4, 5, 5]), bool(rng.random() < 0.6), int(rng.integers(12, 30)), float(rng.uniform(0.4, 0.9))
         out = {}
         stdout, sys.stdout = sys.stdout, devnull
         try:
@@ -136,7 +141,7 @@ def main():
     steps = checked = 0
     begins = np.zeros(5, np.int64)
     for k in range(n_gp):
-        n, can_fall, length = int(rng.choice([3, 4, 5, 5])), bool(rng.random() < 0.7), int(rng.integers(8, 16))
+        n, can_fall, length = pick_n([3, 4, 5, 5]), bool(rng.random() < 0.7), int(rng.integers(8, 16))
         posts = [(70.0, 450.0), (70.0, 290.0), (970.0, 450.0), (970.0, 290.0)]
         pr, pb = [int(x) for x in rng.choice(4, 2, replace=False)]
         ru, bu = float(rng.uniform(-1.0, 1.0)), float(rng.uniform(-1.2, 1.2))          # bearing from the post, field side
@@ -190,7 +195,7 @@ def main():
     t0 = time.time()
     steps, rows = 0, np.zeros(4)
     for k in range(n_dp):
-        n, seed, length, bias = int(rng.choice([2, 4, 6, 10])), 3000 + SB + k, int(rng.integers(30, 60)), float(rng.uniform(0.3, 0.9))
+        n, seed, length, bias = pick_n([2, 4, 6, 10]), 3000 + SB + k, int(rng.integers(30, 60)), float(rng.uniform(0.3, 0.9))
         magn = float(rng.choice([0.5, 1.0, 3.0, 5.0]))
         out = {}
         stdout, sys.stdout = sys.stdout, devnull
@@ -211,7 +216,7 @@ def main():
     t0 = time.time()
     steps = checked = 0
     for k in range(n_rp):
-        n, can_fall, length, fw = int(rng.choice([2, 3, 5])), bool(rng.random() < 0.6), int(rng.integers(10, 25)), float(rng.uniform(0.4, 0.9))
+        n, can_fall, length, fw = pick_n([2, 3, 5]), bool(rng.random() < 0.6), int(rng.integers(10, 25)), float(rng.uniform(0.4, 0.9))
         magn = float(rng.choice([0.5, 1.0, 3.0, 5.0]))
         out = {}
         stdout, sys.stdout = sys.stdout, devnull
@@ -238,11 +243,11 @@ def main():
     begins = np.zeros(5, np.int64)
     kinds, goals = np.zeros(4, np.int64), np.zeros(2, np.int64)
     for k in range(n_out):
-        n, can_fall, length, fw = int(rng.choice([2, 3, 5, 5])), bool(rng.random() < 0.5), int(rng.integers(6, 14)), float(rng.uniform(0.3, 0.9))
+        n, can_fall, length, fw = pick_n([2, 3, 5, 5]), bool(rng.random() < 0.5), int(rng.integers(6, 14)), float(rng.uniform(0.3, 0.9))
         kind = int(rng.choice(4, p=[0.3, 0.3, 0.2, 0.2]))                    # side line | end line beside the goal | goal | a slow ball that stays in
         far, u, inset, speed = bool(rng.random() < 0.5), float(rng.random()), float(rng.uniform(4.0, 25.0)), float(rng.uniform(120.0, 380.0))
         tang = float(rng.uniform(-0.5, 0.5))
-        kickers = [int(x) for x in rng.choice(2 * n, int(rng.integers(0, 4)), replace=False)]
+        kickers = [int(x) for x in rng.choice(2 * n, min(2 * n, int(rng.integers(0, 4))), replace=False)]
         kinds[kind] += 1
 
         def setup(env, kind=kind, far=far, u=u, inset=inset, speed=speed, tang=tang, kickers=kickers):
@@ -295,7 +300,7 @@ def main():
     begins = np.zeros(5, np.int64)
     kicking = 0
     for k in range(n_kick):
-        n, can_fall, length, fw = int(rng.choice([2, 3, 5, 5])), bool(rng.random() < 0.5), int(rng.integers(6, 14)), float(rng.uniform(0.2, 0.8))
+        n, can_fall, length, fw = pick_n([2, 3, 5, 5]), bool(rng.random() < 0.5), int(rng.integers(6, 14)), float(rng.uniform(0.2, 0.8))
         r0, r1 = [int(x) for x in rng.choice(2 * n, 2, replace=False)]
         fx, fy, foot0, foot1, s1 = float(rng.uniform(22.0, 50.0)), float(rng.uniform(-24.0, 24.0)), int(rng.integers(1, 3)), int(rng.integers(1, 3)), int(rng.integers(1, 5))
         bvx, bvy = float(rng.uniform(-40.0, 40.0)), float(rng.uniform(-40.0, 40.0))
@@ -338,7 +343,7 @@ def main():
     begins = np.zeros(5, np.int64)
     penalized = 0
     for k in range(n_pen):
-        n, can_fall, length, fw = int(rng.choice([3, 4, 5, 5])), bool(rng.random() < 0.5), int(rng.integers(6, 14)), float(rng.uniform(0.2, 0.8))
+        n, can_fall, length, fw = pick_n([3, 4, 5, 5]), bool(rng.random() < 0.5), int(rng.integers(6, 14)), float(rng.uniform(0.2, 0.8))
         team = int(rng.integers(0, 2))                        # whose box gets crowded (0: ids 0..n-1, the left box)
         m = min(n, int(rng.integers(3, 5)))
         inbox = [int(x) + team * n for x in rng.choice(n, m, replace=False)]
@@ -401,7 +406,7 @@ def main():
     t0 = time.time()
     steps = touches = finished = allfin = 0
     for k in range(n_fin):
-        n, seed, length, bias = int(rng.choice([2, 3, 4, 6, 10])), 10000 + SB + k, int(rng.integers(12, 30)), float(rng.uniform(0.5, 1.0))
+        n, seed, length, bias = pick_n([2, 3, 4, 6, 10]), 10000 + SB + k, int(rng.integers(12, 30)), float(rng.uniform(0.5, 1.0))
         chosen = rng.random(n) < float(rng.choice([0.5, 0.8, 1.0, 1.0]))
         dist, lat, spd = rng.uniform(60.0, 170.0, n), rng.uniform(-28.0, 28.0, n), rng.uniform(60.0, 160.0, n)
 
@@ -451,12 +456,12 @@ def main():
     begins = np.zeros(5, np.int64)
     refalls = penal = 0
     for k in range(n_fall):
-        n, length, fw = int(rng.choice([2, 3, 5, 5])), int(rng.integers(6, 14)), float(rng.uniform(0.2, 0.8))
+        n, length, fw = pick_n([2, 3, 5, 5]), int(rng.integers(6, 14)), float(rng.uniform(0.2, 0.8))
         down = [int(x) for x in rng.choice(2 * n, min(2 * n, int(rng.integers(2, 5))), replace=False)]
         cnt, left = [int(x) for x in rng.integers(1, 3, len(down))], [float(x) for x in rng.integers(10, 1500, len(down))]
         bang, bdist = float(rng.uniform(-math.pi, math.pi)), float(rng.uniform(24.0, 46.0))
         owned, grace, freec = int(rng.integers(-1, 2)), float(rng.choice([0.0, 0.0, 700.0, 14999.0])), float(rng.choice([0.0, 300.0, 9999.0]))
-        kickers = [int(x) for x in rng.choice(2 * n, int(rng.integers(0, 4)), replace=False)]
+        kickers = [int(x) for x in rng.choice(2 * n, min(2 * n, int(rng.integers(0, 4))), replace=False)]
 
         def setup(env, down=down, cnt=cnt, left=left, bang=bang, bdist=bdist, owned=owned, grace=grace, freec=freec, kickers=kickers):
             Vec2d = gc.Vec2d
@@ -503,7 +508,7 @@ def main():
     begins = np.zeros(5, np.int64)
     fell = penal = 0
     for k in range(n_duel):
-        n, length, fw = int(rng.choice([2, 3, 5, 5])), int(rng.integers(8, 18)), float(rng.uniform(0.2, 0.8))
+        n, length, fw = pick_n([2, 3, 5, 5]), int(rng.integers(8, 18)), float(rng.uniform(0.2, 0.8))
         pairs = min(n, int(rng.integers(1, 4)))
         ia, ib = [int(x) for x in rng.choice(n, pairs, replace=False)], [int(x) + n for x in rng.choice(n, pairs, replace=False)]
         cx, cy = rng.uniform(200.0, 840.0, pairs), (np.arange(pairs) * 180.0 + 150.0 + rng.uniform(-30.0, 30.0, pairs))
@@ -556,7 +561,7 @@ def main():
     t0 = time.time()
     steps = touches = crashed = dead = 0
     for k in range(n_aim):
-        n, seed, length, bias = int(rng.choice([2, 4, 6, 8, 10, 10])), 13000 + SB + k, int(rng.integers(8, 24)), float(rng.uniform(0.3, 0.9))
+        n, seed, length, bias = pick_n([2, 4, 6, 8, 10, 10]), 13000 + SB + k, int(rng.integers(8, 24)), float(rng.uniform(0.3, 0.9))
         aimed = rng.random(n) < 0.8
         what, pick, dist = rng.integers(0, 3, n), rng.random(n), rng.uniform(45.0, 130.0, n)
         off, spd, bearing = rng.uniform(-0.35, 0.35, n), rng.uniform(50.0, 220.0, n), rng.uniform(-math.pi, math.pi, n)
