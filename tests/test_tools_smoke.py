@@ -47,3 +47,26 @@ def test_pair_order_cost_tool_runs(oracle_built, capsys):
     assert "== driving: 32 environments" in out and "== robocup: 32 environments" in out and "pair order reversed" in out
     l = ol.lib()
     assert np.array_equal(_driving_rewards(l, 0, 0.0, 8, 20), _driving_rewards(l, 0, 0.0, 8, 20))
+
+
+def test_own_side_line_excusal_accepts_the_degenerate_row_and_nothing_else():
+    """tools/reference_step_fuzz.py (Partial populations) excuses exactly one thing: a zero-length line at the robot's own position on one
+    side only (a penalized robot on its side line).  A real extra line, or any other difference, stays a failure."""
+    import test_oracle_golden_contacts as tc
+    T, L = tc.RCP_TAIL, tc.RCP_OFF_LINE
+    a = np.zeros(793, np.float32)
+    a[L:L + 5] = [0.3, 0.6, -0.8, 1.0, 0.0]                    # one ordinary line on both sides
+    a[T + 5], a[T + 6] = 1, 1
+    b = a.copy()
+    b[L + 5:L + 10] = [-0.9998, 0.85, -0.52, 0.0, -1.0]        # + a zero-length line at the robot (normalized distance -1) on one side
+    b[T + 5], b[T + 6] = 2, 2
+    assert tc._own_line_excused(a, b, 1e-9) and tc._own_line_excused(b, a, 1e-9)
+    c = b.copy()
+    c[L + 5] = 0.2                                             # the extra line is a real one
+    assert not tc._own_line_excused(a, c, 1e-9)
+    d = b.copy()
+    d[T + 1] = 1                                               # ... or something else differs as well
+    assert not tc._own_line_excused(a, d, 1e-9)
+    e = b.copy()
+    e[3] += 0.5                                                # ... or another block's values do
+    assert not tc._own_line_excused(a, e, 1e-9)
